@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz by running the REFERENCE ITSELF (imported unmodified from
+/root/reference) on seeded inputs.  Runs only in the build container; the fixtures it writes are
+data (inputs + the reference's outputs) and are committed so that the GPU box -- where
+/root/reference does not exist -- can check both the oracle and the HIP path against them.
+
+How the reference is made importable (nothing is copied from it):
+  * sys.path gets tests/golden/_absl_shim (a stand-in ``absl`` written for this repo: absl-py is
+    not installed and there is no network) and /root/reference; bytecode writing is disabled
+    because the reference tree is read-only.
+  * ``config.config`` then defines every flag with its default; ``network.fs_net_repo.*`` import
+    as they are.
+  * The Chamfer CUDA extension cannot be built here (no CUDA).  The reference's own CPU
+    statement of Chamfer, ``losses/metrics/CD/chamfer_python.py:distChamfer`` (declared
+    equivalent by the reference's unit test losses/metrics/CD/unit_test.py:22-33), is loaded by
+    file path and used to produce the Chamfer vectors.
+
+Weights: the reference ships no checkpoint, so ``tgpose_amd.init_weights.seeded_state_dict`` is
+loaded into the reference with ``load_state_dict(strict=True)``; fixtures store only the seed.
+
+Usage:  python tests/golden/make_golden.py   (from the repo root)
+"""
+import importlib.util
+import os
+import sys
+
+sys.dont_write_bytecode = True
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path[:0] = [os.path.join(HERE, "_absl_shim"), REF]
+sys.path.append(ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def _load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+from config.config import *  # noqa: E402,F401,F403  (defines the flags on the shim's FLAGS)
+import absl.flags as flags  # noqa: E402
+import network.fs_net_repo.gcn3d as ref_gcn  # noqa: E402
+from network.fs_net_repo.PoseNet9D import PoseNet9D as RefPoseNet9D  # noqa: E402
+
+FLAGS = flags.FLAGS
+ref_chamfer = _load_by_path("ref_chamfer_python", os.path.join(REF, "losses/metrics/CD/chamfer_python.py"))
+iw = _load_by_path("tgp_init_weights", os.path.join(ROOT, "tg-pose_amd", "init_weights.py"))
+
+
+def synth_points(B, N, seed):
+    """SURVEY.md 8(d) synthetic clouds: 0.1*randn + per-object camera-frame offset."""
+    g = torch.Generator().manual_seed(seed)
+    pts = 0.1 * torch.randn(B, N, 3, generator=g)
+    off = torch.rand(B, 1, 3, generator=g) * torch.tensor([0.4, 0.4, 1.0]) + torch.tensor([-0.2, -0.2, 0.5])
+    obj = torch.randint(0, 6, (B, 1), generator=g).float()
+    return (pts + off).contiguous(), obj
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print("wrote %-28s %8.1f KB" % (name, os.path.getsize(path) / 1024.0))
+
+
+def small_idx(t):
+    t = t.detach().cpu().numpy()
+    assert t.max() < 32767
+    return t.astype(np.int16)
+
+
+# ----------------------------------------------------------------------------- operators
+def gen_knn():
+    g = torch.Generator().manual_seed(11)
+    xyz = 0.1 * torch.randn(2, 300, 3, generator=g)
+    src = xyz[:, torch.randperm(300, generator=g)[:75], :].contiguous()
+    bottle = torch.from_numpy(np.load(os.path.join(REF, "obj_model/points_bottle.npy"))).float()[None]
+    bottle = bottle - bottle.mean(dim=1, keepdim=True)
+    feat = torch.relu(torch.randn(2, 200, 128, generator=g) * 0.7 + 0.2)      # post-ReLU like features
+    feat256 = torch.relu(torch.randn(1, 96, 256, generator=g) * 0.5 + 0.1)
+    dup = torch.cat([xyz[:1, :100], xyz[:1, :100], xyz[:1, :100]], dim=1)       # 3x tiled cloud: exact ties
+    save("knn_ops.npz",
+         xyz=xyz, xyz_k20=small_idx(ref_gcn.get_neighbor_index(xyz, 20)), xyz_k4=small_idx(ref_gcn.get_neighbor_index(xyz, 4)),
+         src=src, nearest=small_idx(ref_gcn.get_nearest_index(xyz, src)),
+         bottle=bottle, bottle_k20=small_idx(ref_gcn.get_neighbor_index(bottle, 20)),
+         feat=feat, feat_k20=small_idx(ref_gcn.get_neighbor_index(feat, 20)),
+         feat256=feat256, feat256_k8=small_idx(ref_gcn.get_neighbor_index(feat256, 8)),
+         dup=dup, dup_k8=small_idx(ref_gcn.get_neighbor_index(dup, 8)))
+
+
+def gen_layers():
+    """Single layers of gcn3d.py run stand-alone on a small cloud (B=2, n=160)."""
+    sd = iw.seeded_state_dict(3)
+    g = torch.Generator().manual_seed(5)
+    xyz = 0.1 * torch.randn(2, 160, 3, generator=g)
+    S = 7
+    conv0 = ref_gcn.HSlayer_surface(kernel_num=128, support_num=S)
+    conv1 = ref_gcn.HS_layer(128, 128, support_num=S)
+    pre = "face_all.encoder."
+    conv0.load_state_dict({k[len(pre + "conv_0."):]: v for k, v in sd.items() if k.startswith(pre + "conv_0.")})
+    conv1.load_state_dict({k[len(pre + "conv_1."):]: v for k, v in sd.items() if k.startswith(pre + "conv_1.")})
+    with torch.no_grad():
+        f0 = conv0(xyz, 20)
+        fin = torch.relu(f0)
+        idx_f = ref_gcn.get_neighbor_index(fin, 20)
+        f1 = conv1(xyz, fin, 20)
+        torch.manual_seed(77)
+        pool = ref_gcn.Pool_layer(4, 4)
+        vp, fp = pool(xyz, fin)
+        torch.manual_seed(77)
+        sample = torch.randperm(160)[:40]
+    save("layers.npz", seed=np.int64(3), xyz=xyz, conv0_out=f0, conv1_in=fin, conv1_rf_idx=small_idx(idx_f),
+         conv1_out=f1, pool_sample=small_idx(sample), pool_v=vp, pool_f=fp)
+
+
+# ----------------------------------------------------------------------------- full forward
+def run_reference(net, pts, obj, seed, train):
+    """Reference forward with every get_neighbor_index / get_nearest_index result recorded."""
+    knn_rec, nn_rec = [], []
+    o_knn, o_nn = ref_gcn.get_neighbor_index, ref_gcn.get_nearest_index
+
+    def w_knn(v, k):
+        r = o_knn(v, k)
+        knn_rec.append(r)
+        return r
+
+    def w_nn(t, s):
+        r = o_nn(t, s)
+        nn_rec.append(r)
+        return r
+
+    ref_gcn.get_neighbor_index, ref_gcn.get_nearest_index = w_knn, w_nn
+    try:
+        FLAGS.train = train
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            out = net(pts, obj)
+    finally:
+        ref_gcn.get_neighbor_index, ref_gcn.get_nearest_index = o_knn, o_nn
+    names = ["conv_0.rf", "conv_0.orl_xyz", "conv_1.rf", "conv_1.orl_xyz", "pool_1.xyz", "conv_2.rf",
+             "conv_2.orl_xyz", "conv_3.rf", "conv_3.orl_xyz", "pool_2.xyz", "conv_4.rf", "conv_4.orl_xyz"]
+    assert len(knn_rec) == len(names) and len(nn_rec) == 2
+    idx = {"face_all.encoder." + n: r for n, r in zip(names, knn_rec)}
+    idx["face_all.encoder.up_1"], idx["face_all.encoder.up_2"] = nn_rec
+    return out, idx
+
+
+def sample_indices(N, seed):
+    """The two randperm draws Face_Enc.forward makes (gcn3d.py:242) after torch.manual_seed(seed)."""
+    torch.manual_seed(seed)
+    i1 = torch.randperm(N)[: int(N / 4)]
+    i2 = torch.randperm(i1.numel())[: int(i1.numel() / 4)]
+    return i1, i2
+
+
+def gen_forward(name, B, N, wseed, pseed, fseed, pts=None, obj=None, keep_feat_rows=64):
+    sd = iw.seeded_state_dict(wseed)
+    net = RefPoseNet9D().eval()
+    net.load_state_dict(sd, strict=True)
+    if pts is None:
+        pts, obj = synth_points(B, N, pseed)
+    out_test, idx = run_reference(net, pts, obj, fseed, train=0)
+    out_train, idx2 = run_reference(net, pts, obj, fseed, train=1)
+    for k in idx:
+        assert torch.equal(idx[k], idx2[k])
+    i1, i2 = sample_indices(N, fseed)
+    arrays = dict(weight_seed=np.int64(wseed), forward_seed=np.int64(fseed), points=pts, obj_id=obj,
+                  sample_idx_1=small_idx(i1), sample_idx_2=small_idx(i2))
+    for k, v in out_test.items():
+        arrays["test." + k] = v
+    for k, v in out_train.items():
+        if k == "feat":                       # (B,N,1286) is large: keep a row slice + per-row sums
+            arrays["train.feat_rows"] = v[:, :keep_feat_rows].contiguous()
+            arrays["train.feat_rowsum"] = v.double().sum(dim=2).float()
+            arrays["train.feat_colsum"] = v.double().sum(dim=1).float()
+        else:
+            arrays["train." + k] = v
+    for k, v in idx.items():
+        arrays["idx." + k] = small_idx(v)
+    save(name, **arrays)
+
+
+# ----------------------------------------------------------------------------- Chamfer
+def gen_chamfer():
+    g = torch.Generator().manual_seed(21)
+    a = torch.rand(4, 100, 3, generator=g)           # the reference's own unit-test shapes,
+    b = torch.rand(4, 200, 3, generator=g)           # losses/metrics/CD/unit_test.py:15-16
+    d1, d2, i1, i2 = ref_chamfer.distChamfer(a, b)
+    cats = ["bottle", "bowl", "camera", "can", "laptop", "mug"]
+    prior = torch.stack([torch.from_numpy(np.load(os.path.join(REF, "obj_model/points_%s.npy" % c))).float() for c in cats])
+    noisy = prior[:, torch.randperm(1024, generator=g)[:1000]] + 0.01 * torch.randn(6, 1000, 3, generator=g)
+    e1, e2, j1, j2 = ref_chamfer.distChamfer(noisy, prior)
+    save("chamfer.npz", a=a, b=b, dist1=d1, dist2=d2, idx1=small_idx(i1), idx2=small_idx(i2),
+         noisy=noisy, prior=prior, p_dist1=e1, p_dist2=e2, p_idx1=small_idx(j1), p_idx2=small_idx(j2))
+
+
+def main():
+    gen_knn()
+    gen_layers()
+    bottle = torch.from_numpy(np.load(os.path.join(REF, "obj_model/points_bottle.npy"))).float()[None]
+    gen_forward("forward_bottle.npz", 1, 1024, wseed=0, pseed=0, fseed=7, pts=bottle, obj=torch.zeros(1, 1))
+    gen_forward("forward_b2_n1028.npz", 2, 1028, wseed=0, pseed=1, fseed=123)
+    gen_forward("forward_b3_n256.npz", 3, 256, wseed=1, pseed=2, fseed=9, keep_feat_rows=96)
+    gen_chamfer()
+
+
+if __name__ == "__main__":
+    main()
