@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- objects/s of PoseNet9D.forward (eval, B=32 per GPU, N=1028) on the HIP path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full forward of the hot path (kNN graphs, 3D-GCN encoder, PH predictor, decoder,
+three heads, pose post-processing) over one batch of B synthetic clouds already resident in HBM
+(BASELINE.json configs[1] extended to the whole forward, which is what `metric` is quoted on).
+Objects are independent in eval mode, so N GPUs run N replicas on their own batches with no
+data-path collective (weak scaling); the only RCCL traffic is the barrier / max-time reduction
+around the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline      the dominant kernel (gemm_f32_kernel<128,128>: fp32 MFMA, the per-point MLPs that
+                hold 95 % of the FLOPs), timed live with HIP events on the launch stream around every
+                one of its launches in the timed steps: achieved = algorithmic FLOPs / time.
+  cpu_baseline  the CPU oracle (the build's restatement of the reference's torch op sequence,
+                oracle/posenet_ref.py mode='torch') timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+B_PER_GPU = 32
+N_POINTS = 1028
+
+
+def synth_batch(B, N, seed):
+    """0.1*randn clouds + camera-frame offsets, random categories."""
+    g = torch.Generator().manual_seed(seed)
+    pts = 0.1 * torch.randn(B, N, 3, generator=g)
+    off = torch.rand(B, 1, 3, generator=g) * torch.tensor([0.4, 0.4, 1.0]) + torch.tensor([-0.2, -0.2, 0.5])
+    obj = torch.randint(0, 6, (B, 1), generator=g).float()
+    return (pts + off).contiguous(), obj
+
+
+def cpu_baseline(sd):
+    """Oracle forward (reference op sequence on torch CPU) on a bounded sample of the same workload."""
+    from oracle import posenet_ref
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    pts, obj = synth_batch(8, N_POINTS, 1)
+    with torch.no_grad():
+        posenet_ref.posenet_forward(sd, pts[:2], obj[:2], mode="torch")           # warm-up
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            posenet_ref.posenet_forward(sd, pts, obj, mode="torch")
+        dt = time.perf_counter() - t0
+    return {"value": round(reps * pts.shape[0] / dt, 3), "unit": "objects/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "%d eval forwards of B=%d, N=%d on torch %s CPU ops (oracle mode='torch', the reference's "
+                      "op sequence), %.1f s" % (reps, pts.shape[0], N_POINTS, torch.__version__, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="objects per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (see the module docstring)" % args.gpus)
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import tgpose_amd
+    from tgpose_amd import PoseNet9D, FLAGS, ops, seeded_state_dict
+    sd = seeded_state_dict(0)
+    net = PoseNet9D()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    FLAGS.train = 0
+    B = args.batch
+    pts, obj = synth_batch(B, N_POINTS, 100 + rank)
+    pts, obj = pts.to(dev), obj.to(dev)
+    torch.manual_seed(rank)
+
+    def step():
+        return net(pts, obj)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    fence()
+    ops.GEMM_TIMER = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timer, ops.GEMM_TIMER = ops.GEMM_TIMER, None
+
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        launches = len(timer)
+        ksec = sum(e0.elapsed_time(e1) for e0, e1, _ in timer) * 1e-3
+        kflop = sum(f for _, _, f in timer)
+        achieved = kflop / ksec / 1e12 if ksec > 0 else 0.0
+        line = {
+            "metric": "objects/sec forward (B=32, N=1028 pts)",
+            "value": round(world * B * args.steps / elapsed, 2),
+            "unit": "objects/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PoseNet9D.forward eval mode, full forward (kNN graphs + 3D-GCN encoder + PH predictor "
+                                   "+ decoder + R/t/s heads), B=%d objects per GPU, N=%d points, seeded random weights "
+                                   "of the reference architecture (27.43 M params)" % (B, N_POINTS),
+                       "objects_per_gpu": B, "points": N_POINTS, "replicas": world},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel": "gemm_f32_kernel<128,128,false,false>",
+                         "launches_timed": launches, "avg_launch_us": round(1e6 * ksec / max(launches, 1), 2),
+                         "share_of_step": round(ksec / elapsed, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

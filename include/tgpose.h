@@ -1,0 +1,169 @@
+/*
+ * tgpose.h -- C ABI of libtgpose_hip.so: the MI355X (gfx950) kernels behind the TG-Pose
+ * point-cloud forward path and its Chamfer distance.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers are DEVICE pointers (fp32 row-major, int32 indices) unless noted;
+ *   - every buffer, including scratch, is owned and sized by the caller; nothing is allocated,
+ *     nothing synchronises; work is enqueued on `stream` (a hipStream_t passed as void*);
+ *   - `ld*` arguments are row strides in ELEMENTS, so operators read/write column slices of
+ *     wider buffers (the 1286-channel concat buffer) in place;
+ *   - return value: 0 = enqueued; > 0 = hipError_t from the launch; < 0 = TGP_E* argument error
+ *     (nothing was enqueued).
+ *
+ * Each declaration cites the reference interface it replaces (paths under the TG-Pose tree).
+ * The reference has exactly one native binding on this path -- the pybind module `chamfer_3D`
+ * (losses/chamfer3D/chamfer_cuda.cpp:30-33) -- and otherwise composes torch ops in
+ * network/fs_net_repo/gcn3d.py; the operator-level entry points below are what a native binding
+ * of those functions would export.  INTEGRATION.md shows the Python-side stubs.
+ */
+#ifndef TGPOSE_H
+#define TGPOSE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGP_ABI_VERSION 1
+#define TGP_EINVAL (-1)       /* null pointer / non-positive size / misaligned stride */
+#define TGP_EUNSUPPORTED (-2) /* shape outside what the kernels are built for */
+
+typedef void *tgp_stream_t; /* hipStream_t */
+
+int tgp_version(void);
+/* largest point count per object / neighbour count the kNN kernels accept */
+int tgp_knn_max_points(void);
+int tgp_knn_max_k(void);
+
+/* ---- geometry ---------------------------------------------------------------------------- */
+
+/* PoseNet9D.py:48  `points - points.mean(dim=1, keepdim=True)`.
+ * points (B,n,3) -> xyz_c (B,n,3), mean (B,3).  The column sums follow ATen's cascade order so
+ * that the centred cloud is bit-identical to the CPU path (the kNN order depends on it). */
+int tgp_center(const float *points, int B, int n, float *xyz_c, float *mean, tgp_stream_t stream);
+
+/* ---- graph construction ------------------------------------------------------------------- */
+
+/* gcn3d.py:14-23 get_neighbor_index for 3-d coordinates.  xyz (B,n,3) packed -> idx (B,n,k):
+ * the k+1 nearest by fl(fl(-2<a,b> + |b|^2) + |a|^2) ordered by (distance, index), rank 0 dropped. */
+int tgp_knn_xyz(const float *xyz, int B, int n, int k, int32_t *idx, tgp_stream_t stream);
+
+/* Bytes of scratch tgp_knn_feat needs for (B,n,d). */
+int64_t tgp_knn_feat_workspace_bytes(int B, int n, int d);
+
+/* gcn3d.py:14-23 get_neighbor_index in feature space (mode 'RF-F', gcn3d.py:149,201-206).
+ * feat (B,n,d) with row stride ld; d a multiple of 32, d <= 480. */
+int tgp_knn_feat(const float *feat, int ld, int B, int n, int d, int k, int32_t *idx, void *workspace,
+                 int64_t workspace_bytes, tgp_stream_t stream);
+
+/* gcn3d.py:26-35 get_nearest_index: for each of n target points the nearest of m source points
+ * by fl(fl(|s|^2 + |t|^2) - 2<t,s>), lowest index on ties.  idx (B,n). */
+int tgp_nn1(const float *target, const float *source, int B, int n, int m, int32_t *idx, tgp_stream_t stream);
+
+/* ---- graph convolution --------------------------------------------------------------------- */
+
+/* F.normalize(directions, dim=0) (gcn3d.py:100,165).  directions (3,SC) -> out (3,SC). */
+int tgp_normalize_dirs(const float *directions, int SC, float *out, tgp_stream_t stream);
+
+/* gcn3d.py:91-106 HSlayer_surface.graph_conv.  xyz (B,n,3), idx (B,n,k), sdn (3,S*C) unit support
+ * directions -> out (B,n,C) row stride ldo:  mean_s max_j relu(<dir_j, sdn[:, s*C+c]>). */
+int tgp_gconv_surface_fwd(const float *xyz, const int32_t *idx, const float *sdn, int B, int n, int k, int S,
+                          int C, float *out, int ldo, tgp_stream_t stream);
+
+/* gcn3d.py:157-180 HS_layer.graph_conv after the dense projection.  proj (B*n, (S+1)*C) row stride
+ * ldp holds [centre | support] = feature_map @ weights + bias; idx is the feature-space graph.
+ * out = centre + mean_s max_j relu(<dir_j, sdn>) * support[idx_j]. */
+int tgp_gconv_hs_fwd(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B,
+                     int n, int k, int S, int C, float *out, int ldo, tgp_stream_t stream);
+
+/* gcn3d.py:210-217 get_ORL_global: g[b,c] = mean_i max_j feat[b, idx[b,i,j], c].
+ * partial: scratch of tgp_orl_partial_floats(B,n,C) floats.  out (B,C). */
+int64_t tgp_orl_partial_floats(int B, int n, int C);
+int tgp_orl_global(const float *feat, int ldf, const int32_t *idx, int B, int n, int k, int C, float *partial,
+                   float *out, tgp_stream_t stream);
+
+/* gcn3d.py:219-245 Pool_layer.forward with the random subsample (randperm, :242) supplied by the
+ * host: out_f[b,m,:] = max_{j<kpool} feat[b, idx[b, sample[m], j], :], out_xyz[b,m] = xyz[b, sample[m]].
+ * idx has row stride ldi (>= kpool) so the k=4 list may be the prefix of a longer one. */
+int tgp_pool_fwd(const float *xyz, const float *feat, int ldf, const int32_t *idx, int ldi, const int32_t *sample,
+                 int B, int n, int n_out, int kpool, int C, float *out_xyz, float *out_f, int ldo,
+                 tgp_stream_t stream);
+
+/* gcn3d.py:38-46 indexing_neighbor_new with one neighbour (FaceRecon.py:69-73 nearest up-sampling):
+ * dst[b,i,0:C] = src[b, idx[b,i], 0:C]. */
+int tgp_gather_rows(const float *src, int lds, const int32_t *idx, int B, int n_src, int n_out, int C, float *dst,
+                    int ldd, tgp_stream_t stream);
+
+/* FaceRecon.py:49-54,75-77 and PoseNet9D.py:63: the tail columns of the concat buffer:
+ * one_hot(obj_id) (n_cls columns at col0), then the centred xyz (3), then zero padding up to ld. */
+int tgp_fill_tail(const float *obj_id, const float *xyz_c, int B, int n, int n_cls, float *feat, int ld, int col0,
+                  tgp_stream_t stream);
+
+/* ---- dense per-point layers ------------------------------------------------------------------ */
+
+typedef struct tgp_gemm_args {
+    /* C[m, n] = act( (sum_k A[m,k] * W[n,k] + bias[n] + rowbias[m / rows_per_obj, n]
+     *                 + res1[m,n] + res2[m,n]) * scale[n] + shift[n] )
+     * A (M,K) row stride lda; W (N,K) row stride ldw (Conv1d/Linear weight layout, FaceRecon.py:93-110,
+     * PoseR.py:16-19); K, lda, ldw multiples of 4; every optional pointer may be NULL. */
+    const float *A; int lda;
+    const float *W; int ldw;
+    float *C; int ldc;                 /* may be NULL when only colmax is wanted */
+    int M, N, K;
+    const float *bias;                 /* [N] */
+    const float *rowbias; int ldrb;    /* [(M / rows_per_obj), N] */
+    int rows_per_obj;
+    const float *res1; int ldr1;
+    const float *res2; int ldr2;
+    const float *scale;                /* [N] eval-mode BatchNorm fold: gamma / sqrt(var + eps) */
+    const float *shift;                /* [N] beta - mean * scale */
+    int act;                           /* 0 none, 1 leaky-relu with `slope` (0 -> ReLU) */
+    float slope;
+    uint32_t *colmax_keys; int ldcm;   /* [(M / rows_per_obj), N] order-preserving keys, zero-filled by the
+                                          caller; decoded by tgp_colmax_decode (torch.max(x, 2), PoseR.py:30) */
+} tgp_gemm_args;
+
+/* nn.Conv1d(kernel 1) / nn.Linear on channel-last rows with the fused epilogue above. */
+int tgp_gemm_f32(const tgp_gemm_args *args, tgp_stream_t stream);
+
+/* keys (rows, N) row stride ldk -> out[r, n] (row stride ldo) and, if out2 != NULL, a second copy
+ * (FaceRecon.py:145-147 concatenates the pooled vector with itself). */
+int tgp_colmax_decode(const uint32_t *keys, int ldk, int rows, int N, float *out, int ldo, float *out2,
+                      tgp_stream_t stream);
+
+/* PoseNet9D.py:50 feat_global.max(2): out[b,c] = max_i x[b,i,c], x (B,n,C) row stride ld. */
+int tgp_colmax(const float *x, int ld, int B, int n, int C, float *out, tgp_stream_t stream);
+
+/* FaceRecon.py:156,162 nn.Sigmoid on a contiguous vector. */
+int tgp_sigmoid(const float *x, float *y, int64_t count, tgp_stream_t stream);
+
+/* PoseNet9D.py:57-66: green/red (B,4) -> unit axes p_* (B,3) and confidences f_* (B); ts (B,6) + mean
+ * -> Pred_T (B,3), Pred_s (B,3). */
+int tgp_head_post(const float *green, const float *red, const float *ts, const float *mean, int B, float *p_green,
+                  float *p_red, float *f_green, float *f_red, float *pred_T, float *pred_s, tgp_stream_t stream);
+
+/* PoseNet9D.py:71 recon + mean, in place on recon (B,n,3). */
+int tgp_add_mean(float *recon, const float *mean, int B, int n, tgp_stream_t stream);
+
+/* ---- Chamfer distance ------------------------------------------------------------------------ */
+
+/* chamfer_3D.forward (losses/chamfer3D/chamfer_cuda.cpp:17-19,31; kernels chamfer3D.cu:12-152).
+ * xyz1 (B,n,3), xyz2 (B,m,3) -> dist1 (B,n), idx1 (B,n) nearest in xyz2; dist2 (B,m), idx2 (B,m)
+ * nearest in xyz1.  Squared distance (dx*dx + dy*dy) + dz*dz in fp32, lowest index on ties. */
+int tgp_chamfer_fwd(const float *xyz1, const float *xyz2, int B, int n, int m, float *dist1, float *dist2,
+                    int32_t *idx1, int32_t *idx2, tgp_stream_t stream);
+
+/* chamfer_3D.backward (chamfer_cuda.cpp:22-27,32; chamfer3D.cu:155-195): ACCUMULATES into
+ * gradxyz1 (B,n,3) / gradxyz2 (B,m,3) (the caller zero-fills, dist_chamfer_3D.py:56-60).
+ * Deterministic: contributions are summed in the serial order of the reference's CPU loop
+ * (tools/pyTorchChamferDistance/chamfer_distance.cpp:140-175), no atomics. */
+int tgp_chamfer_bwd(const float *xyz1, const float *xyz2, int B, int n, int m, const float *graddist1,
+                    const float *graddist2, const int32_t *idx1, const int32_t *idx2, float *gradxyz1,
+                    float *gradxyz2, tgp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGPOSE_H */

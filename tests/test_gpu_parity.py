@@ -1,0 +1,490 @@
+"""GPU parity tests (run on the MI355X box with ``-m gpu``): every HIP entry point, called through
+the C ABI (tgpose_amd.ops -> libtgpose_hip.so), against the CPU oracle on identical seeded inputs
+and against the golden vectors recorded from the reference.
+
+Bars: indices and Chamfer results bit-exact; float layers within 1e-4 (stated per test; most are
+held to a tighter bound).  /root/reference is never touched here.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import golden, knn_rows_equivalent, rows_without_ties, synth_points
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (run with -m gpu on the MI355X box)")
+    from tgpose_amd import ops as _ops, _lib
+    _lib.lib()  # raises if libtgpose_hip.so is missing: there is no fallback
+    return _ops
+
+
+def _oracle():
+    from oracle import _clib, gcn_ref, posenet_ref
+    return _clib, gcn_ref, posenet_ref
+
+
+def g(t):
+    return torch.as_tensor(t).to(DEV)
+
+
+# ----------------------------------------------------------------------------------------- geometry
+@pytest.mark.parametrize("B,n", [(3, 1028), (2, 1024), (4, 257), (1, 64), (5, 100)])
+def test_center_bit_exact(ops, B, n):
+    pts, _ = synth_points(B, n, seed=n)
+    xyz, mean = ops.center(g(pts))
+    ref_mean = pts.mean(dim=1, keepdim=True)
+    assert torch.equal(mean.cpu(), ref_mean[:, 0])
+    assert torch.equal(xyz.cpu(), pts - ref_mean)
+
+
+# ----------------------------------------------------------------------------------------- kNN
+@pytest.mark.parametrize("B,n,k", [(4, 1028, 20), (2, 1024, 20), (3, 257, 20), (3, 257, 4), (5, 64, 8), (2, 300, 20),
+                                   (1, 2048, 20), (2, 130, 16)])
+def test_knn_xyz_bit_exact_vs_oracle(ops, B, n, k):
+    _clib, _, _ = _oracle()
+    pts, _ = synth_points(B, n, seed=7 * n + k)
+    xyz = (pts - pts.mean(dim=1, keepdim=True)).contiguous()
+    want = _clib.knn(xyz.numpy(), k)
+    got = ops.knn_xyz(g(xyz), k).cpu().numpy()
+    assert got.dtype == np.int32 and np.array_equal(got, want)
+
+
+def test_knn_xyz_duplicates_follow_index_order(ops):
+    """3x tiled cloud (evaluation/load_data_eval.py:410-411 tiles short clouds): exact ties everywhere."""
+    _clib, _, _ = _oracle()
+    base, _ = synth_points(2, 100, seed=3)
+    xyz = torch.cat([base, base, base], dim=1).contiguous()
+    want = _clib.knn(xyz.numpy(), 8)
+    got = ops.knn_xyz(g(xyz), 8).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("key,k", [("xyz", 20), ("xyz", 4), ("bottle", 20), ("dup", 8)])
+def test_knn_xyz_vs_reference_golden(ops, key, k):
+    _clib, _, _ = _oracle()
+    gd = golden("knn_ops.npz")
+    x = gd[key]
+    ref = gd["%s_k%d" % (key, k)].astype(np.int64)
+    got = ops.knn_xyz(g(x), k).cpu().numpy()
+    for b in range(x.shape[0]):
+        D = _clib.knn_dist_matrix(x[b])
+        exact, same = knn_rows_equivalent(D, got[b], ref[b])
+        assert exact[rows_without_ties(D, k)].all()
+        if key != "dup":
+            assert same.all()
+    if key == "xyz":
+        assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("B,n,d,k,ld", [(2, 1028, 128, 20, 128), (2, 1028, 128, 20, 1292), (3, 257, 128, 20, 128),
+                                        (3, 257, 256, 20, 256), (4, 64, 256, 8, 256), (1, 200, 64, 5, 64),
+                                        (1, 96, 448, 8, 448)])
+def test_knn_feat_bit_exact_vs_oracle(ops, B, n, d, k, ld):
+    _clib, _, _ = _oracle()
+    gen = torch.Generator().manual_seed(n + d)
+    x = torch.relu(torch.randn(B, n, d, generator=gen) * 0.7 + 0.2)
+    buf = torch.zeros(B, n, ld)
+    buf[:, :, :d] = x
+    want = _clib.knn(x.numpy(), k)
+    got = ops.knn_feat(g(buf)[:, :, :d], k).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("key,k", [("feat", 20), ("feat256", 8)])
+def test_knn_feat_vs_reference_golden(ops, key, k):
+    _clib, _, _ = _oracle()
+    gd = golden("knn_ops.npz")
+    x = gd[key]
+    ref = gd["%s_k%d" % (key, k)].astype(np.int64)
+    got = ops.knn_feat(g(x), k).cpu().numpy()
+    for b in range(x.shape[0]):
+        D = _clib.knn_dist_matrix(x[b])
+        exact, same = knn_rows_equivalent(D, got[b], ref[b])
+        assert same.all() and exact[rows_without_ties(D, k)].all()
+
+
+def test_knn_rejects_unsupported_shapes(ops):
+    from tgpose_amd._lib import TgpError
+    with pytest.raises(TgpError):
+        ops.knn_xyz(torch.zeros(1, 8, 3, device=DEV), 20)           # k + 1 > n
+    with pytest.raises(TgpError):
+        ops.knn_feat(torch.zeros(1, 64, 100, device=DEV), 8)        # d not a multiple of 32
+    with pytest.raises(TgpError):
+        ops.knn_xyz(torch.zeros(1, 4096, 3, device=DEV), 20)        # beyond tgp_knn_max_points
+
+
+@pytest.mark.parametrize("B,n,m", [(3, 1028, 257), (3, 1028, 64), (2, 300, 75), (1, 100, 2500)])
+def test_nearest_index_bit_exact(ops, B, n, m):
+    _clib, _, _ = _oracle()
+    pts, _ = synth_points(B, n, seed=n + m)
+    pts = pts - pts.mean(dim=1, keepdim=True)
+    gen = torch.Generator().manual_seed(1)
+    if m <= n:
+        src = pts[:, torch.randperm(n, generator=gen)[:m]].contiguous()
+    else:
+        src = 0.1 * torch.randn(B, m, 3, generator=gen)
+    want = _clib.nn1(pts.numpy(), src.numpy())
+    got = ops.nn1(g(pts), g(src)).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_nearest_index_vs_reference_golden(ops):
+    gd = golden("knn_ops.npz")
+    got = ops.nn1(g(gd["xyz"]), g(gd["src"])).cpu().numpy()
+    assert np.array_equal(got, gd["nearest"][..., 0])
+
+
+# ----------------------------------------------------------------------------------------- graph conv
+def _rand_layer(C, cin, seed):
+    gen = torch.Generator().manual_seed(seed)
+    S = 7
+    u = lambda *s, a=1.0: (torch.rand(*s, generator=gen) * 2 - 1) * a
+    return {"l.directions": u(3, S * C, a=0.05), "l.weights": u(cin, 8 * C, a=0.06), "l.bias": u(8 * C, a=0.06),
+            "l.STE_layer.weight": u(C, cin, 1, a=0.1), "l.conv2.weight": u(C, 2 * C, 1, a=0.08), "_support_num": S}
+
+
+@pytest.mark.parametrize("B,n,k", [(2, 300, 20), (1, 64, 8), (3, 257, 20)])
+def test_gconv_surface_vs_oracle(ops, B, n, k):
+    _, G, _ = _oracle()
+    import torch.nn.functional as F
+    P = _rand_layer(128, 3, 5)
+    pts, _ = synth_points(B, n, seed=n)
+    xyz = (pts - pts.mean(dim=1, keepdim=True)).contiguous()
+    idx = G.knn_index(xyz, k)
+    theta = torch.relu(G.neighbor_directions(xyz, idx) @ F.normalize(P["l.directions"], dim=0))
+    want = theta.reshape(B, n, k, 7, 128).max(dim=2)[0].mean(dim=2)
+    sdn = ops.normalize_dirs(g(P["l.directions"]))
+    assert torch.allclose(sdn.cpu(), F.normalize(P["l.directions"], dim=0), atol=1e-7, rtol=1e-6)
+    got = ops.gconv_surface(g(xyz), g(idx.int()), sdn, 7, 128)
+    assert torch.allclose(got.cpu(), want, atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,n,k,C", [(2, 300, 20, 128), (2, 257, 20, 256), (2, 64, 8, 512), (1, 130, 7, 128)])
+def test_gconv_hs_vs_oracle(ops, B, n, k, C):
+    _, G, _ = _oracle()
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(C + n)
+    pts, _ = synth_points(B, n, seed=n)
+    xyz = (pts - pts.mean(dim=1, keepdim=True)).contiguous()
+    idx = torch.stack([torch.stack([torch.randperm(n, generator=gen)[:k] for _ in range(n)]) for _ in range(B)])
+    proj = torch.randn(B, n, 9 * C, generator=gen)           # centre | 7 support | (STE columns, ignored here)
+    dirs = (torch.rand(3, 7 * C, generator=gen) * 2 - 1) * 0.05
+    theta = torch.relu(G.neighbor_directions(xyz, idx) @ F.normalize(dirs, dim=0)).reshape(B, n, k, -1)
+    act = (theta * G.gather_rows(proj[:, :, C:8 * C].contiguous(), idx)).view(B, n, k, 7, C)
+    want = proj[:, :, :C] + act.max(dim=2)[0].mean(dim=2)
+    got = ops.gconv_hs(g(xyz), g(idx.int()), g(proj), ops.normalize_dirs(g(dirs)), 7, C)
+    assert torch.allclose(got.cpu(), want, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,n,k,C", [(2, 300, 20, 128), (3, 257, 20, 256), (2, 64, 8, 512)])
+def test_orl_pool_gather_vs_oracle(ops, B, n, k, C):
+    _, G, _ = _oracle()
+    gen = torch.Generator().manual_seed(n)
+    pts, _ = synth_points(B, n, seed=n)
+    xyz = (pts - pts.mean(dim=1, keepdim=True)).contiguous()
+    feat = torch.randn(B, n, C, generator=gen)
+    idx = G.knn_index(xyz, k)
+    want = G.gather_rows(feat, idx).max(dim=2)[0].mean(dim=1)
+    got = ops.orl_global(g(feat), g(idx.int()))
+    assert torch.allclose(got.cpu(), want, atol=1e-5, rtol=1e-5)
+    # Pool_layer at sampled rows: prefix of the k-list is the k=4 list
+    sample = torch.randperm(n, generator=gen)[: n // 4]
+    v_want, f_want = G.pool(xyz, feat, sample, G.GraphCache(), "p")
+    wide = torch.zeros(B, n, C + 12)
+    wide[:, :, 4:4 + C] = feat                                  # read a column slice of a wider buffer
+    v_got, f_got = ops.pool(g(xyz), g(wide)[:, :, 4:4 + C], g(idx.int()), g(sample.int()), kpool=4)
+    assert torch.equal(v_got.cpu(), v_want) and torch.equal(f_got.cpu(), f_want)
+    # nearest up-sampling gather into a slice of a wider buffer
+    near = torch.randint(0, n, (B, 4 * n), generator=gen)
+    dst = torch.full((B, 4 * n, C + 8), -7.0, device=DEV)
+    ops.gather_rows(g(feat), g(near.int()), dst[:, :, 8:])
+    assert torch.equal(dst[:, :, 8:].cpu(), G.gather_rows(feat, near.unsqueeze(-1)).squeeze(2))
+    assert (dst[:, :, :8] == -7.0).all()
+
+
+def test_fill_tail(ops):
+    B, n = 3, 50
+    xyz = torch.randn(B, n, 3)
+    obj = torch.tensor([[2.0], [5.0], [0.0]])
+    feat = torch.full((B, n, 20), 9.0, device=DEV)
+    ops.fill_tail(g(obj.reshape(-1)), g(xyz), feat, 8, 6)
+    f = feat.cpu()
+    assert (f[:, :, :8] == 9.0).all()
+    assert torch.equal(f[:, :, 8:14], torch.zeros(B, 6).scatter_(1, obj.long(), 1).unsqueeze(1).repeat(1, n, 1))
+    assert torch.equal(f[:, :, 14:17], xyz) and (f[:, :, 17:] == 0).all()
+
+
+# ----------------------------------------------------------------------------------------- dense layers
+def _gemm_ref(A, W, bias=None, rowbias=None, rpo=1, res1=None, res2=None, scale=None, shift=None, slope=None):
+    v = A.double() @ W.double().t()
+    if bias is not None:
+        v = v + bias.double()
+    if rowbias is not None:
+        v = v + rowbias.double().repeat_interleave(rpo, dim=0)[: v.shape[0]]
+    if res1 is not None:
+        v = v + res1.double()
+    if res2 is not None:
+        v = v + res2.double()
+    if scale is not None:
+        v = v * scale.double() + shift.double()
+    if slope is not None:
+        v = torch.where(v > 0, v, v * slope)
+    return v
+
+
+@pytest.mark.parametrize("M,N,K", [(8300, 2048, 1292), (1028 * 3, 1024, 1292), (4100, 4096, 64), (257 * 2, 2304, 128), (700, 200, 36),
+                                   (130, 3, 128), (64, 64, 32), (33, 70, 2500), (5000, 256, 1024)])
+def test_gemm_full_epilogue_vs_fp64(ops, M, N, K):
+    gen = torch.Generator().manual_seed(M + N + K)
+    rpo = 257 if M % 257 == 0 else 100
+    nobj = (M + rpo - 1) // rpo
+    A = torch.randn(M, K, generator=gen)
+    W = torch.randn(N, K, generator=gen) / K ** 0.5
+    bias, scale, shift = torch.randn(N, generator=gen), torch.rand(N, generator=gen) + 0.5, torch.randn(N, generator=gen)
+    rowbias = torch.randn(nobj, N, generator=gen)
+    res1, res2 = torch.randn(M, N, generator=gen), torch.randn(M, N + 8, generator=gen)
+    want = _gemm_ref(A, W, bias, rowbias, rpo, res1, res2[:, 4:4 + N], scale, shift, 0.2)
+    keys = torch.zeros(nobj, N, dtype=torch.int32, device=DEV)
+    out = ops.linear_rows(g(A), g(W), bias=g(bias), rowbias=g(rowbias), rows_per_obj=rpo, res1=g(res1),
+                          res2=g(res2)[:, 4:4 + N], scale=g(scale), shift=g(shift), act=1, slope=0.2, colmax_keys=keys)
+    err = (out.cpu().double() - want).abs().max().item()
+    assert err < 2e-5 * max(1.0, want.abs().max().item()), err
+    cm = ops.colmax_decode(keys).cpu()
+    # the fused max-over-points equals the max of the values the kernel itself wrote
+    pad = torch.full((nobj * rpo - M, N), -float("inf"))
+    assert torch.equal(cm, torch.cat([out.cpu(), pad]).view(nobj, rpo, N).max(dim=1)[0])
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 2500, 1024), (32, 1024, 2048), (6, 1286, 2500), (1, 4, 256), (17, 259, 256)])
+def test_gemm_skinny_rows_vs_fp64(ops, M, N, K):
+    gen = torch.Generator().manual_seed(M * N + K)
+    A, W = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen) / K ** 0.5
+    bias, scale, shift = torch.randn(N, generator=gen), torch.rand(N, generator=gen) + 0.5, torch.randn(N, generator=gen)
+    want = _gemm_ref(A, W, bias, scale=scale, shift=shift, slope=0.0)
+    out = ops.linear_rows(g(A), g(W), bias=g(bias), scale=g(scale), shift=g(shift), act=1, slope=0.0)
+    assert (out.cpu().double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    plain = ops.linear_rows(g(A), g(W))
+    assert (plain.cpu().double() - _gemm_ref(A, W)).abs().max().item() < 2e-5
+
+
+def test_gemm_views_into_wider_buffers(ops):
+    """Operands and result addressed as column slices with their own row strides (the concat buffer)."""
+    gen = torch.Generator().manual_seed(0)
+    B, n, K, N = 2, 300, 128, 128
+    buf = torch.randn(B, n, 1292, generator=gen)
+    W = torch.randn(N, K, generator=gen) / K ** 0.5
+    d = g(buf.clone())
+    ops.linear_rows(d[:, :, 128:256], g(W), out=d[:, :, 256:384], act=1, slope=0.0)
+    want = torch.relu(buf[:, :, 128:256].double() @ W.double().t())
+    assert (d[:, :, 256:384].cpu().double() - want).abs().max().item() < 1e-5
+    untouched = torch.ones(1292, dtype=torch.bool)
+    untouched[256:384] = False
+    assert torch.equal(d.cpu()[:, :, untouched], buf[:, :, untouched])
+
+
+def test_small_pointwise_kernels(ops):
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 333, 1292, generator=gen)
+    assert torch.equal(ops.colmax(g(x)[:, :, :1286]).cpu(), x[:, :, :1286].max(dim=1)[0])
+    v = torch.randn(7, 2500, generator=gen) * 4
+    assert torch.allclose(ops.sigmoid(g(v)).cpu(), torch.sigmoid(v), atol=1e-6, rtol=0)
+    gr, rd, ts, mean = (torch.randn(5, c, generator=gen) for c in (4, 4, 6, 3))
+    pg, pr, fg, fr, pT, ps = (t.cpu() for t in ops.head_post(g(gr), g(rd), g(ts), g(mean)))
+    assert torch.allclose(pg, gr[:, 1:] / (torch.norm(gr[:, 1:], dim=1, keepdim=True) + 1e-6), atol=1e-6)
+    assert torch.allclose(pr, rd[:, 1:] / (torch.norm(rd[:, 1:], dim=1, keepdim=True) + 1e-6), atol=1e-6)
+    assert torch.allclose(fg, torch.sigmoid(gr[:, 0]), atol=1e-6) and torch.allclose(fr, torch.sigmoid(rd[:, 0]), atol=1e-6)
+    assert torch.equal(pT, ts[:, :3] + mean) and torch.equal(ps, ts[:, 3:])
+
+
+# ----------------------------------------------------------------------------------------- layers / model
+def test_layer_modules_vs_reference_golden(ops):
+    """HSlayer_surface / HS_layer / Pool_layer stand-alone (operator seam) against the reference's outputs."""
+    from tgpose_amd import seeded_state_dict
+    from tgpose_amd.network.fs_net_repo import gcn3d
+    from tgpose_amd import engine
+    gd = golden("layers.npz")
+    sd = seeded_state_dict(int(gd["seed"]))
+    pre = "face_all.encoder."
+    conv0 = gcn3d.HSlayer_surface(128, 7)
+    conv0.load_state_dict({k[len(pre + "conv_0."):]: v for k, v in sd.items() if k.startswith(pre + "conv_0.")})
+    conv0 = conv0.to(DEV).eval()
+    xyz = g(gd["xyz"])
+    f0 = conv0(xyz, 20)
+    assert np.allclose(f0.cpu().numpy(), gd["conv0_out"], atol=1e-5, rtol=0)
+    conv1 = gcn3d.HS_layer(128, 128, 7)
+    conv1.load_state_dict({k[len(pre + "conv_1."):]: v for k, v in sd.items() if k.startswith(pre + "conv_1.")})
+    conv1 = conv1.to(DEV).eval()
+    fin = g(gd["conv1_in"])
+    # the reference's feature-space graph is injected: torch.topk orders equal distances arbitrarily
+    out = torch.empty(2, 160, 128, device=DEV)
+    engine.hs_layer(conv1._packed(conv1._build), xyz, fin, g(gd["conv1_rf_idx"].astype(np.int32)),
+                    ops.knn_xyz(xyz, 20), out)
+    assert np.allclose(out.cpu().numpy(), gd["conv1_out"], atol=2e-5, rtol=0)
+    # free running: same result wherever the graph has no tie at the boundary
+    free = conv1(xyz, fin, 20).cpu().numpy()
+    assert (np.abs(free - gd["conv1_out"]).max(axis=2) < 2e-5).mean() > 0.98
+    idx = gcn3d.get_neighbor_index(xyz, 4)
+    assert idx.dtype == torch.int64
+    v, f = ops.pool(xyz, fin, idx.int(), g(gd["pool_sample"].astype(np.int32)))
+    assert np.array_equal(v.cpu().numpy(), gd["pool_v"]) and np.array_equal(f.cpu().numpy(), gd["pool_f"])
+
+
+def _net(seed):
+    from tgpose_amd import PoseNet9D, seeded_state_dict
+    net = PoseNet9D()
+    net.load_state_dict(seeded_state_dict(seed), strict=True)
+    return net.to(DEV).eval()
+
+
+@pytest.mark.parametrize("name", ["forward_bottle.npz", "forward_b2_n1028.npz", "forward_b3_n256.npz"])
+def test_forward_vs_reference_golden_teacher_forced(ops, name):
+    """PoseNet9D.forward against the REFERENCE's outputs with the reference's graphs injected.
+    Tolerance 1e-4 absolute (BASELINE.json north_star), on every key of both output dicts."""
+    from tgpose_amd import FLAGS
+    gd = golden(name)
+    net = _net(int(gd["weight_seed"]))
+    pts, obj = g(gd["points"]), g(gd["obj_id"])
+    sample = (torch.from_numpy(gd["sample_idx_1"].astype(np.int64)), torch.from_numpy(gd["sample_idx_2"].astype(np.int64)))
+    inject = {k[4:]: torch.from_numpy(gd[k].astype(np.int32)) for k in gd.files if k.startswith("idx.")}
+    FLAGS.train = 0
+    out = net(pts, obj, sample_idx=sample, inject=inject)
+    assert sorted(out) == sorted(["p_green_R", "p_red_R", "f_green_R", "f_red_R", "Pred_T", "Pred_s"])
+    for k, v in out.items():
+        assert np.allclose(v.cpu().numpy(), gd["test." + k], atol=1e-4, rtol=0), k
+    FLAGS.train = 1
+    try:
+        out = net(pts, obj, sample_idx=sample, inject=inject)
+    finally:
+        FLAGS.train = 0
+    assert len(out) == 11
+    for k in ("recon", "p_green_R", "p_red_R", "f_green_R", "f_red_R", "Pred_T", "Pred_s", "h1", "h2", "feat_global"):
+        assert np.allclose(out[k].cpu().numpy(), gd["train." + k], atol=1e-4, rtol=0), k
+    rows = gd["train.feat_rows"].shape[1]
+    assert np.allclose(out["feat"][:, :rows].cpu().numpy(), gd["train.feat_rows"], atol=1e-4, rtol=0)
+    assert np.allclose(out["feat"].double().sum(2).cpu().numpy(), gd["train.feat_rowsum"], atol=5e-3, rtol=0)
+
+
+@pytest.mark.parametrize("B,N,seed", [(4, 1028, 11), (2, 1024, 12), (3, 512, 13)])
+def test_forward_vs_oracle(ops, B, N, seed):
+    """Same seeded inputs through the HIP path and the CPU oracle.
+    (a) teacher-forced on the oracle's graphs: every output within 1e-4;
+    (b) free running: the xyz graphs must be identical, the feature-space graphs (whose inputs
+        differ in the last bits between CPU and GPU) must agree on >= 99% of rows, and the pose
+        outputs stay within 1e-3."""
+    from tgpose_amd import FLAGS
+    _, _, PR = _oracle()
+    from tgpose_amd import seeded_state_dict
+    sd = seeded_state_dict(seed)
+    net = _net(seed)
+    pts, obj = synth_points(B, N, seed)
+    torch.manual_seed(seed)
+    i1 = torch.randperm(N)[: N // 4]
+    sample = (i1, torch.randperm(i1.numel())[: i1.numel() // 4])
+    with torch.no_grad():
+        want, inter = PR.posenet_forward(sd, pts, obj, sample_idx=sample, train_keys=True, mode="exact",
+                                         want_intermediates=True)
+    FLAGS.train = 1
+    try:
+        forced = net(g(pts), g(obj), sample_idx=sample, inject=inter["indices"])
+        rec = {}
+        free = net(g(pts), g(obj), sample_idx=sample, record=rec)
+    finally:
+        FLAGS.train = 0
+    for k, v in want.items():
+        assert torch.allclose(forced[k].cpu(), v, atol=1e-4, rtol=0), k
+    for name, idx in inter["indices"].items():
+        got = rec[name].cpu().long()
+        got = (got.unsqueeze(-1) if got.dim() == 2 else got)[..., : idx.shape[-1]]   # k=4 list = prefix of the k=20 list
+        same_rows = (got == idx).all(dim=-1).float().mean().item()
+        if name.endswith(".rf") and "conv_0" not in name:
+            assert same_rows >= 0.99, (name, same_rows)
+        else:
+            assert same_rows == 1.0, (name, same_rows)
+    for k in ("p_green_R", "p_red_R", "f_green_R", "f_red_R", "Pred_T", "Pred_s"):
+        assert torch.allclose(free[k].cpu(), want[k], atol=1e-3, rtol=0), k
+
+
+def test_forward_full_batch_properties(ops):
+    """BASELINE size (B=32, N=1028): properties that need no oracle run.
+    Objects are independent in eval mode: each object's result in the batch of 32
+    equals its result alone, bit for bit; repeated runs are bit-identical (no float atomics)."""
+    from tgpose_amd import FLAGS
+    net = _net(0)
+    pts, obj = synth_points(32, 1028, 0)
+    torch.manual_seed(5)
+    i1 = torch.randperm(1028)[:257]
+    sample = (i1, torch.randperm(257)[:64])
+    FLAGS.train = 1
+    try:
+        full = net(g(pts), g(obj), sample_idx=sample)
+        again = net(g(pts), g(obj), sample_idx=sample)
+        one = net(g(pts[5:6]), g(obj[5:6]), sample_idx=sample)
+    finally:
+        FLAGS.train = 0
+    for k in full:
+        assert torch.equal(full[k], again[k]), k
+        assert torch.equal(full[k][5:6], one[k]), k
+        assert torch.isfinite(full[k]).all(), k
+    assert torch.allclose(full["p_green_R"].norm(dim=1), torch.ones(32, device=DEV), atol=1e-4)
+
+
+def test_modules_refuse_training_mode_and_cpu(ops):
+    net = _net(0)
+    pts, obj = synth_points(1, 256, 0)
+    with pytest.raises(RuntimeError):
+        net(pts, obj)                                   # CPU tensors: no fallback
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(g(pts), g(obj))
+
+
+# ----------------------------------------------------------------------------------------- Chamfer
+@pytest.mark.parametrize("B,n,m", [(4, 100, 200), (6, 1028, 1024), (2, 2000, 1000), (3, 1, 5), (1, 1500, 3000)])
+def test_chamfer_forward_backward_bit_exact(ops, B, n, m):
+    _clib, _, _ = _oracle()
+    gen = torch.Generator().manual_seed(n * m)
+    a, b = torch.rand(B, n, 3, generator=gen), torch.rand(B, m, 3, generator=gen)
+    d1 = torch.zeros(B, n, device=DEV)
+    d2 = torch.zeros(B, m, device=DEV)
+    i1 = torch.zeros(B, n, dtype=torch.int32, device=DEV)
+    i2 = torch.zeros(B, m, dtype=torch.int32, device=DEV)
+    assert ops.chamfer_fwd(g(a), g(b), d1, d2, i1, i2) == 1
+    w1, w2, j1, j2 = _clib.chamfer_fwd(a.numpy(), b.numpy())
+    assert np.array_equal(d1.cpu().numpy(), w1) and np.array_equal(d2.cpu().numpy(), w2)
+    assert np.array_equal(i1.cpu().numpy(), j1) and np.array_equal(i2.cpu().numpy(), j2)
+    gd1, gd2 = torch.rand(B, n, generator=gen), torch.rand(B, m, generator=gen)
+    g1 = torch.zeros(B, n, 3, device=DEV)
+    g2 = torch.zeros(B, m, 3, device=DEV)
+    ops.chamfer_bwd(g(a), g(b), g1, g2, g(gd1), g(gd2), i1, i2)
+    r1, r2 = _clib.chamfer_bwd(a.numpy(), b.numpy(), gd1.numpy(), gd2.numpy(), j1, j2)
+    assert np.array_equal(g1.cpu().numpy(), r1) and np.array_equal(g2.cpu().numpy(), r2)
+    # backward ACCUMULATES (chamfer3D.cu:166-171): a second call doubles (up to rounding of the sum)
+    ops.chamfer_bwd(g(a), g(b), g1, g2, g(gd1), g(gd2), i1, i2)
+    assert np.allclose(g1.cpu().numpy(), 2 * r1, atol=1e-6) and np.allclose(g2.cpu().numpy(), 2 * r2, atol=1e-6)
+
+
+def test_chamfer_module_vs_reference_golden_and_autograd(ops):
+    """losses/metrics/CD/unit_test.py:22-33 acceptance rule against the reference's own outputs."""
+    from tgpose_amd import chamfer_3DDist
+    gd = golden("chamfer.npz")
+    cham = chamfer_3DDist()
+    for x, y, pre in ((gd["a"], gd["b"], ""), (gd["noisy"], gd["prior"], "p_")):
+        a = g(x).requires_grad_(True)
+        b = g(y).requires_grad_(True)
+        d1, d2, i1, i2 = cham(a, b)
+        assert torch.mean((d1.cpu() - torch.from_numpy(gd[pre + "dist1"])) ** 2) + \
+            torch.mean((d2.cpu() - torch.from_numpy(gd[pre + "dist2"])) ** 2) < 1e-8
+        assert np.array_equal(i1.cpu().numpy(), gd[pre + "idx1"]) and np.array_equal(i2.cpu().numpy(), gd[pre + "idx2"])
+        (d1.sum() + 0.5 * d2.sum()).backward()
+        ac, bc = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(y).requires_grad_(True)
+        nb = torch.gather(bc, 1, i1.cpu().long().unsqueeze(-1).expand(-1, -1, 3))
+        na = torch.gather(ac, 1, i2.cpu().long().unsqueeze(-1).expand(-1, -1, 3))
+        (((ac - nb) ** 2).sum() + 0.5 * ((bc - na) ** 2).sum()).backward()
+        assert torch.allclose(a.grad.cpu(), ac.grad, atol=1e-6) and torch.allclose(b.grad.cpu(), bc.grad, atol=1e-6)

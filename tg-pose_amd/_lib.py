@@ -1,0 +1,95 @@
+"""ctypes binding of libtgpose_hip.so (the C ABI declared in include/tgpose.h).
+
+There is NO fallback: if the library is missing or a call fails, this raises.  The product path
+never routes through the CPU oracle or through torch ops for the hot layers.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtgpose_hip.so")
+
+c_int, c_i64, c_f32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+class GemmArgs(ctypes.Structure):
+    """struct tgp_gemm_args (include/tgpose.h)"""
+    _fields_ = [
+        ("A", c_vp), ("lda", c_int),
+        ("W", c_vp), ("ldw", c_int),
+        ("C", c_vp), ("ldc", c_int),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("bias", c_vp),
+        ("rowbias", c_vp), ("ldrb", c_int),
+        ("rows_per_obj", c_int),
+        ("res1", c_vp), ("ldr1", c_int),
+        ("res2", c_vp), ("ldr2", c_int),
+        ("scale", c_vp),
+        ("shift", c_vp),
+        ("act", c_int),
+        ("slope", c_f32),
+        ("colmax_keys", c_vp), ("ldcm", c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/tgpose.h declares
+SIGNATURES = {
+    "tgp_version": (c_int, []),
+    "tgp_knn_max_points": (c_int, []),
+    "tgp_knn_max_k": (c_int, []),
+    "tgp_center": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "tgp_knn_xyz": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    "tgp_knn_feat_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
+    "tgp_knn_feat": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp]),
+    "tgp_nn1": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    "tgp_normalize_dirs": (c_int, [c_vp, c_int, c_vp, c_vp]),
+    "tgp_gconv_surface_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
+    "tgp_gconv_hs_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
+    "tgp_orl_partial_floats": (c_i64, [c_int, c_int, c_int]),
+    "tgp_orl_global": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "tgp_pool_fwd": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
+    "tgp_gather_rows": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
+    "tgp_fill_tail": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
+    "tgp_gemm_f32": (c_int, [ctypes.POINTER(GemmArgs), c_vp]),
+    "tgp_colmax_decode": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
+    "tgp_colmax": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "tgp_sigmoid": (c_int, [c_vp, c_vp, c_i64, c_vp]),
+    "tgp_head_post": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "tgp_add_mean": (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
+    "tgp_chamfer_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "tgp_chamfer_bwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class TgpError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared library once; raise loudly if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TgpError(
+                "tgpose_amd: %s not found. Build it with `python -m tgpose_amd.build` (hipcc, gfx950). "
+                "There is no CPU/torch fallback for the HIP path." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if handle.tgp_version() != ABI_VERSION:
+            raise TgpError("tgpose_amd: ABI version mismatch (%d != %d)" % (handle.tgp_version(), ABI_VERSION))
+        _lib = handle
+    return _lib
+
+
+_ERR = {-1: "TGP_EINVAL (bad pointer / size / stride / alignment)", -2: "TGP_EUNSUPPORTED (shape not supported)"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise TgpError("%s failed: %s" % (what, _ERR.get(rc, "hipError_t %d" % rc)))

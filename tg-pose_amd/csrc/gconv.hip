@@ -1,0 +1,363 @@
+// Graph convolution, ORL pooling, kNN max-pool and row gathers of the 3D-GCN encoder on gfx950.
+//
+// The reference materialises (B,n,k,7*C) tensors three times per layer (theta, gathered support,
+// their product: gcn3d.py:166-177) and reduces them afterwards; here one wavefront owns one point
+// and keeps the 7 x 4-channel running maxima in registers while it streams the k gathered support
+// rows (float4 per lane, whole 512 B..1 KiB row segments per wave-instruction) -- nothing of size
+// k*7*C ever exists.  All workgroups of one object are placed on one XCD (tgp_xcd_object_tile) so
+// the object's projection table (n x 8C floats, 3.7 MB at n=1028, C=128) is served from that L2.
+#include "tgp_common.h"
+
+#define GC_S 7          // support directions per kernel (config/config.py:44 gcn_sup_num)
+#define GC_PTS 16       // points per workgroup (4 waves x 4)
+#define GC_MAXK 64
+
+// F.normalize(directions, dim=0): column c of a (3, SC) matrix scaled to unit length (eps 1e-12)
+__global__ void normalize_dirs_kernel(const float *__restrict__ d, int SC, float *__restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= SC) return;
+    const float x = d[c], y = d[SC + c], z = d[2 * SC + c];
+    const float nrm = fmaxf(sqrtf((x * x + y * y) + z * z), 1e-12f);
+    out[c] = x / nrm;
+    out[SC + c] = y / nrm;
+    out[2 * SC + c] = z / nrm;
+}
+
+extern "C" int tgp_normalize_dirs(const float *directions, int SC, float *out, tgp_stream_t stream)
+{
+    TGP_REQUIRE(directions && out && SC > 0);
+    hipLaunchKernelGGL(normalize_dirs_kernel, dim3(tgp_cdiv(SC, 256)), dim3(256), 0, tgp_hs(stream), directions, SC, out);
+    return TGP_LAUNCH_RESULT();
+}
+
+// Lane layout shared by the gather kernels: a row of C floats is covered by C/4 lanes (float4 each).
+//   C = 128: 32 lanes per row, the two wave halves take alternate neighbours (SPLIT = 2)
+//   C = 256: 64 lanes per row
+//   C = 512: two 256-column chunks, one workgroup per chunk (CHUNKS = 2)
+template <int C>
+struct RowLanes {
+    static constexpr int LPR = (C / 4) < 64 ? (C / 4) : 64;
+    static constexpr int SPLIT = 64 / LPR;
+    static constexpr int CHUNKS = (C / 4 + 63) / 64;
+};
+
+template <int C, bool SURFACE>
+__global__ __launch_bounds__(256) void gconv_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ idx,
+                                                    const float *__restrict__ proj, int ldp,
+                                                    const float *__restrict__ sdn, int B, int n, int k,
+                                                    float *__restrict__ out, int ldo, int tiles_per_obj)
+{
+    using RL = RowLanes<C>;
+    int b, tile;
+    if (!tgp_xcd_object_tile(blockIdx.x, B, tiles_per_obj, b, tile)) return;
+    const int chunk = tile % RL::CHUNKS;
+    const int ptile = tile / RL::CHUNKS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane / RL::LPR;
+    const int cb = chunk * 256 + 4 * (lane % RL::LPR);
+    constexpr int SC = GC_S * C;
+
+    // unit support directions of this lane's 4 channels: 7 supports x 3 components
+    float4 sd[GC_S][3];
+#pragma unroll
+    for (int s = 0; s < GC_S; ++s)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sd[s][c] = *reinterpret_cast<const float4 *>(sdn + c * SC + s * C + cb);
+
+    for (int pp = wave; pp < GC_PTS; pp += 4) {
+        const int i = ptile * GC_PTS + pp;
+        if (i >= n) break;
+        const int64_t rowi = (int64_t)b * n + i;
+        // lanes 0..k-1: neighbour id and unit direction (gcn3d.py:48-58)
+        int nj = 0;
+        float dx = 0.f, dy = 0.f, dz = 0.f;
+        if (lane < k) {
+            nj = idx[rowi * k + lane];
+            const float *pn = xyz + ((int64_t)b * n + nj) * 3;
+            const float *pc = xyz + rowi * 3;
+            dx = pn[0] - pc[0];
+            dy = pn[1] - pc[1];
+            dz = pn[2] - pc[2];
+            const float nrm = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-12f);
+            dx = dx / nrm;
+            dy = dy / nrm;
+            dz = dz / nrm;
+        }
+        float4 m[GC_S];
+        const float init = SURFACE ? 0.f : -INFINITY;
+#pragma unroll
+        for (int s = 0; s < GC_S; ++s) m[s] = make_float4(init, init, init, init);
+
+        for (int jj = 0; jj * RL::SPLIT < k; ++jj) {
+            const int j = jj * RL::SPLIT + half;
+            const bool valid = j < k;
+            const int src = valid ? j : 0;
+            const float ux = __shfl(dx, src, 64), uy = __shfl(dy, src, 64), uz = __shfl(dz, src, 64);
+            const int nb = __shfl(nj, src, 64);
+            float4 sup[GC_S];
+            if (!SURFACE) {
+                const float *prow = proj + ((int64_t)b * n + nb) * ldp + C + cb;
+#pragma unroll
+                for (int s = 0; s < GC_S; ++s) sup[s] = *reinterpret_cast<const float4 *>(prow + s * C);
+            }
+            if (valid) {
+#pragma unroll
+                for (int s = 0; s < GC_S; ++s) {
+                    float4 t;
+                    t.x = fmaf(uz, sd[s][2].x, fmaf(uy, sd[s][1].x, ux * sd[s][0].x));
+                    t.y = fmaf(uz, sd[s][2].y, fmaf(uy, sd[s][1].y, ux * sd[s][0].y));
+                    t.z = fmaf(uz, sd[s][2].z, fmaf(uy, sd[s][1].z, ux * sd[s][0].z));
+                    t.w = fmaf(uz, sd[s][2].w, fmaf(uy, sd[s][1].w, ux * sd[s][0].w));
+                    t.x = fmaxf(t.x, 0.f), t.y = fmaxf(t.y, 0.f), t.z = fmaxf(t.z, 0.f), t.w = fmaxf(t.w, 0.f);
+                    if (!SURFACE) t.x *= sup[s].x, t.y *= sup[s].y, t.z *= sup[s].z, t.w *= sup[s].w;
+                    m[s].x = fmaxf(m[s].x, t.x), m[s].y = fmaxf(m[s].y, t.y);
+                    m[s].z = fmaxf(m[s].z, t.z), m[s].w = fmaxf(m[s].w, t.w);
+                }
+            }
+        }
+        if (RL::SPLIT == 2) {
+#pragma unroll
+            for (int s = 0; s < GC_S; ++s) {
+                m[s].x = fmaxf(m[s].x, __shfl_xor(m[s].x, 32, 64));
+                m[s].y = fmaxf(m[s].y, __shfl_xor(m[s].y, 32, 64));
+                m[s].z = fmaxf(m[s].z, __shfl_xor(m[s].z, 32, 64));
+                m[s].w = fmaxf(m[s].w, __shfl_xor(m[s].w, 32, 64));
+            }
+        }
+        if (half == 0) {
+            float4 acc = m[0]; // torch.mean over the 7 supports: sequential sum, then / 7
+#pragma unroll
+            for (int s = 1; s < GC_S; ++s) acc.x += m[s].x, acc.y += m[s].y, acc.z += m[s].z, acc.w += m[s].w;
+            acc.x = acc.x / 7.0f, acc.y = acc.y / 7.0f, acc.z = acc.z / 7.0f, acc.w = acc.w / 7.0f;
+            if (!SURFACE) {
+                const float4 ctr = *reinterpret_cast<const float4 *>(proj + rowi * ldp + cb);
+                acc.x = ctr.x + acc.x, acc.y = ctr.y + acc.y, acc.z = ctr.z + acc.z, acc.w = ctr.w + acc.w;
+            }
+            *reinterpret_cast<float4 *>(out + rowi * ldo + cb) = acc;
+        }
+    }
+}
+
+static int gconv_check(const void *xyz, const void *idx, const void *sdn, const void *out, int B, int n, int k, int S,
+                       int C, int ldo)
+{
+    if (!xyz || !idx || !sdn || !out || B <= 0 || n <= 0 || k <= 0) return TGP_EINVAL;
+    if (S != GC_S || k > GC_MAXK || !(C == 128 || C == 256 || C == 512)) return TGP_EUNSUPPORTED;
+    if (ldo < C || (ldo & 3) || (reinterpret_cast<uintptr_t>(out) & 15) || (reinterpret_cast<uintptr_t>(sdn) & 15))
+        return TGP_EINVAL;
+    return 0;
+}
+
+template <bool SURFACE>
+static int gconv_launch(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B, int n,
+                        int k, int C, float *out, int ldo, hipStream_t stream)
+{
+    const int ptiles = tgp_cdiv(n, GC_PTS);
+#define GC_GO(CC)                                                                                                     \
+    {                                                                                                                 \
+        const int tiles = ptiles * RowLanes<CC>::CHUNKS;                                                              \
+        hipLaunchKernelGGL((gconv_kernel<CC, SURFACE>), dim3(tgp_xcd_grid(B, tiles)), dim3(256), 0, stream, xyz, idx, \
+                           proj, ldp, sdn, B, n, k, out, ldo, tiles);                                                 \
+    }
+    if (C == 128) GC_GO(128) else if (C == 256) GC_GO(256) else GC_GO(512)
+#undef GC_GO
+    return TGP_LAUNCH_RESULT();
+}
+
+extern "C" int tgp_gconv_surface_fwd(const float *xyz, const int32_t *idx, const float *sdn, int B, int n, int k, int S,
+                                     int C, float *out, int ldo, tgp_stream_t stream)
+{
+    const int chk = gconv_check(xyz, idx, sdn, out, B, n, k, S, C, ldo);
+    if (chk) return chk;
+    return gconv_launch<true>(xyz, idx, nullptr, 0, sdn, B, n, k, C, out, ldo, tgp_hs(stream));
+}
+
+extern "C" int tgp_gconv_hs_fwd(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B,
+                                int n, int k, int S, int C, float *out, int ldo, tgp_stream_t stream)
+{
+    const int chk = gconv_check(xyz, idx, sdn, out, B, n, k, S, C, ldo);
+    if (chk) return chk;
+    TGP_REQUIRE(proj && ldp >= (S + 1) * C && (ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(proj) & 15) == 0);
+    return gconv_launch<false>(xyz, idx, proj, ldp, sdn, B, n, k, C, out, ldo, tgp_hs(stream));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ORL: g[b,c] = mean_i max_j feat[b, idx[b,i,j], c]   (gcn3d.py:210-217)
+// stage 1: each workgroup sums the neighbour-max rows of ORL_PTS points -> partial[b, tile, :]
+// stage 2: partials summed in tile order and divided by n (deterministic, no float atomics)
+#define ORL_PTS 64
+
+template <int C>
+__global__ __launch_bounds__(256) void orl_partial_kernel(const float *__restrict__ feat, int ldf,
+                                                          const int32_t *__restrict__ idx, int B, int n, int k,
+                                                          float *__restrict__ partial, int ptiles, int tiles_per_obj)
+{
+    using RL = RowLanes<C>;
+    __shared__ float4 red[4][64];
+    int b, tile;
+    if (!tgp_xcd_object_tile(blockIdx.x, B, tiles_per_obj, b, tile)) return;
+    const int chunk = tile % RL::CHUNKS;
+    const int ptile = tile / RL::CHUNKS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane / RL::LPR;
+    const int cb = chunk * 256 + 4 * (lane % RL::LPR);
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int pp = wave; pp < ORL_PTS; pp += 4) {
+        const int i = ptile * ORL_PTS + pp;
+        if (i >= n) break;
+        const int nj = (lane < k) ? idx[((int64_t)b * n + i) * k + lane] : 0;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int jj = 0; jj * RL::SPLIT < k; ++jj) {
+            const int j = jj * RL::SPLIT + half;
+            const bool valid = j < k;
+            const int nb = __shfl(nj, valid ? j : 0, 64);
+            const float4 v = *reinterpret_cast<const float4 *>(feat + ((int64_t)b * n + nb) * ldf + cb);
+            if (valid) m.x = fmaxf(m.x, v.x), m.y = fmaxf(m.y, v.y), m.z = fmaxf(m.z, v.z), m.w = fmaxf(m.w, v.w);
+        }
+        if (RL::SPLIT == 2) {
+            m.x = fmaxf(m.x, __shfl_xor(m.x, 32, 64));
+            m.y = fmaxf(m.y, __shfl_xor(m.y, 32, 64));
+            m.z = fmaxf(m.z, __shfl_xor(m.z, 32, 64));
+            m.w = fmaxf(m.w, __shfl_xor(m.w, 32, 64));
+        }
+        sum.x += m.x, sum.y += m.y, sum.z += m.z, sum.w += m.w;
+    }
+    red[wave][lane] = sum;
+    __syncthreads();
+    if (wave == 0 && half == 0) {
+        float4 t = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) t.x += red[w][lane].x, t.y += red[w][lane].y, t.z += red[w][lane].z, t.w += red[w][lane].w;
+        *reinterpret_cast<float4 *>(partial + ((int64_t)b * ptiles + ptile) * C + cb) = t;
+    }
+}
+
+__global__ void orl_finish_kernel(const float *__restrict__ partial, int B, int n, int C, int ptiles,
+                                  float *__restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * C) return;
+    const int b = t / C, c = t - b * C;
+    float s = 0.f;
+    for (int p = 0; p < ptiles; ++p) s += partial[((int64_t)b * ptiles + p) * C + c];
+    out[t] = s / (float)n;
+}
+
+extern "C" int64_t tgp_orl_partial_floats(int B, int n, int C)
+{
+    if (B <= 0 || n <= 0 || C <= 0) return 0;
+    return (int64_t)B * tgp_cdiv(n, ORL_PTS) * C;
+}
+
+extern "C" int tgp_orl_global(const float *feat, int ldf, const int32_t *idx, int B, int n, int k, int C, float *partial,
+                              float *out, tgp_stream_t stream)
+{
+    TGP_REQUIRE(feat && idx && partial && out && B > 0 && n > 0 && k > 0);
+    if (k > GC_MAXK || !(C == 128 || C == 256 || C == 512)) return TGP_EUNSUPPORTED;
+    TGP_REQUIRE(ldf >= C && (ldf & 3) == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(partial) & 15) == 0);
+    const int ptiles = tgp_cdiv(n, ORL_PTS);
+#define ORL_GO(CC)                                                                                                   \
+    {                                                                                                                \
+        const int tiles = ptiles * RowLanes<CC>::CHUNKS;                                                             \
+        hipLaunchKernelGGL(orl_partial_kernel<CC>, dim3(tgp_xcd_grid(B, tiles)), dim3(256), 0, tgp_hs(stream), feat,  \
+                           ldf, idx, B, n, k, partial, ptiles, tiles);                                               \
+    }
+    if (C == 128) ORL_GO(128) else if (C == 256) ORL_GO(256) else ORL_GO(512)
+#undef ORL_GO
+    hipLaunchKernelGGL(orl_finish_kernel, dim3(tgp_cdiv(B * C, 256)), dim3(256), 0, tgp_hs(stream), partial, B, n, C,
+                       ptiles, out);
+    return TGP_LAUNCH_RESULT();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Pool_layer: neighbour max at the sampled rows only (the reference computes all n rows and keeps n/4)
+__global__ void pool_kernel(const float *__restrict__ xyz, const float *__restrict__ feat, int ldf,
+                            const int32_t *__restrict__ idx, int ldi, const int32_t *__restrict__ sample, int B, int n,
+                            int n_out, int kpool, int C4, float *__restrict__ out_xyz, float *__restrict__ out_f, int ldo)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)B * n_out * C4) return;
+    const int c4 = (int)(t % C4);
+    const int64_t pm = t / C4;
+    const int mrow = (int)(pm % n_out), b = (int)(pm / n_out);
+    const int s = sample[mrow];
+    const int32_t *nb = idx + ((int64_t)b * n + s) * ldi;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int j = 0; j < kpool; ++j) {
+        const float4 v = *reinterpret_cast<const float4 *>(feat + ((int64_t)b * n + nb[j]) * ldf + 4 * c4);
+        m.x = fmaxf(m.x, v.x), m.y = fmaxf(m.y, v.y), m.z = fmaxf(m.z, v.z), m.w = fmaxf(m.w, v.w);
+    }
+    *reinterpret_cast<float4 *>(out_f + pm * ldo + 4 * c4) = m;
+    if (c4 == 0) {
+        const float *p = xyz + ((int64_t)b * n + s) * 3;
+        float *o = out_xyz + pm * 3;
+        o[0] = p[0], o[1] = p[1], o[2] = p[2];
+    }
+}
+
+extern "C" int tgp_pool_fwd(const float *xyz, const float *feat, int ldf, const int32_t *idx, int ldi,
+                            const int32_t *sample, int B, int n, int n_out, int kpool, int C, float *out_xyz, float *out_f,
+                            int ldo, tgp_stream_t stream)
+{
+    TGP_REQUIRE(xyz && feat && idx && sample && out_xyz && out_f);
+    TGP_REQUIRE(B > 0 && n > 0 && n_out > 0 && n_out <= n && kpool > 0 && ldi >= kpool && C > 0 && (C & 3) == 0);
+    TGP_REQUIRE(ldf >= C && ldo >= C && (ldf & 3) == 0 && (ldo & 3) == 0);
+    TGP_REQUIRE((reinterpret_cast<uintptr_t>(feat) & 15) == 0 && (reinterpret_cast<uintptr_t>(out_f) & 15) == 0);
+    const int64_t total = (int64_t)B * n_out * (C / 4);
+    hipLaunchKernelGGL(pool_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), xyz, feat, ldf, idx, ldi,
+                       sample, B, n, n_out, kpool, C / 4, out_xyz, out_f, ldo);
+    return TGP_LAUNCH_RESULT();
+}
+
+__global__ void gather_rows_kernel(const float *__restrict__ src, int lds, const int32_t *__restrict__ idx, int B,
+                                   int n_src, int n_out, int C4, float *__restrict__ dst, int ldd)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)B * n_out * C4) return;
+    const int c4 = (int)(t % C4);
+    const int64_t row = t / C4;
+    const int b = (int)(row / n_out);
+    const int s = idx[row];
+    *reinterpret_cast<float4 *>(dst + row * ldd + 4 * c4) =
+        *reinterpret_cast<const float4 *>(src + ((int64_t)b * n_src + s) * lds + 4 * c4);
+}
+
+extern "C" int tgp_gather_rows(const float *src, int lds, const int32_t *idx, int B, int n_src, int n_out, int C,
+                               float *dst, int ldd, tgp_stream_t stream)
+{
+    TGP_REQUIRE(src && idx && dst && B > 0 && n_src > 0 && n_out > 0 && C > 0 && (C & 3) == 0);
+    TGP_REQUIRE(lds >= C && ldd >= C && (lds & 3) == 0 && (ldd & 3) == 0);
+    TGP_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+    const int64_t total = (int64_t)B * n_out * (C / 4);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), src, lds, idx, B,
+                       n_src, n_out, C / 4, dst, ldd);
+    return TGP_LAUNCH_RESULT();
+}
+
+// tail columns of the concat buffer: one-hot category | centred xyz | zero padding
+__global__ void fill_tail_kernel(const float *__restrict__ obj_id, const float *__restrict__ xyz_c, int n, int64_t rows,
+                                 int n_cls, float *__restrict__ feat, int ld, int col0)
+{
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const int b = (int)(row / n);
+    const int cls = (int)obj_id[b]; // obj_idh.long()  (FaceRecon.py:54)
+    float *f = feat + row * ld + col0;
+    for (int c = 0; c < n_cls; ++c) f[c] = (c == cls) ? 1.f : 0.f;
+    f[n_cls + 0] = xyz_c[row * 3 + 0];
+    f[n_cls + 1] = xyz_c[row * 3 + 1];
+    f[n_cls + 2] = xyz_c[row * 3 + 2];
+    for (int c = col0 + n_cls + 3; c < ld; ++c) feat[row * ld + c] = 0.f;
+}
+
+extern "C" int tgp_fill_tail(const float *obj_id, const float *xyz_c, int B, int n, int n_cls, float *feat, int ld,
+                             int col0, tgp_stream_t stream)
+{
+    TGP_REQUIRE(obj_id && xyz_c && feat && B > 0 && n > 0 && n_cls > 0 && col0 >= 0 && ld >= col0 + n_cls + 3);
+    const int64_t rows = (int64_t)B * n;
+    hipLaunchKernelGGL(fill_tail_kernel, dim3(tgp_cdiv(rows, 256)), dim3(256), 0, tgp_hs(stream), obj_id, xyz_c, n, rows,
+                       n_cls, feat, ld, col0);
+    return TGP_LAUNCH_RESULT();
+}

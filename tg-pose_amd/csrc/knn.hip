@@ -1,0 +1,352 @@
+// kNN graph construction for the TG-Pose forward path on gfx950.
+//
+// Reference semantics (network/fs_net_repo/gcn3d.py:14-35): distances are the fp32 expansion
+// D_ij = fl(fl(-2*<a_i,a_j> + |a_j|^2) + |a_i|^2) computed with bmm / sum, then topk(k+1) and drop
+// column 0.  The neighbour ORDER therefore depends on the exact rounding, which these kernels
+// reproduce (DESIGN.md "kNN arithmetic"): <a,b> is an ascending-k FMA chain, |a|^2 follows ATen's
+// cascade sum, ties are ordered by index.
+//
+// Selection: one 64-lane wavefront per query row.  Each lane keeps n/64 candidate distances in
+// registers; k+1 rounds of (lane-local min, 6-step butterfly argmin over the wave, retire the
+// winner) emit the neighbours in ascending (distance, index) order.  No N x N matrix exists for
+// the 3-d case (the object's cloud sits in LDS as float4 {x,y,z,|p|^2}); the feature-space case
+// reads rows of a distance matrix produced by the MFMA GEMM (gemm.hip, DIST epilogue).
+#include "tgp_common.h"
+
+#define KNN_MAX_POINTS 2048
+#define KNN_MAX_K 63
+#define KNN_ROWS_PER_BLOCK 32
+
+extern "C" int tgp_knn_max_points(void) { return KNN_MAX_POINTS; }
+extern "C" int tgp_knn_max_k(void) { return KNN_MAX_K; }
+
+// ------------------------------------------------------------------------------------------------
+// ATen row_sum<float> over `size` elements spaced `stride` floats apart (SumKernel.cpp: 4
+// interleaved accumulators, 16-step cascade levels).  Serial on purpose: it fixes the bits of
+// the per-object mean, which fixes the centred cloud, which fixes the neighbour order.
+__device__ float aten_row_sum_strided(const float *in, int stride, int size)
+{
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f},
+          a3[4] = {0.f, 0.f, 0.f, 0.f};
+    const int size_ilp = size / 4;
+    int i = 0;
+    for (; i + 16 <= size_ilp;) {
+        for (int j = 0; j < 16; ++j, ++i) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a0[k] = a0[k] + in[(size_t)(i * 4 + k) * stride];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a1[k] = a1[k] + a0[k];
+            a0[k] = 0.f;
+        }
+        if ((i & (15 << 4)) != 0) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a2[k] = a2[k] + a1[k];
+            a1[k] = 0.f;
+        }
+        if ((i & (15 << 8)) != 0) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a3[k] = a3[k] + a2[k];
+            a2[k] = 0.f;
+        }
+    }
+    for (; i < size_ilp; ++i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a0[k] = a0[k] + in[(size_t)(i * 4 + k) * stride];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a0[k] = a0[k] + a1[k];
+        a0[k] = a0[k] + a2[k];
+        a0[k] = a0[k] + a3[k];
+    }
+    for (int t = size_ilp * 4; t < size; ++t) a0[0] = a0[0] + in[(size_t)t * stride];
+    a0[0] = a0[0] + a0[1];
+    a0[0] = a0[0] + a0[2];
+    a0[0] = a0[0] + a0[3];
+    return 0.f + a0[0];
+}
+
+__global__ void center_mean_kernel(const float *__restrict__ points, int B, int n, float *__restrict__ mean)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * 3) return;
+    const int b = t / 3, c = t - b * 3;
+    const float s = aten_row_sum_strided(points + (size_t)b * n * 3 + c, 3, n);
+    mean[t] = s / (float)n;
+}
+
+__global__ void center_sub_kernel(const float *__restrict__ points, const float *__restrict__ mean, int n,
+                                  int64_t total, float *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int64_t p = t / 3;
+    const int c = (int)(t - p * 3);
+    const int b = (int)(p / n);
+    out[t] = points[t] - mean[b * 3 + c];
+}
+
+extern "C" int tgp_center(const float *points, int B, int n, float *xyz_c, float *mean, tgp_stream_t stream)
+{
+    TGP_REQUIRE(points && xyz_c && mean && B > 0 && n > 0);
+    hipLaunchKernelGGL(center_mean_kernel, dim3(tgp_cdiv(B * 3, 64)), dim3(64), 0, tgp_hs(stream), points, B, n, mean);
+    const int64_t total = (int64_t)B * n * 3;
+    hipLaunchKernelGGL(center_sub_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), points, mean, n,
+                       total, xyz_c);
+    return TGP_LAUNCH_RESULT();
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave-wide top-(k+1) selection over NT register slots per lane
+template <int NT>
+__device__ __forceinline__ void wave_select(float (&d)[NT], int lane, int k, int32_t *__restrict__ out_row)
+{
+    int mine = 0; // lane r-1 keeps the neighbour of rank r
+    for (int r = 0; r <= k; ++r) {
+        float best = d[0];
+        int bt = 0;
+#pragma unroll
+        for (int t = 1; t < NT; ++t) {
+            const bool lt = d[t] < best;
+            best = lt ? d[t] : best;
+            bt = lt ? t : bt;
+        }
+        int bj = lane + (bt << 6);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float od = __shfl_xor(best, off, 64);
+            const int oj = __shfl_xor(bj, off, 64);
+            const bool take = (od < best) || (od == best && oj < bj);
+            best = take ? od : best;
+            bj = take ? oj : bj;
+        }
+        // every lane now holds the same winner (distance, index); retire it from its owner
+        const int owner = bj & 63, slot = bj >> 6;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (t == slot && lane == owner) d[t] = INFINITY;
+        if (r >= 1 && lane == r - 1) mine = bj;
+    }
+    if (lane < k) out_row[lane] = mine;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void knn_xyz_kernel(const float *__restrict__ xyz, int B, int n, int k,
+                                                      int32_t *__restrict__ idx, int tiles_per_obj)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *pts = reinterpret_cast<float4 *>(smem);
+    int b, tile;
+    if (!tgp_xcd_object_tile(blockIdx.x, B, tiles_per_obj, b, tile)) return;
+    const float *xb = xyz + (size_t)b * n * 3;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const float x = xb[j * 3 + 0], y = xb[j * 3 + 1], z = xb[j * 3 + 2];
+        float q = x * x;          // torch.sum(v**2, dim=2) over 3 elements: ((0+x^2)+y^2)+z^2
+        q = q + y * y;
+        q = q + z * z;
+        pts[j] = make_float4(x, y, z, q);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = wave; r < KNN_ROWS_PER_BLOCK; r += 4) {
+        const int i = tile * KNN_ROWS_PER_BLOCK + r;
+        if (i >= n) break;
+        const float4 pi = pts[i];
+        float d[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = lane + (t << 6);
+            float dv = INFINITY;
+            if (j < n) {
+                const float4 pj = pts[j];
+                float inner = pi.x * pj.x;         // bmm(v, v^T): ascending-k FMA chain from 0
+                inner = fmaf(pi.y, pj.y, inner);
+                inner = fmaf(pi.z, pj.z, inner);
+                const float t1 = inner * -2.0f;
+                const float t2 = t1 + pj.w;        // + quadratic.unsqueeze(1)  (column term)
+                dv = t2 + pi.w;                    // + quadratic.unsqueeze(2)  (row term)
+            }
+            d[t] = dv;
+        }
+        wave_select<NT>(d, lane, k, idx + ((size_t)b * n + i) * k);
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void knn_matrix_kernel(const float *__restrict__ D, int B, int n, int k,
+                                                         int32_t *__restrict__ idx, int tiles_per_obj)
+{
+    int b, tile;
+    if (!tgp_xcd_object_tile(blockIdx.x, B, tiles_per_obj, b, tile)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = wave; r < KNN_ROWS_PER_BLOCK; r += 4) {
+        const int i = tile * KNN_ROWS_PER_BLOCK + r;
+        if (i >= n) break;
+        const float *row = D + ((size_t)b * n + i) * n;
+        float d[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = lane + (t << 6);
+            d[t] = (j < n) ? row[j] : INFINITY;
+        }
+        wave_select<NT>(d, lane, k, idx + ((size_t)b * n + i) * k);
+    }
+}
+
+static int knn_check(int B, int n, int k)
+{
+    if (B <= 0 || n <= 0 || k <= 0) return TGP_EINVAL;
+    if (n > KNN_MAX_POINTS || k > KNN_MAX_K || k + 1 > n) return TGP_EUNSUPPORTED;
+    return 0;
+}
+
+extern "C" int tgp_knn_xyz(const float *xyz, int B, int n, int k, int32_t *idx, tgp_stream_t stream)
+{
+    TGP_REQUIRE(xyz && idx);
+    const int chk = knn_check(B, n, k);
+    if (chk) return chk;
+    const int tiles = tgp_cdiv(n, KNN_ROWS_PER_BLOCK);
+    const dim3 grid(tgp_xcd_grid(B, tiles)), block(256);
+    const size_t lds = (size_t)n * sizeof(float4);
+    const int nt = tgp_cdiv(n, 64);
+#define LAUNCH_XYZ(NT) \
+    hipLaunchKernelGGL(knn_xyz_kernel<NT>, grid, block, lds, tgp_hs(stream), xyz, B, n, k, idx, tiles)
+    if (nt <= 1) LAUNCH_XYZ(1);
+    else if (nt <= 2) LAUNCH_XYZ(2);
+    else if (nt <= 5) LAUNCH_XYZ(5);
+    else if (nt <= 8) LAUNCH_XYZ(8);
+    else if (nt <= 17) LAUNCH_XYZ(17);
+    else LAUNCH_XYZ(32);
+#undef LAUNCH_XYZ
+    return TGP_LAUNCH_RESULT();
+}
+
+// |x_r|^2 in ATen's vectorised cascade order (8-wide vectors, 4 interleaved accumulators,
+// lanes summed last).  8 threads cooperate on a row; d % 32 == 0 and d / 32 < 16 (no cascade level).
+__global__ __launch_bounds__(256) void sqnorm_aten_kernel(const float *__restrict__ x, int ld, int64_t rows, int d,
+                                                          float *__restrict__ q)
+{
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int l8 = threadIdx.x & 7;
+    const bool live = row < rows;
+    const float *xr = x + (live ? row : 0) * (int64_t)ld;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int size_ilp = d >> 5;
+    for (int i = 0; i < size_ilp; ++i) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float v = xr[((i << 2) + kk) * 8 + l8];
+            acc[kk] = acc[kk] + v * v;
+        }
+    }
+    float p = acc[0] + acc[1];
+    p = p + acc[2];
+    p = p + acc[3];
+    float fin = 0.f;
+    const int base = (threadIdx.x & 63) & ~7;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) fin = fin + __shfl(p, base + l, 64);
+    if (live && l8 == 0) q[row] = 0.f + fin;
+}
+
+// implemented in gemm.hip: D[b,i,j] = fl(fl(-2*<x_i,x_j> + q_j) + q_i), natural-k MFMA chain
+int tgp_launch_dist_gemm(const float *x, int ld, const float *q, int B, int n, int d, float *D, hipStream_t stream);
+
+extern "C" int64_t tgp_knn_feat_workspace_bytes(int B, int n, int d)
+{
+    (void)d;
+    if (B <= 0 || n <= 0) return 0;
+    return ((int64_t)B * n * n + (int64_t)B * n) * (int64_t)sizeof(float);
+}
+
+extern "C" int tgp_knn_feat(const float *feat, int ld, int B, int n, int d, int k, int32_t *idx, void *workspace,
+                            int64_t workspace_bytes, tgp_stream_t stream)
+{
+    TGP_REQUIRE(feat && idx && workspace);
+    const int chk = knn_check(B, n, k);
+    if (chk) return chk;
+    if (d <= 0 || (d & 31) || (d >> 5) >= 16) return TGP_EUNSUPPORTED;
+    TGP_REQUIRE(ld >= d && (ld & 3) == 0);
+    TGP_REQUIRE(workspace_bytes >= tgp_knn_feat_workspace_bytes(B, n, d));
+    float *D = reinterpret_cast<float *>(workspace);   // (B,n,n) distance matrix, then (B,n) squared norms
+    float *q = D + (size_t)B * n * n;
+    const int64_t rows = (int64_t)B * n;
+    hipLaunchKernelGGL(sqnorm_aten_kernel, dim3(tgp_cdiv(rows * 8, 256)), dim3(256), 0, tgp_hs(stream), feat, ld, rows,
+                       d, q);
+    int rc = tgp_launch_dist_gemm(feat, ld, q, B, n, d, D, tgp_hs(stream));
+    if (rc) return rc;
+    const int tiles = tgp_cdiv(n, KNN_ROWS_PER_BLOCK);
+    const dim3 grid(tgp_xcd_grid(B, tiles)), block(256);
+    const int nt = tgp_cdiv(n, 64);
+#define LAUNCH_MAT(NT) hipLaunchKernelGGL(knn_matrix_kernel<NT>, grid, block, 0, tgp_hs(stream), D, B, n, k, idx, tiles)
+    if (nt <= 1) LAUNCH_MAT(1);
+    else if (nt <= 2) LAUNCH_MAT(2);
+    else if (nt <= 5) LAUNCH_MAT(5);
+    else if (nt <= 8) LAUNCH_MAT(8);
+    else if (nt <= 17) LAUNCH_MAT(17);
+    else LAUNCH_MAT(32);
+#undef LAUNCH_MAT
+    return TGP_LAUNCH_RESULT();
+}
+
+// ------------------------------------------------------------------------------------------------
+// get_nearest_index: one thread per target point, source cloud staged through LDS in chunks.
+#define NN1_CHUNK 1024
+__global__ __launch_bounds__(256) void nn1_kernel(const float *__restrict__ tgt, const float *__restrict__ src, int B,
+                                                  int n, int m, int32_t *__restrict__ idx, int tiles_per_obj)
+{
+    __shared__ float4 s[NN1_CHUNK];
+    int b, tile;
+    if (!tgp_xcd_object_tile(blockIdx.x, B, tiles_per_obj, b, tile)) return;
+    const int i = tile * 256 + threadIdx.x;
+    const bool live = i < n;
+    float tx = 0.f, ty = 0.f, tz = 0.f, qt = 0.f;
+    if (live) {
+        const float *t = tgt + ((size_t)b * n + i) * 3;
+        tx = t[0], ty = t[1], tz = t[2];
+        qt = tx * tx;
+        qt = qt + ty * ty;
+        qt = qt + tz * tz;
+    }
+    float best = 0.f;
+    int besti = 0;
+    for (int j0 = 0; j0 < m; j0 += NN1_CHUNK) {
+        const int cnt = min(NN1_CHUNK, m - j0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
+            const float *p = src + ((size_t)b * m + j0 + j) * 3;
+            const float x = p[0], y = p[1], z = p[2];
+            float q = x * x;
+            q = q + y * y;
+            q = q + z * z;
+            s[j] = make_float4(x, y, z, q);
+        }
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) {
+            const float4 p = s[j];
+            float inner = tx * p.x;
+            inner = fmaf(ty, p.y, inner);
+            inner = fmaf(tz, p.z, inner);
+            const float sum = p.w + qt;               // s_norm_2.unsqueeze(1) + t_norm_2.unsqueeze(2)
+            const float dv = sum - 2.0f * inner;      // - 2 * inner
+            if ((j0 + j) == 0 || dv < best) {
+                best = dv;
+                besti = j0 + j;
+            }
+        }
+    }
+    if (live) idx[(size_t)b * n + i] = besti;
+}
+
+extern "C" int tgp_nn1(const float *target, const float *source, int B, int n, int m, int32_t *idx, tgp_stream_t stream)
+{
+    TGP_REQUIRE(target && source && idx && B > 0 && n > 0 && m > 0);
+    const int tiles = tgp_cdiv(n, 256);
+    hipLaunchKernelGGL(nn1_kernel, dim3(tgp_xcd_grid(B, tiles)), dim3(256), 0, tgp_hs(stream), target, source, B, n, m,
+                       idx, tiles);
+    return TGP_LAUNCH_RESULT();
+}

@@ -1,0 +1,301 @@
+"""Eval-mode forward pipeline of PoseNet9D on the HIP kernels (host orchestration only).
+
+This file turns a reference-format state dict into packed device weights (BatchNorm folded into
+per-channel scale/shift, HS-layer projection and STE weights concatenated into one GEMM operand,
+conv2 split into its feature / global halves, head weights padded to the concat buffer's row
+stride) and walks the layers of ``Face_Enc`` / ``PH_Predictor`` / ``Face_Dec`` / the three heads
+by enqueuing kernels through ``ops`` (the C ABI).  No torch compute op touches activations.
+
+Data layout in HBM (fp32, row-major, rows = points):
+  feat   (B*N, 1292)  concat buffer: fm_0 | fm_1 | up(fm_2) | up(fm_3) | up(fm_4) | one-hot(6) |
+                      centred xyz (3) | 3 zero columns.  Every layer writes its slice in place
+                      (FaceRecon.py:75 torch.cat never happens); the three heads and conv_5 /
+                      decoder read it with K = 1292 against zero-padded weights, which also gives
+                      Pose_Ts its 1289-channel input (PoseNet9D.py:63) without a second buffer.
+  proj9  (B*n, 9*Cout) per HS layer: [centre | 7 support blocks | STE] from ONE GEMM.
+"""
+import math
+
+import torch
+
+from . import ops
+
+BN_EPS = 1e-5
+FEAT_C = 1286
+FEAT_LD = 1292          # 1286 + 3 (xyz) rounded up to a multiple of 4 floats (16-byte rows)
+LEVEL_CH = ((128, 128), (128, 256), (256, 256), (256, 512))   # (Cin, Cout) of conv_1..conv_4
+
+
+def _bn_fold(sd, name):
+    scale = sd[name + ".weight"] / torch.sqrt(sd[name + ".running_var"] + BN_EPS)
+    shift = sd[name + ".bias"] - sd[name + ".running_mean"] * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+def _pad_cols(w, cols):
+    out = torch.zeros(w.shape[0], cols, device=w.device, dtype=w.dtype)
+    out[:, : w.shape[1]] = w
+    return out
+
+
+def _dev_sd(sd, device):
+    return {k: v.detach().to(device=device, dtype=torch.float32) for k, v in sd.items() if v.dtype.is_floating_point}
+
+
+def pack_encoder(sd, e, device):
+    """Face_Enc weights under prefix `e` ('face_all.encoder.') -> list of per-layer dicts."""
+    conv = []
+    c0 = dict(C=128)
+    c0["sdn"] = ops.normalize_dirs(sd[e + "conv_0.directions"])
+    c0["ste"] = _pad_cols(sd[e + "conv_0.STE_layer.weight"][:, :, 0], 4)           # (128, 3 -> 4)
+    w2 = sd[e + "conv_0.conv2.weight"][:, :, 0]
+    c0["w1"], c0["w2"] = w2[:, :128].contiguous(), w2[:, 128:].contiguous()
+    conv.append(c0)
+    for i, (cin, cout) in enumerate(LEVEL_CH, start=1):
+        p = e + "conv_%d." % i
+        c = dict(C=cout, Cin=cin)
+        c["sdn"] = ops.normalize_dirs(sd[p + "directions"])
+        # one GEMM operand: rows [weights^T (8*Cout) ; STE (Cout)], bias [bias ; 0]
+        c["wcat"] = torch.cat([sd[p + "weights"].t(), sd[p + "STE_layer.weight"][:, :, 0]], dim=0).contiguous()
+        c["bcat"] = torch.cat([sd[p + "bias"], torch.zeros(cout, device=device)]).contiguous()
+        w2 = sd[p + "conv2.weight"][:, :, 0]
+        c["w1"], c["w2"] = w2[:, :cout].contiguous(), w2[:, cout:].contiguous()
+        if i <= 3:
+            c["scale"], c["shift"] = _bn_fold(sd, e + "bn%d" % i)
+        conv.append(c)
+    return conv
+
+
+def pack_ph(sd, ph):
+    lin = lambda n: (sd[ph + n + ".weight"].contiguous(), sd[ph + n + ".bias"].contiguous())
+    return dict(w5=_pad_cols(sd[ph + "conv_5.0.weight"][:, :, 0], FEAT_LD), bn5c=_bn_fold(sd, ph + "conv_5.1"),
+                l1=sd[ph + "linear1.weight"].contiguous(), bn5=_bn_fold(sd, ph + "bn5"),
+                l2=lin("linear2"), l3=lin("linear3"), l4=lin("linear4"), l5=lin("linear5"))
+
+
+def pack_decoder(sd, d):
+    dec = []
+    for conv, bn in (("conv1d_block.0", "conv1d_block.1"), ("conv1d_block.3", "conv1d_block.4"),
+                     ("conv1d_block.6", "conv1d_block.7"), ("recon_head.0", "recon_head.1")):
+        w = sd[d + conv + ".weight"][:, :, 0]
+        if w.shape[1] == FEAT_C:
+            w = _pad_cols(w, FEAT_LD)
+        dec.append((w.contiguous(), sd[d + conv + ".bias"].contiguous()) + _bn_fold(sd, d + bn))
+    return dec, (sd[d + "recon_head.3.weight"][:, :, 0].contiguous(), sd[d + "recon_head.3.bias"].contiguous())
+
+
+def pack_head(sd, h):
+    """Rot_green / Rot_red / Pose_Ts under prefix `h` ('rot_green.'); conv1 padded to the concat stride."""
+    cv = lambda n: (sd[h + n + ".weight"][:, :, 0].contiguous(), sd[h + n + ".bias"].contiguous())
+    w1, b1 = cv("conv1")
+    return dict(k_alg=w1.shape[1], c1=(_pad_cols(w1, FEAT_LD), b1) + _bn_fold(sd, h + "bn1"),
+                c2=cv("conv2") + _bn_fold(sd, h + "bn2"),
+                c3=cv("conv3") + _bn_fold(sd, h + "bn3"), c4=cv("conv4"))
+
+
+class Packed(object):
+    """Device-resident, kernel-ready weights of one PoseNet9D (eval mode)."""
+
+    def __init__(self, sd, device, face="face_all.", with_heads=True):
+        sd = _dev_sd(sd, device)
+        self.device = device
+        self.conv = pack_encoder(sd, face + "encoder.", device)
+        self.ph = pack_ph(sd, face + "ph_pred.")
+        self.dec, self.dec_out = pack_decoder(sd, face + "decoder.")
+        self.heads = {h: pack_head(sd, h + ".") for h in ("rot_green", "rot_red", "ts")} if with_heads else {}
+
+
+def _i32(idx, device):
+    """injected graph (any int dtype, any device, (B,n,k) or (B,n,1)) -> contiguous int32 on device"""
+    return idx.to(device=device, dtype=torch.int32).contiguous()
+
+
+class Graphs(object):
+    """Neighbour lists of one forward.  Computed lists are shared between the call sites that the
+    reference recomputes identically (gcn3d.py:85/213/235 all run the same xyz kNN); a test may
+    inject the reference's own lists per call site (names as in tests/golden)."""
+
+    def __init__(self, device, inject=None, record=None, prefix="face_all.encoder."):
+        self.device, self.inject, self.record, self.prefix = device, inject or {}, record, prefix
+
+    def get(self, name, compute):
+        full = self.prefix + name
+        if full in self.inject:
+            idx = _i32(self.inject[full], self.device)
+        else:
+            idx = compute()
+        if self.record is not None:
+            self.record[full] = idx
+        return idx
+
+
+def surface_layer(c, xyz, idx_rf, idx_orl, out, scale=None, shift=None, act=None):
+    """HSlayer_surface.forward (gcn3d.py:78-89) + the caller's activation, written to `out` (B,n,C) view."""
+    B, n, _ = xyz.shape
+    C = c["C"]
+    g = ops.gconv_surface(xyz, idx_rf, c["sdn"], 7, C)
+    rb = ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
+    xyz4 = torch.zeros(B, n, 4, device=xyz.device, dtype=torch.float32)
+    xyz4[:, :, :3].copy_(xyz)
+    ste = ops.linear_rows(xyz4, c["ste"])
+    ops.linear_rows(g, c["w1"], out=out, rowbias=rb, rows_per_obj=n, res1=g, res2=ste, scale=scale, shift=shift,
+                    act=0 if act is None else 1, slope=0.0)
+    return out
+
+
+def hs_layer(c, xyz, fmap, idx_rf, idx_orl, out, scale=None, shift=None, act=None):
+    """HS_layer.forward (gcn3d.py:142-155) + the caller's BatchNorm(eval)/ReLU, written to `out`."""
+    B, n, _ = xyz.shape
+    C = c["C"]
+    proj9 = ops.linear_rows(fmap, c["wcat"], bias=c["bcat"])                    # (B,n,9C): centre|support|STE
+    g = ops.gconv_hs(xyz, idx_rf, proj9, c["sdn"], 7, C)
+    rb = ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
+    ops.linear_rows(g, c["w1"], out=out, rowbias=rb, rows_per_obj=n, res1=g, res2=proj9[:, :, 8 * C:], scale=scale,
+                    shift=shift, act=0 if act is None else 1, slope=0.0)
+    return out
+
+
+def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6):
+    """Face_Enc.forward (FaceRecon.py:39-86) -> feat buffer (B,N,FEAT_LD) and intermediates."""
+    dev = points_c.device
+    B, N, _ = points_c.shape
+    xyz = points_c
+    feat = torch.empty(B, N, FEAT_LD, device=dev, dtype=torch.float32)
+    s1, s2 = (_i32(s, dev) for s in sample_idx)
+    N1, N2 = s1.numel(), s2.numel()
+
+    knn0 = {}
+
+    def xyz_graph(level, pts, k):
+        if level not in knn0:
+            knn0[level] = ops.knn_xyz(pts, k)
+        return knn0[level]
+
+    cv = pk.conv
+    fm0 = feat[:, :, 0:128]
+    surface_layer(cv[0], xyz, graphs.get("conv_0.rf", lambda: xyz_graph(0, xyz, kmax)),
+                  graphs.get("conv_0.orl_xyz", lambda: xyz_graph(0, xyz, kmax)), fm0, act="relu")
+    fm1 = feat[:, :, 128:256]
+    hs_layer(cv[1], xyz, fm0, graphs.get("conv_1.rf", lambda: ops.knn_feat(fm0, kmax)),
+             graphs.get("conv_1.orl_xyz", lambda: xyz_graph(0, xyz, kmax)), fm1, cv[1]["scale"], cv[1]["shift"], "relu")
+    v1, fp1 = ops.pool(xyz, fm1, graphs.get("pool_1.xyz", lambda: xyz_graph(0, xyz, kmax)), s1, kpool=4)
+
+    k1 = min(kmax, N1 // 8)
+    fm2 = torch.empty(B, N1, 256, device=dev, dtype=torch.float32)
+    hs_layer(cv[2], v1, fp1, graphs.get("conv_2.rf", lambda: ops.knn_feat(fp1, k1)),
+             graphs.get("conv_2.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm2, cv[2]["scale"], cv[2]["shift"], "relu")
+    fm3 = torch.empty(B, N1, 256, device=dev, dtype=torch.float32)
+    hs_layer(cv[3], v1, fm2, graphs.get("conv_3.rf", lambda: ops.knn_feat(fm2, k1)),
+             graphs.get("conv_3.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm3, cv[3]["scale"], cv[3]["shift"], "relu")
+    v2, fp2 = ops.pool(v1, fm3, graphs.get("pool_2.xyz", lambda: xyz_graph(1, v1, k1)), s2, kpool=4)
+
+    k2 = min(kmax, N2 // 8)
+    fm4 = torch.empty(B, N2, 512, device=dev, dtype=torch.float32)
+    hs_layer(cv[4], v2, fp2, graphs.get("conv_4.rf", lambda: ops.knn_feat(fp2, k2)),
+             graphs.get("conv_4.orl_xyz", lambda: xyz_graph(2, v2, k2)), fm4)
+
+    near1 = graphs.get("up_1", lambda: ops.nn1(xyz, v1)).view(B, N)
+    near2 = graphs.get("up_2", lambda: ops.nn1(xyz, v2)).view(B, N)
+    ops.gather_rows(fm2, near1, feat[:, :, 256:512])
+    ops.gather_rows(fm3, near1, feat[:, :, 512:768])
+    ops.gather_rows(fm4, near2, feat[:, :, 768:1280])
+    ops.fill_tail(obj_id.reshape(-1).float(), xyz, feat, 1280, n_cls)
+    inter = dict(fm_2=fm2, fm_3=fm3, fm_4=fm4, v_pool_1=v1, v_pool_2=v2)
+    return feat, inter
+
+
+def ph_forward(pk, feat, N):
+    """PH_Predictor.forward (FaceRecon.py:139-167) -> h1, h2 (B,2500) and back = pi1_1 + pi2_1 (B,FEAT_LD)."""
+    B = feat.shape[0]
+    dev = feat.device
+    ph = pk.ph
+    keys = torch.zeros(B, 1024, device=dev, dtype=torch.int32)
+    ops.linear_rows(feat, ph["w5"], scale=ph["bn5c"][0], shift=ph["bn5c"][1], act=1, slope=0.2, want_out=False,
+                    colmax_keys=keys, rows_per_obj=N, k_alg=FEAT_C)
+    g = ops.colmax_decode(keys, out2=True)                                       # cat((max, max), 1)
+    fa = ops.linear_rows(g, ph["l1"], scale=ph["bn5"][0], shift=ph["bn5"][1], act=1, slope=0.2)
+    pi1 = ops.linear_rows(fa, ph["l2"][0], bias=ph["l2"][1])
+    pi2 = ops.linear_rows(fa, ph["l3"][0], bias=ph["l3"][1])
+    back = torch.zeros(B, FEAT_LD, device=dev, dtype=torch.float32)
+    b1 = ops.linear_rows(pi1, ph["l4"][0], bias=ph["l4"][1])
+    ops.linear_rows(pi2, ph["l5"][0], bias=ph["l5"][1], res1=b1, out=back[:, :FEAT_C])
+    return ops.sigmoid(pi1), ops.sigmoid(pi2), back
+
+
+def decoder_forward(pk, feat, back, N):
+    """Face_Dec.forward on feat + back (FaceRecon.py:165,112-117) -> recon (B,N,3).
+
+    conv(feat + back) = conv(feat) + W @ back: the broadcast add of the topology code becomes a
+    per-object bias of the first GEMM, so (B,1286,N) feat_ph is never materialised."""
+    B = feat.shape[0]
+    w0, b0, sc0, sh0 = pk.dec[0]
+    x = feat
+    rb = ops.linear_rows(back, w0) if back is not None else None
+    x = ops.linear_rows(x, w0, bias=b0, rowbias=rb, rows_per_obj=N, scale=sc0, shift=sh0, act=1, k_alg=FEAT_C)
+    for w, b, sc, sh in pk.dec[1:]:
+        x = ops.linear_rows(x, w, bias=b, scale=sc, shift=sh, act=1)
+    return ops.linear_rows(x, pk.dec_out[0], bias=pk.dec_out[1])
+
+
+def head_forward(hd, feat, N):
+    """Rot_green / Rot_red / Pose_Ts (PoseR.py:26-39, PoseTs.py:31-45) -> (B, 4|6)."""
+    B = feat.shape[0]
+    w, b, sc, sh = hd["c1"]
+    x = ops.linear_rows(feat, w, bias=b, scale=sc, shift=sh, act=1, k_alg=hd["k_alg"])
+    w, b, sc, sh = hd["c2"]
+    keys = torch.zeros(B, w.shape[0], device=feat.device, dtype=torch.int32)
+    ops.linear_rows(x, w, bias=b, scale=sc, shift=sh, act=1, want_out=False, colmax_keys=keys, rows_per_obj=N)
+    x = ops.colmax_decode(keys)
+    w, b, sc, sh = hd["c3"]
+    x = ops.linear_rows(x, w, bias=b, scale=sc, shift=sh, act=1)
+    return ops.linear_rows(x, hd["c4"][0], bias=hd["c4"][1])
+
+
+def draw_sample_idx(N):
+    """The two ``torch.randperm`` draws of Face_Enc.forward, from the global CPU generator in the
+    reference's order (pool_1 then pool_2; gcn3d.py:241-242)."""
+    i1 = torch.randperm(N)[: int(N / 4)]
+    i2 = torch.randperm(i1.numel())[: int(i1.numel() / 4)]
+    return i1, i2
+
+
+def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6):
+    """PoseNet9D(only_encoder=False).forward in eval mode (PoseNet9D.py:46-91)."""
+    if points.dim() != 3 or points.shape[2] != 3:
+        raise ValueError("points must be (B,N,3)")
+    B, N, _ = points.shape
+    if N // 4 // 4 // 8 < 1:
+        raise ValueError("need at least 128 points per object (k = min(20, n // 8) must be >= 1 at every level)")
+    if sample_idx is None:
+        sample_idx = draw_sample_idx(N)
+    points = points.contiguous().float()
+    xyz, mean = ops.center(points)
+    graphs = Graphs(points.device, inject, record)
+    feat, inter = encoder_forward(pk, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
+    h1, h2, back = ph_forward(pk, feat, N)
+    recon = decoder_forward(pk, feat, back, N)
+    green = head_forward(pk.heads["rot_green"], feat, N)
+    red = head_forward(pk.heads["rot_red"], feat, N)
+    ts = head_forward(pk.heads["ts"], feat, N)
+    pg, pr, fg, fr, pT, ps = ops.head_post(green, red, ts, mean)
+    out = dict()
+    if train_keys:
+        out["recon"] = ops.add_mean_(recon, mean)
+    out.update(p_green_R=pg, p_red_R=pr, f_green_R=fg, f_red_R=fr, Pred_T=pT, Pred_s=ps)
+    if train_keys:
+        out["h1"], out["h2"] = h1, h2
+        out["feat"] = feat[:, :, :FEAT_C]
+        out["feat_global"] = ops.colmax(feat[:, :, :FEAT_C])
+    return out
+
+
+def encoder_only_forward(pk, points, obj_id, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6):
+    """PoseNet9D(only_encoder=True).forward (PoseNet9D.py:35-45): encoder + decoder without the PH branch."""
+    B, N, _ = points.shape
+    if sample_idx is None:
+        sample_idx = draw_sample_idx(N)
+    xyz, mean = ops.center(points.contiguous().float())
+    graphs = Graphs(points.device, inject, record, prefix="face_enc.encoder.")
+    feat, _ = encoder_forward(pk, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
+    recon = decoder_forward(pk, feat, None, N)
+    return dict(feat_global=ops.colmax(feat[:, :, :FEAT_C]), recon=recon)

@@ -1,0 +1,130 @@
+"""Drop-in for ``network/fs_net_repo/FaceRecon.py``: encoder, topology (PH) predictor, decoder.
+
+The classes keep the reference's attribute names so that ``state_dict()`` keys match a reference
+checkpoint exactly (Face_Enc :12, Face_Dec :89, PH_Predictor :120, FaceNet :170); their forwards
+run the eval-mode HIP pipeline of ``tgpose_amd.engine``.
+"""
+import torch
+import torch.nn as nn
+
+from ... import engine, ops
+from ...config import FLAGS
+from . import gcn3d
+from .gcn3d import _Packable, _need_eval
+
+
+class _WithBuffers(_Packable):
+    def _sig(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+
+class Face_Enc(_WithBuffers):
+    def __init__(self):
+        super().__init__()
+        self.neighbor_num = FLAGS.gcn_n_num
+        self.support_num = FLAGS.gcn_sup_num
+        self.conv_0 = gcn3d.HSlayer_surface(kernel_num=128, support_num=self.support_num)
+        self.conv_1 = gcn3d.HS_layer(128, 128, support_num=self.support_num)
+        self.pool_1 = gcn3d.Pool_layer(pooling_rate=4, neighbor_num=4)
+        self.conv_2 = gcn3d.HS_layer(128, 256, support_num=self.support_num)
+        self.conv_3 = gcn3d.HS_layer(256, 256, support_num=self.support_num)
+        self.pool_2 = gcn3d.Pool_layer(pooling_rate=4, neighbor_num=4)
+        self.conv_4 = gcn3d.HS_layer(256, 512, support_num=self.support_num)
+        self.bn1 = nn.BatchNorm1d(128)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.bn3 = nn.BatchNorm1d(256)
+        # present in every reference checkpoint, never used by the forward path (enable_proj=False everywhere)
+        self.proj_layer = nn.Sequential(nn.Conv1d(1286, 1286, kernel_size=1, bias=False), nn.BatchNorm1d(1286),
+                                        nn.LeakyReLU(negative_slope=0.2), nn.Conv1d(1286, 1286, kernel_size=1, bias=False))
+
+    def forward(self, vertices, cat_id, enable_proj=False):
+        """vertices (B,N,3) already centred, cat_id (B,1) -> feat (B,N,1286), feat_global (B,1286,N)."""
+        _need_eval(self)
+        if enable_proj:
+            raise NotImplementedError("enable_proj=True is never used by the reference's train/eval path")
+        dev = vertices.device
+        conv = self._packed(lambda: engine.pack_encoder(engine._dev_sd(self.state_dict(), dev), "", dev))
+        pk = type("EncPack", (), dict(conv=conv))
+        xyz = vertices.detach().float().contiguous()
+        feat, _ = engine.encoder_forward(pk, xyz, cat_id, engine.draw_sample_idx(xyz.shape[1]),
+                                         engine.Graphs(dev), self.neighbor_num, FLAGS.obj_c)
+        feat = feat[:, :, : engine.FEAT_C]
+        return feat, feat.permute(0, 2, 1)
+
+
+class Face_Dec(_WithBuffers):
+    def __init__(self, dim_fuse):
+        super().__init__()
+        self.recon_num = 3
+        self.conv1d_block = nn.Sequential(
+            nn.Conv1d(dim_fuse, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
+            nn.Conv1d(512, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
+            nn.Conv1d(512, 256, 1), nn.BatchNorm1d(256), nn.ReLU(inplace=True))
+        self.recon_head = nn.Sequential(nn.Conv1d(256, 128, 1), nn.BatchNorm1d(128), nn.ReLU(inplace=True),
+                                        nn.Conv1d(128, self.recon_num, 1))
+
+    def forward(self, x):
+        """x (B,1286,N) -> recon (B,N,3)"""
+        _need_eval(self)
+        B, C, N = x.shape
+        dev = x.device
+        dec, dec_out = self._packed(lambda: engine.pack_decoder(engine._dev_sd(self.state_dict(), dev), ""))
+        pk = type("DecPack", (), dict(dec=dec, dec_out=dec_out))
+        rows = torch.zeros(B, N, engine.FEAT_LD, device=dev, dtype=torch.float32)
+        rows[:, :, :C].copy_(x.detach().float().transpose(1, 2))
+        return engine.decoder_forward(pk, rows, None, N)
+
+
+class PH_Predictor(_WithBuffers):
+    def __init__(self):
+        super().__init__()
+        self.output_channels = FLAGS.output_channels
+        self.conv_5 = nn.Sequential(nn.Conv1d(128 + 128 + 256 + 256 + 512 + 6, 1024, kernel_size=1, bias=False),
+                                    nn.BatchNorm1d(1024), nn.LeakyReLU(negative_slope=0.2))
+        self.linear1 = nn.Linear(1024 * 2, 1024, bias=False)
+        self.bn5 = nn.BatchNorm1d(1024)
+        self.dp1 = nn.Dropout(p=0.5)
+        self.linear2 = nn.Linear(1024, self.output_channels)
+        self.linear3 = nn.Linear(1024, self.output_channels)
+        self.linear4 = nn.Linear(self.output_channels, 1286)
+        self.linear5 = nn.Linear(self.output_channels, 1286)
+        self.ac2 = nn.Sigmoid()
+        self.ac3 = nn.Sigmoid()
+
+    def forward(self, feat):
+        """feat (B,N,1286) -> feat + back-projected topology code (B,1286,N), h1, h2 (B,2500)."""
+        _need_eval(self)
+        B, N, C = feat.shape
+        dev = feat.device
+        ph = self._packed(lambda: engine.pack_ph(engine._dev_sd(self.state_dict(), dev), ""))
+        pk = type("PhPack", (), dict(ph=ph))
+        rows = torch.zeros(B, N, engine.FEAT_LD, device=dev, dtype=torch.float32)
+        rows[:, :, :C].copy_(feat.detach().float())
+        h1, h2, back = engine.ph_forward(pk, rows, N)
+        return feat.permute(0, 2, 1) + back[:, :C].unsqueeze(-1), h1, h2
+
+
+class FaceNet(_WithBuffers):
+    def __init__(self):
+        super().__init__()
+        self.encoder = Face_Enc()
+        self.decoder = Face_Dec(1286)
+        self.ph_pred = PH_Predictor()
+
+    def forward(self, vertices, cat_id, enable_proj=False, pred_PH=True):
+        """-> recon (B,N,3), feat (B,N,1286), feat_global (B,1286,N), h1, h2   (FaceRecon.py:178-200)"""
+        _need_eval(self)
+        if enable_proj:
+            raise NotImplementedError("enable_proj=True is never used by the reference's train/eval path")
+        dev = vertices.device
+        pk = self._packed(lambda: engine.Packed(self.state_dict(), dev, face="", with_heads=False))
+        xyz = vertices.detach().float().contiguous()
+        N = xyz.shape[1]
+        feat, _ = engine.encoder_forward(pk, xyz, cat_id, engine.draw_sample_idx(N), engine.Graphs(dev),
+                                         self.encoder.neighbor_num, FLAGS.obj_c)
+        h1 = h2 = back = None
+        if pred_PH:
+            h1, h2, back = engine.ph_forward(pk, feat, N)
+        recon = engine.decoder_forward(pk, feat, back, N)
+        f = feat[:, :, : engine.FEAT_C]
+        return recon, f, f.permute(0, 2, 1), h1, h2

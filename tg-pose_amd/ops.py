@@ -1,0 +1,299 @@
+"""Tensor-level wrappers over the C ABI: pointer/stride plumbing only, no compute.
+
+Every function enqueues HIP kernels on torch's current stream of the tensors' device and returns
+device tensors; nothing synchronises.  Inputs must be fp32 (indices int32), on a GPU, with the
+layouts documented in include/tgpose.h -- violations raise instead of being silently copied.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import GemmArgs, check
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _f32(t, name, dims=None):
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32):
+        raise TypeError("%s must be a float32 GPU tensor" % name)
+    if dims is not None and t.dim() != dims:
+        raise ValueError("%s must have %d dims" % (name, dims))
+    return t
+
+
+def _rows(t, name):
+    """(…, C) tensor whose rows are contiguous; returns (tensor, row stride in elements)."""
+    _f32(t, name)
+    if t.stride(-1) != 1:
+        raise ValueError("%s: last dim must be contiguous" % name)
+    ld = t.stride(-2)
+    if t.dim() == 3 and t.stride(0) != t.shape[1] * ld:
+        raise ValueError("%s: batch stride must equal n * row stride" % name)
+    return t, ld
+
+
+def _i32(t, name):
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+        raise TypeError("%s must be a contiguous int32 GPU tensor" % name)
+    return t
+
+
+def center(points):
+    """points (B,n,3) -> (xyz_c (B,n,3), mean (B,3))"""
+    _f32(points, "points", 3)
+    points = points.contiguous()
+    B, n, _ = points.shape
+    xyz = torch.empty_like(points)
+    mean = torch.empty(B, 3, device=points.device, dtype=torch.float32)
+    check(_lib.lib().tgp_center(_p(points), B, n, _p(xyz), _p(mean), _stream(points)), "tgp_center")
+    return xyz, mean
+
+
+def knn_xyz(xyz, k):
+    """xyz (B,n,3) contiguous -> idx (B,n,k) int32"""
+    _f32(xyz, "xyz", 3)
+    if not xyz.is_contiguous() or xyz.shape[2] != 3:
+        raise ValueError("xyz must be contiguous (B,n,3)")
+    B, n, _ = xyz.shape
+    idx = torch.empty(B, n, k, device=xyz.device, dtype=torch.int32)
+    check(_lib.lib().tgp_knn_xyz(_p(xyz), B, n, int(k), _p(idx), _stream(xyz)), "tgp_knn_xyz")
+    return idx
+
+
+def knn_feat(feat, k, workspace=None):
+    """feat (B,n,d) rows contiguous (row stride may exceed d) -> idx (B,n,k) int32"""
+    feat, ld = _rows(feat, "feat")
+    B, n, d = feat.shape
+    need = _lib.lib().tgp_knn_feat_workspace_bytes(B, n, d)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty((need + 3) // 4, device=feat.device, dtype=torch.float32)
+    idx = torch.empty(B, n, k, device=feat.device, dtype=torch.int32)
+    check(_lib.lib().tgp_knn_feat(_p(feat), ld, B, n, d, int(k), _p(idx), _p(workspace),
+                                  workspace.numel() * workspace.element_size(), _stream(feat)), "tgp_knn_feat")
+    return idx
+
+
+def nn1(target, source):
+    """(B,n,3),(B,m,3) -> idx (B,n) int32"""
+    _f32(target, "target", 3), _f32(source, "source", 3)
+    target, source = target.contiguous(), source.contiguous()
+    B, n, _ = target.shape
+    m = source.shape[1]
+    idx = torch.empty(B, n, device=target.device, dtype=torch.int32)
+    check(_lib.lib().tgp_nn1(_p(target), _p(source), B, n, m, _p(idx), _stream(target)), "tgp_nn1")
+    return idx
+
+
+def normalize_dirs(directions):
+    _f32(directions, "directions", 2)
+    directions = directions.contiguous()
+    out = torch.empty_like(directions)
+    check(_lib.lib().tgp_normalize_dirs(_p(directions), directions.shape[1], _p(out), _stream(directions)),
+          "tgp_normalize_dirs")
+    return out
+
+
+def gconv_surface(xyz, idx, sdn, S, C, out=None):
+    _f32(xyz, "xyz", 3), _i32(idx, "idx")
+    B, n, k = idx.shape
+    if out is None:
+        out = torch.empty(B, n, C, device=xyz.device, dtype=torch.float32)
+    out, ldo = _rows(out, "out")
+    check(_lib.lib().tgp_gconv_surface_fwd(_p(xyz), _p(idx), _p(sdn), B, n, k, S, C, _p(out), ldo, _stream(xyz)),
+          "tgp_gconv_surface_fwd")
+    return out
+
+
+def gconv_hs(xyz, idx, proj, sdn, S, C, out=None):
+    _f32(xyz, "xyz", 3), _i32(idx, "idx")
+    proj, ldp = _rows(proj, "proj")
+    B, n, k = idx.shape
+    if out is None:
+        out = torch.empty(B, n, C, device=xyz.device, dtype=torch.float32)
+    out, ldo = _rows(out, "out")
+    check(_lib.lib().tgp_gconv_hs_fwd(_p(xyz), _p(idx), _p(proj), ldp, _p(sdn), B, n, k, S, C, _p(out), ldo,
+                                      _stream(xyz)), "tgp_gconv_hs_fwd")
+    return out
+
+
+def orl_global(feat, idx):
+    """feat (B,n,C), idx (B,n,k) -> (B,C)"""
+    feat, ldf = _rows(feat, "feat")
+    _i32(idx, "idx")
+    B, n, C = feat.shape
+    k = idx.shape[2]
+    partial = torch.empty(_lib.lib().tgp_orl_partial_floats(B, n, C), device=feat.device, dtype=torch.float32)
+    out = torch.empty(B, C, device=feat.device, dtype=torch.float32)
+    check(_lib.lib().tgp_orl_global(_p(feat), ldf, _p(idx), B, n, k, C, _p(partial), _p(out), _stream(feat)),
+          "tgp_orl_global")
+    return out
+
+
+def pool(xyz, feat, idx, sample, kpool=4, out_f=None):
+    """xyz (B,n,3), feat (B,n,C), idx (B,n,>=kpool) int32, sample (n_out,) int32 -> (xyz_p, feat_p)"""
+    _f32(xyz, "xyz", 3)
+    feat, ldf = _rows(feat, "feat")
+    _i32(idx, "idx"), _i32(sample, "sample")
+    B, n, C = feat.shape
+    n_out = sample.numel()
+    out_xyz = torch.empty(B, n_out, 3, device=xyz.device, dtype=torch.float32)
+    if out_f is None:
+        out_f = torch.empty(B, n_out, C, device=xyz.device, dtype=torch.float32)
+    out_f, ldo = _rows(out_f, "out_f")
+    check(_lib.lib().tgp_pool_fwd(_p(xyz), _p(feat), ldf, _p(idx), idx.shape[2], _p(sample), B, n, n_out, kpool, C,
+                                  _p(out_xyz), _p(out_f), ldo, _stream(xyz)), "tgp_pool_fwd")
+    return out_xyz, out_f
+
+
+def gather_rows(src, idx, dst):
+    """dst[b,i,:C] = src[b, idx[b,i], :C]; src (B,n_src,C), idx (B,n_out) int32, dst (B,n_out,C) view"""
+    src, lds = _rows(src, "src")
+    dst, ldd = _rows(dst, "dst")
+    _i32(idx, "idx")
+    B, n_src, C = src.shape
+    n_out = idx.shape[1]
+    check(_lib.lib().tgp_gather_rows(_p(src), lds, _p(idx), B, n_src, n_out, C, _p(dst), ldd, _stream(src)),
+          "tgp_gather_rows")
+    return dst
+
+
+def fill_tail(obj_id, xyz_c, feat, col0, n_cls):
+    _f32(obj_id, "obj_id"), _f32(xyz_c, "xyz_c", 3)
+    feat, ld = _rows(feat, "feat")
+    B, n, _ = xyz_c.shape
+    check(_lib.lib().tgp_fill_tail(_p(obj_id.contiguous()), _p(xyz_c), B, n, n_cls, _p(feat), ld, col0, _stream(feat)),
+          "tgp_fill_tail")
+
+
+# bench.py sets this to a list to time, with HIP events on the launch stream, every launch that the
+# library routes to its 128x128-tile MFMA kernel (same rule as tgp_gemm_f32 in csrc/gemm.hip).
+GEMM_TIMER = None
+
+
+def _routes_to_big_tile(M, N):
+    return M > 32 and ((M + 127) // 128) * ((N + 127) // 128) >= 1024
+
+
+def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, bias=None, rowbias=None,
+         rows_per_obj=0, res1=None, ldr1=0, res2=None, ldr2=0, scale=None, shift=None, act=0, slope=0.0,
+         colmax_keys=None, k_alg=None):
+    """Raw call into tgp_gemm_f32.  A/W/C/res* are tensors whose data_ptr is the first element of the
+    operand (views into wider buffers are fine); all sizes/strides are explicit.  k_alg: the layer's
+    true input width when K includes zero padding (only used for FLOP accounting in bench.py)."""
+    timed = GEMM_TIMER is not None and _routes_to_big_tile(M, N)
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(A.device))
+    a = GemmArgs()
+    a.A, a.lda, a.W, a.ldw = _p(A), lda, _p(W), ldw
+    a.C, a.ldc = (_p(C), ldc) if C is not None else (None, 0)
+    a.M, a.N, a.K = M, N, K
+    a.bias = _p(bias)
+    a.rowbias, a.ldrb = (_p(rowbias), rowbias.stride(0)) if rowbias is not None else (None, 0)
+    a.rows_per_obj = rows_per_obj
+    a.res1, a.ldr1 = _p(res1), ldr1
+    a.res2, a.ldr2 = _p(res2), ldr2
+    a.scale, a.shift = _p(scale), _p(shift)
+    a.act, a.slope = act, slope
+    a.colmax_keys, a.ldcm = (_p(colmax_keys), colmax_keys.stride(0)) if colmax_keys is not None else (None, 0)
+    check(_lib.lib().tgp_gemm_f32(ctypes.byref(a), _stream(A)), "tgp_gemm_f32")
+    if timed:
+        e1.record(torch.cuda.current_stream(A.device))
+        GEMM_TIMER.append((e0, e1, 2.0 * M * N * (k_alg or K)))
+    return C
+
+
+def linear_rows(x, weight, bias=None, scale=None, shift=None, act=0, slope=0.0, out=None, rowbias=None,
+                rows_per_obj=0, res1=None, res2=None, colmax_keys=None, want_out=True, k_alg=None):
+    """x (..., K) rows (row stride >= K), weight (N, Kw>=K) -> (..., N).  Convenience over gemm()."""
+    x, lda = _rows(x, "x")
+    weight, ldw = _rows(weight, "weight")
+    K = x.shape[-1]
+    M = math.prod(x.shape[:-1])
+    N = weight.shape[0]
+    ldc = 0
+    if want_out:
+        if out is None:
+            out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+        out, ldc = _rows(out, "out")
+    r1 = r2 = None
+    l1 = l2 = 0
+    if res1 is not None:
+        r1, l1 = _rows(res1, "res1")
+    if res2 is not None:
+        r2, l2 = _rows(res2, "res2")
+    gemm(x, weight, out if want_out else None, M=M, N=N, K=K, lda=lda, ldw=ldw, ldc=ldc, bias=bias, rowbias=rowbias,
+         rows_per_obj=rows_per_obj, res1=r1, ldr1=l1, res2=r2, ldr2=l2, scale=scale, shift=shift, act=act, slope=slope,
+         colmax_keys=colmax_keys, k_alg=k_alg)
+    return out
+
+
+def colmax_decode(keys, out2=False):
+    rows, N = keys.shape
+    out = torch.empty(rows, 2 * N if out2 else N, device=keys.device, dtype=torch.float32)
+    second = out[:, N:] if out2 else None
+    check(_lib.lib().tgp_colmax_decode(_p(keys), keys.stride(0), rows, N, _p(out), out.stride(0), _p(second),
+                                       _stream(keys)), "tgp_colmax_decode")
+    return out
+
+
+def colmax(x):
+    """x (B,n,C) rows -> (B,C) max over n"""
+    x, ld = _rows(x, "x")
+    B, n, C = x.shape
+    out = torch.empty(B, C, device=x.device, dtype=torch.float32)
+    check(_lib.lib().tgp_colmax(_p(x), ld, B, n, C, _p(out), _stream(x)), "tgp_colmax")
+    return out
+
+
+def sigmoid(x):
+    _f32(x, "x")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(_lib.lib().tgp_sigmoid(_p(x), _p(y), x.numel(), _stream(x)), "tgp_sigmoid")
+    return y
+
+
+def head_post(green, red, ts, mean):
+    B = green.shape[0]
+    dev = green.device
+    pg, pr = torch.empty(B, 3, device=dev), torch.empty(B, 3, device=dev)
+    fg, fr = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    pT, ps = torch.empty(B, 3, device=dev), torch.empty(B, 3, device=dev)
+    check(_lib.lib().tgp_head_post(_p(green), _p(red), _p(ts), _p(mean), B, _p(pg), _p(pr), _p(fg), _p(fr), _p(pT),
+                                   _p(ps), _stream(green)), "tgp_head_post")
+    return pg, pr, fg, fr, pT, ps
+
+
+def add_mean_(recon, mean):
+    B, n, _ = recon.shape
+    check(_lib.lib().tgp_add_mean(_p(recon), _p(mean), B, n, _stream(recon)), "tgp_add_mean")
+    return recon
+
+
+def chamfer_fwd(xyz1, xyz2, dist1, dist2, idx1, idx2):
+    """chamfer_3D.forward convention: caller allocates every output (dist_chamfer_3D.py:33-45)."""
+    _f32(xyz1, "xyz1", 3), _f32(xyz2, "xyz2", 3)
+    if not (xyz1.is_contiguous() and xyz2.is_contiguous()):
+        raise ValueError("chamfer inputs must be contiguous (dist_chamfer_3D.py:72-73)")
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    check(_lib.lib().tgp_chamfer_fwd(_p(xyz1), _p(xyz2), B, n, m, _p(dist1), _p(dist2), _p(_i32(idx1, "idx1")),
+                                     _p(_i32(idx2, "idx2")), _stream(xyz1)), "tgp_chamfer_fwd")
+    return 1
+
+
+def chamfer_bwd(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2):
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    check(_lib.lib().tgp_chamfer_bwd(_p(xyz1), _p(xyz2), B, n, m, _p(graddist1), _p(graddist2), _p(idx1), _p(idx2),
+                                     _p(gradxyz1), _p(gradxyz2), _stream(xyz1)), "tgp_chamfer_bwd")
+    return 1
