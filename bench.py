@@ -13,7 +13,7 @@ data-path collective (weak scaling); the only RCCL traffic is the barrier / max-
 around the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      the dominant kernel (gemm_f32_kernel<128,128>: fp32 MFMA, the per-point MLPs that
+  roofline      the dominant kernel (gemm_main_kernel: fp32 MFMA, the per-point MLPs that
                 hold 95 % of the FLOPs), timed live with HIP events on the launch stream around every
                 one of its launches in the timed steps: achieved = algorithmic FLOPs / time.
   cpu_baseline  the CPU oracle (the build's restatement of the reference's torch op sequence,
@@ -150,7 +150,7 @@ def main():
                        "objects_per_gpu": B, "points": N_POINTS, "replicas": world},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                         "kernel": "gemm_f32_kernel<128,128,false,false>",
+                         "kernel": "gemm_main_kernel",
                          "launches_timed": launches, "avg_launch_us": round(1e6 * ksec / max(launches, 1), 2),
                          "share_of_step": round(ksec / elapsed, 4)},
         }

@@ -121,8 +121,18 @@ typedef struct tgp_gemm_args {
     const float *shift;                /* [N] beta - mean * scale */
     int act;                           /* 0 none, 1 leaky-relu with `slope` (0 -> ReLU) */
     float slope;
-    uint32_t *colmax_keys; int ldcm;   /* [(M / rows_per_obj), N] order-preserving keys, zero-filled by the
+    uint32_t *colmax_keys; int ldcm;   /* [(M / rows_per_obj), cm_cols] order-preserving keys, zero-filled by the
                                           caller; decoded by tgp_colmax_decode (torch.max(x, 2), PoseR.py:30) */
+    /* Column ranges let ONE launch serve several layers that read the same rows (conv_5 and the three
+     * head conv1 layers all read `feat`): per-column slope, colmax only for the first cm_cols columns,
+     * C stored only for columns >= c_col0 (at C[m * ldc + n - c_col0]). */
+    const float *slope_vec;            /* [N] per-column leaky slope, overrides `slope`; may be NULL */
+    int cm_cols;                       /* 0 = all N columns */
+    int c_col0;
+    /* batch > 1: `batch` independent problems of the same shape in one launch; operand b starts at
+     * A + b*batch_stride_a etc. (element strides; vec = bias/scale/shift/slope_vec). */
+    int batch;
+    int64_t batch_stride_a, batch_stride_w, batch_stride_c, batch_stride_vec, batch_stride_colmax;
 } tgp_gemm_args;
 
 /* nn.Conv1d(kernel 1) / nn.Linear on channel-last rows with the fused epilogue above. */

@@ -35,7 +35,7 @@ def g(t):
 
 
 # ----------------------------------------------------------------------------------------- geometry
-@pytest.mark.parametrize("B,n", [(3, 1028), (2, 1024), (4, 257), (1, 64), (5, 100)])
+@pytest.mark.parametrize("B,n", [(3, 1028), (2, 1024), (4, 257), (1, 64), (5, 100), (2, 2047), (1, 9000), (33, 1028)])
 def test_center_bit_exact(ops, B, n):
     pts, _ = synth_points(B, n, seed=n)
     xyz, mean = ops.center(g(pts))
@@ -239,7 +239,7 @@ def _gemm_ref(A, W, bias=None, rowbias=None, rpo=1, res1=None, res2=None, scale=
     return v
 
 
-@pytest.mark.parametrize("M,N,K", [(8300, 2048, 1292), (1028 * 3, 1024, 1292), (4100, 4096, 64), (257 * 2, 2304, 128), (700, 200, 36),
+@pytest.mark.parametrize("M,N,K", [(8300, 2048, 1292), (32896, 1024, 256), (1028 * 3, 1024, 1292), (4100, 4096, 64), (257 * 2, 2304, 128), (700, 200, 36),
                                    (130, 3, 128), (64, 64, 32), (33, 70, 2500), (5000, 256, 1024)])
 def test_gemm_full_epilogue_vs_fp64(ops, M, N, K):
     gen = torch.Generator().manual_seed(M + N + K)
@@ -260,6 +260,40 @@ def test_gemm_full_epilogue_vs_fp64(ops, M, N, K):
     # the fused max-over-points equals the max of the values the kernel itself wrote
     pad = torch.full((nobj * rpo - M, N), -float("inf"))
     assert torch.equal(cm, torch.cat([out.cpu(), pad]).view(nobj, rpo, N).max(dim=1)[0])
+
+
+def test_gemm_fused_column_ranges_and_batch(ops):
+    """One launch serving several layers (conv_5 + three head conv1): per-column slope, colmax on the first
+    columns only, C stored from c_col0 on; and the batched form used for the three head conv2 layers."""
+    gen = torch.Generator().manual_seed(3)
+    M, K, N, rpo = 1028 * 2 + 300, 1292, 1536, 1028
+    nobj = (M + rpo - 1) // rpo
+    A, W = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen) / K ** 0.5
+    bias, scale, shift = torch.randn(N, generator=gen), torch.rand(N, generator=gen) + 0.5, torch.randn(N, generator=gen)
+    slope = torch.cat([torch.full((512,), 0.2), torch.zeros(N - 512)])
+    v = (A.double() @ W.double().t() + bias.double()) * scale.double() + shift.double()
+    want = torch.where(v > 0, v, v * slope.double())
+    keys = torch.zeros(nobj, 512, dtype=torch.int32, device=DEV)
+    C = torch.full((M, N - 512 + 4), -3.0, device=DEV)
+    ops.gemm(g(A), g(W), C, M=M, N=N, K=K, lda=K, ldw=K, ldc=C.shape[1], bias=g(bias), scale=g(scale), shift=g(shift),
+             act=1, slope_vec=g(slope), colmax_keys=keys, cm_cols=512, c_col0=512, rows_per_obj=rpo)
+    assert (C[:, : N - 512].cpu().double() - want[:, 512:]).abs().max().item() < 3e-5
+    assert (C[:, N - 512:] == -3.0).all()
+    pad = torch.full((nobj * rpo - M, 512), -float("inf"), dtype=torch.float64)
+    cm_want = torch.cat([want[:, :512], pad]).view(nobj, rpo, 512).max(dim=1)[0]
+    assert (ops.colmax_decode(keys).cpu().double() - cm_want).abs().max().item() < 3e-5
+    # batched: 3 problems reading column blocks of one activation buffer
+    Hb = torch.randn(M, 3 * 256, generator=gen)
+    W2 = torch.randn(3, 64, 256, generator=gen) / 16
+    b2, s2, t2 = torch.randn(3, 64, generator=gen), torch.rand(3, 64, generator=gen) + 0.5, torch.randn(3, 64, generator=gen)
+    keys2 = torch.zeros(3, nobj, 64, dtype=torch.int32, device=DEV)
+    ops.gemm(g(Hb), g(W2), None, M=M, N=64, K=256, lda=768, ldw=256, ldc=0, bias=g(b2), scale=g(s2), shift=g(t2), act=1,
+             slope=0.0, colmax_keys=keys2, rows_per_obj=rpo, batch=3, batch_strides=(256, 64 * 256, 0, 64, nobj * 64))
+    got = ops.colmax_decode(keys2.view(3 * nobj, 64)).view(3, nobj, 64).cpu().double()
+    for z in range(3):
+        vz = torch.relu((Hb[:, z * 256:(z + 1) * 256].double() @ W2[z].double().t() + b2[z].double()) * s2[z].double() + t2[z].double())
+        wz = torch.cat([vz, torch.full((nobj * rpo - M, 64), -float("inf"), dtype=torch.float64)]).view(nobj, rpo, 64).max(dim=1)[0]
+        assert (got[z] - wz).abs().max().item() < 3e-5
 
 
 @pytest.mark.parametrize("M,N,K", [(32, 2500, 1024), (32, 1024, 2048), (6, 1286, 2500), (1, 4, 256), (17, 259, 256)])

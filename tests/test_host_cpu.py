@@ -45,15 +45,17 @@ def test_gemm_args_struct_matches_header_layout():
     import subprocess
     import tempfile
     from tgpose_amd import _lib
-    src = '#include <stdio.h>\n#include <stddef.h>\n#include "tgpose.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",' \
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "tgpose.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",' \
           'sizeof(tgp_gemm_args),offsetof(tgp_gemm_args,M),offsetof(tgp_gemm_args,rowbias),' \
-          'offsetof(tgp_gemm_args,slope),offsetof(tgp_gemm_args,ldcm));return 0;}\n'
+          'offsetof(tgp_gemm_args,slope),offsetof(tgp_gemm_args,ldcm),offsetof(tgp_gemm_args,c_col0),' \
+          'offsetof(tgp_gemm_args,batch_stride_colmax));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
     G = _lib.GemmArgs
-    assert [int(x) for x in out] == [ctypes.sizeof(G), G.M.offset, G.rowbias.offset, G.slope.offset, G.ldcm.offset]
+    assert [int(x) for x in out] == [ctypes.sizeof(G), G.M.offset, G.rowbias.offset, G.slope.offset, G.ldcm.offset,
+                                     G.c_col0.offset, G.batch_stride_colmax.offset]
 
 
 def test_state_dict_contract_matches_reference_checkpoint_names():

@@ -29,6 +29,11 @@ class GemmArgs(ctypes.Structure):
         ("act", c_int),
         ("slope", c_f32),
         ("colmax_keys", c_vp), ("ldcm", c_int),
+        ("slope_vec", c_vp),
+        ("cm_cols", c_int), ("c_col0", c_int),
+        ("batch", c_int),
+        ("batch_stride_a", c_i64), ("batch_stride_w", c_i64), ("batch_stride_c", c_i64),
+        ("batch_stride_vec", c_i64), ("batch_stride_colmax", c_i64),
     ]
 
 

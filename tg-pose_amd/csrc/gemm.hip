@@ -33,52 +33,61 @@ struct GemmParams {
     int ldr2;
     const float *scale;
     const float *shift;
+    const float *slope_vec;
     int act;
     float slope;
     uint32_t *cm;
     int ldcm;
-    int64_t sA, sW, sC; // per-batch (blockIdx.z) element strides
-    const float *qrow;  // DIST epilogue
+    int cm_cols;     // colmax covers columns [0, cm_cols)
+    int c_col0;      // C is stored for columns >= c_col0, at C[row * ldc + col - c_col0]
+    int batch;
+    int64_t sA, sW, sC, sV, sCM; // per-batch element strides (A, W, C, per-column vectors, colmax keys)
+    const float *qrow;           // DIST epilogue
     const float *qcol;
     int64_t sq;
+    // tile schedule of the main kernel: per batch, M-tile rows [0, mt_big) use 128x128 tiles, the rest 64x64
+    int mt_big, tiles_n_big, tiles_big, tiles_m_small, tiles_n_small;
 };
 
 #define GEMM_BK 32
 #define GEMM_LD 36
 
+// One BM x BN output tile at (m0, n0) of batch z.  256 threads.
 template <int BM, int BN, bool NATURAL_K, bool DIST>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p)
+__device__ __forceinline__ void gemm_tile(const GemmParams &p, const int m0, const int n0, const int z, float *smem)
 {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int PA = BM / 32, PW = BN / 32;
     constexpr int BUF = (BM + BN) * GEMM_LD;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const float *A = p.A + (int64_t)blockIdx.z * p.sA;
-    const float *W = p.W + (int64_t)blockIdx.z * p.sW;
+    const float *A = p.A + (int64_t)z * p.sA;
+    const float *W = p.W + (int64_t)z * p.sW;
 
     const int kq = tid & 7, r0 = tid >> 3;
     float4 ra[PA], rw[PW];
 
+    // Guards without branches: every lane loads from a clamped (always valid) address, then selects.
     auto load_tile = [&](int kt) {
         const int kcol = kt * GEMM_BK + kq * 4;
         const bool kok = kcol < p.K;
+        const int kc = kok ? kcol : 0;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int row = m0 + r0 + 32 * i;
-            ra[i] = (kok && row < p.M) ? *reinterpret_cast<const float4 *>(A + (int64_t)row * p.lda + kcol)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = kok && row < p.M;
+            const float4 v = *reinterpret_cast<const float4 *>(A + (int64_t)(row < p.M ? row : p.M - 1) * p.lda + kc);
+            ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             const int row = n0 + r0 + 32 * i;
-            rw[i] = (kok && row < p.N) ? *reinterpret_cast<const float4 *>(W + (int64_t)row * p.ldw + kcol)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = kok && row < p.N;
+            const float4 v = *reinterpret_cast<const float4 *>(W + (int64_t)(row < p.N ? row : p.N - 1) * p.ldw + kc);
+            rw[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto store_tile = [&](int buf) {
@@ -153,9 +162,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p)
         const int col = n0 + wn * (BN / 2) + j * 32 + r;
         const bool colok = col < p.N;
         if constexpr (DIST) {
-            const float *qrow = p.qrow + (int64_t)blockIdx.z * p.sq;
-            const float *qcol = p.qcol + (int64_t)blockIdx.z * p.sq;
-            float *C = p.C + (int64_t)blockIdx.z * p.sC;
+            const float *qrow = p.qrow + (int64_t)z * p.sq;
+            const float *qcol = p.qcol + (int64_t)z * p.sq;
+            float *C = p.C + (int64_t)z * p.sC;
             const float qc = colok ? qcol[col] : 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -169,9 +178,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p)
                     }
                 }
         } else {
-            const float bias = (colok && p.bias) ? p.bias[col] : 0.f;
-            const float sc = (colok && p.scale) ? p.scale[col] : 1.f;
-            const float sh = (colok && p.shift) ? p.shift[col] : 0.f;
+            const int64_t vo = (int64_t)z * p.sV;
+            const float bias = (colok && p.bias) ? p.bias[vo + col] : 0.f;
+            const float sc = (colok && p.scale) ? p.scale[vo + col] : 1.f;
+            const float sh = (colok && p.shift) ? p.shift[vo + col] : 0.f;
+            const float slope = (colok && p.slope_vec) ? p.slope_vec[vo + col] : p.slope;
+            float *C = (p.C && col >= p.c_col0) ? p.C + (int64_t)z * p.sC + (col - p.c_col0) : nullptr;
+            uint32_t *cm = (p.cm && col < p.cm_cols) ? p.cm + (int64_t)z * p.sCM + col : nullptr;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int rbase = m0 + wm * (BM / 2) + i * 32 + 4 * h;
@@ -195,12 +208,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p)
                     if (p.res1) v += p.res1[(int64_t)row * p.ldr1 + col];
                     if (p.res2) v += p.res2[(int64_t)row * p.ldr2 + col];
                     if (p.scale) v = v * sc + sh;
-                    if (p.act == 1) v = v > 0.f ? v : v * p.slope;
-                    if (p.C) p.C[(int64_t)row * p.ldc + col] = v;
-                    if (p.cm) {
+                    if (p.act == 1) v = v > 0.f ? v : v * slope;
+                    if (C) C[(int64_t)row * p.ldc] = v;
+                    if (cm) {
                         const uint32_t key = tgp_float_key(v);
                         if (obj != run_obj) {
-                            if (run_obj >= 0) atomicMax(p.cm + (int64_t)run_obj * p.ldcm + col, run_key);
+                            if (run_obj >= 0) atomicMax(cm + (int64_t)run_obj * p.ldcm, run_key);
                             run_obj = obj;
                             run_key = key;
                         } else {
@@ -208,27 +221,59 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p)
                         }
                     }
                 }
-                if (p.cm && run_obj >= 0) atomicMax(p.cm + (int64_t)run_obj * p.ldcm + col, run_key);
+                if (cm && run_obj >= 0) atomicMax(cm + (int64_t)run_obj * p.ldcm, run_key);
             }
         }
     }
 }
 
+// Main kernel: blocks [0, tiles_big) take 128x128 tiles (N fastest, then M, then batch); the remaining
+// blocks cover the leftover M rows with 64x64 tiles.  M = B*1028 is 257 tiles of 128 (257 is prime), so a
+// plain grid leaves e.g. 2056 tiles for 512 resident workgroups = 4.02 rounds -> 5; giving the last
+// M-tile rows to quarter-size tiles, dispatched last, fills the tail round instead (4.25).
+__global__ __launch_bounds__(256) void gemm_main_kernel(GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int L = blockIdx.x;
+    if (L < p.tiles_big) {
+        const int per_batch = p.mt_big * p.tiles_n_big;
+        const int z = L / per_batch;
+        L -= z * per_batch;
+        gemm_tile<128, 128, false, false>(p, (L / p.tiles_n_big) * 128, (L % p.tiles_n_big) * 128, z, smem);
+    } else {
+        L -= p.tiles_big;
+        const int per_batch = p.tiles_m_small * p.tiles_n_small;
+        const int z = L / per_batch;
+        L -= z * per_batch;
+        gemm_tile<64, 64, false, false>(p, p.mt_big * 128 + (L / p.tiles_n_small) * 64, (L % p.tiles_n_small) * 64, z, smem);
+    }
+}
+
+template <bool NAT, bool DIST>
+__global__ __launch_bounds__(256) void gemm_small_kernel(GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_tile<64, 64, NAT, DIST>(p, blockIdx.y * 64, blockIdx.x * 64, blockIdx.z, smem);
+}
+
 // ---------------------------------------------------------------------------------------------------
-// M <= 32: one wave per 4 output columns, lanes stride over K in float4 steps.
+// M <= 32 rows (per-object vectors): weight streaming.  A workgroup owns 4 output columns; its 4 waves
+// split K (wave w takes k = 1024*i + 256*w + 4*lane), so N waves are in flight for N columns and every
+// W element is read exactly once with 16-byte lane loads.  Per wave a 6-step butterfly sums the lanes,
+// then the 4 waves are combined through LDS in fixed order (deterministic).
 #define SKINNY_COLS 4
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(GemmParams p)
 {
+    __shared__ float red[4][SKINNY_COLS][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nb = (blockIdx.x * 4 + wave) * SKINNY_COLS;
-    if (nb >= p.N) return;
+    const int nb = blockIdx.x * SKINNY_COLS;
     float acc[SKINNY_COLS][32];
 #pragma unroll
     for (int c = 0; c < SKINNY_COLS; ++c)
 #pragma unroll
         for (int m = 0; m < 32; ++m) acc[c][m] = 0.f;
 
-    for (int k0 = lane * 4; k0 < p.K; k0 += 256) {
+    for (int k0 = wave * 256 + lane * 4; k0 < p.K; k0 += 1024) {
         float4 w[SKINNY_COLS];
 #pragma unroll
         for (int c = 0; c < SKINNY_COLS; ++c)
@@ -260,29 +305,86 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(GemmParams p)
             for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
             if (lane == m) mine = s;
         }
+        if (lane < 32) red[wave][c][lane] = mine;
+    }
+    __syncthreads();
+    // 128 threads finish: thread -> (column c, row m)
+    if (threadIdx.x < SKINNY_COLS * 32) {
+        const int c = threadIdx.x >> 5, m = threadIdx.x & 31;
         const int col = nb + c;
-        if (lane < p.M && col < p.N) {
-            float v = mine + (p.bias ? p.bias[col] : 0.f);
+        if (m < p.M && col < p.N) {
+            float v = ((red[0][c][m] + red[1][c][m]) + red[2][c][m]) + red[3][c][m];
+            v += (p.bias ? p.bias[col] : 0.f);
             if (p.scale) v = v * p.scale[col] + (p.shift ? p.shift[col] : 0.f);
             if (p.act == 1) v = v > 0.f ? v : v * p.slope;
-            p.C[(int64_t)lane * p.ldc + col] = v;
+            p.C[(int64_t)m * p.ldc + col] = v;
         }
     }
 }
 
-template <int BM, int BN, bool NAT, bool DIST>
-static int launch_tiled(const GemmParams &p, int batch, hipStream_t stream)
+static int set_lds_limit(const void *fn, size_t lds)
 {
-    const dim3 grid(tgp_cdiv(p.N, BN), tgp_cdiv(p.M, BM), batch), block(256);
-    const size_t lds = (size_t)2 * (BM + BN) * GEMM_LD * sizeof(float);
+    if (lds <= 64 * 1024) return 0; // > 64 KiB of dynamic LDS needs the opt-in
+    return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+static int resident_slots(void)
+{
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        slots = 2 * cus; // two 73.7 KB workgroups per CU
+    }
+    return slots;
+}
+
+template <bool NAT, bool DIST>
+static int launch_small(const GemmParams &p, hipStream_t stream)
+{
+    const size_t lds = (size_t)2 * (64 + 64) * GEMM_LD * sizeof(float);
+    hipLaunchKernelGGL((gemm_small_kernel<NAT, DIST>), dim3(tgp_cdiv(p.N, 64), tgp_cdiv(p.M, 64), p.batch), dim3(256), lds,
+                       stream, p);
+    return TGP_LAUNCH_RESULT();
+}
+
+// Split the M-tile rows between 128x128 tiles and a tail of 64x64 tiles so that the tail round is filled.
+static int launch_main(GemmParams &p, hipStream_t stream)
+{
+    const int S = resident_slots();
+    const int tiles_m = tgp_cdiv(p.M, 128), tiles_n = tgp_cdiv(p.N, 128);
+    const int64_t T = (int64_t)tiles_m * tiles_n * p.batch;
+    const double small_cost = 0.3; // a 64x64 tile in units of a 128x128 tile (measured ~0.27-0.3)
+    // candidate (a): every row on big tiles
+    int best_mt = tiles_m;
+    double best = (double)((T + S - 1) / S);
+    // candidate (b): big tiles for whole M-tile rows up to the last full round, small tiles for the rest
+    const int64_t cap = (T / S) * S;
+    const int mt_b = (int)(cap / ((int64_t)tiles_n * p.batch));
+    if (mt_b < tiles_m) {
+        const int64_t tb = (int64_t)mt_b * tiles_n * p.batch;
+        const int rows_left = p.M - mt_b * 128;
+        const int64_t ts = (int64_t)tgp_cdiv(rows_left, 64) * tgp_cdiv(p.N, 64) * p.batch;
+        const double est = (double)((tb + S - 1) / S) + small_cost * (double)((ts + S - 1) / S);
+        if (est < best) best = est, best_mt = mt_b;
+    }
+    p.mt_big = best_mt;
+    p.tiles_n_big = tiles_n;
+    p.tiles_big = best_mt * tiles_n * p.batch;
+    const int rows_left = p.M - best_mt * 128;
+    p.tiles_m_small = rows_left > 0 ? tgp_cdiv(rows_left, 64) : 0;
+    p.tiles_n_small = tgp_cdiv(p.N, 64);
+    const int total = p.tiles_big + p.tiles_m_small * p.tiles_n_small * p.batch;
+    const size_t lds = (size_t)2 * (128 + 128) * GEMM_LD * sizeof(float);
     static bool attr_set = false;
-    if (!attr_set) { // > 64 KiB of dynamic LDS needs the opt-in
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_kernel<BM, BN, NAT, DIST>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+    if (!attr_set) {
+        const int e = set_lds_limit(reinterpret_cast<const void *>(gemm_main_kernel), lds);
+        if (e) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, NAT, DIST>), grid, block, lds, stream, p);
+    hipLaunchKernelGGL(gemm_main_kernel, dim3(total), dim3(256), lds, stream, p);
     return TGP_LAUNCH_RESULT();
 }
 
@@ -292,24 +394,31 @@ extern "C" int tgp_gemm_f32(const tgp_gemm_args *a, tgp_stream_t stream)
     TGP_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0);
     TGP_REQUIRE((a->K & 3) == 0 && (a->lda & 3) == 0 && (a->ldw & 3) == 0 && a->lda >= a->K && a->ldw >= a->K);
     TGP_REQUIRE((reinterpret_cast<uintptr_t>(a->A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a->W) & 15) == 0);
-    TGP_REQUIRE(!a->C || a->ldc >= a->N);
+    TGP_REQUIRE(a->c_col0 >= 0 && a->c_col0 <= a->N && (!a->C || a->ldc >= a->N - a->c_col0));
     TGP_REQUIRE(!(a->rowbias || a->colmax_keys) || a->rows_per_obj > 0);
     TGP_REQUIRE(a->act == 0 || a->act == 1);
-    GemmParams p;
+    TGP_REQUIRE(a->batch >= 0 && a->cm_cols >= 0 && a->cm_cols <= a->N);
+    GemmParams p = {};
     p.A = a->A, p.W = a->W, p.C = a->C;
     p.lda = a->lda, p.ldw = a->ldw, p.ldc = a->ldc, p.M = a->M, p.N = a->N, p.K = a->K;
     p.bias = a->bias, p.rowbias = a->rowbias, p.ldrb = a->ldrb, p.rows_per_obj = a->rows_per_obj > 0 ? a->rows_per_obj : 1;
     p.res1 = a->res1, p.ldr1 = a->ldr1, p.res2 = a->res2, p.ldr2 = a->ldr2;
-    p.scale = a->scale, p.shift = a->shift, p.act = a->act, p.slope = a->slope;
+    p.scale = a->scale, p.shift = a->shift, p.slope_vec = a->slope_vec, p.act = a->act, p.slope = a->slope;
     p.cm = a->colmax_keys, p.ldcm = a->ldcm;
-    p.sA = p.sW = p.sC = 0, p.qrow = p.qcol = nullptr, p.sq = 0;
-    if (a->M <= 32 && a->C && !a->rowbias && !a->res1 && !a->res2 && !a->colmax_keys) {
-        hipLaunchKernelGGL(skinny_gemm_kernel, dim3(tgp_cdiv(a->N, 4 * SKINNY_COLS)), dim3(256), 0, tgp_hs(stream), p);
+    p.cm_cols = a->cm_cols > 0 ? a->cm_cols : a->N;
+    p.c_col0 = a->c_col0;
+    p.batch = a->batch > 0 ? a->batch : 1;
+    p.sA = a->batch_stride_a, p.sW = a->batch_stride_w, p.sC = a->batch_stride_c, p.sV = a->batch_stride_vec;
+    p.sCM = a->batch_stride_colmax;
+    const bool plain = !a->rowbias && !a->res1 && !a->res2 && !a->colmax_keys && !a->slope_vec && a->c_col0 == 0 &&
+                       p.batch == 1;
+    if (a->M <= 32 && a->C && plain) {
+        hipLaunchKernelGGL(skinny_gemm_kernel, dim3(tgp_cdiv(a->N, SKINNY_COLS)), dim3(256), 0, tgp_hs(stream), p);
         return TGP_LAUNCH_RESULT();
     }
-    const int64_t big_tiles = (int64_t)tgp_cdiv(a->M, 128) * tgp_cdiv(a->N, 128);
-    if (big_tiles >= 1024) return launch_tiled<128, 128, false, false>(p, 1, tgp_hs(stream));
-    return launch_tiled<64, 64, false, false>(p, 1, tgp_hs(stream));
+    const int64_t big_tiles = (int64_t)tgp_cdiv(a->M, 128) * tgp_cdiv(a->N, 128) * p.batch;
+    if (big_tiles >= resident_slots() / 2 && a->N > 64) return launch_main(p, tgp_hs(stream));
+    return launch_small<false, false>(p, tgp_hs(stream));
 }
 
 // feature-space distance matrix for tgp_knn_feat (knn.hip)
@@ -320,10 +429,11 @@ int tgp_launch_dist_gemm(const float *x, int ld, const float *q, int B, int n, i
     p.A = x, p.W = x, p.C = D;
     p.lda = ld, p.ldw = ld, p.ldc = n, p.M = n, p.N = n, p.K = d;
     p.rows_per_obj = 1;
+    p.batch = B;
     p.sA = p.sW = (int64_t)n * ld;
     p.sC = (int64_t)n * n;
     p.qrow = q, p.qcol = q, p.sq = n;
-    return launch_tiled<64, 64, true, true>(p, B, stream);
+    return launch_small<true, true>(p, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -15,7 +15,6 @@
 
 #define KNN_MAX_POINTS 2048
 #define KNN_MAX_K 63
-#define KNN_ROWS_PER_BLOCK 32
 
 extern "C" int tgp_knn_max_points(void) { return KNN_MAX_POINTS; }
 extern "C" int tgp_knn_max_k(void) { return KNN_MAX_K; }
@@ -70,13 +69,60 @@ __device__ float aten_row_sum_strided(const float *in, int stride, int size)
     return 0.f + a0[0];
 }
 
-__global__ void center_mean_kernel(const float *__restrict__ points, int B, int n, float *__restrict__ mean)
+__global__ void center_mean_serial_kernel(const float *__restrict__ points, int B, int n, float *__restrict__ mean)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B * 3) return;
     const int b = t / 3, c = t - b * 3;
     const float s = aten_row_sum_strided(points + (size_t)b * n * 3 + c, 3, n);
     mean[t] = s / (float)n;
+}
+
+// The same sum, parallel: in ATen's cascade every run of 16 "rows" (4 interleaved elements each) is summed
+// from zero before it is merged into the next level, so the runs are independent.  One workgroup per
+// object: threads sum the runs, three threads then replay the merges in order.  Bit-identical to the
+// serial routine above (tests compare both against torch on the CPU).
+#define CM_MAX_RUNS 128
+__global__ __launch_bounds__(256) void center_mean_kernel(const float *__restrict__ points, int n, float *__restrict__ mean)
+{
+    __shared__ float part[3][4][CM_MAX_RUNS + 1];
+    const int b = blockIdx.x;
+    const float *in = points + (size_t)b * n * 3;
+    const int size_ilp = n / 4, full = size_ilp / 16;
+    for (int t = threadIdx.x; t < 12 * (full + 1); t += blockDim.x) {
+        const int c = t % 3, k = (t / 3) & 3, j = t / 12;
+        const int lo = j * 16, hi = (j < full) ? lo + 16 : size_ilp;
+        float acc = 0.f;
+        for (int i = lo; i < hi; ++i) acc = acc + in[(size_t)(i * 4 + k) * 3 + c];
+        part[c][k][j] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        float fin[4];
+        for (int k = 0; k < 4; ++k) {
+            float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int j = 0; j < full; ++j) {
+                a1 = a1 + part[c][k][j];
+                if (((j + 1) & 15) != 0) continue;
+                a2 = a2 + a1;
+                a1 = 0.f;
+                if (((j + 1) & 255) != 0) continue;
+                a3 = a3 + a2;
+                a2 = 0.f;
+            }
+            float a0 = part[c][k][full];
+            a0 = a0 + a1;
+            a0 = a0 + a2;
+            a0 = a0 + a3;
+            fin[k] = a0;
+        }
+        for (int t = size_ilp * 4; t < n; ++t) fin[0] = fin[0] + in[(size_t)t * 3 + c];
+        float s = fin[0] + fin[1];
+        s = s + fin[2];
+        s = s + fin[3];
+        mean[b * 3 + c] = (0.f + s) / (float)n;
+    }
 }
 
 __global__ void center_sub_kernel(const float *__restrict__ points, const float *__restrict__ mean, int n,
@@ -93,7 +139,11 @@ __global__ void center_sub_kernel(const float *__restrict__ points, const float 
 extern "C" int tgp_center(const float *points, int B, int n, float *xyz_c, float *mean, tgp_stream_t stream)
 {
     TGP_REQUIRE(points && xyz_c && mean && B > 0 && n > 0);
-    hipLaunchKernelGGL(center_mean_kernel, dim3(tgp_cdiv(B * 3, 64)), dim3(64), 0, tgp_hs(stream), points, B, n, mean);
+    if (n / 64 < CM_MAX_RUNS)
+        hipLaunchKernelGGL(center_mean_kernel, dim3(B), dim3(256), 0, tgp_hs(stream), points, n, mean);
+    else
+        hipLaunchKernelGGL(center_mean_serial_kernel, dim3(tgp_cdiv(B * 3, 64)), dim3(64), 0, tgp_hs(stream), points, B, n,
+                           mean);
     const int64_t total = (int64_t)B * n * 3;
     hipLaunchKernelGGL(center_sub_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), points, mean, n,
                        total, xyz_c);
@@ -136,7 +186,7 @@ __device__ __forceinline__ void wave_select(float (&d)[NT], int lane, int k, int
 
 template <int NT>
 __global__ __launch_bounds__(256) void knn_xyz_kernel(const float *__restrict__ xyz, int B, int n, int k,
-                                                      int32_t *__restrict__ idx, int tiles_per_obj)
+                                                      int32_t *__restrict__ idx, int tiles_per_obj, int rpb)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *pts = reinterpret_cast<float4 *>(smem);
@@ -152,8 +202,8 @@ __global__ __launch_bounds__(256) void knn_xyz_kernel(const float *__restrict__ 
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r = wave; r < KNN_ROWS_PER_BLOCK; r += 4) {
-        const int i = tile * KNN_ROWS_PER_BLOCK + r;
+    for (int r = wave; r < rpb; r += 4) {
+        const int i = tile * rpb + r;
         if (i >= n) break;
         const float4 pi = pts[i];
         float d[NT];
@@ -178,13 +228,13 @@ __global__ __launch_bounds__(256) void knn_xyz_kernel(const float *__restrict__ 
 
 template <int NT>
 __global__ __launch_bounds__(256) void knn_matrix_kernel(const float *__restrict__ D, int B, int n, int k,
-                                                         int32_t *__restrict__ idx, int tiles_per_obj)
+                                                         int32_t *__restrict__ idx, int tiles_per_obj, int rpb)
 {
     int b, tile;
     if (!tgp_xcd_object_tile(blockIdx.x, B, tiles_per_obj, b, tile)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r = wave; r < KNN_ROWS_PER_BLOCK; r += 4) {
-        const int i = tile * KNN_ROWS_PER_BLOCK + r;
+    for (int r = wave; r < rpb; r += 4) {
+        const int i = tile * rpb + r;
         if (i >= n) break;
         const float *row = D + ((size_t)b * n + i) * n;
         float d[NT];
@@ -195,6 +245,15 @@ __global__ __launch_bounds__(256) void knn_matrix_kernel(const float *__restrict
         }
         wave_select<NT>(d, lane, k, idx + ((size_t)b * n + i) * k);
     }
+}
+
+// Query rows per workgroup: one wave handles rpb/4 rows back to back.  The selection is a chain of
+// dependent cross-lane steps, so it needs many waves per SIMD to hide latency: aim at >= 2048 workgroups.
+static int knn_rows_per_block(int B, int n)
+{
+    int rpb = 32;
+    while (rpb > 4 && (int64_t)B * tgp_cdiv(n, rpb) < 2048) rpb >>= 1;
+    return rpb;
 }
 
 static int knn_check(int B, int n, int k)
@@ -209,12 +268,13 @@ extern "C" int tgp_knn_xyz(const float *xyz, int B, int n, int k, int32_t *idx, 
     TGP_REQUIRE(xyz && idx);
     const int chk = knn_check(B, n, k);
     if (chk) return chk;
-    const int tiles = tgp_cdiv(n, KNN_ROWS_PER_BLOCK);
+    const int rpb = knn_rows_per_block(B, n);
+    const int tiles = tgp_cdiv(n, rpb);
     const dim3 grid(tgp_xcd_grid(B, tiles)), block(256);
     const size_t lds = (size_t)n * sizeof(float4);
     const int nt = tgp_cdiv(n, 64);
 #define LAUNCH_XYZ(NT) \
-    hipLaunchKernelGGL(knn_xyz_kernel<NT>, grid, block, lds, tgp_hs(stream), xyz, B, n, k, idx, tiles)
+    hipLaunchKernelGGL(knn_xyz_kernel<NT>, grid, block, lds, tgp_hs(stream), xyz, B, n, k, idx, tiles, rpb)
     if (nt <= 1) LAUNCH_XYZ(1);
     else if (nt <= 2) LAUNCH_XYZ(2);
     else if (nt <= 5) LAUNCH_XYZ(5);
@@ -279,10 +339,11 @@ extern "C" int tgp_knn_feat(const float *feat, int ld, int B, int n, int d, int 
                        d, q);
     int rc = tgp_launch_dist_gemm(feat, ld, q, B, n, d, D, tgp_hs(stream));
     if (rc) return rc;
-    const int tiles = tgp_cdiv(n, KNN_ROWS_PER_BLOCK);
+    const int rpb = knn_rows_per_block(B, n);
+    const int tiles = tgp_cdiv(n, rpb);
     const dim3 grid(tgp_xcd_grid(B, tiles)), block(256);
     const int nt = tgp_cdiv(n, 64);
-#define LAUNCH_MAT(NT) hipLaunchKernelGGL(knn_matrix_kernel<NT>, grid, block, 0, tgp_hs(stream), D, B, n, k, idx, tiles)
+#define LAUNCH_MAT(NT) hipLaunchKernelGGL(knn_matrix_kernel<NT>, grid, block, 0, tgp_hs(stream), D, B, n, k, idx, tiles, rpb)
     if (nt <= 1) LAUNCH_MAT(1);
     else if (nt <= 2) LAUNCH_MAT(2);
     else if (nt <= 5) LAUNCH_MAT(5);

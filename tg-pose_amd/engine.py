@@ -93,6 +93,27 @@ def pack_head(sd, h):
                 c3=cv("conv3") + _bn_fold(sd, h + "bn3"), c4=cv("conv4"))
 
 
+HEAD_ORDER = ("rot_green", "rot_red", "ts")
+
+
+def pack_wide(ph, heads):
+    """conv_5 (PH_Predictor) and the three heads' conv1 all read `feat`: one (4096, 1292) operand.
+    Columns [0,1024) = conv_5 (no bias, LeakyReLU 0.2, only its max over points is needed);
+    columns [1024,4096) = rot_green | rot_red | ts conv1 (+bias, ReLU).  Also stacks the heads' conv2."""
+    dev = ph["w5"].device
+    z = torch.zeros(1024, device=dev)
+    cat = lambda i: torch.cat([hd["c1"][i] for hd in heads]).contiguous()
+    c2 = lambda i: torch.stack([hd["c2"][i] for hd in heads]).contiguous()
+    return dict(
+        W=torch.cat([ph["w5"]] + [hd["c1"][0] for hd in heads], dim=0).contiguous(),
+        bias=torch.cat([z, cat(1)]).contiguous(),
+        scale=torch.cat([ph["bn5c"][0], cat(2)]).contiguous(),
+        shift=torch.cat([ph["bn5c"][1], cat(3)]).contiguous(),
+        slope=torch.cat([z + 0.2, torch.zeros(3072, device=dev)]).contiguous(),
+        k_alg=(FEAT_C + sum(hd["k_alg"] for hd in heads)) / 4.0,
+        W2=c2(0), b2=c2(1), scale2=c2(2), shift2=c2(3))
+
+
 class Packed(object):
     """Device-resident, kernel-ready weights of one PoseNet9D (eval mode)."""
 
@@ -103,6 +124,8 @@ class Packed(object):
         self.ph = pack_ph(sd, face + "ph_pred.")
         self.dec, self.dec_out = pack_decoder(sd, face + "decoder.")
         self.heads = {h: pack_head(sd, h + ".") for h in ("rot_green", "rot_red", "ts")} if with_heads else {}
+        if with_heads:
+            self.wide = pack_wide(self.ph, [self.heads[h] for h in HEAD_ORDER])
 
 
 def _i32(idx, device):
@@ -204,14 +227,8 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6):
     return feat, inter
 
 
-def ph_forward(pk, feat, N):
-    """PH_Predictor.forward (FaceRecon.py:139-167) -> h1, h2 (B,2500) and back = pi1_1 + pi2_1 (B,FEAT_LD)."""
-    B = feat.shape[0]
-    dev = feat.device
-    ph = pk.ph
-    keys = torch.zeros(B, 1024, device=dev, dtype=torch.int32)
-    ops.linear_rows(feat, ph["w5"], scale=ph["bn5c"][0], shift=ph["bn5c"][1], act=1, slope=0.2, want_out=False,
-                    colmax_keys=keys, rows_per_obj=N, k_alg=FEAT_C)
+def ph_tail(ph, keys, B, dev):
+    """PH_Predictor after the max over points (FaceRecon.py:145-165): keys = colmax keys of conv_5."""
     g = ops.colmax_decode(keys, out2=True)                                       # cat((max, max), 1)
     fa = ops.linear_rows(g, ph["l1"], scale=ph["bn5"][0], shift=ph["bn5"][1], act=1, slope=0.2)
     pi1 = ops.linear_rows(fa, ph["l2"][0], bias=ph["l2"][1])
@@ -220,6 +237,42 @@ def ph_forward(pk, feat, N):
     b1 = ops.linear_rows(pi1, ph["l4"][0], bias=ph["l4"][1])
     ops.linear_rows(pi2, ph["l5"][0], bias=ph["l5"][1], res1=b1, out=back[:, :FEAT_C])
     return ops.sigmoid(pi1), ops.sigmoid(pi2), back
+
+
+def ph_forward(pk, feat, N):
+    """PH_Predictor.forward (FaceRecon.py:139-167) -> h1, h2 (B,2500) and back = pi1_1 + pi2_1 (B,FEAT_LD)."""
+    B = feat.shape[0]
+    ph = pk.ph
+    keys = torch.zeros(B, 1024, device=feat.device, dtype=torch.int32)
+    ops.linear_rows(feat, ph["w5"], scale=ph["bn5c"][0], shift=ph["bn5c"][1], act=1, slope=0.2, want_out=False,
+                    colmax_keys=keys, rows_per_obj=N, k_alg=FEAT_C)
+    return ph_tail(ph, keys, B, feat.device)
+
+
+def wide_forward(pk, feat, N):
+    """conv_5 + the three head conv1 in one GEMM over `feat` (N_out = 4096), then the three head conv2
+    (+BN, ReLU, max over points) as one batched launch.  Returns (keys5 (B,1024), pooled (3,B,256))."""
+    B = feat.shape[0]
+    dev = feat.device
+    w = pk.wide
+    M = B * N
+    keys5 = torch.zeros(B, 1024, device=dev, dtype=torch.int32)
+    H = torch.empty(M, 3072, device=dev, dtype=torch.float32)
+    ops.gemm(feat, w["W"], H, M=M, N=4096, K=FEAT_LD, lda=FEAT_LD, ldw=FEAT_LD, ldc=3072, bias=w["bias"],
+             scale=w["scale"], shift=w["shift"], act=1, slope_vec=w["slope"], colmax_keys=keys5, cm_cols=1024,
+             c_col0=1024, rows_per_obj=N, k_alg=w["k_alg"])
+    keys2 = torch.zeros(3, B, 256, device=dev, dtype=torch.int32)
+    ops.gemm(H, w["W2"], None, M=M, N=256, K=1024, lda=3072, ldw=1024, ldc=0, bias=w["b2"], scale=w["scale2"],
+             shift=w["shift2"], act=1, slope=0.0, colmax_keys=keys2, rows_per_obj=N, batch=3,
+             batch_strides=(1024, 256 * 1024, 0, 256, B * 256))
+    return keys5, ops.colmax_decode(keys2.view(3 * B, 256)).view(3, B, 256)
+
+
+def head_tail(hd, pooled):
+    """conv3 (+BN, ReLU), dropout(eval) = identity, conv4 on the pooled (B,256) vector."""
+    w, b, sc, sh = hd["c3"]
+    x = ops.linear_rows(pooled, w, bias=b, scale=sc, shift=sh, act=1)
+    return ops.linear_rows(x, hd["c4"][0], bias=hd["c4"][1])
 
 
 def decoder_forward(pk, feat, back, N):
@@ -272,11 +325,10 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
     xyz, mean = ops.center(points)
     graphs = Graphs(points.device, inject, record)
     feat, inter = encoder_forward(pk, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
-    h1, h2, back = ph_forward(pk, feat, N)
+    keys5, pooled = wide_forward(pk, feat, N)
+    h1, h2, back = ph_tail(pk.ph, keys5, B, points.device)
     recon = decoder_forward(pk, feat, back, N)
-    green = head_forward(pk.heads["rot_green"], feat, N)
-    red = head_forward(pk.heads["rot_red"], feat, N)
-    ts = head_forward(pk.heads["ts"], feat, N)
+    green, red, ts = (head_tail(pk.heads[h], pooled[i]) for i, h in enumerate(HEAD_ORDER))
     pg, pr, fg, fr, pT, ps = ops.head_post(green, red, ts, mean)
     out = dict()
     if train_keys:

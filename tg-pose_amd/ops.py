@@ -178,17 +178,28 @@ def fill_tail(obj_id, xyz_c, feat, col0, n_cls):
 GEMM_TIMER = None
 
 
-def _routes_to_big_tile(M, N):
-    return M > 32 and ((M + 127) // 128) * ((N + 127) // 128) >= 1024
+def _routes_to_big_tile(M, N, batch=1):
+    return N > 64 and ((M + 127) // 128) * ((N + 127) // 128) * batch >= _big_tile_threshold()
+
+
+_BIG_THR = None
+
+
+def _big_tile_threshold():
+    """resident_slots() / 2 of csrc/gemm.hip: one 128x128 workgroup per CU"""
+    global _BIG_THR
+    if _BIG_THR is None:
+        _BIG_THR = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    return _BIG_THR
 
 
 def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, bias=None, rowbias=None,
          rows_per_obj=0, res1=None, ldr1=0, res2=None, ldr2=0, scale=None, shift=None, act=0, slope=0.0,
-         colmax_keys=None, k_alg=None):
+         colmax_keys=None, k_alg=None, slope_vec=None, cm_cols=0, c_col0=0, batch=1, batch_strides=None):
     """Raw call into tgp_gemm_f32.  A/W/C/res* are tensors whose data_ptr is the first element of the
     operand (views into wider buffers are fine); all sizes/strides are explicit.  k_alg: the layer's
     true input width when K includes zero padding (only used for FLOP accounting in bench.py)."""
-    timed = GEMM_TIMER is not None and _routes_to_big_tile(M, N)
+    timed = GEMM_TIMER is not None and _routes_to_big_tile(M, N, batch)
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(A.device))
@@ -203,11 +214,14 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
     a.res2, a.ldr2 = _p(res2), ldr2
     a.scale, a.shift = _p(scale), _p(shift)
     a.act, a.slope = act, slope
-    a.colmax_keys, a.ldcm = (_p(colmax_keys), colmax_keys.stride(0)) if colmax_keys is not None else (None, 0)
+    a.colmax_keys, a.ldcm = (_p(colmax_keys), colmax_keys.stride(-2)) if colmax_keys is not None else (None, 0)
+    a.slope_vec, a.cm_cols, a.c_col0, a.batch = _p(slope_vec), cm_cols, c_col0, batch
+    if batch_strides is not None:
+        (a.batch_stride_a, a.batch_stride_w, a.batch_stride_c, a.batch_stride_vec, a.batch_stride_colmax) = batch_strides
     check(_lib.lib().tgp_gemm_f32(ctypes.byref(a), _stream(A)), "tgp_gemm_f32")
     if timed:
         e1.record(torch.cuda.current_stream(A.device))
-        GEMM_TIMER.append((e0, e1, 2.0 * M * N * (k_alg or K)))
+        GEMM_TIMER.append((e0, e1, 2.0 * M * N * (k_alg or K) * batch))
     return C
 
 
