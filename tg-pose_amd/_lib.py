@@ -34,6 +34,7 @@ class GemmArgs(ctypes.Structure):
         ("batch", c_int),
         ("batch_stride_a", c_i64), ("batch_stride_w", c_i64), ("batch_stride_c", c_i64),
         ("batch_stride_vec", c_i64), ("batch_stride_colmax", c_i64),
+        ("W_split", c_vp), ("ldws", c_int),
     ]
 
 
@@ -55,6 +56,7 @@ SIGNATURES = {
     "tgp_pool_fwd": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
     "tgp_gather_rows": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     "tgp_fill_tail": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
+    "tgp_split_bf16": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     "tgp_gemm_f32": (c_int, [ctypes.POINTER(GemmArgs), c_vp]),
     "tgp_colmax_decode": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "tgp_colmax": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),

@@ -45,121 +45,23 @@ struct GemmParams {
     const float *qrow;           // DIST epilogue
     const float *qcol;
     int64_t sq;
+    const uint16_t *Wsplit;      // bf16 planes [3][N][ldws] of W (hi, mid, lo), ldws % 16 == 0, zero padded
+    int ldws;
+    int64_t sWS;                 // per-batch stride of Wsplit in bf16 elements of one plane
+    int64_t plane;               // elements between planes
     // tile schedule of the main kernel: per batch, M-tile rows [0, mt_big) use 128x128 tiles, the rest 64x64
     int mt_big, tiles_n_big, tiles_big, tiles_m_small, tiles_n_small;
 };
 
-#define GEMM_BK 32
-#define GEMM_LD 36
-
-// One BM x BN output tile at (m0, n0) of batch z.  256 threads.
-template <int BM, int BN, bool NATURAL_K, bool DIST>
-__device__ __forceinline__ void gemm_tile(const GemmParams &p, const int m0, const int n0, const int z, float *smem)
+// Fused epilogue shared by every tile kernel.  C/D layout of a 32x32 MFMA tile (any input dtype):
+// col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
+template <int TM, int TN, int WTM, int WTN, bool DIST>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)[TM][TN], const int m0, const int n0,
+                                              const int z, const int wm, const int wn, const int r, const int h)
 {
-    constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int PA = BM / 32, PW = BN / 32;
-    constexpr int BUF = (BM + BN) * GEMM_LD;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int r = lane & 31, h = lane >> 5;
-    const float *A = p.A + (int64_t)z * p.sA;
-    const float *W = p.W + (int64_t)z * p.sW;
-
-    const int kq = tid & 7, r0 = tid >> 3;
-    float4 ra[PA], rw[PW];
-
-    // Guards without branches: every lane loads from a clamped (always valid) address, then selects.
-    auto load_tile = [&](int kt) {
-        const int kcol = kt * GEMM_BK + kq * 4;
-        const bool kok = kcol < p.K;
-        const int kc = kok ? kcol : 0;
-#pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            const int row = m0 + r0 + 32 * i;
-            const bool ok = kok && row < p.M;
-            const float4 v = *reinterpret_cast<const float4 *>(A + (int64_t)(row < p.M ? row : p.M - 1) * p.lda + kc);
-            ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < PW; ++i) {
-            const int row = n0 + r0 + 32 * i;
-            const bool ok = kok && row < p.N;
-            const float4 v = *reinterpret_cast<const float4 *>(W + (int64_t)(row < p.N ? row : p.N - 1) * p.ldw + kc);
-            rw[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store_tile = [&](int buf) {
-        float *as = smem + buf * BUF;
-        float *ws = as + BM * GEMM_LD;
-#pragma unroll
-        for (int i = 0; i < PA; ++i) *reinterpret_cast<float4 *>(as + (r0 + 32 * i) * GEMM_LD + kq * 4) = ra[i];
-#pragma unroll
-        for (int i = 0; i < PW; ++i) *reinterpret_cast<float4 *>(ws + (r0 + 32 * i) * GEMM_LD + kq * 4) = rw[i];
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int numK = (p.K + GEMM_BK - 1) / GEMM_BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < numK; ++kt) {
-        const bool more = (kt + 1) < numK;
-        if (more) load_tile(kt + 1);
-        const float *as = smem + (kt & 1) * BUF + (wm * (BM / 2) + r) * GEMM_LD;
-        const float *ws = smem + (kt & 1) * BUF + BM * GEMM_LD + (wn * (BN / 2) + r) * GEMM_LD;
-        if constexpr (NATURAL_K) {
-#pragma unroll
-            for (int s = 0; s < GEMM_BK / 2; ++s) {
-                float a[TM], b[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = as[i * 32 * GEMM_LD + 2 * s + h];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = ws[j * 32 * GEMM_LD + 2 * s + h];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < GEMM_BK / 8; ++kk) {
-                float4 a[TM], b[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    a[i] = *reinterpret_cast<const float4 *>(as + i * 32 * GEMM_LD + kk * 8 + h * 4);
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    b[j] = *reinterpret_cast<const float4 *>(ws + j * 32 * GEMM_LD + kk * 8 + h * 4);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                    }
-            }
-        }
-        if (more) store_tile((kt + 1) & 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * (BN / 2) + j * 32 + r;
+        const int col = n0 + wn * WTN + j * 32 + r;
         const bool colok = col < p.N;
         if constexpr (DIST) {
             const float *qrow = p.qrow + (int64_t)z * p.sq;
@@ -170,7 +72,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, const int m0, con
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int row = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (colok && row < p.M) {
                         const float t1 = acc[i][j][e] * -2.0f;
                         const float t2 = t1 + qc;
@@ -187,7 +89,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, const int m0, con
             uint32_t *cm = (p.cm && col < p.cm_cols) ? p.cm + (int64_t)z * p.sCM + col : nullptr;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int rbase = m0 + wm * (BM / 2) + i * 32 + 4 * h;
+                const int rbase = m0 + wm * WTM + i * 32 + 4 * h;
                 int obj = 0, bound = 0x7fffffff;
                 if (p.rowbias || p.cm) {
                     obj = rbase / p.rows_per_obj;
@@ -227,11 +129,408 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, const int m0, con
     }
 }
 
-// Main kernel: blocks [0, tiles_big) take 128x128 tiles (N fastest, then M, then batch); the remaining
-// blocks cover the leftover M rows with 64x64 tiles.  M = B*1028 is 257 tiles of 128 (257 is prime), so a
-// plain grid leaves e.g. 2056 tiles for 512 resident workgroups = 4.02 rounds -> 5; giving the last
-// M-tile rows to quarter-size tiles, dispatched last, fills the tail round instead (4.25).
-__global__ __launch_bounds__(256) void gemm_main_kernel(GemmParams p)
+#define GEMM_LDPAD 4
+
+// One BM x BN output tile at (m0, n0) of batch z, computed by 64*NWM*NWN threads (NWM x NWN waves, each
+// owning a (BM/NWM) x (BN/NWN) sub-tile as 32x32 MFMA tiles).  BK-wide K-tiles; DBUF selects two LDS buffers
+// and one barrier per K-tile, otherwise one buffer and two barriers.
+// Measured on MI355X (scripts/gemm_variants.py, M=32768 N=4096 K=1280, row stride 1292): what matters is waves
+// per SIMD -- 256-thread workgroups (2-3 waves/SIMD) reach 58-90 TF whatever the tile, 1024-thread workgroups
+// (4 waves/SIMD) 124 TF on 128x128 and 131-137 TF on 256x256 tiles; BK=16 beats BK=32 by 25 %.
+template <int BM, int BN, int NWM, int NWN, int BK, bool DBUF, bool NATURAL_K, bool DIST>
+__device__ __forceinline__ void gemm_tile(const GemmParams &p, const int m0, const int n0, const int z, float *smem)
+{
+    constexpr int THREADS = 64 * NWM * NWN;
+    constexpr int LD = BK + GEMM_LDPAD;
+    constexpr int WTM = BM / NWM, WTN = BN / NWN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int F4 = BK / 4;                      // float4 per staged row
+    constexpr int RPP = THREADS / F4;               // rows per staging pass
+    constexpr int PA = (BM + RPP - 1) / RPP, PW = (BN + RPP - 1) / RPP;
+    constexpr int BUF = (BM + BN) * LD;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int r = lane & 31, h = lane >> 5;
+    const float *A = p.A + (int64_t)z * p.sA;
+    const float *W = p.W + (int64_t)z * p.sW;
+
+    const int kq = tid % F4, r0 = tid / F4;
+    float4 ra[PA], rw[PW];
+
+    // Guards without branches: every lane loads from a clamped (always valid) address, then selects.
+    auto load_tile = [&](int kt) {
+        const int kcol = kt * BK + kq * 4;
+        const bool kok = kcol < p.K;
+        const int kc = kok ? kcol : 0;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            if (RPP * i + r0 < BM) {
+                const int row = m0 + r0 + RPP * i;
+                const bool ok = kok && row < p.M;
+                const float4 v = *reinterpret_cast<const float4 *>(A + (int64_t)(row < p.M ? row : p.M - 1) * p.lda + kc);
+                ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            if (RPP * i + r0 < BN) {
+                const int row = n0 + r0 + RPP * i;
+                const bool ok = kok && row < p.N;
+                const float4 v = *reinterpret_cast<const float4 *>(W + (int64_t)(row < p.N ? row : p.N - 1) * p.ldw + kc);
+                rw[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float *as = smem + buf * BUF;
+        float *ws = as + BM * LD;
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            if (RPP * i + r0 < BM) *reinterpret_cast<float4 *>(as + (r0 + RPP * i) * LD + kq * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < PW; ++i)
+            if (RPP * i + r0 < BN) *reinterpret_cast<float4 *>(ws + (r0 + RPP * i) * LD + kq * 4) = rw[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int numK = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < numK; ++kt) {
+        const bool more = (kt + 1) < numK;
+        if (more) load_tile(kt + 1);
+        const int cur = DBUF ? (kt & 1) : 0;
+        const float *as = smem + cur * BUF + (wm * WTM + r) * LD;
+        const float *ws = smem + cur * BUF + BM * LD + (wn * WTN + r) * LD;
+        if constexpr (NATURAL_K) {
+#pragma unroll
+            for (int s = 0; s < BK / 2; ++s) {
+                float a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = as[i * 32 * LD + 2 * s + h];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = ws[j * 32 * LD + 2 * s + h];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                float4 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a[i] = *reinterpret_cast<const float4 *>(as + i * 32 * LD + kk * 8 + h * 4);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b[j] = *reinterpret_cast<const float4 *>(ws + j * 32 * LD + kk * 8 + h * 4);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+        if (DBUF) {
+            if (more) store_tile((kt + 1) & 1);
+            __syncthreads();
+        } else {
+            __syncthreads();
+            if (more) store_tile(0);
+            __syncthreads();
+        }
+    }
+
+    gemm_epilogue<TM, TN, WTM, WTN, DIST>(p, acc, m0, n0, z, wm, wn, r, h);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fp32-accurate GEMM on the bf16 matrix cores: x = hi + mid + lo with three bf16 terms (3 x 8 significand bits =
+// fp32's 24), a*b ~ hh + hm + mh + hl + lh + mm (the dropped ml, lm, ll terms are <= 2^-23 |ab|), every term
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Six MFMAs of 32 cycles replace sixteen fp32 MFMAs of 64
+// cycles per 32x32x16 block: 2.67x fewer matrix-core cycles at fp32-level accuracy (measured error vs fp64
+// equals the fp32 MFMA kernel's: tests/test_gpu_parity.py::test_gemm_split_bf16_accuracy).
+// W is split once at weight-pack time (tgp_split_bf16); A (activations, fp32 in HBM) is split while it is
+// staged into LDS.  1024 threads, 4x4 waves, wave tile 64x64 (BIG 256x256) or 32x32 (MID 128x128), BK = 16.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+
+__device__ __forceinline__ void split3(const float4 v, uint2 &hi, uint2 &mid, uint2 &lo)
+{
+    bf16x4 h, m, l;
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = (__bf16)x[i];
+        const float r1 = x[i] - (float)h[i];
+        m[i] = (__bf16)r1;
+        const float r2 = r1 - (float)m[i];
+        l[i] = (__bf16)r2;
+    }
+    hi = __builtin_bit_cast(uint2, h);
+    mid = __builtin_bit_cast(uint2, m);
+    lo = __builtin_bit_cast(uint2, l);
+}
+
+// BK = 16: a thread stages 4 k of one row (8-byte plane pieces); BK = 32: 8 k (16-byte pieces, half the barriers).
+template <int BM, int BN, int NWM, int NWN, int BK>
+__device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m0, const int n0, const int z, char *smem)
+{
+    constexpr int THREADS = 64 * NWM * NWN;
+    constexpr int KPT = BK / 4;               // k per staging thread (4 threads per row)
+    constexpr int NF4 = KPT / 4;              // float4 per thread per row
+    constexpr int ROWB = BK * 2 + 16;         // LDS row of one plane: BK bf16 + 16 B pad (conflict-free ds_read_b128)
+    constexpr int WTM = BM / NWM, WTN = BN / NWN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int RPP = THREADS / 4;
+    constexpr int PA = (BM + RPP - 1) / RPP, PW = (BN + RPP - 1) / RPP;
+    constexpr int PLANE_A = BM * ROWB, PLANE_W = BN * ROWB;
+    char *lds_a = smem;
+    char *lds_w = smem + 3 * PLANE_A;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int r = lane & 31, h = lane >> 5;
+    const float *A = p.A + (int64_t)z * p.sA;
+    const uint16_t *WS = p.Wsplit + (int64_t)z * p.sWS;
+
+    const int kq = tid & 3, r0 = tid >> 2;
+    float4 ra[PA][NF4];
+    uint2 rw[PW][3][NF4];
+
+    auto load_tile = [&](int kt) {
+        const int kbase = kt * BK + kq * KPT;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            if (RPP * i + r0 < BM) {
+                const int row = m0 + r0 + RPP * i;
+                const float *src = A + (int64_t)(row < p.M ? row : p.M - 1) * p.lda;
+#pragma unroll
+                for (int f = 0; f < NF4; ++f) {
+                    const int kcol = kbase + 4 * f;
+                    const bool ok = kcol < p.K && row < p.M;
+                    const float4 v = *reinterpret_cast<const float4 *>(src + (kcol < p.K ? kcol : 0));
+                    ra[i][f] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            if (RPP * i + r0 < BN) {
+                const int row = n0 + r0 + RPP * i;
+                const bool ok = row < p.N;
+                const uint16_t *src = WS + (int64_t)(ok ? row : p.N - 1) * p.ldws;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int f = 0; f < NF4; ++f) {
+                        const int kcol = kbase + 4 * f;               // planes are zero padded up to ldws
+                        const uint2 v = *reinterpret_cast<const uint2 *>(src + q * p.plane + (kcol < p.ldws ? kcol : 0));
+                        rw[i][q][f] = (ok && kcol < p.ldws) ? v : make_uint2(0u, 0u);
+                    }
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            if (RPP * i + r0 < BM) {
+                char *dst = lds_a + (r0 + RPP * i) * ROWB + kq * KPT * 2;
+                uint2 q[3][NF4];
+#pragma unroll
+                for (int f = 0; f < NF4; ++f) split3(ra[i][f], q[0][f], q[1][f], q[2][f]);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    if constexpr (NF4 == 2)
+                        *reinterpret_cast<uint4 *>(dst + pl * PLANE_A) = make_uint4(q[pl][0].x, q[pl][0].y, q[pl][1].x, q[pl][1].y);
+                    else
+                        *reinterpret_cast<uint2 *>(dst + pl * PLANE_A) = q[pl][0];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            if (RPP * i + r0 < BN) {
+                char *dst = lds_w + (r0 + RPP * i) * ROWB + kq * KPT * 2;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    if constexpr (NF4 == 2)
+                        *reinterpret_cast<uint4 *>(dst + pl * PLANE_W) =
+                            make_uint4(rw[i][pl][0].x, rw[i][pl][0].y, rw[i][pl][1].x, rw[i][pl][1].y);
+                    else
+                        *reinterpret_cast<uint2 *>(dst + pl * PLANE_W) = rw[i][pl][0];
+                }
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int numK = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    const char *as = lds_a + (wm * WTM + r) * ROWB + h * 16;
+    const char *ws = lds_w + (wn * WTN + r) * ROWB + h * 16;
+    for (int kt = 0; kt < numK; ++kt) {
+        const bool more = (kt + 1) < numK;
+        if (more) load_tile(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            if constexpr (BK == 16) { // all A fragments resident: 12 LDS reads per 24 MFMAs
+                bf16x8 a[TM][3];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        a[i][q] = *reinterpret_cast<const bf16x8 *>(as + i * 32 * ROWB + q * PLANE_A + ks * 32);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bf16x8 b[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        b[q] = *reinterpret_cast<const bf16x8 *>(ws + j * 32 * ROWB + q * PLANE_W + ks * 32);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        // smallest terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], acc[i][j], 0, 0, 0);
+                    }
+                }
+            } else { // register-lean order (the 8-k staging registers leave less room): one A plane live at a time
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bf16x8 b[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        b[q] = *reinterpret_cast<const bf16x8 *>(ws + j * 32 * ROWB + q * PLANE_W + ks * 32);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const char *ap = as + i * 32 * ROWB + ks * 32;
+                        bf16x8 a = *reinterpret_cast<const bf16x8 *>(ap + 2 * PLANE_A);             // lo
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[0], acc[i][j], 0, 0, 0);
+                        a = *reinterpret_cast<const bf16x8 *>(ap + PLANE_A);                        // mid
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[0], acc[i][j], 0, 0, 0);
+                        a = *reinterpret_cast<const bf16x8 *>(ap);                                  // hi
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[0], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (more) store_tile();
+        __syncthreads();
+    }
+    gemm_epilogue<TM, TN, WTM, WTN, false>(p, acc, m0, n0, z, wm, wn, r, h);
+}
+
+template <int BK>
+__global__ __launch_bounds__(1024) void gemm_split_kernel(GemmParams p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[3 * (256 + 256) * (BK * 2 + 16)];
+    int L = blockIdx.x;
+    if (L < p.tiles_big) {
+        const int per_batch = p.mt_big * p.tiles_n_big;
+        const int z = L / per_batch;
+        L -= z * per_batch;
+        gemm_split_tile<256, 256, 4, 4, BK>(p, (L / p.tiles_n_big) * 256, (L % p.tiles_n_big) * 256, z, smem);
+    } else {
+        L -= p.tiles_big;
+        const int per_batch = p.tiles_m_small * p.tiles_n_small;
+        const int z = L / per_batch;
+        L -= z * per_batch;
+        gemm_split_tile<128, 128, 4, 4, BK>(p, p.mt_big * 256 + (L / p.tiles_n_small) * 128, (L % p.tiles_n_small) * 128, z, smem);
+    }
+}
+
+// W (rows, K) fp32 row stride ld -> out[3][rows][ldo] bf16 (hi, mid, lo planes), zero padded to ldo columns
+__global__ void split_bf16_kernel(const float *__restrict__ W, int rows, int K, int ld, uint16_t *__restrict__ out, int ldo)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)rows * ldo) return;
+    const int rr = (int)(t / ldo), c = (int)(t - (int64_t)rr * ldo);
+    const float x = c < K ? W[(int64_t)rr * ld + c] : 0.f;
+    const __bf16 hb = (__bf16)x;
+    const float r1 = x - (float)hb;
+    const __bf16 mb = (__bf16)r1;
+    const __bf16 lb = (__bf16)(r1 - (float)mb);
+    const int64_t plane = (int64_t)rows * ldo;
+    out[t] = __builtin_bit_cast(uint16_t, hb);
+    out[t + plane] = __builtin_bit_cast(uint16_t, mb);
+    out[t + 2 * plane] = __builtin_bit_cast(uint16_t, lb);
+}
+
+extern "C" int tgp_split_bf16(const float *W, int rows, int K, int ld, uint16_t *out, int ldo, tgp_stream_t stream)
+{
+    TGP_REQUIRE(W && out && rows > 0 && K > 0 && ld >= K && ldo >= K && (ldo & 15) == 0);
+    hipLaunchKernelGGL(split_bf16_kernel, dim3(tgp_cdiv((int64_t)rows * ldo, 256)), dim3(256), 0, tgp_hs(stream), W, rows, K,
+                       ld, out, ldo);
+    return TGP_LAUNCH_RESULT();
+}
+
+// Main kernel, 1024 threads (16 waves = 4 per SIMD, one workgroup per CU): blocks [0, tiles_big) take
+// 256x256 tiles (N fastest, then M, then batch); the remaining blocks cover the leftover M rows with 128x128
+// tiles.  M = B*1028 rarely divides into whole rounds of 256 resident workgroups (e.g. 129 x 16 = 2064 tiles
+// = 8.06 rounds -> 9); handing the last M-tile rows to quarter-size tiles, dispatched last, fills the final
+// round instead.
+#define GEMM_BIG 256
+#define GEMM_MID 128
+__global__ __launch_bounds__(1024) void gemm_main_kernel(GemmParams p)
+{
+    __shared__ __attribute__((aligned(16))) float smem[(GEMM_BIG + GEMM_BIG) * (16 + GEMM_LDPAD)];
+    int L = blockIdx.x;
+    if (L < p.tiles_big) {
+        const int per_batch = p.mt_big * p.tiles_n_big;
+        const int z = L / per_batch;
+        L -= z * per_batch;
+        gemm_tile<GEMM_BIG, GEMM_BIG, 4, 4, 16, false, false, false>(p, (L / p.tiles_n_big) * GEMM_BIG,
+                                                                     (L % p.tiles_n_big) * GEMM_BIG, z, smem);
+    } else {
+        L -= p.tiles_big;
+        const int per_batch = p.tiles_m_small * p.tiles_n_small;
+        const int z = L / per_batch;
+        L -= z * per_batch;
+        gemm_tile<GEMM_MID, GEMM_MID, 4, 4, 16, false, false, false>(p, p.mt_big * GEMM_BIG + (L / p.tiles_n_small) * GEMM_MID,
+                                                                     (L % p.tiles_n_small) * GEMM_MID, z, smem);
+    }
+}
+
+// 256-thread schedule (two 73.7 KB workgroups per CU): 128x128 tiles + a tail of 64x64 tiles.  Better than the
+// 1024-thread schedule when a launch has only one to three rounds of tiles (finer quantisation, and the second
+// resident workgroup overlaps another one's prologue/epilogue).
+__global__ __launch_bounds__(256) void gemm_main256_kernel(GemmParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int L = blockIdx.x;
@@ -239,13 +538,13 @@ __global__ __launch_bounds__(256) void gemm_main_kernel(GemmParams p)
         const int per_batch = p.mt_big * p.tiles_n_big;
         const int z = L / per_batch;
         L -= z * per_batch;
-        gemm_tile<128, 128, false, false>(p, (L / p.tiles_n_big) * 128, (L % p.tiles_n_big) * 128, z, smem);
+        gemm_tile<128, 128, 2, 2, 32, true, false, false>(p, (L / p.tiles_n_big) * 128, (L % p.tiles_n_big) * 128, z, smem);
     } else {
         L -= p.tiles_big;
         const int per_batch = p.tiles_m_small * p.tiles_n_small;
         const int z = L / per_batch;
         L -= z * per_batch;
-        gemm_tile<64, 64, false, false>(p, p.mt_big * 128 + (L / p.tiles_n_small) * 64, (L % p.tiles_n_small) * 64, z, smem);
+        gemm_tile<64, 64, 2, 2, 32, true, false, false>(p, p.mt_big * 128 + (L / p.tiles_n_small) * 64, (L % p.tiles_n_small) * 64, z, smem);
     }
 }
 
@@ -253,7 +552,7 @@ template <bool NAT, bool DIST>
 __global__ __launch_bounds__(256) void gemm_small_kernel(GemmParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    gemm_tile<64, 64, NAT, DIST>(p, blockIdx.y * 64, blockIdx.x * 64, blockIdx.z, smem);
+    gemm_tile<64, 64, 2, 2, 32, true, NAT, DIST>(p, blockIdx.y * 64, blockIdx.x * 64, blockIdx.z, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -295,17 +594,30 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(GemmParams p)
             }
         }
     }
+    // Lane reduction by recursive halving: at each step a lane keeps one half of its live values and adds the
+    // partner lane's copy of that half (126 cross-lane moves instead of 128 x 6); lane l ends with the totals
+    // of flattened indices 2l and 2l+1 (index = column * 32 + row).
+    float v[SKINNY_COLS * 32];
 #pragma unroll
-    for (int c = 0; c < SKINNY_COLS; ++c) {
-        float mine = 0.f;
+    for (int c = 0; c < SKINNY_COLS; ++c)
 #pragma unroll
-        for (int m = 0; m < 32; ++m) {
-            float s = acc[c][m];
+        for (int m = 0; m < 32; ++m) v[c * 32 + m] = acc[c][m];
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-            if (lane == m) mine = s;
+    for (int step = 0; step < 6; ++step) {
+        const int half = (SKINNY_COLS * 16) >> step;
+        const int off = 32 >> step;
+        const bool up = (lane & off) != 0;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+            const float keep = up ? v[i + half] : v[i];
+            const float send = up ? v[i] : v[i + half];
+            v[i] = keep + __shfl_xor(send, off, 64);
         }
-        if (lane < 32) red[wave][c][lane] = mine;
+    }
+    {
+        float *flat = &red[wave][0][0];
+        flat[2 * lane] = v[0];
+        flat[2 * lane + 1] = v[1];
     }
     __syncthreads();
     // 128 threads finish: thread -> (column c, row m)
@@ -336,7 +648,7 @@ static int resident_slots(void)
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
-        slots = 2 * cus; // two 73.7 KB workgroups per CU
+        slots = cus; // one 1024-thread workgroup per CU
     }
     return slots;
 }
@@ -344,47 +656,80 @@ static int resident_slots(void)
 template <bool NAT, bool DIST>
 static int launch_small(const GemmParams &p, hipStream_t stream)
 {
-    const size_t lds = (size_t)2 * (64 + 64) * GEMM_LD * sizeof(float);
+    const size_t lds = (size_t)2 * (64 + 64) * (32 + GEMM_LDPAD) * sizeof(float);
     hipLaunchKernelGGL((gemm_small_kernel<NAT, DIST>), dim3(tgp_cdiv(p.N, 64), tgp_cdiv(p.M, 64), p.batch), dim3(256), lds,
                        stream, p);
     return TGP_LAUNCH_RESULT();
 }
 
-// Split the M-tile rows between 128x128 tiles and a tail of 64x64 tiles so that the tail round is filled.
+// Split the M-tile rows between big tiles and a tail of half-size tiles so that the last round is filled.
+// Returns the estimated duration in units of one big tile; fills the schedule fields of p.
+static double plan_tiles(GemmParams &p, int big, int64_t S, double tail_cost, int tail_per_idle)
+{
+    const int small = big / 2;
+    const int rows_big = tgp_cdiv(p.M, big), tiles_nb = tgp_cdiv(p.N, big), tiles_ns = tgp_cdiv(p.N, small);
+    auto estimate = [&](int mt) {
+        const int64_t tb = (int64_t)mt * tiles_nb * p.batch;
+        const int left = p.M - mt * big;
+        const int64_t ts = left > 0 ? (int64_t)tgp_cdiv(left, small) * tiles_ns * p.batch : 0;
+        const int64_t idle = (S - tb % S) % S;                 // slots the last big round leaves idle
+        const int64_t ts_after = ts > idle * tail_per_idle ? ts - idle * tail_per_idle : 0;
+        return (double)((tb + S - 1) / S) + tail_cost * (double)((ts_after + S - 1) / S);
+    };
+    int best_mt = rows_big; // (a) every row on big tiles
+    double best = estimate(rows_big);
+    const int64_t per_row = (int64_t)tiles_nb * p.batch;
+    const int mt_b = (int)((((int64_t)rows_big * per_row) / S) * S / per_row); // (b) whole rows up to the last full round
+    if (mt_b < rows_big && estimate(mt_b) < best) best = estimate(mt_b), best_mt = mt_b;
+    if (estimate(0) < best) best = estimate(0), best_mt = 0;                   // (c) everything on half-size tiles
+    p.mt_big = best_mt;
+    p.tiles_n_big = tiles_nb;
+    p.tiles_big = best_mt * tiles_nb * p.batch;
+    const int rows_left = p.M - best_mt * big;
+    p.tiles_m_small = rows_left > 0 ? tgp_cdiv(rows_left, small) : 0;
+    p.tiles_n_small = tiles_ns;
+    return best;
+}
+
+int tgp_split_bk = 32; // development switch (scripts/gemm_ab.py): K-tile of the split kernel, 16 or 32
+
+static int launch_split(GemmParams &p, hipStream_t stream)
+{
+    plan_tiles(p, GEMM_BIG, resident_slots(), 0.27, 3);
+    const int total = p.tiles_big + p.tiles_m_small * p.tiles_n_small * p.batch;
+    if (tgp_split_bk == 16)
+        hipLaunchKernelGGL(gemm_split_kernel<16>, dim3(total), dim3(1024), 0, stream, p);
+    else
+        hipLaunchKernelGGL(gemm_split_kernel<32>, dim3(total), dim3(1024), 0, stream, p);
+    return TGP_LAUNCH_RESULT();
+}
+
+extern "C" void tgp_debug_set_split_bk(int bk) { tgp_split_bk = (bk == 16) ? 16 : 32; }
+
 static int launch_main(GemmParams &p, hipStream_t stream)
 {
-    const int S = resident_slots();
-    const int tiles_m = tgp_cdiv(p.M, 128), tiles_n = tgp_cdiv(p.N, 128);
-    const int64_t T = (int64_t)tiles_m * tiles_n * p.batch;
-    const double small_cost = 0.3; // a 64x64 tile in units of a 128x128 tile (measured ~0.27-0.3)
-    // candidate (a): every row on big tiles
-    int best_mt = tiles_m;
-    double best = (double)((T + S - 1) / S);
-    // candidate (b): big tiles for whole M-tile rows up to the last full round, small tiles for the rest
-    const int64_t cap = (T / S) * S;
-    const int mt_b = (int)(cap / ((int64_t)tiles_n * p.batch));
-    if (mt_b < tiles_m) {
-        const int64_t tb = (int64_t)mt_b * tiles_n * p.batch;
-        const int rows_left = p.M - mt_b * 128;
-        const int64_t ts = (int64_t)tgp_cdiv(rows_left, 64) * tgp_cdiv(p.N, 64) * p.batch;
-        const double est = (double)((tb + S - 1) / S) + small_cost * (double)((ts + S - 1) / S);
-        if (est < best) best = est, best_mt = mt_b;
+    const int cus = resident_slots();
+    // Cost of one round of tiles in microseconds per unit of K, measured inside the forward on MI355X (rocprof,
+    // profiles/r01_b and r01_c): 1024-thread schedule 0.285 (wide GEMM 2.99 ms = 8.27 rounds x 1292), 256-thread
+    // schedule 0.142 (3.01 ms = 16.3 rounds x 1292; decoder conv0 421 us = 2.3 rounds).  The 1024-thread tiles win
+    // when their round count is favourable (e.g. the K=128 projection GEMMs), the 256-thread ones otherwise.
+    GemmParams q = p;
+    const double t1024 = plan_tiles(p, GEMM_BIG, cus, 0.27, 3) * 0.285;
+    const double t256 = plan_tiles(q, 128, 2 * (int64_t)cus, 0.3, 3) * 0.142;
+    if (t1024 <= t256) {
+        const int total = p.tiles_big + p.tiles_m_small * p.tiles_n_small * p.batch;
+        hipLaunchKernelGGL(gemm_main_kernel, dim3(total), dim3(1024), 0, stream, p);
+        return TGP_LAUNCH_RESULT();
     }
-    p.mt_big = best_mt;
-    p.tiles_n_big = tiles_n;
-    p.tiles_big = best_mt * tiles_n * p.batch;
-    const int rows_left = p.M - best_mt * 128;
-    p.tiles_m_small = rows_left > 0 ? tgp_cdiv(rows_left, 64) : 0;
-    p.tiles_n_small = tgp_cdiv(p.N, 64);
-    const int total = p.tiles_big + p.tiles_m_small * p.tiles_n_small * p.batch;
-    const size_t lds = (size_t)2 * (128 + 128) * GEMM_LD * sizeof(float);
+    const int total = q.tiles_big + q.tiles_m_small * q.tiles_n_small * q.batch;
+    const size_t lds = (size_t)2 * (128 + 128) * (32 + GEMM_LDPAD) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        const int e = set_lds_limit(reinterpret_cast<const void *>(gemm_main_kernel), lds);
+        const int e = set_lds_limit(reinterpret_cast<const void *>(gemm_main256_kernel), lds);
         if (e) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_main_kernel, dim3(total), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(gemm_main256_kernel, dim3(total), dim3(256), lds, stream, q);
     return TGP_LAUNCH_RESULT();
 }
 
@@ -416,8 +761,18 @@ extern "C" int tgp_gemm_f32(const tgp_gemm_args *a, tgp_stream_t stream)
         hipLaunchKernelGGL(skinny_gemm_kernel, dim3(tgp_cdiv(a->N, SKINNY_COLS)), dim3(256), 0, tgp_hs(stream), p);
         return TGP_LAUNCH_RESULT();
     }
-    const int64_t big_tiles = (int64_t)tgp_cdiv(a->M, 128) * tgp_cdiv(a->N, 128) * p.batch;
-    if (big_tiles >= resident_slots() / 2 && a->N > 64) return launch_main(p, tgp_hs(stream));
+    const int64_t mid_tiles = (int64_t)tgp_cdiv(a->M, GEMM_MID) * tgp_cdiv(a->N, GEMM_MID) * p.batch;
+    if (mid_tiles >= resident_slots() / 2 && a->N > 64) {
+        if (a->W_split) {
+            TGP_REQUIRE(a->ldws >= ((a->K + 15) & ~15) && (a->ldws & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(a->W_split) & 7) == 0);
+            p.Wsplit = a->W_split, p.ldws = a->ldws;
+            p.plane = (int64_t)a->N * a->ldws * (a->batch > 0 ? a->batch : 1);
+            p.sWS = (int64_t)a->N * a->ldws;
+            return launch_split(p, tgp_hs(stream));
+        }
+        return launch_main(p, tgp_hs(stream));
+    }
     return launch_small<false, false>(p, tgp_hs(stream));
 }
 

@@ -50,6 +50,7 @@ def pack_encoder(sd, e, device):
     c0["ste"] = _pad_cols(sd[e + "conv_0.STE_layer.weight"][:, :, 0], 4)           # (128, 3 -> 4)
     w2 = sd[e + "conv_0.conv2.weight"][:, :, 0]
     c0["w1"], c0["w2"] = w2[:, :128].contiguous(), w2[:, 128:].contiguous()
+    c0["w1_s"] = ops.split_bf16(c0["w1"])
     conv.append(c0)
     for i, (cin, cout) in enumerate(LEVEL_CH, start=1):
         p = e + "conv_%d." % i
@@ -57,9 +58,11 @@ def pack_encoder(sd, e, device):
         c["sdn"] = ops.normalize_dirs(sd[p + "directions"])
         # one GEMM operand: rows [weights^T (8*Cout) ; STE (Cout)], bias [bias ; 0]
         c["wcat"] = torch.cat([sd[p + "weights"].t(), sd[p + "STE_layer.weight"][:, :, 0]], dim=0).contiguous()
+        c["wcat_s"] = ops.split_bf16(c["wcat"])
         c["bcat"] = torch.cat([sd[p + "bias"], torch.zeros(cout, device=device)]).contiguous()
         w2 = sd[p + "conv2.weight"][:, :, 0]
         c["w1"], c["w2"] = w2[:, :cout].contiguous(), w2[:, cout:].contiguous()
+        c["w1_s"] = ops.split_bf16(c["w1"])
         if i <= 3:
             c["scale"], c["shift"] = _bn_fold(sd, e + "bn%d" % i)
         conv.append(c)
@@ -80,7 +83,8 @@ def pack_decoder(sd, d):
         w = sd[d + conv + ".weight"][:, :, 0]
         if w.shape[1] == FEAT_C:
             w = _pad_cols(w, FEAT_LD)
-        dec.append((w.contiguous(), sd[d + conv + ".bias"].contiguous()) + _bn_fold(sd, d + bn))
+        w = w.contiguous()
+        dec.append((w, sd[d + conv + ".bias"].contiguous()) + _bn_fold(sd, d + bn) + (ops.split_bf16(w),))
     return dec, (sd[d + "recon_head.3.weight"][:, :, 0].contiguous(), sd[d + "recon_head.3.bias"].contiguous())
 
 
@@ -104,7 +108,7 @@ def pack_wide(ph, heads):
     z = torch.zeros(1024, device=dev)
     cat = lambda i: torch.cat([hd["c1"][i] for hd in heads]).contiguous()
     c2 = lambda i: torch.stack([hd["c2"][i] for hd in heads]).contiguous()
-    return dict(
+    w = dict(
         W=torch.cat([ph["w5"]] + [hd["c1"][0] for hd in heads], dim=0).contiguous(),
         bias=torch.cat([z, cat(1)]).contiguous(),
         scale=torch.cat([ph["bn5c"][0], cat(2)]).contiguous(),
@@ -112,6 +116,9 @@ def pack_wide(ph, heads):
         slope=torch.cat([z + 0.2, torch.zeros(3072, device=dev)]).contiguous(),
         k_alg=(FEAT_C + sum(hd["k_alg"] for hd in heads)) / 4.0,
         W2=c2(0), b2=c2(1), scale2=c2(2), shift2=c2(3))
+    w["Ws"] = ops.split_bf16(w["W"])
+    w["W2s"] = ops.split_bf16(w["W2"])
+    return w
 
 
 class Packed(object):
@@ -162,7 +169,7 @@ def surface_layer(c, xyz, idx_rf, idx_orl, out, scale=None, shift=None, act=None
     xyz4[:, :, :3].copy_(xyz)
     ste = ops.linear_rows(xyz4, c["ste"])
     ops.linear_rows(g, c["w1"], out=out, rowbias=rb, rows_per_obj=n, res1=g, res2=ste, scale=scale, shift=shift,
-                    act=0 if act is None else 1, slope=0.0)
+                    act=0 if act is None else 1, slope=0.0, w_split=c.get("w1_s"))
     return out
 
 
@@ -170,11 +177,11 @@ def hs_layer(c, xyz, fmap, idx_rf, idx_orl, out, scale=None, shift=None, act=Non
     """HS_layer.forward (gcn3d.py:142-155) + the caller's BatchNorm(eval)/ReLU, written to `out`."""
     B, n, _ = xyz.shape
     C = c["C"]
-    proj9 = ops.linear_rows(fmap, c["wcat"], bias=c["bcat"])                    # (B,n,9C): centre|support|STE
+    proj9 = ops.linear_rows(fmap, c["wcat"], bias=c["bcat"], w_split=c.get("wcat_s"))   # (B,n,9C): centre|support|STE
     g = ops.gconv_hs(xyz, idx_rf, proj9, c["sdn"], 7, C)
     rb = ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
     ops.linear_rows(g, c["w1"], out=out, rowbias=rb, rows_per_obj=n, res1=g, res2=proj9[:, :, 8 * C:], scale=scale,
-                    shift=shift, act=0 if act is None else 1, slope=0.0)
+                    shift=shift, act=0 if act is None else 1, slope=0.0, w_split=c.get("w1_s"))
     return out
 
 
@@ -260,11 +267,11 @@ def wide_forward(pk, feat, N):
     H = torch.empty(M, 3072, device=dev, dtype=torch.float32)
     ops.gemm(feat, w["W"], H, M=M, N=4096, K=FEAT_LD, lda=FEAT_LD, ldw=FEAT_LD, ldc=3072, bias=w["bias"],
              scale=w["scale"], shift=w["shift"], act=1, slope_vec=w["slope"], colmax_keys=keys5, cm_cols=1024,
-             c_col0=1024, rows_per_obj=N, k_alg=w["k_alg"])
+             c_col0=1024, rows_per_obj=N, k_alg=w["k_alg"], w_split=w["Ws"])
     keys2 = torch.zeros(3, B, 256, device=dev, dtype=torch.int32)
     ops.gemm(H, w["W2"], None, M=M, N=256, K=1024, lda=3072, ldw=1024, ldc=0, bias=w["b2"], scale=w["scale2"],
              shift=w["shift2"], act=1, slope=0.0, colmax_keys=keys2, rows_per_obj=N, batch=3,
-             batch_strides=(1024, 256 * 1024, 0, 256, B * 256))
+             batch_strides=(1024, 256 * 1024, 0, 256, B * 256), w_split=w["W2s"])
     return keys5, ops.colmax_decode(keys2.view(3 * B, 256)).view(3, B, 256)
 
 
@@ -281,12 +288,12 @@ def decoder_forward(pk, feat, back, N):
     conv(feat + back) = conv(feat) + W @ back: the broadcast add of the topology code becomes a
     per-object bias of the first GEMM, so (B,1286,N) feat_ph is never materialised."""
     B = feat.shape[0]
-    w0, b0, sc0, sh0 = pk.dec[0]
+    w0, b0, sc0, sh0, ws0 = pk.dec[0]
     x = feat
     rb = ops.linear_rows(back, w0) if back is not None else None
-    x = ops.linear_rows(x, w0, bias=b0, rowbias=rb, rows_per_obj=N, scale=sc0, shift=sh0, act=1, k_alg=FEAT_C)
-    for w, b, sc, sh in pk.dec[1:]:
-        x = ops.linear_rows(x, w, bias=b, scale=sc, shift=sh, act=1)
+    x = ops.linear_rows(x, w0, bias=b0, rowbias=rb, rows_per_obj=N, scale=sc0, shift=sh0, act=1, k_alg=FEAT_C, w_split=ws0)
+    for w, b, sc, sh, ws in pk.dec[1:]:
+        x = ops.linear_rows(x, w, bias=b, scale=sc, shift=sh, act=1, w_split=ws)
     return ops.linear_rows(x, pk.dec_out[0], bias=pk.dec_out[1])
 
 

@@ -173,6 +173,23 @@ def fill_tail(obj_id, xyz_c, feat, col0, n_cls):
           "tgp_fill_tail")
 
 
+# "split": launches large enough for the tile kernels use the bf16x3 operand-split kernel when the caller
+# supplies pre-split weights (fp32-level accuracy on the bf16 matrix cores); "fp32": always the fp32 MFMA kernels.
+GEMM_MODE = "split"
+
+
+def split_bf16(W):
+    """W (..., rows, K) fp32 with contiguous rows -> int16 tensor (3, ..., rows, ldo) of bf16 bit patterns: the hi /
+    mid / lo planes consumed by the split GEMM kernel (ldo = K rounded up to 16, zero padded)."""
+    W = W.contiguous()
+    K = W.shape[-1]
+    rows = W.numel() // K
+    ldo = (K + 15) // 16 * 16
+    out = torch.empty((3,) + tuple(W.shape[:-1]) + (ldo,), device=W.device, dtype=torch.int16)
+    check(_lib.lib().tgp_split_bf16(_p(W), rows, K, K, _p(out), ldo, _stream(W)), "tgp_split_bf16")
+    return out
+
+
 # bench.py sets this to a list to time, with HIP events on the launch stream, every launch that the
 # library routes to its 128x128-tile MFMA kernel (same rule as tgp_gemm_f32 in csrc/gemm.hip).
 GEMM_TIMER = None
@@ -186,16 +203,16 @@ _BIG_THR = None
 
 
 def _big_tile_threshold():
-    """resident_slots() / 2 of csrc/gemm.hip: one 128x128 workgroup per CU"""
+    """resident_slots() / 2 of csrc/gemm.hip (slots = CUs: one 1024-thread workgroup per CU)"""
     global _BIG_THR
     if _BIG_THR is None:
-        _BIG_THR = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+        _BIG_THR = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count // 2
     return _BIG_THR
 
 
 def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, bias=None, rowbias=None,
          rows_per_obj=0, res1=None, ldr1=0, res2=None, ldr2=0, scale=None, shift=None, act=0, slope=0.0,
-         colmax_keys=None, k_alg=None, slope_vec=None, cm_cols=0, c_col0=0, batch=1, batch_strides=None):
+         colmax_keys=None, k_alg=None, slope_vec=None, cm_cols=0, c_col0=0, batch=1, batch_strides=None, w_split=None):
     """Raw call into tgp_gemm_f32.  A/W/C/res* are tensors whose data_ptr is the first element of the
     operand (views into wider buffers are fine); all sizes/strides are explicit.  k_alg: the layer's
     true input width when K includes zero padding (only used for FLOP accounting in bench.py)."""
@@ -218,6 +235,8 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
     a.slope_vec, a.cm_cols, a.c_col0, a.batch = _p(slope_vec), cm_cols, c_col0, batch
     if batch_strides is not None:
         (a.batch_stride_a, a.batch_stride_w, a.batch_stride_c, a.batch_stride_vec, a.batch_stride_colmax) = batch_strides
+    if w_split is not None and GEMM_MODE == "split":
+        a.W_split, a.ldws = _p(w_split), w_split.shape[-1]
     check(_lib.lib().tgp_gemm_f32(ctypes.byref(a), _stream(A)), "tgp_gemm_f32")
     if timed:
         e1.record(torch.cuda.current_stream(A.device))
@@ -226,7 +245,7 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
 
 
 def linear_rows(x, weight, bias=None, scale=None, shift=None, act=0, slope=0.0, out=None, rowbias=None,
-                rows_per_obj=0, res1=None, res2=None, colmax_keys=None, want_out=True, k_alg=None):
+                rows_per_obj=0, res1=None, res2=None, colmax_keys=None, want_out=True, k_alg=None, w_split=None):
     """x (..., K) rows (row stride >= K), weight (N, Kw>=K) -> (..., N).  Convenience over gemm()."""
     x, lda = _rows(x, "x")
     weight, ldw = _rows(weight, "weight")
@@ -246,7 +265,7 @@ def linear_rows(x, weight, bias=None, scale=None, shift=None, act=0, slope=0.0, 
         r2, l2 = _rows(res2, "res2")
     gemm(x, weight, out if want_out else None, M=M, N=N, K=K, lda=lda, ldw=ldw, ldc=ldc, bias=bias, rowbias=rowbias,
          rows_per_obj=rows_per_obj, res1=r1, ldr1=l1, res2=r2, ldr2=l2, scale=scale, shift=shift, act=act, slope=slope,
-         colmax_keys=colmax_keys, k_alg=k_alg)
+         colmax_keys=colmax_keys, k_alg=k_alg, w_split=w_split)
     return out
 
 
