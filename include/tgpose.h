@@ -133,15 +133,16 @@ typedef struct tgp_gemm_args {
      * A + b*batch_stride_a etc. (element strides; vec = bias/scale/shift/slope_vec). */
     int batch;
     int64_t batch_stride_a, batch_stride_w, batch_stride_c, batch_stride_vec, batch_stride_colmax;
-    /* Optional: W pre-split into three bf16 planes by tgp_split_bf16 ([3][batch*N][ldws], ldws % 16 == 0).  When
+    /* Optional: W pre-split into three bf16 terms by tgp_split_bf16 ([batch*N][ldws/16][3][16], ldws % 16 == 0).  When
      * given, launches that are large enough for the tile kernels run on the bf16 matrix cores with the
      * 3-term operand split (six MFMA terms, fp32 accumulate): fp32-level accuracy at 2.67x fewer MFMA cycles.
      * W itself is still required (small launches and the skinny kernel read it). */
     const uint16_t *W_split; int ldws;
 } tgp_gemm_args;
 
-/* W (rows, K) fp32, row stride ld -> out: three bf16 planes [3][rows][ldo] (hi, mid, lo; x = hi+mid+lo to
- * 2^-24), columns K..ldo-1 zero.  Done once per weight version. */
+/* W (rows, K) fp32, row stride ld -> out[rows][ldo/16][3][16] bf16: per 16-wide K-tile the hi, mid and lo terms
+ * (x = hi+mid+lo to 2^-24) stored back to back; columns K..ldo-1 zero.  3*rows*ldo elements.  Done once per
+ * weight version. */
 int tgp_split_bf16(const float *W, int rows, int K, int ld, uint16_t *out, int ldo, tgp_stream_t stream);
 
 /* nn.Conv1d(kernel 1) / nn.Linear on channel-last rows with the fused epilogue above. */

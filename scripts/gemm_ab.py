@@ -36,8 +36,13 @@ for (M, N, K) in ((32768, 4096, 1280), (32896, 4096, 1292), (32896, 512, 1292), 
     e32 = (C[:300].double() - ref).abs().max().item()
     WS = ops.split_bf16(W[:, :K].contiguous())
     C.zero_()
-    res["split bf16x3"] = timeit(lambda: ops.gemm(A, W, C, M=M, N=N, K=K, lda=LD, ldw=LD, ldc=N, w_split=WS))
-    es = (C[:300].double() - ref).abs().max().item()
+    es = 0.0
+    for sv, nm in ((0, "single buffer"), (1, "double buffer")):
+        lib.tgp_debug_set_split_variant(sv)
+        C.zero_()
+        res["split " + nm] = timeit(lambda: ops.gemm(A, W, C, M=M, N=N, K=K, lda=LD, ldw=LD, ldc=N, w_split=WS))
+        es = max(es, (C[:300].double() - ref).abs().max().item())
+    lib.tgp_debug_set_split_variant(1)
     res["split bias+bn+relu"] = timeit(lambda: ops.gemm(A, W, C, M=M, N=N, K=K, lda=LD, ldw=LD, ldc=N, bias=bias, scale=scale, shift=shift, act=1, w_split=WS))
     print("   max |err| vs fp64: fp32-MFMA %.3e   bf16x3-split %.3e   (|ref| max %.2f)" % (e32, es, ref.abs().max().item()))
     res["prod bias+bn+relu"] = timeit(lambda: ops.gemm(A, W, C, M=M, N=N, K=K, lda=LD, ldw=LD, ldc=N, bias=bias, scale=scale, shift=shift, act=1))

@@ -274,10 +274,10 @@ def test_gemm_split_bf16_accuracy(ops, M, N, K, scale_a):
     ref = A[rows].double() @ W.double().t()
     dA, dW = g(A), g(W)
     ws = ops.split_bf16(dW)
-    assert ws.shape == (3, N, (K + 15) // 16 * 16) and ws.dtype == torch.int16
-    # the three planes reconstruct W to fp32 precision
-    planes = ws.view(torch.bfloat16).float()[:, :, :K]
-    assert (planes.sum(0).cpu().double() - W.double()).abs().max().item() <= 2.0 ** -22 * W.abs().max().item()
+    assert ws.shape == (N, (K + 15) // 16, 3, 16) and ws.dtype == torch.int16
+    # the three terms reconstruct W to fp32 precision
+    terms = ws.view(torch.bfloat16).float().permute(2, 0, 1, 3).reshape(3, N, -1)[:, :, :K]
+    assert (terms.sum(0).cpu().double() - W.double()).abs().max().item() <= 2.0 ** -22 * W.abs().max().item()
     old = ops.GEMM_MODE
     try:
         ops.GEMM_MODE = "split"

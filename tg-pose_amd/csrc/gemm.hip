@@ -45,7 +45,7 @@ struct GemmParams {
     const float *qrow;           // DIST epilogue
     const float *qcol;
     int64_t sq;
-    const uint16_t *Wsplit;      // bf16 planes [3][N][ldws] of W (hi, mid, lo), ldws % 16 == 0, zero padded
+    const uint16_t *Wsplit;      // bf16 (hi, mid, lo) of W as [N][ldws / 16][3][16], ldws % 16 == 0, zero padded
     int ldws;
     int64_t sWS;                 // per-batch stride of Wsplit in bf16 elements of one plane
     int64_t plane;               // elements between planes
@@ -290,19 +290,22 @@ __device__ __forceinline__ void split3(const float4 v, uint2 &hi, uint2 &mid, ui
     lo = __builtin_bit_cast(uint2, l);
 }
 
-// BK = 16: a thread stages 4 k of one row (8-byte plane pieces); BK = 32: 8 k (16-byte pieces, half the barriers).
-template <int BM, int BN, int NWM, int NWN, int BK>
+// W planes are stored interleaved per K-tile: Wsplit[row][k / 16][plane][16] bf16, so the 3 x 16 values one
+// K-tile needs from a row are 96 contiguous bytes = six 16-byte chunks (chunk c: plane c / 2, k half c % 2).
+template <int BM, int BN, int NWM, int NWN, bool DBUF>
 __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m0, const int n0, const int z, char *smem)
 {
     constexpr int THREADS = 64 * NWM * NWN;
-    constexpr int KPT = BK / 4;               // k per staging thread (4 threads per row)
-    constexpr int NF4 = KPT / 4;              // float4 per thread per row
-    constexpr int ROWB = BK * 2 + 16;         // LDS row of one plane: BK bf16 + 16 B pad (conflict-free ds_read_b128)
+    constexpr int BK = 16;
+    constexpr int ROWB = BK * 2 + 16;         // LDS row of one plane: 16 bf16 + 16 B pad (conflict-free ds_read_b128)
     constexpr int WTM = BM / NWM, WTN = BN / NWN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int RPP = THREADS / 4;
-    constexpr int PA = (BM + RPP - 1) / RPP, PW = (BN + RPP - 1) / RPP;
+    constexpr int RPP = THREADS / 4;          // A: 4 threads per row, one float4 each
+    constexpr int PA = (BM + RPP - 1) / RPP;
+    constexpr int WCH = BN * 6;               // W: 16-byte chunks per K-tile
+    constexpr int PW = (WCH + THREADS - 1) / THREADS;
     constexpr int PLANE_A = BM * ROWB, PLANE_W = BN * ROWB;
+    constexpr int BUFB = 3 * (PLANE_A + PLANE_W);
     char *lds_a = smem;
     char *lds_w = smem + 3 * PLANE_A;
 
@@ -312,73 +315,54 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
     const int r = lane & 31, h = lane >> 5;
     const float *A = p.A + (int64_t)z * p.sA;
     const uint16_t *WS = p.Wsplit + (int64_t)z * p.sWS;
+    const int64_t wrow = 3 * (int64_t)p.ldws; // elements per row of Wsplit
 
     const int kq = tid & 3, r0 = tid >> 2;
-    float4 ra[PA][NF4];
-    uint2 rw[PW][3][NF4];
+    float4 ra[PA];
+    uint4 rw[PW];
 
     auto load_tile = [&](int kt) {
-        const int kbase = kt * BK + kq * KPT;
+        const int kcol = kt * BK + kq * 4;
+        const bool kok = kcol < p.K;
+        const int kc = kok ? kcol : 0;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             if (RPP * i + r0 < BM) {
                 const int row = m0 + r0 + RPP * i;
-                const float *src = A + (int64_t)(row < p.M ? row : p.M - 1) * p.lda;
-#pragma unroll
-                for (int f = 0; f < NF4; ++f) {
-                    const int kcol = kbase + 4 * f;
-                    const bool ok = kcol < p.K && row < p.M;
-                    const float4 v = *reinterpret_cast<const float4 *>(src + (kcol < p.K ? kcol : 0));
-                    ra[i][f] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                const bool ok = kok && row < p.M;
+                const float4 v = *reinterpret_cast<const float4 *>(A + (int64_t)(row < p.M ? row : p.M - 1) * p.lda + kc);
+                ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
-            if (RPP * i + r0 < BN) {
-                const int row = n0 + r0 + RPP * i;
+            const int g = tid + THREADS * i;
+            if (g < WCH) {
+                const int row = n0 + g / 6, c = g % 6;
                 const bool ok = row < p.N;
-                const uint16_t *src = WS + (int64_t)(ok ? row : p.N - 1) * p.ldws;
-#pragma unroll
-                for (int q = 0; q < 3; ++q)
-#pragma unroll
-                    for (int f = 0; f < NF4; ++f) {
-                        const int kcol = kbase + 4 * f;               // planes are zero padded up to ldws
-                        const uint2 v = *reinterpret_cast<const uint2 *>(src + q * p.plane + (kcol < p.ldws ? kcol : 0));
-                        rw[i][q][f] = (ok && kcol < p.ldws) ? v : make_uint2(0u, 0u);
-                    }
+                const uint4 v = *reinterpret_cast<const uint4 *>(WS + (int64_t)(ok ? row : p.N - 1) * wrow + kt * 48 + c * 8);
+                rw[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
             }
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             if (RPP * i + r0 < BM) {
-                char *dst = lds_a + (r0 + RPP * i) * ROWB + kq * KPT * 2;
-                uint2 q[3][NF4];
-#pragma unroll
-                for (int f = 0; f < NF4; ++f) split3(ra[i][f], q[0][f], q[1][f], q[2][f]);
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    if constexpr (NF4 == 2)
-                        *reinterpret_cast<uint4 *>(dst + pl * PLANE_A) = make_uint4(q[pl][0].x, q[pl][0].y, q[pl][1].x, q[pl][1].y);
-                    else
-                        *reinterpret_cast<uint2 *>(dst + pl * PLANE_A) = q[pl][0];
-                }
+                char *dst = lds_a + buf * BUFB + (r0 + RPP * i) * ROWB + kq * 8;
+                uint2 q0, q1, q2;
+                split3(ra[i], q0, q1, q2);
+                *reinterpret_cast<uint2 *>(dst) = q0;
+                *reinterpret_cast<uint2 *>(dst + PLANE_A) = q1;
+                *reinterpret_cast<uint2 *>(dst + 2 * PLANE_A) = q2;
             }
         }
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
-            if (RPP * i + r0 < BN) {
-                char *dst = lds_w + (r0 + RPP * i) * ROWB + kq * KPT * 2;
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    if constexpr (NF4 == 2)
-                        *reinterpret_cast<uint4 *>(dst + pl * PLANE_W) =
-                            make_uint4(rw[i][pl][0].x, rw[i][pl][0].y, rw[i][pl][1].x, rw[i][pl][1].y);
-                    else
-                        *reinterpret_cast<uint2 *>(dst + pl * PLANE_W) = rw[i][pl][0];
-                }
+            const int g = tid + THREADS * i;
+            if (g < WCH) {
+                const int row = g / 6, c = g % 6;
+                *reinterpret_cast<uint4 *>(lds_w + buf * BUFB + (c >> 1) * PLANE_W + row * ROWB + (c & 1) * 16) = rw[i];
             }
         }
     };
@@ -393,89 +377,68 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
 
     const int numK = (p.K + BK - 1) / BK;
     load_tile(0);
-    store_tile();
+    store_tile(0);
     __syncthreads();
-    const char *as = lds_a + (wm * WTM + r) * ROWB + h * 16;
-    const char *ws = lds_w + (wn * WTN + r) * ROWB + h * 16;
     for (int kt = 0; kt < numK; ++kt) {
         const bool more = (kt + 1) < numK;
         if (more) load_tile(kt + 1);
+        const int cur = DBUF ? (kt & 1) : 0;
+        const char *as = lds_a + cur * BUFB + (wm * WTM + r) * ROWB + h * 16;
+        const char *ws = lds_w + cur * BUFB + (wn * WTN + r) * ROWB + h * 16;
+        bf16x8 a[TM][3];
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            if constexpr (BK == 16) { // all A fragments resident: 12 LDS reads per 24 MFMAs
-                bf16x8 a[TM][3];
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+            for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8 *>(as + i * 32 * ROWB + q * PLANE_A);
 #pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        a[i][q] = *reinterpret_cast<const bf16x8 *>(as + i * 32 * ROWB + q * PLANE_A + ks * 32);
+        for (int j = 0; j < TN; ++j) {
+            bf16x8 b[3];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    bf16x8 b[3];
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        b[q] = *reinterpret_cast<const bf16x8 *>(ws + j * 32 * ROWB + q * PLANE_W + ks * 32);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        // smallest terms first
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], acc[i][j], 0, 0, 0);
-                    }
-                }
-            } else { // register-lean order (the 8-k staging registers leave less room): one A plane live at a time
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    bf16x8 b[3];
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        b[q] = *reinterpret_cast<const bf16x8 *>(ws + j * 32 * ROWB + q * PLANE_W + ks * 32);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        const char *ap = as + i * 32 * ROWB + ks * 32;
-                        bf16x8 a = *reinterpret_cast<const bf16x8 *>(ap + 2 * PLANE_A);             // lo
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[0], acc[i][j], 0, 0, 0);
-                        a = *reinterpret_cast<const bf16x8 *>(ap + PLANE_A);                        // mid
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[0], acc[i][j], 0, 0, 0);
-                        a = *reinterpret_cast<const bf16x8 *>(ap);                                  // hi
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[2], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[0], acc[i][j], 0, 0, 0);
-                    }
-                }
-            }
+            for (int q = 0; q < 3; ++q) b[q] = *reinterpret_cast<const bf16x8 *>(ws + j * 32 * ROWB + q * PLANE_W);
+            // six terms, smallest first; consecutive MFMAs alternate between the accumulators of this column
+#define SPLIT_TERM(QA, QB)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) acc[i][j] =                                               \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][QA], b[QB], acc[i][j], 0, 0, 0);
+            SPLIT_TERM(0, 2)
+            SPLIT_TERM(2, 0)
+            SPLIT_TERM(1, 1)
+            SPLIT_TERM(0, 1)
+            SPLIT_TERM(1, 0)
+            SPLIT_TERM(0, 0)
+#undef SPLIT_TERM
         }
-        __syncthreads();
-        if (more) store_tile();
-        __syncthreads();
+        if (DBUF) {
+            if (more) store_tile((kt + 1) & 1);
+            __syncthreads();
+        } else {
+            __syncthreads();
+            if (more) store_tile(0);
+            __syncthreads();
+        }
     }
     gemm_epilogue<TM, TN, WTM, WTN, false>(p, acc, m0, n0, z, wm, wn, r, h);
 }
 
-template <int BK>
+template <bool DBUF>
 __global__ __launch_bounds__(1024) void gemm_split_kernel(GemmParams p)
 {
-    __shared__ __attribute__((aligned(16))) char smem[3 * (256 + 256) * (BK * 2 + 16)];
+    __shared__ __attribute__((aligned(16))) char smem[(DBUF ? 2 : 1) * 3 * (256 + 256) * 48];
     int L = blockIdx.x;
     if (L < p.tiles_big) {
         const int per_batch = p.mt_big * p.tiles_n_big;
         const int z = L / per_batch;
         L -= z * per_batch;
-        gemm_split_tile<256, 256, 4, 4, BK>(p, (L / p.tiles_n_big) * 256, (L % p.tiles_n_big) * 256, z, smem);
+        gemm_split_tile<256, 256, 4, 4, DBUF>(p, (L / p.tiles_n_big) * 256, (L % p.tiles_n_big) * 256, z, smem);
     } else {
         L -= p.tiles_big;
         const int per_batch = p.tiles_m_small * p.tiles_n_small;
         const int z = L / per_batch;
         L -= z * per_batch;
-        gemm_split_tile<128, 128, 4, 4, BK>(p, p.mt_big * 256 + (L / p.tiles_n_small) * 128, (L % p.tiles_n_small) * 128, z, smem);
+        gemm_split_tile<128, 128, 4, 4, DBUF>(p, p.mt_big * 256 + (L / p.tiles_n_small) * 128, (L % p.tiles_n_small) * 128, z, smem);
     }
 }
 
-// W (rows, K) fp32 row stride ld -> out[3][rows][ldo] bf16 (hi, mid, lo planes), zero padded to ldo columns
+// W (rows, K) fp32 row stride ld -> out[rows][ldo / 16][3][16] bf16 (hi, mid, lo per K-tile), zero padded to ldo
 __global__ void split_bf16_kernel(const float *__restrict__ W, int rows, int K, int ld, uint16_t *__restrict__ out, int ldo)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -486,10 +449,10 @@ __global__ void split_bf16_kernel(const float *__restrict__ W, int rows, int K, 
     const float r1 = x - (float)hb;
     const __bf16 mb = (__bf16)r1;
     const __bf16 lb = (__bf16)(r1 - (float)mb);
-    const int64_t plane = (int64_t)rows * ldo;
-    out[t] = __builtin_bit_cast(uint16_t, hb);
-    out[t + plane] = __builtin_bit_cast(uint16_t, mb);
-    out[t + 2 * plane] = __builtin_bit_cast(uint16_t, lb);
+    uint16_t *o = out + ((int64_t)rr * (ldo / 16) + c / 16) * 48 + (c & 15);
+    o[0] = __builtin_bit_cast(uint16_t, hb);
+    o[16] = __builtin_bit_cast(uint16_t, mb);
+    o[32] = __builtin_bit_cast(uint16_t, lb);
 }
 
 extern "C" int tgp_split_bf16(const float *W, int rows, int K, int ld, uint16_t *out, int ldo, tgp_stream_t stream)
@@ -691,20 +654,20 @@ static double plan_tiles(GemmParams &p, int big, int64_t S, double tail_cost, in
     return best;
 }
 
-int tgp_split_bk = 32; // development switch (scripts/gemm_ab.py): K-tile of the split kernel, 16 or 32
+int tgp_split_variant = 1; // development switch (scripts/gemm_ab.py): 0 single LDS buffer, 1 double buffer
 
 static int launch_split(GemmParams &p, hipStream_t stream)
 {
     plan_tiles(p, GEMM_BIG, resident_slots(), 0.27, 3);
-    const int total = p.tiles_big + p.tiles_m_small * p.tiles_n_small * p.batch;
-    if (tgp_split_bk == 16)
-        hipLaunchKernelGGL(gemm_split_kernel<16>, dim3(total), dim3(1024), 0, stream, p);
+    const dim3 grid(p.tiles_big + p.tiles_m_small * p.tiles_n_small * p.batch);
+    if (tgp_split_variant == 0)
+        hipLaunchKernelGGL(gemm_split_kernel<false>, grid, dim3(1024), 0, stream, p);
     else
-        hipLaunchKernelGGL(gemm_split_kernel<32>, dim3(total), dim3(1024), 0, stream, p);
+        hipLaunchKernelGGL(gemm_split_kernel<true>, grid, dim3(1024), 0, stream, p);
     return TGP_LAUNCH_RESULT();
 }
 
-extern "C" void tgp_debug_set_split_bk(int bk) { tgp_split_bk = (bk == 16) ? 16 : 32; }
+extern "C" void tgp_debug_set_split_variant(int v) { tgp_split_variant = v; }
 
 static int launch_main(GemmParams &p, hipStream_t stream)
 {
@@ -765,10 +728,10 @@ extern "C" int tgp_gemm_f32(const tgp_gemm_args *a, tgp_stream_t stream)
     if (mid_tiles >= resident_slots() / 2 && a->N > 64) {
         if (a->W_split) {
             TGP_REQUIRE(a->ldws >= ((a->K + 15) & ~15) && (a->ldws & 15) == 0 &&
-                        (reinterpret_cast<uintptr_t>(a->W_split) & 7) == 0);
+                        (reinterpret_cast<uintptr_t>(a->W_split) & 15) == 0);
             p.Wsplit = a->W_split, p.ldws = a->ldws;
-            p.plane = (int64_t)a->N * a->ldws * (a->batch > 0 ? a->batch : 1);
-            p.sWS = (int64_t)a->N * a->ldws;
+            p.plane = 0;
+            p.sWS = 3 * (int64_t)a->N * a->ldws;
             return launch_split(p, tgp_hs(stream));
         }
         return launch_main(p, tgp_hs(stream));

@@ -179,13 +179,13 @@ GEMM_MODE = "split"
 
 
 def split_bf16(W):
-    """W (..., rows, K) fp32 with contiguous rows -> int16 tensor (3, ..., rows, ldo) of bf16 bit patterns: the hi /
-    mid / lo planes consumed by the split GEMM kernel (ldo = K rounded up to 16, zero padded)."""
+    """W (..., rows, K) fp32 -> int16 tensor (..., rows, ldo // 16, 3, 16) of bf16 bit patterns: per 16-wide K-tile the
+    hi / mid / lo terms consumed by the split GEMM kernel (ldo = K rounded up to 16, zero padded)."""
     W = W.contiguous()
     K = W.shape[-1]
     rows = W.numel() // K
     ldo = (K + 15) // 16 * 16
-    out = torch.empty((3,) + tuple(W.shape[:-1]) + (ldo,), device=W.device, dtype=torch.int16)
+    out = torch.empty(tuple(W.shape[:-1]) + (ldo // 16, 3, 16), device=W.device, dtype=torch.int16)
     check(_lib.lib().tgp_split_bf16(_p(W), rows, K, K, _p(out), ldo, _stream(W)), "tgp_split_bf16")
     return out
 
@@ -236,7 +236,7 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
     if batch_strides is not None:
         (a.batch_stride_a, a.batch_stride_w, a.batch_stride_c, a.batch_stride_vec, a.batch_stride_colmax) = batch_strides
     if w_split is not None and GEMM_MODE == "split":
-        a.W_split, a.ldws = _p(w_split), w_split.shape[-1]
+        a.W_split, a.ldws = _p(w_split), w_split.shape[-3] * 16
     check(_lib.lib().tgp_gemm_f32(ctypes.byref(a), _stream(A)), "tgp_gemm_f32")
     if timed:
         e1.record(torch.cuda.current_stream(A.device))
