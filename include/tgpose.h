@@ -84,6 +84,11 @@ int64_t tgp_orl_partial_floats(int B, int n, int C);
 int tgp_orl_global(const float *feat, int ldf, const int32_t *idx, int B, int n, int k, int C, float *partial,
                    float *out, tgp_stream_t stream);
 
+/* get_ORL_global followed by the global half of ORL_forward's conv2 (gcn3d.py:108-112,182-186):
+ * g as above (optionally stored to g_out, may be NULL), rb[b,:] = g[b,:] @ W2^T with w2t = W2 transposed (C,C). */
+int tgp_orl_rowbias(const float *feat, int ldf, const int32_t *idx, int B, int n, int k, int C, float *partial,
+                    const float *w2t, float *g_out, float *rb, tgp_stream_t stream);
+
 /* gcn3d.py:219-245 Pool_layer.forward with the random subsample (randperm, :242) supplied by the
  * host: out_f[b,m,:] = max_{j<kpool} feat[b, idx[b, sample[m], j], :], out_xyz[b,m] = xyz[b, sample[m]].
  * idx has row stride ldi (>= kpool) so the k=4 list may be the prefix of a longer one. */

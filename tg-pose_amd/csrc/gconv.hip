@@ -244,6 +244,30 @@ __global__ void orl_finish_kernel(const float *__restrict__ partial, int B, int 
     out[t] = s / (float)n;
 }
 
+// Same as orl_finish_kernel, then rb[b, :] = g[b, :] @ W2^T: the "global" half of the layer's conv2
+// (gcn3d.py:108-112: conv2(cat[f, g]) = W1 f + W2 g).  One workgroup per object; w2t is W2 transposed (C_in, C_out)
+// so consecutive threads read consecutive floats.
+__global__ __launch_bounds__(256) void orl_finish_project_kernel(const float *__restrict__ partial, int n, int C, int ptiles,
+                                                                 const float *__restrict__ w2t, float *__restrict__ g_out,
+                                                                 float *__restrict__ rb)
+{
+    __shared__ float g[512];
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int p = 0; p < ptiles; ++p) s += partial[((int64_t)b * ptiles + p) * C + c];
+        s = s / (float)n;
+        g[c] = s;
+        if (g_out) g_out[(int64_t)b * C + c] = s;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < C; o += blockDim.x) {
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc = fmaf(g[c], w2t[(int64_t)c * C + o], acc);
+        rb[(int64_t)b * C + o] = acc;
+    }
+}
+
 extern "C" int64_t tgp_orl_partial_floats(int B, int n, int C)
 {
     if (B <= 0 || n <= 0 || C <= 0) return 0;
@@ -268,6 +292,26 @@ extern "C" int tgp_orl_global(const float *feat, int ldf, const int32_t *idx, in
 #undef ORL_GO
     hipLaunchKernelGGL(orl_finish_kernel, dim3(tgp_cdiv(B * C, 256)), dim3(256), 0, tgp_hs(stream), partial, B, n, C,
                        ptiles, out);
+    return TGP_LAUNCH_RESULT();
+}
+
+extern "C" int tgp_orl_rowbias(const float *feat, int ldf, const int32_t *idx, int B, int n, int k, int C, float *partial,
+                               const float *w2t, float *g_out, float *rb, tgp_stream_t stream)
+{
+    TGP_REQUIRE(feat && idx && partial && w2t && rb && B > 0 && n > 0 && k > 0);
+    if (k > GC_MAXK || !(C == 128 || C == 256 || C == 512)) return TGP_EUNSUPPORTED;
+    TGP_REQUIRE(ldf >= C && (ldf & 3) == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(partial) & 15) == 0);
+    const int ptiles = tgp_cdiv(n, ORL_PTS);
+#define ORL_GO(CC)                                                                                                   \
+    {                                                                                                                \
+        const int tiles = ptiles * RowLanes<CC>::CHUNKS;                                                             \
+        hipLaunchKernelGGL(orl_partial_kernel<CC>, dim3(tgp_xcd_grid(B, tiles)), dim3(256), 0, tgp_hs(stream), feat,  \
+                           ldf, idx, B, n, k, partial, ptiles, tiles);                                               \
+    }
+    if (C == 128) ORL_GO(128) else if (C == 256) ORL_GO(256) else ORL_GO(512)
+#undef ORL_GO
+    hipLaunchKernelGGL(orl_finish_project_kernel, dim3(B), dim3(256), 0, tgp_hs(stream), partial, n, C, ptiles, w2t, g_out, rb);
     return TGP_LAUNCH_RESULT();
 }
 

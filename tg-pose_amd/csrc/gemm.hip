@@ -529,6 +529,9 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(GemmParams p)
     __shared__ float red[4][SKINNY_COLS][32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nb = blockIdx.x * SKINNY_COLS;
+    const int z = blockIdx.y;
+    p.A += (int64_t)z * p.sA;
+    p.W += (int64_t)z * p.sW;
     float acc[SKINNY_COLS][32];
 #pragma unroll
     for (int c = 0; c < SKINNY_COLS; ++c)
@@ -588,11 +591,13 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(GemmParams p)
         const int c = threadIdx.x >> 5, m = threadIdx.x & 31;
         const int col = nb + c;
         if (m < p.M && col < p.N) {
+            const int64_t vo = (int64_t)z * p.sV;
             float v = ((red[0][c][m] + red[1][c][m]) + red[2][c][m]) + red[3][c][m];
-            v += (p.bias ? p.bias[col] : 0.f);
-            if (p.scale) v = v * p.scale[col] + (p.shift ? p.shift[col] : 0.f);
+            v += (p.bias ? p.bias[vo + col] : 0.f);
+            if (p.res1) v += p.res1[(int64_t)m * p.ldr1 + col];
+            if (p.scale) v = v * p.scale[vo + col] + (p.shift ? p.shift[vo + col] : 0.f);
             if (p.act == 1) v = v > 0.f ? v : v * p.slope;
-            p.C[(int64_t)m * p.ldc + col] = v;
+            p.C[(int64_t)z * p.sC + (int64_t)m * p.ldc + col] = v;
         }
     }
 }
@@ -718,10 +723,10 @@ extern "C" int tgp_gemm_f32(const tgp_gemm_args *a, tgp_stream_t stream)
     p.batch = a->batch > 0 ? a->batch : 1;
     p.sA = a->batch_stride_a, p.sW = a->batch_stride_w, p.sC = a->batch_stride_c, p.sV = a->batch_stride_vec;
     p.sCM = a->batch_stride_colmax;
-    const bool plain = !a->rowbias && !a->res1 && !a->res2 && !a->colmax_keys && !a->slope_vec && a->c_col0 == 0 &&
-                       p.batch == 1;
+    const bool plain = !a->rowbias && !a->res2 && !a->colmax_keys && !a->slope_vec && a->c_col0 == 0 &&
+                       (p.batch == 1 || !a->res1);
     if (a->M <= 32 && a->C && plain) {
-        hipLaunchKernelGGL(skinny_gemm_kernel, dim3(tgp_cdiv(a->N, SKINNY_COLS)), dim3(256), 0, tgp_hs(stream), p);
+        hipLaunchKernelGGL(skinny_gemm_kernel, dim3(tgp_cdiv(a->N, SKINNY_COLS), p.batch), dim3(256), 0, tgp_hs(stream), p);
         return TGP_LAUNCH_RESULT();
     }
     const int64_t mid_tiles = (int64_t)tgp_cdiv(a->M, GEMM_MID) * tgp_cdiv(a->N, GEMM_MID) * p.batch;

@@ -38,6 +38,12 @@ def _pad_cols(w, cols):
     return out
 
 
+def _pad_rows(w, rows):
+    out = torch.zeros((rows,) + tuple(w.shape[1:]), device=w.device, dtype=w.dtype)
+    out[: w.shape[0]] = w
+    return out
+
+
 def _dev_sd(sd, device):
     return {k: v.detach().to(device=device, dtype=torch.float32) for k, v in sd.items() if v.dtype.is_floating_point}
 
@@ -51,6 +57,7 @@ def pack_encoder(sd, e, device):
     w2 = sd[e + "conv_0.conv2.weight"][:, :, 0]
     c0["w1"], c0["w2"] = w2[:, :128].contiguous(), w2[:, 128:].contiguous()
     c0["w1_s"] = ops.split_bf16(c0["w1"])
+    c0["w2t"] = c0["w2"].t().contiguous()
     conv.append(c0)
     for i, (cin, cout) in enumerate(LEVEL_CH, start=1):
         p = e + "conv_%d." % i
@@ -63,6 +70,7 @@ def pack_encoder(sd, e, device):
         w2 = sd[p + "conv2.weight"][:, :, 0]
         c["w1"], c["w2"] = w2[:, :cout].contiguous(), w2[:, cout:].contiguous()
         c["w1_s"] = ops.split_bf16(c["w1"])
+        c["w2t"] = c["w2"].t().contiguous()
         if i <= 3:
             c["scale"], c["shift"] = _bn_fold(sd, e + "bn%d" % i)
         conv.append(c)
@@ -71,9 +79,13 @@ def pack_encoder(sd, e, device):
 
 def pack_ph(sd, ph):
     lin = lambda n: (sd[ph + n + ".weight"].contiguous(), sd[ph + n + ".bias"].contiguous())
+    l2, l3, l4, l5 = lin("linear2"), lin("linear3"), lin("linear4"), lin("linear5")
     return dict(w5=_pad_cols(sd[ph + "conv_5.0.weight"][:, :, 0], FEAT_LD), bn5c=_bn_fold(sd, ph + "conv_5.1"),
                 l1=sd[ph + "linear1.weight"].contiguous(), bn5=_bn_fold(sd, ph + "bn5"),
-                l2=lin("linear2"), l3=lin("linear3"), l4=lin("linear4"), l5=lin("linear5"))
+                # linear2 | linear3 share their input: one (5000, 1024) operand; linear4(pi1) + linear5(pi2) is one
+                # (1286, 5000) operand applied to [pi1 | pi2] with bias b4 + b5
+                l23=(torch.cat([l2[0], l3[0]], 0).contiguous(), torch.cat([l2[1], l3[1]]).contiguous()),
+                l45=(torch.cat([l4[0], l5[0]], 1).contiguous(), (l4[1] + l5[1]).contiguous()), n_code=l2[0].shape[0])
 
 
 def pack_decoder(sd, d):
@@ -118,6 +130,12 @@ def pack_wide(ph, heads):
         W2=c2(0), b2=c2(1), scale2=c2(2), shift2=c2(3))
     w["Ws"] = ops.split_bf16(w["W"])
     w["W2s"] = ops.split_bf16(w["W2"])
+    # conv3 / conv4 of the three heads as batched skinny GEMMs (conv4 rows padded to 8: outputs 4, 4, 6)
+    c3 = lambda i: torch.stack([hd["c3"][i] for hd in heads]).contiguous()
+    w["W3"], w["b3"], w["scale3"], w["shift3"] = c3(0), c3(1), c3(2), c3(3)
+    w["W4"] = torch.stack([_pad_rows(hd["c4"][0], 8) for hd in heads]).contiguous()
+    w["b4"] = torch.stack([_pad_rows(hd["c4"][1].unsqueeze(1), 8)[:, 0] for hd in heads]).contiguous()
+    w["n_out"] = [hd["c4"][0].shape[0] for hd in heads]
     return w
 
 
@@ -138,6 +156,27 @@ class Packed(object):
 def _i32(idx, device):
     """injected graph (any int dtype, any device, (B,n,k) or (B,n,1)) -> contiguous int32 on device"""
     return idx.to(device=device, dtype=torch.int32).contiguous()
+
+
+_PIN = {}
+
+
+def _upload_i32(t, device):
+    """small host index vector -> device int32 through a reused pinned staging buffer (asynchronous copy; a
+    pageable-memory copy would block the host until the stream drains and leave the GPU idle between forwards)"""
+    if t.is_cuda:
+        return t.to(device=device, dtype=torch.int32).contiguous()
+    n = t.numel()
+    ring = _PIN.setdefault(n, dict(slots=[[torch.empty(n, dtype=torch.int32).pin_memory(), None] for _ in range(4)], i=0))
+    ring["i"] = (ring["i"] + 1) % len(ring["slots"])
+    slot = ring["slots"][ring["i"]]
+    if slot[1] is not None:
+        slot[1].synchronize()          # the copy that last used this staging buffer has completed
+    slot[0].copy_(t)
+    out = slot[0].to(device, non_blocking=True)
+    slot[1] = torch.cuda.Event()
+    slot[1].record(torch.cuda.current_stream(device))
+    return out
 
 
 class Graphs(object):
@@ -164,7 +203,7 @@ def surface_layer(c, xyz, idx_rf, idx_orl, out, scale=None, shift=None, act=None
     B, n, _ = xyz.shape
     C = c["C"]
     g = ops.gconv_surface(xyz, idx_rf, c["sdn"], 7, C)
-    rb = ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
+    rb = ops.orl_rowbias(g, idx_orl, c["w2t"]) if "w2t" in c else ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
     xyz4 = torch.zeros(B, n, 4, device=xyz.device, dtype=torch.float32)
     xyz4[:, :, :3].copy_(xyz)
     ste = ops.linear_rows(xyz4, c["ste"])
@@ -179,7 +218,7 @@ def hs_layer(c, xyz, fmap, idx_rf, idx_orl, out, scale=None, shift=None, act=Non
     C = c["C"]
     proj9 = ops.linear_rows(fmap, c["wcat"], bias=c["bcat"], w_split=c.get("wcat_s"))   # (B,n,9C): centre|support|STE
     g = ops.gconv_hs(xyz, idx_rf, proj9, c["sdn"], 7, C)
-    rb = ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
+    rb = ops.orl_rowbias(g, idx_orl, c["w2t"]) if "w2t" in c else ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
     ops.linear_rows(g, c["w1"], out=out, rowbias=rb, rows_per_obj=n, res1=g, res2=proj9[:, :, 8 * C:], scale=scale,
                     shift=shift, act=0 if act is None else 1, slope=0.0, w_split=c.get("w1_s"))
     return out
@@ -191,8 +230,9 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6):
     B, N, _ = points_c.shape
     xyz = points_c
     feat = torch.empty(B, N, FEAT_LD, device=dev, dtype=torch.float32)
-    s1, s2 = (_i32(s, dev) for s in sample_idx)
-    N1, N2 = s1.numel(), s2.numel()
+    N1, N2 = sample_idx[0].numel(), sample_idx[1].numel()
+    s12 = _upload_i32(torch.cat([sample_idx[0].reshape(-1), sample_idx[1].reshape(-1)]), dev)
+    s1, s2 = s12[:N1], s12[N1:]
 
     knn0 = {}
 
@@ -238,12 +278,12 @@ def ph_tail(ph, keys, B, dev):
     """PH_Predictor after the max over points (FaceRecon.py:145-165): keys = colmax keys of conv_5."""
     g = ops.colmax_decode(keys, out2=True)                                       # cat((max, max), 1)
     fa = ops.linear_rows(g, ph["l1"], scale=ph["bn5"][0], shift=ph["bn5"][1], act=1, slope=0.2)
-    pi1 = ops.linear_rows(fa, ph["l2"][0], bias=ph["l2"][1])
-    pi2 = ops.linear_rows(fa, ph["l3"][0], bias=ph["l3"][1])
+    pi = ops.linear_rows(fa, ph["l23"][0], bias=ph["l23"][1])                    # (B, 5000) = [pi1 | pi2]
     back = torch.zeros(B, FEAT_LD, device=dev, dtype=torch.float32)
-    b1 = ops.linear_rows(pi1, ph["l4"][0], bias=ph["l4"][1])
-    ops.linear_rows(pi2, ph["l5"][0], bias=ph["l5"][1], res1=b1, out=back[:, :FEAT_C])
-    return ops.sigmoid(pi1), ops.sigmoid(pi2), back
+    ops.linear_rows(pi, ph["l45"][0], bias=ph["l45"][1], out=back[:, :FEAT_C])   # pi1_1 + pi2_1
+    h = ops.sigmoid(pi)
+    nc = ph["n_code"]
+    return h[:, :nc], h[:, nc:], back
 
 
 def ph_forward(pk, feat, N):
@@ -258,7 +298,8 @@ def ph_forward(pk, feat, N):
 
 def wide_forward(pk, feat, N):
     """conv_5 + the three head conv1 in one GEMM over `feat` (N_out = 4096), then the three head conv2
-    (+BN, ReLU, max over points) as one batched launch.  Returns (keys5 (B,1024), pooled (3,B,256))."""
+    (+BN, ReLU, max over points) as one batched launch, then conv3 / conv4 batched over the heads.
+    Returns (keys5 (B,1024), [green (B,4), red (B,4), ts (B,6)])."""
     B = feat.shape[0]
     dev = feat.device
     w = pk.wide
@@ -272,7 +313,15 @@ def wide_forward(pk, feat, N):
     ops.gemm(H, w["W2"], None, M=M, N=256, K=1024, lda=3072, ldw=1024, ldc=0, bias=w["b2"], scale=w["scale2"],
              shift=w["shift2"], act=1, slope=0.0, colmax_keys=keys2, rows_per_obj=N, batch=3,
              batch_strides=(1024, 256 * 1024, 0, 256, B * 256), w_split=w["W2s"])
-    return keys5, ops.colmax_decode(keys2.view(3 * B, 256)).view(3, B, 256)
+    pooled = ops.colmax_decode(keys2.view(3 * B, 256))                          # (3B, 256)
+    # conv3 (+BN, ReLU), dropout(eval) = identity, conv4: two batched launches for the three heads
+    x3 = torch.empty(3, B, 256, device=dev, dtype=torch.float32)
+    ops.gemm(pooled, w["W3"], x3, M=B, N=256, K=256, lda=256, ldw=256, ldc=256, bias=w["b3"], scale=w["scale3"],
+             shift=w["shift3"], act=1, slope=0.0, batch=3, batch_strides=(B * 256, 256 * 256, B * 256, 256, 0))
+    o4 = torch.empty(3, B, 8, device=dev, dtype=torch.float32)
+    ops.gemm(x3, w["W4"], o4, M=B, N=8, K=256, lda=256, ldw=256, ldc=8, bias=w["b4"], batch=3,
+             batch_strides=(B * 256, 8 * 256, B * 8, 8, 0))
+    return keys5, [o4[i, :, : w["n_out"][i]].contiguous() for i in range(3)]
 
 
 def head_tail(hd, pooled):
@@ -332,10 +381,9 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
     xyz, mean = ops.center(points)
     graphs = Graphs(points.device, inject, record)
     feat, inter = encoder_forward(pk, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
-    keys5, pooled = wide_forward(pk, feat, N)
+    keys5, (green, red, ts) = wide_forward(pk, feat, N)
     h1, h2, back = ph_tail(pk.ph, keys5, B, points.device)
     recon = decoder_forward(pk, feat, back, N)
-    green, red, ts = (head_tail(pk.heads[h], pooled[i]) for i, h in enumerate(HEAD_ORDER))
     pg, pr, fg, fr, pT, ps = ops.head_post(green, red, ts, mean)
     out = dict()
     if train_keys:

@@ -137,6 +137,19 @@ def orl_global(feat, idx):
     return out
 
 
+def orl_rowbias(feat, idx, w2t):
+    """feat (B,n,C), idx (B,n,k), w2t (C,C) = W2^T -> rb (B,C) = mean_i max_j feat[idx] @ W2^T"""
+    feat, ldf = _rows(feat, "feat")
+    _i32(idx, "idx")
+    B, n, C = feat.shape
+    k = idx.shape[2]
+    partial = torch.empty(_lib.lib().tgp_orl_partial_floats(B, n, C), device=feat.device, dtype=torch.float32)
+    rb = torch.empty(B, C, device=feat.device, dtype=torch.float32)
+    check(_lib.lib().tgp_orl_rowbias(_p(feat), ldf, _p(idx), B, n, k, C, _p(partial), _p(w2t), None, _p(rb), _stream(feat)),
+          "tgp_orl_rowbias")
+    return rb
+
+
 def pool(xyz, feat, idx, sample, kpool=4, out_f=None):
     """xyz (B,n,3), feat (B,n,C), idx (B,n,>=kpool) int32, sample (n_out,) int32 -> (xyz_p, feat_p)"""
     _f32(xyz, "xyz", 3)
