@@ -245,27 +245,33 @@ __global__ void orl_finish_kernel(const float *__restrict__ partial, int B, int 
 }
 
 // Same as orl_finish_kernel, then rb[b, :] = g[b, :] @ W2^T: the "global" half of the layer's conv2
-// (gcn3d.py:108-112: conv2(cat[f, g]) = W1 f + W2 g).  One workgroup per object; w2t is W2 transposed (C_in, C_out)
-// so consecutive threads read consecutive floats.
+// (gcn3d.py:108-112: conv2(cat[f, g]) = W1 f + W2 g).  Workgroup = (object, 64 output channels); its 4 waves
+// split the input channels and are combined through LDS in fixed order.  w2t is W2 transposed (C_in, C_out) so
+// consecutive lanes read consecutive floats.
 __global__ __launch_bounds__(256) void orl_finish_project_kernel(const float *__restrict__ partial, int n, int C, int ptiles,
                                                                  const float *__restrict__ w2t, float *__restrict__ g_out,
                                                                  float *__restrict__ rb)
 {
     __shared__ float g[512];
-    const int b = blockIdx.x;
+    __shared__ float part[4][64];
+    const int b = blockIdx.x, ob = blockIdx.y * 64;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float s = 0.f;
         for (int p = 0; p < ptiles; ++p) s += partial[((int64_t)b * ptiles + p) * C + c];
         s = s / (float)n;
         g[c] = s;
-        if (g_out) g_out[(int64_t)b * C + c] = s;
+        if (g_out && blockIdx.y == 0) g_out[(int64_t)b * C + c] = s;
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < C; o += blockDim.x) {
-        float acc = 0.f;
-        for (int c = 0; c < C; ++c) acc = fmaf(g[c], w2t[(int64_t)c * C + o], acc);
-        rb[(int64_t)b * C + o] = acc;
-    }
+    const int o = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int per = C / 4;
+    float acc = 0.f;
+    const float *w = w2t + (int64_t)(ks * per) * C + ob + o;
+#pragma unroll 8
+    for (int c = 0; c < per; ++c) acc = fmaf(g[ks * per + c], w[(int64_t)c * C], acc);
+    part[ks][o] = acc;
+    __syncthreads();
+    if (ks == 0) rb[(int64_t)b * C + ob + o] = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
 }
 
 extern "C" int64_t tgp_orl_partial_floats(int B, int n, int C)
@@ -311,7 +317,8 @@ extern "C" int tgp_orl_rowbias(const float *feat, int ldf, const int32_t *idx, i
     }
     if (C == 128) ORL_GO(128) else if (C == 256) ORL_GO(256) else ORL_GO(512)
 #undef ORL_GO
-    hipLaunchKernelGGL(orl_finish_project_kernel, dim3(B), dim3(256), 0, tgp_hs(stream), partial, n, C, ptiles, w2t, g_out, rb);
+    hipLaunchKernelGGL(orl_finish_project_kernel, dim3(B, C / 64), dim3(256), 0, tgp_hs(stream), partial, n, C, ptiles, w2t, g_out,
+                       rb);
     return TGP_LAUNCH_RESULT();
 }
 

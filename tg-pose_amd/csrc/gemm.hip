@@ -511,6 +511,14 @@ __global__ __launch_bounds__(256) void gemm_main256_kernel(GemmParams p)
     }
 }
 
+// Feature-space distance matrix for larger clouds: 128x128 tiles on 1024 threads (4 waves per SIMD), ascending-k
+// fp32 MFMA chain (bit-identical to the CPU sgemm the reference's neighbour order depends on).
+__global__ __launch_bounds__(1024) void gemm_dist_kernel(GemmParams p)
+{
+    __shared__ __attribute__((aligned(16))) float smem[(128 + 128) * (16 + GEMM_LDPAD)];
+    gemm_tile<128, 128, 4, 4, 16, false, true, true>(p, blockIdx.y * 128, blockIdx.x * 128, blockIdx.z, smem);
+}
+
 template <bool NAT, bool DIST>
 __global__ __launch_bounds__(256) void gemm_small_kernel(GemmParams p)
 {
@@ -756,6 +764,10 @@ int tgp_launch_dist_gemm(const float *x, int ld, const float *q, int B, int n, i
     p.sA = p.sW = (int64_t)n * ld;
     p.sC = (int64_t)n * n;
     p.qrow = q, p.qcol = q, p.sq = n;
+    if (n >= 512) {
+        hipLaunchKernelGGL(gemm_dist_kernel, dim3(tgp_cdiv(n, 128), tgp_cdiv(n, 128), B), dim3(1024), 0, stream, p);
+        return TGP_LAUNCH_RESULT();
+    }
     return launch_small<true, true>(p, stream);
 }
 

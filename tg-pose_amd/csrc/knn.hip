@@ -151,35 +151,85 @@ extern "C" int tgp_center(const float *points, int B, int n, float *xyz_c, float
 }
 
 // ------------------------------------------------------------------------------------------------
-// wave-wide top-(k+1) selection over NT register slots per lane
+// wave-wide top-(k+1) selection over NT register slots per lane (slot t of lane l is candidate j = l + 64 t).
+//
+// NT <= 2: every round scans the slots.  NT > 2: each lane first builds a sorted cache of its 3 smallest
+// (distance, slot) keys in one pass; a round is then a 6-step butterfly argmin over the cache heads plus a pop on
+// the winning lane.  A lane rarely owns more than 3 of the k+1 nearest (0.5 % of lanes at k = 20, n = 1028); when one
+// runs dry the whole wave rebuilds its caches from the keys greater than the last one each lane gave away.
 template <int NT>
 __device__ __forceinline__ void wave_select(float (&d)[NT], int lane, int k, int32_t *__restrict__ out_row)
 {
     int mine = 0; // lane r-1 keeps the neighbour of rank r
-    for (int r = 0; r <= k; ++r) {
-        float best = d[0];
-        int bt = 0;
+    if constexpr (NT <= 2) {
+        for (int r = 0; r <= k; ++r) {
+            float best = d[0];
+            int bt = 0;
 #pragma unroll
-        for (int t = 1; t < NT; ++t) {
-            const bool lt = d[t] < best;
-            best = lt ? d[t] : best;
-            bt = lt ? t : bt;
+            for (int t = 1; t < NT; ++t) {
+                const bool lt = d[t] < best;
+                best = lt ? d[t] : best;
+                bt = lt ? t : bt;
+            }
+            int bj = lane + (bt << 6);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float od = __shfl_xor(best, off, 64);
+                const int oj = __shfl_xor(bj, off, 64);
+                const bool take = (od < best) || (od == best && oj < bj);
+                best = take ? od : best;
+                bj = take ? oj : bj;
+            }
+            const int owner = bj & 63, slot = bj >> 6;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (t == slot && lane == owner) d[t] = INFINITY;
+            if (r >= 1 && lane == r - 1) mine = bj;
         }
-        int bj = lane + (bt << 6);
+    } else {
+        float c0, c1, c2;      // cache: c0 <= c1 <= c2, equal distances in slot order
+        int s0, s1, s2;
+        float lastd = -INFINITY; // the last key this lane gave away: (lastd, lasts)
+        int lasts = -1;
+        auto refill = [&]() {
+            c0 = c1 = c2 = INFINITY;
+            s0 = s1 = s2 = NT;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float od = __shfl_xor(best, off, 64);
-            const int oj = __shfl_xor(bj, off, 64);
-            const bool take = (od < best) || (od == best && oj < bj);
-            best = take ? od : best;
-            bj = take ? oj : bj;
+            for (int t = 0; t < NT; ++t) {
+                const float v = d[t];
+                const bool after = (v > lastd) || (v == lastd && t > lasts);
+                const bool lt0 = after && v < c0, lt1 = after && v < c1, lt2 = after && v < c2;
+                c2 = lt1 ? c1 : (lt2 ? v : c2);
+                s2 = lt1 ? s1 : (lt2 ? t : s2);
+                c1 = lt0 ? c0 : (lt1 ? v : c1);
+                s1 = lt0 ? s0 : (lt1 ? t : s1);
+                c0 = lt0 ? v : c0;
+                s0 = lt0 ? t : s0;
+            }
+        };
+        refill();
+        for (int r = 0; r <= k; ++r) {
+            float best = c0;
+            int bj = lane + (s0 << 6); // an empty cache (s0 == NT) carries distance +inf and never wins a finite round
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float od = __shfl_xor(best, off, 64);
+                const int oj = __shfl_xor(bj, off, 64);
+                const bool take = (od < best) || (od == best && oj < bj);
+                best = take ? od : best;
+                bj = take ? oj : bj;
+            }
+            if (r >= 1 && lane == r - 1) mine = bj;
+            bool dry = false;
+            if (lane == (bj & 63)) { // pop
+                lastd = c0, lasts = s0;
+                c0 = c1, s0 = s1;
+                c1 = c2, s1 = s2;
+                c2 = INFINITY, s2 = NT;
+                dry = (s0 == NT);
+            }
+            if (__any(dry)) refill();
         }
-        // every lane now holds the same winner (distance, index); retire it from its owner
-        const int owner = bj & 63, slot = bj >> 6;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (t == slot && lane == owner) d[t] = INFINITY;
-        if (r >= 1 && lane == r - 1) mine = bj;
     }
     if (lane < k) out_row[lane] = mine;
 }
