@@ -137,6 +137,13 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
+        traffic = None
+        try:   # HBM/fabric bytes per launch of the dominant kernel from the committed PMC passes (not a live measurement)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")))["kernels"]
+            key = "void gemm_split_kernel<true>" if args.gemm == "split" else "gemm_main256_kernel"
+            traffic = pmc[key]["bytes_per_launch_corrected"] if key in pmc and args.gemm == "split" else None
+        except Exception:
+            traffic = None
         launches = len(timer)
         ksec = sum(e0.elapsed_time(e1) for e0, e1, _ in timer) * 1e-3
         kflop = sum(f for _, _, f in timer)
@@ -165,7 +172,7 @@ def main():
                                    "of the reference architecture (27.43 M params)" % (B, N_POINTS),
                        "objects_per_gpu": B, "points": N_POINTS, "replicas": world},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
                          "kernel": kernel_name, "peak_basis": peak_basis,
                          "launches_timed": launches, "avg_launch_us": round(1e6 * ksec / max(launches, 1), 2),
                          "share_of_step": round(ksec / elapsed, 4)},

@@ -304,7 +304,9 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
     constexpr int PA = (BM + RPP - 1) / RPP;
     constexpr int WCH = BN * 6;               // W: 16-byte chunks per K-tile
     constexpr int PW = (WCH + THREADS - 1) / THREADS;
-    constexpr int PLANE_A = BM * ROWB, PLANE_W = BN * ROWB;
+    // plane strides carry 32 extra bytes: the hi / mid / lo planes then start 8 banks apart, which removes the 3-way
+    // conflicts of the staging writes (one row's six W chunks, or one A quad's three terms, hit distinct banks)
+    constexpr int PLANE_A = BM * ROWB + 32, PLANE_W = BN * ROWB + 32;
     constexpr int BUFB = 3 * (PLANE_A + PLANE_W);
     char *lds_a = smem;
     char *lds_w = smem + 3 * PLANE_A;
@@ -406,9 +408,12 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
             SPLIT_TERM(1, 0)
             SPLIT_TERM(0, 0)
 #undef SPLIT_TERM
+            // With two LDS stages the next tile can be split and written while this wave still has MFMAs to issue:
+            // done after the first column block, the VALU / LDS-write work overlaps the other waves' MFMAs instead of
+            // sitting between the last MFMA and the barrier.
+            if (DBUF && j == (TN > 1 ? TN / 2 - 1 : 0) && more) store_tile((kt + 1) & 1);
         }
         if (DBUF) {
-            if (more) store_tile((kt + 1) & 1);
             __syncthreads();
         } else {
             __syncthreads();
@@ -422,7 +427,7 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
 template <bool DBUF>
 __global__ __launch_bounds__(1024) void gemm_split_kernel(GemmParams p)
 {
-    __shared__ __attribute__((aligned(16))) char smem[(DBUF ? 2 : 1) * 3 * (256 + 256) * 48];
+    __shared__ __attribute__((aligned(16))) char smem[(DBUF ? 2 : 1) * 3 * ((256 + 256) * 48 + 64)];
     int L = blockIdx.x;
     if (L < p.tiles_big) {
         const int per_batch = p.mt_big * p.tiles_n_big;
