@@ -188,6 +188,33 @@ int tgp_chamfer_bwd(const float *xyz1, const float *xyz2, int B, int n, int m, c
                     const float *graddist2, const int32_t *idx1, const int32_t *idx2, float *gradxyz1,
                     float *gradxyz2, tgp_stream_t stream);
 
+/* ---- density-aware Chamfer loss (config 3: forward + Chamfer loss) ------------------------------ */
+
+/* calc_dcd after the Chamfer search (losses/TDA_loss_sym_recon.py:427-445): per object
+ * loss = mean_i(1 - exp(-alpha d1_i) w1_i) + 0.5 mean_j(1 - exp(-alpha d2_j) w2_j),
+ * w1_i = frac_21 / (count1[idx1_i]^n_lambda + 1e-6) with count1 = bincount(idx1) (w2 likewise, frac_12).
+ * loss (B); w1 (B,n), w2 (B,m) are optional outputs kept for the backward pass. n, m <= 4096. */
+int tgp_dcd_fwd(const float *dist1, const float *dist2, const int32_t *idx1, const int32_t *idx2, int B, int n,
+                int m, float alpha, float n_lambda, int non_reg, float *loss, float *w1, float *w2,
+                tgp_stream_t stream);
+
+/* Gradient of the above w.r.t. the distances (the weights are detached, :433,438): graddist1 (B,n), graddist2 (B,m)
+ * from gloss (B); they feed tgp_chamfer_bwd. */
+int tgp_dcd_bwd(const float *dist1, const float *dist2, const float *w1, const float *w2, const float *gloss,
+                int B, int n, int m, float alpha, float *graddist1, float *graddist2, tgp_stream_t stream);
+
+/* TDA_loss.R_DCD pose normalisation (:326-339): R from the predicted axes p_g, p_r (B,3) and confidences f_g, f_r
+ * (B) -- for objects with sym[b*sym_ld] == 1 the green axis is paired with column 0 of the true rotation gR (B,3,3)
+ * -- then out[b,i] = (R^T (points[b,i] - p_t[b])) * p_s[b].  R_out (B,3,3) optional. */
+int tgp_canonicalize(const float *points, const float *gR, const float *p_g, const float *f_g, const float *p_r,
+                     const float *f_r, const float *p_t, const float *p_s, const float *sym, int sym_ld, int B,
+                     int n, float *out, float *R_out, tgp_stream_t stream);
+
+/* Pose assembly of the evaluater: generate_RT([p_green, p_red], [f_green, f_red], T, mode='vec', sym)
+ * (evaluater/RT_TDA_Evaluater.py:94; tools/rot_utils.py:95-98 to_R_matrices).  rt (B,4,4); sym may be NULL. */
+int tgp_generate_rt(const float *p_green, const float *p_red, const float *f_green, const float *f_red,
+                    const float *T, const float *sym, int sym_ld, int B, float *rt, tgp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -206,7 +206,101 @@ def gen_chamfer():
          noisy=noisy, prior=prior, p_dist1=e1, p_dist2=e2, p_idx1=small_idx(j1), p_idx2=small_idx(j2))
 
 
+# ----------------------------------------------------------------------------- density-aware Chamfer loss
+def load_reference_loss():
+    """Import losses/TDA_loss_sym_recon.py unmodified.  Its two import-time dependencies that cannot exist here
+    are pre-seeded in sys.modules: `losses.chamfer3D.dist_chamfer_3D` (JIT-builds CUDA; replaced by a module whose
+    chamfer_3DDist delegates to the reference's own losses/metrics/CD/chamfer_python.distChamfer) and
+    `tools.geom_utils` (source missing from the reference tree, only py3.8 bytecode; `batch_dot` restated from
+    the disassembly recorded in SURVEY.md 8c)."""
+    import types
+    cham_pkg = types.ModuleType("losses.chamfer3D")
+    cham_pkg.__path__ = []
+    cham_mod = types.ModuleType("losses.chamfer3D.dist_chamfer_3D")
+
+    class chamfer_3DDist(torch.nn.Module):
+        def forward(self, a, b):
+            return ref_chamfer.distChamfer(a, b)
+
+    cham_mod.chamfer_3DDist = chamfer_3DDist
+    cham_pkg.dist_chamfer_3D = cham_mod
+    geom = types.ModuleType("tools.geom_utils")
+
+    def batch_dot(a, b, keepdim=False):
+        r = torch.matmul(a.unsqueeze(-2), b.unsqueeze(-1)).squeeze(-1)
+        return r if keepdim else r.squeeze(-1)
+
+    geom.batch_dot = batch_dot
+    sys.modules["losses.chamfer3D"] = cham_pkg
+    sys.modules["losses.chamfer3D.dist_chamfer_3D"] = cham_mod
+    sys.modules.setdefault("tools.geom_utils", geom)
+    import losses.TDA_loss_sym_recon as ref_loss
+    return ref_loss
+
+
+def gen_dcd():
+    ref_loss = load_reference_loss()
+    g = torch.Generator().manual_seed(31)
+    cats = ["bottle", "bowl", "camera", "can", "laptop", "mug"]
+    prior = torch.stack([torch.from_numpy(np.load(os.path.join(REF, "obj_model/points_%s.npy" % c))).float() for c in cats])
+    B = 6
+    # a plausible network state: noisy, posed copies of the priors as "recon", predicted axes near the true ones
+    def rand_rot(n):
+        q = torch.randn(n, 4, generator=g)
+        q = q / q.norm(dim=1, keepdim=True)
+        w, x, y, z = q.unbind(1)
+        return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                            2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                            2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1).view(n, 3, 3)
+    gR = rand_rot(B)
+    t = torch.randn(B, 3, generator=g) * 0.1 + torch.tensor([0.0, 0.0, 1.0])
+    s = torch.rand(B, 3, generator=g) * 0.5 + 0.75
+    sel = torch.randperm(1024, generator=g)[:1028 - 1024 + 1000]
+    src = prior[:, torch.randint(0, 1024, (1028,), generator=g)]
+    recon = torch.matmul(src / s.unsqueeze(1), gR.transpose(1, 2)) + t.unsqueeze(1) + 0.004 * torch.randn(B, 1028, 3, generator=g)
+    p_g = gR[:, :, 1] + 0.05 * torch.randn(B, 3, generator=g)
+    p_r = gR[:, :, 0] + 0.05 * torch.randn(B, 3, generator=g)
+    p_g, p_r = p_g / p_g.norm(dim=1, keepdim=True), p_r / p_r.norm(dim=1, keepdim=True)
+    f_g, f_r = torch.rand(B, generator=g) * 0.5 + 0.4, torch.rand(B, generator=g) * 0.5 + 0.4
+    sym = torch.zeros(B, 4)
+    sym[0, 0] = sym[1, 0] = sym[3, 0] = 1                     # bottle, bowl, can are symmetric about y
+    loss_mod = ref_loss.TDA_loss()
+    with torch.no_grad():
+        dcd = ref_loss.calc_dcd(recon, prior, alpha=70, n_lambda=0.3)
+        cd_p, cd_t = ref_loss.calc_cd(recon, prior)
+        r_dcd = loss_mod.R_DCD(prior, recon, gR, p_g, f_g, p_r, f_r, t, s, sym)
+        ny, nx = ref_loss.get_vertical_rot_vec_in_batch(f_g, f_r, p_g, p_r)
+        pR = ref_loss.get_rot_mat_y_first(ny, nx)
+    # gradient of mean(calc_dcd) w.r.t. the reconstruction (through exp(-alpha d) only: the weights are detached)
+    rr = recon.clone().requires_grad_(True)
+    ref_loss.calc_dcd(rr, prior, alpha=70, n_lambda=0.3).mean().backward()
+    save("dcd.npz", recon=recon, prior=prior, gR=gR, t=t, s=s, p_g=p_g, p_r=p_r, f_g=f_g, f_r=f_r, sym=sym,
+         dcd=dcd, cd_p=cd_p, cd_t=cd_t, r_dcd=r_dcd, new_y=ny, new_x=nx, p_R=pR, dcd_grad=rr.grad)
+
+
+def gen_pose_assembly():
+    """to_R_matrices (tools/rot_utils.py:95-98) is importable; generate_RT itself exists only as py3.8 bytecode
+    (tools/geom_utils), its recorded semantics are: zero f_red where sym[:,0]==1, R = to_R_matrices,
+    RT = [[R, T], [0, 1]].  The fixture stores the rotations the reference computes for both confidence settings."""
+    import tools.rot_utils as ru
+    g = torch.Generator().manual_seed(41)
+    B = 16
+    p_g = torch.randn(B, 3, generator=g)
+    p_r = torch.randn(B, 3, generator=g)
+    p_g, p_r = p_g / p_g.norm(dim=1, keepdim=True), p_r / p_r.norm(dim=1, keepdim=True)
+    f_g, f_r = torch.rand(B, generator=g), torch.rand(B, generator=g)
+    T = torch.randn(B, 3, generator=g)
+    sym = torch.zeros(B, 4)
+    sym[::3, 0] = 1
+    with torch.no_grad():
+        R_plain = ru.to_R_matrices(f_g, f_r, p_g, p_r)
+        R_sym = ru.to_R_matrices(f_g, torch.where(sym[:, 0] == 1, torch.zeros_like(f_r), f_r), p_g, p_r)
+    save("pose_assembly.npz", p_g=p_g, p_r=p_r, f_g=f_g, f_r=f_r, T=T, sym=sym, R_plain=R_plain, R_sym=R_sym)
+
+
 def main():
+    gen_pose_assembly()
+    gen_dcd()
     gen_knn()
     gen_layers()
     bottle = torch.from_numpy(np.load(os.path.join(REF, "obj_model/points_bottle.npy"))).float()[None]

@@ -586,3 +586,84 @@ def test_chamfer_module_vs_reference_golden_and_autograd(ops):
         na = torch.gather(ac, 1, i2.cpu().long().unsqueeze(-1).expand(-1, -1, 3))
         (((ac - nb) ** 2).sum() + 0.5 * ((bc - na) ** 2).sum()).backward()
         assert torch.allclose(a.grad.cpu(), ac.grad, atol=1e-6) and torch.allclose(b.grad.cpu(), bc.grad, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------------------- density-aware Chamfer loss
+def test_dcd_and_r_dcd_vs_reference_golden(ops):
+    """calc_cd / calc_dcd / R_DCD on the HIP kernels against values produced by the imported reference
+    (tests/golden/dcd.npz) and against the CPU oracle; gradient of calc_dcd against the reference's autograd."""
+    from tgpose_amd.losses import dcd as D
+    from oracle import loss_ref as L
+    gd = golden("dcd.npz")
+    t = lambda k: g(gd[k])
+    cd_p, cd_t = D.calc_cd(t("recon"), t("prior"))
+    assert np.allclose(cd_p.cpu().numpy(), gd["cd_p"], atol=1e-6) and np.allclose(cd_t.cpu().numpy(), gd["cd_t"], atol=1e-6)
+    # canonicalised clouds (where the loss is informative)
+    canon_ref, R_ref = L.canonicalize(*(torch.from_numpy(gd[k]) for k in ("recon", "gR", "p_g", "f_g", "p_r", "f_r", "t", "s", "sym")))
+    canon, R = ops.canonicalize(t("recon"), t("gR"), t("p_g"), t("f_g"), t("p_r"), t("f_r"), t("t"), t("s"), t("sym"))
+    assert torch.allclose(R.cpu(), R_ref, atol=1e-6) and torch.allclose(canon.cpu(), canon_ref, atol=1e-6)
+    assert np.allclose(R.cpu().numpy()[[2, 4, 5]], gd["p_R"][[2, 4, 5]], atol=1e-6)      # non-symmetric objects: reference R
+    want, _ = L.calc_dcd(canon_ref, torch.from_numpy(gd["prior"]), 70.0, 0.3)
+    got = D.calc_dcd(g(canon_ref), t("prior"), alpha=70, n_lambda=0.3)
+    assert torch.allclose(got.cpu(), want, atol=2e-6)
+    assert np.allclose(D.calc_dcd(t("recon"), t("prior"), alpha=70, n_lambda=0.3).cpu().numpy(), gd["dcd"], atol=2e-6)
+    val = D.R_DCD(t("prior"), t("recon"), t("gR"), t("p_g"), t("f_g"), t("p_r"), t("f_r"), t("t"), t("s"), t("sym"))
+    assert abs(val.item() - float(gd["r_dcd"])) < 2e-6
+    # gradient through exp(-alpha d) and the Chamfer backward
+    x = t("recon").clone().requires_grad_(True)
+    D.calc_dcd(x, t("prior"), alpha=70, n_lambda=0.3).mean().backward()
+    assert np.allclose(x.grad.cpu().numpy(), gd["dcd_grad"], atol=1e-7, rtol=1e-4)
+    y = g(canon_ref).clone().requires_grad_(True)
+    D.calc_dcd(y, t("prior"), alpha=70, n_lambda=0.3).sum().backward()
+    yr = canon_ref.clone().requires_grad_(True)
+    d1, d2, i1, i2 = L.chamfer(yr, torch.from_numpy(gd["prior"]))
+    nb = torch.gather(torch.from_numpy(gd["prior"]), 1, i1.unsqueeze(-1).expand(-1, -1, 3))
+    na = torch.gather(yr, 1, i2.unsqueeze(-1).expand(-1, -1, 3))
+    dd1, dd2 = ((yr - nb) ** 2).sum(-1), ((torch.from_numpy(gd["prior"]) - na) ** 2).sum(-1)
+    tot = 0
+    for b in range(6):
+        w1 = 1.0 / (torch.bincount(i1[b])[i1[b]].float() ** 0.3 + 1e-6) * (1024 / 1028)
+        w2 = 1.0 / (torch.bincount(i2[b])[i2[b]].float() ** 0.3 + 1e-6) * (1028 / 1024)
+        tot = tot + (1 - torch.exp(-70 * dd1[b]) * w1).mean() + 0.5 * (1 - torch.exp(-70 * dd2[b]) * w2).mean()
+    tot.backward()
+    assert torch.allclose(y.grad.cpu(), yr.grad, atol=2e-6, rtol=1e-4)
+
+
+def test_generate_rt_vs_reference_golden(ops):
+    """Pose assembly against the rotations tools/rot_utils.to_R_matrices produced in the reference (sym and non-sym)."""
+    from tgpose_amd.pose import generate_RT
+    gd = golden("pose_assembly.npz")
+    t = lambda k: g(gd[k])
+    rt = generate_RT([t("p_g"), t("p_r")], [t("f_g"), t("f_r")], t("T"), mode="vec", sym=t("sym")).cpu().numpy()
+    assert np.allclose(rt[:, :3, :3], gd["R_sym"], atol=2e-6) and np.array_equal(rt[:, :3, 3], gd["T"])
+    assert np.array_equal(rt[:, 3], np.tile(np.array([0, 0, 0, 1], np.float32), (16, 1)))
+    plain = generate_RT([t("p_g"), t("p_r")], [t("f_g"), t("f_r")], t("T"), mode="vec", sym=None).cpu().numpy()
+    assert np.allclose(plain[:, :3, :3], gd["R_plain"], atol=2e-6)
+    det = np.linalg.det(rt[:, :3, :3].astype(np.float64))
+    assert np.allclose(det, 1.0, atol=1e-5)
+
+
+def test_batched_inference_matches_per_image_runs(ops):
+    """f-1: detections of several images in one forward give the same poses as image-by-image runs."""
+    from tgpose_amd.pose import batched_inference, generate_RT
+    from tgpose_amd import FLAGS
+    net = _net(2)
+    FLAGS.train = 0
+    gen = torch.Generator().manual_seed(0)
+    counts = [3, 0, 5, 2]
+    clouds, cats, means, syms = [], [], [], []
+    for c in counts:
+        p, o = synth_points(max(c, 1), 1024, seed=10 + c)
+        clouds.append(p[:c]); cats.append(o[:c])
+        means.append(torch.rand(c, 3, generator=gen) * 0.1)
+        s = torch.zeros(c, 4); s[::2, 0] = 1
+        syms.append(s)
+    torch.manual_seed(3)
+    res = batched_inference(net, clouds, cats, means, syms)
+    assert [r["pred_RTs"].shape[0] for r in res] == counts
+    torch.manual_seed(3)            # same random subsample as the batched run (one draw per forward)
+    pts = torch.cat([c for c in clouds if c.shape[0]])
+    out = net(g(pts), g(torch.cat([c for c in cats if c.shape[0]])))
+    rt = generate_RT([out["p_green_R"], out["p_red_R"]], [out["f_green_R"], out["f_red_R"]], out["Pred_T"],
+                     sym=g(torch.cat([s for s in syms if s.shape[0]]))).cpu().numpy()
+    assert np.array_equal(np.concatenate([r["pred_RTs"] for r in res if r["pred_RTs"].shape[0]]), rt)

@@ -149,3 +149,19 @@ def test_chamfer_backward_matches_autograd_of_definition():
     loss.backward()
     g1, g2 = _clib.chamfer_bwd(g["a"], g["b"], w1.numpy(), w2.numpy(), i1, i2)
     assert np.allclose(g1, a.grad.numpy(), atol=1e-6) and np.allclose(g2, b.grad.numpy(), atol=1e-6)
+
+
+def test_dcd_loss_pieces_vs_reference():
+    """calc_cd, calc_dcd, the axis/rotation helpers and R_DCD of losses/TDA_loss_sym_recon.py (imported reference)."""
+    from oracle import loss_ref as L
+    g = golden("dcd.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    cd_p, cd_t = L.calc_cd(t("recon"), t("prior"))
+    assert torch.allclose(cd_p, t("cd_p"), atol=1e-6) and torch.allclose(cd_t, t("cd_t"), atol=1e-6)
+    dcd, _ = L.calc_dcd(t("recon"), t("prior"), 70.0, 0.3)
+    assert torch.allclose(dcd, t("dcd"), atol=1e-6)
+    ny, nx = L.vertical_axes(t("f_g"), t("f_r"), t("p_g"), t("p_r"))
+    assert torch.allclose(ny, t("new_y"), atol=1e-6) and torch.allclose(nx, t("new_x"), atol=1e-6)
+    assert torch.allclose(L.rot_from_y_x(ny, nx), t("p_R"), atol=1e-6)
+    val = L.r_dcd(t("prior"), t("recon"), t("gR"), t("p_g"), t("f_g"), t("p_r"), t("f_r"), t("t"), t("s"), t("sym"))
+    assert abs(val.item() - float(g["r_dcd"])) < 1e-6

@@ -1,0 +1,75 @@
+"""Drop-in for the Chamfer-based pieces of ``losses/TDA_loss_sym_recon.py`` on the HIP kernels:
+``calc_cd`` (:495-509), ``calc_dcd`` (:411-450) and the forward value of ``TDA_loss.R_DCD`` (:326-342).
+
+``calc_dcd`` is differentiable w.r.t. the predicted cloud exactly as the reference is: the density weights are
+detached, the gradient flows through exp(-alpha d) into the Chamfer backward (``tgp_dcd_bwd`` ->
+``tgp_chamfer_bwd``).  The reference's Python loop over the batch with ``torch.bincount`` per sample becomes one
+launch with one workgroup per object.
+"""
+import torch
+from torch.autograd import Function
+
+from .. import ops
+from .chamfer3D.dist_chamfer_3D import chamfer_3DDist
+
+
+def calc_cd(pred, gt, return_raw=False, separate=False):
+    dist1, dist2, idx1, idx2 = chamfer_3DDist()(pred, gt)
+    if separate:
+        res = [torch.cat([torch.sqrt(dist1).mean(1).unsqueeze(0), torch.sqrt(dist2).mean(1).unsqueeze(0)]),
+               torch.cat([dist1.mean(1).unsqueeze(0), dist2.mean(1).unsqueeze(0)])]
+    else:
+        res = [(torch.sqrt(dist1).mean(1) + torch.sqrt(dist2).mean(1)) / 2, dist1.mean(1) + dist2.mean(1)]
+    if return_raw:
+        res.extend([dist1, dist2, idx1, idx2])
+    return res
+
+
+class _DcdFunction(Function):
+    @staticmethod
+    def forward(ctx, pred, gt, alpha, n_lambda, non_reg):
+        B, n, _ = pred.shape
+        m = gt.shape[1]
+        dev = pred.device
+        dist1, dist2 = torch.zeros(B, n, device=dev), torch.zeros(B, m, device=dev)
+        idx1 = torch.zeros(B, n, device=dev, dtype=torch.int32)
+        idx2 = torch.zeros(B, m, device=dev, dtype=torch.int32)
+        ops.chamfer_fwd(pred, gt, dist1, dist2, idx1, idx2)
+        loss, w1, w2 = ops.dcd_fwd(dist1, dist2, idx1, idx2, alpha, n_lambda, non_reg)
+        ctx.save_for_backward(pred, gt, dist1, dist2, idx1, idx2, w1, w2)
+        ctx.alpha = alpha
+        ctx.mark_non_differentiable(idx1, idx2)
+        return loss, dist1, dist2, idx1, idx2
+
+    @staticmethod
+    def backward(ctx, gloss, gdist1, gdist2, gi1, gi2):
+        pred, gt, dist1, dist2, idx1, idx2, w1, w2 = ctx.saved_tensors
+        gd1, gd2 = ops.dcd_bwd(dist1, dist2, w1, w2, gloss.contiguous().float(), ctx.alpha)
+        if gdist1 is not None:
+            gd1 = gd1 + gdist1
+        if gdist2 is not None:
+            gd2 = gd2 + gdist2
+        g_pred, g_gt = torch.zeros_like(pred), torch.zeros_like(gt)
+        ops.chamfer_bwd(pred, gt, g_pred, g_gt, gd1.contiguous(), gd2.contiguous(), idx1, idx2)
+        return g_pred, g_gt, None, None, None
+
+
+def calc_dcd(pred_recon, cate_gt, alpha=0.1, n_lambda=0.3, return_raw=False, non_reg=False):
+    """-> per-object loss (B,) [+ dist1, dist2, idx1, idx2 when return_raw]"""
+    pred = pred_recon.float().contiguous()
+    gt = cate_gt.float().contiguous()
+    assert pred.shape[0] == gt.shape[0]
+    loss, dist1, dist2, idx1, idx2 = _DcdFunction.apply(pred, gt, float(alpha), float(n_lambda), bool(non_reg))
+    if return_raw:
+        return [loss, dist1, dist2, idx1, idx2]
+    return loss
+
+
+def R_DCD(cate_ori, points, g_R, p_g_vec, f_g_vec, p_r_vec, f_r_vec, p_t, p_s, sym):
+    """Forward value of TDA_loss.R_DCD: canonicalise the reconstruction with the predicted pose, density-aware
+    Chamfer against the category prior (alpha 70, lambda 0.3), mean over the batch.  No gradient w.r.t. the pose
+    inputs in this round (the canonicalisation kernel is forward-only)."""
+    with torch.no_grad():
+        canon, _ = ops.canonicalize(points.float(), g_R.float(), p_g_vec.float(), f_g_vec.float(), p_r_vec.float(),
+                                    f_r_vec.float(), p_t.float(), p_s.float(), sym.float())
+        return torch.mean(calc_dcd(canon, cate_ori, alpha=70, n_lambda=0.3, return_raw=False, non_reg=False))

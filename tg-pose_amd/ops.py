@@ -343,3 +343,54 @@ def chamfer_bwd(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2
     check(_lib.lib().tgp_chamfer_bwd(_p(xyz1), _p(xyz2), B, n, m, _p(graddist1), _p(graddist2), _p(idx1), _p(idx2),
                                      _p(gradxyz1), _p(gradxyz2), _stream(xyz1)), "tgp_chamfer_bwd")
     return 1
+
+
+def dcd_fwd(dist1, dist2, idx1, idx2, alpha, n_lambda, non_reg=False, want_weights=True):
+    """calc_dcd after the Chamfer search -> (loss (B,), w1 (B,n), w2 (B,m))"""
+    B, n = dist1.shape
+    m = dist2.shape[1]
+    dev = dist1.device
+    loss = torch.empty(B, device=dev, dtype=torch.float32)
+    w1 = torch.empty(B, n, device=dev, dtype=torch.float32) if want_weights else None
+    w2 = torch.empty(B, m, device=dev, dtype=torch.float32) if want_weights else None
+    check(_lib.lib().tgp_dcd_fwd(_p(dist1.contiguous()), _p(dist2.contiguous()), _p(_i32(idx1, "idx1")), _p(_i32(idx2, "idx2")),
+                                 B, n, m, float(alpha), float(n_lambda), int(bool(non_reg)), _p(loss), _p(w1), _p(w2),
+                                 _stream(dist1)), "tgp_dcd_fwd")
+    return loss, w1, w2
+
+
+def dcd_bwd(dist1, dist2, w1, w2, gloss, alpha):
+    B, n = dist1.shape
+    m = dist2.shape[1]
+    gd1, gd2 = torch.empty_like(dist1), torch.empty_like(dist2)
+    check(_lib.lib().tgp_dcd_bwd(_p(dist1), _p(dist2), _p(w1), _p(w2), _p(gloss.contiguous()), B, n, m, float(alpha), _p(gd1),
+                                 _p(gd2), _stream(dist1)), "tgp_dcd_bwd")
+    return gd1, gd2
+
+
+def canonicalize(points, gR, p_g, f_g, p_r, f_r, p_t, p_s, sym):
+    """R_DCD pose normalisation -> (points_re_n (B,n,3), R (B,3,3))"""
+    c = lambda t: _f32(t.contiguous(), "arg")
+    points, gR, p_g, f_g, p_r, f_r, p_t, p_s, sym = map(c, (points, gR, p_g, f_g, p_r, f_r, p_t, p_s, sym))
+    B, n, _ = points.shape
+    out = torch.empty_like(points)
+    R = torch.empty(B, 3, 3, device=points.device, dtype=torch.float32)
+    check(_lib.lib().tgp_canonicalize(_p(points), _p(gR), _p(p_g), _p(f_g), _p(p_r), _p(f_r), _p(p_t), _p(p_s), _p(sym),
+                                      sym.shape[1] if sym.dim() > 1 else 1, B, n, _p(out), _p(R), _stream(points)),
+          "tgp_canonicalize")
+    return out, R
+
+
+def generate_rt(p_green, p_red, f_green, f_red, T, sym=None):
+    """-> (B,4,4) pose matrices"""
+    c = lambda t: _f32(t.contiguous(), "arg")
+    p_green, p_red, f_green, f_red, T = map(c, (p_green, p_red, f_green.reshape(-1), f_red.reshape(-1), T))
+    B = p_green.shape[0]
+    out = torch.empty(B, 4, 4, device=p_green.device, dtype=torch.float32)
+    sld = 0
+    if sym is not None:
+        sym = c(sym.float())
+        sld = sym.shape[1] if sym.dim() > 1 else 1
+    check(_lib.lib().tgp_generate_rt(_p(p_green), _p(p_red), _p(f_green), _p(f_red), _p(T), _p(sym), sld, B, _p(out),
+                                     _stream(p_green)), "tgp_generate_rt")
+    return out
