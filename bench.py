@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="objects per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="batches in flight per GPU: step i runs on HIP stream i %% S (independent batches overlap "
+                         "each other's tail rounds and small kernels)")
     ap.add_argument("--gemm", choices=("split", "fp32"), default="split",
                     help="split: fp32-accurate GEMM on the bf16 matrix cores (3-term operand split, 6 MFMA terms); "
                          "fp32: v_mfma_f32_32x32x2_f32 kernels")
@@ -89,13 +92,22 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # TGP_BENCH_SHARE_GPU=1 is a rehearsal mode for a one-GPU box: every rank uses cuda:0 and the control plane
+    # (barrier, max-time reduction) runs over gloo, because RCCL refuses two ranks on one device.
+    share = os.environ.get("TGP_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit("rank %d: no cuda:%d on this node (%d GPUs visible)" % (rank, dev_index, torch.cuda.device_count()))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import tgpose_amd
     from tgpose_amd import PoseNet9D, FLAGS, ops, seeded_state_dict
@@ -110,10 +122,18 @@ def main():
     pts, obj = pts.to(dev), obj.to(dev)
     torch.manual_seed(rank)
 
-    def step():
-        return net(pts, obj)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else [None]
+    step_no = [0]
 
-    for _ in range(args.warmup):
+    def step():
+        st = streams[step_no[0] % len(streams)]
+        step_no[0] += 1
+        if st is None:
+            return net(pts, obj)
+        with torch.cuda.stream(st):
+            return net(pts, obj)
+
+    for _ in range(max(args.warmup, len(streams))):
         step()
 
     def fence():
@@ -132,7 +152,7 @@ def main():
     timer, ops.GEMM_TIMER = ops.GEMM_TIMER, None
 
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -170,7 +190,7 @@ def main():
             "config": {"workload": "PoseNet9D.forward eval mode, full forward (kNN graphs + 3D-GCN encoder + PH predictor "
                                    "+ decoder + R/t/s heads), B=%d objects per GPU, N=%d points, seeded random weights "
                                    "of the reference architecture (27.43 M params)" % (B, N_POINTS),
-                       "objects_per_gpu": B, "points": N_POINTS, "replicas": world},
+                       "objects_per_gpu": B, "points": N_POINTS, "replicas": world, "batches_in_flight": len(streams)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "kernel": kernel_name, "peak_basis": peak_basis,
