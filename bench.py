@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="batches in flight per GPU: step i runs on HIP stream i %% S (independent batches overlap "
                          "each other's tail rounds and small kernels)")
+    ap.add_argument("--no-branch-streams", action="store_true", help="run the decoder branch in line instead of on a side stream")
     ap.add_argument("--gemm", choices=("split", "fp32"), default="split",
                     help="split: fp32-accurate GEMM on the bf16 matrix cores (3-term operand split, 6 MFMA terms); "
                          "fp32: v_mfma_f32_32x32x2_f32 kernels")
@@ -117,6 +118,8 @@ def main():
     net = net.to(dev).eval()
     FLAGS.train = 0
     ops.GEMM_MODE = args.gemm
+    from tgpose_amd import engine as _engine
+    _engine.BRANCH_STREAMS = not args.no_branch_streams
     B = args.batch
     pts, obj = synth_batch(B, N_POINTS, 100 + rank)
     pts, obj = pts.to(dev), obj.to(dev)

@@ -496,6 +496,46 @@ def test_forward_vs_oracle(ops, B, N, seed):
         assert torch.allclose(free[k].cpu(), want[k], atol=5e-4, rtol=0), k
 
 
+@pytest.mark.parametrize("B,N,seed", [(35, 1024, 21), (1, 2048, 22), (2, 640, 23)])
+def test_forward_other_batch_and_cloud_sizes(ops, B, N, seed):
+    """Shapes off the benchmark point: more than 32 objects (the per-object GEMMs leave the skinny kernel), a
+    single large cloud, a cloud size that is no multiple of 128.  Teacher-forced on the oracle's graphs, 1e-4."""
+    from tgpose_amd import FLAGS, seeded_state_dict
+    _, _, PR = _oracle()
+    sd = seeded_state_dict(seed)
+    net = _net(seed)
+    pts, obj = synth_points(B, N, seed)
+    torch.manual_seed(seed)
+    i1 = torch.randperm(N)[: N // 4]
+    sample = (i1, torch.randperm(i1.numel())[: i1.numel() // 4])
+    with torch.no_grad():
+        want, inter = PR.posenet_forward(sd, pts, obj, sample_idx=sample, train_keys=True, mode="exact",
+                                         want_intermediates=True)
+    FLAGS.train = 1
+    try:
+        got = net(g(pts), g(obj), sample_idx=sample, inject=inter["indices"])
+    finally:
+        FLAGS.train = 0
+    for k, v in want.items():
+        assert torch.allclose(got[k].cpu(), v, atol=1e-4, rtol=0), k
+
+
+def test_forward_large_batch_runs(ops):
+    """BASELINE config 3 size (B=256, N=1028): runs, finite, and agrees with a B=32 slice run to 1e-5."""
+    from tgpose_amd import FLAGS
+    net = _net(0)
+    pts, obj = synth_points(256, 1028, 3)
+    torch.manual_seed(1)
+    i1 = torch.randperm(1028)[:257]
+    sample = (i1, torch.randperm(257)[:64])
+    FLAGS.train = 0
+    big = net(g(pts), g(obj), sample_idx=sample)
+    part = net(g(pts[64:96]), g(obj[64:96]), sample_idx=sample)
+    for k in big:
+        assert torch.isfinite(big[k]).all(), k
+        assert torch.allclose(big[k][64:96], part[k], atol=5e-4, rtol=0), k
+
+
 def test_forward_full_batch_properties(ops):
     """BASELINE size (B=32, N=1028): properties that need no oracle run.
     * repeated runs are bit-identical (no float atomics anywhere);

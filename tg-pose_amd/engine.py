@@ -159,6 +159,16 @@ def _i32(idx, device):
 
 
 _PIN = {}
+_SIDE = {}
+BRANCH_STREAMS = True   # run the PH-tail -> decoder chain beside the head chain on a second HIP stream
+
+
+def _side_stream(device):
+    key = torch.device(device).index
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
 
 
 def _upload_i32(t, device):
@@ -296,10 +306,9 @@ def ph_forward(pk, feat, N):
     return ph_tail(ph, keys, B, feat.device)
 
 
-def wide_forward(pk, feat, N):
-    """conv_5 + the three head conv1 in one GEMM over `feat` (N_out = 4096), then the three head conv2
-    (+BN, ReLU, max over points) as one batched launch, then conv3 / conv4 batched over the heads.
-    Returns (keys5 (B,1024), [green (B,4), red (B,4), ts (B,6)])."""
+def wide_gemm(pk, feat, N):
+    """conv_5 + the three head conv1 in one GEMM over `feat` (N_out = 4096).
+    Returns (keys5 (B,1024) colmax keys of conv_5, H (B*N, 3072) head activations)."""
     B = feat.shape[0]
     dev = feat.device
     w = pk.wide
@@ -309,6 +318,15 @@ def wide_forward(pk, feat, N):
     ops.gemm(feat, w["W"], H, M=M, N=4096, K=FEAT_LD, lda=FEAT_LD, ldw=FEAT_LD, ldc=3072, bias=w["bias"],
              scale=w["scale"], shift=w["shift"], act=1, slope_vec=w["slope"], colmax_keys=keys5, cm_cols=1024,
              c_col0=1024, rows_per_obj=N, k_alg=w["k_alg"], w_split=w["Ws"])
+    return keys5, H
+
+
+def head_chain(pk, H, B, N):
+    """The three heads after conv1: conv2 (+BN, ReLU, max over points) as one batched launch, then conv3 / conv4
+    batched over the heads.  Returns [green (B,4), red (B,4), ts (B,6)]."""
+    dev = H.device
+    w = pk.wide
+    M = B * N
     keys2 = torch.zeros(3, B, 256, device=dev, dtype=torch.int32)
     ops.gemm(H, w["W2"], None, M=M, N=256, K=1024, lda=3072, ldw=1024, ldc=0, bias=w["b2"], scale=w["scale2"],
              shift=w["shift2"], act=1, slope=0.0, colmax_keys=keys2, rows_per_obj=N, batch=3,
@@ -321,7 +339,12 @@ def wide_forward(pk, feat, N):
     o4 = torch.empty(3, B, 8, device=dev, dtype=torch.float32)
     ops.gemm(x3, w["W4"], o4, M=B, N=8, K=256, lda=256, ldw=256, ldc=8, bias=w["b4"], batch=3,
              batch_strides=(B * 256, 8 * 256, B * 8, 8, 0))
-    return keys5, [o4[i, :, : w["n_out"][i]].contiguous() for i in range(3)]
+    return [o4[i, :, : w["n_out"][i]].contiguous() for i in range(3)]
+
+
+def wide_forward(pk, feat, N):
+    keys5, H = wide_gemm(pk, feat, N)
+    return keys5, head_chain(pk, H, feat.shape[0], N)
 
 
 def head_tail(hd, pooled):
@@ -381,9 +404,29 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
     xyz, mean = ops.center(points)
     graphs = Graphs(points.device, inject, record)
     feat, inter = encoder_forward(pk, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
-    keys5, (green, red, ts) = wide_forward(pk, feat, N)
-    h1, h2, back = ph_tail(pk.ph, keys5, B, points.device)
-    recon = decoder_forward(pk, feat, back, N)
+    if BRANCH_STREAMS:
+        # after the fused wide GEMM the head chain (conv2 -> max -> conv3 -> conv4) and the PH tail -> decoder chain are
+        # independent: the second runs on a side stream and fills the tail rounds / skinny launches of the first
+        cur = torch.cuda.current_stream(points.device)
+        side = _side_stream(points.device)
+        keys5, H = wide_gemm(pk, feat, N)
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        with torch.cuda.stream(side):
+            side.wait_event(fork)
+            h1, h2, back = ph_tail(pk.ph, keys5, B, points.device)
+            recon = decoder_forward(pk, feat, back, N)
+            join = torch.cuda.Event()
+            join.record(side)
+        for t in (keys5, H, feat, h1, h2, back, recon):
+            t.record_stream(side)
+        green, red, ts = head_chain(pk, H, B, N)
+        cur.wait_event(join)
+    else:
+        keys5, H = wide_gemm(pk, feat, N)
+        green, red, ts = head_chain(pk, H, B, N)
+        h1, h2, back = ph_tail(pk.ph, keys5, B, points.device)
+        recon = decoder_forward(pk, feat, back, N)
     pg, pr, fg, fr, pT, ps = ops.head_post(green, red, ts, mean)
     out = dict()
     if train_keys:
