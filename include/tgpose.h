@@ -172,6 +172,25 @@ int tgp_head_post(const float *green, const float *red, const float *ts, const f
 /* PoseNet9D.py:71 recon + mean, in place on recon (B,n,3). */
 int tgp_add_mean(float *recon, const float *mean, int B, int n, tgp_stream_t stream);
 
+/* ---- training-mode BatchNorm / dropout ------------------------------------------------------- */
+
+/* nn.BatchNorm1d in train mode on channel-last rows x (rows, C) with row stride ld: per-channel batch mean and
+ * BIASED variance (two passes, deterministic).  workspace: tgp_bn_workspace_floats(rows, C) floats. */
+int64_t tgp_bn_workspace_floats(int64_t rows, int C);
+int tgp_bn_stats(const float *x, int ld, int64_t rows, int C, float *mean, float *var, float *workspace,
+                 tgp_stream_t stream);
+
+/* y = (x - mean) / sqrt(var + eps) * gamma + beta, then leaky-relu (act = 1; per-column slope_vec overrides slope);
+ * out may alias x or be NULL; colmax_keys as in tgp_gemm_args (max over each object's rows_per_obj rows for the
+ * first cm_cols columns). */
+int tgp_bn_apply(const float *x, int ld, int64_t rows, int C, const float *mean, const float *var,
+                 const float *gamma, const float *beta, float eps, int act, float slope, const float *slope_vec,
+                 float *out, int ldo, uint32_t *colmax_keys, int ldcm, int cm_cols, int rows_per_obj,
+                 tgp_stream_t stream);
+
+/* nn.Dropout(p) in train mode with the keep mask (uint8 0/1) supplied by the host: y = keep ? x / (1 - p) : 0. */
+int tgp_dropout_apply(const float *x, const uint8_t *keep, float p, int64_t count, float *y, tgp_stream_t stream);
+
 /* ---- Chamfer distance ------------------------------------------------------------------------ */
 
 /* chamfer_3D.forward (losses/chamfer3D/chamfer_cuda.cpp:17-19,31; kernels chamfer3D.cu:12-152).

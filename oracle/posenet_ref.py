@@ -1,7 +1,8 @@
 """Oracle (TEST INFRASTRUCTURE): CPU restatement of ``PoseNet9D.forward`` and the sub-networks it
 calls, as one stateless function over a reference-format state dict.
 
-Follows, in eval mode (BatchNorm running statistics, dropout off):
+Follows, in eval mode (BatchNorm running statistics, dropout off) and -- with bn_train=True -- in training
+mode with dropout disabled (batch statistics; the running statistics after the step are returned too):
     network/fs_net_repo/PoseNet9D.py:33-91   top level, output dict
     network/fs_net_repo/FaceRecon.py:39-86   Face_Enc.forward
     network/fs_net_repo/FaceRecon.py:139-167 PH_Predictor.forward
@@ -18,7 +19,14 @@ BN_EPS = 1e-5  # nn.BatchNorm1d default, used by every BN in the reference
 
 
 def _bn(P, name, x):
-    """eval-mode BatchNorm1d over (B,C,L) or (B,C)."""
+    """BatchNorm1d over (B,C,L) or (B,C): running statistics (eval) or, when P["_bn_train"] is set, batch statistics
+    with the momentum-0.1 running-statistics update nn.BatchNorm1d makes, collected in P["_bn_new"]."""
+    if P.get("_bn_train"):
+        rm, rv = P[name + ".running_mean"].clone(), P[name + ".running_var"].clone()
+        y = F.batch_norm(x, rm, rv, P[name + ".weight"], P[name + ".bias"], True, 0.1, BN_EPS)
+        P["_bn_new"][name + ".running_mean"], P["_bn_new"][name + ".running_var"] = rm, rv
+        P["_bn_new"][name + ".num_batches_tracked"] = P[name + ".num_batches_tracked"] + 1
+        return y
     return F.batch_norm(x, P[name + ".running_mean"], P[name + ".running_var"], P[name + ".weight"],
                         P[name + ".bias"], False, 0.0, BN_EPS)
 
@@ -96,8 +104,9 @@ DEFAULT_FLAGS = dict(gcn_n_num=20, gcn_sup_num=7, obj_c=6)
 
 
 def posenet_forward(P, points, obj_id, sample_idx=None, train_keys=False, mode="exact", inject=None,
-                    flags=None, want_intermediates=False):
-    """PoseNet9D(only_encoder=False).forward in eval mode.
+                    flags=None, want_intermediates=False, bn_train=False):
+    """PoseNet9D(only_encoder=False).forward in eval mode, or (bn_train=True) in training mode with dropout
+    disabled; then out["_bn_new"] holds every BatchNorm buffer after the step.
 
     P           reference-format state dict (CPU fp32 tensors), keys as trainer/RL_TDA.py saves them
     sample_idx  (idx1, idx2) for the two Pool_layers; None -> drawn from the global CPU generator
@@ -107,6 +116,7 @@ def posenet_forward(P, points, obj_id, sample_idx=None, train_keys=False, mode="
     flags = dict(DEFAULT_FLAGS, **(flags or {}))
     P = dict(P)
     P["_support_num"] = flags["gcn_sup_num"]
+    P["_bn_train"], P["_bn_new"] = bool(bn_train), {}
     cache = G.GraphCache(mode=mode, inject=inject)
     B, N, _ = points.shape
     if sample_idx is None:
@@ -138,8 +148,35 @@ def posenet_forward(P, points, obj_id, sample_idx=None, train_keys=False, mode="
         out["h1"], out["h2"] = h1, h2
         out["feat"] = feat
         out["feat_global"] = feat_t.max(2)[0]
+    if bn_train:
+        out["_bn_new"] = P["_bn_new"]
     if want_intermediates:
         inter.update(indices=cache.record, sample_idx=sample_idx, xyz=xyz, feat=feat,
                      green=green, red=red, ts=ts, recon=recon, h1=h1, h2=h2)
+        return out, inter
+    return out
+
+
+def encoder_only_forward(P, points, obj_id, sample_idx=None, mode="exact", inject=None, flags=None, bn_train=False,
+                         want_intermediates=False):
+    """PoseNet9D(only_encoder=True).forward (PoseNet9D.py:35-45; the trainer's net2): encoder + decoder on the plain
+    feature (pred_PH=False, FaceRecon.py:190-199), keys prefixed face_enc."""
+    flags = dict(DEFAULT_FLAGS, **(flags or {}))
+    P = dict(P)
+    P["_support_num"] = flags["gcn_sup_num"]
+    P["_bn_train"], P["_bn_new"] = bool(bn_train), {}
+    cache = G.GraphCache(mode=mode, inject=inject)
+    B, N, _ = points.shape
+    if sample_idx is None:
+        i1 = G.draw_sample_idx(N)
+        sample_idx = (i1, G.draw_sample_idx(i1.numel()))
+    xyz = points - points.mean(dim=1, keepdim=True)
+    feat, inter = encoder(P, "face_enc.", xyz, obj_id, sample_idx, cache, flags)
+    recon = decoder(P, "face_enc.", feat.permute(0, 2, 1))
+    out = dict(feat_global=feat.permute(0, 2, 1).max(2)[0], recon=recon)
+    if bn_train:
+        out["_bn_new"] = P["_bn_new"]
+    if want_intermediates:
+        inter.update(indices=cache.record, sample_idx=sample_idx, feat=feat)
         return out, inter
     return out

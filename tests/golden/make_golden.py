@@ -192,6 +192,37 @@ def gen_forward(name, B, N, wseed, pseed, fseed, pts=None, obj=None, keep_feat_r
     save(name, **arrays)
 
 
+def gen_forward_train(name, B, N, wseed, pseed, fseed, steps=2):
+    """The reference in TRAINING mode (net.train(): batch-statistics BatchNorm that moves its running statistics), as
+    the trainer runs it (trainer/RL_TDA.py:116-120 never calls .eval()).  Dropout is set to p = 0: its mask comes from
+    the host generator and cannot be reproduced on another device.  `steps` consecutive forwards on the same batch;
+    the fixture holds the last step's outputs and every BatchNorm buffer after the last step."""
+    sd = iw.seeded_state_dict(wseed)
+    net = RefPoseNet9D().train()
+    net.load_state_dict(sd, strict=True)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    pts, obj = synth_points(B, N, pseed)
+    for _ in range(steps):
+        out, idx = run_reference(net, pts, obj, fseed, train=1)
+    i1, i2 = sample_indices(N, fseed)
+    arrays = dict(weight_seed=np.int64(wseed), forward_seed=np.int64(fseed), steps=np.int64(steps), points=pts, obj_id=obj,
+                  sample_idx_1=small_idx(i1), sample_idx_2=small_idx(i2))
+    for k, v in out.items():
+        if k == "feat":
+            arrays["train.feat_rows"] = v[:, :32].contiguous()
+            arrays["train.feat_rowsum"] = v.double().sum(dim=2).float()
+        else:
+            arrays["train." + k] = v
+    for k, v in idx.items():            # the graphs are the same at every step: training-mode BN ignores the running statistics
+        arrays["idx." + k] = small_idx(v)
+    for k, v in net.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            arrays["bn." + k] = v
+    save(name, **arrays)
+
+
 # ----------------------------------------------------------------------------- Chamfer
 def gen_chamfer():
     g = torch.Generator().manual_seed(21)
@@ -307,6 +338,7 @@ def main():
     gen_forward("forward_bottle.npz", 1, 1024, wseed=0, pseed=0, fseed=7, pts=bottle, obj=torch.zeros(1, 1))
     gen_forward("forward_b2_n1028.npz", 2, 1028, wseed=0, pseed=1, fseed=123)
     gen_forward("forward_b3_n256.npz", 3, 256, wseed=1, pseed=2, fseed=9, keep_feat_rows=96)
+    gen_forward_train("forward_train_b4_n256.npz", 4, 256, wseed=2, pseed=5, fseed=31)
     gen_chamfer()
 
 

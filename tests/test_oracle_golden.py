@@ -127,6 +127,28 @@ def test_forward_torch_mode_vs_reference(name):
         assert np.allclose(out[k].numpy(), g["test." + k], atol=1e-4, rtol=0), k
 
 
+@pytest.mark.parametrize("mode,inject", [("exact", True), ("torch", False)])
+def test_forward_training_mode_vs_reference(mode, inject):
+    """net.train() (batch-statistics BatchNorm, dropout p = 0), two consecutive steps as the fixture was made: the
+    last step's outputs and every BatchNorm buffer after it."""
+    g = golden("forward_train_b4_n256.npz")
+    sd = seeded_state_dict(int(g["weight_seed"]))
+    pts, obj = torch.from_numpy(g["points"]), torch.from_numpy(g["obj_id"])
+    sample = (torch.from_numpy(g["sample_idx_1"].astype(np.int64)), torch.from_numpy(g["sample_idx_2"].astype(np.int64)))
+    inj = {k[4:]: torch.from_numpy(g[k].astype(np.int64)) for k in g.files if k.startswith("idx.")} if inject else None
+    with torch.no_grad():
+        for _ in range(int(g["steps"])):
+            out = PR.posenet_forward(sd, pts, obj, sample_idx=sample, train_keys=True, mode=mode, inject=inj, bn_train=True)
+            sd.update(out.pop("_bn_new"))
+    for k in ("recon", "p_green_R", "p_red_R", "f_green_R", "f_red_R", "Pred_T", "Pred_s", "h1", "h2", "feat_global"):
+        assert np.allclose(out[k].numpy(), g["train." + k], atol=2e-5, rtol=0), k
+    assert np.allclose(out["feat"][:, :32].numpy(), g["train.feat_rows"], atol=2e-5, rtol=0)
+    bn_keys = [k for k in g.files if k.startswith("bn.")]
+    assert len(bn_keys) == 3 * 19                  # 18 BatchNorm1d on the path + encoder.proj_layer.1 (unused: untouched)
+    for k in bn_keys:
+        assert np.allclose(sd[k[3:]].numpy(), g[k], atol=1e-5, rtol=1e-5), k
+
+
 def test_chamfer_vs_reference_unit_test_rule():
     """losses/metrics/CD/unit_test.py:22-33: mean squared distance error < 1e-8, indices identical."""
     g = golden("chamfer.npz")

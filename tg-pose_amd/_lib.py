@@ -64,6 +64,11 @@ SIGNATURES = {
     "tgp_sigmoid": (c_int, [c_vp, c_vp, c_i64, c_vp]),
     "tgp_head_post": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tgp_add_mean": (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
+    "tgp_bn_workspace_floats": (c_i64, [c_i64, c_int]),
+    "tgp_bn_stats": (c_int, [c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "tgp_bn_apply": (c_int, [c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_int, c_f32, c_vp, c_vp, c_int, c_vp,
+                             c_int, c_int, c_int, c_vp]),
+    "tgp_dropout_apply": (c_int, [c_vp, c_vp, c_f32, c_i64, c_vp, c_vp]),
     "tgp_chamfer_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tgp_chamfer_bwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tgp_dcd_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_f32, c_int, c_vp, c_vp, c_vp, c_vp]),

@@ -1,4 +1,5 @@
-"""Eval-mode forward pipeline of PoseNet9D on the HIP kernels (host orchestration only).
+"""Forward pipeline of PoseNet9D on the HIP kernels (host orchestration only): eval mode, and at the end of the
+file the training-mode variant (batch-statistics BatchNorm, dropout).
 
 This file turns a reference-format state dict into packed device weights (BatchNorm folded into
 per-channel scale/shift, HS-layer projection and STE weights concatenated into one GEMM operand,
@@ -26,10 +27,21 @@ FEAT_LD = 1292          # 1286 + 3 (xyz) rounded up to a multiple of 4 floats (1
 LEVEL_CH = ((128, 128), (128, 256), (256, 256), (256, 512))   # (Cin, Cout) of conv_1..conv_4
 
 
-def _bn_fold(sd, name):
+_FOLDS = None   # while a Packed is being built: list of (bn name, scale tensor, shift tensor) to refresh later
+
+
+def _fold_values(sd, name):
     scale = sd[name + ".weight"] / torch.sqrt(sd[name + ".running_var"] + BN_EPS)
-    shift = sd[name + ".bias"] - sd[name + ".running_mean"] * scale
-    return scale.contiguous(), shift.contiguous()
+    return scale, sd[name + ".bias"] - sd[name + ".running_mean"] * scale
+
+
+def _bn_fold(sd, name):
+    """eval-mode BatchNorm as per-channel (scale, shift); registered so Packed.refold can refresh it in place"""
+    scale, shift = _fold_values(sd, name)
+    scale, shift = scale.contiguous(), shift.contiguous()
+    if _FOLDS is not None:
+        _FOLDS.append((name, scale, shift))
+    return scale, shift
 
 
 def _pad_cols(w, cols):
@@ -112,7 +124,7 @@ def pack_head(sd, h):
 HEAD_ORDER = ("rot_green", "rot_red", "ts")
 
 
-def pack_wide(ph, heads):
+def pack_wide(ph, heads, bn_names=None):
     """conv_5 (PH_Predictor) and the three heads' conv1 all read `feat`: one (4096, 1292) operand.
     Columns [0,1024) = conv_5 (no bias, LeakyReLU 0.2, only its max over points is needed);
     columns [1024,4096) = rot_green | rot_red | ts conv1 (+bias, ReLU).  Also stacks the heads' conv2."""
@@ -136,21 +148,42 @@ def pack_wide(ph, heads):
     w["W4"] = torch.stack([_pad_rows(hd["c4"][0], 8) for hd in heads]).contiguous()
     w["b4"] = torch.stack([_pad_rows(hd["c4"][1].unsqueeze(1), 8)[:, 0] for hd in heads]).contiguous()
     w["n_out"] = [hd["c4"][0].shape[0] for hd in heads]
+    if _FOLDS is not None and bn_names is not None:      # the concatenated copies must follow the running statistics too
+        _FOLDS.append((bn_names["conv5"], w["scale"][0:1024], w["shift"][0:1024]))
+        for i, h in enumerate(bn_names["heads"]):
+            _FOLDS.append((h + "bn1", w["scale"][1024 * (i + 1):1024 * (i + 2)], w["shift"][1024 * (i + 1):1024 * (i + 2)]))
+            _FOLDS.append((h + "bn2", w["scale2"][i], w["shift2"][i]))
+            _FOLDS.append((h + "bn3", w["scale3"][i], w["shift3"][i]))
     return w
 
 
 class Packed(object):
-    """Device-resident, kernel-ready weights of one PoseNet9D (eval mode)."""
+    """Device-resident, kernel-ready weights of one PoseNet9D.  The heavy operands (concatenated / padded / bf16-split
+    weights) depend on the parameters only; the eval-mode BatchNorm folds also depend on the running statistics and
+    are refreshed in place by refold() when those change (every training step moves them)."""
 
     def __init__(self, sd, device, face="face_all.", with_heads=True):
+        global _FOLDS
         sd = _dev_sd(sd, device)
-        self.device = device
-        self.conv = pack_encoder(sd, face + "encoder.", device)
-        self.ph = pack_ph(sd, face + "ph_pred.")
-        self.dec, self.dec_out = pack_decoder(sd, face + "decoder.")
-        self.heads = {h: pack_head(sd, h + ".") for h in ("rot_green", "rot_red", "ts")} if with_heads else {}
-        if with_heads:
-            self.wide = pack_wide(self.ph, [self.heads[h] for h in HEAD_ORDER])
+        self.device, self.face = device, face
+        self.folds = _FOLDS = []
+        try:
+            self.conv = pack_encoder(sd, face + "encoder.", device)
+            self.ph = pack_ph(sd, face + "ph_pred.")
+            self.dec, self.dec_out = pack_decoder(sd, face + "decoder.")
+            self.heads = {h: pack_head(sd, h + ".") for h in HEAD_ORDER} if with_heads else {}
+            if with_heads:
+                self.wide = pack_wide(self.ph, [self.heads[h] for h in HEAD_ORDER],
+                                      dict(conv5=face + "ph_pred.conv_5.1", heads=[h + "." for h in HEAD_ORDER]))
+        finally:
+            _FOLDS = None
+
+    def refold(self, sd):
+        sd = _dev_sd(sd, self.device)
+        for name, scale, shift in self.folds:
+            sc, sh = _fold_values(sd, name)
+            scale.copy_(sc)
+            shift.copy_(sh)
 
 
 def _i32(idx, device):
@@ -448,4 +481,181 @@ def encoder_only_forward(pk, points, obj_id, sample_idx=None, inject=None, recor
     graphs = Graphs(points.device, inject, record, prefix="face_enc.encoder.")
     feat, _ = encoder_forward(pk, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
     recon = decoder_forward(pk, feat, None, N)
+    return dict(feat_global=ops.colmax(feat[:, :, :FEAT_C]), recon=recon)
+
+
+# =====================================================================================================
+# Training-mode forward (module.training == True): BatchNorm uses batch statistics and updates its running
+# statistics, dropout is active.  Forward only (what the reference's net2 runs under torch.no_grad() every step,
+# trainer/RL_TDA.py:117-118, and the forward half of net1's step); the backward pass is not built yet.
+# The dense layers run the same GEMM kernels without the folded scale/shift; tgp_bn_stats / tgp_bn_apply then
+# normalise in place (two deterministic reduction passes + one apply pass over the activation).
+# =====================================================================================================
+class TrainBN(object):
+    def __init__(self, sd, momentum=0.1, update_running=True):
+        self.sd, self.momentum, self.update = sd, momentum, update_running
+
+    def _update(self, name, mean, var, rows):
+        if not self.update:
+            return
+        rm, rv = self.sd[name + ".running_mean"], self.sd[name + ".running_var"]
+        m = self.momentum
+        rm.mul_(1 - m).add_(mean, alpha=m)
+        rv.mul_(1 - m).add_(var, alpha=m * rows / max(rows - 1, 1))     # unbiased estimate, as nn.BatchNorm1d
+        self.sd[name + ".num_batches_tracked"].add_(1)
+
+    def __call__(self, name, x, act=0, slope=0.0, **kw):
+        out, mean, var = ops.bn_train(x, self.sd[name + ".weight"], self.sd[name + ".bias"], BN_EPS, act, slope, **kw)
+        self._update(name, mean, var, math.prod(x.shape[:-1]))
+        return out
+
+    def multi(self, names, x, act, slope_vec, **kw):
+        """one normalisation over columns that belong to several BatchNorm modules (the fused wide GEMM)"""
+        gamma = torch.cat([self.sd[n + ".weight"] for n in names])
+        beta = torch.cat([self.sd[n + ".bias"] for n in names])
+        out, mean, var = ops.bn_train(x, gamma, beta, BN_EPS, act, 0.0, slope_vec=slope_vec, **kw)
+        rows, o = math.prod(x.shape[:-1]), 0
+        for n in names:
+            c = self.sd[n + ".weight"].numel()
+            self._update(n, mean[o:o + c], var[o:o + c], rows)
+            o += c
+        return out
+
+
+def encoder_forward_train(pk, bn, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6):
+    """Face_Enc.forward with batch-statistics BatchNorm (bn1..bn3)."""
+    e = pk.face + "encoder."
+    dev = points_c.device
+    B, N, _ = points_c.shape
+    xyz = points_c
+    feat = torch.empty(B, N, FEAT_LD, device=dev, dtype=torch.float32)
+    N1, N2 = sample_idx[0].numel(), sample_idx[1].numel()
+    s12 = _upload_i32(torch.cat([sample_idx[0].reshape(-1), sample_idx[1].reshape(-1)]), dev)
+    s1, s2 = s12[:N1], s12[N1:]
+    knn0 = {}
+
+    def xyz_graph(level, pts, k):
+        if level not in knn0:
+            knn0[level] = ops.knn_xyz(pts, k)
+        return knn0[level]
+
+    cv = pk.conv
+    fm0 = feat[:, :, 0:128]
+    surface_layer(cv[0], xyz, graphs.get("conv_0.rf", lambda: xyz_graph(0, xyz, kmax)),
+                  graphs.get("conv_0.orl_xyz", lambda: xyz_graph(0, xyz, kmax)), fm0, act="relu")
+    fm1 = feat[:, :, 128:256]
+    hs_layer(cv[1], xyz, fm0, graphs.get("conv_1.rf", lambda: ops.knn_feat(fm0, kmax)),
+                    graphs.get("conv_1.orl_xyz", lambda: xyz_graph(0, xyz, kmax)), fm1)
+    bn(e + "bn1", fm1, act=1)
+    v1, fp1 = ops.pool(xyz, fm1, graphs.get("pool_1.xyz", lambda: xyz_graph(0, xyz, kmax)), s1, kpool=4)
+    k1 = min(kmax, N1 // 8)
+    fm2 = torch.empty(B, N1, 256, device=dev, dtype=torch.float32)
+    hs_layer(cv[2], v1, fp1, graphs.get("conv_2.rf", lambda: ops.knn_feat(fp1, k1)),
+                    graphs.get("conv_2.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm2)
+    bn(e + "bn2", fm2, act=1)
+    fm3 = torch.empty(B, N1, 256, device=dev, dtype=torch.float32)
+    hs_layer(cv[3], v1, fm2, graphs.get("conv_3.rf", lambda: ops.knn_feat(fm2, k1)),
+                    graphs.get("conv_3.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm3)
+    bn(e + "bn3", fm3, act=1)
+    v2, fp2 = ops.pool(v1, fm3, graphs.get("pool_2.xyz", lambda: xyz_graph(1, v1, k1)), s2, kpool=4)
+    k2 = min(kmax, N2 // 8)
+    fm4 = torch.empty(B, N2, 512, device=dev, dtype=torch.float32)
+    hs_layer(cv[4], v2, fp2, graphs.get("conv_4.rf", lambda: ops.knn_feat(fp2, k2)),
+             graphs.get("conv_4.orl_xyz", lambda: xyz_graph(2, v2, k2)), fm4)
+    near1 = graphs.get("up_1", lambda: ops.nn1(xyz, v1)).view(B, N)
+    near2 = graphs.get("up_2", lambda: ops.nn1(xyz, v2)).view(B, N)
+    ops.gather_rows(fm2, near1, feat[:, :, 256:512])
+    ops.gather_rows(fm3, near1, feat[:, :, 512:768])
+    ops.gather_rows(fm4, near2, feat[:, :, 768:1280])
+    ops.fill_tail(obj_id.reshape(-1).float(), xyz, feat, 1280, n_cls)
+    return feat
+
+
+def decoder_forward_train(pk, bn, feat, back, N):
+    d = pk.face + "decoder."
+    names = (d + "conv1d_block.1", d + "conv1d_block.4", d + "conv1d_block.7", d + "recon_head.1")
+    w0, b0, _, _, ws0 = pk.dec[0]
+    rb = ops.linear_rows(back, w0) if back is not None else None
+    x = ops.linear_rows(feat, w0, bias=b0, rowbias=rb, rows_per_obj=N, w_split=ws0)
+    bn(names[0], x, act=1)
+    for (w, b, _, _, ws), nm in zip(pk.dec[1:], names[1:]):
+        x = ops.linear_rows(x, w, bias=b, w_split=ws)
+        bn(nm, x, act=1)
+    return ops.linear_rows(x, pk.dec_out[0], bias=pk.dec_out[1])
+
+
+def posenet_forward_train(pk, sd, points, obj_id, train_keys, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6,
+                          dropout_p=(0.5, 0.2), update_running=True, generator=None):
+    """PoseNet9D(only_encoder=False).forward with module.training == True (no autograd)."""
+    B, N, _ = points.shape
+    if B < 2:     # bn5 / the heads' bn3 normalise over the B pooled rows; torch refuses a single row the same way
+        raise ValueError("Expected more than 1 value per channel when training, got input size [%d, 256]" % B)
+    if sample_idx is None:
+        sample_idx = draw_sample_idx(N)
+    dev = points.device
+    points = points.contiguous().float()
+    bn = TrainBN(sd, update_running=update_running)
+    xyz, mean = ops.center(points)
+    graphs = Graphs(dev, inject, record)
+    feat = encoder_forward_train(pk, bn, xyz, obj_id.to(dev), sample_idx, graphs, kmax, n_cls)
+    M = B * N
+    w = pk.wide
+    ph = pk.face + "ph_pred."
+    # conv_5 | three head conv1 in one GEMM (bias only), then one batch-statistics normalisation over the 4096 columns
+    Hall = torch.empty(M, 4096, device=dev, dtype=torch.float32)
+    ops.gemm(feat, w["W"], Hall, M=M, N=4096, K=FEAT_LD, lda=FEAT_LD, ldw=FEAT_LD, ldc=4096, bias=w["bias"], w_split=w["Ws"],
+             k_alg=w["k_alg"])
+    keys5 = torch.zeros(B, 1024, device=dev, dtype=torch.int32)
+    bn.multi([ph + "conv_5.1"] + [h + ".bn1" for h in HEAD_ORDER], Hall, 1, w["slope"], colmax_keys=keys5, cm_cols=1024,
+             rows_per_obj=N)
+    # PH tail
+    g = ops.colmax_decode(keys5, out2=True)
+    fa = ops.linear_rows(g, pk.ph["l1"])
+    bn(ph + "bn5", fa, act=1, slope=0.2)
+    fa = ops.dropout(fa, dropout_p[0], generator)
+    pi = ops.linear_rows(fa, pk.ph["l23"][0], bias=pk.ph["l23"][1])
+    back = torch.zeros(B, FEAT_LD, device=dev, dtype=torch.float32)
+    ops.linear_rows(pi, pk.ph["l45"][0], bias=pk.ph["l45"][1], out=back[:, :FEAT_C])
+    hcode = ops.sigmoid(pi)
+    nc = pk.ph["n_code"]
+    recon = decoder_forward_train(pk, bn, feat, back, N)
+    # heads: conv2 raw for the three heads in one batched launch, per-head BatchNorm + ReLU + max over points
+    X2 = torch.empty(3, M, 256, device=dev, dtype=torch.float32)
+    ops.gemm(Hall[:, 1024:], w["W2"], X2, M=M, N=256, K=1024, lda=4096, ldw=1024, ldc=256, bias=w["b2"], batch=3,
+             batch_strides=(1024, 256 * 1024, M * 256, 256, 0), w_split=w["W2s"])
+    keys2 = torch.zeros(3, B, 256, device=dev, dtype=torch.int32)
+    outs = []
+    for i, h in enumerate(HEAD_ORDER):
+        bn(h + ".bn2", X2[i], act=1, colmax_keys=keys2[i], rows_per_obj=N, want_out=False)
+    pooled = ops.colmax_decode(keys2.view(3 * B, 256)).view(3, B, 256)
+    for i, h in enumerate(HEAD_ORDER):
+        hd = pk.heads[h]
+        x = ops.linear_rows(pooled[i], hd["c3"][0], bias=hd["c3"][1])
+        bn(h + ".bn3", x, act=1)
+        x = ops.dropout(x, dropout_p[1], generator)
+        outs.append(ops.linear_rows(x, hd["c4"][0], bias=hd["c4"][1]))
+    green, red, ts = outs
+    pg, pr, fg, fr, pT, ps = ops.head_post(green, red, ts, mean)
+    out = dict()
+    if train_keys:
+        out["recon"] = ops.add_mean_(recon, mean)
+    out.update(p_green_R=pg, p_red_R=pr, f_green_R=fg, f_red_R=fr, Pred_T=pT, Pred_s=ps)
+    if train_keys:
+        out["h1"], out["h2"] = hcode[:, :nc], hcode[:, nc:]
+        out["feat"] = feat[:, :, :FEAT_C]
+        out["feat_global"] = ops.colmax(feat[:, :, :FEAT_C])
+    return out
+
+
+def encoder_only_forward_train(pk, sd, points, obj_id, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6,
+                               update_running=True):
+    """PoseNet9D(only_encoder=True).forward in training mode (the reference's net2)."""
+    B, N, _ = points.shape
+    if sample_idx is None:
+        sample_idx = draw_sample_idx(N)
+    bn = TrainBN(sd, update_running=update_running)
+    xyz, mean = ops.center(points.contiguous().float())
+    graphs = Graphs(points.device, inject, record, prefix="face_enc.encoder.")
+    feat = encoder_forward_train(pk, bn, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
+    recon = decoder_forward_train(pk, bn, feat, None, N)
     return dict(feat_global=ops.colmax(feat[:, :, :FEAT_C]), recon=recon)

@@ -4,7 +4,8 @@
 reference's key sets (PoseNet9D.py:69-90: 11 keys when FLAGS.train, 6 otherwise), submodule
 names (face_all / face_enc, rot_green, rot_red, ts) and therefore state-dict keys, so
 ``load_state_dict(checkpoint['net1_state_dict'])`` (evaluater/RT_TDA_Evaluater.py:39) works
-unchanged.  The forward is the eval-mode HIP pipeline; extra keyword-only arguments let tests
+unchanged.  The forward is the HIP pipeline of ``tgpose_amd.engine`` -- eval mode, or training mode
+(batch-statistics BatchNorm, dropout) without autograd; extra keyword-only arguments let tests
 pin the random subsample and inject / record neighbour graphs.
 """
 import torch
@@ -31,18 +32,39 @@ class PoseNet9D(_WithBuffers):
             self.face_enc = FaceNet()
 
     def packed(self, device):
-        face = "face_enc." if self.only_encoder else "face_all."
-        return self._packed(lambda: engine.Packed(self.state_dict(), device, face=face,
-                                                  with_heads=not self.only_encoder))
+        """Kernel-ready weights: rebuilt when a parameter changes, BatchNorm folds refreshed when only the running
+        statistics changed (a training-mode forward moves them)."""
+        psig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        bsig = tuple((b.data_ptr(), b._version) for b in self.buffers())
+        if getattr(self, "_pk_psig", None) != psig:
+            face = "face_enc." if self.only_encoder else "face_all."
+            self._pk = engine.Packed(self.state_dict(), device, face=face, with_heads=not self.only_encoder)
+            self._pk_psig, self._pk_bsig = psig, bsig
+        elif self._pk_bsig != bsig:
+            self._pk.refold(self.state_dict())
+            self._pk_bsig = tuple((b.data_ptr(), b._version) for b in self.buffers())
+        return self._pk
 
     def forward(self, points, obj_id, enable_proj=False, *, sample_idx=None, inject=None, record=None):
-        _need_eval(self)
         if enable_proj:
             raise NotImplementedError("enable_proj=True is never used by the reference's train/eval path")
         if not points.is_cuda:
             raise RuntimeError("tgpose_amd.PoseNet9D runs on the GPU only (no CPU fallback); move inputs to cuda")
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "PoseNet9D: the training-mode forward is built (batch-statistics BatchNorm, dropout) but the backward pass "
+                "is not; call it under torch.no_grad() (as trainer/RL_TDA.py:117-118 does for net2) or use .eval()")
         pk = self.packed(points.device)
         with torch.no_grad():
+            if self.training:
+                sd = self.state_dict()
+                if self.only_encoder:
+                    return engine.encoder_only_forward_train(pk, sd, points, obj_id, sample_idx, inject, record,
+                                                             FLAGS.gcn_n_num, FLAGS.obj_c)
+                p_ph = self.face_all.ph_pred.dp1.p
+                p_hd = self.rot_green.drop1.p
+                return engine.posenet_forward_train(pk, sd, points, obj_id, bool(FLAGS.train), sample_idx, inject, record,
+                                                    FLAGS.gcn_n_num, FLAGS.obj_c, dropout_p=(p_ph, p_hd))
             if self.only_encoder:
                 return engine.encoder_only_forward(pk, points, obj_id, sample_idx, inject, record,
                                                    FLAGS.gcn_n_num, FLAGS.obj_c)

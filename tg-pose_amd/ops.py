@@ -394,3 +394,39 @@ def generate_rt(p_green, p_red, f_green, f_red, T, sym=None):
     check(_lib.lib().tgp_generate_rt(_p(p_green), _p(p_red), _p(f_green), _p(f_red), _p(T), _p(sym), sld, B, _p(out),
                                      _stream(p_green)), "tgp_generate_rt")
     return out
+
+
+def bn_train(x, gamma, beta, eps=1e-5, act=0, slope=0.0, slope_vec=None, out=None, colmax_keys=None, cm_cols=0,
+             rows_per_obj=0, want_out=True):
+    """Training-mode BatchNorm over rows: x (..., C) rows (row stride may exceed C).  Normalises (in place unless `out`),
+    applies the activation, optionally feeds colmax keys.  Returns (out, batch_mean (C,), biased batch_var (C,))."""
+    x, ld = _rows(x, "x")
+    C = x.shape[-1]
+    rows = math.prod(x.shape[:-1])
+    dev = x.device
+    mean = torch.empty(C, device=dev, dtype=torch.float32)
+    var = torch.empty(C, device=dev, dtype=torch.float32)
+    ws = torch.empty(_lib.lib().tgp_bn_workspace_floats(rows, C), device=dev, dtype=torch.float32)
+    check(_lib.lib().tgp_bn_stats(_p(x), ld, rows, C, _p(mean), _p(var), _p(ws), _stream(x)), "tgp_bn_stats")
+    ldo = 0
+    if want_out:
+        out = x if out is None else out
+        out, ldo = _rows(out, "out")
+    else:
+        out = None
+    check(_lib.lib().tgp_bn_apply(_p(x), ld, rows, C, _p(mean), _p(var), _p(gamma), _p(beta), float(eps), act, float(slope),
+                                  _p(slope_vec), _p(out), ldo, _p(colmax_keys),
+                                  colmax_keys.stride(-2) if colmax_keys is not None else 0, cm_cols, rows_per_obj, _stream(x)),
+          "tgp_bn_apply")
+    return out, mean, var
+
+
+def dropout(x, p, generator=None):
+    """nn.Dropout(p) in train mode: the keep mask comes from torch's generator on the tensor's device."""
+    if p <= 0.0:
+        return x
+    x = x.contiguous()
+    keep = (torch.rand(x.shape, device=x.device, generator=generator) >= p).to(torch.uint8)
+    y = torch.empty_like(x)
+    check(_lib.lib().tgp_dropout_apply(_p(x), _p(keep), float(p), x.numel(), _p(y), _stream(x)), "tgp_dropout_apply")
+    return y
