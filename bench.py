@@ -79,8 +79,9 @@ def main():
                     help="batches in flight per GPU: step i runs on HIP stream i %% S (independent batches overlap "
                          "each other's tail rounds and small kernels)")
     ap.add_argument("--no-branch-streams", action="store_true", help="run the decoder branch in line instead of on a side stream")
-    ap.add_argument("--gemm", choices=("split", "fp32"), default="split",
-                    help="split: fp32-accurate GEMM on the bf16 matrix cores (3-term operand split, 6 MFMA terms); "
+    ap.add_argument("--gemm", choices=("split16", "split", "fp32"), default="split16",
+                    help="split16: fp32-accurate GEMM on the fp16 matrix cores (2-term operand split, 3 MFMA terms); "
+                         "split: the same on the bf16 matrix cores (3-term split, 6 MFMA terms, full fp32 range); "
                          "fp32: v_mfma_f32_32x32x2_f32 kernels")
     args = ap.parse_args()
 
@@ -163,8 +164,8 @@ def main():
         traffic = None
         try:   # HBM/fabric bytes per launch of the dominant kernel from the committed PMC passes (not a live measurement)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")))["kernels"]
-            key = "void gemm_split_kernel<true>" if args.gemm == "split" else "gemm_main256_kernel"
-            traffic = pmc[key]["bytes_per_launch_corrected"] if key in pmc and args.gemm == "split" else None
+            key = {"split": "void gemm_split_kernel<true>", "split16": "void gemm_split_kernel<true, true>"}.get(args.gemm)
+            traffic = pmc[key]["bytes_per_launch_corrected"] if key in pmc else None
         except Exception:
             traffic = None
         launches = len(timer)
@@ -176,6 +177,11 @@ def main():
             peak = PEAK_BF16_MFMA_TFLOPS / 6.0
             peak_basis = ("algorithmic fp32 FLOPs; each fp32 product costs 6 bf16 MFMA terms (3-term operand split), so "
                           "the bound is the dense bf16 MFMA peak 2500 TFLOP/s / 6; for scale, the fp32 MFMA peak is 157.3")
+        elif args.gemm == "split16":
+            kernel_name = "gemm_split_kernel<f16>"
+            peak = PEAK_BF16_MFMA_TFLOPS / 3.0
+            peak_basis = ("algorithmic fp32 FLOPs; each fp32 product costs 3 fp16 MFMA terms (2-term operand split), so the "
+                          "bound is the dense fp16 MFMA peak 2500 TFLOP/s / 3; for scale, the fp32 MFMA peak is 157.3")
         else:
             kernel_name = "gemm_main256_kernel / gemm_main_kernel"
             peak = PEAK_F32_MFMA_TFLOPS
@@ -188,8 +194,9 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "gemm_mode": ("fp32-accurate 3xbf16 operand split on the bf16 matrix cores, fp32 accumulate" if args.gemm == "split"
-                          else "fp32 MFMA"),
+            "gemm_mode": {"split": "fp32-accurate 3xbf16 operand split on the bf16 matrix cores, fp32 accumulate",
+                          "split16": "fp32-accurate 2xfp16 operand split on the fp16 matrix cores, fp32 accumulate",
+                          "fp32": "fp32 MFMA"}[args.gemm],
             "config": {"workload": "PoseNet9D.forward eval mode, full forward (kNN graphs + 3D-GCN encoder + PH predictor "
                                    "+ decoder + R/t/s heads), B=%d objects per GPU, N=%d points, seeded random weights "
                                    "of the reference architecture (27.43 M params)" % (B, N_POINTS),

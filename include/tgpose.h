@@ -143,12 +143,19 @@ typedef struct tgp_gemm_args {
      * 3-term operand split (six MFMA terms, fp32 accumulate): fp32-level accuracy at 2.67x fewer MFMA cycles.
      * W itself is still required (small launches and the skinny kernel read it). */
     const uint16_t *W_split; int ldws;
+    /* 0: W_split holds the three bf16 planes of tgp_split_bf16 (any fp32-range operands);
+     * 1: the two fp16 planes of tgp_split_f16 ([batch*N][ldws/16][2][16]) -- three MFMA terms instead of six, products
+     *    accurate to ~2^-22; requires |A|, |W| < 65504 (an out-of-range operand yields inf/NaN, never a wrong finite
+     *    number) */
+    int w_split_kind;
 } tgp_gemm_args;
 
 /* W (rows, K) fp32, row stride ld -> out[rows][ldo/16][3][16] bf16: per 16-wide K-tile the hi, mid and lo terms
  * (x = hi+mid+lo to 2^-24) stored back to back; columns K..ldo-1 zero.  3*rows*ldo elements.  Done once per
  * weight version. */
 int tgp_split_bf16(const float *W, int rows, int K, int ld, uint16_t *out, int ldo, tgp_stream_t stream);
+/* Same for the two-term fp16 split: out[rows][ldo/16][2][16] (hi, lo), 2*rows*ldo elements. */
+int tgp_split_f16(const float *W, int rows, int K, int ld, uint16_t *out, int ldo, tgp_stream_t stream);
 
 /* nn.Conv1d(kernel 1) / nn.Linear on channel-last rows with the fused epilogue above. */
 int tgp_gemm_f32(const tgp_gemm_args *args, tgp_stream_t stream);

@@ -34,7 +34,7 @@ class GemmArgs(ctypes.Structure):
         ("batch", c_int),
         ("batch_stride_a", c_i64), ("batch_stride_w", c_i64), ("batch_stride_c", c_i64),
         ("batch_stride_vec", c_i64), ("batch_stride_colmax", c_i64),
-        ("W_split", c_vp), ("ldws", c_int),
+        ("W_split", c_vp), ("ldws", c_int), ("w_split_kind", c_int),
     ]
 
 
@@ -58,6 +58,7 @@ SIGNATURES = {
     "tgp_gather_rows": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     "tgp_fill_tail": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
     "tgp_split_bf16": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),
+    "tgp_split_f16": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     "tgp_gemm_f32": (c_int, [ctypes.POINTER(GemmArgs), c_vp]),
     "tgp_colmax_decode": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "tgp_colmax": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),

@@ -47,6 +47,12 @@ struct GemmParams {
     int64_t sq;
     const uint16_t *Wsplit;      // bf16 (hi, mid, lo) of W as [N][ldws / 16][3][16], ldws % 16 == 0, zero padded
     int ldws;
+    int split_f16;               // 0: three bf16 planes, 1: two fp16 planes
+    // block order of the split kernel: segment g covers blocks [seg_end[g-1], seg_end[g]) and maps them to consecutive
+    // tiles of one kind starting at seg_base[g] (bit g of seg_small: half-size tiles)
+    int nseg, seg_small;
+    int seg_end[8], seg_base[8];
+    unsigned long long *stamps;  // development only: per block {start, loop start, loop end, end} of s_memrealtime (100 MHz)
     int64_t sWS;                 // per-batch stride of Wsplit in bf16 elements of one plane
     int64_t plane;               // elements between planes
     // tile schedule of the main kernel: per batch, M-tile rows [0, mt_big) use 128x128 tiles, the rest 64x64
@@ -292,24 +298,48 @@ __device__ __forceinline__ void split3(const float4 v, uint2 &hi, uint2 &mid, ui
 
 // W planes are stored interleaved per K-tile: Wsplit[row][k / 16][plane][16] bf16, so the 3 x 16 values one
 // K-tile needs from a row are 96 contiguous bytes = six 16-byte chunks (chunk c: plane c / 2, k half c % 2).
-template <int BM, int BN, int NWM, int NWN, bool DBUF>
+//
+// F16 = true is the two-term fp16 variant: x = hi + lo with 2 x 11 significand bits, a*b ~ hh + hl + lh (the dropped ll
+// term is <= 2^-22 |ab|; the operand itself is represented to ~2^-23), three v_mfma_f32_32x32x16_f16 per block instead
+// of six: half the matrix-core cycles again.  Its price is fp16's range: |a|, |w| must stay below 65504 (an
+// overflowing operand becomes inf and the output NaN -- loud, not silent) and terms below 6e-8 vanish (an absolute
+// error far under fp32's rounding of any O(1) dot product).  W planes: Wsplit[row][k / 16][2][16].
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split2(const float4 v, uint2 &hi, uint2 &lo)
+{
+    // vector form so that the packed conversions of gfx950 (v_cvt_pk_f16_f32) and v_pk_add_f32 are used
+    const f32x4 x = {v.x, v.y, v.z, v.w};
+    const f16x4 h = __builtin_convertvector(x, f16x4);
+    const f32x4 rest = x - __builtin_convertvector(h, f32x4);
+    const f16x4 l = __builtin_convertvector(rest, f16x4);
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+}
+
+template <int BM, int BN, int NWM, int NWN, int PD, bool F16, bool SKEW>
 __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m0, const int n0, const int z, char *smem)
 {
     constexpr int THREADS = 64 * NWM * NWN;
     constexpr int BK = 16;
+    constexpr int NP = F16 ? 2 : 3;           // operand planes
     constexpr int ROWB = BK * 2 + 16;         // LDS row of one plane: 16 bf16 + 16 B pad (conflict-free ds_read_b128)
     constexpr int WTM = BM / NWM, WTN = BN / NWN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int RPP = THREADS / 4;          // A: 4 threads per row, one float4 each
     constexpr int PA = (BM + RPP - 1) / RPP;
-    constexpr int WCH = BN * 6;               // W: 16-byte chunks per K-tile
+    constexpr int NCH = 2 * NP;               // 16-byte chunks per row and K-tile
+    constexpr int WCH = BN * NCH;             // W: 16-byte chunks per K-tile
     constexpr int PW = (WCH + THREADS - 1) / THREADS;
     // plane strides carry 32 extra bytes: the hi / mid / lo planes then start 8 banks apart, which removes the 3-way
     // conflicts of the staging writes (one row's six W chunks, or one A quad's three terms, hit distinct banks)
     constexpr int PLANE_A = BM * ROWB + 32, PLANE_W = BN * ROWB + 32;
-    constexpr int BUFB = 3 * (PLANE_A + PLANE_W);
+    constexpr int BUFB = NP * (PLANE_A + PLANE_W);
     char *lds_a = smem;
-    char *lds_w = smem + 3 * PLANE_A;
+    char *lds_w = smem + NP * PLANE_A;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -317,53 +347,72 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
     const int r = lane & 31, h = lane >> 5;
     const float *A = p.A + (int64_t)z * p.sA;
     const uint16_t *WS = p.Wsplit + (int64_t)z * p.sWS;
-    const int64_t wrow = 3 * (int64_t)p.ldws; // elements per row of Wsplit
+    const int64_t wrow = NP * (int64_t)p.ldws; // elements per row of Wsplit
 
+    // PD = 0: one LDS stage.  PD >= 1: two LDS stages, global loads PD K-tiles ahead of the MFMAs through a ring of PD
+    // register sets (8 VGPRs each on the big tile): one K-tile of MFMAs is ~0.6 us, shorter than a loaded memory
+    // system's latency, so a single tile of lookahead leaves the matrix cores waiting.
+    constexpr bool DBUF = PD > 0;
+    constexpr int NS = PD > 0 ? PD : 1;
     const int kq = tid & 3, r0 = tid >> 2;
-    float4 ra[PA];
-    uint4 rw[PW];
+    float4 ra_[NS][PA];
+    uint4 rw_[NS][PW];
 
-    auto load_tile = [&](int kt) {
-        const int kcol = kt * BK + kq * 4;
-        const bool kok = kcol < p.K;
-        const int kc = kok ? kcol : 0;
+    // Operand loads are buffer loads against per-tile resource descriptors whose extent ends at the operand's last
+    // valid row: rows past M (N) read as zero in hardware, so the loads carry no predicates, sit in straight-line code
+    // and stay in flight across K-tiles (with per-lane guards the compiler wraps each load in a branch and has to drain
+    // vmcnt to zero around it, which serialises the prefetch).  The K tail of A is masked when the tile is stored.
+    const int64_t a_rows = p.M - m0, w_rows = p.N - n0;
+    const int64_t a_bytes = a_rows * p.lda * 4 - (p.lda - p.K) * 4, w_bytes = w_rows * wrow * 2;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(A + (int64_t)m0 * p.lda), 0, (int)(a_bytes > 0x7fffffff ? 0x7fffffff : a_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t *>(WS + (int64_t)n0 * wrow), 0, (int)(w_bytes > 0x7fffffff ? 0x7fffffff : w_bytes), 0x00020000);
+    int voff_a[PA], voff_w[PW];
 #pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            if (RPP * i + r0 < BM) {
-                const int row = m0 + r0 + RPP * i;
-                const bool ok = kok && row < p.M;
-                const float4 v = *reinterpret_cast<const float4 *>(A + (int64_t)(row < p.M ? row : p.M - 1) * p.lda + kc);
-                ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
+    for (int i = 0; i < PA; ++i) voff_a[i] = ((r0 + RPP * i) * p.lda + kq * 4) * 4;
 #pragma unroll
-        for (int i = 0; i < PW; ++i) {
-            const int g = tid + THREADS * i;
-            if (g < WCH) {
-                const int row = n0 + g / 6, c = g % 6;
-                const bool ok = row < p.N;
-                const uint4 v = *reinterpret_cast<const uint4 *>(WS + (int64_t)(ok ? row : p.N - 1) * wrow + kt * 48 + c * 8);
-                rw[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
-            }
-        }
+    for (int i = 0; i < PW; ++i) {
+        const int g = tid + THREADS * i;
+        voff_w[i] = (int)((g / NCH) * wrow * 2) + (g % NCH) * 16;
+    }
+    auto load_tile = [&](int kt, float4 (&ra)[PA], uint4 (&rw)[PW]) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            if (RPP * i + r0 < BM)
+                ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff_a[i], kt * (BK * 4), 0));
+#pragma unroll
+        for (int i = 0; i < PW; ++i)
+            if (tid + THREADS * i < WCH)
+                rw[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff_w[i], kt * (32 * NP), 0));
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const int kt, const float4 (&ra_in)[PA], const uint4 (&rw)[PW]) {
+        const bool kok = kt * BK + kq * 4 < p.K;   // K % 4 == 0: a quad is wholly inside or outside
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             if (RPP * i + r0 < BM) {
                 char *dst = lds_a + buf * BUFB + (r0 + RPP * i) * ROWB + kq * 8;
-                uint2 q0, q1, q2;
-                split3(ra[i], q0, q1, q2);
-                *reinterpret_cast<uint2 *>(dst) = q0;
-                *reinterpret_cast<uint2 *>(dst + PLANE_A) = q1;
-                *reinterpret_cast<uint2 *>(dst + 2 * PLANE_A) = q2;
+                float4 ra[PA];
+                ra[i] = kok ? ra_in[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (F16) {
+                    uint2 q0, q1;
+                    split2(ra[i], q0, q1);
+                    *reinterpret_cast<uint2 *>(dst) = q0;
+                    *reinterpret_cast<uint2 *>(dst + PLANE_A) = q1;
+                } else {
+                    uint2 q0, q1, q2;
+                    split3(ra[i], q0, q1, q2);
+                    *reinterpret_cast<uint2 *>(dst) = q0;
+                    *reinterpret_cast<uint2 *>(dst + PLANE_A) = q1;
+                    *reinterpret_cast<uint2 *>(dst + 2 * PLANE_A) = q2;
+                }
             }
         }
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             const int g = tid + THREADS * i;
             if (g < WCH) {
-                const int row = g / 6, c = g % 6;
+                const int row = g / NCH, c = g % NCH;
                 *reinterpret_cast<uint4 *>(lds_w + buf * BUFB + (c >> 1) * PLANE_W + row * ROWB + (c & 1) * 16) = rw[i];
             }
         }
@@ -378,68 +427,116 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int numK = (p.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (p.stamps) st0 = __builtin_amdgcn_s_memrealtime();
+    load_tile(0, ra_[0], rw_[0]);
+    store_tile(0, 0, ra_[0], rw_[0]);
+#pragma unroll
+    for (int s = 1; s < NS; ++s) load_tile(s, ra_[s], rw_[s]);
     __syncthreads();
-    for (int kt = 0; kt < numK; ++kt) {
+    if (p.stamps) st1 = __builtin_amdgcn_s_memrealtime();
+    // step kt: tile kt is in LDS stage kt & 1; registers slot (kt + 1) % NS hold tile kt + 1 (loaded NS steps ago);
+    // the load of tile kt + NS goes into slot kt % NS, whose tile kt was written to LDS during step kt - 1.
+    // SKEW (needs PD >= 2, so that tile kt + 1 is already in registers when step kt starts): the four waves that share a
+    // SIMD (w, w+4, w+8, w+12) convert and store the next tile at different points of the step -- before, in the middle
+    // of, or after their MFMAs.  Run in lockstep, all waves would leave the matrix core idle during the conversion
+    // phase and then queue on it; skewed, one wave's VALU / LDS-write work runs under another's MFMAs.
+    static_assert(!SKEW || PD >= 2, "SKEW needs a prefetch depth of two tiles");
+    const int role = SKEW ? ((wave >> 2) & 3) : 1;
+    auto step = [&](const int kt, float4 (&ra_new)[PA], uint4 (&rw_new)[PW], float4 (&ra_next)[PA], uint4 (&rw_next)[PW]) {
         const bool more = (kt + 1) < numK;
-        if (more) load_tile(kt + 1);
+        // issued unconditionally (past the last K-tile the descriptor's bounds make it a load of zeros that is never
+        // stored): a conditional issue would force the compiler to drain vmcnt to zero before the next tile's store
+        if (DBUF || more) load_tile(kt + NS, ra_new, rw_new);
         const int cur = DBUF ? (kt & 1) : 0;
+        if (SKEW && role == 0 && more) store_tile((kt + 1) & 1, kt + 1, ra_next, rw_next);
         const char *as = lds_a + cur * BUFB + (wm * WTM + r) * ROWB + h * 16;
         const char *ws = lds_w + cur * BUFB + (wn * WTN + r) * ROWB + h * 16;
-        bf16x8 a[TM][3];
+        uint4 a[TM][NP];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) a[i][q] = *reinterpret_cast<const bf16x8 *>(as + i * 32 * ROWB + q * PLANE_A);
+            for (int q = 0; q < NP; ++q) a[i][q] = *reinterpret_cast<const uint4 *>(as + i * 32 * ROWB + q * PLANE_A);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            bf16x8 b[3];
+            uint4 b[NP];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) b[q] = *reinterpret_cast<const bf16x8 *>(ws + j * 32 * ROWB + q * PLANE_W);
-            // six terms, smallest first; consecutive MFMAs alternate between the accumulators of this column
-#define SPLIT_TERM(QA, QB)                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) acc[i][j] =                                               \
-        __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][QA], b[QB], acc[i][j], 0, 0, 0);
-            SPLIT_TERM(0, 2)
-            SPLIT_TERM(2, 0)
-            SPLIT_TERM(1, 1)
-            SPLIT_TERM(0, 1)
-            SPLIT_TERM(1, 0)
-            SPLIT_TERM(0, 0)
+            for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const uint4 *>(ws + j * 32 * ROWB + q * PLANE_W);
+            // terms smallest first; consecutive MFMAs alternate between the accumulators of this column
+#define SPLIT_TERM(QA, QB)                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                       \
+    {                                                                                                                    \
+        if constexpr (F16)                                                                                               \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i][QA]),                      \
+                                                               __builtin_bit_cast(f16x8, b[QB]), acc[i][j], 0, 0, 0);    \
+        else                                                                                                             \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][QA]),                    \
+                                                                __builtin_bit_cast(bf16x8, b[QB]), acc[i][j], 0, 0, 0);  \
+    }
+            if constexpr (F16) {
+                SPLIT_TERM(0, 1)
+                SPLIT_TERM(1, 0)
+                SPLIT_TERM(0, 0)
+            } else {
+                SPLIT_TERM(0, 2)
+                SPLIT_TERM(2, 0)
+                SPLIT_TERM(1, 1)
+                SPLIT_TERM(0, 1)
+                SPLIT_TERM(1, 0)
+                SPLIT_TERM(0, 0)
+            }
 #undef SPLIT_TERM
             // With two LDS stages the next tile can be split and written while this wave still has MFMAs to issue:
             // done after the first column block, the VALU / LDS-write work overlaps the other waves' MFMAs instead of
             // sitting between the last MFMA and the barrier.
-            if (DBUF && j == (TN > 1 ? TN / 2 - 1 : 0) && more) store_tile((kt + 1) & 1);
+            if (DBUF && j == (TN > 1 ? TN / 2 - 1 : 0) && more && (role & 1)) store_tile((kt + 1) & 1, kt + 1, ra_next, rw_next);
         }
+        if (SKEW && role == 2 && more) store_tile((kt + 1) & 1, kt + 1, ra_next, rw_next);
         if (DBUF) {
             __syncthreads();
         } else {
             __syncthreads();
-            if (more) store_tile(0);
+            if (more) store_tile(0, kt + 1, ra_new, rw_new);
             __syncthreads();
         }
+    };
+    if constexpr (NS == 1) {
+        for (int kt = 0; kt < numK; ++kt) step(kt, ra_[0], rw_[0], ra_[0], rw_[0]);
+    } else {
+        // unrolled by NS so that the ring slots are compile-time register sets
+        for (int kt0 = 0; kt0 < numK; kt0 += NS) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                if (kt0 + s < numK) step(kt0 + s, ra_[s], rw_[s], ra_[(s + 1) % NS], rw_[(s + 1) % NS]);
+        }
     }
+    if (p.stamps) st2 = __builtin_amdgcn_s_memrealtime();
     gemm_epilogue<TM, TN, WTM, WTN, false>(p, acc, m0, n0, z, wm, wn, r, h);
+    if (p.stamps && threadIdx.x == 0) {
+        unsigned long long *o = p.stamps + 5 * (size_t)blockIdx.x;
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[0] = st0, o[1] = st1, o[2] = st2, o[3] = __builtin_amdgcn_s_memrealtime(), o[4] = xcc;
+    }
 }
 
-template <bool DBUF>
+template <int PD, bool F16, bool SKEW>
 __global__ __launch_bounds__(1024) void gemm_split_kernel(GemmParams p)
 {
-    __shared__ __attribute__((aligned(16))) char smem[(DBUF ? 2 : 1) * 3 * ((256 + 256) * 48 + 64)];
-    int L = blockIdx.x;
-    if (L < p.tiles_big) {
+    __shared__ __attribute__((aligned(16))) char smem[(PD > 0 ? 2 : 1) * (F16 ? 2 : 3) * ((256 + 256) * 48 + 64)];
+    int seg = 0;
+    while (seg < p.nseg - 1 && (int)blockIdx.x >= p.seg_end[seg]) ++seg;
+    int L = p.seg_base[seg] + (int)blockIdx.x - (seg ? p.seg_end[seg - 1] : 0);
+    if (!((p.seg_small >> seg) & 1)) {
         const int per_batch = p.mt_big * p.tiles_n_big;
         const int z = L / per_batch;
         L -= z * per_batch;
-        gemm_split_tile<256, 256, 4, 4, DBUF>(p, (L / p.tiles_n_big) * 256, (L % p.tiles_n_big) * 256, z, smem);
+        gemm_split_tile<256, 256, 4, 4, PD, F16, SKEW>(p, (L / p.tiles_n_big) * 256, (L % p.tiles_n_big) * 256, z, smem);
     } else {
-        L -= p.tiles_big;
         const int per_batch = p.tiles_m_small * p.tiles_n_small;
         const int z = L / per_batch;
         L -= z * per_batch;
-        gemm_split_tile<128, 128, 4, 4, DBUF>(p, p.mt_big * 256 + (L / p.tiles_n_small) * 128, (L % p.tiles_n_small) * 128, z, smem);
+        gemm_split_tile<128, 128, 4, 4, PD, F16, SKEW>(p, p.mt_big * 256 + (L / p.tiles_n_small) * 128, (L % p.tiles_n_small) * 128, z, smem);
     }
 }
 
@@ -464,6 +561,28 @@ extern "C" int tgp_split_bf16(const float *W, int rows, int K, int ld, uint16_t 
 {
     TGP_REQUIRE(W && out && rows > 0 && K > 0 && ld >= K && ldo >= K && (ldo & 15) == 0);
     hipLaunchKernelGGL(split_bf16_kernel, dim3(tgp_cdiv((int64_t)rows * ldo, 256)), dim3(256), 0, tgp_hs(stream), W, rows, K,
+                       ld, out, ldo);
+    return TGP_LAUNCH_RESULT();
+}
+
+// W (rows, K) fp32 -> out[rows][ldo / 16][2][16] fp16 (hi, lo per K-tile), zero padded to ldo
+__global__ void split_f16_kernel(const float *__restrict__ W, int rows, int K, int ld, uint16_t *__restrict__ out, int ldo)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)rows * ldo) return;
+    const int rr = (int)(t / ldo), c = (int)(t - (int64_t)rr * ldo);
+    const float x = c < K ? W[(int64_t)rr * ld + c] : 0.f;
+    const _Float16 hb = (_Float16)x;
+    const _Float16 lb = (_Float16)(x - (float)hb);
+    uint16_t *o = out + ((int64_t)rr * (ldo / 16) + c / 16) * 32 + (c & 15);
+    o[0] = __builtin_bit_cast(uint16_t, hb);
+    o[16] = __builtin_bit_cast(uint16_t, lb);
+}
+
+extern "C" int tgp_split_f16(const float *W, int rows, int K, int ld, uint16_t *out, int ldo, tgp_stream_t stream)
+{
+    TGP_REQUIRE(W && out && rows > 0 && K > 0 && ld >= K && ldo >= K && (ldo & 15) == 0);
+    hipLaunchKernelGGL(split_f16_kernel, dim3(tgp_cdiv((int64_t)rows * ldo, 256)), dim3(256), 0, tgp_hs(stream), W, rows, K,
                        ld, out, ldo);
     return TGP_LAUNCH_RESULT();
 }
@@ -672,20 +791,80 @@ static double plan_tiles(GemmParams &p, int big, int64_t S, double tail_cost, in
     return best;
 }
 
-int tgp_split_variant = 1; // development switch (scripts/gemm_ab.py): 0 single LDS buffer, 1 double buffer
+extern unsigned long long *tgp_split_stamps;
+// development switch (scripts/split_ab.py).  low 3 bits: -1/7 = production choice (fp16: two LDS stages + two K-tiles of
+// register prefetch; bf16: one K-tile, its registers allow no more), 0 single LDS stage, 1 / 2 double buffer with that
+// many K-tiles of prefetch, 4 = 2 + skewed waves (fp16 only); bit 3: staggered block order
+int tgp_split_variant = 7;
+
+// Block order of the split kernel.  Default: all big tiles, then the half-size tail tiles.  With many rounds of equal
+// tiles every CU reaches its epilogue at the same moment and the chip alternates between "all CUs compute, HBM idle"
+// and "all CUs store 256 KB each, matrix cores idle".  The staggered order starts a quarter of the CUs on a big tile and
+// gives the others one, two or three quarter-size tiles first, which leaves four populations a quarter of a tile apart
+// for the rest of the launch: store bursts of a quarter of the CUs, four times as often.
+static void order_tiles(GemmParams &p, int64_t S, bool stagger)
+{
+    const int tiles_small = p.tiles_m_small * p.tiles_n_small * p.batch;
+    const int q = (int)(S / 4);
+    int nb = 0, ns = 0, n = 0, end = 0;
+    auto seg = [&](int count, bool small) {
+        if (count <= 0) return;
+        p.seg_base[n] = small ? ns : nb;
+        (small ? ns : nb) += count;
+        end += count;
+        p.seg_end[n] = end;
+        p.seg_small |= (small ? 1 : 0) << n;
+        ++n;
+    };
+    p.seg_small = 0;
+    if (stagger && q > 0 && (S & 3) == 0 && p.tiles_big >= 4 * q && tiles_small >= 6 * q) {
+        seg(q, false), seg(3 * q, true), seg(q, false), seg(2 * q, true), seg(q, false), seg(q, true);
+    }
+    seg(p.tiles_big - nb, false);
+    seg(tiles_small - ns, true);
+    p.nseg = n;
+}
 
 static int launch_split(GemmParams &p, hipStream_t stream)
 {
-    plan_tiles(p, GEMM_BIG, resident_slots(), 0.27, 3);
+    const int64_t S = resident_slots();
+    plan_tiles(p, GEMM_BIG, S, 0.27, 3);
+    const bool stagger = (tgp_split_variant & 8) != 0 && tgp_split_variant != 7;
+    if (stagger && p.tiles_big >= 3 * S) {
+        // hand enough M-tile rows to the half-size tiles for the staggered start (1.5 S of them)
+        const int64_t per_row = 4 * (int64_t)p.tiles_n_big * p.batch;   // half-size tiles per big M-tile row
+        const int64_t have = (int64_t)p.tiles_m_small * p.tiles_n_small * p.batch;
+        const int rows = (int)tgp_cdiv(3 * S / 2 + S / 4 - have > 0 ? 3 * S / 2 + S / 4 - have : 0, per_row);
+        if (rows > 0 && rows < p.mt_big) {
+            p.mt_big -= rows;
+            p.tiles_big = p.mt_big * p.tiles_n_big * p.batch;
+            p.tiles_m_small = tgp_cdiv(p.M - p.mt_big * GEMM_BIG, GEMM_BIG / 2);
+        }
+    }
+    order_tiles(p, S, stagger);
+    p.stamps = tgp_split_stamps;
     const dim3 grid(p.tiles_big + p.tiles_m_small * p.tiles_n_small * p.batch);
-    if (tgp_split_variant == 0)
-        hipLaunchKernelGGL(gemm_split_kernel<false>, grid, dim3(1024), 0, stream, p);
-    else
-        hipLaunchKernelGGL(gemm_split_kernel<true>, grid, dim3(1024), 0, stream, p);
+#define LAUNCH_SPLIT(PD, F16, SKEW) hipLaunchKernelGGL((gemm_split_kernel<PD, F16, SKEW>), grid, dim3(1024), 0, stream, p)
+    if (p.split_f16) {
+        switch (tgp_split_variant & 7) {
+        case 0: LAUNCH_SPLIT(0, true, false); break;
+        case 1: LAUNCH_SPLIT(1, true, false); break;
+        case 4: LAUNCH_SPLIT(2, true, true); break;
+        default: LAUNCH_SPLIT(2, true, false); break;
+        }
+    } else {
+        switch (tgp_split_variant & 7) {
+        case 0: LAUNCH_SPLIT(0, false, false); break;
+        default: LAUNCH_SPLIT(1, false, false); break;
+        }
+    }
+#undef LAUNCH_SPLIT
     return TGP_LAUNCH_RESULT();
 }
 
+unsigned long long *tgp_split_stamps = nullptr;
 extern "C" void tgp_debug_set_split_variant(int v) { tgp_split_variant = v; }
+extern "C" void tgp_debug_set_split_stamps(unsigned long long *buf) { tgp_split_stamps = buf; }
 
 static int launch_main(GemmParams &p, hipStream_t stream)
 {
@@ -747,9 +926,11 @@ extern "C" int tgp_gemm_f32(const tgp_gemm_args *a, tgp_stream_t stream)
         if (a->W_split) {
             TGP_REQUIRE(a->ldws >= ((a->K + 15) & ~15) && (a->ldws & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(a->W_split) & 15) == 0);
+            TGP_REQUIRE(a->w_split_kind == 0 || a->w_split_kind == 1);
             p.Wsplit = a->W_split, p.ldws = a->ldws;
             p.plane = 0;
-            p.sWS = 3 * (int64_t)a->N * a->ldws;
+            p.split_f16 = a->w_split_kind;
+            p.sWS = (a->w_split_kind ? 2 : 3) * (int64_t)a->N * a->ldws;
             return launch_split(p, tgp_hs(stream));
         }
         return launch_main(p, tgp_hs(stream));

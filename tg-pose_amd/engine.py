@@ -68,7 +68,7 @@ def pack_encoder(sd, e, device):
     c0["ste"] = _pad_cols(sd[e + "conv_0.STE_layer.weight"][:, :, 0], 4)           # (128, 3 -> 4)
     w2 = sd[e + "conv_0.conv2.weight"][:, :, 0]
     c0["w1"], c0["w2"] = w2[:, :128].contiguous(), w2[:, 128:].contiguous()
-    c0["w1_s"] = ops.split_bf16(c0["w1"])
+    c0["w1_s"] = ops.split_w(c0["w1"])
     c0["w2t"] = c0["w2"].t().contiguous()
     conv.append(c0)
     for i, (cin, cout) in enumerate(LEVEL_CH, start=1):
@@ -77,11 +77,11 @@ def pack_encoder(sd, e, device):
         c["sdn"] = ops.normalize_dirs(sd[p + "directions"])
         # one GEMM operand: rows [weights^T (8*Cout) ; STE (Cout)], bias [bias ; 0]
         c["wcat"] = torch.cat([sd[p + "weights"].t(), sd[p + "STE_layer.weight"][:, :, 0]], dim=0).contiguous()
-        c["wcat_s"] = ops.split_bf16(c["wcat"])
+        c["wcat_s"] = ops.split_w(c["wcat"])
         c["bcat"] = torch.cat([sd[p + "bias"], torch.zeros(cout, device=device)]).contiguous()
         w2 = sd[p + "conv2.weight"][:, :, 0]
         c["w1"], c["w2"] = w2[:, :cout].contiguous(), w2[:, cout:].contiguous()
-        c["w1_s"] = ops.split_bf16(c["w1"])
+        c["w1_s"] = ops.split_w(c["w1"])
         c["w2t"] = c["w2"].t().contiguous()
         if i <= 3:
             c["scale"], c["shift"] = _bn_fold(sd, e + "bn%d" % i)
@@ -108,7 +108,7 @@ def pack_decoder(sd, d):
         if w.shape[1] == FEAT_C:
             w = _pad_cols(w, FEAT_LD)
         w = w.contiguous()
-        dec.append((w, sd[d + conv + ".bias"].contiguous()) + _bn_fold(sd, d + bn) + (ops.split_bf16(w),))
+        dec.append((w, sd[d + conv + ".bias"].contiguous()) + _bn_fold(sd, d + bn) + (ops.split_w(w),))
     return dec, (sd[d + "recon_head.3.weight"][:, :, 0].contiguous(), sd[d + "recon_head.3.bias"].contiguous())
 
 
@@ -140,8 +140,8 @@ def pack_wide(ph, heads, bn_names=None):
         slope=torch.cat([z + 0.2, torch.zeros(3072, device=dev)]).contiguous(),
         k_alg=(FEAT_C + sum(hd["k_alg"] for hd in heads)) / 4.0,
         W2=c2(0), b2=c2(1), scale2=c2(2), shift2=c2(3))
-    w["Ws"] = ops.split_bf16(w["W"])
-    w["W2s"] = ops.split_bf16(w["W2"])
+    w["Ws"] = ops.split_w(w["W"])
+    w["W2s"] = ops.split_w(w["W2"])
     # conv3 / conv4 of the three heads as batched skinny GEMMs (conv4 rows padded to 8: outputs 4, 4, 6)
     c3 = lambda i: torch.stack([hd["c3"][i] for hd in heads]).contiguous()
     w["W3"], w["b3"], w["scale3"], w["shift3"] = c3(0), c3(1), c3(2), c3(3)

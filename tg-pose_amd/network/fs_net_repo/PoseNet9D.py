@@ -11,7 +11,7 @@ pin the random subsample and inject / record neighbour graphs.
 import torch
 import torch.nn as nn
 
-from ... import engine
+from ... import engine, ops
 from ...config import FLAGS
 from .FaceRecon import FaceNet, _WithBuffers
 from .gcn3d import _need_eval
@@ -34,7 +34,7 @@ class PoseNet9D(_WithBuffers):
     def packed(self, device):
         """Kernel-ready weights: rebuilt when a parameter changes, BatchNorm folds refreshed when only the running
         statistics changed (a training-mode forward moves them)."""
-        psig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        psig = (ops.GEMM_MODE,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         bsig = tuple((b.data_ptr(), b._version) for b in self.buffers())
         if getattr(self, "_pk_psig", None) != psig:
             face = "face_enc." if self.only_encoder else "face_all."

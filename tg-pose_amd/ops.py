@@ -186,9 +186,27 @@ def fill_tail(obj_id, xyz_c, feat, col0, n_cls):
           "tgp_fill_tail")
 
 
-# "split": launches large enough for the tile kernels use the bf16x3 operand-split kernel when the caller
-# supplies pre-split weights (fp32-level accuracy on the bf16 matrix cores); "fp32": always the fp32 MFMA kernels.
-GEMM_MODE = "split"
+# How launches large enough for the tile kernels run when the caller supplies pre-split weights:
+#   "split16"  two-term fp16 operand split, 3 MFMA terms (products to ~2^-22; operands must stay below 65504)
+#   "split"    three-term bf16 operand split, 6 MFMA terms (fp32 range, products to ~2^-23)
+#   "fp32"     always the fp32 MFMA kernels
+# split_w() packs weights for the mode current at pack time; gemm() reads the kind off the packed tensor's shape.
+GEMM_MODE = "split16"
+
+
+def split_w(W):
+    return split_f16(W) if GEMM_MODE == "split16" else split_bf16(W)
+
+
+def split_f16(W):
+    """W (..., rows, K) fp32 -> int16 tensor (..., rows, ldo // 16, 2, 16) of fp16 bit patterns (hi, lo per K-tile)."""
+    W = W.contiguous()
+    K = W.shape[-1]
+    rows = W.numel() // K
+    ldo = (K + 15) // 16 * 16
+    out = torch.empty(tuple(W.shape[:-1]) + (ldo // 16, 2, 16), device=W.device, dtype=torch.int16)
+    check(_lib.lib().tgp_split_f16(_p(W), rows, K, K, _p(out), ldo, _stream(W)), "tgp_split_f16")
+    return out
 
 
 def split_bf16(W):
@@ -248,8 +266,9 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
     a.slope_vec, a.cm_cols, a.c_col0, a.batch = _p(slope_vec), cm_cols, c_col0, batch
     if batch_strides is not None:
         (a.batch_stride_a, a.batch_stride_w, a.batch_stride_c, a.batch_stride_vec, a.batch_stride_colmax) = batch_strides
-    if w_split is not None and GEMM_MODE == "split":
+    if w_split is not None and GEMM_MODE != "fp32":
         a.W_split, a.ldws = _p(w_split), w_split.shape[-3] * 16
+        a.w_split_kind = 1 if w_split.shape[-2] == 2 else 0
     check(_lib.lib().tgp_gemm_f32(ctypes.byref(a), _stream(A)), "tgp_gemm_f32")
     if timed:
         e1.record(torch.cuda.current_stream(A.device))
