@@ -162,10 +162,15 @@ def main():
 
     if rank == 0:
         traffic = None
-        try:   # HBM/fabric bytes per launch of the dominant kernel from the committed PMC passes (not a live measurement)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")))["kernels"]
-            key = {"split": "void gemm_split_kernel<true>", "split16": "void gemm_split_kernel<true, true>"}.get(args.gemm)
-            traffic = pmc[key]["bytes_per_launch_corrected"] if key in pmc else None
+        try:   # HBM/fabric bytes per launch of the dominant kernel from the latest committed PMC passes (not a live measurement)
+            import glob
+            pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))["kernels"]
+            if args.gemm == "fp32":
+                keys = [k for k in pmc if "gemm_main256_kernel" in k]
+            else:   # gemm_split_kernel<prefetch depth, fp16?, interleaved?>; older files: <dbuf> (bf16) / <dbuf, fp16>
+                f16 = lambda k: ", true" in k.split("<", 1)[-1]
+                keys = [k for k in pmc if "gemm_split_kernel" in k and f16(k) == (args.gemm == "split16")]
+            traffic = pmc[keys[0]]["bytes_per_launch_corrected"] if keys else None
         except Exception:
             traffic = None
         launches = len(timer)

@@ -392,8 +392,10 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
         for (int i = 0; i < PA; ++i) {
             if (RPP * i + r0 < BM) {
                 char *dst = lds_a + buf * BUFB + (r0 + RPP * i) * ROWB + kq * 8;
-                float4 ra[PA];
-                ra[i] = kok ? ra_in[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 ra[PA];   // masked with AND, not a select: a select on a pending load is compiled into a branch
+                const uint32_t km = kok ? 0xffffffffu : 0u;
+                const uint4 rbits = __builtin_bit_cast(uint4, ra_in[i]);
+                ra[i] = __builtin_bit_cast(float4, make_uint4(rbits.x & km, rbits.y & km, rbits.z & km, rbits.w & km));
                 if constexpr (F16) {
                     uint2 q0, q1;
                     split2(ra[i], q0, q1);
@@ -437,19 +439,19 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
     if (p.stamps) st1 = __builtin_amdgcn_s_memrealtime();
     // step kt: tile kt is in LDS stage kt & 1; registers slot (kt + 1) % NS hold tile kt + 1 (loaded NS steps ago);
     // the load of tile kt + NS goes into slot kt % NS, whose tile kt was written to LDS during step kt - 1.
-    // SKEW (needs PD >= 2, so that tile kt + 1 is already in registers when step kt starts): the four waves that share a
-    // SIMD (w, w+4, w+8, w+12) convert and store the next tile at different points of the step -- before, in the middle
-    // of, or after their MFMAs.  Run in lockstep, all waves would leave the matrix core idle during the conversion
-    // phase and then queue on it; skewed, one wave's VALU / LDS-write work runs under another's MFMAs.
-    static_assert(!SKEW || PD >= 2, "SKEW needs a prefetch depth of two tiles");
-    const int role = SKEW ? ((wave >> 2) & 3) : 1;
+    // SKEW (fp16, PD >= 2) = interleaved schedule: tile kt + 1 is already in registers when step kt starts, so its
+    // conversion and LDS store need not sit in one block between two groups of MFMAs, where all four waves of a SIMD
+    // reach it together and leave the matrix core idle.  The step is one basic block (loads and stores unconditional:
+    // past the last K-tile they move zeros) and sched_group_barrier asks for 1 MFMA : 3 VALU throughout, so every
+    // wave's conversion runs in the shadow of its own MFMAs.
+    static_assert(!SKEW || (PD >= 2 && F16), "the interleaved schedule needs two tiles of prefetch");
+    const int role = 1;
     auto step = [&](const int kt, float4 (&ra_new)[PA], uint4 (&rw_new)[PW], float4 (&ra_next)[PA], uint4 (&rw_next)[PW]) {
         const bool more = (kt + 1) < numK;
         // issued unconditionally (past the last K-tile the descriptor's bounds make it a load of zeros that is never
         // stored): a conditional issue would force the compiler to drain vmcnt to zero before the next tile's store
         if (DBUF || more) load_tile(kt + NS, ra_new, rw_new);
         const int cur = DBUF ? (kt & 1) : 0;
-        if (SKEW && role == 0 && more) store_tile((kt + 1) & 1, kt + 1, ra_next, rw_next);
         const char *as = lds_a + cur * BUFB + (wm * WTM + r) * ROWB + h * 16;
         const char *ws = lds_w + cur * BUFB + (wn * WTN + r) * ROWB + h * 16;
         uint4 a[TM][NP];
@@ -489,9 +491,22 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
             // With two LDS stages the next tile can be split and written while this wave still has MFMAs to issue:
             // done after the first column block, the VALU / LDS-write work overlaps the other waves' MFMAs instead of
             // sitting between the last MFMA and the barrier.
-            if (DBUF && j == (TN > 1 ? TN / 2 - 1 : 0) && more && (role & 1)) store_tile((kt + 1) & 1, kt + 1, ra_next, rw_next);
+            if (!SKEW && DBUF && j == (TN > 1 ? TN / 2 - 1 : 0) && more) store_tile((kt + 1) & 1, kt + 1, ra_next, rw_next);
         }
-        if (SKEW && role == 2 && more) store_tile((kt + 1) & 1, kt + 1, ra_next, rw_next);
+        if constexpr (SKEW) {
+            store_tile((kt + 1) & 1, kt + 1, ra_next, rw_next);
+            // masks: 0x2 VALU, 0x8 MFMA, 0x20 VMEM read, 0x100 DS read, 0x200 DS write
+            __builtin_amdgcn_sched_group_barrier(0x20, PA + PW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM * NP + NP, 0);
+#pragma unroll
+            for (int g = 0; g < TM * TN * 3; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
+                if (g == 1) __builtin_amdgcn_sched_group_barrier(0x100, (TN - 1) * NP, 0);
+                if (g == TM * TN * 3 - 3) __builtin_amdgcn_sched_group_barrier(0x200, 3 * PA, 0);
+                if (g == TM * TN * 3 - 2) __builtin_amdgcn_sched_group_barrier(0x200, PW, 0);
+            }
+        }
         if (DBUF) {
             __syncthreads();
         } else {
@@ -651,80 +666,94 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(GemmParams p)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// M <= 32 rows (per-object vectors): weight streaming.  A workgroup owns 4 output columns; its 4 waves
-// split K (wave w takes k = 1024*i + 256*w + 4*lane), so N waves are in flight for N columns and every
-// W element is read exactly once with 16-byte lane loads.  Per wave a 6-step butterfly sums the lanes,
-// then the 4 waves are combined through LDS in fixed order (deterministic).
-#define SKINNY_COLS 4
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(GemmParams p)
+// M <= 32 rows (per-object vectors: the PH predictor's linears, the heads after their max-pool): weight streaming.
+// A workgroup owns 32 output columns and all M rows; its 8 waves split K (wave w takes the 16-wide K-chunks
+// w, w + 8, ...), each accumulating the 32 x 32 block as four v_mfma_f32_16x16x4_f32 tiles, so every W element is read
+// once with 16-byte lane loads and the (<= 32, K) activation is re-read once per 32 columns (from L2).  Lane
+// (c = lane % 16, q = lane / 16) loads the float4 at k = chunk + 4q of row / column c (and c + 16); MFMA sub-step s
+// takes component s of every lane, i.e. k-slot q of the instruction is k = chunk + 4q + s for both operands.  The 8
+// partial blocks are combined through LDS in fixed order (deterministic).
+// Narrow outputs (few column blocks) use 16 columns per workgroup and 16 waves instead, to put more CUs on the stream.
+#define SKINNY_UNROLL 4
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int NT, int SKINNY_WAVES>   // NT 16-column tiles per workgroup
+__global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmParams p)
 {
-    __shared__ float red[4][SKINNY_COLS][32];
+    constexpr int SKINNY_COLS = 16 * NT;
+    __shared__ float red[SKINNY_WAVES][32][SKINNY_COLS + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c16 = lane & 15, q = lane >> 4;
     const int nb = blockIdx.x * SKINNY_COLS;
     const int z = blockIdx.y;
-    p.A += (int64_t)z * p.sA;
-    p.W += (int64_t)z * p.sW;
-    float acc[SKINNY_COLS][32];
+    const float *A = p.A + (int64_t)z * p.sA;
+    const float *W = p.W + (int64_t)z * p.sW;
+    // rows / columns past the end are clamped: they only feed outputs that are never stored
+    const float *arow[2], *wrow[NT];
 #pragma unroll
-    for (int c = 0; c < SKINNY_COLS; ++c)
+    for (int t = 0; t < 2; ++t) {
+        const int row = c16 + 16 * t;
+        arow[t] = A + (int64_t)(row < p.M ? row : p.M - 1) * p.lda + 4 * q;
+    }
 #pragma unroll
-        for (int m = 0; m < 32; ++m) acc[c][m] = 0.f;
+    for (int t = 0; t < NT; ++t) {
+        const int col = nb + c16 + 16 * t;
+        wrow[t] = W + (int64_t)(col < p.N ? col : p.N - 1) * p.ldw + 4 * q;
+    }
+    f32x4v acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = wave * 256 + lane * 4; k0 < p.K; k0 += 1024) {
-        float4 w[SKINNY_COLS];
+    const int chunks = (p.K + 15) / 16;
+    for (int c0 = wave; c0 < chunks; c0 += SKINNY_WAVES * SKINNY_UNROLL) {
+        float4 a[SKINNY_UNROLL][2], w[SKINNY_UNROLL][NT];
 #pragma unroll
-        for (int c = 0; c < SKINNY_COLS; ++c)
-            w[c] = (nb + c < p.N) ? *reinterpret_cast<const float4 *>(p.W + (int64_t)(nb + c) * p.ldw + k0)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < SKINNY_UNROLL; ++u) {
+            const int k = (c0 + u * SKINNY_WAVES) * 16;
+            const bool ok = k + 4 * q < p.K;          // K % 4 == 0; also false for chunks past the end
+            const int kc = ok ? k : 0;
 #pragma unroll
-        for (int m = 0; m < 32; ++m) {
-            if (m < p.M) {
-                const float4 a = *reinterpret_cast<const float4 *>(p.A + (int64_t)m * p.lda + k0);
+            for (int t = 0; t < 2; ++t) {
+                const float4 av = *reinterpret_cast<const float4 *>(arow[t] + kc);
+                a[u][t] = ok ? av : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-                for (int c = 0; c < SKINNY_COLS; ++c) {
-                    float s = acc[c][m];
-                    s = fmaf(a.x, w[c].x, s);
-                    s = fmaf(a.y, w[c].y, s);
-                    s = fmaf(a.z, w[c].z, s);
-                    s = fmaf(a.w, w[c].w, s);
-                    acc[c][m] = s;
-                }
+            for (int t = 0; t < NT; ++t) {
+                const float4 wv = *reinterpret_cast<const float4 *>(wrow[t] + kc);
+                w[u][t] = ok ? wv : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-    }
-    // Lane reduction by recursive halving: at each step a lane keeps one half of its live values and adds the
-    // partner lane's copy of that half (126 cross-lane moves instead of 128 x 6); lane l ends with the totals
-    // of flattened indices 2l and 2l+1 (index = column * 32 + row).
-    float v[SKINNY_COLS * 32];
 #pragma unroll
-    for (int c = 0; c < SKINNY_COLS; ++c)
+        for (int u = 0; u < SKINNY_UNROLL; ++u) {
 #pragma unroll
-        for (int m = 0; m < 32; ++m) v[c * 32 + m] = acc[c][m];
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int step = 0; step < 6; ++step) {
-        const int half = (SKINNY_COLS * 16) >> step;
-        const int off = 32 >> step;
-        const bool up = (lane & off) != 0;
-#pragma unroll
-        for (int i = 0; i < half; ++i) {
-            const float keep = up ? v[i + half] : v[i];
-            const float send = up ? v[i] : v[i + half];
-            v[i] = keep + __shfl_xor(send, off, 64);
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].x, w[u][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].y, w[u][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].z, w[u][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i].w, w[u][j].w, acc[i][j], 0, 0, 0);
+                }
         }
     }
-    {
-        float *flat = &red[wave][0][0];
-        flat[2 * lane] = v[0];
-        flat[2 * lane + 1] = v[1];
-    }
+    // accumulator element e of lane (c16, q) is C[row = 16 i + 4 q + e][col = 16 j + c16]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wave][16 * i + 4 * q + e][16 * j + c16] = acc[i][j][e];
     __syncthreads();
-    // 128 threads finish: thread -> (column c, row m)
-    if (threadIdx.x < SKINNY_COLS * 32) {
-        const int c = threadIdx.x >> 5, m = threadIdx.x & 31;
+    for (int o = threadIdx.x; o < 32 * SKINNY_COLS; o += 64 * SKINNY_WAVES) {
+        const int m = o / SKINNY_COLS, c = o % SKINNY_COLS;
         const int col = nb + c;
         if (m < p.M && col < p.N) {
             const int64_t vo = (int64_t)z * p.sV;
-            float v = ((red[0][c][m] + red[1][c][m]) + red[2][c][m]) + red[3][c][m];
+            float v = red[0][m][c];
+#pragma unroll
+            for (int wv = 1; wv < SKINNY_WAVES; ++wv) v += red[wv][m][c];
             v += (p.bias ? p.bias[vo + col] : 0.f);
             if (p.res1) v += p.res1[(int64_t)m * p.ldr1 + col];
             if (p.scale) v = v * p.scale[vo + col] + (p.shift ? p.shift[vo + col] : 0.f);
@@ -918,7 +947,10 @@ extern "C" int tgp_gemm_f32(const tgp_gemm_args *a, tgp_stream_t stream)
     const bool plain = !a->rowbias && !a->res2 && !a->colmax_keys && !a->slope_vec && a->c_col0 == 0 &&
                        (p.batch == 1 || !a->res1);
     if (a->M <= 32 && a->C && plain) {
-        hipLaunchKernelGGL(skinny_gemm_kernel, dim3(tgp_cdiv(a->N, SKINNY_COLS), p.batch), dim3(256), 0, tgp_hs(stream), p);
+        if ((int64_t)tgp_cdiv(a->N, 32) * p.batch >= resident_slots() / 2)
+            hipLaunchKernelGGL((skinny_gemm_kernel<2, 8>), dim3(tgp_cdiv(a->N, 32), p.batch), dim3(512), 0, tgp_hs(stream), p);
+        else
+            hipLaunchKernelGGL((skinny_gemm_kernel<1, 16>), dim3(tgp_cdiv(a->N, 16), p.batch), dim3(1024), 0, tgp_hs(stream), p);
         return TGP_LAUNCH_RESULT();
     }
     const int64_t mid_tiles = (int64_t)tgp_cdiv(a->M, GEMM_MID) * tgp_cdiv(a->N, GEMM_MID) * p.batch;
