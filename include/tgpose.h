@@ -241,6 +241,44 @@ int tgp_canonicalize(const float *points, const float *gR, const float *p_g, con
 int tgp_generate_rt(const float *p_green, const float *p_red, const float *f_green, const float *f_red,
                     const float *T, const float *sym, int sym_ld, int B, float *rt, tgp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Backward pass of the dense per-point layers (what torch autograd runs for nn.Conv1d(k=1) / nn.Linear /
+ * nn.BatchNorm1d(train) / F.relu / F.leaky_relu / torch.max in loss.backward(), trainer/RL_TDA.py:205-224).
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* C (N, K) (+)= A^T B over the rows: C[n][k] = sum_m A[m][n] * B[m][k]  (weight gradient dW = dx^T a).
+ * workspace: tgp_gemm_tn_workspace_floats(rows, N, K) floats.  Row slices are summed in slice order (deterministic). */
+int64_t tgp_gemm_tn_workspace_floats(int64_t rows, int N, int K);
+int tgp_gemm_tn_f32(const float *A, int lda, const float *B, int ldb, int64_t rows, int N, int K, float *C, int ldc,
+                    int accumulate, float *workspace, tgp_stream_t stream);
+
+/* out[c] (+)= sum over rows of dy[r][c] (bias gradient).  workspace: tgp_bw_workspace_floats(rows, C). */
+int64_t tgp_bw_workspace_floats(int64_t rows, int C);
+int tgp_colsum(const float *dy, int lddy, int64_t rows, int C, float *out, int accumulate, float *workspace, tgp_stream_t stream);
+
+/* y = act(BN_train(x)) backward: dz = dy * act'(z); dgamma = sum dz*xhat; dbeta = sum dz;
+ * dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)).  x is the raw layer output the forward normalised, mean / var
+ * its batch statistics (tgp_bn_stats).  dx may alias dy.  workspace: tgp_bw_workspace_floats(rows, C). */
+int tgp_bn_bwd(const float *dy, int lddy, const float *x, int ld, int64_t rows, int C, const float *mean, const float *var,
+               float eps, const float *gamma, const float *beta, int act, float slope, const float *slope_vec, float *dx,
+               int lddx, float *dgamma, float *dbeta, float *workspace, tgp_stream_t stream);
+
+/* The same for a layer followed by a max over each object's points: dpool (objects, C) is the gradient of the pooled
+ * vector, argrow (objects, C) the winning global row from tgp_colmax_arg; dx (objects*rows_per_obj, C) is dense. */
+int tgp_bn_bwd_pooled(const float *dpool, int ldp, const int *argrow, int lda, const float *x, int ld, int objects,
+                      int rows_per_obj, int C, const float *mean, const float *var, float eps, const float *gamma,
+                      const float *beta, int act, float slope, const float *slope_vec, float *dx, int lddx, float *dgamma,
+                      float *dbeta, tgp_stream_t stream);
+
+/* out[o][c] = max over the object's n rows of act(BN(x)) (mean == NULL: of x), argrow[o][c] = the winning global row
+ * (first on ties, as torch.max). */
+int tgp_colmax_arg(const float *x, int ld, int objects, int n, int C, const float *mean, const float *var, float eps,
+                   const float *gamma, const float *beta, int act, float slope, const float *slope_vec, float *out, int ldo,
+                   int *argrow, int lda, tgp_stream_t stream);
+
+/* dst (cols, rows) = src (rows, cols)^T. */
+int tgp_transpose(const float *src, int ld_src, int rows, int cols, float *dst, int ld_dst, tgp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

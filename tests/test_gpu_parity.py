@@ -909,3 +909,65 @@ def test_batched_inference_matches_per_image_runs(ops):
     rt = generate_RT([out["p_green_R"], out["p_red_R"]], [out["f_green_R"], out["f_red_R"]], out["Pred_T"],
                      sym=g(torch.cat([s for s in syms if s.shape[0]]))).cpu().numpy()
     assert np.array_equal(np.concatenate([r["pred_RTs"] for r in res if r["pred_RTs"].shape[0]]), rt)
+
+
+# ----------------------------------------------------------------------------------------- backward kernels
+@pytest.mark.parametrize("rows,N,K,lda,ldb", [(32896, 256, 1024, 256, 1024), (8224, 300, 77, 304, 1292), (1000, 1024, 1292, 1024, 1292),
+                                              (32, 256, 256, 256, 256), (33, 5, 3, 8, 4), (4112, 2304, 128, 2304, 128)])
+def test_gemm_tn_vs_fp64(ops, rows, N, K, lda, ldb):
+    """dW = dx^T a (reduction over the rows) against an fp64 product; fp32 MFMA accumulation, slices summed in order."""
+    gen = torch.Generator().manual_seed(rows + N)
+    A, Bm = torch.randn(rows, lda, generator=gen), torch.randn(rows, ldb, generator=gen)
+    want = A[:, :N].double().t() @ Bm[:, :K].double()
+    got = ops.gemm_tn(g(A)[:, :N], g(Bm)[:, :K])
+    scale = want.abs().max().item()
+    assert (got.cpu().double() - want).abs().max().item() <= 2e-6 * scale * max(1.0, (rows / 1000) ** 0.5)
+    again = ops.gemm_tn(g(A)[:, :N], g(Bm)[:, :K])
+    assert torch.equal(got, again)
+    acc = ops.gemm_tn(g(A)[:, :N], g(Bm)[:, :K], out=got.clone(), accumulate=True)
+    assert torch.allclose(acc, 2 * got, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("rows,C,act,slope", [(4112, 128, 1, 0.0), (1028, 256, 1, 0.2), (32, 256, 0, 0.0), (3000, 70, 1, 0.0)])
+def test_bn_backward_vs_autograd(ops, rows, C, act, slope):
+    """tgp_bn_bwd / tgp_colsum / tgp_transpose against torch autograd of F.batch_norm(training) + (leaky) ReLU on the CPU."""
+    gen = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=gen) * 2 + 0.3).requires_grad_(True)
+    gamma = (torch.rand(C, generator=gen) + 0.5).requires_grad_(True)
+    beta = torch.randn(C, generator=gen).requires_grad_(True)
+    dy = torch.randn(rows, C, generator=gen)
+    z = torch.nn.functional.batch_norm(x, None, None, gamma, beta, True, 0.0, 1e-5)
+    y = z if act == 0 else torch.nn.functional.leaky_relu(z, slope)
+    y.backward(dy)
+    _, mean, var = ops.bn_train(g(x.detach()), g(gamma.detach()), g(beta.detach()), 1e-5, act, slope, want_out=False,
+                                colmax_keys=torch.zeros(1, C, dtype=torch.int32, device=DEV), rows_per_obj=rows)
+    dx, dg, db = ops.bn_bwd(g(dy), g(x.detach()), mean, var, g(gamma.detach()), g(beta.detach()), 1e-5, act, slope)
+    tol = 2e-5 * max(1.0, (rows / 1000) ** 0.5)
+    assert torch.allclose(dx.cpu(), x.grad, atol=tol, rtol=1e-4)
+    assert torch.allclose(dg.cpu(), gamma.grad, atol=tol * rows ** 0.5, rtol=1e-4)
+    assert torch.allclose(db.cpu(), beta.grad, atol=tol * rows ** 0.5, rtol=1e-4)
+    assert torch.allclose(ops.colsum(g(dy)).cpu(), dy.sum(0), atol=tol * rows ** 0.5, rtol=1e-5)
+    assert torch.equal(ops.transpose(g(dy)).cpu(), dy.t().contiguous())
+
+
+@pytest.mark.parametrize("B,n,C,slope", [(3, 257, 192, 0.2), (4, 1028, 256, 0.0)])
+def test_pooled_bn_backward_vs_autograd(ops, B, n, C, slope):
+    """max over points of act(BN_train(x)): tgp_colmax_arg + tgp_bn_bwd_pooled against torch autograd."""
+    gen = torch.Generator().manual_seed(B * n)
+    x = torch.randn(B * n, C, generator=gen).requires_grad_(True)
+    gamma = (torch.rand(C, generator=gen) + 0.5).requires_grad_(True)
+    beta = torch.randn(C, generator=gen).requires_grad_(True)
+    dpool = torch.randn(B, C, generator=gen)
+    z = torch.nn.functional.batch_norm(x, None, None, gamma, beta, True, 0.0, 1e-5)
+    y = torch.nn.functional.leaky_relu(z, slope)
+    pooled, arg = y.view(B, n, C).max(1)
+    pooled.backward(dpool)
+    dx_, mean, var = ops.bn_train(g(x.detach()), g(gamma.detach()), g(beta.detach()), 1e-5, 1, slope, want_out=False,
+                                  colmax_keys=torch.zeros(B, C, dtype=torch.int32, device=DEV), rows_per_obj=n)
+    got, argrow = ops.colmax_arg(g(x.detach()), B, n, bn=(mean, var, g(gamma.detach()), g(beta.detach())), act=1, slope=slope)
+    assert torch.allclose(got.cpu(), pooled.detach(), atol=2e-5, rtol=1e-5)
+    assert torch.equal(argrow.cpu().long() - torch.arange(B)[:, None] * n, arg)
+    dx, dg, db = ops.bn_bwd_pooled(g(dpool), argrow, g(x.detach()), n, mean, var, g(gamma.detach()), g(beta.detach()), 1e-5, 1, slope)
+    assert torch.allclose(dx.cpu(), x.grad, atol=2e-6, rtol=1e-4)
+    assert torch.allclose(dg.cpu(), gamma.grad, atol=2e-5, rtol=1e-4)
+    assert torch.allclose(db.cpu(), beta.grad, atol=2e-5, rtol=1e-4)

@@ -59,6 +59,17 @@ SIGNATURES = {
     "tgp_fill_tail": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
     "tgp_split_bf16": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     "tgp_split_f16": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),
+    "tgp_gemm_tn_workspace_floats": (c_i64, [c_i64, c_int, c_int]),
+    "tgp_gemm_tn_f32": (c_int, [c_vp, c_int, c_vp, c_int, c_i64, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
+    "tgp_bw_workspace_floats": (c_i64, [c_i64, c_int]),
+    "tgp_colsum": (c_int, [c_vp, c_int, c_i64, c_int, c_vp, c_int, c_vp, c_vp]),
+    "tgp_bn_bwd": (c_int, [c_vp, c_int, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_int, c_f32, c_vp,
+                           c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "tgp_bn_bwd_pooled": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_f32, c_vp, c_vp,
+                                  c_int, c_f32, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "tgp_colmax_arg": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_int, c_f32, c_vp, c_vp,
+                               c_int, c_vp, c_int, c_vp]),
+    "tgp_transpose": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     "tgp_gemm_f32": (c_int, [ctypes.POINTER(GemmArgs), c_vp]),
     "tgp_colmax_decode": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "tgp_colmax": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),

@@ -1,0 +1,369 @@
+// Backward-pass kernels of the dense per-point layers (Conv1d k=1 / Linear + BatchNorm(train) + activation + max over
+// points), gfx950.  What torch autograd runs for nn.Conv1d / nn.BatchNorm1d / F.relu / torch.max in the reference's
+// training step (trainer/RL_TDA.py:205-224 calls loss.backward() on the graph PoseNet9D.forward built).
+//
+//   y = act(BN(x)),  x = a W^T + b        dW = dx^T a   (tgp_gemm_tn_f32: reduction over the rows)
+//                                          da = dx W     (tgp_gemm_f32 on the transposed weight)
+//                                          db = sum_rows dx (tgp_colsum)
+//   BN(train):  dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)),  dz = dy * act'(z)
+//               dgamma = sum dz * xhat,  dbeta = sum dz
+// All reductions over rows are chunked and summed in chunk order (deterministic).
+#include "tgp_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------
+// C[n][k] = sum_m A[m][n] * B[m][k]   (A: rows x N, B: rows x K, both row-major, reduction over the rows)
+// v_mfma_f32_32x32x2_f32 takes its operands one element per lane: lane (i = lane % 32, kk = lane / 32) supplies
+// A^T[i][kk] = A[m + kk][n0 + i] -- 32 consecutive floats of one row for 32 consecutive lanes, so both operands are read
+// straight from global memory, coalesced, with no LDS transpose.  A workgroup (4 waves, 2 x 2) owns a 128 x 128 tile of C
+// and one slice of the rows; slices are written to a workspace and summed in order by gemm_tn_reduce_kernel.
+#define TN_TILE 128
+#define TN_UNROLL 8
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                                                      int64_t rows, int N, int K, int64_t rows_per_slice,
+                                                      float *__restrict__ C, int ldc, int64_t slice_stride)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int nb = blockIdx.y * TN_TILE + (wave >> 1) * 64, kb = blockIdx.x * TN_TILE + (wave & 1) * 64;
+    const int64_t m0 = (int64_t)blockIdx.z * rows_per_slice;
+    const int64_t m1 = m0 + rows_per_slice < rows ? m0 + rows_per_slice : rows;
+    // clamped column offsets (always valid addresses); out-of-range columns are zeroed by the select below
+    int acol[2], bcol[2];
+    bool aok[2], bok[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        aok[t] = nb + 32 * t + i < N, bok[t] = kb + 32 * t + i < K;
+        acol[t] = aok[t] ? nb + 32 * t + i : 0, bcol[t] = bok[t] ? kb + 32 * t + i : 0;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[x][y][e] = 0.f;
+
+    for (int64_t m = m0; m < m1; m += 2 * TN_UNROLL) {
+        float a[TN_UNROLL][2], b[TN_UNROLL][2];
+#pragma unroll
+        for (int u = 0; u < TN_UNROLL; ++u) {
+            const int64_t row = m + 2 * u + kk;
+            const bool rok = row < m1;
+            const int64_t rc = rok ? row : m1 - 1;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float av = A[rc * lda + acol[t]], bv = B[rc * ldb + bcol[t]];
+                a[u][t] = (rok && aok[t]) ? av : 0.f;
+                b[u][t] = (rok && bok[t]) ? bv : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TN_UNROLL; ++u)
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][x], b[u][y], acc[x][y], 0, 0, 0);
+    }
+    float *out = C + (int64_t)blockIdx.z * slice_stride;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int col = kb + 32 * y + i;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = nb + 32 * x + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                if (row < N && col < K) out[(int64_t)row * ldc + col] = acc[x][y][e];
+            }
+        }
+}
+
+// out[n][k] (+)= sum over slices, in slice order
+__global__ void gemm_tn_reduce_kernel(const float *__restrict__ part, int slices, int64_t slice_stride, int N, int K,
+                                      float *__restrict__ out, int ldo, int accumulate)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)N * K) return;
+    const int n = (int)(t / K), k = (int)(t - (int64_t)n * K);
+    float s = 0.f;
+    for (int z = 0; z < slices; ++z) s += part[(int64_t)z * slice_stride + t];
+    float *o = out + (int64_t)n * ldo + k;
+    *o = accumulate ? *o + s : s;
+}
+
+static int tn_slices(int64_t rows, int N, int K)
+{
+    const int64_t tiles = (int64_t)tgp_cdiv(N, TN_TILE) * tgp_cdiv(K, TN_TILE);
+    int64_t s = tgp_cdiv((int64_t)1024, tiles);           // ~4 workgroups per CU in flight
+    const int64_t max_s = tgp_cdiv(rows, (int64_t)256);   // at least 256 rows per slice
+    if (s > max_s) s = max_s;
+    return (int)(s < 1 ? 1 : s);
+}
+
+extern "C" int64_t tgp_gemm_tn_workspace_floats(int64_t rows, int N, int K)
+{
+    if (rows <= 0 || N <= 0 || K <= 0) return 0;
+    return (int64_t)tn_slices(rows, N, K) * N * K;
+}
+
+extern "C" int tgp_gemm_tn_f32(const float *A, int lda, const float *B, int ldb, int64_t rows, int N, int K, float *C, int ldc,
+                               int accumulate, float *workspace, tgp_stream_t stream)
+{
+    TGP_REQUIRE(A && B && C && workspace && rows > 0 && N > 0 && K > 0 && lda >= N && ldb >= K && ldc >= K);
+    const int slices = tn_slices(rows, N, K);
+    int64_t per = tgp_cdiv(rows, (int64_t)slices);
+    per = (per + 2 * TN_UNROLL - 1) / (2 * TN_UNROLL) * (2 * TN_UNROLL);
+    const int used = (int)tgp_cdiv(rows, per);
+    const int64_t stride = (int64_t)N * K;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tgp_cdiv(K, TN_TILE), tgp_cdiv(N, TN_TILE), used), dim3(256), 0, tgp_hs(stream), A,
+                       lda, B, ldb, rows, N, K, per, workspace, K, stride);
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(tgp_cdiv(stride, (int64_t)256)), dim3(256), 0, tgp_hs(stream), workspace, used,
+                       stride, N, K, C, ldc, accumulate);
+    return TGP_LAUNCH_RESULT();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Column sums (bias gradients) and the two BatchNorm-backward sums, chunked like bn.hip.
+#define BW_CHUNK 1024
+
+__device__ __forceinline__ float act_grad(float z, int act, float slope) { return (act == 1 && !(z > 0.f)) ? slope : 1.f; }
+
+// MODE 0: partial[chunk][c] = sum dy;  MODE 1: s1 = sum dz, s2 = sum dz * xhat (dz = dy * act'(z), z = xhat * gamma + beta)
+template <int MODE>
+__global__ __launch_bounds__(256) void bw_partial_kernel(const float *__restrict__ dy, int lddy, const float *__restrict__ x, int ld,
+                                                         int64_t rows, int C, const float *__restrict__ mean,
+                                                         const float *__restrict__ var, float eps, const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, int act, float slope,
+                                                         const float *__restrict__ slope_vec, float *__restrict__ p1,
+                                                         float *__restrict__ p2)
+{
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int slice = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * BW_CHUNK;
+    const int64_t r1 = r0 + BW_CHUNK < rows ? r0 + BW_CHUNK : rows;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+        float mu = 0.f, inv = 0.f, g = 0.f, b = 0.f, sl = 0.f;
+        if (MODE == 1) mu = mean[c], inv = 1.0f / sqrtf(var[c] + eps), g = gamma[c], b = beta[c], sl = slope_vec ? slope_vec[c] : slope;
+        for (int64_t r = r0 + slice; r < r1; r += 4) {
+            float d = dy[r * lddy + c];
+            if (MODE == 1) {
+                const float xh = (x[r * ld + c] - mu) * inv;
+                d *= act_grad(xh * g + b, act, sl);
+                s2 += d * xh;
+            }
+            s1 += d;
+        }
+    }
+    red[0][slice][threadIdx.x & 63] = s1;
+    red[1][slice][threadIdx.x & 63] = s2;
+    __syncthreads();
+    if (slice == 0 && c < C) {
+        const int l = threadIdx.x;
+        p1[(int64_t)blockIdx.y * C + c] = ((red[0][0][l] + red[0][1][l]) + red[0][2][l]) + red[0][3][l];
+        if (MODE == 1) p2[(int64_t)blockIdx.y * C + c] = ((red[1][0][l] + red[1][1][l]) + red[1][2][l]) + red[1][3][l];
+    }
+}
+
+__global__ void bw_finish_kernel(const float *__restrict__ partial, int chunks, int C, float *__restrict__ out, int accumulate)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += partial[(int64_t)k * C + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+extern "C" int64_t tgp_bw_workspace_floats(int64_t rows, int C) { return rows > 0 && C > 0 ? 2 * (int64_t)tgp_cdiv(rows, BW_CHUNK) * C : 0; }
+
+extern "C" int tgp_colsum(const float *dy, int lddy, int64_t rows, int C, float *out, int accumulate, float *workspace,
+                          tgp_stream_t stream)
+{
+    TGP_REQUIRE(dy && out && workspace && rows > 0 && C > 0 && lddy >= C);
+    const int chunks = tgp_cdiv(rows, BW_CHUNK);
+    hipLaunchKernelGGL(bw_partial_kernel<0>, dim3(tgp_cdiv(C, 64), chunks), dim3(256), 0, tgp_hs(stream), dy, lddy,
+                       (const float *)nullptr, 0, rows, C, (const float *)nullptr, (const float *)nullptr, 0.f,
+                       (const float *)nullptr, (const float *)nullptr, 0, 0.f, (const float *)nullptr, workspace, (float *)nullptr);
+    hipLaunchKernelGGL(bw_finish_kernel, dim3(tgp_cdiv(C, 256)), dim3(256), 0, tgp_hs(stream), workspace, chunks, C, out, accumulate);
+    return TGP_LAUNCH_RESULT();
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restrict__ dy, int lddy, const float *__restrict__ x, int ld,
+                                                           int64_t rows, int C, const float *__restrict__ mean,
+                                                           const float *__restrict__ var, float eps, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, int act, float slope,
+                                                           const float *__restrict__ slope_vec, const float *__restrict__ s1,
+                                                           const float *__restrict__ s2, float *__restrict__ dx, int lddx)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int slice = threadIdx.x >> 6;
+    if (c >= C) return;
+    const float mu = mean[c], inv = 1.0f / sqrtf(var[c] + eps), g = gamma[c], b = beta[c];
+    const float sl = slope_vec ? slope_vec[c] : slope;
+    const float inv_n = (float)(1.0 / (double)rows);
+    const float m1 = s1[c] * inv_n, m2 = s2[c] * inv_n, scale = g * inv;
+    const int64_t r0 = (int64_t)blockIdx.y * BW_CHUNK;
+    const int64_t r1 = r0 + BW_CHUNK < rows ? r0 + BW_CHUNK : rows;
+    for (int64_t r = r0 + slice; r < r1; r += 4) {
+        const float xh = (x[r * ld + c] - mu) * inv;
+        const float dz = dy[r * lddy + c] * act_grad(xh * g + b, act, sl);
+        dx[r * lddx + c] = scale * ((dz - m1) - xh * m2);
+    }
+}
+
+// BatchNorm(train) + activation backward.  dgamma = sum dz * xhat, dbeta = sum dz are returned (they double as the
+// batch sums of the dx formula).  dx may alias dy.
+extern "C" int tgp_bn_bwd(const float *dy, int lddy, const float *x, int ld, int64_t rows, int C, const float *mean,
+                          const float *var, float eps, const float *gamma, const float *beta, int act, float slope,
+                          const float *slope_vec, float *dx, int lddx, float *dgamma, float *dbeta, float *workspace,
+                          tgp_stream_t stream)
+{
+    TGP_REQUIRE(dy && x && mean && var && gamma && beta && dx && dgamma && dbeta && workspace && rows > 0 && C > 0);
+    TGP_REQUIRE(lddy >= C && ld >= C && lddx >= C && (act == 0 || act == 1));
+    const int chunks = tgp_cdiv(rows, BW_CHUNK);
+    float *p1 = workspace, *p2 = workspace + (int64_t)chunks * C;
+    const dim3 grid(tgp_cdiv(C, 64), chunks), block(256);
+    hipLaunchKernelGGL(bw_partial_kernel<1>, grid, block, 0, tgp_hs(stream), dy, lddy, x, ld, rows, C, mean, var, eps, gamma, beta,
+                       act, slope, slope_vec, p1, p2);
+    hipLaunchKernelGGL(bw_finish_kernel, dim3(tgp_cdiv(C, 256)), dim3(256), 0, tgp_hs(stream), p1, chunks, C, dbeta, 0);
+    hipLaunchKernelGGL(bw_finish_kernel, dim3(tgp_cdiv(C, 256)), dim3(256), 0, tgp_hs(stream), p2, chunks, C, dgamma, 0);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, block, 0, tgp_hs(stream), dy, lddy, x, ld, rows, C, mean, var, eps, gamma, beta,
+                       act, slope, slope_vec, dbeta, dgamma, dx, lddx);
+    return TGP_LAUNCH_RESULT();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Layers whose output only feeds a max over each object's points (conv_5, the heads' conv2): the incoming gradient is
+// (objects x C) and lands on one row per (object, channel) -- the argmax the forward recorded.
+// sums: s1[c] = sum_b dz(b, c), s2[c] = sum_b dz(b, c) * xhat(argmax(b, c), c); one thread per channel, objects in order.
+__global__ void bn_bwd_pooled_sums_kernel(const float *__restrict__ dpool, int ldp, const int *__restrict__ argrow, int lda,
+                                          const float *__restrict__ x, int ld, int objects, int C, const float *__restrict__ mean,
+                                          const float *__restrict__ var, float eps, const float *__restrict__ gamma,
+                                          const float *__restrict__ beta, int act, float slope, const float *__restrict__ slope_vec,
+                                          float *__restrict__ s1, float *__restrict__ s2)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mu = mean[c], inv = 1.0f / sqrtf(var[c] + eps), g = gamma[c], b = beta[c];
+    const float sl = slope_vec ? slope_vec[c] : slope;
+    float a1 = 0.f, a2 = 0.f;
+    for (int o = 0; o < objects; ++o) {
+        const int64_t r = argrow[(int64_t)o * lda + c];
+        const float xh = (x[r * ld + c] - mu) * inv;
+        const float dz = dpool[(int64_t)o * ldp + c] * act_grad(xh * g + b, act, sl);
+        a1 += dz, a2 += dz * xh;
+    }
+    s1[c] = a1, s2[c] = a2;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_pooled_apply_kernel(const float *__restrict__ dpool, int ldp,
+                                                                  const int *__restrict__ argrow, int lda,
+                                                                  const float *__restrict__ x, int ld, int64_t rows, int rows_per_obj,
+                                                                  int C, const float *__restrict__ mean, const float *__restrict__ var,
+                                                                  float eps, const float *__restrict__ gamma,
+                                                                  const float *__restrict__ beta, int act, float slope,
+                                                                  const float *__restrict__ slope_vec, const float *__restrict__ s1,
+                                                                  const float *__restrict__ s2, float *__restrict__ dx, int lddx)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int slice = threadIdx.x >> 6;
+    if (c >= C) return;
+    const float mu = mean[c], inv = 1.0f / sqrtf(var[c] + eps), g = gamma[c], b = beta[c];
+    const float sl = slope_vec ? slope_vec[c] : slope;
+    const float inv_n = (float)(1.0 / (double)rows);
+    const float m1 = s1[c] * inv_n, m2 = s2[c] * inv_n, scale = g * inv;
+    const int64_t r0 = (int64_t)blockIdx.y * BW_CHUNK;
+    const int64_t r1 = r0 + BW_CHUNK < rows ? r0 + BW_CHUNK : rows;
+    for (int64_t r = r0 + slice; r < r1; r += 4) {
+        const float xh = (x[r * ld + c] - mu) * inv;
+        const int64_t o = r / rows_per_obj;
+        float dz = 0.f;
+        if (argrow[o * lda + c] == r) dz = dpool[o * ldp + c] * act_grad(xh * g + b, act, sl);
+        dx[r * lddx + c] = scale * ((dz - m1) - xh * m2);
+    }
+}
+
+extern "C" int tgp_bn_bwd_pooled(const float *dpool, int ldp, const int *argrow, int lda, const float *x, int ld, int objects,
+                                 int rows_per_obj, int C, const float *mean, const float *var, float eps, const float *gamma,
+                                 const float *beta, int act, float slope, const float *slope_vec, float *dx, int lddx,
+                                 float *dgamma, float *dbeta, tgp_stream_t stream)
+{
+    TGP_REQUIRE(dpool && argrow && x && mean && var && gamma && beta && dx && dgamma && dbeta);
+    TGP_REQUIRE(objects > 0 && rows_per_obj > 0 && C > 0 && ldp >= C && lda >= C && ld >= C && lddx >= C && (act == 0 || act == 1));
+    const int64_t rows = (int64_t)objects * rows_per_obj;
+    hipLaunchKernelGGL(bn_bwd_pooled_sums_kernel, dim3(tgp_cdiv(C, 64)), dim3(64), 0, tgp_hs(stream), dpool, ldp, argrow, lda, x, ld,
+                       objects, C, mean, var, eps, gamma, beta, act, slope, slope_vec, dbeta, dgamma);
+    hipLaunchKernelGGL(bn_bwd_pooled_apply_kernel, dim3(tgp_cdiv(C, 64), tgp_cdiv(rows, (int64_t)BW_CHUNK)), dim3(256), 0,
+                       tgp_hs(stream), dpool, ldp, argrow, lda, x, ld, rows, rows_per_obj, C, mean, var, eps, gamma, beta, act,
+                       slope, slope_vec, dbeta, dgamma, dx, lddx);
+    return TGP_LAUNCH_RESULT();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// max over each object's points with the winning row (first row on ties, as torch.max) of y = act(BN(x)) computed on the
+// fly from the raw layer output (mean == NULL: y = x).  One thread per (object, channel) walks the object's rows:
+// coalesced across channels.
+__global__ void colmax_arg_kernel(const float *__restrict__ x, int ld, int n, int C, const float *__restrict__ mean,
+                                  const float *__restrict__ var, float eps, const float *__restrict__ gamma,
+                                  const float *__restrict__ beta, int act, float slope, const float *__restrict__ slope_vec,
+                                  float *__restrict__ out, int ldo, int *__restrict__ argrow, int lda)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int o = blockIdx.y;
+    if (c >= C) return;
+    float mu = 0.f, a = 1.f, b = 0.f, sl = 0.f;
+    if (mean) mu = mean[c], a = gamma[c] / sqrtf(var[c] + eps), b = beta[c], sl = slope_vec ? slope_vec[c] : slope;
+    const int64_t r0 = (int64_t)o * n;
+    float best = 0.f;
+    int64_t arg = r0;
+    for (int64_t r = r0; r < r0 + n; ++r) {
+        float v = x[r * ld + c];
+        if (mean) {
+            v = (v - mu) * a + b;      // same expression as bn_apply_kernel: the pooled value equals the stored activation
+            if (act == 1) v = v > 0.f ? v : v * sl;
+        }
+        if (r == r0 || v > best || (v != v && best == best)) best = v, arg = r;   // NaN propagates like torch.max
+    }
+    out[(int64_t)o * ldo + c] = best;
+    argrow[(int64_t)o * lda + c] = (int)arg;
+}
+
+extern "C" int tgp_colmax_arg(const float *x, int ld, int objects, int n, int C, const float *mean, const float *var, float eps,
+                              const float *gamma, const float *beta, int act, float slope, const float *slope_vec, float *out,
+                              int ldo, int *argrow, int lda, tgp_stream_t stream)
+{
+    TGP_REQUIRE(x && out && argrow && objects > 0 && n > 0 && C > 0 && ld >= C && ldo >= C && lda >= C);
+    TGP_REQUIRE(!mean || (var && gamma && beta));
+    TGP_REQUIRE((int64_t)objects * n < 0x7fffffff);
+    hipLaunchKernelGGL(colmax_arg_kernel, dim3(tgp_cdiv(C, 64), objects), dim3(64), 0, tgp_hs(stream), x, ld, n, C, mean, var, eps,
+                       gamma, beta, act, slope, slope_vec, out, ldo, argrow, lda);
+    return TGP_LAUNCH_RESULT();
+}
+
+// dst (cols, rows) = src (rows, cols)^T   (weights, once per step, for da = dx W through the forward GEMM kernels)
+__global__ void transpose_kernel(const float *__restrict__ src, int lds_, int rows, int cols, float *__restrict__ dst, int ldd)
+{
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + threadIdx.x;
+        tile[j][threadIdx.x] = (r < rows && c < cols) ? src[(int64_t)r * lds_ + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + threadIdx.x;
+        if (c < cols && r < rows) dst[(int64_t)c * ldd + r] = tile[threadIdx.x][j];
+    }
+}
+
+extern "C" int tgp_transpose(const float *src, int ld_src, int rows, int cols, float *dst, int ld_dst, tgp_stream_t stream)
+{
+    TGP_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows);
+    hipLaunchKernelGGL(transpose_kernel, dim3(tgp_cdiv(cols, 32), tgp_cdiv(rows, 32)), dim3(32, 8), 0, tgp_hs(stream), src, ld_src,
+                       rows, cols, dst, ld_dst);
+    return TGP_LAUNCH_RESULT();
+}

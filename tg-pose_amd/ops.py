@@ -449,3 +449,86 @@ def dropout(x, p, generator=None):
     y = torch.empty_like(x)
     check(_lib.lib().tgp_dropout_apply(_p(x), _p(keep), float(p), x.numel(), _p(y), _stream(x)), "tgp_dropout_apply")
     return y
+
+
+# ------------------------------------------------------------------------------------------------- backward pass
+def _ws(floats, dev):
+    return torch.empty(max(int(floats), 1), device=dev, dtype=torch.float32)
+
+
+def gemm_tn(a, b, out=None, accumulate=False):
+    """out (N, K) (+)= a^T b over the rows: a (rows, N), b (rows, K) row views (row stride >= width).  dW = dx^T x."""
+    a, lda = _rows(a.reshape(-1, a.shape[-1]) if a.dim() > 2 and a.is_contiguous() else a, "a")
+    b, ldb = _rows(b.reshape(-1, b.shape[-1]) if b.dim() > 2 and b.is_contiguous() else b, "b")
+    rows, N, K = math.prod(a.shape[:-1]), a.shape[-1], b.shape[-1]
+    if math.prod(b.shape[:-1]) != rows:
+        raise ValueError("gemm_tn: row counts differ")
+    if out is None:
+        out = torch.empty(N, K, device=a.device, dtype=torch.float32)
+    out, ldc = _rows(out, "out")
+    ws = _ws(_lib.lib().tgp_gemm_tn_workspace_floats(rows, N, K), a.device)
+    check(_lib.lib().tgp_gemm_tn_f32(_p(a), lda, _p(b), ldb, rows, N, K, _p(out), ldc, int(accumulate), _p(ws), _stream(a)),
+          "tgp_gemm_tn_f32")
+    return out
+
+
+def colsum(dy, out=None, accumulate=False):
+    dy, ld = _rows(dy, "dy")
+    rows, C = math.prod(dy.shape[:-1]), dy.shape[-1]
+    if out is None:
+        out = torch.empty(C, device=dy.device, dtype=torch.float32)
+    ws = _ws(_lib.lib().tgp_bw_workspace_floats(rows, C), dy.device)
+    check(_lib.lib().tgp_colsum(_p(dy), ld, rows, C, _p(out), int(accumulate), _p(ws), _stream(dy)), "tgp_colsum")
+    return out
+
+
+def bn_bwd(dy, x, mean, var, gamma, beta, eps=1e-5, act=0, slope=0.0, slope_vec=None, dx=None):
+    """Backward of y = act(BatchNorm_train(x)) over rows.  Returns (dx, dgamma, dbeta); dx defaults to in place on dy."""
+    dy, lddy = _rows(dy, "dy")
+    x, ld = _rows(x, "x")
+    rows, C = math.prod(x.shape[:-1]), x.shape[-1]
+    dx = dy if dx is None else dx
+    dx, lddx = _rows(dx, "dx")
+    dg = torch.empty(C, device=x.device, dtype=torch.float32)
+    db = torch.empty(C, device=x.device, dtype=torch.float32)
+    ws = _ws(_lib.lib().tgp_bw_workspace_floats(rows, C), x.device)
+    check(_lib.lib().tgp_bn_bwd(_p(dy), lddy, _p(x), ld, rows, C, _p(mean), _p(var), float(eps), _p(gamma), _p(beta), act,
+                                float(slope), _p(slope_vec), _p(dx), lddx, _p(dg), _p(db), _p(ws), _stream(x)), "tgp_bn_bwd")
+    return dx, dg, db
+
+
+def bn_bwd_pooled(dpool, argrow, x, rows_per_obj, mean, var, gamma, beta, eps=1e-5, act=0, slope=0.0, slope_vec=None, dx=None):
+    """Backward of max-over-points(act(BatchNorm_train(x))): dpool (objects, C), argrow (objects, C) int32 -> dense dx."""
+    x, ld = _rows(x, "x")
+    objects, C = dpool.shape
+    if dx is None:
+        dx = torch.empty(objects * rows_per_obj, C, device=x.device, dtype=torch.float32)
+    dx, lddx = _rows(dx, "dx")
+    dg = torch.empty(C, device=x.device, dtype=torch.float32)
+    db = torch.empty(C, device=x.device, dtype=torch.float32)
+    check(_lib.lib().tgp_bn_bwd_pooled(_p(dpool), dpool.stride(0), _p(argrow), argrow.stride(0), _p(x), ld, objects, rows_per_obj,
+                                       C, _p(mean), _p(var), float(eps), _p(gamma), _p(beta), act, float(slope), _p(slope_vec),
+                                       _p(dx), lddx, _p(dg), _p(db), _stream(x)), "tgp_bn_bwd_pooled")
+    return dx, dg, db
+
+
+def colmax_arg(x, objects, n, bn=None, act=0, slope=0.0, slope_vec=None, eps=1e-5):
+    """max over each object's n rows (+ winning global row, int32) of act(BN(x)); bn = (mean, var, gamma, beta) or None."""
+    x, ld = _rows(x, "x")
+    C = x.shape[-1]
+    out = torch.empty(objects, C, device=x.device, dtype=torch.float32)
+    arg = torch.empty(objects, C, device=x.device, dtype=torch.int32)
+    mean, var, gamma, beta = bn if bn is not None else (None, None, None, None)
+    check(_lib.lib().tgp_colmax_arg(_p(x), ld, objects, n, C, _p(mean), _p(var), float(eps), _p(gamma), _p(beta), act,
+                                    float(slope), _p(slope_vec), _p(out), out.stride(0), _p(arg), arg.stride(0), _stream(x)),
+          "tgp_colmax_arg")
+    return out, arg
+
+
+def transpose(w):
+    """(rows, cols) -> contiguous (cols, rows)"""
+    w, ld = _rows(w, "w")
+    rows, cols = w.shape
+    out = torch.empty(cols, rows, device=w.device, dtype=torch.float32)
+    check(_lib.lib().tgp_transpose(_p(w), ld, rows, cols, _p(out), rows, _stream(w)), "tgp_transpose")
+    return out
