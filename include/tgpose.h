@@ -279,6 +279,33 @@ int tgp_colmax_arg(const float *x, int ld, int objects, int n, int C, const floa
 /* dst (cols, rows) = src (rows, cols)^T. */
 int tgp_transpose(const float *src, int ld_src, int rows, int cols, float *dst, int ld_dst, tgp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Backward pass of the graph layers (the `_bwd` entry points of SURVEY.md section 8b, seam #2).  Scatters use hardware
+ * float atomics (as the reference's CUDA autograd does for index / max backward); d* outputs that are scattered into
+ * must be zero-initialised (or hold a gradient to accumulate onto) by the caller.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* HSlayer_surface.graph_conv (gcn3d.py:91-106): dg (B,n,C) -> dsdn (3, S*C), the gradient w.r.t. the unit support
+ * directions (F.normalize's own backward stays with the caller).  workspace: tgp_gconv_bwd_workspace_floats(B, n, C). */
+int64_t tgp_gconv_bwd_workspace_floats(int B, int n, int C);
+int tgp_gconv_surface_bwd(const float *xyz, const int32_t *idx, const float *sdn, const float *dg, int ldg, int B, int n, int k,
+                          int S, int C, float *dsdn, float *workspace, tgp_stream_t stream);
+
+/* HS_layer.graph_conv (gcn3d.py:157-180): proj (B,n,>=8C) = [centre | 7 support blocks] as in tgp_gconv_hs_fwd;
+ * dproj (same layout) += d centre, d support (scatter to the arg-max neighbour); dsdn (3, S*C) as above. */
+int tgp_gconv_hs_bwd(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, const float *dg, int ldg,
+                     int B, int n, int k, int S, int C, float *dproj, int lddp, float *dsdn, float *workspace, tgp_stream_t stream);
+
+/* y[b][p][c] = max_j src[b][idx[b][p][j]][c], p < n_rows (get_ORL_global's and Pool_layer's neighbour max):
+ * dsrc[b][arg][c] += dy.  per_object != 0: dy is (B, C) and every row receives dy[b][c] * scale (the mean over the
+ * points that follows in get_ORL_global: scale = 1 / n); else dy is (B*n_rows, C). */
+int tgp_nbrmax_bwd(const float *src, int ld_src, const int32_t *idx, int B, int n_src, int n_rows, int k, int C, const float *dy,
+                   int lddy, int per_object, float scale, float *dsrc, int ld_dsrc, tgp_stream_t stream);
+
+/* tgp_gather_rows backward: dsrc[b][idx[b][p]][:] += dy[b][p][:]. */
+int tgp_gather_rows_bwd(const float *dy, int lddy, const int32_t *idx, int B, int n_src, int n_out, int C, float *dsrc,
+                        int ld_dsrc, tgp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

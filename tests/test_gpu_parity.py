@@ -588,14 +588,12 @@ def test_forward_full_batch_properties(ops):
     assert torch.allclose(full["p_green_R"].norm(dim=1), torch.ones(32, device=DEV), atol=1e-4)
 
 
-def test_modules_refuse_cpu_and_autograd(ops):
+def test_modules_refuse_cpu_and_single_object_training(ops):
     net = _net(0)
     pts, obj = synth_points(1, 256, 0)
     with pytest.raises(RuntimeError):
         net(pts, obj)                                   # CPU tensors: no fallback
     net.train()
-    with pytest.raises(NotImplementedError):            # the backward pass is not built: refuse rather than return
-        net(g(pts), g(obj))                             # tensors that silently carry no graph
     with torch.no_grad():
         with pytest.raises(ValueError):                 # nn.BatchNorm1d's own rule: one object has no batch statistics
             net(g(pts), g(obj))
@@ -971,3 +969,206 @@ def test_pooled_bn_backward_vs_autograd(ops, B, n, C, slope):
     assert torch.allclose(dx.cpu(), x.grad, atol=2e-6, rtol=1e-4)
     assert torch.allclose(dg.cpu(), gamma.grad, atol=2e-5, rtol=1e-4)
     assert torch.allclose(db.cpu(), beta.grad, atol=2e-5, rtol=1e-4)
+
+
+# ----------------------------------------------------------------------------------------- autograd (training step)
+GRAD_TOL = 3e-2
+GRAD_ATOL = 1e-2     # conv biases in front of a BatchNorm have an exactly zero gradient: both sides return rounding noise
+
+
+def _oracle_grads(PR, sd, pts, obj, sample, weights, only_encoder=False):
+    """CPU oracle in training mode (dropout off) with torch autograd: outputs, graphs and d(sum_k <out_k, w_k>)/d(param)."""
+    P = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running_" not in k else v.clone())
+         for k, v in sd.items()}
+    fwd = PR.encoder_only_forward if only_encoder else PR.posenet_forward
+    kw = {} if only_encoder else dict(train_keys=True)
+    out, inter = fwd(P, pts, obj, sample_idx=sample, mode="exact", bn_train=True, want_intermediates=True, **kw)
+    out.pop("_bn_new")
+    loss = sum((out[k] * weights[k]).sum() for k in weights)
+    loss.backward()
+    return out, inter, {k: v.grad for k, v in P.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None}
+
+
+def _loss_weights(out, seed):
+    gen = torch.Generator().manual_seed(seed)
+    scale = dict(feat=1e-3, recon=1e-2, h1=1e-2, h2=1e-2, feat_global=1e-2)
+    return {k: torch.randn(v.shape, generator=gen) * scale.get(k, 1.0) for k, v in out.items()}
+
+
+@pytest.mark.parametrize("B,N,seed", [(3, 256, 41), (3, 1028, 42)])
+def test_backward_full_network_vs_oracle_autograd(ops, B, N, seed):
+    """loss.backward() through PoseNet9D (training mode, dropout p = 0) against torch autograd of the CPU oracle on the same
+    graphs: every parameter's gradient, for a loss that weights every output tensor.
+
+    Metric: relative L2 error per parameter <= 3 %.  The network's gradient is discontinuous wherever a ReLU input or a
+    max over neighbours / points changes sign or winner, and two fp32 evaluations whose forward activations differ by 1e-6
+    disagree on a handful of those ~1e5 decisions per layer; each flip moves one activation's gradient by O(1).  torch's
+    own fp32 GPU ops against its fp64 ops show the same size of deviation on this network (scripts/debug_grad3.py: up to
+    17 % in the max norm at one BatchNorm input, 1-5 % in the weights downstream), so a max-norm bound would test the coin
+    flips, not the kernels.  The kernels themselves are checked tightly (1e-4 .. 1e-6) where no such decision separates
+    the two sides: test_gemm_tn_vs_fp64, test_bn_backward_vs_autograd, test_pooled_bn_backward_vs_autograd,
+    test_hs_layer_backward_vs_oracle_autograd, test_surface_layer_backward_vs_oracle_autograd,
+    test_pool_and_upsample_backward_vs_autograd."""
+    from tgpose_amd import FLAGS, seeded_state_dict
+    _, _, PR = _oracle()
+    sd = seeded_state_dict(seed)
+    pts, obj = synth_points(B, N, seed)
+    torch.manual_seed(seed)
+    i1 = torch.randperm(N)[: N // 4]
+    sample = (i1, torch.randperm(i1.numel())[: i1.numel() // 4])
+    with torch.no_grad():
+        probe = PR.posenet_forward(sd, pts, obj, sample_idx=sample, train_keys=True, mode="exact", bn_train=True)
+    probe.pop("_bn_new")
+    weights = _loss_weights(probe, seed)
+    want_out, inter, want = _oracle_grads(PR, sd, pts, obj, sample, weights)
+    net = _train_net(seed)
+    FLAGS.train = 1
+    try:
+        out = net(g(pts), g(obj), sample_idx=sample, inject=inter["indices"])
+    finally:
+        FLAGS.train = 0
+    for k, v in want_out.items():
+        assert torch.allclose(out[k].detach().cpu(), v.detach(), atol=1e-4, rtol=0), k
+    loss = sum((out[k] * g(weights[k])).sum() for k in weights)
+    loss.backward()
+    got = {k: p.grad for k, p in net.named_parameters()}
+    assert set(want) <= set(got)
+    rel = {}
+    for k, w in want.items():
+        assert got[k] is not None, k
+        rel[k] = (got[k].cpu() - w).norm().item() / (w.norm().item() + GRAD_ATOL)
+    for k in sorted(rel, key=rel.get, reverse=True)[:8]:
+        print("|dg|_2 / |g|_2  %-50s %.2e   (|g|_2 %.3e)" % (k, rel[k], want[k].norm().item()))
+    bad = {k: v for k, v in rel.items() if v > GRAD_TOL}
+    assert not bad, bad
+    unused = [k for k in got if k not in want and got[k] is not None and got[k].abs().max() > 0]
+    assert not unused, unused
+
+
+def test_backward_encoder_only_vs_oracle_autograd(ops):
+    from tgpose_amd import PoseNet9D, seeded_state_dict
+    _, _, PR = _oracle()
+    B, N, seed = 3, 512, 43
+    sd = seeded_state_dict(seed, only_encoder=True)
+    pts, obj = synth_points(B, N, seed)
+    torch.manual_seed(seed)
+    i1 = torch.randperm(N)[: N // 4]
+    sample = (i1, torch.randperm(i1.numel())[: i1.numel() // 4])
+    gen = torch.Generator().manual_seed(seed)
+    weights = dict(feat_global=torch.randn(B, 1286, generator=gen) * 1e-2, recon=torch.randn(B, N, 3, generator=gen))
+    want_out, inter, want = _oracle_grads(PR, sd, pts, obj, sample, weights, only_encoder=True)
+    net = PoseNet9D(only_encoder=True)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).train()
+    out = net(g(pts), g(obj), sample_idx=sample, inject=inter["indices"])
+    for k in weights:
+        assert torch.allclose(out[k].detach().cpu(), want_out[k].detach(), atol=1e-4, rtol=0), k
+    sum((out[k] * g(weights[k])).sum() for k in weights).backward()
+    for k, w in want.items():
+        p = dict(net.named_parameters())[k]
+        err, ref = (p.grad.cpu() - w).norm().item(), w.norm().item()
+        assert err <= GRAD_TOL * (ref + GRAD_ATOL), (k, err, ref)
+
+
+def _layer_params(sd, prefix):
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize("name,cin,cout,n,k", [("conv_1", 128, 128, 257, 20), ("conv_4", 256, 512, 64, 8), ("conv_2", 128, 256, 100, 12)])
+def test_hs_layer_backward_vs_oracle_autograd(ops, name, cin, cout, n, k):
+    """One HS_layer (gcn3d.py:142-186) forward + backward: d(feature map), d(weights), d(bias), d(directions), d(STE),
+    d(conv2) against torch autograd of the CPU oracle on the same graphs.  No BatchNorm / ReLU on the activations here, so
+    the comparison is tight: 1e-4 of each gradient's largest entry."""
+    from tgpose_amd import seeded_state_dict, autograd as AG
+    from tgpose_amd.network.fs_net_repo.gcn3d import HS_layer
+    _, G, _ = _oracle()
+    B = 3
+    sd = seeded_state_dict(7)
+    lp = _layer_params(sd, "face_all.encoder.%s." % name)
+    gen = torch.Generator().manual_seed(n + k)
+    xyz = torch.randn(B, n, 3, generator=gen) * 0.1
+    fm = torch.randn(B, n, cin, generator=gen).abs()
+    w = torch.randn(B, n, cout, generator=gen)
+    P = {"L." + k_: v.clone().requires_grad_(True) for k_, v in lp.items()}
+    P["_support_num"] = 7
+    fm_ref = fm.clone().requires_grad_(True)
+    cache = G.GraphCache(mode="exact")
+    out_ref = G.hs_conv(P, "L", xyz, fm_ref, k, cache)
+    (out_ref * w).sum().backward()
+    layer = HS_layer(cin, cout, 7)
+    layer.load_state_dict(lp)
+    layer = layer.to(DEV)
+    fm_g = g(fm).requires_grad_(True)
+    inject = {"x." + kk.split(".", 1)[1]: v.int() for kk, v in cache.record.items()}
+    graphs = AG._GraphSource(torch.device(DEV), inject, None, "x.")
+    out = AG._hs(layer, "rf_name", g(xyz), fm_g, _Renamer(graphs), 0, k)
+    assert torch.allclose(out.detach().cpu(), out_ref.detach(), atol=2e-5, rtol=1e-5)
+    (out * g(w)).sum().backward()
+    pairs = [("fm", fm_g.grad, fm_ref.grad)] + [(k_, dict(layer.named_parameters())[k_].grad, P["L." + k_].grad) for k_ in lp]
+    for nm, a, r in pairs:
+        err, ref = (a.cpu() - r).abs().max().item(), r.abs().max().item()
+        assert err <= 1e-4 * ref + 1e-6, (nm, err, ref)
+
+
+class _Renamer(object):
+    """maps the layer-local graph names used by autograd._hs / _surface onto the two lists of a single-layer test"""
+
+    def __init__(self, graphs):
+        self.graphs, self.g = graphs, graphs.g
+
+    def __call__(self, name, level, x, k):
+        return self.graphs("rf" if name.endswith(".rf") else "orl_xyz", level, x, k)
+
+
+def test_surface_layer_backward_vs_oracle_autograd(ops):
+    from tgpose_amd import seeded_state_dict, autograd as AG
+    from tgpose_amd.network.fs_net_repo.gcn3d import HSlayer_surface
+    _, G, _ = _oracle()
+    B, n, k = 3, 300, 20
+    lp = _layer_params(seeded_state_dict(8), "face_all.encoder.conv_0.")
+    gen = torch.Generator().manual_seed(5)
+    xyz = torch.randn(B, n, 3, generator=gen) * 0.1
+    w = torch.randn(B, n, 128, generator=gen)
+    P = {"L." + k_: v.clone().requires_grad_(True) for k_, v in lp.items()}
+    P["_support_num"] = 7
+    cache = G.GraphCache(mode="exact")
+    out_ref = G.surface_conv(P, "L", xyz, k, cache)
+    (out_ref * w).sum().backward()
+    layer = HSlayer_surface(128, 7)
+    layer.load_state_dict(lp)
+    layer = layer.to(DEV)
+    inject = {"x." + kk.split(".", 1)[1]: v.int() for kk, v in cache.record.items()}
+    graphs = AG._GraphSource(torch.device(DEV), inject, None, "x.")
+    out = AG._surface(layer, g(xyz), _Renamer(graphs), k)
+    assert torch.allclose(out.detach().cpu(), out_ref.detach(), atol=2e-5, rtol=1e-5)
+    (out * g(w)).sum().backward()
+    for k_ in lp:
+        a, r = dict(layer.named_parameters())[k_].grad, P["L." + k_].grad
+        err, ref = (a.cpu() - r).abs().max().item(), r.abs().max().item()
+        assert err <= 1e-4 * ref + 1e-6, (k_, err, ref)
+
+
+def test_pool_and_upsample_backward_vs_autograd(ops):
+    """Pool_layer's neighbour max at the sampled points and the nearest-neighbour upsampling (FaceRecon.py:66-72)."""
+    from tgpose_amd import autograd as AG
+    _, G, _ = _oracle()
+    B, n, C = 3, 257, 128
+    gen = torch.Generator().manual_seed(9)
+    xyz = torch.randn(B, n, 3, generator=gen) * 0.1
+    fm = torch.randn(B, n, C, generator=gen)
+    sample = torch.randperm(n, generator=gen)[: n // 4]
+    cache = G.GraphCache(mode="exact")
+    fr = fm.clone().requires_grad_(True)
+    v_ref, f_ref = G.pool(xyz, fr, sample, cache, "p")
+    near = G.nearest_index(xyz, v_ref)                       # (B, n, 1)
+    up_ref = G.gather_rows(f_ref, near).squeeze(2)
+    w = torch.randn(B, n, C, generator=gen)
+    (up_ref * w).sum().backward()
+    fg = g(fm).requires_grad_(True)
+    idx = ops.knn_xyz(g(xyz), 20)
+    assert torch.equal(idx[:, :, :4].cpu().long(), cache.record["p.xyz"])
+    v, f = AG._PoolMax.apply(g(xyz), fg, idx, g(sample.int()))
+    up = AG._GatherRows.apply(f, g(near.squeeze(2).int()))
+    assert torch.equal(up.detach().cpu(), up_ref.detach())
+    (up * g(w)).sum().backward()
+    assert torch.allclose(fg.grad.cpu(), fr.grad, atol=1e-5, rtol=1e-5)

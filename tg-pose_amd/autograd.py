@@ -1,0 +1,365 @@
+"""Training-mode forward WITH autograd: PoseNet9D.forward as a graph of torch.autograd.Functions whose forward and
+backward both run on the HIP kernels (C ABI of include/tgpose.h), so that ``loss.backward()`` (trainer/RL_TDA.py:205-224)
+produces the gradients of every parameter.
+
+torch's autograd engine only sequences the backward and carries the glue that moves no arithmetic of its own
+(concatenation of the per-level features, the residual / broadcast adds of an HS layer, the (B, <=8) head post-processing):
+every GEMM, BatchNorm, graph convolution, neighbourhood max and scatter below is a HIP kernel.  The faster, fused
+no-autograd paths of ``engine.py`` are untouched; this module trades fusion for differentiability (round 1: correctness).
+
+Reference graph restated here: network/fs_net_repo/gcn3d.py:78-112,142-186,210-245, FaceRecon.py:39-86,112-117,139-167,
+PoseR.py:26-39, PoseTs.py:31-45, PoseNet9D.py:33-91.
+"""
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import engine, ops
+
+BN_EPS = engine.BN_EPS
+FEAT_C, FEAT_LD = engine.FEAT_C, engine.FEAT_LD
+S = 7
+
+
+def _pad4(t):
+    """pad the last dim with zeros to a multiple of 4 (the GEMM kernels read 16-byte quads)"""
+    r = (-t.shape[-1]) % 4
+    return F.pad(t, (0, r)) if r else t
+
+
+def _split_if_big(w, rows, grads=False):
+    """operand split for the tile GEMM kernels.  Gradients span many orders of magnitude below 1, outside what the
+    two-term fp16 split represents (fp16 bottoms out at 6e-8): the backward GEMMs use the three-term bf16 split, which
+    keeps fp32's range."""
+    if rows <= 32 or ops.GEMM_MODE == "fp32":
+        return None
+    return ops.split_bf16(w) if grads else ops.split_w(w)
+
+
+class _Linear(Function):
+    """y = x W^T (+ b): x (..., K) rows, W (N, K).  dW = dy^T x (TN GEMM), dx = dy W (forward kernel on W^T), db = colsum."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x = x.contiguous()
+        rows = x.numel() // x.shape[-1]
+        y = ops.linear_rows(x, W.contiguous(), bias=b, w_split=_split_if_big(W.contiguous(), rows))
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        N, K = W.shape
+        dy2 = dy.reshape(-1, N)
+        x2 = x.reshape(-1, K)
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dyp = _pad4(dy2).contiguous()                       # the reduction dim of this GEMM is N
+            wt = ops.transpose(W.contiguous())                  # (K, N)
+            wt = _pad4(wt).contiguous()
+            dx = ops.linear_rows(dyp, wt, w_split=_split_if_big(wt, dyp.shape[0], grads=True)).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            dW = ops.gemm_tn(dy2.contiguous(), x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy2.contiguous())
+        return dx, dW, db
+
+
+def linear(x, W, b=None):
+    return _Linear.apply(x, W, b)
+
+
+class _BNAct(Function):
+    """act(BatchNorm1d_train(x)) over rows (..., C); updates the module's running statistics like nn.BatchNorm1d."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, act, slope):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _, mean, var = ops.bn_train(x, gamma, beta, BN_EPS, act, slope, out=y)
+        _update_running(bn, mean, var, x.numel() // x.shape[-1])
+        ctx.save_for_backward(x, mean, var, gamma, beta)
+        ctx.act, ctx.slope = act, slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, var, gamma, beta = ctx.saved_tensors
+        dx, dg, db = ops.bn_bwd(dy.contiguous(), x, mean, var, gamma, beta, BN_EPS, ctx.act, ctx.slope, dx=torch.empty_like(x))
+        return dx, dg, db, None, None, None
+
+
+class _BNActPool(Function):
+    """max over each object's points of act(BatchNorm1d_train(x)): x (B, n, C) -> (B, C)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, act, slope):
+        x = x.contiguous()
+        B, n, C = x.shape
+        keys = torch.zeros(B, C, device=x.device, dtype=torch.int32)
+        _, mean, var = ops.bn_train(x, gamma, beta, BN_EPS, act, slope, want_out=False, colmax_keys=keys, rows_per_obj=n)
+        _update_running(bn, mean, var, B * n)
+        pooled, arg = ops.colmax_arg(x, B, n, bn=(mean, var, gamma, beta), act=act, slope=slope)
+        ctx.save_for_backward(x, mean, var, gamma, beta, arg)
+        ctx.act, ctx.slope = act, slope
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpool):
+        x, mean, var, gamma, beta, arg = ctx.saved_tensors
+        B, n, C = x.shape
+        dx, dg, db = ops.bn_bwd_pooled(dpool.contiguous(), arg, x, n, mean, var, gamma, beta, BN_EPS, ctx.act, ctx.slope)
+        return dx.view(B, n, C), dg, db, None, None, None
+
+
+def _update_running(bn, mean, var, rows):
+    if bn is None or not bn.track_running_stats:
+        return
+    m = bn.momentum
+    with torch.no_grad():
+        bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+        bn.running_var.mul_(1 - m).add_(var, alpha=m * rows / max(rows - 1, 1))
+        bn.num_batches_tracked.add_(1)
+
+
+def bn_act(x, bn, act=1, slope=0.0):
+    return _BNAct.apply(x, bn.weight, bn.bias, bn, act, slope)
+
+
+def bn_act_pool(x, bn, act=1, slope=0.0):
+    return _BNActPool.apply(x, bn.weight, bn.bias, bn, act, slope)
+
+
+class _GConvSurface(Function):
+    @staticmethod
+    def forward(ctx, xyz, idx, sdn, C):
+        g = ops.gconv_surface(xyz, idx, sdn.contiguous(), S, C)
+        ctx.save_for_backward(xyz, idx, sdn)
+        ctx.C = C
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        xyz, idx, sdn = ctx.saved_tensors
+        return None, None, ops.gconv_surface_bwd(xyz, idx, sdn.contiguous(), dg.contiguous(), S, ctx.C), None
+
+
+class _GConvHS(Function):
+    @staticmethod
+    def forward(ctx, xyz, idx, proj, sdn, C):
+        proj = proj.contiguous()
+        g = ops.gconv_hs(xyz, idx, proj, sdn.contiguous(), S, C)
+        ctx.save_for_backward(xyz, idx, proj, sdn)
+        ctx.C = C
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        xyz, idx, proj, sdn = ctx.saved_tensors
+        dproj, dsdn = ops.gconv_hs_bwd(xyz, idx, proj, sdn.contiguous(), dg.contiguous(), S, ctx.C)
+        return None, None, dproj, dsdn, None
+
+
+class _NbrMaxMean(Function):
+    """get_ORL_global without the repeat: mean over points of the max over each point's neighbours -> (B, C)"""
+
+    @staticmethod
+    def forward(ctx, g, idx):
+        g = g.contiguous()
+        ctx.save_for_backward(g, idx)
+        return ops.orl_global(g, idx)
+
+    @staticmethod
+    def backward(ctx, dglob):
+        g, idx = ctx.saved_tensors
+        return ops.nbrmax_bwd(g, idx, dglob.contiguous(), per_object=True, scale=1.0 / g.shape[1]), None
+
+
+class _PoolMax(Function):
+    """Pool_layer's feature half: max over the 4 nearest neighbours at the sampled points"""
+
+    @staticmethod
+    def forward(ctx, xyz, fm, idx, sample):
+        fm = fm.contiguous()
+        v, f = ops.pool(xyz, fm, idx, sample, kpool=4)
+        ctx.save_for_backward(fm, idx[:, sample.long(), :4].contiguous())
+        ctx.mark_non_differentiable(v)
+        return v, f
+
+    @staticmethod
+    def backward(ctx, _dv, df):
+        fm, idx_s = ctx.saved_tensors
+        return None, ops.nbrmax_bwd(fm, idx_s, df.contiguous()), None, None
+
+
+class _GatherRows(Function):
+    @staticmethod
+    def forward(ctx, fm, near):
+        fm = fm.contiguous()
+        B, n_src, C = fm.shape
+        out = torch.empty(B, near.shape[1], C, device=fm.device, dtype=torch.float32)
+        ops.gather_rows(fm, near, out)
+        ctx.save_for_backward(near)
+        ctx.n_src = n_src
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (near,) = ctx.saved_tensors
+        return ops.gather_rows_bwd(dy.contiguous(), near, ctx.n_src), None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def _orl(layer, g, idx_orl):
+    """ORL_forward (gcn3d.py:108-112,182-186): conv2(cat[g, global]) + g, with the concatenation split into the two
+    halves of conv2's weight (the global half is one row per object)."""
+    C = g.shape[-1]
+    w = layer.conv2.weight[:, :, 0]
+    glob = _NbrMaxMean.apply(g, idx_orl)                                  # (B, C)
+    return linear(g, w[:, :C]) + linear(glob, w[:, C:]).unsqueeze(1) + g
+
+
+def _surface(layer, xyz, graphs, kmax):
+    C = layer.kernel_num
+    sdn = F.normalize(layer.directions, dim=0)
+    g = _GConvSurface.apply(xyz, graphs("conv_0.rf", 0, xyz, kmax), sdn, C)
+    out = _orl(layer, g, graphs("conv_0.orl_xyz", 0, xyz, kmax))
+    ste = linear(_pad4(xyz), _pad4(layer.STE_layer.weight[:, :, 0]))
+    return out + ste
+
+
+def _hs(layer, name, xyz, fm, graphs, level, k):
+    C = layer.out_channel
+    sdn = F.normalize(layer.directions, dim=0)
+    idx_rf = graphs(name + ".rf", None, fm, k)
+    proj = linear(fm, layer.weights.t(), layer.bias)                      # (B, n, 8C) = [centre | support]
+    g = _GConvHS.apply(xyz, idx_rf, proj, sdn, C)
+    out = _orl(layer, g, graphs(name + ".orl_xyz", level, xyz, k))
+    return out + linear(fm, layer.STE_layer.weight[:, :, 0])
+
+
+class _GraphSource(object):
+    """neighbour lists of one forward (computed by the HIP kNN kernels on detached tensors, shared per level like
+    engine.Graphs; tests may inject the reference's own lists)"""
+
+    def __init__(self, device, inject, record, prefix):
+        self.g = engine.Graphs(device, inject, record, prefix)
+        self.xyz = {}
+
+    def __call__(self, name, level, x, k):
+        def compute():
+            with torch.no_grad():
+                if level is None:
+                    return ops.knn_feat(x.detach().contiguous(), k)
+                if level not in self.xyz:
+                    self.xyz[level] = ops.knn_xyz(x.detach().contiguous(), k)
+                return self.xyz[level]
+        return self.g.get(name, compute)
+
+
+def encoder(enc, xyz, obj_id, sample_idx, graphs, kmax=20, n_cls=6):
+    """Face_Enc.forward (FaceRecon.py:39-86) -> feat (B, N, FEAT_LD): [fm_0..fm_4 | one-hot | xyz | 0 0 0]"""
+    B, N, _ = xyz.shape
+    dev = xyz.device
+    s1 = sample_idx[0].to(device=dev, dtype=torch.int32)
+    s2 = sample_idx[1].to(device=dev, dtype=torch.int32)
+    fm0 = torch.relu(_surface(enc.conv_0, xyz, graphs, kmax))
+    fm1 = bn_act(_hs(enc.conv_1, "conv_1", xyz, fm0, graphs, 0, kmax), enc.bn1)
+    v1, fp1 = _PoolMax.apply(xyz, fm1, graphs("pool_1.xyz", 0, xyz, kmax), s1)
+    k1 = min(kmax, v1.shape[1] // 8)
+    fm2 = bn_act(_hs(enc.conv_2, "conv_2", v1, fp1, graphs, 1, k1), enc.bn2)
+    fm3 = bn_act(_hs(enc.conv_3, "conv_3", v1, fm2, graphs, 1, k1), enc.bn3)
+    v2, fp2 = _PoolMax.apply(v1, fm3, graphs("pool_2.xyz", 1, v1, k1), s2)
+    k2 = min(kmax, v2.shape[1] // 8)
+    fm4 = _hs(enc.conv_4, "conv_4", v2, fp2, graphs, 2, k2)
+    with torch.no_grad():
+        near1 = graphs.g.get("up_1", lambda: ops.nn1(xyz, v1)).view(B, N)
+        near2 = graphs.g.get("up_2", lambda: ops.nn1(xyz, v2)).view(B, N)
+        one_hot = torch.zeros(B, n_cls, device=dev).scatter_(1, obj_id.view(-1, 1).long(), 1)
+        tail = torch.cat([one_hot.unsqueeze(1).expand(B, N, n_cls), xyz, torch.zeros(B, N, FEAT_LD - FEAT_C - 3, device=dev)], 2)
+    return torch.cat([fm0, fm1, _GatherRows.apply(fm2, near1), _GatherRows.apply(fm3, near1), _GatherRows.apply(fm4, near2),
+                      tail], dim=2)
+
+
+def _w_feat(conv, cols=FEAT_C):
+    """weight of a Conv1d that reads the concat buffer, zero-padded to its row stride (the xyz columns included for Pose_Ts)"""
+    w = conv.weight[:, :, 0]
+    return F.pad(w, (0, FEAT_LD - w.shape[1]))
+
+
+def ph_predictor(ph, feat):
+    """PH_Predictor.forward (FaceRecon.py:139-167) -> back = pi1_1 + pi2_1 (B, FEAT_LD-padded), h1, h2"""
+    x = linear(feat, _w_feat(ph.conv_5[0]))
+    g = bn_act_pool(x, ph.conv_5[1], act=1, slope=0.2)                     # (B, 1024)
+    g = torch.cat((g, g), 1)
+    fa = bn_act(linear(g, ph.linear1.weight), ph.bn5, act=1, slope=0.2)
+    fa = ph.dp1(fa)
+    pi1 = linear(fa, ph.linear2.weight, ph.linear2.bias)
+    pi2 = linear(fa, ph.linear3.weight, ph.linear3.bias)
+    back = linear(_pad4(pi1), _pad4(ph.linear4.weight), ph.linear4.bias) + linear(_pad4(pi2), _pad4(ph.linear5.weight), ph.linear5.bias)
+    return back, torch.sigmoid(pi1), torch.sigmoid(pi2)
+
+
+def decoder(dec, feat, back):
+    """Face_Dec.forward on feat + back (FaceRecon.py:112-117,165): conv(feat + back) = conv(feat) + W back per object"""
+    blk = dec.conv1d_block
+    w0 = _w_feat(blk[0])
+    x = linear(feat, w0, blk[0].bias)
+    if back is not None:
+        x = x + linear(F.pad(back, (0, FEAT_LD - back.shape[1])), w0).unsqueeze(1)
+    x = bn_act(x, blk[1])
+    x = bn_act(linear(x, blk[3].weight[:, :, 0], blk[3].bias), blk[4])
+    x = bn_act(linear(x, blk[6].weight[:, :, 0], blk[6].bias), blk[7])
+    x = bn_act(linear(x, dec.recon_head[0].weight[:, :, 0], dec.recon_head[0].bias), dec.recon_head[1])
+    return linear(x, dec.recon_head[3].weight[:, :, 0], dec.recon_head[3].bias)
+
+
+def point_head(hd, feat):
+    """Rot_green / Rot_red / Pose_Ts (PoseR.py:26-39, PoseTs.py:31-45) on the concat buffer -> (B, out)"""
+    x = bn_act(linear(feat, _w_feat(hd.conv1), hd.conv1.bias), hd.bn1)
+    x = bn_act_pool(linear(x, hd.conv2.weight[:, :, 0], hd.conv2.bias), hd.bn2)
+    x = bn_act(linear(x, hd.conv3.weight[:, :, 0], hd.conv3.bias), hd.bn3)
+    x = hd.drop1(x)
+    return linear(x, hd.conv4.weight[:, :, 0], hd.conv4.bias)
+
+
+def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6):
+    """PoseNet9D.forward (PoseNet9D.py:33-91) with autograd; net is the drop-in module (training mode)."""
+    B, N, _ = points.shape
+    if B < 2:
+        raise ValueError("Expected more than 1 value per channel when training, got input size [%d, 256]" % B)
+    if sample_idx is None:
+        sample_idx = engine.draw_sample_idx(N)
+    points = points.contiguous().float()
+    mean = points.mean(dim=1, keepdim=True)
+    with torch.no_grad():
+        xyz, _ = ops.center(points)            # bit-identical to the reference's centring (kNN indices depend on it)
+    if net.only_encoder:
+        face = net.face_enc
+        graphs = _GraphSource(points.device, inject, record, "face_enc.encoder.")
+        feat = encoder(face.encoder, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
+        return dict(feat_global=feat[:, :, :FEAT_C].max(1)[0], recon=decoder(face.decoder, feat, None))
+    face = net.face_all
+    graphs = _GraphSource(points.device, inject, record, "face_all.encoder.")
+    feat = encoder(face.encoder, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
+    back, h1, h2 = ph_predictor(face.ph_pred, feat)
+    recon = decoder(face.decoder, feat, back)
+    green = point_head(net.rot_green, feat)
+    red = point_head(net.rot_red, feat)
+    ts = point_head(net.ts, feat)
+    out = dict()
+    if train_keys:
+        out["recon"] = recon + mean
+    out["p_green_R"] = green[:, 1:] / (torch.norm(green[:, 1:], dim=1, keepdim=True) + 1e-6)
+    out["p_red_R"] = red[:, 1:] / (torch.norm(red[:, 1:], dim=1, keepdim=True) + 1e-6)
+    out["f_green_R"] = torch.sigmoid(green[:, 0])
+    out["f_red_R"] = torch.sigmoid(red[:, 0])
+    out["Pred_T"] = ts[:, 0:3] + mean[:, 0]
+    out["Pred_s"] = ts[:, 3:6]
+    if train_keys:
+        out["h1"], out["h2"] = h1, h2
+        out["feat"] = feat[:, :, :FEAT_C]
+        out["feat_global"] = feat[:, :, :FEAT_C].max(1)[0]
+    return out

@@ -51,9 +51,10 @@ class PoseNet9D(_WithBuffers):
         if not points.is_cuda:
             raise RuntimeError("tgpose_amd.PoseNet9D runs on the GPU only (no CPU fallback); move inputs to cuda")
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "PoseNet9D: the training-mode forward is built (batch-statistics BatchNorm, dropout) but the backward pass "
-                "is not; call it under torch.no_grad() (as trainer/RL_TDA.py:117-118 does for net2) or use .eval()")
+            # differentiable path: the same kernels composed as torch.autograd.Functions (tgpose_amd/autograd.py)
+            from ... import autograd as tgp_autograd
+            return tgp_autograd.posenet_forward(self, points, obj_id, bool(FLAGS.train), sample_idx, inject, record,
+                                                FLAGS.gcn_n_num, FLAGS.obj_c)
         pk = self.packed(points.device)
         with torch.no_grad():
             if self.training:

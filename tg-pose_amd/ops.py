@@ -532,3 +532,53 @@ def transpose(w):
     out = torch.empty(cols, rows, device=w.device, dtype=torch.float32)
     check(_lib.lib().tgp_transpose(_p(w), ld, rows, cols, _p(out), rows, _stream(w)), "tgp_transpose")
     return out
+
+
+def gconv_surface_bwd(xyz, idx, sdn, dg, S, C):
+    """-> dsdn (3, S*C)"""
+    dg, ldg = _rows(dg, "dg")
+    B, n, k = idx.shape
+    dsdn = torch.empty(3, S * C, device=xyz.device, dtype=torch.float32)
+    ws = _ws(_lib.lib().tgp_gconv_bwd_workspace_floats(B, n, C), xyz.device)
+    check(_lib.lib().tgp_gconv_surface_bwd(_p(xyz), _p(idx), _p(sdn), _p(dg), ldg, B, n, k, S, C, _p(dsdn), _p(ws), _stream(xyz)),
+          "tgp_gconv_surface_bwd")
+    return dsdn
+
+
+def gconv_hs_bwd(xyz, idx, proj, sdn, dg, S, C):
+    """-> (dproj (B,n,8C) = [d centre | d support], dsdn (3, S*C))"""
+    proj, ldp = _rows(proj, "proj")
+    dg, ldg = _rows(dg, "dg")
+    B, n, k = idx.shape
+    dproj = torch.zeros(B, n, 8 * C, device=xyz.device, dtype=torch.float32)
+    dsdn = torch.empty(3, S * C, device=xyz.device, dtype=torch.float32)
+    ws = _ws(_lib.lib().tgp_gconv_bwd_workspace_floats(B, n, C), xyz.device)
+    check(_lib.lib().tgp_gconv_hs_bwd(_p(xyz), _p(idx), _p(proj), ldp, _p(sdn), _p(dg), ldg, B, n, k, S, C, _p(dproj), 8 * C,
+                                      _p(dsdn), _p(ws), _stream(xyz)), "tgp_gconv_hs_bwd")
+    return dproj, dsdn
+
+
+def nbrmax_bwd(src, idx, dy, per_object=False, scale=1.0, dsrc=None):
+    """backward of y[b,p] = max_j src[b, idx[b,p,j]]: idx (B, n_rows, k) int32; dy (B,n_rows,C) or (B,C) when per_object."""
+    src, lds = _rows(src, "src")
+    _i32(idx, "idx")
+    B, n_src, C = src.shape
+    n_rows, k = idx.shape[1], idx.shape[2]
+    dy, lddy = _rows(dy, "dy")
+    if dsrc is None:
+        dsrc = torch.zeros(B, n_src, C, device=src.device, dtype=torch.float32)
+    dsrc, ldds = _rows(dsrc, "dsrc")
+    check(_lib.lib().tgp_nbrmax_bwd(_p(src), lds, _p(idx), B, n_src, n_rows, k, C, _p(dy), lddy, int(per_object), float(scale),
+                                    _p(dsrc), ldds, _stream(src)), "tgp_nbrmax_bwd")
+    return dsrc
+
+
+def gather_rows_bwd(dy, idx, n_src):
+    """backward of gather_rows: dy (B,n_out,C) rows, idx (B,n_out) int32 -> dsrc (B,n_src,C)"""
+    dy, lddy = _rows(dy, "dy")
+    _i32(idx, "idx")
+    B, n_out, C = dy.shape
+    dsrc = torch.zeros(B, n_src, C, device=dy.device, dtype=torch.float32)
+    check(_lib.lib().tgp_gather_rows_bwd(_p(dy), lddy, _p(idx), B, n_src, n_out, C, _p(dsrc), C, _stream(dy)),
+          "tgp_gather_rows_bwd")
+    return dsrc
