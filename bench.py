@@ -83,6 +83,10 @@ def main():
                     help="split16: fp32-accurate GEMM on the fp16 matrix cores (2-term operand split, 3 MFMA terms); "
                          "split: the same on the bf16 matrix cores (3-term split, 6 MFMA terms, full fp32 range); "
                          "fp32: v_mfma_f32_32x32x2_f32 kernels")
+    ap.add_argument("--workload", choices=("forward", "train_step"), default="forward",
+                    help="forward: the headline metric (eval-mode forward).  train_step: BASELINE config 3/4 -- training-mode "
+                         "forward with autograd, Chamfer (DCD) + pose regression loss, backward, gradient all-reduce over the "
+                         "ranks, clip, SGD step; objects/s of whole steps")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,6 +140,30 @@ def main():
             return net(pts, obj)
         with torch.cuda.stream(st):
             return net(pts, obj)
+
+    if args.workload == "train_step":
+        from tgpose_amd import shard
+        from tgpose_amd.losses.dcd import calc_dcd
+        net.train()
+        FLAGS.train = 1
+        opt = torch.optim.SGD(net.parameters(), lr=1e-5, momentum=0.9)
+        gen = torch.Generator().manual_seed(7 + rank)
+        prior = (torch.randn(B, 1024, 3, generator=gen) * 0.1).to(dev) + pts.mean(1, keepdim=True)
+        tgt = {k: torch.randn(B, 3, generator=gen).to(dev) for k in ("p_green_R", "p_red_R", "Pred_T", "Pred_s")}
+        code = torch.rand(B, 2500, generator=gen).to(dev)
+
+        def step():
+            out = net(pts, obj)
+            loss = calc_dcd(out["recon"], prior)[0].mean()
+            for k, t in tgt.items():
+                loss = loss + torch.nn.functional.smooth_l1_loss(out[k], t)
+            loss = loss + torch.nn.functional.mse_loss(out["h1"], code) + torch.nn.functional.mse_loss(out["h2"], code)
+            loss.backward()
+            shard.allreduce_gradients(net.parameters())
+            torch.nn.utils.clip_grad_norm_(net.parameters(), 5.0)         # trainer/RL_TDA.py:223
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            return loss
 
     for _ in range(max(args.warmup, len(streams))):
         step()
@@ -192,7 +220,8 @@ def main():
             peak = PEAK_F32_MFMA_TFLOPS
             peak_basis = "fp32 MFMA (v_mfma_f32_32x32x2_f32) dense peak"
         line = {
-            "metric": "objects/sec forward (B=32, N=1028 pts)",
+            "metric": ("objects/sec forward (B=32, N=1028 pts)" if args.workload == "forward"
+                       else "objects/sec training step (forward + loss + backward + optimizer, B=%d, N=%d pts)" % (B, N_POINTS)),
             "value": round(world * B * args.steps / elapsed, 2),
             "unit": "objects/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -202,9 +231,11 @@ def main():
             "gemm_mode": {"split": "fp32-accurate 3xbf16 operand split on the bf16 matrix cores, fp32 accumulate",
                           "split16": "fp32-accurate 2xfp16 operand split on the fp16 matrix cores, fp32 accumulate",
                           "fp32": "fp32 MFMA"}[args.gemm],
-            "config": {"workload": "PoseNet9D.forward eval mode, full forward (kNN graphs + 3D-GCN encoder + PH predictor "
-                                   "+ decoder + R/t/s heads), B=%d objects per GPU, N=%d points, seeded random weights "
-                                   "of the reference architecture (27.43 M params)" % (B, N_POINTS),
+            "config": {"workload": ("PoseNet9D.forward eval mode, full forward (kNN graphs + 3D-GCN encoder + PH predictor "
+                                    "+ decoder + R/t/s heads), B=%d objects per GPU, N=%d points, seeded random weights "
+                                    "of the reference architecture (27.43 M params)" % (B, N_POINTS)) if args.workload == "forward"
+                       else ("training step: PoseNet9D training-mode forward with autograd, DCD Chamfer + pose + topology-code "
+                             "loss, backward, gradient all-reduce, clip, SGD; B=%d objects per GPU, N=%d points" % (B, N_POINTS)),
                        "objects_per_gpu": B, "points": N_POINTS, "replicas": world, "batches_in_flight": len(streams)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,

@@ -223,6 +223,49 @@ def gen_forward_train(name, B, N, wseed, pseed, fseed, steps=2):
     save(name, **arrays)
 
 
+def gen_backward(name, B, N, wseed, pseed, fseed):
+    """loss.backward() through the reference in training mode (dropout p = 0): loss = sum_k <out_k, w_k> with seeded random
+    weights w_k on every output tensor.  The fixture keeps, per parameter, the gradient's L2 norm, its sum and 16 evenly
+    spaced entries (the full gradients are 110 MB), plus the graphs and the subsample that produced them."""
+    sd = iw.seeded_state_dict(wseed)
+    net = RefPoseNet9D().train()
+    net.load_state_dict(sd, strict=True)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    pts, obj = synth_points(B, N, pseed)
+    knn_rec, nn_rec = [], []
+    o_knn, o_nn = ref_gcn.get_neighbor_index, ref_gcn.get_nearest_index
+    ref_gcn.get_neighbor_index = lambda v, k: (knn_rec.append(o_knn(v, k)), knn_rec[-1])[1]
+    ref_gcn.get_nearest_index = lambda t, s_: (nn_rec.append(o_nn(t, s_)), nn_rec[-1])[1]
+    try:
+        FLAGS.train = 1
+        torch.manual_seed(fseed)
+        out = net(pts, obj)
+    finally:
+        ref_gcn.get_neighbor_index, ref_gcn.get_nearest_index = o_knn, o_nn
+    gen = torch.Generator().manual_seed(fseed)
+    scale = dict(feat=1e-3, recon=1e-2, h1=1e-2, h2=1e-2, feat_global=1e-2)
+    keys = ["recon", "p_green_R", "p_red_R", "f_green_R", "f_red_R", "Pred_T", "Pred_s", "h1", "h2", "feat", "feat_global"]
+    weights = {k: torch.randn(out[k].shape, generator=gen) * scale.get(k, 1.0) for k in keys}
+    sum((out[k] * weights[k]).sum() for k in keys).backward()
+    names = ["conv_0.rf", "conv_0.orl_xyz", "conv_1.rf", "conv_1.orl_xyz", "pool_1.xyz", "conv_2.rf",
+             "conv_2.orl_xyz", "conv_3.rf", "conv_3.orl_xyz", "pool_2.xyz", "conv_4.rf", "conv_4.orl_xyz"]
+    i1, i2 = sample_indices(N, fseed)
+    arrays = dict(weight_seed=np.int64(wseed), forward_seed=np.int64(fseed), points=pts, obj_id=obj,
+                  sample_idx_1=small_idx(i1), sample_idx_2=small_idx(i2))
+    for n_, r in zip(names, knn_rec):
+        arrays["idx.face_all.encoder." + n_] = small_idx(r)
+    arrays["idx.face_all.encoder.up_1"], arrays["idx.face_all.encoder.up_2"] = small_idx(nn_rec[0]), small_idx(nn_rec[1])
+    for k, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        gflat = p.grad.reshape(-1)
+        pick = torch.linspace(0, gflat.numel() - 1, 16).long()
+        arrays["grad." + k] = torch.cat([gflat.norm().view(1), gflat.double().sum().float().view(1), gflat[pick]])
+    save(name, **arrays)
+
+
 # ----------------------------------------------------------------------------- Chamfer
 def gen_chamfer():
     g = torch.Generator().manual_seed(21)
@@ -339,6 +382,7 @@ def main():
     gen_forward("forward_b2_n1028.npz", 2, 1028, wseed=0, pseed=1, fseed=123)
     gen_forward("forward_b3_n256.npz", 3, 256, wseed=1, pseed=2, fseed=9, keep_feat_rows=96)
     gen_forward_train("forward_train_b4_n256.npz", 4, 256, wseed=2, pseed=5, fseed=31)
+    gen_backward("backward_b3_n256.npz", 3, 256, wseed=3, pseed=6, fseed=33)
     gen_chamfer()
 
 

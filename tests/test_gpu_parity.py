@@ -1172,3 +1172,27 @@ def test_pool_and_upsample_backward_vs_autograd(ops):
     assert torch.equal(up.detach().cpu(), up_ref.detach())
     (up * g(w)).sum().backward()
     assert torch.allclose(fg.grad.cpu(), fr.grad, atol=1e-5, rtol=1e-5)
+
+
+def test_backward_vs_reference_golden(ops):
+    """loss.backward() through the HIP path against the gradients of the REFERENCE run in training mode (fixture from
+    tests/golden/make_golden.py: norm, sum and 16 samples of every parameter's gradient).  Relative L2-norm agreement 3 %,
+    the samples within 3 % of the gradient's norm (see test_backward_full_network_vs_oracle_autograd for why not tighter)."""
+    from tgpose_amd import FLAGS
+    from tests.test_oracle_golden import golden_backward_case, grad_summary
+    gd, pts, obj, sample, inj, weights = golden_backward_case()
+    net = _train_net(int(gd["weight_seed"]))
+    FLAGS.train = 1
+    try:
+        out = net(g(pts), g(obj), sample_idx=sample, inject={k: v.int() for k, v in inj.items()})
+    finally:
+        FLAGS.train = 0
+    sum((out[k] * g(weights[k])).sum() for k in weights).backward()
+    params = dict(net.named_parameters())
+    for k in gd.files:
+        if not k.startswith("grad."):
+            continue
+        got, want = grad_summary(params[k[5:]].grad.cpu()).numpy(), gd[k]
+        scale = max(abs(want[0]), GRAD_ATOL)
+        assert abs(got[0] - want[0]) <= GRAD_TOL * scale, (k, got[0], want[0])
+        assert np.abs(got[2:] - want[2:]).max() <= GRAD_TOL * scale, (k, got[2:6], want[2:6])

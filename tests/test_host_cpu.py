@@ -152,3 +152,42 @@ def test_object_sharding_two_ranks_gloo():
     assert (lo0, hi0, lo1, hi1) == (0, 34, 34, 67)
     assert t0 == t1 == 1.5
     assert g0 == [float(i) for i in range(67)] and g1 is None
+
+
+def _grad_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tgpose_amd import shard
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in ((300, 7), (5,), (64, 64), (1000,), (3, 3))]
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float(rank + 1)) * (i + 1) + torch.arange(p.numel(), dtype=torch.float32).view_as(p) * 1e-3
+    params[1].grad = None                                  # an unused parameter is skipped, not sent
+    n = shard.allreduce_gradients(params, bucket_bytes=8192)
+    q.put((rank, n, [None if p.grad is None else p.grad.clone() for p in params]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_two_ranks_gloo():
+    """Data-parallel training step: after the exchange every rank holds the mean of the ranks' gradients, bucketed."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, n0, g0), (_, n1, g1) = res
+    assert n0 == n1 and n0 >= 2                            # 8 KB buckets: several messages
+    for i, (a, b) in enumerate(zip(g0, g1)):
+        if i == 1:
+            assert a is None and b is None
+            continue
+        want = torch.full_like(a, 1.5) * (i + 1) + torch.arange(a.numel(), dtype=torch.float32).view_as(a) * 1e-3
+        assert torch.allclose(a, want) and torch.equal(a, b)

@@ -149,6 +149,43 @@ def test_forward_training_mode_vs_reference(mode, inject):
         assert np.allclose(sd[k[3:]].numpy(), g[k], atol=1e-5, rtol=1e-5), k
 
 
+def golden_backward_case():
+    g = golden("backward_b3_n256.npz")
+    seed = int(g["forward_seed"])
+    pts, obj = torch.from_numpy(g["points"]), torch.from_numpy(g["obj_id"])
+    sample = (torch.from_numpy(g["sample_idx_1"].astype(np.int64)), torch.from_numpy(g["sample_idx_2"].astype(np.int64)))
+    inj = {k[4:]: torch.from_numpy(g[k].astype(np.int64)) for k in g.files if k.startswith("idx.")}
+    gen = torch.Generator().manual_seed(seed)
+    scale = dict(feat=1e-3, recon=1e-2, h1=1e-2, h2=1e-2, feat_global=1e-2)
+    keys = ["recon", "p_green_R", "p_red_R", "f_green_R", "f_red_R", "Pred_T", "Pred_s", "h1", "h2", "feat", "feat_global"]
+    shapes = dict(recon=(3, 256, 3), p_green_R=(3, 3), p_red_R=(3, 3), f_green_R=(3,), f_red_R=(3,), Pred_T=(3, 3), Pred_s=(3, 3),
+                  h1=(3, 2500), h2=(3, 2500), feat=(3, 256, 1286), feat_global=(3, 1286))
+    weights = {k: torch.randn(shapes[k], generator=gen) * scale.get(k, 1.0) for k in keys}    # same draws as make_golden.py
+    return g, pts, obj, sample, inj, weights
+
+
+def grad_summary(gflat):
+    gflat = gflat.reshape(-1)
+    pick = torch.linspace(0, gflat.numel() - 1, 16).long()
+    return torch.cat([gflat.norm().view(1), gflat.double().sum().float().view(1), gflat[pick]])
+
+
+def test_backward_oracle_autograd_vs_reference():
+    """torch autograd through the oracle's training-mode forward against loss.backward() through the reference itself
+    (fixture: per-parameter gradient norm, sum and 16 samples), same graphs, same loss weights."""
+    g, pts, obj, sample, inj, weights = golden_backward_case()
+    sd = seeded_state_dict(int(g["weight_seed"]))
+    P = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running_" not in k else v.clone()) for k, v in sd.items()}
+    out = PR.posenet_forward(P, pts, obj, sample_idx=sample, train_keys=True, mode="exact", inject=inj, bn_train=True)
+    out.pop("_bn_new")
+    sum((out[k] * weights[k]).sum() for k in weights).backward()
+    keys = [k for k in g.files if k.startswith("grad.")]
+    assert len(keys) == 103
+    for k in keys:
+        got, want = grad_summary(P[k[5:]].grad).numpy(), g[k]
+        assert np.allclose(got, want, rtol=2e-3, atol=2e-4 * max(1.0, abs(want[0]))), (k, got[:3], want[:3])
+
+
 def test_chamfer_vs_reference_unit_test_rule():
     """losses/metrics/CD/unit_test.py:22-33: mean squared distance error < 1e-8, indices identical."""
     g = golden("chamfer.npz")

@@ -41,3 +41,38 @@ def gather_rows_to_rank0(rows, total, device):
     if rank != 0:
         return None
     return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(out, sizes)], dim=0)
+
+
+# ------------------------------------------------------------------------------------------------- training
+def allreduce_gradients(params, bucket_bytes=64 << 20, average=True):
+    """Data-parallel gradient exchange (BASELINE config 4): every rank holds the gradients of its
+    own shard of the objects; sum (or average) them over the ranks so that all replicas take the same optimizer step.
+
+    The 27.43 M fp32 gradients (109.7 MB) go out in a few large buckets -- xGMI is point to point, so RCCL's ring
+    all-reduce is bound per link and wants few, large messages rather than one collective per tensor.  Buckets follow the
+    reverse parameter order (the order backward produces them).  Call after loss.backward() and BEFORE
+    clip_grad_norm_ (trainer/RL_TDA.py:223 clips the gradients the optimizer will see: the averaged ones).
+    Returns the number of buckets sent.  Single process / uninitialised process group: no-op."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    world = dist.get_world_size()
+    grads = [p.grad for p in reversed(list(params)) if p.grad is not None]
+    buckets, cur, size = [], [], 0
+    for g in grads:
+        cur.append(g)
+        size += g.numel() * g.element_size()
+        if size >= bucket_bytes:
+            buckets.append(cur)
+            cur, size = [], 0
+    if cur:
+        buckets.append(cur)
+    for b in buckets:
+        flat = torch.cat([g.reshape(-1) for g in b])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if average:
+            flat.div_(world)
+        o = 0
+        for g in b:
+            g.copy_(flat[o:o + g.numel()].view_as(g))
+            o += g.numel()
+    return len(buckets)
