@@ -81,6 +81,93 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float *__restrict__ 
         }
 }
 
+// The same product with the row slabs staged through LDS (aligned operands: lda, ldb, N, K multiples of 4, 16-byte aligned
+// bases): 16 rows x 128 columns of A and of B per step, loaded once per workgroup with 16-byte lane loads (the direct form
+// above re-reads every operand element per wave and is bound by the L1), double buffered.  The MFMA operand reads are
+// ds_read_b32 of 32 consecutive floats per half wave: conflict free.
+#define TN_ROWS 16
+
+__global__ __launch_bounds__(256) void gemm_tn_lds_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                                                          int64_t rows, int N, int K, int64_t rows_per_slice,
+                                                          float *__restrict__ C, int ldc, int64_t slice_stride)
+{
+    __shared__ __attribute__((aligned(16))) float sa[2][TN_ROWS][TN_TILE];
+    __shared__ __attribute__((aligned(16))) float sb[2][TN_ROWS][TN_TILE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const int n0 = blockIdx.y * TN_TILE, k0 = blockIdx.x * TN_TILE;
+    const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+    const int64_t m0 = (int64_t)blockIdx.z * rows_per_slice;
+    const int64_t m1 = m0 + rows_per_slice < rows ? m0 + rows_per_slice : rows;
+    // staging: thread -> (row r and r + 8, float4 column c4)
+    const int r = tid >> 5, c4 = (tid & 31) * 4;
+    const bool a_ok = n0 + c4 < N, b_ok = k0 + c4 < K;      // N, K multiples of 4: a quad is wholly inside or outside
+    const float *ap = A + (a_ok ? n0 + c4 : 0), *bp = B + (b_ok ? k0 + c4 : 0);
+    float4 ra[2], rb[2];
+    auto load = [&](int64_t m) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int64_t row = m + r + 8 * t;
+            const int64_t rc = row < m1 ? row : m1 - 1;
+            const float4 av = *reinterpret_cast<const float4 *>(ap + rc * lda);
+            const float4 bv = *reinterpret_cast<const float4 *>(bp + rc * ldb);
+            const float fa = (row < m1 && a_ok) ? 1.f : 0.f, fb = (row < m1 && b_ok) ? 1.f : 0.f;
+            // multiply by a 0/1 mask instead of selecting: keeps the loads free of branches (and of early waits)
+            ra[t] = make_float4(av.x * fa, av.y * fa, av.z * fa, av.w * fa);
+            rb[t] = make_float4(bv.x * fb, bv.y * fb, bv.z * fb, bv.w * fb);
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            *reinterpret_cast<float4 *>(&sa[buf][r + 8 * t][c4]) = ra[t];
+            *reinterpret_cast<float4 *>(&sb[buf][r + 8 * t][c4]) = rb[t];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[x][y][e] = 0.f;
+
+    load(m0);
+    store(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t m = m0; m < m1; m += TN_ROWS) {
+        const bool more = m + TN_ROWS < m1;
+        if (more) load(m + TN_ROWS);
+#pragma unroll
+        for (int u = 0; u < TN_ROWS / 2; ++u) {
+            float a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[t] = sa[buf][2 * u + kk][wn + 32 * t + i], b[t] = sb[buf][2 * u + kk][wk + 32 * t + i];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+        }
+        if (more) store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float *out = C + (int64_t)blockIdx.z * slice_stride;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const int col = k0 + wk + 32 * y + i;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = n0 + wn + 32 * x + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                if (row < N && col < K) out[(int64_t)row * ldc + col] = acc[x][y][e];
+            }
+        }
+}
+
 // out[n][k] (+)= sum over slices, in slice order
 __global__ void gemm_tn_reduce_kernel(const float *__restrict__ part, int slices, int64_t slice_stride, int N, int K,
                                       float *__restrict__ out, int ldo, int accumulate)
@@ -118,8 +205,12 @@ extern "C" int tgp_gemm_tn_f32(const float *A, int lda, const float *B, int ldb,
     per = (per + 2 * TN_UNROLL - 1) / (2 * TN_UNROLL) * (2 * TN_UNROLL);
     const int used = (int)tgp_cdiv(rows, per);
     const int64_t stride = (int64_t)N * K;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tgp_cdiv(K, TN_TILE), tgp_cdiv(N, TN_TILE), used), dim3(256), 0, tgp_hs(stream), A,
-                       lda, B, ldb, rows, N, K, per, workspace, K, stride);
+    const bool aligned = !((lda | ldb | N | K) & 3) && !((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15);
+    const dim3 grid(tgp_cdiv(K, TN_TILE), tgp_cdiv(N, TN_TILE), used);
+    if (aligned)
+        hipLaunchKernelGGL(gemm_tn_lds_kernel, grid, dim3(256), 0, tgp_hs(stream), A, lda, B, ldb, rows, N, K, per, workspace, K, stride);
+    else
+        hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, tgp_hs(stream), A, lda, B, ldb, rows, N, K, per, workspace, K, stride);
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(tgp_cdiv(stride, (int64_t)256)), dim3(256), 0, tgp_hs(stream), workspace, used,
                        stride, N, K, C, ldc, accumulate);
     return TGP_LAUNCH_RESULT();
@@ -149,7 +240,8 @@ __global__ __launch_bounds__(256) void bw_partial_kernel(const float *__restrict
     if (c < C) {
         float mu = 0.f, inv = 0.f, g = 0.f, b = 0.f, sl = 0.f;
         if (MODE == 1) mu = mean[c], inv = 1.0f / sqrtf(var[c] + eps), g = gamma[c], b = beta[c], sl = slope_vec ? slope_vec[c] : slope;
-        for (int64_t r = r0 + slice; r < r1; r += 4) {
+#pragma unroll 8
+    for (int64_t r = r0 + slice; r < r1; r += 4) {
             float d = dy[r * lddy + c];
             if (MODE == 1) {
                 const float xh = (x[r * ld + c] - mu) * inv;
@@ -208,6 +300,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
     const float m1 = s1[c] * inv_n, m2 = s2[c] * inv_n, scale = g * inv;
     const int64_t r0 = (int64_t)blockIdx.y * BW_CHUNK;
     const int64_t r1 = r0 + BW_CHUNK < rows ? r0 + BW_CHUNK : rows;
+#pragma unroll 8
     for (int64_t r = r0 + slice; r < r1; r += 4) {
         const float xh = (x[r * ld + c] - mu) * inv;
         const float dz = dy[r * lddy + c] * act_grad(xh * g + b, act, sl);
@@ -278,6 +371,7 @@ __global__ __launch_bounds__(256) void bn_bwd_pooled_apply_kernel(const float *_
     const float m1 = s1[c] * inv_n, m2 = s2[c] * inv_n, scale = g * inv;
     const int64_t r0 = (int64_t)blockIdx.y * BW_CHUNK;
     const int64_t r1 = r0 + BW_CHUNK < rows ? r0 + BW_CHUNK : rows;
+#pragma unroll 8
     for (int64_t r = r0 + slice; r < r1; r += 4) {
         const float xh = (x[r * ld + c] - mu) * inv;
         const int64_t o = r / rows_per_obj;

@@ -23,7 +23,8 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
     float acc = 0.f;
     if (c < C) {
         const float mu = center ? center[c] : 0.f;
-        for (int64_t r = r0 + slice; r < r1; r += 4) {
+#pragma unroll 8
+    for (int64_t r = r0 + slice; r < r1; r += 4) {
             const float d = x[r * ld + c] - mu;
             acc += SQUARE ? d * d : d;
         }
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
     const bool do_cm = cm && c < cm_cols;
     uint32_t run_key = 0;
     int64_t run_obj = -1;
+#pragma unroll 8
     for (int64_t r = r0 + slice; r < r1; r += 4) {
         float v = (x[r * ld + c] - mu) * a + b;
         if (act == 1) v = v > 0.f ? v : v * sl;

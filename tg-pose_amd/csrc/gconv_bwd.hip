@@ -9,6 +9,7 @@
 #define GB_S 7
 #define GB_PTS 16   // points per workgroup and channel lane
 #define GB_MAXK 64
+#define GB_GROUP 32  // partials summed per workgroup in the first reduction level
 
 // thread -> (channel c, point stream): blockDim 256; C <= 256: 256 / C point streams per workgroup
 struct GbMap {
@@ -46,33 +47,56 @@ __global__ __launch_bounds__(256) void gconv_bwd_kernel(const float *__restrict_
 #pragma unroll
         for (int a = 0; a < 3; ++a) D[s][a] = c < C ? sdn[a * SC + s * C + c] : 0.f, dD[s][a] = 0.f;
 
+    // neighbour ids and unit directions of the workgroup's points, once, into LDS: the per-channel loops below then depend
+    // on global memory only for the support rows (independent loads the compiler can keep in flight)
+    __shared__ int s_nb[2 * GB_PTS][GB_MAXK];
+    __shared__ float s_dir[2 * GB_PTS][GB_MAXK][3];
+    {
+        const int pts = GB_PTS * mp.streams;
+        const int base = tile * pts;
+        for (int e = threadIdx.x; e < pts * k; e += 256) {
+            const int lp = e / k, j = e - lp * k;
+            const int i = base + lp;
+            int nb = 0;
+            float ux = 0.f, uy = 0.f, uz = 0.f;
+            if (i < n) {
+                const int64_t rowi = (int64_t)b * n + i;
+                nb = idx[rowi * k + j];
+                const int64_t rown = (int64_t)b * n + nb;
+                ux = xyz[rown * 3] - xyz[rowi * 3], uy = xyz[rown * 3 + 1] - xyz[rowi * 3 + 1], uz = xyz[rown * 3 + 2] - xyz[rowi * 3 + 2];
+                const float nrm = fmaxf(sqrtf((ux * ux + uy * uy) + uz * uz), 1e-12f);
+                ux = ux / nrm, uy = uy / nrm, uz = uz / nrm;
+            }
+            s_nb[lp][j] = nb;
+            s_dir[lp][j][0] = ux, s_dir[lp][j][1] = uy, s_dir[lp][j][2] = uz;
+        }
+        __syncthreads();
+    }
     const int p0 = (tile * mp.streams + mp.stream) * GB_PTS;
     for (int pp = 0; pp < GB_PTS; ++pp) {
         const int i = p0 + pp;
         if (i >= n || c >= C) break;
+        const int lp = mp.stream * GB_PTS + pp;
         const int64_t rowi = (int64_t)b * n + i;
         const float g = dg[rowi * ldg + c] / 7.0f;
-        const float cx = xyz[rowi * 3], cy = xyz[rowi * 3 + 1], cz = xyz[rowi * 3 + 2];
-        float best[GB_S], bth[GB_S], bsup[GB_S], bdir[GB_S][3];
-        int barg[GB_S];
+        float best[GB_S], bth[GB_S], bsup[GB_S];
+        int barg[GB_S], bj[GB_S];
 #pragma unroll
-        for (int s = 0; s < GB_S; ++s) best[s] = SURFACE ? 0.f : -INFINITY, barg[s] = -1, bth[s] = 0.f, bsup[s] = 0.f;
+        for (int s = 0; s < GB_S; ++s) best[s] = SURFACE ? 0.f : -INFINITY, barg[s] = -1, bj[s] = 0, bth[s] = 0.f, bsup[s] = 0.f;
+#pragma unroll 4
         for (int j = 0; j < k; ++j) {
-            const int nb = idx[rowi * k + j];
+            const int nb = s_nb[lp][j];
             const int64_t rown = (int64_t)b * n + nb;
-            float ux = xyz[rown * 3] - cx, uy = xyz[rown * 3 + 1] - cy, uz = xyz[rown * 3 + 2] - cz;
-            const float nrm = fmaxf(sqrtf((ux * ux + uy * uy) + uz * uz), 1e-12f);
-            ux = ux / nrm, uy = uy / nrm, uz = uz / nrm;
+            const float ux = s_dir[lp][j][0], uy = s_dir[lp][j][1], uz = s_dir[lp][j][2];
+            float sup[GB_S];
+#pragma unroll
+            for (int s = 0; s < GB_S; ++s) sup[s] = SURFACE ? 1.f : proj[rown * ldp + C + s * C + c];
 #pragma unroll
             for (int s = 0; s < GB_S; ++s) {
                 float th = fmaf(uz, D[s][2], fmaf(uy, D[s][1], ux * D[s][0]));   // same expression as the forward kernel
                 th = fmaxf(th, 0.f);
-                const float sup = SURFACE ? 1.f : proj[rown * ldp + C + s * C + c];
-                const float v = SURFACE ? th : th * sup;
-                if (v > best[s]) {      // first maximum wins, as torch.max
-                    best[s] = v, barg[s] = nb, bth[s] = th, bsup[s] = sup;
-                    bdir[s][0] = ux, bdir[s][1] = uy, bdir[s][2] = uz;
-                }
+                const float v = SURFACE ? th : th * sup[s];
+                if (v > best[s]) best[s] = v, barg[s] = nb, bj[s] = j, bth[s] = th, bsup[s] = sup[s];   // first maximum wins
             }
         }
         if (!SURFACE) unsafeAtomicAdd(dproj + rowi * lddp + c, dg[rowi * ldg + c]);
@@ -82,7 +106,7 @@ __global__ __launch_bounds__(256) void gconv_bwd_kernel(const float *__restrict_
             if (!SURFACE && bth[s] != 0.f) unsafeAtomicAdd(dproj + ((int64_t)b * n + barg[s]) * lddp + C + s * C + c, g * bth[s]);
             if (bth[s] > 0.f) {
                 const float dth = SURFACE ? g : g * bsup[s];
-                dD[s][0] += dth * bdir[s][0], dD[s][1] += dth * bdir[s][1], dD[s][2] += dth * bdir[s][2];
+                dD[s][0] += dth * s_dir[lp][bj[s]][0], dD[s][1] += dth * s_dir[lp][bj[s]][1], dD[s][2] += dth * s_dir[lp][bj[s]][2];
             }
         }
     }
@@ -95,13 +119,17 @@ __global__ __launch_bounds__(256) void gconv_bwd_kernel(const float *__restrict_
     }
 }
 
-__global__ void partial_sum_kernel(const float *__restrict__ partial, int64_t parts, int64_t width, float *__restrict__ out)
+// out[group][t] = sum of up to `group_size` consecutive parts (fixed order): run twice for a two-level deterministic sum
+__global__ void partial_sum_kernel(const float *__restrict__ partial, int64_t parts, int64_t width, int64_t group_size,
+                                   float *__restrict__ out)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= width) return;
+    const int64_t q0 = (int64_t)blockIdx.y * group_size;
+    const int64_t q1 = q0 + group_size < parts ? q0 + group_size : parts;
     float s = 0.f;
-    for (int64_t q = 0; q < parts; ++q) s += partial[q * width + t];
-    out[t] = s;
+    for (int64_t q = q0; q < q1; ++q) s += partial[q * width + t];
+    out[(int64_t)blockIdx.y * width + t] = s;
 }
 
 static int64_t gb_parts(int B, int n, int C)
@@ -114,7 +142,8 @@ static int64_t gb_parts(int B, int n, int C)
 extern "C" int64_t tgp_gconv_bwd_workspace_floats(int B, int n, int C)
 {
     if (B <= 0 || n <= 0 || C <= 0) return 0;
-    return gb_parts(B, n, C) * 3 * GB_S * C;
+    const int64_t parts = gb_parts(B, n, C);
+    return (parts + tgp_cdiv(parts, (int64_t)GB_GROUP)) * 3 * GB_S * C;
 }
 
 static int gconv_bwd_launch(bool surface, const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn,
@@ -135,9 +164,13 @@ static int gconv_bwd_launch(bool surface, const float *xyz, const int32_t *idx, 
     else
         hipLaunchKernelGGL(gconv_bwd_kernel<false>, grid, dim3(256), 0, stream, xyz, idx, proj, ldp, sdn, dg, ldg, B, n, k, C, dproj,
                            lddp, workspace);
-    const int64_t width = 3 * (int64_t)GB_S * C;
-    hipLaunchKernelGGL(partial_sum_kernel, dim3(tgp_cdiv(width, (int64_t)256)), dim3(256), 0, stream, workspace, gb_parts(B, n, C),
-                       width, dsdn);
+    const int64_t width = 3 * (int64_t)GB_S * C, parts = gb_parts(B, n, C);
+    const int groups = tgp_cdiv(parts, (int64_t)GB_GROUP);
+    float *level2 = workspace + parts * width;
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(tgp_cdiv(width, (int64_t)256), groups), dim3(256), 0, stream, workspace, parts,
+                       width, (int64_t)GB_GROUP, level2);
+    hipLaunchKernelGGL(partial_sum_kernel, dim3(tgp_cdiv(width, (int64_t)256), 1), dim3(256), 0, stream, level2, (int64_t)groups,
+                       width, (int64_t)groups, dsdn);
     return TGP_LAUNCH_RESULT();
 }
 
