@@ -306,6 +306,14 @@ int tgp_nbrmax_bwd(const float *src, int ld_src, const int32_t *idx, int B, int 
 int tgp_gather_rows_bwd(const float *dy, int lddy, const int32_t *idx, int B, int n_src, int n_out, int C, float *dsrc,
                         int ld_dsrc, tgp_stream_t stream);
 
+/* Differentiable half of TDA_loss.R_DCD's canonicalisation (losses/TDA_loss_sym_recon.py:334-337):
+ * out[b][i] = (R[b]^T (points[b][i] - t[b])) * s[b]; R (B,3,3) row-major, t, s (B,3).  The backward returns dpoints (may be
+ * NULL), dR, dt, ds (per-object sums over the n points, fixed order). */
+int tgp_pose_transform_fwd(const float *points, const float *R, const float *t, const float *s, int B, int n, float *out,
+                           tgp_stream_t stream);
+int tgp_pose_transform_bwd(const float *points, const float *R, const float *t, const float *s, const float *dout, int B, int n,
+                           float *dpoints, float *dR, float *dt, float *ds, tgp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

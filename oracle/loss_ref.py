@@ -12,8 +12,15 @@ from . import _clib
 
 
 def chamfer(pred, gt):
+    """Chamfer search by the C oracle.  When an input requires grad the distances are re-expressed through the found
+    indices with torch ops (d1 = |pred - gt[idx1]|^2), which gives exactly the gradient the reference's Chamfer backward
+    scatters (chamfer3D.cu:155-195) and lets torch autograd differentiate the losses built on top."""
     d1, d2, i1, i2 = _clib.chamfer_fwd(pred.detach().numpy(), gt.detach().numpy())
-    return torch.from_numpy(d1), torch.from_numpy(d2), torch.from_numpy(i1.astype(np.int64)), torch.from_numpy(i2.astype(np.int64))
+    i1, i2 = torch.from_numpy(i1.astype(np.int64)), torch.from_numpy(i2.astype(np.int64))
+    if pred.requires_grad or gt.requires_grad:
+        take = lambda src, idx: torch.gather(src, 1, idx.unsqueeze(-1).expand(-1, -1, 3))
+        return ((pred - take(gt, i1)) ** 2).sum(-1), ((gt - take(pred, i2)) ** 2).sum(-1), i1, i2
+    return torch.from_numpy(d1), torch.from_numpy(d2), i1, i2
 
 
 def calc_cd(pred, gt):

@@ -1196,3 +1196,23 @@ def test_backward_vs_reference_golden(ops):
         scale = max(abs(want[0]), GRAD_ATOL)
         assert abs(got[0] - want[0]) <= GRAD_TOL * scale, (k, got[0], want[0])
         assert np.abs(got[2:] - want[2:]).max() <= GRAD_TOL * scale, (k, got[2:6], want[2:6])
+
+
+def test_r_dcd_gradients_vs_oracle_autograd(ops):
+    """TDA_loss.R_DCD end to end with gradients: d/d(recon, axes, confidences, translation, size) against torch autograd of
+    the CPU oracle (loss_ref.r_dcd, itself pinned to the reference's value by tests/golden/dcd.npz)."""
+    from oracle import loss_ref as L
+    from tgpose_amd.losses import dcd as D
+    gd = golden("dcd.npz")
+    names = ("recon", "p_g", "f_g", "p_r", "f_r", "t", "s")
+    cpu = {k: torch.from_numpy(gd[k]).clone().requires_grad_(True) for k in names}
+    fix = {k: torch.from_numpy(gd[k]) for k in ("prior", "gR", "sym")}
+    ref = L.r_dcd(fix["prior"], cpu["recon"], fix["gR"], cpu["p_g"], cpu["f_g"], cpu["p_r"], cpu["f_r"], cpu["t"], cpu["s"], fix["sym"])
+    ref.backward()
+    dev = {k: g(gd[k]).clone().requires_grad_(True) for k in names}
+    val = D.R_DCD(g(gd["prior"]), dev["recon"], g(gd["gR"]), dev["p_g"], dev["f_g"], dev["p_r"], dev["f_r"], dev["t"], dev["s"], g(gd["sym"]))
+    assert abs(val.item() - ref.item()) < 2e-6 and abs(val.item() - float(gd["r_dcd"])) < 2e-6
+    val.backward()
+    for k in names:
+        a, r = dev[k].grad.cpu(), cpu[k].grad
+        assert torch.allclose(a, r, atol=2e-6 + 1e-4 * r.abs().max().item(), rtol=1e-4), (k, (a - r).abs().max().item(), r.abs().max().item())

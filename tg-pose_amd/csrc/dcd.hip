@@ -220,3 +220,81 @@ extern "C" int tgp_generate_rt(const float *p_green, const float *p_red, const f
                        sym, sym_ld, B, rt);
     return TGP_LAUNCH_RESULT();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Differentiable half of R_DCD's canonicalisation (TDA_loss_sym_recon.py:334-337): out = (R^T (p - t)) * s per object,
+// with R (B,3,3), t (B,3), s (B,3) given (the (B,3)-sized axis arithmetic that builds R stays with the caller).
+__global__ __launch_bounds__(256) void pose_transform_kernel(const float *__restrict__ points, const float *__restrict__ R,
+                                                             const float *__restrict__ t, const float *__restrict__ s, int n,
+                                                             float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *Rb = R + b * 9;
+    const float *pt = points + ((size_t)b * n + i) * 3;
+    const float d0 = pt[0] - t[b * 3], d1 = pt[1] - t[b * 3 + 1], d2 = pt[2] - t[b * 3 + 2];
+    float *o = out + ((size_t)b * n + i) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = ((Rb[k] * d0 + Rb[3 + k] * d1) + Rb[6 + k] * d2) * s[b * 3 + k];
+}
+
+extern "C" int tgp_pose_transform_fwd(const float *points, const float *R, const float *t, const float *s, int B, int n, float *out,
+                                      tgp_stream_t stream)
+{
+    TGP_REQUIRE(points && R && t && s && out && B > 0 && n > 0);
+    hipLaunchKernelGGL(pose_transform_kernel, dim3(tgp_cdiv(n, 256), B), dim3(256), 0, tgp_hs(stream), points, R, t, s, n, out);
+    return TGP_LAUNCH_RESULT();
+}
+
+// backward: g = dout * s;  dpoints = R g;  dt = -sum_i R g_i;  dR[j][k] = sum_i d_j g_k;  ds_k = sum_i (R^T d)_k dout_k.
+// One workgroup per object; the 15 sums are reduced in LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void pose_transform_bwd_kernel(const float *__restrict__ points, const float *__restrict__ R,
+                                                                 const float *__restrict__ t, const float *__restrict__ s,
+                                                                 const float *__restrict__ dout, int n, float *__restrict__ dpoints,
+                                                                 float *__restrict__ dR, float *__restrict__ dt, float *__restrict__ ds)
+{
+    __shared__ float red[15][256];
+    const int b = blockIdx.x;
+    const float *Rb = R + b * 9;
+    float acc[15];
+#pragma unroll
+    for (int q = 0; q < 15; ++q) acc[q] = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const size_t o = ((size_t)b * n + i) * 3;
+        const float d[3] = {points[o] - t[b * 3], points[o + 1] - t[b * 3 + 1], points[o + 2] - t[b * 3 + 2]};
+        float g[3], rd[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            g[k] = dout[o + k] * s[b * 3 + k];
+            rd[k] = (Rb[k] * d[0] + Rb[3 + k] * d[1]) + Rb[6 + k] * d[2];
+            acc[12 + k] += rd[k] * dout[o + k];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float dp = (Rb[3 * j] * g[0] + Rb[3 * j + 1] * g[1]) + Rb[3 * j + 2] * g[2];
+            if (dpoints) dpoints[o + j] = dp;
+            acc[9 + j] -= dp;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[3 * j + k] += d[j] * g[k];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 15; ++q) red[q][threadIdx.x] = acc[q];
+    __syncthreads();
+    if (threadIdx.x < 15) {
+        float v = 0.f;
+        for (int l = 0; l < 256; ++l) v += red[threadIdx.x][l];
+        if (threadIdx.x < 9) dR[b * 9 + threadIdx.x] = v;
+        else if (threadIdx.x < 12) dt[b * 3 + threadIdx.x - 9] = v;
+        else ds[b * 3 + threadIdx.x - 12] = v;
+    }
+}
+
+extern "C" int tgp_pose_transform_bwd(const float *points, const float *R, const float *t, const float *s, const float *dout, int B,
+                                      int n, float *dpoints, float *dR, float *dt, float *ds, tgp_stream_t stream)
+{
+    TGP_REQUIRE(points && R && t && s && dout && dR && dt && ds && B > 0 && n > 0);
+    hipLaunchKernelGGL(pose_transform_bwd_kernel, dim3(B), dim3(256), 0, tgp_hs(stream), points, R, t, s, dout, n, dpoints, dR, dt, ds);
+    return TGP_LAUNCH_RESULT();
+}

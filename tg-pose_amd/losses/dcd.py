@@ -1,11 +1,13 @@
 """Drop-in for the Chamfer-based pieces of ``losses/TDA_loss_sym_recon.py`` on the HIP kernels:
-``calc_cd`` (:495-509), ``calc_dcd`` (:411-450) and the forward value of ``TDA_loss.R_DCD`` (:326-342).
+``calc_cd`` (:495-509), ``calc_dcd`` (:411-450) and ``TDA_loss.R_DCD`` (:326-342), all differentiable.
 
 ``calc_dcd`` is differentiable w.r.t. the predicted cloud exactly as the reference is: the density weights are
 detached, the gradient flows through exp(-alpha d) into the Chamfer backward (``tgp_dcd_bwd`` ->
 ``tgp_chamfer_bwd``).  The reference's Python loop over the batch with ``torch.bincount`` per sample becomes one
 launch with one workgroup per object.
 """
+import math
+
 import torch
 from torch.autograd import Function
 
@@ -65,11 +67,53 @@ def calc_dcd(pred_recon, cate_gt, alpha=0.1, n_lambda=0.3, return_raw=False, non
     return loss
 
 
+class _PoseTransform(Function):
+    """(R^T (points - t)) * s with gradients for all four inputs (HIP forward and backward)"""
+
+    @staticmethod
+    def forward(ctx, points, R, t, s):
+        ctx.save_for_backward(points, R, t, s)
+        return ops.pose_transform(points, R, t, s)
+
+    @staticmethod
+    def backward(ctx, dout):
+        points, R, t, s = ctx.saved_tensors
+        dp, dR, dt, ds = ops.pose_transform_bwd(points, R, t, s, dout, need_points=ctx.needs_input_grad[0])
+        return dp, dR, dt, ds
+
+
+def _rodrigues(k, angle, v):
+    """v rotated about the unit axis k by `angle` (the matrix of to_rot_matrix_in_batch applied to v)"""
+    c, s_ = torch.cos(angle), torch.sin(angle)
+    return v * c + torch.cross(k, v, dim=-1) * s_ + k * (k * v).sum(-1, keepdim=True) * (1 - c)
+
+
+def _vertical_axes(c1, c2, y, z):
+    """get_vertical_rot_vec_in_batch (TDA_loss_sym_recon.py:370-395) on (B,3) tensors: rotate y and z about their common
+    normal until they are perpendicular, sharing the correction in proportion to the other axis' confidence"""
+    c1, c2 = c1.unsqueeze(-1), c2.unsqueeze(-1)
+    k = torch.cross(y, z, dim=-1)
+    k = k / (torch.norm(k, dim=-1, keepdim=True) + 1e-8)
+    theta = torch.acos(torch.clamp((y * z).sum(-1, keepdim=True), -1 + 1e-6, 1 - 1e-6)) - math.pi / 2
+    return _rodrigues(k, c2 / (c1 + c2) * theta, y), _rodrigues(k, -(c1 / (c1 + c2)) * theta, z)
+
+
+def pose_rotation(g_R, p_g_vec, f_g_vec, p_r_vec, f_r_vec, sym):
+    """The rotation R_DCD canonicalises with (TDA_loss_sym_recon.py:327-333, get_rot_mat_y_first :351-360): (B,3,3),
+    differentiable w.r.t. the predicted axes and confidences ((B,3)-sized torch arithmetic)."""
+    ys, xs = _vertical_axes(f_g_vec, torch.full_like(f_g_vec, 1e-5), p_g_vec, g_R[..., 0])
+    y, x = _vertical_axes(f_g_vec, f_r_vec, p_g_vec, p_r_vec)
+    flag = sym[:, 0].unsqueeze(-1) == 1
+    y, x = torch.where(flag, ys, y), torch.where(flag, xs, x)
+    y = torch.nn.functional.normalize(y, dim=-1)
+    z = torch.nn.functional.normalize(torch.cross(x, y, dim=-1), dim=-1)
+    return torch.stack((torch.cross(y, z, dim=-1), y, z), dim=-1)
+
+
 def R_DCD(cate_ori, points, g_R, p_g_vec, f_g_vec, p_r_vec, f_r_vec, p_t, p_s, sym):
-    """Forward value of TDA_loss.R_DCD: canonicalise the reconstruction with the predicted pose, density-aware
-    Chamfer against the category prior (alpha 70, lambda 0.3), mean over the batch.  No gradient w.r.t. the pose
-    inputs in this round (the canonicalisation kernel is forward-only)."""
-    with torch.no_grad():
-        canon, _ = ops.canonicalize(points.float(), g_R.float(), p_g_vec.float(), f_g_vec.float(), p_r_vec.float(),
-                                    f_r_vec.float(), p_t.float(), p_s.float(), sym.float())
-        return torch.mean(calc_dcd(canon, cate_ori, alpha=70, n_lambda=0.3, return_raw=False, non_reg=False))
+    """TDA_loss.R_DCD (:326-342): canonicalise the reconstruction with the predicted pose, density-aware Chamfer against the
+    category prior (alpha 70, lambda 0.3), mean over the batch.  Differentiable w.r.t. the reconstruction and every pose
+    input, as in the reference."""
+    R = pose_rotation(g_R.float(), p_g_vec.float(), f_g_vec.float(), p_r_vec.float(), f_r_vec.float(), sym.float())
+    canon = _PoseTransform.apply(points.float(), R, p_t.float(), p_s.float())
+    return torch.mean(calc_dcd(canon, cate_ori, alpha=70, n_lambda=0.3, return_raw=False, non_reg=False))

@@ -582,3 +582,25 @@ def gather_rows_bwd(dy, idx, n_src):
     check(_lib.lib().tgp_gather_rows_bwd(_p(dy), lddy, _p(idx), B, n_src, n_out, C, _p(dsrc), C, _stream(dy)),
           "tgp_gather_rows_bwd")
     return dsrc
+
+
+def pose_transform(points, R, t, s):
+    """out = (R^T (points - t)) * s per object: points (B,n,3), R (B,3,3), t, s (B,3)"""
+    points, R, t, s = points.contiguous(), R.contiguous(), t.contiguous(), s.contiguous()
+    B, n, _ = points.shape
+    out = torch.empty_like(points)
+    check(_lib.lib().tgp_pose_transform_fwd(_p(points), _p(R), _p(t), _p(s), B, n, _p(out), _stream(points)), "tgp_pose_transform_fwd")
+    return out
+
+
+def pose_transform_bwd(points, R, t, s, dout, need_points=True):
+    points, R, t, s, dout = points.contiguous(), R.contiguous(), t.contiguous(), s.contiguous(), dout.contiguous()
+    B, n, _ = points.shape
+    dev = points.device
+    dp = torch.empty_like(points) if need_points else None
+    dR = torch.empty(B, 3, 3, device=dev, dtype=torch.float32)
+    dt = torch.empty(B, 3, device=dev, dtype=torch.float32)
+    ds = torch.empty(B, 3, device=dev, dtype=torch.float32)
+    check(_lib.lib().tgp_pose_transform_bwd(_p(points), _p(R), _p(t), _p(s), _p(dout), B, n, _p(dp), _p(dR), _p(dt), _p(ds),
+                                            _stream(points)), "tgp_pose_transform_bwd")
+    return dp, dR, dt, ds
