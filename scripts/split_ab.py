@@ -28,12 +28,12 @@ for (M, N, K, LD) in shapes:
     for mode, split in (("split", ops.split_bf16), ("split16", ops.split_f16)):
         ops.GEMM_MODE = mode
         WS = split(W[:, :K].contiguous())
-        for v in ((1,) if mode == "split" else (1, 2, 4)):
+        for v in ((1,) if mode == "split" else (2,)):
             lib.tgp_debug_set_split_variant(v)
             t = timeit(lambda: ops.gemm(A, W, C, M=M, N=N, K=K, lda=LD, ldw=LD, ldc=N, w_split=WS))
             line += "  %s/v%d %.3f ms %.0f TF" % (mode, v, t, flops / t / 1e9)
             if mode == "split16":
-                if v == 1: Cref = C.clone()
-                elif not torch.equal(C, Cref): line += " MISMATCH(%g)" % (C - Cref).abs().max().item()
+                ref = A[-300:, :K].double() @ W[:, :K].double().t()
+                line += " tail-rows err %.1e" % ((C[-300:].double() - ref).abs().max().item() / ref.abs().max().item())
     lib.tgp_debug_set_split_variant(7)
     print(line, flush=True)

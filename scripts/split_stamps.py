@@ -31,6 +31,11 @@ print("big tiles: prologue %.2f us  loop %.2f us  epilogue %.2f us  (medians)" %
     np.median(us(big[:, 1] - big[:, 0])), np.median(us(big[:, 2] - big[:, 1])), np.median(us(big[:, 3] - big[:, 2]))))
 print("percentiles epilogue us", np.percentile(us(big[:, 3] - big[:, 2]), [5, 25, 50, 75, 95]))
 print("percentiles loop us", np.percentile(us(big[:, 2] - big[:, 1]), [5, 25, 50, 75, 95]))
+if len(s) > 2048:
+    sm = s[2048:]
+    print("small tiles (%d): prologue %.2f us  loop %.2f us  epilogue (combine + store) %.2f us  start %.1f..%.1f" % (
+        len(sm), np.median(us(sm[:, 1] - sm[:, 0])), np.median(us(sm[:, 2] - sm[:, 1])), np.median(us(sm[:, 3] - sm[:, 2])),
+        us(sm[:, 0].min() - t0), us(sm[:, 0].max() - t0)))
 starts = np.sort(us(s[:, 0] - t0))
 print("block start times (us), every 256th:", starts[::256])
 ends = np.sort(us(s[:, 3] - t0))

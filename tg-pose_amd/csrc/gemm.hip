@@ -135,6 +135,77 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
     }
 }
 
+// The same epilogue restructured for instruction count (the generic form above costs ~50 instructions per element, and
+// with 64 elements per lane and 4 waves per SIMD that was 20 us per 256 x 256 tile -- 15 % of the wide GEMM):
+//  * addresses are (wave-uniform base + compile-time row offset * ld) + one per-lane offset, so a store or a residual load
+//    is one instruction with a scalar base;
+//  * a wave tile (<= 64 rows) touches at most two objects when rows_per_obj >= its height: the per-object bias is two
+//    preloaded values and a select, the max over points two running keys and two atomics per 16 rows.
+// Preconditions (checked by the caller, else the generic form runs): rows_per_obj >= WTM when rowbias / colmax are used.
+template <int TM, int TN, int WTM, int WTN>
+__device__ __forceinline__ void gemm_epilogue_fast(const GemmParams &p, f32x16 (&acc)[TM][TN], const int m0, const int n0,
+                                                   const int z, const int wm, const int wn, const int r, const int h)
+{
+    const int64_t vo = (int64_t)z * p.sV;
+    const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;       // wave-uniform
+    const bool full_rows = row0 + WTM <= p.M;
+    int obj0 = 0, bound = 0x7fffffff;
+    if (p.rowbias || p.cm) {
+        obj0 = row0 / p.rows_per_obj;
+        bound = (obj0 + 1) * p.rows_per_obj;                     // rows >= bound belong to object obj0 + 1
+    }
+    const int last_row = (row0 + WTM < p.M ? row0 + WTM : p.M) - 1;
+    const bool two_objs = bound <= last_row;
+    float *Cb = p.C ? p.C + (int64_t)z * p.sC + (int64_t)row0 * p.ldc + (col0 - p.c_col0) : nullptr;
+    const float *R1 = p.res1 ? p.res1 + (int64_t)row0 * p.ldr1 + col0 : nullptr;
+    const float *R2 = p.res2 ? p.res2 + (int64_t)row0 * p.ldr2 + col0 : nullptr;
+    const int lane_c = 4 * h * p.ldc + r, lane_r1 = 4 * h * p.ldr1 + r, lane_r2 = 4 * h * p.ldr2 + r;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + j * 32 + r;
+        const bool colok = col < p.N;
+        const float bias = (colok && p.bias) ? p.bias[vo + col] : 0.f;
+        const float sc = (colok && p.scale) ? p.scale[vo + col] : 1.f;
+        const float sh = (colok && p.shift) ? p.shift[vo + col] : 0.f;
+        const float slope = (colok && p.slope_vec) ? p.slope_vec[vo + col] : p.slope;
+        const bool store_c = Cb && colok && col >= p.c_col0;
+        const bool do_cm = p.cm && colok && col < p.cm_cols;
+        float rb0 = 0.f, rb1 = 0.f;
+        if (p.rowbias && colok && row0 < p.M) {   // a wave tile wholly past the last row has no object: nothing to read
+            rb0 = p.rowbias[(int64_t)obj0 * p.ldrb + col];
+            if (two_objs) rb1 = p.rowbias[(int64_t)(obj0 + 1) * p.ldrb + col];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            uint32_t key0 = 0, key1 = 0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int roff = i * 32 + (e & 3) + 8 * (e >> 2);            // compile-time
+                const int row = row0 + roff + 4 * h;
+                const bool ok = full_rows || row < p.M;
+                const bool second = row >= bound;
+                float v = acc[i][j][e] + bias;
+                if (p.rowbias) v += second ? rb1 : rb0;
+                if (R1) v += (colok && ok) ? R1[(int64_t)roff * p.ldr1 + (lane_r1 + j * 32)] : 0.f;
+                if (R2) v += (colok && ok) ? R2[(int64_t)roff * p.ldr2 + (lane_r2 + j * 32)] : 0.f;
+                if (p.scale) v = v * sc + sh;
+                if (p.act == 1) v = v > 0.f ? v : v * slope;
+                if (store_c && ok) Cb[(int64_t)roff * p.ldc + (lane_c + j * 32)] = v;
+                if (do_cm && ok) {
+                    const uint32_t key = tgp_float_key(v);
+                    if (second) key1 = key > key1 ? key : key1;
+                    else key0 = key > key0 ? key : key0;
+                }
+            }
+            if (do_cm) {
+                uint32_t *cm = p.cm + (int64_t)z * p.sCM + col;
+                if (key0) atomicMax(cm + (int64_t)obj0 * p.ldcm, key0);
+                if (key1) atomicMax(cm + (int64_t)(obj0 + 1) * p.ldcm, key1);
+            }
+        }
+    }
+}
+
 #define GEMM_LDPAD 4
 
 // One BM x BN output tile at (m0, n0) of batch z, computed by 64*NWM*NWN threads (NWM x NWN waves, each
@@ -264,7 +335,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, const int m0, con
         }
     }
 
-    gemm_epilogue<TM, TN, WTM, WTN, DIST>(p, acc, m0, n0, z, wm, wn, r, h);
+    if constexpr (DIST) {
+        gemm_epilogue<TM, TN, WTM, WTN, true>(p, acc, m0, n0, z, wm, wn, r, h);
+    } else {
+        if (!(p.rowbias || p.cm) || p.rows_per_obj >= WTM) gemm_epilogue_fast<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h);
+        else gemm_epilogue<TM, TN, WTM, WTN, false>(p, acc, m0, n0, z, wm, wn, r, h);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -320,30 +396,39 @@ __device__ __forceinline__ void split2(const float4 v, uint2 &hi, uint2 &lo)
     lo = __builtin_bit_cast(uint2, l);
 }
 
-template <int BM, int BN, int NWM, int NWN, int PD, bool F16, bool SKEW>
+//
+// KG > 1 is the quarter tile of the launch's last round: the workgroup's waves form KG groups that each take every KG-th
+// K-tile of the same BM x BN output (intra-workgroup split-K), so a 128 x 128 tile keeps 64 x 64 wave tiles -- 12 MFMAs
+// per wave between barriers like the big tile -- and needs a quarter of the K-steps; the groups' accumulators are combined
+// through LDS in a fixed order before the epilogue.  LDS rows are "virtual rows" v = group * BM + row.
+template <int BM, int BN, int NWM, int NWN, int PD, bool F16, bool SKEW, int KG = 1, int STAGES = (PD > 0 ? 2 : 1)>
 __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m0, const int n0, const int z, char *smem)
 {
-    constexpr int THREADS = 64 * NWM * NWN;
+    constexpr int WPG = NWM * NWN;            // waves per K-group
+    constexpr int THREADS = 64 * WPG * KG;
     constexpr int BK = 16;
     constexpr int NP = F16 ? 2 : 3;           // operand planes
     constexpr int ROWB = BK * 2 + 16;         // LDS row of one plane: 16 bf16 + 16 B pad (conflict-free ds_read_b128)
     constexpr int WTM = BM / NWM, WTN = BN / NWN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int VA = BM * KG, VW = BN * KG; // virtual rows staged per step
     constexpr int RPP = THREADS / 4;          // A: 4 threads per row, one float4 each
-    constexpr int PA = (BM + RPP - 1) / RPP;
+    constexpr int PA = (VA + RPP - 1) / RPP;
     constexpr int NCH = 2 * NP;               // 16-byte chunks per row and K-tile
-    constexpr int WCH = BN * NCH;             // W: 16-byte chunks per K-tile
+    constexpr int WCH = VW * NCH;             // W: 16-byte chunks per step
     constexpr int PW = (WCH + THREADS - 1) / THREADS;
     // plane strides carry 32 extra bytes: the hi / mid / lo planes then start 8 banks apart, which removes the 3-way
     // conflicts of the staging writes (one row's six W chunks, or one A quad's three terms, hit distinct banks)
-    constexpr int PLANE_A = BM * ROWB + 32, PLANE_W = BN * ROWB + 32;
+    constexpr int PLANE_A = VA * ROWB + 32, PLANE_W = VW * ROWB + 32;
     constexpr int BUFB = NP * (PLANE_A + PLANE_W);
+    static_assert(KG == 1 || STAGES == 1, "the split-K tile uses one LDS stage");
     char *lds_a = smem;
     char *lds_w = smem + NP * PLANE_A;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / NWN, wn = wave % NWN;
+    const int kg = wave / WPG;
+    const int wm = (wave % WPG) / NWN, wn = (wave % WPG) % NWN;
     const int r = lane & 31, h = lane >> 5;
     const float *A = p.A + (int64_t)z * p.sA;
     const uint16_t *WS = p.Wsplit + (int64_t)z * p.sWS;
@@ -352,7 +437,7 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
     // PD = 0: one LDS stage.  PD >= 1: two LDS stages, global loads PD K-tiles ahead of the MFMAs through a ring of PD
     // register sets (8 VGPRs each on the big tile): one K-tile of MFMAs is ~0.6 us, shorter than a loaded memory
     // system's latency, so a single tile of lookahead leaves the matrix cores waiting.
-    constexpr bool DBUF = PD > 0;
+    constexpr bool DBUF = STAGES == 2;        // LDS stages; with one stage a step is compute | barrier | store | barrier
     constexpr int NS = PD > 0 ? PD : 1;
     const int kq = tid & 3, r0 = tid >> 2;
     float4 ra_[NS][PA];
@@ -370,27 +455,33 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
         const_cast<uint16_t *>(WS + (int64_t)n0 * wrow), 0, (int)(w_bytes > 0x7fffffff ? 0x7fffffff : w_bytes), 0x00020000);
     int voff_a[PA], voff_w[PW];
 #pragma unroll
-    for (int i = 0; i < PA; ++i) voff_a[i] = ((r0 + RPP * i) * p.lda + kq * 4) * 4;
+    for (int i = 0; i < PA; ++i) {
+        const int v = r0 + RPP * i;            // virtual row: K-group v / BM, tile row v % BM
+        voff_a[i] = ((v % BM) * p.lda + (v / BM) * BK + kq * 4) * 4;
+    }
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
         const int g = tid + THREADS * i;
-        voff_w[i] = (int)((g / NCH) * wrow * 2) + (g % NCH) * 16;
+        const int v = g / NCH;
+        voff_w[i] = (int)((v % BN) * wrow * 2) + (v / BN) * (32 * NP) + (g % NCH) * 16;
     }
+    // kt counts steps: step kt covers the K-tiles kt * KG .. kt * KG + KG - 1 (one per K-group)
     auto load_tile = [&](int kt, float4 (&ra)[PA], uint4 (&rw)[PW]) {
 #pragma unroll
         for (int i = 0; i < PA; ++i)
-            if (RPP * i + r0 < BM)
-                ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff_a[i], kt * (BK * 4), 0));
+            if (RPP * i + r0 < VA)
+                ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff_a[i], kt * (KG * BK * 4), 0));
 #pragma unroll
         for (int i = 0; i < PW; ++i)
             if (tid + THREADS * i < WCH)
-                rw[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff_w[i], kt * (32 * NP), 0));
+                rw[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff_w[i], kt * (KG * 32 * NP), 0));
     };
     auto store_tile = [&](int buf, const int kt, const float4 (&ra_in)[PA], const uint4 (&rw)[PW]) {
-        const bool kok = kt * BK + kq * 4 < p.K;   // K % 4 == 0: a quad is wholly inside or outside
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            if (RPP * i + r0 < BM) {
+            if (RPP * i + r0 < VA) {
+                // K % 4 == 0: a quad is wholly inside or outside
+                const bool kok = (kt * KG + (r0 + RPP * i) / BM) * BK + kq * 4 < p.K;
                 char *dst = lds_a + buf * BUFB + (r0 + RPP * i) * ROWB + kq * 8;
                 float4 ra[PA];   // masked with AND, not a select: a select on a pending load is compiled into a branch
                 const uint32_t km = kok ? 0xffffffffu : 0u;
@@ -428,7 +519,7 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int numK = (p.K + BK - 1) / BK;
+    const int numK = ((p.K + BK - 1) / BK + KG - 1) / KG;     // steps
     unsigned long long st0 = 0, st1 = 0, st2 = 0;
     if (p.stamps) st0 = __builtin_amdgcn_s_memrealtime();
     load_tile(0, ra_[0], rw_[0]);
@@ -450,10 +541,10 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
         const bool more = (kt + 1) < numK;
         // issued unconditionally (past the last K-tile the descriptor's bounds make it a load of zeros that is never
         // stored): a conditional issue would force the compiler to drain vmcnt to zero before the next tile's store
-        if (DBUF || more) load_tile(kt + NS, ra_new, rw_new);
+        if (DBUF || NS > 1 || more) load_tile(kt + NS, ra_new, rw_new);
         const int cur = DBUF ? (kt & 1) : 0;
-        const char *as = lds_a + cur * BUFB + (wm * WTM + r) * ROWB + h * 16;
-        const char *ws = lds_w + cur * BUFB + (wn * WTN + r) * ROWB + h * 16;
+        const char *as = lds_a + cur * BUFB + (kg * BM + wm * WTM + r) * ROWB + h * 16;
+        const char *ws = lds_w + cur * BUFB + (kg * BN + wn * WTN + r) * ROWB + h * 16;
         uint4 a[TM][NP];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -511,7 +602,10 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
             __syncthreads();
         } else {
             __syncthreads();
-            if (more) store_tile(0, kt + 1, ra_new, rw_new);
+            if (more) {
+                if constexpr (NS == 1) store_tile(0, kt + 1, ra_new, rw_new);
+                else store_tile(0, kt + 1, ra_next, rw_next);
+            }
             __syncthreads();
         }
     };
@@ -526,7 +620,39 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
         }
     }
     if (p.stamps) st2 = __builtin_amdgcn_s_memrealtime();
-    gemm_epilogue<TM, TN, WTM, WTN, false>(p, acc, m0, n0, z, wm, wn, r, h);
+    if constexpr (KG > 1) {
+        // combine the K-groups' accumulators: (g0 + g1) + (g2 + g3), one group's 64 registers x 64 lanes through LDS at a
+        // time (lane-major rows: conflict free); the loop's last barrier has already retired every operand read
+        static_assert(KG == 4 || KG == 2, "pairwise combination");
+        float *slot = reinterpret_cast<float *>(smem) + (wave % WPG) * (TM * TN * 16 * 64) + lane;
+        auto give = [&]() {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) slot[((i * TN + j) * 16 + e) * 64] = acc[i][j][e];
+        };
+        auto take = [&]() {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] += slot[((i * TN + j) * 16 + e) * 64];
+        };
+        auto hand = [&](int from, int to) {
+            if (kg == from) give();
+            __syncthreads();
+            if (kg == to) take();
+            __syncthreads();
+        };
+        hand(1, 0);
+        if (KG == 4) hand(3, 2), hand(2, 0);
+        if (kg != 0) return;
+    }
+    if (!(p.rowbias || p.cm) || p.rows_per_obj >= WTM) gemm_epilogue_fast<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h);
+    else gemm_epilogue<TM, TN, WTM, WTN, false>(p, acc, m0, n0, z, wm, wn, r, h);
     if (p.stamps && threadIdx.x == 0) {
         unsigned long long *o = p.stamps + 5 * (size_t)blockIdx.x;
         unsigned xcc;
@@ -538,7 +664,8 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
 template <int PD, bool F16, bool SKEW>
 __global__ __launch_bounds__(1024) void gemm_split_kernel(GemmParams p)
 {
-    __shared__ __attribute__((aligned(16))) char smem[(PD > 0 ? 2 : 1) * (F16 ? 2 : 3) * ((256 + 256) * 48 + 64)];
+    // two stages of the 256 x 256 tile = one stage of the split-K quarter tile (4 x (128 + 128) virtual rows)
+    __shared__ __attribute__((aligned(16))) char smem[2 * (F16 ? 2 : 3) * ((256 + 256) * 48 + 64)];
     int seg = 0;
     while (seg < p.nseg - 1 && (int)blockIdx.x >= p.seg_end[seg]) ++seg;
     int L = p.seg_base[seg] + (int)blockIdx.x - (seg ? p.seg_end[seg - 1] : 0);
@@ -551,7 +678,11 @@ __global__ __launch_bounds__(1024) void gemm_split_kernel(GemmParams p)
         const int per_batch = p.tiles_m_small * p.tiles_n_small;
         const int z = L / per_batch;
         L -= z * per_batch;
-        gemm_split_tile<128, 128, 4, 4, PD, F16, SKEW>(p, p.mt_big * 256 + (L / p.tiles_n_small) * 128, (L % p.tiles_n_small) * 128, z, smem);
+        const int sm0 = p.mt_big * 256 + (L / p.tiles_n_small) * 128, sn0 = (L % p.tiles_n_small) * 128;
+        // (an intra-workgroup split-K form of this tile -- template parameter KG -- was measured: 73 instead of 80 us for
+        // the wide layer's last round, but it sums K in another order than the big tiles, so an object's result would
+        // depend on whether its rows fall into the last 128 of the batch; not used)
+        gemm_split_tile<128, 128, 4, 4, PD, F16, false>(p, sm0, sn0, z, smem);
     }
 }
 
