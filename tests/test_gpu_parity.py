@@ -1216,3 +1216,36 @@ def test_r_dcd_gradients_vs_oracle_autograd(ops):
     for k in names:
         a, r = dev[k].grad.cpu(), cpu[k].grad
         assert torch.allclose(a, r, atol=2e-6 + 1e-4 * r.abs().max().item(), rtol=1e-4), (k, (a - r).abs().max().item(), r.abs().max().item())
+
+
+def test_graph_replay_equals_eager(ops):
+    """net.graph_replay: the captured hipGraph must return bit for bit what the eager launches return, follow new inputs
+    and new subsample draws on every replay, and survive a change of the running statistics (in-place refold)."""
+    from tgpose_amd import FLAGS
+    net = _net(3)
+    FLAGS.train = 0
+    B, N = 6, 1028
+    cases = []
+    for seed in (1, 2, 3):
+        pts, obj = synth_points(B, N, seed)
+        torch.manual_seed(seed)
+        i1 = torch.randperm(N)[: N // 4]
+        cases.append((g(pts), g(obj), (i1, torch.randperm(i1.numel())[: i1.numel() // 4])))
+    eager = [net(p, o, sample_idx=s) for p, o, s in cases]
+    net.graph_replay = True
+    try:
+        for (p, o, s), want in zip(cases, eager):
+            got = net(p, o, sample_idx=s)
+            for k in want:
+                assert torch.equal(got[k], want[k]), k
+        with torch.no_grad():
+            net.rot_green.bn1.running_mean.add_(0.05)
+        net.graph_replay = False
+        want = net(*cases[0][:2], sample_idx=cases[0][2])
+        net.graph_replay = True
+        got = net(*cases[0][:2], sample_idx=cases[0][2])
+        assert not torch.equal(want["p_green_R"], eager[0]["p_green_R"])
+        for k in want:
+            assert torch.equal(got[k], want[k]), k
+    finally:
+        net.graph_replay = False

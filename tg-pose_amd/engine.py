@@ -196,8 +196,11 @@ _SIDE = {}
 BRANCH_STREAMS = True   # run the PH-tail -> decoder chain beside the head chain on a second HIP stream
 
 
-def _side_stream(device):
-    key = torch.device(device).index
+SIDE_TAG = 0            # GraphedForward gives each half batch its own side stream
+
+
+def _side_stream(device, tag=None):
+    key = (torch.device(device).index, SIDE_TAG if tag is None else tag)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
@@ -451,8 +454,9 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
             recon = decoder_forward(pk, feat, back, N)
             join = torch.cuda.Event()
             join.record(side)
-        for t in (keys5, H, feat, h1, h2, back, recon):
-            t.record_stream(side)
+        if not torch.cuda.is_current_stream_capturing():      # a captured graph owns its pool: nothing to protect
+            for t in (keys5, H, feat, h1, h2, back, recon):
+                t.record_stream(side)
         green, red, ts = head_chain(pk, H, B, N)
         cur.wait_event(join)
     else:
@@ -659,3 +663,79 @@ def encoder_only_forward_train(pk, sd, points, obj_id, sample_idx=None, inject=N
     feat = encoder_forward_train(pk, bn, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
     recon = decoder_forward_train(pk, bn, feat, None, N)
     return dict(feat_global=ops.colmax(feat[:, :, :FEAT_C]), recon=recon)
+
+
+# =====================================================================================================
+# hipGraph replay of the eval-mode forward.  One forward is ~100 kernel launches of 5-1000 us; captured once per
+# (B, N, output set) with torch.cuda.graph (hipStreamBeginCapture around the same C-ABI launches) and replayed, the
+# launch overhead and the gaps between dependent kernels disappear from the host's and the GPU's timeline.  With
+# parts = 2 the batch is captured as two half batches on two forked streams: eval-mode objects are independent
+# (SURVEY.md 8e), so the halves' tail rounds, small kernels and epilogues overlap each other inside one graph.
+# Inputs are copied into static buffers before a replay; the returned tensors are the graph's static outputs, valid
+# until the next replay (the usual contract of graph replay).
+# =====================================================================================================
+class GraphedForward(object):
+    def __init__(self, pk, B, N, device, train_keys=False, parts=1, kmax=20, n_cls=6):
+        global SIDE_TAG
+        if parts not in (1, 2) or (parts == 2 and B % 2):
+            raise ValueError("parts must be 1, or 2 with an even batch")
+        self.B, self.N, self.device = B, N, device
+        n1 = N // 4
+        n2 = n1 // 4
+        self.points = torch.zeros(B, N, 3, device=device)
+        self.obj = torch.zeros(B, 1, device=device)
+        self.s1 = torch.zeros(n1, device=device, dtype=torch.int32)
+        self.s2 = torch.zeros(n2, device=device, dtype=torch.int32)
+        self._pin = torch.empty(n1 + n2, dtype=torch.int32).pin_memory()
+        self._s12 = torch.zeros(n1 + n2, device=device, dtype=torch.int32)
+        half = B // parts
+
+        def run():
+            self.s1.copy_(self._s12[:n1])
+            self.s2.copy_(self._s12[n1:])
+            if parts == 1:
+                return posenet_forward(pk, self.points, self.obj, train_keys, (self.s1, self.s2), None, None, kmax, n_cls)
+            global SIDE_TAG, BRANCH_STREAMS
+            branch, BRANCH_STREAMS = BRANCH_STREAMS, False     # two streams in all: the halves overlap each other
+            cur = torch.cuda.current_stream(device)
+            other = _side_stream(device, "half")
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            outs = []
+            for part, stream in ((0, cur), (1, other)):
+                SIDE_TAG = part
+                with torch.cuda.stream(stream):
+                    if part:
+                        stream.wait_event(fork)
+                    sl = slice(part * half, (part + 1) * half)
+                    outs.append(posenet_forward(pk, self.points[sl], self.obj[sl], train_keys, (self.s1, self.s2), None, None,
+                                                kmax, n_cls))
+                    if part:
+                        join = torch.cuda.Event()
+                        join.record(stream)
+            SIDE_TAG, BRANCH_STREAMS = 0, branch
+            cur.wait_event(join)
+            return {k: torch.cat([outs[0][k], outs[1][k]], 0) for k in outs[0]}
+
+        warm = torch.cuda.Stream(device=device)
+        warm.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(warm):           # first-use work (LDS limits, lazy module loads) must not happen under capture
+            run()
+            run()
+        torch.cuda.current_stream(device).wait_stream(warm)
+        torch.cuda.synchronize(device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = run()
+
+    def __call__(self, points, obj_id, sample_idx=None):
+        if tuple(points.shape) != (self.B, self.N, 3):
+            raise ValueError("GraphedForward was captured for points of shape (%d, %d, 3)" % (self.B, self.N))
+        if sample_idx is None:
+            sample_idx = draw_sample_idx(self.N)
+        self._pin.copy_(torch.cat([sample_idx[0].reshape(-1), sample_idx[1].reshape(-1)]).to(torch.int32))
+        self._s12.copy_(self._pin, non_blocking=True)
+        self.points.copy_(points, non_blocking=True)
+        self.obj.copy_(obj_id.reshape(self.B, 1).to(self.points.dtype), non_blocking=True)
+        self.graph.replay()
+        return self.out

@@ -69,5 +69,15 @@ class PoseNet9D(_WithBuffers):
             if self.only_encoder:
                 return engine.encoder_only_forward(pk, points, obj_id, sample_idx, inject, record,
                                                    FLAGS.gcn_n_num, FLAGS.obj_c)
+            if getattr(self, "graph_replay", False) and inject is None and record is None:
+                # opt-in (net.graph_replay = True): the forward of this (batch, cloud size, output set) is captured once as
+                # a hipGraph and replayed; the returned tensors are the graph's static outputs, valid until the next call
+                key = (id(pk), tuple(points.shape), bool(FLAGS.train), ops.GEMM_MODE, engine.BRANCH_STREAMS)
+                graphs = self.__dict__.setdefault("_graphs", {})
+                if key not in graphs:
+                    graphs.clear()                      # one resident graph: its private pool holds every activation
+                    graphs[key] = engine.GraphedForward(pk, points.shape[0], points.shape[1], points.device, bool(FLAGS.train),
+                                                        1, FLAGS.gcn_n_num, FLAGS.obj_c)
+                return dict(graphs[key](points, obj_id, sample_idx))
             return engine.posenet_forward(pk, points, obj_id, bool(FLAGS.train), sample_idx, inject, record,
                                           FLAGS.gcn_n_num, FLAGS.obj_c)
