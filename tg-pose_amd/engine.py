@@ -258,11 +258,42 @@ def surface_layer(c, xyz, idx_rf, idx_orl, out, scale=None, shift=None, act=None
     return out
 
 
+def _beside(device, fn, tag="knn"):
+    """run fn() on a side stream forked from the current one; returns (result, join event).  Inside a captured graph this
+    is a parallel branch; in eager mode the allocator is told that the results will be consumed on the current stream."""
+    cur = torch.cuda.current_stream(device)
+    side = _side_stream(device, (SIDE_TAG, tag))
+    fork = torch.cuda.Event()
+    fork.record(cur)
+    with torch.cuda.stream(side):
+        side.wait_event(fork)
+        res = fn()
+        join = torch.cuda.Event()
+        join.record(side)
+    if not torch.cuda.is_current_stream_capturing():
+        for t in (res if isinstance(res, (tuple, list)) else (res,)):
+            if torch.is_tensor(t):
+                t.record_stream(cur)
+    return res, join
+
+
 def hs_layer(c, xyz, fmap, idx_rf, idx_orl, out, scale=None, shift=None, act=None):
-    """HS_layer.forward (gcn3d.py:142-155) + the caller's BatchNorm(eval)/ReLU, written to `out`."""
+    """HS_layer.forward (gcn3d.py:142-155) + the caller's BatchNorm(eval)/ReLU, written to `out`.
+    idx_rf / idx_orl may be callables: they are then evaluated on a side stream (the feature-space kNN -- distance GEMM +
+    selection -- and the level's xyz kNN depend only on the layer's inputs) while this stream runs the projection GEMM."""
     B, n, _ = xyz.shape
     C = c["C"]
+    join = None
+    if callable(idx_rf) or callable(idx_orl):
+        if BRANCH_STREAMS:
+            (idx_rf, idx_orl), join = _beside(xyz.device, lambda: (idx_rf() if callable(idx_rf) else idx_rf,
+                                                                   idx_orl() if callable(idx_orl) else idx_orl))
+        else:
+            idx_rf = idx_rf() if callable(idx_rf) else idx_rf
+            idx_orl = idx_orl() if callable(idx_orl) else idx_orl
     proj9 = ops.linear_rows(fmap, c["wcat"], bias=c["bcat"], w_split=c.get("wcat_s"))   # (B,n,9C): centre|support|STE
+    if join is not None:
+        torch.cuda.current_stream(xyz.device).wait_event(join)
     g = ops.gconv_hs(xyz, idx_rf, proj9, c["sdn"], 7, C)
     rb = ops.orl_rowbias(g, idx_orl, c["w2t"]) if "w2t" in c else ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
     ops.linear_rows(g, c["w1"], out=out, rowbias=rb, rows_per_obj=n, res1=g, res2=proj9[:, :, 8 * C:], scale=scale,
@@ -292,23 +323,23 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6):
     surface_layer(cv[0], xyz, graphs.get("conv_0.rf", lambda: xyz_graph(0, xyz, kmax)),
                   graphs.get("conv_0.orl_xyz", lambda: xyz_graph(0, xyz, kmax)), fm0, act="relu")
     fm1 = feat[:, :, 128:256]
-    hs_layer(cv[1], xyz, fm0, graphs.get("conv_1.rf", lambda: ops.knn_feat(fm0, kmax)),
+    hs_layer(cv[1], xyz, fm0, lambda: graphs.get("conv_1.rf", lambda: ops.knn_feat(fm0, kmax)),
              graphs.get("conv_1.orl_xyz", lambda: xyz_graph(0, xyz, kmax)), fm1, cv[1]["scale"], cv[1]["shift"], "relu")
     v1, fp1 = ops.pool(xyz, fm1, graphs.get("pool_1.xyz", lambda: xyz_graph(0, xyz, kmax)), s1, kpool=4)
 
     k1 = min(kmax, N1 // 8)
     fm2 = torch.empty(B, N1, 256, device=dev, dtype=torch.float32)
-    hs_layer(cv[2], v1, fp1, graphs.get("conv_2.rf", lambda: ops.knn_feat(fp1, k1)),
-             graphs.get("conv_2.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm2, cv[2]["scale"], cv[2]["shift"], "relu")
+    hs_layer(cv[2], v1, fp1, lambda: graphs.get("conv_2.rf", lambda: ops.knn_feat(fp1, k1)),
+             lambda: graphs.get("conv_2.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm2, cv[2]["scale"], cv[2]["shift"], "relu")
     fm3 = torch.empty(B, N1, 256, device=dev, dtype=torch.float32)
-    hs_layer(cv[3], v1, fm2, graphs.get("conv_3.rf", lambda: ops.knn_feat(fm2, k1)),
+    hs_layer(cv[3], v1, fm2, lambda: graphs.get("conv_3.rf", lambda: ops.knn_feat(fm2, k1)),
              graphs.get("conv_3.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm3, cv[3]["scale"], cv[3]["shift"], "relu")
     v2, fp2 = ops.pool(v1, fm3, graphs.get("pool_2.xyz", lambda: xyz_graph(1, v1, k1)), s2, kpool=4)
 
     k2 = min(kmax, N2 // 8)
     fm4 = torch.empty(B, N2, 512, device=dev, dtype=torch.float32)
-    hs_layer(cv[4], v2, fp2, graphs.get("conv_4.rf", lambda: ops.knn_feat(fp2, k2)),
-             graphs.get("conv_4.orl_xyz", lambda: xyz_graph(2, v2, k2)), fm4)
+    hs_layer(cv[4], v2, fp2, lambda: graphs.get("conv_4.rf", lambda: ops.knn_feat(fp2, k2)),
+             lambda: graphs.get("conv_4.orl_xyz", lambda: xyz_graph(2, v2, k2)), fm4)
 
     near1 = graphs.get("up_1", lambda: ops.nn1(xyz, v1)).view(B, N)
     near2 = graphs.get("up_2", lambda: ops.nn1(xyz, v2)).view(B, N)
