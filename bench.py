@@ -126,6 +126,10 @@ def main():
     net = net.to(dev).eval()
     FLAGS.train = 0
     ops.GEMM_MODE = args.gemm
+    if os.environ.get("TGP_SPLIT_VARIANT"):       # development A/B of split-GEMM variants (csrc/gemm.hip)
+        import ctypes
+        from tgpose_amd import _lib
+        ctypes.CDLL(_lib.LIB_PATH).tgp_debug_set_split_variant(int(os.environ["TGP_SPLIT_VARIANT"]))
     from tgpose_amd import engine as _engine
     _engine.BRANCH_STREAMS = not args.no_branch_streams
     B = args.batch
@@ -249,7 +253,7 @@ def main():
             peak = PEAK_F32_MFMA_TFLOPS
             peak_basis = "fp32 MFMA (v_mfma_f32_32x32x2_f32) dense peak"
         line = {
-            "metric": ("objects/sec forward (B=32, N=1028 pts)" if args.workload == "forward"
+            "metric": ("objects/sec forward (B=%d, N=%d pts)" % (B, N_POINTS) if args.workload == "forward"
                        else "objects/sec training step (forward + loss + backward + optimizer, B=%d, N=%d pts)" % (B, N_POINTS)),
             "value": round(world * B * args.steps / elapsed, 2),
             "unit": "objects/s",

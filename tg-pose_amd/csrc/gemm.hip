@@ -686,6 +686,31 @@ __global__ __launch_bounds__(1024) void gemm_split_kernel(GemmParams p)
     }
 }
 
+// The same tiles as two independent 512-thread workgroups per CU (256 x 128 outputs each, 4 x 2 waves of 64 x 64; tail:
+// 128 x 128).  Two barrier domains per CU de-phase on their own: while one workgroup waits at its barrier or runs its
+// epilogue the other keeps the matrix cores busy.  The price is 1.5x the operand traffic per output (A rows are shared
+// by half as many columns).
+template <int PD, bool F16>
+__global__ __launch_bounds__(512, 4) void gemm_split512_kernel(GemmParams p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[(PD > 0 ? 2 : 1) * (F16 ? 2 : 3) * ((256 + 128) * 48 + 64)];
+    int seg = 0;
+    while (seg < p.nseg - 1 && (int)blockIdx.x >= p.seg_end[seg]) ++seg;
+    int L = p.seg_base[seg] + (int)blockIdx.x - (seg ? p.seg_end[seg - 1] : 0);
+    if (!((p.seg_small >> seg) & 1)) {
+        const int per_batch = p.mt_big * p.tiles_n_big;
+        const int z = L / per_batch;
+        L -= z * per_batch;
+        gemm_split_tile<256, 128, 4, 2, PD, F16, false>(p, (L / p.tiles_n_big) * 256, (L % p.tiles_n_big) * 128, z, smem);
+    } else {
+        const int per_batch = p.tiles_m_small * p.tiles_n_small;
+        const int z = L / per_batch;
+        L -= z * per_batch;
+        gemm_split_tile<128, 128, 4, 2, PD, F16, false>(p, p.mt_big * 256 + (L / p.tiles_n_small) * 128, (L % p.tiles_n_small) * 128,
+                                                        z, smem);
+    }
+}
+
 // W (rows, K) fp32 row stride ld -> out[rows][ldo / 16][3][16] bf16 (hi, mid, lo per K-tile), zero padded to ldo
 __global__ void split_bf16_kernel(const float *__restrict__ W, int rows, int K, int ld, uint16_t *__restrict__ out, int ldo)
 {
@@ -924,10 +949,12 @@ static int launch_small(const GemmParams &p, hipStream_t stream)
 
 // Split the M-tile rows between big tiles and a tail of half-size tiles so that the last round is filled.
 // Returns the estimated duration in units of one big tile; fills the schedule fields of p.
-static double plan_tiles(GemmParams &p, int big, int64_t S, double tail_cost, int tail_per_idle)
+static double plan_tiles(GemmParams &p, int big, int64_t S, double tail_cost, int tail_per_idle, int big_n = 0, int small_n = 0)
 {
     const int small = big / 2;
-    const int rows_big = tgp_cdiv(p.M, big), tiles_nb = tgp_cdiv(p.N, big), tiles_ns = tgp_cdiv(p.N, small);
+    if (!big_n) big_n = big;
+    if (!small_n) small_n = small;
+    const int rows_big = tgp_cdiv(p.M, big), tiles_nb = tgp_cdiv(p.N, big_n), tiles_ns = tgp_cdiv(p.N, small_n);
     auto estimate = [&](int mt) {
         const int64_t tb = (int64_t)mt * tiles_nb * p.batch;
         const int left = p.M - mt * big;
@@ -987,6 +1014,22 @@ static void order_tiles(GemmParams &p, int64_t S, bool stagger)
 
 static int launch_split(GemmParams &p, hipStream_t stream)
 {
+    // few 256 x 256 tiles (narrow outputs: N <= 256, or less than ~1.5 rounds of them) leave CUs idle or half-empty: such
+    // launches run as 256 x 128 tiles on two 512-thread workgroups per CU (measured: M=32896, N=256, K=1024 126 -> 92 us;
+    // the wide layer, in contrast, 1.04 -> 1.32 ms)
+    const int64_t sq_tiles = (int64_t)tgp_cdiv(p.M, GEMM_BIG) * tgp_cdiv(p.N, GEMM_BIG) * p.batch;
+    const bool narrow = p.N <= 256 || sq_tiles * 2 < 3 * (int64_t)resident_slots();
+    const bool force512 = tgp_split_variant != 7 && (tgp_split_variant & 16), forbid512 = tgp_split_variant != 7 && (tgp_split_variant & 32);
+    if (p.split_f16 && (force512 || (narrow && !forbid512))) {
+        // two 512-thread workgroups per CU, 256 x 128 tiles (+ 128 x 128 tail tiles)
+        plan_tiles(p, GEMM_BIG, 2 * (int64_t)resident_slots(), 0.55, 2, 128, 128);
+        order_tiles(p, 2 * (int64_t)resident_slots(), false);
+        p.stamps = tgp_split_stamps;
+        const dim3 grid512(p.tiles_big + p.tiles_m_small * p.tiles_n_small * p.batch);
+        if ((tgp_split_variant & 7) == 1) hipLaunchKernelGGL((gemm_split512_kernel<1, true>), grid512, dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_split512_kernel<2, true>), grid512, dim3(512), 0, stream, p);
+        return TGP_LAUNCH_RESULT();
+    }
     const int64_t S = resident_slots();
     plan_tiles(p, GEMM_BIG, S, 0.27, 3);
     const bool stagger = (tgp_split_variant & 8) != 0 && tgp_split_variant != 7;
