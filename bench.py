@@ -167,18 +167,33 @@ def main():
         tgt = {k: torch.randn(B, 3, generator=gen).to(dev) for k in ("p_green_R", "p_red_R", "Pred_T", "Pred_s")}
         code = torch.rand(B, 2500, generator=gen).to(dev)
 
-        def step():
-            out = net(pts, obj)
+        def loss_fn(out):
             loss = calc_dcd(out["recon"], prior)[0].mean()
             for k, t in tgt.items():
                 loss = loss + torch.nn.functional.smooth_l1_loss(out[k], t)
-            loss = loss + torch.nn.functional.mse_loss(out["h1"], code) + torch.nn.functional.mse_loss(out["h2"], code)
-            loss.backward()
+            return loss + torch.nn.functional.mse_loss(out["h1"], code) + torch.nn.functional.mse_loss(out["h2"], code)
+
+        def finish():
             shard.allreduce_gradients(net.parameters())
             torch.nn.utils.clip_grad_norm_(net.parameters(), 5.0)         # trainer/RL_TDA.py:223
             opt.step()
-            opt.zero_grad(set_to_none=True)
-            return loss
+
+        if args.graph:
+            # forward + loss + backward replayed as one hipGraph; the collective, the clip and the optimizer step stay eager
+            from tgpose_amd.autograd import GraphedBackward
+            graphed_bwd = GraphedBackward(net, pts, obj, loss_fn)
+
+            def step():
+                loss = graphed_bwd()
+                finish()
+                return loss
+        else:
+            def step():
+                opt.zero_grad(set_to_none=True)
+                loss = loss_fn(net(pts, obj))
+                loss.backward()
+                finish()
+                return loss
 
     for _ in range(max(args.warmup, len(streams))):
         step()

@@ -1249,3 +1249,40 @@ def test_graph_replay_equals_eager(ops):
             assert torch.equal(got[k], want[k]), k
     finally:
         net.graph_replay = False
+
+
+def test_graphed_backward_equals_eager(ops):
+    """GraphedBackward (forward + loss + backward as one hipGraph) against the eager autograd path: same loss, same
+    gradients (the scatter atomics reorder fp32 sums: 1e-5 of each gradient's largest entry), on two different draws."""
+    from tgpose_amd import FLAGS
+    from tgpose_amd.autograd import GraphedBackward
+    net = _train_net(5)
+    B, N = 4, 1028
+    pts, obj = synth_points(B, N, 5)
+    gen = torch.Generator().manual_seed(5)
+    tgt = g(torch.randn(B, 3, generator=gen))
+    loss_fn = lambda out: (out["recon"] ** 2).mean() + torch.nn.functional.smooth_l1_loss(out["Pred_T"], tgt) + out["h1"].mean()
+    FLAGS.train = 1
+    try:
+        gb = GraphedBackward(net, g(pts), g(obj), loss_fn)
+        for seed in (1, 2):
+            torch.manual_seed(seed)
+            i1 = torch.randperm(N)[: N // 4]
+            sample = (i1, torch.randperm(i1.numel())[: i1.numel() // 4])
+            rm = {k: v.clone() for k, v in net.state_dict().items() if "running" in k}
+            loss_g = gb(sample_idx=sample).item()
+            grads_g = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+            net.load_state_dict(rm, strict=False)
+            for p in net.parameters():                            # in place: the graph owns these .grad buffers
+                if p.grad is not None:
+                    p.grad.zero_()
+            loss_e = loss_fn(net(g(pts), g(obj), sample_idx=sample))
+            loss_e.backward()
+            assert abs(loss_g - loss_e.item()) <= 1e-6 * max(1.0, abs(loss_e.item()))
+            for k, p in net.named_parameters():
+                if p.grad is None:
+                    continue
+                ref = p.grad.abs().max().item()
+                assert (grads_g[k] - p.grad).abs().max().item() <= 1e-5 * ref + 1e-7, k
+    finally:
+        FLAGS.train = 0
