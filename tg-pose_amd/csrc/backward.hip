@@ -401,29 +401,48 @@ extern "C" int tgp_bn_bwd_pooled(const float *dpool, int ldp, const int *argrow,
 // max over each object's points with the winning row (first row on ties, as torch.max) of y = act(BN(x)) computed on the
 // fly from the raw layer output (mean == NULL: y = x).  One thread per (object, channel) walks the object's rows:
 // coalesced across channels.
-__global__ void colmax_arg_kernel(const float *__restrict__ x, int ld, int n, int C, const float *__restrict__ mean,
+__global__ __launch_bounds__(256) void colmax_arg_kernel(const float *__restrict__ x, int ld, int n, int C, const float *__restrict__ mean,
                                   const float *__restrict__ var, float eps, const float *__restrict__ gamma,
                                   const float *__restrict__ beta, int act, float slope, const float *__restrict__ slope_vec,
                                   float *__restrict__ out, int ldo, int *__restrict__ argrow, int lda)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    // 64 channels x 4 row slices per workgroup; slice s scans the contiguous rows [s * n / 4, (s + 1) * n / 4) of the
+    // object, the four (value, row) candidates are merged in slice order with a strict '>' so the first row wins ties
+    __shared__ float s_best[4][64];
+    __shared__ int s_arg[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int slice = threadIdx.x >> 6;
     const int o = blockIdx.y;
-    if (c >= C) return;
     float mu = 0.f, a = 1.f, b = 0.f, sl = 0.f;
-    if (mean) mu = mean[c], a = gamma[c] / sqrtf(var[c] + eps), b = beta[c], sl = slope_vec ? slope_vec[c] : slope;
+    if (c < C && mean) mu = mean[c], a = gamma[c] / sqrtf(var[c] + eps), b = beta[c], sl = slope_vec ? slope_vec[c] : slope;
     const int64_t r0 = (int64_t)o * n;
+    const int64_t ra = r0 + (int64_t)n * slice / 4, rb = r0 + (int64_t)n * (slice + 1) / 4;
     float best = 0.f;
-    int64_t arg = r0;
-    for (int64_t r = r0; r < r0 + n; ++r) {
-        float v = x[r * ld + c];
-        if (mean) {
-            v = (v - mu) * a + b;      // same expression as bn_apply_kernel: the pooled value equals the stored activation
-            if (act == 1) v = v > 0.f ? v : v * sl;
+    int64_t arg = -1;
+    if (c < C) {
+#pragma unroll 8
+        for (int64_t r = ra; r < rb; ++r) {
+            float v = x[r * ld + c];
+            if (mean) {
+                v = (v - mu) * a + b;      // same expression as bn_apply_kernel: the pooled value equals the stored activation
+                if (act == 1) v = v > 0.f ? v : v * sl;
+            }
+            if (arg < 0 || v > best || (v != v && best == best)) best = v, arg = r;   // NaN propagates like torch.max
         }
-        if (r == r0 || v > best || (v != v && best == best)) best = v, arg = r;   // NaN propagates like torch.max
     }
-    out[(int64_t)o * ldo + c] = best;
-    argrow[(int64_t)o * lda + c] = (int)arg;
+    s_best[slice][threadIdx.x & 63] = best;
+    s_arg[slice][threadIdx.x & 63] = (int)arg;
+    __syncthreads();
+    if (slice == 0 && c < C) {
+        const int l = threadIdx.x;
+        for (int s = 1; s < 4; ++s) {
+            const float v = s_best[s][l];
+            const int r = s_arg[s][l];
+            if (r >= 0 && (arg < 0 || v > best || (v != v && best == best))) best = v, arg = r;
+        }
+        out[(int64_t)o * ldo + c] = best;
+        argrow[(int64_t)o * lda + c] = (int)arg;
+    }
 }
 
 extern "C" int tgp_colmax_arg(const float *x, int ld, int objects, int n, int C, const float *mean, const float *var, float eps,
@@ -433,7 +452,7 @@ extern "C" int tgp_colmax_arg(const float *x, int ld, int objects, int n, int C,
     TGP_REQUIRE(x && out && argrow && objects > 0 && n > 0 && C > 0 && ld >= C && ldo >= C && lda >= C);
     TGP_REQUIRE(!mean || (var && gamma && beta));
     TGP_REQUIRE((int64_t)objects * n < 0x7fffffff);
-    hipLaunchKernelGGL(colmax_arg_kernel, dim3(tgp_cdiv(C, 64), objects), dim3(64), 0, tgp_hs(stream), x, ld, n, C, mean, var, eps,
+    hipLaunchKernelGGL(colmax_arg_kernel, dim3(tgp_cdiv(C, 64), objects), dim3(256), 0, tgp_hs(stream), x, ld, n, C, mean, var, eps,
                        gamma, beta, act, slope, slope_vec, out, ldo, argrow, lda);
     return TGP_LAUNCH_RESULT();
 }
