@@ -28,7 +28,7 @@ for (M, N, K, LD) in shapes:
     for mode, split in (("split", ops.split_bf16), ("split16", ops.split_f16)):
         ops.GEMM_MODE = mode
         WS = split(W[:, :K].contiguous())
-        for v in ((1,) if mode == "split" else (2, 18)):
+        for v in ((1,) if mode == "split" else (2, 66)):
             lib.tgp_debug_set_split_variant(v)
             t = timeit(lambda: ops.gemm(A, W, C, M=M, N=N, K=K, lda=LD, ldw=LD, ldc=N, w_split=WS))
             line += "  %s/v%d %.3f ms %.0f TF" % (mode, v, t, flops / t / 1e9)

@@ -686,6 +686,155 @@ __global__ __launch_bounds__(1024) void gemm_split_kernel(GemmParams p)
     }
 }
 
+// 256 x 256 fp16-split tile with 32-wide K steps: half the barriers of the BK = 16 form (24 MFMAs per wave between
+// barriers).  LDS rows are 64 bytes (32 fp16) without padding -- two stages of 2 planes x 512 rows = 128 KB -- and the four
+// 16-byte chunks of a row are XOR-swizzled with (row >> 2) & 3, which makes the ds_read_b128 fragment reads (16 lanes per
+// LDS cycle: rows {0-3,12-15,20-27} / {4-11,16-19,28-31} of a 32-row block) hit 64 distinct banks.  One register slot of
+// prefetch (a step is ~2 us of matrix work, enough to cover the loads issued one step ahead).
+template <int BM, int BN, int NWM, int NWN>
+__device__ __forceinline__ void gemm_split_tile32(const GemmParams &p, const int m0, const int n0, const int z, char *smem)
+{
+    constexpr int THREADS = 64 * NWM * NWN;
+    constexpr int BK = 32, ROWB = 64, NP = 2;
+    constexpr int WTM = BM / NWM, WTN = BN / NWN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int RPP = THREADS / 8;                 // A: 8 threads per row, one float4 each
+    constexpr int PA = BM / RPP;
+    constexpr int WCH = BN * 8;                      // W: 16-byte chunks per step (2 K-tiles x 2 planes x 2 halves)
+    constexpr int PW = WCH / THREADS;
+    constexpr int PLANE_A = BM * ROWB, PLANE_W = BN * ROWB;
+    constexpr int BUFB = NP * (PLANE_A + PLANE_W);
+    static_assert(BM % RPP == 0 && WCH % THREADS == 0, "tile / thread mapping");
+    char *lds_a = smem;
+    char *lds_w = smem + NP * PLANE_A;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int r = lane & 31, h = lane >> 5;
+    const float *A = p.A + (int64_t)z * p.sA;
+    const uint16_t *WS = p.Wsplit + (int64_t)z * p.sWS;
+    const int64_t wrow = NP * (int64_t)p.ldws;
+
+    const int kq = tid & 7, r0 = tid >> 3;
+    float4 ra[PA];
+    uint4 rw[PW];
+    const int64_t a_rows = p.M - m0, w_rows = p.N - n0;
+    const int64_t a_bytes = a_rows * p.lda * 4 - (p.lda - p.K) * 4, w_bytes = w_rows * wrow * 2;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(A + (int64_t)m0 * p.lda), 0, (int)(a_bytes > 0x7fffffff ? 0x7fffffff : a_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t *>(WS + (int64_t)n0 * wrow), 0, (int)(w_bytes > 0x7fffffff ? 0x7fffffff : w_bytes), 0x00020000);
+    int voff_a[PA], voff_w[PW], lds_wo[PW];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) voff_a[i] = ((r0 + RPP * i) * p.lda + kq * 4) * 4;
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int g = tid + THREADS * i;
+        const int row = g >> 3, cc = g & 7;           // cc: K-tile t = cc >> 2, plane = (cc >> 1) & 1, half = cc & 1
+        voff_w[i] = (int)(row * wrow * 2) + (cc >> 2) * 64 + ((cc >> 1) & 1) * 32 + (cc & 1) * 16;
+        const int chunk = ((cc >> 2) * 2 + (cc & 1)) ^ ((row >> 2) & 3);
+        lds_wo[i] = ((cc >> 1) & 1) * PLANE_W + row * ROWB + chunk * 16;
+    }
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff_a[i], kt * (BK * 4), 0));
+#pragma unroll
+        for (int i = 0; i < PW; ++i)
+            rw[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff_w[i], kt * 128, 0));
+    };
+    auto store_tile = [&](int buf, const int kt) {
+        const uint32_t km = (kt * BK + kq * 4 < p.K) ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int row = r0 + RPP * i;
+            const uint4 rbits = __builtin_bit_cast(uint4, ra[i]);
+            const float4 v = __builtin_bit_cast(float4, make_uint4(rbits.x & km, rbits.y & km, rbits.z & km, rbits.w & km));
+            uint2 q0, q1;
+            split2(v, q0, q1);
+            char *dst = lds_a + buf * BUFB + row * ROWB + (((kq >> 1) ^ ((row >> 2) & 3)) * 16) + (kq & 1) * 8;
+            *reinterpret_cast<uint2 *>(dst) = q0;
+            *reinterpret_cast<uint2 *>(dst + PLANE_A) = q1;
+        }
+#pragma unroll
+        for (int i = 0; i < PW; ++i) *reinterpret_cast<uint4 *>(lds_w + buf * BUFB + lds_wo[i]) = rw[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int numK = (p.K + BK - 1) / BK;
+    unsigned long long st0 = 0, st1 = 0, st2 = 0;
+    if (p.stamps) st0 = __builtin_amdgcn_s_memrealtime();
+    load_tile(0);
+    store_tile(0, 0);
+    __syncthreads();
+    if (p.stamps) st1 = __builtin_amdgcn_s_memrealtime();
+    const int swz = (r >> 2) & 3;
+    for (int kt = 0; kt < numK; ++kt) {
+        load_tile(kt + 1);        // unconditional: past K the descriptors return zeros / the A mask clears the quad
+        const int cur = kt & 1;
+        const char *as = lds_a + cur * BUFB + (wm * WTM + r) * ROWB;
+        const char *ws = lds_w + cur * BUFB + (wn * WTN + r) * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int co = ((2 * kk + h) ^ swz) * 16;
+            uint4 a[TM][NP];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) a[i][q] = *reinterpret_cast<const uint4 *>(as + i * 32 * ROWB + q * PLANE_A + co);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                uint4 b[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) b[q] = *reinterpret_cast<const uint4 *>(ws + j * 32 * ROWB + q * PLANE_W + co);
+#define T32(QA, QB)                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                    \
+        __builtin_bit_cast(f16x8, a[i][QA]), __builtin_bit_cast(f16x8, b[QB]), acc[i][j], 0, 0, 0);
+                T32(0, 1)
+                T32(1, 0)
+                T32(0, 0)
+#undef T32
+            }
+            if (kk == 0) store_tile(cur ^ 1, kt + 1);     // between the two halves: under the other waves' MFMAs
+        }
+        __syncthreads();
+    }
+    if (p.stamps) st2 = __builtin_amdgcn_s_memrealtime();
+    if (!(p.rowbias || p.cm) || p.rows_per_obj >= WTM) gemm_epilogue_fast<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h);
+    else gemm_epilogue<TM, TN, WTM, WTN, false>(p, acc, m0, n0, z, wm, wn, r, h);
+    if (p.stamps && threadIdx.x == 0) {
+        unsigned long long *o = p.stamps + 5 * (size_t)blockIdx.x;
+        o[0] = st0, o[1] = st1, o[2] = st2, o[3] = __builtin_amdgcn_s_memrealtime(), o[4] = 0;
+    }
+}
+
+__global__ __launch_bounds__(1024) void gemm_split32_kernel(GemmParams p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * (256 + 256) * 64];
+    int seg = 0;
+    while (seg < p.nseg - 1 && (int)blockIdx.x >= p.seg_end[seg]) ++seg;
+    int L = p.seg_base[seg] + (int)blockIdx.x - (seg ? p.seg_end[seg - 1] : 0);
+    if (!((p.seg_small >> seg) & 1)) {
+        const int per_batch = p.mt_big * p.tiles_n_big;
+        const int z = L / per_batch;
+        L -= z * per_batch;
+        gemm_split_tile32<256, 256, 4, 4>(p, (L / p.tiles_n_big) * 256, (L % p.tiles_n_big) * 256, z, smem);
+    } else {
+        const int per_batch = p.tiles_m_small * p.tiles_n_small;
+        const int z = L / per_batch;
+        L -= z * per_batch;
+        gemm_split_tile<128, 128, 4, 4, 2, true, false>(p, p.mt_big * 256 + (L / p.tiles_n_small) * 128, (L % p.tiles_n_small) * 128, z, smem);
+    }
+}
+
 // The same tiles as two independent 512-thread workgroups per CU (256 x 128 outputs each, 4 x 2 waves of 64 x 64; tail:
 // 128 x 128).  Two barrier domains per CU de-phase on their own: while one workgroup waits at its barrier or runs its
 // epilogue the other keeps the matrix cores busy.  The price is 1.5x the operand traffic per output (A rows are shared
@@ -1032,6 +1181,12 @@ static int launch_split(GemmParams &p, hipStream_t stream)
     }
     const int64_t S = resident_slots();
     plan_tiles(p, GEMM_BIG, S, 0.27, 3);
+    if (p.split_f16 && tgp_split_variant != 7 && (tgp_split_variant & 64)) {
+        order_tiles(p, S, false);
+        p.stamps = tgp_split_stamps;
+        hipLaunchKernelGGL(gemm_split32_kernel, dim3(p.tiles_big + p.tiles_m_small * p.tiles_n_small * p.batch), dim3(1024), 0, stream, p);
+        return TGP_LAUNCH_RESULT();
+    }
     const bool stagger = (tgp_split_variant & 8) != 0 && tgp_split_variant != 7;
     if (stagger && p.tiles_big >= 3 * S) {
         // hand enough M-tile rows to the half-size tiles for the staggered start (1.5 S of them)
