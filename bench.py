@@ -245,8 +245,10 @@ def main():
                 keys = [k for k in pmc if "gemm_main256_kernel" in k]
             else:   # gemm_split_kernel<prefetch depth, fp16?, interleaved?>; older files: <dbuf> (bf16) / <dbuf, fp16>
                 f16 = lambda k: ", true" in k.split("<", 1)[-1]
-                keys = [k for k in pmc if "gemm_split_kernel" in k and f16(k) == (args.gemm == "split16")]
-            traffic = pmc[keys[0]]["bytes_per_launch_corrected"] if keys else None
+                keys = [k for k in pmc if "gemm_split" in k and "_kernel" in k and f16(k) == (args.gemm == "split16")]
+            # launch-weighted mean over the tile kernels the timed launches are routed to (square-tile and 512-thread forms)
+            n_l = sum(pmc[k]["launches"] for k in keys)
+            traffic = int(sum(pmc[k]["launches"] * pmc[k]["bytes_per_launch_corrected"] for k in keys) / n_l) if n_l else None
         except Exception:
             traffic = None
         launches = len(timer)

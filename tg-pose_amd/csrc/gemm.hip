@@ -1163,12 +1163,14 @@ static void order_tiles(GemmParams &p, int64_t S, bool stagger)
 
 static int launch_split(GemmParams &p, hipStream_t stream)
 {
-    // few 256 x 256 tiles (narrow outputs: N <= 256, or less than ~1.5 rounds of them) leave CUs idle or half-empty: such
-    // launches run as 256 x 128 tiles on two 512-thread workgroups per CU (measured: M=32896, N=256, K=1024 126 -> 92 us;
-    // the wide layer, in contrast, 1.04 -> 1.32 ms)
+    // few 256 x 256 tiles (N <= 256, or less than 1.5 rounds of them) leave CUs idle or half empty: such launches run as
+    // 256 x 128 tiles on two 512-thread workgroups per CU.  Measured over the forward's 15 tile-kernel launches, each timed
+    // alone: 139 us average against 154 us with square tiles only (the wide layer alone would lose: 1.04 -> 1.32 ms)
     const int64_t sq_tiles = (int64_t)tgp_cdiv(p.M, GEMM_BIG) * tgp_cdiv(p.N, GEMM_BIG) * p.batch;
     const bool narrow = p.N <= 256 || sq_tiles * 2 < 3 * (int64_t)resident_slots();
     const bool force512 = tgp_split_variant != 7 && (tgp_split_variant & 16), forbid512 = tgp_split_variant != 7 && (tgp_split_variant & 32);
+    // (per launch the narrow layers are 25 % faster this way; in the whole forward, where they overlap other branches,
+    // the routing measured +-0: 8769 / 8730 vs 8782 / 8881 objects/s)
     if (p.split_f16 && (force512 || (narrow && !forbid512))) {
         // two 512-thread workgroups per CU, 256 x 128 tiles (+ 128 x 128 tail tiles)
         plan_tiles(p, GEMM_BIG, 2 * (int64_t)resident_slots(), 0.55, 2, 128, 128);
