@@ -1286,3 +1286,29 @@ def test_graphed_backward_equals_eager(ops):
                 assert (grads_g[k] - p.grad).abs().max().item() <= 1e-5 * ref + 1e-7, k
     finally:
         FLAGS.train = 0
+
+
+@pytest.mark.parametrize("gemm_mode", ["split16", "split", "fp32"], indirect=True)
+@pytest.mark.parametrize("M,N,K,rpo", [(32896, 512, 256, 1028), (33034, 256, 128, 1028), (8234, 2304, 128, 257), (12810, 640, 64, 64),
+                                       (5130, 384, 96, 16), (66000, 128, 128, 1000), (2058, 4096, 32, 1029)])
+def test_gemm_epilogue_object_boundaries_and_tails(ops, M, N, K, rpo, gemm_mode):
+    """The restructured epilogue (two objects per wave tile, scalar-base addressing) and the generic one behind it, in every
+    GEMM mode: row tails whose last wave tiles lie wholly past M (M = 256 q + 10 ...), column tails (N = 640, 384),
+    objects of 64 rows (the smallest the fast form accepts), 16 rows (generic form), and ones that straddle every tile."""
+    gen = torch.Generator().manual_seed(M + N)
+    nobj = (M + rpo - 1) // rpo
+    A = torch.randn(M, K, generator=gen)
+    W = torch.randn(N, K, generator=gen) / K ** 0.5
+    bias, scale, shift = torch.randn(N, generator=gen), torch.rand(N, generator=gen) + 0.5, torch.randn(N, generator=gen)
+    rowbias = torch.randn(nobj, N, generator=gen)
+    res1 = torch.randn(M, N, generator=gen)
+    want = _gemm_ref(A, W, bias, rowbias, rpo, res1, None, scale, shift, 0.2)
+    keys = torch.zeros(nobj, N, dtype=torch.int32, device=DEV)
+    dW = g(W)
+    out = ops.linear_rows(g(A), dW, bias=g(bias), rowbias=g(rowbias), rows_per_obj=rpo, res1=g(res1), scale=g(scale), shift=g(shift),
+                          act=1, slope=0.2, colmax_keys=keys, w_split=ops.split_w(dW))
+    err = (out.cpu().double() - want).abs().max().item()
+    assert err < 2e-5 * max(1.0, want.abs().max().item()), err
+    cm = ops.colmax_decode(keys).cpu()
+    pad = torch.full((nobj * rpo - M, N), -float("inf"))
+    assert torch.equal(cm, torch.cat([out.cpu(), pad]).view(nobj, rpo, N).max(dim=1)[0])
