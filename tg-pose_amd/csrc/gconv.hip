@@ -139,6 +139,118 @@ __global__ __launch_bounds__(256) void gconv_kernel(const float *__restrict__ xy
     }
 }
 
+// HS_layer.graph_conv with the object's support table staged in LDS ("LDS-staged neighbour tiles").
+// The wave-per-point kernel above gathers k rows of 7C floats per point from L2: every support row is fetched ~k times
+// (conv_1: 2.4 GB of L2 -> CU traffic per forward for a 118 MB table), and the L2's bandwidth bounds it.  Here a workgroup
+// owns (object, CH channels): it loads that channel slice of the object's table -- [n][7][CH] floats, each element of the
+// table read from global memory exactly once per forward -- plus the object's xyz into LDS, then every thread (point,
+// channel quad) walks its k neighbours with ds_read_b128.  Same per-element arithmetic and order as gconv_kernel (fmaf
+// chain, max over neighbours, sequential mean over the 7 supports): results are bit-identical.
+template <int CH>
+__global__ __launch_bounds__(1024) void gconv_lds_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ idx,
+                                                         const float *__restrict__ proj, int ldp, const float *__restrict__ sdn,
+                                                         int B, int n, int k, int C, float *__restrict__ out, int ldo)
+{
+    extern __shared__ __attribute__((aligned(16))) float gl_smem[];
+    constexpr int QC = CH / 4;                 // float4 chunks per table row segment (fill)
+    constexpr int PC = CH / 2;                 // channel pairs per workgroup: a thread owns (point, pair) -- 42 direction
+    constexpr int ROW = GC_S * CH;             // registers instead of 84, which keeps 4 waves per SIMD
+    float4 *s_xyz = reinterpret_cast<float4 *>(gl_smem);
+    float *s_tab = gl_smem + 4 * n;
+    int b, chunk;
+    if (!tgp_xcd_object_tile(blockIdx.x, B, C / CH, b, chunk)) return;
+    const int c0 = chunk * CH;
+    const int SC = GC_S * C;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    for (int i = tid; i < n; i += nthr) {
+        const float *pt = xyz + ((int64_t)b * n + i) * 3;
+        s_xyz[i] = make_float4(pt[0], pt[1], pt[2], 0.f);
+    }
+    for (int e = tid; e < n * GC_S * QC; e += nthr) {
+        const int row = e / (GC_S * QC), rem = e - row * (GC_S * QC);
+        const int sidx = rem / QC, q = rem - sidx * QC;
+        const float4 v = *reinterpret_cast<const float4 *>(proj + ((int64_t)b * n + row) * ldp + C + sidx * C + c0 + q * 4);
+        *reinterpret_cast<float4 *>(s_tab + row * ROW + sidx * CH + q * 4) = v;
+    }
+    const int q = tid % PC, pl = tid / PC, pstep = nthr / PC;
+    const int cb = c0 + q * 2;
+    float2 sd[GC_S][3];
+#pragma unroll
+    for (int sidx = 0; sidx < GC_S; ++sidx)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sd[sidx][c] = *reinterpret_cast<const float2 *>(sdn + c * SC + sidx * C + cb);
+    __syncthreads();
+    for (int i = pl; i < n; i += pstep) {
+        const int64_t rowi = (int64_t)b * n + i;
+        const float4 pc = s_xyz[i];
+        float2 m[GC_S];
+#pragma unroll
+        for (int sidx = 0; sidx < GC_S; ++sidx) m[sidx] = make_float2(-INFINITY, -INFINITY);
+        const int32_t *nbrs = idx + rowi * k;
+#pragma unroll 4
+        for (int j = 0; j < k; ++j) {
+            const int nb = nbrs[j];
+            const float4 pn = s_xyz[nb];
+            float dx = pn.x - pc.x, dy = pn.y - pc.y, dz = pn.z - pc.z;
+            const float nrm = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-12f);
+            const float ux = dx / nrm, uy = dy / nrm, uz = dz / nrm;
+            const float *trow = s_tab + nb * ROW + q * 2;
+#pragma unroll
+            for (int sidx = 0; sidx < GC_S; ++sidx) {
+                const float2 sup = *reinterpret_cast<const float2 *>(trow + sidx * CH);
+                float2 t;
+                t.x = fmaf(uz, sd[sidx][2].x, fmaf(uy, sd[sidx][1].x, ux * sd[sidx][0].x));
+                t.y = fmaf(uz, sd[sidx][2].y, fmaf(uy, sd[sidx][1].y, ux * sd[sidx][0].y));
+                t.x = fmaxf(t.x, 0.f) * sup.x, t.y = fmaxf(t.y, 0.f) * sup.y;
+                m[sidx].x = fmaxf(m[sidx].x, t.x), m[sidx].y = fmaxf(m[sidx].y, t.y);
+            }
+        }
+        float2 acc = m[0];   // torch.mean over the 7 supports: sequential sum, then / 7
+#pragma unroll
+        for (int sidx = 1; sidx < GC_S; ++sidx) acc.x += m[sidx].x, acc.y += m[sidx].y;
+        acc.x = acc.x / 7.0f, acc.y = acc.y / 7.0f;
+        const float2 ctr = *reinterpret_cast<const float2 *>(proj + rowi * ldp + cb);
+        acc.x = ctr.x + acc.x, acc.y = ctr.y + acc.y;
+        *reinterpret_cast<float2 *>(out + rowi * ldo + cb) = acc;
+    }
+}
+
+// picks the widest channel slice whose table fits with two workgroups per CU (<= 72 KB): measured 137 -> 88 us (n = 257,
+// C = 256), 37 -> 25 us (n = 64, C = 512); larger clouds keep the L2 gather
+template <int CH>
+static int gconv_lds_go(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B, int n, int k,
+                        int C, float *out, int ldo, size_t lds, hipStream_t stream)
+{
+    auto fn = gconv_lds_kernel<CH>;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int threads = lds > 72 * 1024 ? 1024 : 512;
+    hipLaunchKernelGGL(fn, dim3(tgp_xcd_grid(B, C / CH)), dim3(threads), lds, stream, xyz, idx, proj, ldp, sdn, B, n, k, C, out, ldo);
+    return TGP_LAUNCH_RESULT();
+}
+
+int tgp_gconv_lds_mode = 1;   // development switch (scripts): 0 = always the gather-from-L2 kernel
+extern "C" void tgp_debug_set_gconv_lds(int v) { tgp_gconv_lds_mode = v; }
+
+static int gconv_lds_launch(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B, int n, int k,
+                            int C, float *out, int ldo, hipStream_t stream, bool &done)
+{
+    done = false;
+    if (!tgp_gconv_lds_mode) return 0;
+    auto bytes = [&](int ch) { return (size_t)n * (GC_S * ch + 4) * sizeof(float); };
+    done = true;
+    if (bytes(16) <= 72 * 1024 && C % 16 == 0) return gconv_lds_go<16>(xyz, idx, proj, ldp, sdn, B, n, k, C, out, ldo, bytes(16), stream);
+    if (bytes(8) <= 72 * 1024 && C % 8 == 0) return gconv_lds_go<8>(xyz, idx, proj, ldp, sdn, B, n, k, C, out, ldo, bytes(8), stream);
+    // a 4-channel slice (n = 1028: 131 KB, one workgroup per CU) measured slower than the L2 gather: 208 vs 168 us
+    if (tgp_gconv_lds_mode == 2 && bytes(4) <= 150 * 1024) return gconv_lds_go<4>(xyz, idx, proj, ldp, sdn, B, n, k, C, out, ldo, bytes(4), stream);
+    done = false;
+    return 0;
+}
+
 static int gconv_check(const void *xyz, const void *idx, const void *sdn, const void *out, int B, int n, int k, int S,
                        int C, int ldo)
 {
@@ -179,6 +291,9 @@ extern "C" int tgp_gconv_hs_fwd(const float *xyz, const int32_t *idx, const floa
     const int chk = gconv_check(xyz, idx, sdn, out, B, n, k, S, C, ldo);
     if (chk) return chk;
     TGP_REQUIRE(proj && ldp >= (S + 1) * C && (ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(proj) & 15) == 0);
+    bool done = false;
+    const int rc = gconv_lds_launch(xyz, idx, proj, ldp, sdn, B, n, k, C, out, ldo, tgp_hs(stream), done);
+    if (done || rc) return rc;
     return gconv_launch<false>(xyz, idx, proj, ldp, sdn, B, n, k, C, out, ldo, tgp_hs(stream));
 }
 
