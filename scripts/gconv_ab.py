@@ -29,3 +29,18 @@ for (B, n, k, C) in ((32, 1028, 20, 128), (32, 257, 20, 256), (32, 64, 8, 512), 
     print("B=%d n=%d k=%d C=%d  L2-gather %.1f us  LDS-staged %.1f us  identical %s" % (
         B, n, k, C, res[0][1] * 1e3, res[1][1] * 1e3, torch.equal(res[0][0], res[1][0])), flush=True)
 lib.tgp_debug_set_gconv_lds(1)
+
+print("ORL pooling (orl_rowbias):")
+for (B, n, k, C) in ((32, 1028, 20, 128), (32, 257, 20, 256), (32, 64, 8, 512), (5, 300, 12, 256)):
+    idx = torch.stack([torch.stack([torch.randperm(n, generator=gen)[:k] for _ in range(n)]) for _ in range(min(B, 4))]).int()
+    idx = idx.repeat((B + 3) // 4, 1, 1)[:B].contiguous().to(dev)
+    feat = torch.randn(B, n, C, generator=gen).to(dev)
+    w2t = torch.randn(C, C, generator=gen).to(dev)
+    res = {}
+    for mode in (0, 1):
+        lib.tgp_debug_set_orl_lds(mode)
+        out = ops.orl_rowbias(feat, idx, w2t)
+        res[mode] = (out.clone(), timeit(lambda: ops.orl_rowbias(feat, idx, w2t)))
+    print("B=%d n=%d k=%d C=%d  L2-gather %.1f us  LDS-staged %.1f us  identical %s" % (
+        B, n, k, C, res[0][1] * 1e3, res[1][1] * 1e3, torch.equal(res[0][0], res[1][0])), flush=True)
+lib.tgp_debug_set_orl_lds(1)

@@ -348,6 +348,80 @@ __global__ __launch_bounds__(256) void orl_partial_kernel(const float *__restric
     }
 }
 
+// The same neighbour max / per-tile point sums with the object's feature table staged in LDS in 16-channel slices
+// (n = 1028: 66 KB), every row read from global memory once instead of ~k times.  A thread owns (point tile, wave slot,
+// channel pair) and reproduces the summation order of orl_partial_kernel exactly (slot w sums points w, w+4, ... of the
+// tile, then ((s0 + s1) + s2) + s3), so `partial` is bit-identical.
+#define ORL_CH 16
+__global__ __launch_bounds__(1024) void orl_lds_kernel(const float *__restrict__ feat, int ldf, const int32_t *__restrict__ idx, int B,
+                                                       int n, int k, int C, float *__restrict__ partial, int ptiles)
+{
+    extern __shared__ __attribute__((aligned(16))) float ol_smem[];
+    float *s_tab = ol_smem;                          // [n][ORL_CH]
+    float *s_red = ol_smem + (size_t)n * ORL_CH;     // [ptiles][4][ORL_CH]
+    int b, chunk;
+    if (!tgp_xcd_object_tile(blockIdx.x, B, C / ORL_CH, b, chunk)) return;
+    const int c0 = chunk * ORL_CH;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    for (int e = tid; e < n * (ORL_CH / 4); e += nthr) {
+        const int row = e / (ORL_CH / 4), q = e % (ORL_CH / 4);
+        *reinterpret_cast<float4 *>(s_tab + row * ORL_CH + q * 4) =
+            *reinterpret_cast<const float4 *>(feat + ((int64_t)b * n + row) * ldf + c0 + q * 4);
+    }
+    __syncthreads();
+    constexpr int PC = ORL_CH / 2;
+    for (int t = tid; t < ptiles * 4 * PC; t += nthr) {
+        const int pair = t % PC, w = (t / PC) & 3, pt = t / (4 * PC);
+        float2 sum = make_float2(0.f, 0.f);
+        for (int pp = w; pp < ORL_PTS; pp += 4) {
+            const int i = pt * ORL_PTS + pp;
+            if (i >= n) break;
+            const int32_t *nb = idx + ((int64_t)b * n + i) * k;
+            float2 m = make_float2(-INFINITY, -INFINITY);
+#pragma unroll 4
+            for (int j = 0; j < k; ++j) {
+                const float2 v = *reinterpret_cast<const float2 *>(s_tab + nb[j] * ORL_CH + pair * 2);
+                m.x = fmaxf(m.x, v.x), m.y = fmaxf(m.y, v.y);
+            }
+            sum.x += m.x, sum.y += m.y;
+        }
+        *reinterpret_cast<float2 *>(s_red + (pt * 4 + w) * ORL_CH + pair * 2) = sum;
+    }
+    __syncthreads();
+    for (int t = tid; t < ptiles * ORL_CH; t += nthr) {
+        const int pt = t / ORL_CH, c = t % ORL_CH;
+        const float *r = s_red + pt * 4 * ORL_CH + c;
+        partial[((int64_t)b * ptiles + pt) * C + c0 + c] = ((r[0] + r[ORL_CH]) + r[2 * ORL_CH]) + r[3 * ORL_CH];
+    }
+}
+
+int tgp_orl_lds_mode = 1;   // development switch: 0 = always the gather-from-L2 kernel
+extern "C" void tgp_debug_set_orl_lds(int v) { tgp_orl_lds_mode = v; }
+
+// returns true when the LDS form was launched
+static bool orl_lds_launch(const float *feat, int ldf, const int32_t *idx, int B, int n, int k, int C, float *partial, int ptiles,
+                           hipStream_t stream, int &rc)
+{
+    rc = 0;
+    const size_t lds = ((size_t)n * ORL_CH + (size_t)ptiles * 4 * ORL_CH) * sizeof(float);
+    if (!tgp_orl_lds_mode || lds > 72 * 1024 || C % ORL_CH) return false;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(orl_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+        if (e != hipSuccess) {
+            rc = (int)e;
+            return true;
+        }
+        attr_set = true;
+    }
+    const int slots = ptiles * 4 * (ORL_CH / 2);
+    const int threads = slots >= 768 ? 1024 : (slots >= 384 ? 512 : 256);
+    hipLaunchKernelGGL(orl_lds_kernel, dim3(tgp_xcd_grid(B, C / ORL_CH)), dim3(threads), lds, stream, feat, ldf, idx, B, n, k, C, partial,
+                       ptiles);
+    rc = TGP_LAUNCH_RESULT();
+    return true;
+}
+
 __global__ void orl_finish_kernel(const float *__restrict__ partial, int B, int n, int C, int ptiles,
                                   float *__restrict__ out)
 {
@@ -409,7 +483,10 @@ extern "C" int tgp_orl_global(const float *feat, int ldf, const int32_t *idx, in
         hipLaunchKernelGGL(orl_partial_kernel<CC>, dim3(tgp_xcd_grid(B, tiles)), dim3(256), 0, tgp_hs(stream), feat,  \
                            ldf, idx, B, n, k, partial, ptiles, tiles);                                               \
     }
-    if (C == 128) ORL_GO(128) else if (C == 256) ORL_GO(256) else ORL_GO(512)
+    int lrc = 0;
+    if (orl_lds_launch(feat, ldf, idx, B, n, k, C, partial, ptiles, tgp_hs(stream), lrc)) {
+        if (lrc) return lrc;
+    } else if (C == 128) ORL_GO(128) else if (C == 256) ORL_GO(256) else ORL_GO(512)
 #undef ORL_GO
     hipLaunchKernelGGL(orl_finish_kernel, dim3(tgp_cdiv(B * C, 256)), dim3(256), 0, tgp_hs(stream), partial, B, n, C,
                        ptiles, out);
@@ -430,7 +507,10 @@ extern "C" int tgp_orl_rowbias(const float *feat, int ldf, const int32_t *idx, i
         hipLaunchKernelGGL(orl_partial_kernel<CC>, dim3(tgp_xcd_grid(B, tiles)), dim3(256), 0, tgp_hs(stream), feat,  \
                            ldf, idx, B, n, k, partial, ptiles, tiles);                                               \
     }
-    if (C == 128) ORL_GO(128) else if (C == 256) ORL_GO(256) else ORL_GO(512)
+    int lrc = 0;
+    if (orl_lds_launch(feat, ldf, idx, B, n, k, C, partial, ptiles, tgp_hs(stream), lrc)) {
+        if (lrc) return lrc;
+    } else if (C == 128) ORL_GO(128) else if (C == 256) ORL_GO(256) else ORL_GO(512)
 #undef ORL_GO
     hipLaunchKernelGGL(orl_finish_project_kernel, dim3(B, C / 64), dim3(256), 0, tgp_hs(stream), partial, n, C, ptiles, w2t, g_out,
                        rb);
