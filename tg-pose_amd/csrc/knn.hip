@@ -157,6 +157,34 @@ extern "C" int tgp_center(const float *points, int B, int n, float *xyz_c, float
 // (distance, slot) keys in one pass; a round is then a 6-step butterfly argmin over the cache heads plus a pop on
 // the winning lane.  A lane rarely owns more than 3 of the k+1 nearest (0.5 % of lanes at k = 20, n = 1028); when one
 // runs dry the whole wave rebuilds its caches from the keys greater than the last one each lane gave away.
+// Wave-wide unsigned minimum on the VALU: four DPP steps (quad swaps, half-row and row mirrors) leave every 16-lane row
+// uniform, the four row values are combined on the scalar unit.  No LDS crossbar (ds_bpermute) round trips: the selection
+// below is a chain of dependent wave reductions, and each __shfl_xor in it cost a crossbar latency.
+__device__ __forceinline__ uint32_t wave_umin(uint32_t v)
+{
+    uint32_t o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false); // row_half_mirror
+    v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false); // row_mirror
+    v = o < v ? o : v;
+    const uint32_t r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+    return a < b ? a : b;
+}
+
+// (distance, index) argmin over the wave: the smallest order-preserving key, then the smallest index among its holders
+__device__ __forceinline__ int wave_argmin(float best, int bj)
+{
+    const uint32_t key = tgp_float_key(best);
+    const uint32_t mk = wave_umin(key);
+    return (int)wave_umin(key == mk ? (uint32_t)bj : 0xffffffffu);
+}
+
 template <int NT>
 __device__ __forceinline__ void wave_select(float (&d)[NT], int lane, int k, int32_t *__restrict__ out_row)
 {
@@ -171,15 +199,7 @@ __device__ __forceinline__ void wave_select(float (&d)[NT], int lane, int k, int
                 best = lt ? d[t] : best;
                 bt = lt ? t : bt;
             }
-            int bj = lane + (bt << 6);
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float od = __shfl_xor(best, off, 64);
-                const int oj = __shfl_xor(bj, off, 64);
-                const bool take = (od < best) || (od == best && oj < bj);
-                best = take ? od : best;
-                bj = take ? oj : bj;
-            }
+            int bj = wave_argmin(best, lane + (bt << 6));
             const int owner = bj & 63, slot = bj >> 6;
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -209,16 +229,8 @@ __device__ __forceinline__ void wave_select(float (&d)[NT], int lane, int k, int
         };
         refill();
         for (int r = 0; r <= k; ++r) {
-            float best = c0;
-            int bj = lane + (s0 << 6); // an empty cache (s0 == NT) carries distance +inf and never wins a finite round
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float od = __shfl_xor(best, off, 64);
-                const int oj = __shfl_xor(bj, off, 64);
-                const bool take = (od < best) || (od == best && oj < bj);
-                best = take ? od : best;
-                bj = take ? oj : bj;
-            }
+            // an empty cache (s0 == NT) carries distance +inf and never wins a finite round
+            const int bj = wave_argmin(c0, lane + (s0 << 6));
             if (r >= 1 && lane == r - 1) mine = bj;
             bool dry = false;
             if (lane == (bj & 63)) { // pop
