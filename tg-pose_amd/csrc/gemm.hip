@@ -260,15 +260,24 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, const int m0, con
             }
         }
     };
+    // NATURAL_K reads single floats (row r, column 2s + h) -- with rows LD = BK + 4 floats apart, rows r and r + 8 share a
+    // bank: a 4-way conflict on every operand read.  The two low column bits are therefore XOR-ed with (row >> 3) & 3: the
+    // four rows that collide land in the four banks of one aligned quad (a float4 store just permutes its components).
+    auto swz = [&](const float4 v, const int row) -> float4 {
+        if constexpr (!NATURAL_K) return v;
+        const int g = (row >> 3) & 3;
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        return make_float4(e[0 ^ g], e[1 ^ g], e[2 ^ g], e[3 ^ g]);
+    };
     auto store_tile = [&](int buf) {
         float *as = smem + buf * BUF;
         float *ws = as + BM * LD;
 #pragma unroll
         for (int i = 0; i < PA; ++i)
-            if (RPP * i + r0 < BM) *reinterpret_cast<float4 *>(as + (r0 + RPP * i) * LD + kq * 4) = ra[i];
+            if (RPP * i + r0 < BM) *reinterpret_cast<float4 *>(as + (r0 + RPP * i) * LD + kq * 4) = swz(ra[i], r0 + RPP * i);
 #pragma unroll
         for (int i = 0; i < PW; ++i)
-            if (RPP * i + r0 < BN) *reinterpret_cast<float4 *>(ws + (r0 + RPP * i) * LD + kq * 4) = rw[i];
+            if (RPP * i + r0 < BN) *reinterpret_cast<float4 *>(ws + (r0 + RPP * i) * LD + kq * 4) = swz(rw[i], r0 + RPP * i);
     };
 
     f32x16 acc[TM][TN];
@@ -295,9 +304,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, const int m0, con
             for (int s = 0; s < BK / 2; ++s) {
                 float a[TM], b[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = as[i * 32 * LD + 2 * s + h];
+                for (int i = 0; i < TM; ++i) a[i] = as[i * 32 * LD + ((2 * s + h) ^ ((r >> 3) & 3))];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = ws[j * 32 * LD + 2 * s + h];
+                for (int j = 0; j < TN; ++j) b[j] = ws[j * 32 * LD + ((2 * s + h) ^ ((r >> 3) & 3))];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll

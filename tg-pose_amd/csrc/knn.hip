@@ -182,6 +182,9 @@ __device__ __forceinline__ int wave_argmin(float best, int bj)
 {
     const uint32_t key = tgp_float_key(best);
     const uint32_t mk = wave_umin(key);
+    const unsigned long long holders = __ballot(key == mk);
+    if (__popcll(holders) == 1)                                  // wave-uniform: the usual case, one lane holds the minimum
+        return __builtin_amdgcn_readlane(bj, __ffsll((long long)holders) - 1);
     return (int)wave_umin(key == mk ? (uint32_t)bj : 0xffffffffu);
 }
 
