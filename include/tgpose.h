@@ -314,6 +314,22 @@ int tgp_pose_transform_fwd(const float *points, const float *R, const float *t, 
 int tgp_pose_transform_bwd(const float *points, const float *R, const float *t, const float *s, const float *dout, int B, int n,
                            float *dpoints, float *dR, float *dt, float *ds, tgp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Pairwise metrics of the NOCS pose evaluation (evaluation/eval_utils_v1.py): every (prediction, ground truth) pair of a
+ * result set in one launch, double precision as the numpy original.  RT: (P,4,4) row-major, scales: (P,3).
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* compute_3d_iou_new (:829-887): the reference's IoU of the two posed boxes -- its amax / amin run over axis 0 of the [3, 8]
+ * corner array (:842-845), so the overlap is taken over eight per-corner (min, max) coordinate ranges; reproduced as written.
+ * The fourth RT row is honoured (transform_coordinates_3d divides by it, :1011).  symmetric[t] != 0 (bottle / bowl / can,
+ * mug with a hidden handle) -> the maximum over 20 rotations of box 1 about its own y axis. */
+int tgp_iou3d_pairs(const double *RT1, const double *RT2, const double *scales1, const double *scales2, const int *symmetric,
+                    int P, double *iou, tgp_stream_t stream);
+
+/* compute_RT_degree_cm_symmetry (:890-963): out[t] = {rotation error in degrees, translation error in cm}.
+ * mode[t]: 0 general, 1 symmetric about y (angle between the y axes), 2 symmetric under a half turn about y. */
+int tgp_rt_error_pairs(const double *RT1, const double *RT2, const int *mode, int P, double *out, tgp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -372,7 +372,51 @@ def gen_pose_assembly():
     save("pose_assembly.npz", p_g=p_g, p_r=p_r, f_g=f_g, f_r=f_r, T=T, sym=sym, R_plain=R_plain, R_sym=R_sym)
 
 
+# ----------------------------------------------------------------------------- evaluation metrics (mAP)
+from tests.util import synth_eval_results  # noqa: E402  (pure numpy; shared with the GPU tests)
+
+
+def load_reference_eval():
+    import types
+    for m in ("cv2", "skimage", "skimage.color", "scipy.misc"):       # imported at module level, unused by the mAP path
+        sys.modules.setdefault(m, types.ModuleType(m))
+    return _load_by_path("ref_eval_utils", os.path.join(REF, "evaluation/eval_utils_v1.py"))
+
+
+def gen_eval_map():
+    """compute_degree_cm_mAP of the reference (evaluation/eval_utils_v1.py:1227) on a synthetic result list, with the
+    evaluater's threshold grids (RT_TDA_Evaluater.py:111-124) coarsened, in both pose-matching modes; plus raw pair metrics."""
+    import tempfile
+    ev = load_reference_eval()
+    synset = ['BG', 'bottle', 'bowl', 'camera', 'can', 'laptop', 'mug']
+    res = synth_eval_results(4)
+    deg, shift, iou = list(range(0, 61, 5)), [i / 2 for i in range(0, 21, 2)], [i / 100 for i in range(0, 101, 5)]
+    arrays = dict(seed=np.int64(4), degree=np.array(deg), shift=np.array(shift), iou=np.array(iou))
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, use in (("pose_only", True), ("pose_det", False)):
+            a, b = ev.compute_degree_cm_mAP(res, synset, tmp, deg, shift, iou, iou_pose_thres=0.1, use_matches_for_pose=use,
+                                            plot_figure=False)
+            arrays[tag + ".iou_aps"], arrays[tag + ".pose_aps"] = a, b
+    rng = np.random.RandomState(11)
+    RT1, RT2, S1, S2, sym, mode, out_iou, out_err = [], [], [], [], [], [], [], []
+    names = {0: ("camera", 1), 1: ("bottle", 1), 2: ("phone", 1)}
+    insts = [(r['pred_RTs'][i], r['pred_scales'][i], r['gt_RTs'][j], r['gt_scales'][j])
+             for r in res for i in range(len(r['pred_RTs'])) for j in range(len(r['gt_RTs']))][:120]
+    for k, (a, sa, b, sb) in enumerate(insts):
+        m = k % 3
+        cname, hv = names[m]
+        out_iou.append(ev.compute_3d_iou_new(a, b, sa, sb, hv, cname, cname))
+        out_err.append(ev.compute_RT_degree_cm_symmetry(a, b, 1, hv, ['BG', cname]))
+        RT1.append(a), RT2.append(b), S1.append(sa), S2.append(sb), sym.append(int(cname == "bottle")), mode.append(m)
+    arrays.update(pair_RT1=np.stack(RT1), pair_RT2=np.stack(RT2), pair_S1=np.stack(S1), pair_S2=np.stack(S2),
+                  pair_sym=np.array(sym, dtype=np.int32), pair_mode=np.array(mode, dtype=np.int32),
+                  pair_iou=np.array(out_iou, dtype=np.float64), pair_err=np.stack(out_err).astype(np.float64))
+    np.savez_compressed(os.path.join(HERE, "eval_map.npz"), **arrays)
+    print("wrote eval_map.npz")
+
+
 def main():
+    gen_eval_map()
     gen_pose_assembly()
     gen_dcd()
     gen_knn()

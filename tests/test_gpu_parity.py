@@ -5,6 +5,8 @@ and against the golden vectors recorded from the reference.
 Bars: indices and Chamfer results bit-exact; float layers within 1e-4 (stated per test; most are
 held to a tighter bound).  /root/reference is never touched here.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1312,3 +1314,45 @@ def test_gemm_epilogue_object_boundaries_and_tails(ops, M, N, K, rpo, gemm_mode)
     cm = ops.colmax_decode(keys).cpu()
     pad = torch.full((nobj * rpo - M, N), -float("inf"))
     assert torch.equal(cm, torch.cat([out.cpu(), pad]).view(nobj, rpo, N).max(dim=1)[0])
+
+
+# ----------------------------------------------------------------------------------------- evaluation (f-2: mAP)
+def test_eval_pair_metrics_vs_oracle_and_reference(ops):
+    """tgp_iou3d_pairs / tgp_rt_error_pairs (fp64) against the reference's values (fixture) and the numpy oracle."""
+    from oracle import eval_ref as E
+    from tgpose_amd.evaluation import pair_metrics
+    gd = golden("eval_map.npz")
+    iou, err = pair_metrics(gd["pair_RT1"], gd["pair_RT2"], gd["pair_S1"], gd["pair_S2"], gd["pair_sym"], gd["pair_mode"])
+    assert np.abs(iou - gd["pair_iou"]).max() <= 1e-12
+    assert np.allclose(err, gd["pair_err"], rtol=1e-10, atol=1e-9, equal_nan=True)
+    rng = np.random.RandomState(0)
+    from tests.util import synth_eval_results
+    res = synth_eval_results(9, n_img=12)
+    pairs = [(r['pred_RTs'][i], r['gt_RTs'][j], r['pred_scales'][i], r['gt_scales'][j])
+             for r in res for i in range(len(r['pred_RTs'])) for j in range(len(r['gt_RTs']))]
+    sym, mode = rng.randint(0, 2, len(pairs)).astype(np.int32), rng.randint(0, 3, len(pairs)).astype(np.int32)
+    iou, err = pair_metrics(np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs]), np.stack([p[2] for p in pairs]),
+                            np.stack([p[3] for p in pairs]), sym, mode)
+    for t, (a, b, sa, sb) in enumerate(pairs):
+        assert abs(iou[t] - E.iou_3d(a, b, sa, sb, bool(sym[t]))) <= 1e-12
+        assert np.allclose(err[t], E.rt_error(a, b, int(mode[t])), rtol=1e-10, atol=1e-9, equal_nan=True)
+
+
+@pytest.mark.parametrize("tag,use", [("pose_only", True), ("pose_det", False)])
+def test_eval_map_vs_reference(ops, tag, use):
+    """compute_degree_cm_mAP (device pair metrics + threshold-vectorised matching) against the reference's
+    compute_degree_cm_mAP on the same synthetic result list: every entry of iou_3d_aps and pose_aps."""
+    import tempfile
+    from tests.util import synth_eval_results
+    from tgpose_amd.evaluation import compute_degree_cm_mAP
+    gd = golden("eval_map.npz")
+    res = synth_eval_results(int(gd["seed"]))
+    synset = ['BG', 'bottle', 'bowl', 'camera', 'can', 'laptop', 'mug']
+    with tempfile.TemporaryDirectory() as tmp:
+        iou_aps, pose_aps = compute_degree_cm_mAP(res, synset, tmp, list(gd["degree"]), list(gd["shift"]), list(gd["iou"]),
+                                                  iou_pose_thres=0.1, use_matches_for_pose=use)
+        assert os.path.exists(os.path.join(tmp, "mAP_data.npz"))
+    assert iou_aps.shape == gd[tag + ".iou_aps"].shape and pose_aps.shape == gd[tag + ".pose_aps"].shape
+    assert np.allclose(iou_aps, gd[tag + ".iou_aps"], rtol=0, atol=1e-12, equal_nan=True)
+    assert np.allclose(pose_aps, gd[tag + ".pose_aps"], rtol=0, atol=1e-12, equal_nan=True)
+    assert 0.05 < gd[tag + ".pose_aps"][-1, 2, 5] < 0.95          # the fixture is neither trivially empty nor perfect

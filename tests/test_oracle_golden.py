@@ -186,6 +186,19 @@ def test_backward_oracle_autograd_vs_reference():
         assert np.allclose(got, want, rtol=2e-3, atol=2e-4 * max(1.0, abs(want[0]))), (k, got[:3], want[:3])
 
 
+def test_eval_pair_metrics_vs_reference():
+    """oracle/eval_ref.py (3D IoU with the 20-rotation search, rotation / translation error in its three symmetry modes)
+    against compute_3d_iou_new / compute_RT_degree_cm_symmetry of the imported reference."""
+    from oracle import eval_ref as E
+    g = golden("eval_map.npz")
+    for t in range(len(g["pair_iou"])):
+        iou = E.iou_3d(g["pair_RT1"][t], g["pair_RT2"][t], g["pair_S1"][t], g["pair_S2"][t], bool(g["pair_sym"][t]))
+        err = E.rt_error(g["pair_RT1"][t], g["pair_RT2"][t], int(g["pair_mode"][t]))
+        assert abs(iou - g["pair_iou"][t]) <= 1e-12
+        assert np.allclose(err, g["pair_err"][t], rtol=1e-10, atol=1e-9, equal_nan=True)
+    assert len(set(g["pair_mode"])) == 3 and g["pair_sym"].any() and (g["pair_iou"] > 0).any()
+
+
 def test_chamfer_vs_reference_unit_test_rule():
     """losses/metrics/CD/unit_test.py:22-33: mean squared distance error < 1e-8, indices identical."""
     g = golden("chamfer.npz")

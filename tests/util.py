@@ -42,3 +42,56 @@ def rows_without_ties(D, k):
     """Rows whose k+2 smallest distances are pairwise distinct (no tie can affect a top-(k+1))."""
     s = np.sort(D, axis=1)[:, : k + 2]
     return (np.diff(s, axis=1) > 0).all(axis=1)
+
+
+def synth_eval_results(seed, n_img=40):
+    """A synthetic ``final_results`` list in the evaluater's format (evaluater/RT_TDA_Evaluater.py:99-105): per image a few
+    ground-truth instances of the six NOCS classes, predictions = perturbed ground truth + false positives + misses."""
+    rng = np.random.RandomState(seed)
+
+    def rand_RT(scale_noise=0.0):
+        q = rng.randn(4)
+        q /= np.linalg.norm(q)
+        w, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        RT = np.eye(4)
+        RT[:3, :3] = R * (1.0 + scale_noise * rng.rand())
+        RT[:3, 3] = rng.uniform(-0.3, 0.3, 3) + np.array([0, 0, 1.0])
+        return RT
+
+    def perturb(RT, ang, shift):
+        ax = rng.randn(3)
+        ax /= np.linalg.norm(ax)
+        a = np.deg2rad(ang) * rng.rand()
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        dR = np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+        out = RT.copy()
+        out[:3, :3] = dR @ RT[:3, :3]
+        out[:3, 3] += rng.randn(3) * shift
+        return out
+
+    results = []
+    for img in range(n_img):
+        G = rng.randint(0, 6) if img % 9 else 0
+        gt_cls = rng.randint(1, 7, G).astype(np.int32)
+        gt_RTs = np.stack([rand_RT(0.3) for _ in range(G)]) if G else np.zeros((0, 4, 4))
+        gt_scales = rng.uniform(0.05, 0.4, (G, 3))
+        hv = rng.randint(0, 2, G)
+        pr_cls, pr_RT, pr_sc, pr_score = [], [], [], []
+        for j in range(G):
+            if rng.rand() < 0.85:
+                pr_cls.append(gt_cls[j] if rng.rand() < 0.9 else rng.randint(1, 7))
+                pr_RT.append(perturb(gt_RTs[j], rng.choice([3, 8, 25, 90]), rng.choice([0.005, 0.02, 0.08])))
+                pr_sc.append(gt_scales[j] * rng.uniform(0.8, 1.25, 3))
+                pr_score.append(rng.uniform(0.3, 1.0))
+        for _ in range(rng.randint(0, 3)):
+            pr_cls.append(rng.randint(1, 7)), pr_RT.append(rand_RT()), pr_sc.append(rng.uniform(0.05, 0.4, 3))
+            pr_score.append(rng.uniform(0.05, 0.6))
+        P = len(pr_cls)
+        results.append(dict(gt_class_ids=gt_cls, gt_RTs=gt_RTs, gt_scales=gt_scales, gt_handle_visibility=hv,
+                            pred_bboxes=rng.randint(1, 400, (P, 4)).astype(np.float64), pred_class_ids=np.array(pr_cls, dtype=np.int32),
+                            pred_scales=np.array(pr_sc).reshape(P, 3), pred_scores=np.array(pr_score),
+                            pred_RTs=np.stack(pr_RT) if P else np.zeros((0, 4, 4))))
+    return results

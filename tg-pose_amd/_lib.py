@@ -75,6 +75,8 @@ SIGNATURES = {
     "tgp_gconv_hs_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp,
                                  c_vp, c_vp]),
     "tgp_nbrmax_bwd": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_f32, c_vp, c_int, c_vp]),
+    "tgp_iou3d_pairs": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "tgp_rt_error_pairs": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "tgp_pose_transform_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "tgp_pose_transform_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tgp_gather_rows_bwd": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
