@@ -158,20 +158,34 @@ def main():
 
     if args.workload == "train_step":
         from tgpose_amd import shard
-        from tgpose_amd.losses.dcd import calc_dcd
+        from tgpose_amd.losses.TDA_loss_sym_recon import TDA_loss
         net.train()
         FLAGS.train = 1
         opt = torch.optim.SGD(net.parameters(), lr=1e-5, momentum=0.9)
         gen = torch.Generator().manual_seed(7 + rank)
-        prior = (torch.randn(B, 1024, 3, generator=gen) * 0.1).to(dev) + pts.mean(1, keepdim=True)
-        tgt = {k: torch.randn(B, 3, generator=gen).to(dev) for k in ("p_green_R", "p_red_R", "Pred_T", "Pred_s")}
-        code = torch.rand(B, 2500, generator=gen).to(dev)
+        # the trainer's TDA step (trainer/RL_TDA.py:139-178): all fourteen terms of engine/organize_loss.py's 'TDA' list against
+        # synthetic targets -- random poses, the cloud's own centre as translation, persistence images, a category prior
+        q = torch.randn(B, 4, generator=gen)
+        q = q / q.norm(dim=1, keepdim=True)
+        qw, qx, qy, qz = q.unbind(1)
+        gt_R = torch.stack([1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw), 2 * (qx * qy + qz * qw),
+                            1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw), 2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw),
+                            1 - 2 * (qx * qx + qy * qy)], 1).view(B, 3, 3).to(dev)
+        pats = torch.tensor([[1, 1, 0, 1], [1, 1, 0, 1], [0, 0, 0, 0], [1, 1, 1, 1], [0, 1, 0, 0], [0, 1, 0, 0]])   # sym_info per category
+        gt_list = {"Rot1": gt_R[:, :, 1].contiguous(), "Rot2": gt_R[:, :, 0].contiguous(), "Recon": pts, "R": gt_R,
+                   "Tran": pts.mean(1), "Size": (0.1 + 0.2 * torch.rand(B, 3, generator=gen)).to(dev), "proto": None,
+                   "points_category": (torch.randn(B, 1024, 3, generator=gen) * 0.1).to(dev)}
+        for k in ("h1", "h2", "pdh1_category", "pdh2_category"):
+            gt_list[k] = torch.rand(B, 2500, generator=gen).to(dev)
+        sym = pats[obj.reshape(-1).long().cpu() % 6].to(dev)
+        names = ['Rot1', 'Rot2', 'Rot1_cos', 'Rot2_cos', 'Rot_regular', 'Tran', 'Size', 'R_con', 'TDA_h1', 'TDA_h2', 'TDA_h1_cate',
+                 'TDA_h2_cate', 'Prop_sym', 'R_DCD_cate_pred']
+        tda = TDA_loss()
 
         def loss_fn(out):
-            loss = calc_dcd(out["recon"], prior)[0].mean()
-            for k, t in tgt.items():
-                loss = loss + torch.nn.functional.smooth_l1_loss(out[k], t)
-            return loss + torch.nn.functional.mse_loss(out["h1"], code) + torch.nn.functional.mse_loss(out["h2"], code)
+            pred = {'Rot1': out['p_green_R'], 'Rot1_f': out['f_green_R'], 'Rot2': out['p_red_R'], 'Rot2_f': out['f_red_R'],
+                    'Recon': out['recon'], 'Tran': out['Pred_T'], 'Size': out['Pred_s'], 'TDA_h1': out['h1'], 'TDA_h2': out['h2']}
+            return 0.9 * sum(v.sum() for v in tda(names, pred, gt_list, sym).values())               # trainer/RL_TDA.py:212-213
 
         def finish():
             shard.allreduce_gradients(net.parameters())

@@ -315,6 +315,51 @@ int tgp_pose_transform_bwd(const float *points, const float *R, const float *t, 
                            float *dpoints, float *dR, float *dt, float *ds, tgp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * The regression terms of the training loss either side of Chamfer (losses/TDA_loss_sym_recon.py, losses/consistency_loss.py).
+ * The reference loops over the batch in Python with one host synchronisation per object and term (`if sym[i, 0] == 1`);
+ * these entries make the symmetry tests on the device, one launch per bundle, so the loss is capturable in a HIP graph.
+ * sym: (B, sym_ld) int32, column 0 = symmetric about y, column 1.. = reflection flags (datasets' sym_info).
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* TDA_loss.forward's eight small terms (:42-86 via cal_loss_Rot1 :223, cal_cosine_dis :243, cal_loss_Rot2 :227,
+ * cal_cosine_dis_sym :247, cal_rot_regular_angle :265, cal_loss_Tran :285, cal_loss_Size :288, cal_loss_R_con :205), UNWEIGHTED:
+ * out[0..7] = Rot1, Rot1_cos, Rot2, Rot2_cos, Rot_regular, Tran, Size, R_con; out[8] = number of objects with sym0 != 1.
+ * rot1, rot2, tran, size and their targets are (B,3); f1, f2 (B) the predicted confidences.  kind 0 = nn.L1Loss,
+ * 1 = nn.SmoothL1Loss(beta) (FLAGS.fsnet_loss_type, :20-35). */
+int tgp_pose_terms_fwd(const float *rot1, const float *rot2, const float *f1, const float *f2, const float *tran, const float *size,
+                       const float *g_rot1, const float *g_rot2, const float *g_tran, const float *g_size, const int32_t *sym,
+                       int sym_ld, int B, int kind, float beta, float *out, tgp_stream_t stream);
+/* gradient of sum_k gw[k] out[k] (gw: 8 floats on the device) w.r.t. the six predictions; fwd_out = the forward's out */
+int tgp_pose_terms_bwd(const float *rot1, const float *rot2, const float *f1, const float *f2, const float *tran, const float *size,
+                       const float *g_rot1, const float *g_rot2, const float *g_tran, const float *g_size, const int32_t *sym,
+                       int sym_ld, int B, int kind, float beta, const float *fwd_out, const float *gw, float *d_rot1, float *d_rot2,
+                       float *d_f1, float *d_f2, float *d_tran, float *d_size, tgp_stream_t stream);
+
+/* prop_sym_matching_loss (losses/consistency_loss.py:19-48 = TDA_loss_sym_recon.py:120-148): L1 between the reconstruction
+ * PC_re (B,N,3) and the cloud PC (B,N,3) mapped by the object's symmetry in the ground-truth frame (half turn about y /
+ * mirror in z / identity, :171-203), mean over B*N*3 -> loss[0].  workspace: tgp_sym_recon_workspace_floats(B, N) floats.
+ * The backward writes dPC and / or dPC_re (either may be NULL) for the upstream gradient gloss[0]. */
+int64_t tgp_sym_recon_workspace_floats(int B, int N);
+int tgp_sym_recon_fwd(const float *PC, const float *PC_re, const float *gt_R, const float *gt_t, const int32_t *sym, int sym_ld,
+                      int sym_cols, int B, int N, float *workspace, float *loss, tgp_stream_t stream);
+int tgp_sym_recon_bwd(const float *PC, const float *PC_re, const float *gt_R, const float *gt_t, const int32_t *sym, int sym_ld,
+                      int sym_cols, int B, int N, const float *gloss, float *dPC, float *dPC_re, tgp_stream_t stream);
+
+/* ph_loss_fn / omega (TDA_loss_sym_recon.py:292-322): out[0] = mean(|a - b| * w), a, b, wsrc (B,D), w = 1 on rows with
+ * sum(wsrc) > 0.  The reference's host-side has_nan_or_inf branch (|a - a| instead) is folded in: NaN when a holds a
+ * NaN / Inf, 0 when only b does; out[1] = 1 when the plain mean was taken.  rows: 4*B floats kept for the backward, which
+ * writes da (B,D) for the upstream gradient gout[0]. */
+int tgp_rowl1_fwd(const float *a, const float *b, const float *wsrc, int B, int D, float *rows, float *out, tgp_stream_t stream);
+int tgp_rowl1_bwd(const float *a, const float *b, const float *rows, const float *fwd_out, const float *gout, int B, int D, float *da,
+                  tgp_stream_t stream);
+
+/* feat_consistency_loss (losses/consistency_loss.py:11-16, unweighted): loss[0] = 2 - 2 sum_b <x1_b/|x1_b|, x2_b/|x2_b|> / B,
+ * x1, x2 (B,C), norms clamped at 1e-12 as F.normalize.  rows: 3*B floats kept for the backward (d1 / d2 may be NULL). */
+int tgp_feat_consistency_fwd(const float *x1, const float *x2, int B, int C, float *rows, float *loss, tgp_stream_t stream);
+int tgp_feat_consistency_bwd(const float *x1, const float *x2, const float *rows, const float *gloss, int B, int C, float *d1, float *d2,
+                             tgp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Pairwise metrics of the NOCS pose evaluation (evaluation/eval_utils_v1.py): every (prediction, ground truth) pair of a
  * result set in one launch, double precision as the numpy original.  RT: (P,4,4) row-major, scales: (P,3).
  * ------------------------------------------------------------------------------------------------------------------ */

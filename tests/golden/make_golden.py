@@ -352,6 +352,53 @@ def gen_dcd():
          dcd=dcd, cd_p=cd_p, cd_t=cd_t, r_dcd=r_dcd, new_y=ny, new_x=nx, p_R=pR, dcd_grad=rr.grad)
 
 
+def gen_tda_loss():
+    """TDA_loss.forward with the trainer's 'TDA' name list minus R_DCD (covered by dcd.npz), and the two functions of
+    losses/consistency_loss.py, on a seeded batch that holds every symmetry pattern; values and gradients w.r.t. every prediction."""
+    ref_loss = load_reference_loss()
+    import losses.consistency_loss as ref_con
+    from tests.util import synth_loss_batch
+    out = {}
+    for kind in ("l1", "smoothl1"):
+        FLAGS.fsnet_loss_type = kind
+        mod = ref_loss.TDA_loss()
+        pred, gt, sym, extra = synth_loss_batch(seed=41)
+        names = ['Rot1', 'Rot2', 'Rot1_cos', 'Rot2_cos', 'Rot_regular', 'Tran', 'Size', 'R_con', 'TDA_h1', 'TDA_h2', 'TDA_h1_cate', 'TDA_h2_cate']
+        if kind == "l1":
+            names.append('Prop_sym')                       # TDA_loss defines loss_func for 'l1' only
+        for v in pred.values():
+            v.requires_grad_(True)
+        res = mod(names, pred, gt, sym)
+        sum(v.sum() for v in res.values()).backward()
+        for k, v in res.items():
+            out["%s.loss.%s" % (kind, k)] = v.detach().reshape(-1)
+        for k, v in pred.items():
+            out["%s.grad.%s" % (kind, k)] = v.grad if v.grad is not None else torch.zeros_like(v)
+    FLAGS.fsnet_loss_type = "l1"
+    pred, gt, sym, extra = synth_loss_batch(seed=41)
+    for name, d in (("pred", pred), ("gt", gt), ("in", extra)):
+        for k, v in d.items():
+            out["%s.%s" % (name, k)] = v
+    out["in.sym"] = sym
+    # consistency_loss.py: both clouds and both feature sets as leaves
+    x1, x2 = extra["feat1"].clone().requires_grad_(True), extra["feat2"].clone().requires_grad_(True)
+    l = ref_con.feat_consistency_loss(x1, x2)
+    l.backward()
+    out["con.feat"], out["con.feat.g1"], out["con.feat.g2"] = l.detach().reshape(1), x1.grad, x2.grad
+    a, b = pred["Recon"].detach().clone().requires_grad_(True), extra["recon2"].clone().requires_grad_(True)
+    l = ref_con.prop_sym_matching_loss(a, b, gt["R"], gt["Tran"], sym)
+    l.backward()
+    out["con.sym"], out["con.sym.gPC"], out["con.sym.gRe"] = l.detach().reshape(1), a.grad, b.grad
+    # the NaN / Inf branches of ph_loss_fn
+    mod = ref_loss.TDA_loss()
+    bad_pred, bad_gt = pred["TDA_h1"].detach().clone(), gt["h1"].clone()
+    bad_pred[1, 3] = float("inf")
+    bad_gt[2, 5] = float("nan")
+    out["ph.bad_pred"] = mod.ph_loss_fn(bad_pred, gt["h1"]).reshape(1)
+    out["ph.bad_gt"] = mod.ph_loss_fn(pred["TDA_h1"].detach(), bad_gt).reshape(1)
+    save("tda_loss.npz", **out)
+
+
 def gen_pose_assembly():
     """to_R_matrices (tools/rot_utils.py:95-98) is importable; generate_RT itself exists only as py3.8 bytecode
     (tools/geom_utils), its recorded semantics are: zero f_red where sym[:,0]==1, R = to_R_matrices,
@@ -416,6 +463,7 @@ def gen_eval_map():
 
 
 def main():
+    gen_tda_loss()
     gen_eval_map()
     gen_pose_assembly()
     gen_dcd()

@@ -1356,3 +1356,142 @@ def test_eval_map_vs_reference(ops, tag, use):
     assert np.allclose(iou_aps, gd[tag + ".iou_aps"], rtol=0, atol=1e-12, equal_nan=True)
     assert np.allclose(pose_aps, gd[tag + ".pose_aps"], rtol=0, atol=1e-12, equal_nan=True)
     assert 0.05 < gd[tag + ".pose_aps"][-1, 2, 5] < 0.95          # the fixture is neither trivially empty nor perfect
+
+
+# ----------------------------------------------------------------------------------------- loss bundle
+def _dev_loss_case(pred, gt, sym, extra):
+    dp = {k: g(v.detach()).clone().requires_grad_(True) for k, v in pred.items()}
+    return dp, {k: g(v) for k, v in gt.items()}, g(sym), {k: g(v) for k, v in extra.items()}
+
+
+@pytest.mark.parametrize("kind", ["l1", "smoothl1"])
+def test_tda_loss_vs_reference_and_oracle(ops, kind):
+    """TDA_loss.forward on the HIP kernels against the values and gradients the imported reference produced
+    (tests/golden/tda_loss.npz) and against the CPU oracle: every term of the trainer's name list, both penalty kinds."""
+    from tests.test_oracle_golden import tda_loss_case, tda_loss_oracle
+    from tgpose_amd import FLAGS
+    from tgpose_amd.losses.TDA_loss_sym_recon import TDA_loss
+    gd, pred, gt, sym, extra = tda_loss_case()
+    dp, dg, dsym, _ = _dev_loss_case(pred, gt, sym, extra)
+    names = ['Rot1', 'Rot2', 'Rot1_cos', 'Rot2_cos', 'Rot_regular', 'Tran', 'Size', 'R_con', 'TDA_h1', 'TDA_h2', 'TDA_h1_cate', 'TDA_h2_cate']
+    if kind == "l1":
+        names.append('Prop_sym')
+    old = FLAGS.fsnet_loss_type
+    FLAGS.fsnet_loss_type = kind
+    try:
+        mod = TDA_loss()
+        res = mod(names, dp, dg, dsym)
+        if kind == "smoothl1":
+            with pytest.raises(AttributeError):                       # as the reference: loss_func exists for 'l1' only
+                mod(['Prop_sym'], dp, dg, dsym)
+    finally:
+        FLAGS.fsnet_loss_type = old
+    sum(v.sum() for v in res.values()).backward()
+    ora = tda_loss_oracle(kind, pred, gt, sym)
+    want = {k.split(".", 2)[2]: gd[k] for k in gd.files if k.startswith(kind + ".loss.")}
+    assert set(res) == set(want)
+    for k, v in res.items():
+        assert tuple(v.shape) == (() if want[k].shape == (1,) and k not in ("Rot2", "Rot2_cos", "Rot_r_a") else (1,)), k
+        assert abs(v.item() - want[k][0]) <= 2e-6 * max(1.0, abs(want[k][0])), (kind, k, v.item(), want[k])
+        assert abs(v.item() - ora[k].item()) <= 2e-6 * max(1.0, abs(want[k][0])), (kind, k)
+    for k, v in dp.items():
+        r = gd["%s.grad.%s" % (kind, k)]
+        got = v.grad.cpu().numpy() if v.grad is not None else np.zeros_like(r)
+        assert np.allclose(got, r, atol=1e-7 + 2e-5 * np.abs(r).max(), rtol=2e-5), (kind, k, np.abs(got - r).max(), np.abs(r).max())
+
+
+def test_consistency_losses_vs_reference(ops):
+    """losses/consistency_loss.py: feat_consistency_loss and prop_sym_matching_loss, values and the gradients w.r.t. BOTH
+    operands (the trainer passes a reconstruction as the first cloud), plus the NaN / Inf branches of ph_loss_fn."""
+    from tests.test_oracle_golden import tda_loss_case
+    from tgpose_amd.losses.consistency_loss import feat_consistency_loss, prop_sym_matching_loss
+    from tgpose_amd.losses.TDA_loss_sym_recon import TDA_loss
+    gd, pred, gt, sym, extra = tda_loss_case()
+    x1, x2 = g(extra["feat1"]).requires_grad_(True), g(extra["feat2"]).requires_grad_(True)
+    l = feat_consistency_loss(x1, x2)
+    l.backward()
+    assert abs(l.item() - gd["con.feat"][0]) < 2e-6
+    assert np.allclose(x1.grad.cpu().numpy(), gd["con.feat.g1"], atol=2e-7, rtol=1e-5)
+    assert np.allclose(x2.grad.cpu().numpy(), gd["con.feat.g2"], atol=2e-7, rtol=1e-5)
+    a, b = g(pred["Recon"].detach()).requires_grad_(True), g(extra["recon2"]).requires_grad_(True)
+    l = prop_sym_matching_loss(a, b, g(gt["R"]), g(gt["Tran"]), g(sym))
+    l.backward()
+    assert abs(l.item() - gd["con.sym"][0]) < 1e-7
+    # sign() of a difference that is zero up to rounding may flip between the two evaluation orders: compare where it is not
+    for got, key in ((a.grad, "con.sym.gPC"), (b.grad, "con.sym.gRe")):
+        d = np.abs(got.cpu().numpy() - gd[key])
+        assert (d > 1e-8).mean() < 1e-3, (key, (d > 1e-8).mean())
+    mod = TDA_loss()
+    bad_pred, bad_gt = g(pred["TDA_h1"].detach()).clone(), g(gt["h1"]).clone()
+    bad_pred[1, 3], bad_gt[2, 5] = float("inf"), float("nan")
+    assert torch.isnan(mod.ph_loss_fn(bad_pred, g(gt["h1"]))).item() and np.isnan(gd["ph.bad_pred"][0])
+    live = g(pred["TDA_h1"].detach()).requires_grad_(True)
+    z = mod.ph_loss_fn(live, bad_gt)
+    z.backward()
+    assert z.item() == 0 == gd["ph.bad_gt"][0] and live.grad.abs().max().item() == 0
+
+
+def test_tda_loss_large_batch_and_graph_capture(ops):
+    """B larger than one workgroup's stride and the trainer's cloud size against the oracle, then the same loss + backward
+    captured in a HIP graph: capture fails on any host read-back, so a replay proves the bundle is synchronisation-free; the
+    replay must reproduce the eager values and gradients bit for bit and follow new inputs."""
+    from tests.test_oracle_golden import tda_loss_oracle
+    from tests.util import synth_loss_batch
+    from tgpose_amd.losses.TDA_loss_sym_recon import TDA_loss
+    from tgpose_amd.losses.consistency_loss import feat_consistency_loss, prop_sym_matching_loss
+    names = ['Rot1', 'Rot2', 'Rot1_cos', 'Rot2_cos', 'Rot_regular', 'Tran', 'Size', 'R_con', 'TDA_h1', 'TDA_h2', 'TDA_h1_cate', 'TDA_h2_cate',
+             'Prop_sym']
+    pred, gt, sym, extra = synth_loss_batch(seed=5, B=300, N=1028, D=2500, C=1286)
+    cp = {k: v.clone().requires_grad_(True) for k, v in pred.items()}
+    ora = tda_loss_oracle("l1", cp, gt, sym)
+    sum(v.sum() for v in ora.values()).backward()
+    dp, dg, dsym, dx = _dev_loss_case(pred, gt, sym, extra)
+    dp["feat1"] = dx["feat1"].clone().requires_grad_(True)            # the encoder feature of net1 is a prediction too
+    mod = TDA_loss()
+
+    def step():
+        res = mod(names, dp, dg, dsym)
+        total = sum(v.sum() for v in res.values()) + 0.1 * feat_consistency_loss(dp["feat1"], dx["feat2"]) \
+            + 0.1 * prop_sym_matching_loss(dp["Recon"], dx["recon2"], dg["R"], dg["Tran"], dsym)
+        total.backward()
+        return res, total
+
+    res, total = step()
+    for k, v in res.items():
+        assert abs(v.item() - ora[k].item()) <= 5e-6 * max(1.0, abs(ora[k].item())), (k, v.item(), ora[k].item())
+    for k in ("Rot1", "Rot2", "Rot1_f", "Rot2_f", "Tran", "Size", "TDA_h1", "TDA_h2"):
+        r = cp[k].grad.numpy()
+        assert np.allclose(dp[k].grad.cpu().numpy(), r, atol=1e-8 + 2e-5 * np.abs(r).max(), rtol=2e-5), k
+    eager = {k: v.grad.clone() for k, v in dp.items()}
+    eager_total = total.detach().clone()
+    # The eager autograd graph must be gone before capture: its AccumulateGrad nodes are bound to the stream they were made on
+    # (the default one), and a backward captured on another stream would hand its gradients across -- pulling the default
+    # stream into the capture, which HIP answers with a crash in hipStreamEndCapture rather than an error.
+    del res, total
+    for v in dp.values():
+        v.grad.zero_()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+            for v in dp.values():
+                v.grad.zero_()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        _, gtotal = step()
+    for v in dp.values():
+        v.grad.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(gtotal, eager_total)
+    for k, v in dp.items():
+        assert torch.equal(v.grad, eager[k]), k
+    with torch.no_grad():
+        dp["Tran"].add_(0.05)
+        for v in dp.values():
+            v.grad.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(gtotal).item() and not torch.equal(gtotal, eager_total)          # the replay read the new translation

@@ -237,3 +237,60 @@ def test_dcd_loss_pieces_vs_reference():
     assert torch.allclose(L.rot_from_y_x(ny, nx), t("p_R"), atol=1e-6)
     val = L.r_dcd(t("prior"), t("recon"), t("gR"), t("p_g"), t("f_g"), t("p_r"), t("f_r"), t("t"), t("s"), t("sym"))
     assert abs(val.item() - float(g["r_dcd"])) < 1e-6
+
+
+def tda_loss_case(g=None):
+    """the fixture's operands as torch tensors: pred (leaves), gt, sym, extras"""
+    g = golden("tda_loss.npz") if g is None else g
+    pick = lambda pre: {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
+    pred = {k: v.clone().requires_grad_(True) for k, v in pick("pred.").items()}
+    extra = pick("in.")
+    return g, pred, pick("gt."), extra.pop("sym"), extra
+
+
+def tda_loss_oracle(kind, pred, gt, sym):
+    """oracle/tda_loss_ref.py assembled as TDA_loss.forward assembles its dict (weights of config/config.py)"""
+    from oracle import tda_loss_ref as T
+    W = T.WEIGHTS
+    p = T.pose_terms(pred, gt, sym, kind)
+    res = {"Rot1": W["rot_1_w"] * p["Rot1"], "Rot1_cos": W["rot_1_w"] * p["Rot1_cos"], "Rot2": W["rot_2_w"] * p["Rot2"],
+           "Rot2_cos": W["rot_2_w"] * p["Rot2_cos"], "Rot_r_a": W["rot_regular"] * p["Rot_regular"], "Tran": W["tran_w"] * p["Tran"],
+           "Size": W["size_w"] * p["Size"], "R_con": W["r_con_w"] * p["R_con"],
+           "TDA_h1": W["h1_w"] * T.ph_loss(pred["TDA_h1"], gt["h1"]), "TDA_h2": W["h2_w"] * T.ph_loss(pred["TDA_h2"], gt["h2"]),
+           "TDA_h1_cate": T.ph_loss_cate(pred["TDA_h1"], gt["pdh1_category"], gt["h1"]),
+           "TDA_h2_cate": T.ph_loss_cate(pred["TDA_h2"], gt["pdh2_category"], gt["h2"])}
+    if kind == "l1":
+        res["Prop_sym"] = W["prop_sym_w"] * T.prop_sym_matching_loss(gt["Recon"], pred["Recon"], gt["R"], gt["Tran"], sym)
+    return res
+
+
+def test_tda_loss_oracle_vs_reference():
+    """oracle/tda_loss_ref.py against TDA_loss.forward / consistency_loss of the imported reference: every term, both penalty
+    kinds, and the gradient of the summed loss w.r.t. every prediction."""
+    from oracle import tda_loss_ref as T
+    for kind in ("l1", "smoothl1"):
+        g, pred, gt, sym, extra = tda_loss_case()
+        res = tda_loss_oracle(kind, pred, gt, sym)
+        sum(v.sum() for v in res.values()).backward()
+        want = {k.split(".", 2)[2]: g[k] for k in g.files if k.startswith(kind + ".loss.")}
+        assert set(want) == set(res)
+        for k, v in res.items():
+            assert abs(v.item() - want[k][0]) <= 1e-6 * max(1.0, abs(want[k][0])), (kind, k, v.item(), want[k])
+        for k, v in pred.items():
+            r = g["%s.grad.%s" % (kind, k)]
+            got = v.grad.numpy() if v.grad is not None else np.zeros_like(r)
+            assert np.allclose(got, r, atol=1e-7 + 1e-5 * np.abs(r).max(), rtol=1e-5), (kind, k)
+    x1, x2 = extra["feat1"].clone().requires_grad_(True), extra["feat2"].clone().requires_grad_(True)
+    l = T.WEIGHTS["feat_consist_w"] * T.feat_consistency(x1, x2)
+    l.backward()
+    assert abs(l.item() - g["con.feat"][0]) < 1e-6
+    assert np.allclose(x1.grad.numpy(), g["con.feat.g1"], atol=1e-7) and np.allclose(x2.grad.numpy(), g["con.feat.g2"], atol=1e-7)
+    a, b = pred["Recon"].detach().clone().requires_grad_(True), extra["recon2"].clone().requires_grad_(True)
+    l = T.prop_sym_matching_loss(a, b, gt["R"], gt["Tran"], sym)
+    l.backward()
+    assert abs(l.item() - g["con.sym"][0]) < 1e-7
+    assert np.allclose(a.grad.numpy(), g["con.sym.gPC"], atol=1e-9) and np.allclose(b.grad.numpy(), g["con.sym.gRe"], atol=1e-9)
+    bad_pred, bad_gt = pred["TDA_h1"].detach().clone(), gt["h1"].clone()
+    bad_pred[1, 3], bad_gt[2, 5] = float("inf"), float("nan")
+    assert np.isnan(g["ph.bad_pred"][0]) and torch.isnan(T.ph_loss(bad_pred, gt["h1"]))
+    assert g["ph.bad_gt"][0] == 0 and T.ph_loss(pred["TDA_h1"].detach(), bad_gt).item() == 0

@@ -95,3 +95,35 @@ def synth_eval_results(seed, n_img=40):
                             pred_scales=np.array(pr_sc).reshape(P, 3), pred_scores=np.array(pr_score),
                             pred_RTs=np.stack(pr_RT) if P else np.zeros((0, 4, 4))))
     return results
+
+
+def synth_loss_batch(seed=41, B=10, N=96, D=50, C=70):
+    """A training-step's worth of loss operands on the CPU: predictions near their targets (so the smooth-L1 knee, the
+    confidence target exp(-13.7 d^2) and the sign flips all get exercised), every symmetry pattern of datasets' sym_info plus
+    the degenerate ones, persistence images with some all-zero rows.  -> pred dict, gt dict, sym (B,4) int64, extras"""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(B, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    w, x, y, z = q.unbind(1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                     2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1).view(B, 3, 3)
+    t = 0.1 * torch.randn(B, 3, generator=g) + torch.tensor([0.0, 0.0, 0.8])
+    s = 0.2 + 0.3 * torch.rand(B, 3, generator=g)
+    pats = [[1, 1, 0, 1], [1, 1, 1, 1], [0, 0, 0, 0], [0, 1, 0, 0], [1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 1, 0], [1, 0, 1, 0]]
+    sym = torch.tensor([pats[i % len(pats)] for i in range(B)], dtype=torch.int64)
+    nrm = lambda v: v / v.norm(dim=1, keepdim=True)
+    cano = (torch.rand(B, N, 3, generator=g) - 0.5) * s.unsqueeze(1)
+    PC = cano @ R.transpose(1, 2) + t.unsqueeze(1)
+    h = lambda: torch.relu(torch.randn(B, D, generator=g)) * (torch.rand(B, 1, generator=g) > 0.25)
+    gt = {"Rot1": R[:, :, 1].contiguous(), "Rot2": R[:, :, 0].contiguous(), "Recon": PC, "Tran": t, "Size": s, "h1": h(), "h2": h(),
+          "pdh1_category": h(), "pdh2_category": h(), "R": R}
+    pred = {"Rot1": nrm(gt["Rot1"] + 0.15 * torch.randn(B, 3, generator=g)), "Rot2": nrm(gt["Rot2"] + 0.15 * torch.randn(B, 3, generator=g)),
+            "Rot1_f": torch.rand(B, generator=g), "Rot2_f": torch.rand(B, generator=g),
+            "Recon": PC + 0.02 * torch.randn(B, N, 3, generator=g), "Tran": t + 0.3 * torch.randn(B, 3, generator=g),
+            "Size": s + 0.3 * torch.randn(B, 3, generator=g), "TDA_h1": gt["h1"] + 0.3 * torch.randn(B, D, generator=g),
+            "TDA_h2": gt["h2"] + 0.3 * torch.randn(B, D, generator=g)}
+    extra = {"feat1": torch.randn(B, C, generator=g), "feat2": torch.randn(B, C, generator=g),
+             "recon2": PC + 0.02 * torch.randn(B, N, 3, generator=g)}
+    extra["feat2"][3] = 0.0                                # a row F.normalize clamps
+    return pred, gt, sym, extra

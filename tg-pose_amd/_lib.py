@@ -77,6 +77,15 @@ SIGNATURES = {
     "tgp_nbrmax_bwd": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_f32, c_vp, c_int, c_vp]),
     "tgp_iou3d_pairs": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "tgp_rt_error_pairs": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "tgp_pose_terms_fwd": (c_int, [c_vp] * 11 + [c_int, c_int, c_int, c_f32, c_vp, c_vp]),
+    "tgp_pose_terms_bwd": (c_int, [c_vp] * 11 + [c_int, c_int, c_int, c_f32] + [c_vp] * 8 + [c_vp]),
+    "tgp_sym_recon_workspace_floats": (c_i64, [c_int, c_int]),
+    "tgp_sym_recon_fwd": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "tgp_sym_recon_bwd": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "tgp_rowl1_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "tgp_rowl1_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    "tgp_feat_consistency_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "tgp_feat_consistency_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_pose_transform_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "tgp_pose_transform_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tgp_gather_rows_bwd": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),

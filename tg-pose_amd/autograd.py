@@ -372,7 +372,12 @@ class GraphedBackward(object):
     between dependent kernels are gone (bench.py --workload train_step: 28.1 -> 26.8 ms per B=32 step).  Gradients land in
     the parameters' static ``.grad`` buffers (zeroed in place before each replay -- never set them to None afterwards, the
     graph writes to those very tensors); the gradient all-reduce, the clip and the optimizer step stay with the caller.  ``loss_fn(out) -> scalar`` must be built from ops that can be captured (no host
-    synchronisation); inputs are copied into static buffers, the per-forward subsample is drawn on the host as usual."""
+    synchronisation); inputs are copied into static buffers, the per-forward subsample is drawn on the host as usual.
+
+    Drop every loss / output of earlier EAGER steps over the same parameters before constructing this: a live autograd graph
+    keeps its AccumulateGrad nodes, which are bound to the stream they were created on; the captured backward would hand its
+    gradients across to that stream, pulling it into the capture, and HIP crashes in hipStreamEndCapture instead of raising
+    (scripts/capture_probe.py reproduces it)."""
 
     def __init__(self, net, points, obj_id, loss_fn):
         dev = points.device

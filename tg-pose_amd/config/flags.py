@@ -19,6 +19,16 @@ _DEFAULTS = dict(
     random_points=1024,  # :48
     train=1,             # :53
     output_channels=2500,  # :150
+    # weights of the loss terms (losses/TDA_loss_sym_recon.py, losses/consistency_loss.py)
+    fsnet_loss_type="l1",  # :68
+    rot_1_w=8.0, rot_2_w=8.0,  # :71-72
+    rot_regular=4.0,     # :74
+    tran_w=8.0, size_w=8.0, recon_w=8.0,  # :75-77
+    r_con_w=1.0,         # :78
+    h1_w=4.0, h2_w=4.0,  # :79-80
+    feat_consist_w=2.0,  # :83
+    DCD_align=1.0,       # :101
+    prop_sym_w=1.0,      # :114
 )
 
 

@@ -604,3 +604,104 @@ def pose_transform_bwd(points, R, t, s, dout, need_points=True):
     check(_lib.lib().tgp_pose_transform_bwd(_p(points), _p(R), _p(t), _p(s), _p(dout), B, n, _p(dp), _p(dR), _p(dt), _p(ds),
                                             _stream(points)), "tgp_pose_transform_bwd")
     return dp, dR, dt, ds
+
+
+# ---- the regression terms of the training loss (csrc/tdaloss.hip) ---------------------------------------------------------
+
+def sym_i32(sym):
+    """sym_info as the kernels read it: (B, S) int32, contiguous"""
+    if sym.dim() != 2:
+        raise ValueError("sym must be (B, S)")
+    return sym.to(torch.int32).contiguous()
+
+
+def _pose_args(pred, gt, sym, kind, beta):
+    B = pred[0].shape[0]
+    for t in tuple(pred) + tuple(gt):
+        _f32(t, "pose term operand")
+        if t.shape[0] != B or not t.is_contiguous():
+            raise ValueError("pose term operands must be contiguous with %d rows" % B)
+    if sym.dtype != torch.int32 or sym.shape[0] != B or not sym.is_contiguous():
+        raise ValueError("sym must be (B, S) int32 contiguous (ops.sym_i32)")
+    return [_p(t) for t in pred] + [_p(t) for t in gt] + [_p(sym), sym.shape[1], B, int(kind), float(beta)]
+
+
+def pose_terms_fwd(pred, gt, sym, kind=0, beta=0.5):
+    """pred = (rot1, rot2, f1, f2, tran, size), gt = (rot1, rot2, tran, size) -> 9 floats: the eight unweighted terms + valid count"""
+    out = torch.empty(9, device=pred[0].device, dtype=torch.float32)
+    check(_lib.lib().tgp_pose_terms_fwd(*_pose_args(pred, gt, sym, kind, beta), _p(out), _stream(out)), "tgp_pose_terms_fwd")
+    return out
+
+
+def pose_terms_bwd(pred, gt, sym, kind, beta, fwd_out, gw):
+    grads = [torch.empty_like(t) for t in pred]
+    d = dict(zip(("rot1", "rot2", "f1", "f2", "tran", "size"), grads))
+    check(_lib.lib().tgp_pose_terms_bwd(*_pose_args(pred, gt, sym, kind, beta), _p(fwd_out), _p(gw), _p(d["rot1"]), _p(d["rot2"]),
+                                        _p(d["f1"]), _p(d["f2"]), _p(d["tran"]), _p(d["size"]), _stream(fwd_out)), "tgp_pose_terms_bwd")
+    return grads
+
+
+def _sym_recon_args(PC, PC_re, gt_R, gt_t, sym):
+    for t, n in ((PC, "PC"), (PC_re, "PC_re"), (gt_R, "gt_R"), (gt_t, "gt_t")):
+        _f32(t, n)
+        if not t.is_contiguous():
+            raise ValueError("%s must be contiguous" % n)
+    B, N, _ = PC.shape
+    if PC_re.shape != PC.shape or gt_R.shape != (B, 3, 3) or gt_t.shape != (B, 3) or sym.shape[0] != B or sym.dtype != torch.int32:
+        raise ValueError("prop_sym_matching_loss operand shapes")
+    return [_p(PC), _p(PC_re), _p(gt_R), _p(gt_t), _p(sym), sym.shape[1], sym.shape[1], B, N]
+
+
+def sym_recon_fwd(PC, PC_re, gt_R, gt_t, sym):
+    B, N, _ = PC.shape
+    ws = torch.empty(int(_lib.lib().tgp_sym_recon_workspace_floats(B, N)), device=PC.device, dtype=torch.float32)
+    loss = torch.empty(1, device=PC.device, dtype=torch.float32)
+    check(_lib.lib().tgp_sym_recon_fwd(*_sym_recon_args(PC, PC_re, gt_R, gt_t, sym), _p(ws), _p(loss), _stream(PC)), "tgp_sym_recon_fwd")
+    return loss
+
+
+def sym_recon_bwd(PC, PC_re, gt_R, gt_t, sym, gloss, need_pc, need_re):
+    dPC = torch.empty_like(PC) if need_pc else None
+    dRe = torch.empty_like(PC_re) if need_re else None
+    check(_lib.lib().tgp_sym_recon_bwd(*_sym_recon_args(PC, PC_re, gt_R, gt_t, sym), _p(gloss), _p(dPC), _p(dRe), _stream(PC)),
+          "tgp_sym_recon_bwd")
+    return dPC, dRe
+
+
+def rowl1_fwd(a, b, wsrc):
+    for t in (a, b, wsrc):
+        _f32(t, "rowl1 operand", 2)
+    if a.shape != b.shape or a.shape != wsrc.shape or not (a.is_contiguous() and b.is_contiguous() and wsrc.is_contiguous()):
+        raise ValueError("rowl1 operands must be contiguous and of one shape")
+    B, D = a.shape
+    rows = torch.empty(B, 4, device=a.device, dtype=torch.float32)
+    out = torch.empty(2, device=a.device, dtype=torch.float32)
+    check(_lib.lib().tgp_rowl1_fwd(_p(a), _p(b), _p(wsrc), B, D, _p(rows), _p(out), _stream(a)), "tgp_rowl1_fwd")
+    return out, rows
+
+
+def rowl1_bwd(a, b, rows, fwd_out, gout):
+    B, D = a.shape
+    da = torch.empty_like(a)
+    check(_lib.lib().tgp_rowl1_bwd(_p(a), _p(b), _p(rows), _p(fwd_out), _p(gout), B, D, _p(da), _stream(a)), "tgp_rowl1_bwd")
+    return da
+
+
+def feat_consistency_fwd(x1, x2):
+    _f32(x1, "x1", 2), _f32(x2, "x2", 2)
+    if x1.shape != x2.shape or not (x1.is_contiguous() and x2.is_contiguous()):
+        raise ValueError("feat_consistency operands must be contiguous and of one shape")
+    B, C = x1.shape
+    rows = torch.empty(B, 3, device=x1.device, dtype=torch.float32)
+    loss = torch.empty(1, device=x1.device, dtype=torch.float32)
+    check(_lib.lib().tgp_feat_consistency_fwd(_p(x1), _p(x2), B, C, _p(rows), _p(loss), _stream(x1)), "tgp_feat_consistency_fwd")
+    return loss, rows
+
+
+def feat_consistency_bwd(x1, x2, rows, gloss, need1, need2):
+    B, C = x1.shape
+    d1 = torch.empty_like(x1) if need1 else None
+    d2 = torch.empty_like(x2) if need2 else None
+    check(_lib.lib().tgp_feat_consistency_bwd(_p(x1), _p(x2), _p(rows), _p(gloss), B, C, _p(d1), _p(d2), _stream(x1)),
+          "tgp_feat_consistency_bwd")
+    return d1, d2
