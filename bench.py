@@ -75,9 +75,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="objects per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="batches in flight per GPU: step i runs on HIP stream i %% S (independent batches overlap "
-                         "each other's tail rounds and small kernels)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="batches in flight per GPU: step i runs on HIP stream i %% S over its own batch (independent batches "
+                         "overlap each other's tail rounds and small kernels); 1 = one forward at a time")
     ap.add_argument("--no-branch-streams", action="store_true", help="run the decoder branch in line instead of on a side stream")
     ap.add_argument("--gemm", choices=("split16", "split", "fp32"), default="split16",
                     help="split16: fp32-accurate GEMM on the fp16 matrix cores (2-term operand split, 3 MFMA terms); "
@@ -148,8 +148,23 @@ def main():
         with torch.cuda.stream(st):
             return net(pts, obj)
 
+    replayers, one_in_flight = None, None
     if args.graph == 1 and args.workload == "forward" and args.streams == 1:
         net.graph_replay = True                 # PoseNet9D.forward captures once, then replays
+    elif args.graph == 1 and args.workload == "forward":
+        # S batches in flight: one captured forward (own static buffers, own activation pool) per HIP stream; step i replays
+        # graph i % S on stream i % S over its own batch, so one batch's tail rounds and small kernels overlap the other's
+        # GEMMs.  Every step is still one whole forward of B objects; a batch's latency is S steps.
+        batches = [tuple(t.to(dev) for t in synth_batch(B, N_POINTS, 100 + rank + 1000 * i)) for i in range(len(streams))]
+        replayers = [_engine.GraphedForward(net.packed(dev), B, N_POINTS, dev, train_keys=False) for _ in streams]
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream(dev))
+
+        def step():
+            i = step_no[0] % len(streams)
+            step_no[0] += 1
+            with torch.cuda.stream(streams[i]):
+                return replayers[i](*batches[i])
     elif args.graph == 2 and args.workload == "forward":
         graphed = _engine.GraphedForward(net.packed(dev), B, N_POINTS, dev, train_keys=False, parts=2)
 
@@ -228,7 +243,32 @@ def main():
     timer, ops.GEMM_TIMER = ops.GEMM_TIMER, None
     roof_note = "HIP events around every tile-kernel launch of the timed region"
     roof_elapsed = elapsed
-    if getattr(net, "graph_replay", False):
+    if replayers is not None:
+        # the kernels of overlapping replays cannot be bracketed one by one: time them in serial eager launches of the same
+        # forward right after the timed region (same process, same weights)
+        def step():
+            return net(pts, obj)
+        k_roof = min(args.steps, 10)
+        step()
+        fence()
+        ops.GEMM_TIMER = []
+        t1 = time.perf_counter()
+        for _ in range(k_roof):
+            step()
+        fence()
+        roof_elapsed = time.perf_counter() - t1
+        timer, ops.GEMM_TIMER = ops.GEMM_TIMER, None
+        roof_note = ("HIP events around every tile-kernel launch of %d serial eager steps run after the timed region "
+                     "(%d graph replays in flight there)" % (k_roof, len(streams)))
+        # for reference: the same replayed forward with ONE batch in flight (what a latency-bound caller sees)
+        fence()
+        t2 = time.perf_counter()
+        with torch.cuda.stream(streams[0]):
+            for _ in range(args.steps):
+                replayers[0](*batches[0])
+        fence()
+        one_in_flight = world * B * args.steps / (time.perf_counter() - t2)
+    elif getattr(net, "graph_replay", False):
         # a replayed graph has no launch to bracket with events: the same kernels are timed in an eager pass of the same
         # steps right after the timed region (same process, same inputs); the rocprof summary covers both
         net.graph_replay = False
@@ -266,8 +306,8 @@ def main():
         except Exception:
             traffic = None
         launches = len(timer)
-        ksec = sum(e0.elapsed_time(e1) for e0, e1, _ in timer) * 1e-3
-        kflop = sum(f for _, _, f in timer)
+        ksec = sum(e0.elapsed_time(e1) for e0, e1, *_ in timer) * 1e-3
+        kflop = sum(f for _, _, f, *_ in timer)
         achieved = kflop / ksec / 1e12 if ksec > 0 else 0.0
         if args.gemm == "split":
             kernel_name = "gemm_split_kernel"
@@ -301,13 +341,16 @@ def main():
                        else ("training step: PoseNet9D training-mode forward with autograd, DCD Chamfer + pose + topology-code "
                              "loss, backward, gradient all-reduce, clip, SGD; B=%d objects per GPU, N=%d points" % (B, N_POINTS)),
                        "objects_per_gpu": B, "points": N_POINTS, "replicas": world, "batches_in_flight": len(streams),
-                       "hipgraph": {0: "off", 1: "whole batch", 2: "two half batches on forked streams"}[args.graph]},
+                       "hipgraph": {0: "off", 1: "whole batch" if replayers is None else "whole batch, one captured forward per stream",
+                                    2: "two half batches on forked streams"}[args.graph]},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "kernel": kernel_name, "peak_basis": peak_basis,
                          "launches_timed": launches, "avg_launch_us": round(1e6 * ksec / max(launches, 1), 2),
                          "share_of_step": round(ksec / roof_elapsed, 4), "measured": roof_note},
         }
+        if one_in_flight is not None:
+            line["config"]["objects_per_s_one_batch_in_flight"] = round(one_in_flight, 1)     # this rank's clock, not max-over-ranks
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(line), flush=True)

@@ -1495,3 +1495,39 @@ def test_tda_loss_large_batch_and_graph_capture(ops):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.isfinite(gtotal).item() and not torch.equal(gtotal, eager_total)          # the replay read the new translation
+
+
+def test_two_replays_in_flight_equal_serial(ops):
+    """bench.py's default keeps two captured forwards in flight on two HIP streams.  Each GraphedForward owns its static inputs,
+    outputs and activation pool, so concurrent replays must return exactly what the same batches return one after the other."""
+    from tgpose_amd import FLAGS, engine
+    net = _net(3)
+    FLAGS.train = 0
+    B, N = 4, 1028
+    pk = net.packed(DEV)
+    reps = [engine.GraphedForward(pk, B, N, torch.device(DEV), train_keys=False) for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    data = []
+    for seed in (11, 12, 13, 14):
+        pts, obj = synth_points(B, N, seed)
+        torch.manual_seed(seed)
+        i1 = torch.randperm(N)[: N // 4]
+        data.append((g(pts), g(obj), (i1, torch.randperm(i1.numel())[: i1.numel() // 4])))
+    serial = []
+    for pts, obj, smp in data:
+        serial.append({k: v.clone() for k, v in reps[0](pts, obj, smp).items()})
+        torch.cuda.synchronize()
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+    got = []
+    for rnd in range(2):                       # two rounds of two overlapping replays
+        outs = []
+        for i in range(2):
+            pts, obj, smp = data[2 * rnd + i]
+            with torch.cuda.stream(streams[i]):
+                outs.append(reps[i](pts, obj, smp))
+        torch.cuda.synchronize()
+        got += [{k: v.clone() for k, v in o.items()} for o in outs]
+    for want, have in zip(serial, got):
+        for k in want:
+            assert torch.equal(want[k], have[k]), k

@@ -387,7 +387,7 @@ class GraphedBackward(object):
         self.points, self.obj = points.clone(), obj_id.clone().float()
         self.s1 = torch.zeros(n1, dtype=torch.int32, device=dev)
         self.s2 = torch.zeros(n1 // 4, dtype=torch.int32, device=dev)
-        self._pin = torch.empty(n1 + n1 // 4, dtype=torch.int32).pin_memory()
+        self._pins = engine.PinnedRing(n1 + n1 // 4)
         self._s12 = torch.zeros(n1 + n1 // 4, dtype=torch.int32, device=dev)
 
         def run():
@@ -418,8 +418,7 @@ class GraphedBackward(object):
 
     def _draw(self, sample_idx):
         i1, i2 = sample_idx if sample_idx is not None else engine.draw_sample_idx(self.N)
-        self._pin.copy_(torch.cat([i1.reshape(-1), i2.reshape(-1)]).to(torch.int32))
-        self._s12.copy_(self._pin, non_blocking=True)
+        self._pins.upload(torch.cat([i1.reshape(-1), i2.reshape(-1)]), self._s12)
 
     def __call__(self, points=None, obj_id=None, sample_idx=None):
         if points is not None:

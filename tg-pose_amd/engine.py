@@ -705,6 +705,27 @@ def encoder_only_forward_train(pk, sd, points, obj_id, sample_idx=None, inject=N
 # Inputs are copied into static buffers before a replay; the returned tensors are the graph's static outputs, valid
 # until the next replay (the usual contract of graph replay).
 # =====================================================================================================
+class PinnedRing(object):
+    """Host staging for the per-forward subsample indices.  A replay is enqueued asynchronously, so the host may be several
+    steps ahead of the device: each upload takes the next of `slots` pinned buffers and first waits for the copy that last
+    read that buffer (an event), instead of overwriting a buffer an in-flight copy may still be reading."""
+
+    def __init__(self, numel, slots=4):
+        self.bufs = [torch.empty(numel, dtype=torch.int32).pin_memory() for _ in range(slots)]
+        self.done = [None] * slots
+        self.at = 0
+
+    def upload(self, values, dst):
+        i = self.at
+        self.at = (i + 1) % len(self.bufs)
+        if self.done[i] is not None:
+            self.done[i].synchronize()
+        self.bufs[i].copy_(values.to(torch.int32))
+        dst.copy_(self.bufs[i], non_blocking=True)
+        self.done[i] = torch.cuda.Event()
+        self.done[i].record(torch.cuda.current_stream(dst.device))
+
+
 class GraphedForward(object):
     def __init__(self, pk, B, N, device, train_keys=False, parts=1, kmax=20, n_cls=6):
         global SIDE_TAG
@@ -717,7 +738,7 @@ class GraphedForward(object):
         self.obj = torch.zeros(B, 1, device=device)
         self.s1 = torch.zeros(n1, device=device, dtype=torch.int32)
         self.s2 = torch.zeros(n2, device=device, dtype=torch.int32)
-        self._pin = torch.empty(n1 + n2, dtype=torch.int32).pin_memory()
+        self._pins = PinnedRing(n1 + n2)
         self._s12 = torch.zeros(n1 + n2, device=device, dtype=torch.int32)
         half = B // parts
 
@@ -764,8 +785,7 @@ class GraphedForward(object):
             raise ValueError("GraphedForward was captured for points of shape (%d, %d, 3)" % (self.B, self.N))
         if sample_idx is None:
             sample_idx = draw_sample_idx(self.N)
-        self._pin.copy_(torch.cat([sample_idx[0].reshape(-1), sample_idx[1].reshape(-1)]).to(torch.int32))
-        self._s12.copy_(self._pin, non_blocking=True)
+        self._pins.upload(torch.cat([sample_idx[0].reshape(-1), sample_idx[1].reshape(-1)]), self._s12)
         self.points.copy_(points, non_blocking=True)
         self.obj.copy_(obj_id.reshape(self.B, 1).to(self.points.dtype), non_blocking=True)
         self.graph.replay()

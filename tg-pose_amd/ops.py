@@ -224,6 +224,7 @@ def split_bf16(W):
 # bench.py sets this to a list to time, with HIP events on the launch stream, every launch that the
 # library routes to its 128x128-tile MFMA kernel (same rule as tgp_gemm_f32 in csrc/gemm.hip).
 GEMM_TIMER = None
+GEMM_TIMER_ALL = False      # development: time the small-tile and skinny launches too (scripts/gemm_shapes.py)
 
 
 def _routes_to_big_tile(M, N, batch=1):
@@ -247,7 +248,7 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
     """Raw call into tgp_gemm_f32.  A/W/C/res* are tensors whose data_ptr is the first element of the
     operand (views into wider buffers are fine); all sizes/strides are explicit.  k_alg: the layer's
     true input width when K includes zero padding (only used for FLOP accounting in bench.py)."""
-    timed = GEMM_TIMER is not None and _routes_to_big_tile(M, N, batch)
+    timed = GEMM_TIMER is not None and (GEMM_TIMER_ALL or _routes_to_big_tile(M, N, batch))
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(A.device))
@@ -272,7 +273,7 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
     check(_lib.lib().tgp_gemm_f32(ctypes.byref(a), _stream(A)), "tgp_gemm_f32")
     if timed:
         e1.record(torch.cuda.current_stream(A.device))
-        GEMM_TIMER.append((e0, e1, 2.0 * M * N * (k_alg or K) * batch))
+        GEMM_TIMER.append((e0, e1, 2.0 * M * N * (k_alg or K) * batch, (M, N, K, batch)))
     return C
 
 
