@@ -8,16 +8,24 @@
 One "step" = one full forward of the hot path (kNN graphs, 3D-GCN encoder, PH predictor, decoder,
 three heads, pose post-processing) over one batch of B synthetic clouds already resident in HBM
 (BASELINE.json configs[1] extended to the whole forward, which is what `metric` is quoted on).
-Objects are independent in eval mode, so N GPUs run N replicas on their own batches with no
+The forward is replayed as a captured hipGraph; by default two batches are in flight (`--streams 2`:
+one captured forward per HIP stream, step i on stream i % 2 over its own batch), `--streams 1` keeps
+one.  Objects are independent in eval mode, so N GPUs run N replicas on their own batches with no
 data-path collective (weak scaling); the only RCCL traffic is the barrier / max-time reduction
 around the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      the dominant kernel (gemm_main_kernel: fp32 MFMA, the per-point MLPs that
-                hold 95 % of the FLOPs), timed live with HIP events on the launch stream around every
-                one of its launches in the timed steps: achieved = algorithmic FLOPs / time.
+  roofline      the dominant kernel family (gemm_split_kernel / gemm_split512_kernel: the operand-split
+                GEMM on the fp16 matrix cores that holds the per-point MLPs, 95 % of the FLOPs), timed
+                with HIP events on the launch stream around every one of its launches: achieved =
+                algorithmic fp32 FLOPs / time.  Replayed graphs have no launch to bracket, so the
+                events go around serial eager launches of the same steps right after the timed region
+                (`roofline.measured` says which).
   cpu_baseline  the CPU oracle (the build's restatement of the reference's torch op sequence,
                 oracle/posenet_ref.py mode='torch') timed on this host's cores on a bounded sample.
+
+`--workload train_step` times the trainer's step instead (training-mode forward with autograd, the
+fourteen-term TDA loss, backward, gradient all-reduce, clip, SGD), replayed as one hipGraph.
 """
 import argparse
 import json
