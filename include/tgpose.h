@@ -148,6 +148,15 @@ typedef struct tgp_gemm_args {
      *    accurate to ~2^-22; requires |A|, |W| < 65504 (an out-of-range operand yields inf/NaN, never a wrong finite
      *    number) */
     int w_split_kind;
+    /* Backward GEMMs on the fp16 split (w_split_kind 1 only; all three optional).  Gradients lie far below fp16's range, so
+     * the caller picks a power of two s with max|A| * s < 65504 (tgp_absmax_scale): A is multiplied by *a_scale before it is
+     * split, the accumulated sums by *c_scale (= 1 / s, or 1 when a later pass unscales) before the epilogue.  Both are
+     * device pointers, so the scale of a step is chosen on the device and the step stays capturable in a graph.
+     * ksplit_chunk > 0: split-K -- the `batch` problems are consecutive K-chunks of ONE problem: problem b reads
+     * A[:, b*chunk : b*chunk + K], the W_split K-tiles from b*chunk on, and writes C + b*batch_stride_c (partial sums the
+     * caller adds up, tgp_sum_slabs); chunk % 16 == 0, operands zero-padded so that every chunk holds K columns. */
+    const float *a_scale, *c_scale;
+    int ksplit_chunk;
 } tgp_gemm_args;
 
 /* W (rows, K) fp32, row stride ld -> out[rows][ldo/16][3][16] bf16: per 16-wide K-tile the hi, mid and lo terms
@@ -313,6 +322,21 @@ int tgp_pose_transform_fwd(const float *points, const float *R, const float *t, 
                            tgp_stream_t stream);
 int tgp_pose_transform_bwd(const float *points, const float *R, const float *t, const float *s, const float *dout, int B, int n,
                            float *dpoints, float *dR, float *dt, float *ds, tgp_stream_t stream);
+
+/* ---- backward GEMMs on the fp16 operand split: scale selection, scaled transposes, K-split partial sums ----------------- */
+
+/* out = {s, 1/s, max|x|} on the device: s = 2^k, the largest power of two with max|x| * s <= target (s = 1 for an all-zero
+ * tensor).  x (rows, cols) row stride ld; workspace: 512 uint32. */
+int tgp_absmax_scale(const float *x, int ld, int64_t rows, int cols, float target, uint32_t *workspace, float *out,
+                     tgp_stream_t stream);
+/* dst (cols, rows_pad) = (src (rows, cols) * *scale)^T as fp32 (scale may be NULL), columns rows.. zero */
+int tgp_transpose_scaled(const float *src, int ld_src, int rows, int cols, const float *scale, float *dst, int rows_pad,
+                         tgp_stream_t stream);
+/* the same, written as the fp16 hi / lo planes of tgp_split_f16: dst [cols][rows_pad / 16][2][16]; rows_pad % 16 == 0 */
+int tgp_transpose_split_f16(const float *src, int ld_src, int rows, int cols, const float *scale, uint16_t *dst, int rows_pad,
+                            tgp_stream_t stream);
+/* out[i] (+)= *scale * sum_z parts[z * n + i], z ascending (scale may be NULL) */
+int tgp_sum_slabs(const float *parts, int Z, int64_t n, const float *scale, float *out, int accumulate, tgp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * The regression terms of the training loss either side of Chamfer (losses/TDA_loss_sym_recon.py, losses/consistency_loss.py).

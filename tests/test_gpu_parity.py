@@ -5,6 +5,7 @@ and against the golden vectors recorded from the reference.
 Bars: indices and Chamfer results bit-exact; float layers within 1e-4 (stated per test; most are
 held to a tighter bound).  /root/reference is never touched here.
 """
+import math
 import os
 
 import numpy as np
@@ -926,6 +927,57 @@ def test_gemm_tn_vs_fp64(ops, rows, N, K, lda, ldb):
     assert torch.equal(got, again)
     acc = ops.gemm_tn(g(A)[:, :N], g(Bm)[:, :K], out=got.clone(), accumulate=True)
     assert torch.allclose(acc, 2 * got, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("rows,N,K", [(32896, 256, 1024), (32896, 1024, 1292), (8224, 2304, 128), (4112, 512, 512), (32896, 131, 260)])
+@pytest.mark.parametrize("mag", [1.0, 3e-7])
+def test_gemm_tn_fp16_split_vs_fp64(ops, rows, N, K, mag):
+    """The weight-gradient GEMM on the fp16 split kernels (scale chosen on the device, K-split partial sums): gradient-sized
+    operands -- magnitudes around `mag`, a log-normal spread of four decades, some all-zero rows -- against fp64, against the
+    fp32 MFMA path, run-to-run identical, accumulate form; and the device-side scale itself."""
+    assert ops.tn_split_ok(rows, N, K)
+    gen = torch.Generator().manual_seed(rows + N + K)
+    dy = torch.randn(rows, N, generator=gen) * torch.exp(2.3 * torch.randn(rows, 1, generator=gen)) * mag
+    dy[::7] = 0.0
+    x = torch.randn(rows, K, generator=gen) * 3 + 0.5
+    want = dy.double().t() @ x.double()
+    ref = want.abs().max().item()
+    sc = ops.absmax_scale(g(dy)).cpu()
+    mx = dy.abs().max().item()
+    assert sc[2].item() == mx and sc[0].item() * sc[1].item() == 1.0 and 16384.0 <= mx * sc[0].item() <= 32768.0
+    assert math.log2(sc[0].item()) == round(math.log2(sc[0].item()))
+    got = ops.gemm_tn(g(dy), g(x))
+    err = (got.cpu().double() - want).abs().max().item()
+    assert err <= 2e-6 * ref * max(1.0, (rows / 1000) ** 0.5), (err, ref)
+    old, ops.TN_SPLIT = ops.TN_SPLIT, False
+    try:
+        base = ops.gemm_tn(g(dy), g(x))
+    finally:
+        ops.TN_SPLIT = old
+    assert (base.cpu().double() - want).abs().max().item() * 3 + 1e-7 * ref >= err      # no worse than ~3x the fp32 MFMA path
+    assert torch.equal(got, ops.gemm_tn(g(dy), g(x)))
+    acc = ops.gemm_tn(g(dy), g(x), out=got.clone(), accumulate=True)
+    assert torch.allclose(acc, 2 * got, rtol=1e-6, atol=0)
+    zero = ops.gemm_tn(g(torch.zeros(rows, N)), g(x))
+    assert zero.abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("rows,N,K", [(32896, 1024, 1292), (8224, 256, 2304), (32896, 512, 512)])
+def test_linear_backward_fp16_split_vs_fp64(ops, rows, N, K):
+    """_Linear.backward with both GEMMs on the scaled fp16 split (dx = dy W through a_scale / c_scale, dW through the K-split
+    path) against fp64, with gradient-sized dy."""
+    from tgpose_amd import autograd as AG
+    gen = torch.Generator().manual_seed(rows + N)
+    x = (torch.randn(rows, K, generator=gen) * 2 + 0.3)
+    W = torch.randn(N, K, generator=gen) / K ** 0.5
+    dy = torch.randn(rows, N, generator=gen) * torch.exp(2.0 * torch.randn(rows, 1, generator=gen)) * 1e-6
+    xd, Wd = g(x).requires_grad_(True), g(W).requires_grad_(True)
+    AG.linear(xd, Wd).backward(g(dy))
+    want_dx = dy.double() @ W.double()
+    want_dW = dy.double().t() @ x.double()
+    for got, want in ((xd.grad, want_dx), (Wd.grad, want_dW)):
+        err = (got.cpu().double() - want).abs().max().item()
+        assert err <= 3e-6 * want.abs().max().item() * max(1.0, (rows / 1000) ** 0.5), (err, want.abs().max().item())
 
 
 @pytest.mark.parametrize("rows,C,act,slope", [(4112, 128, 1, 0.0), (1028, 256, 1, 0.2), (32, 256, 0, 0.0), (3000, 70, 1, 0.0)])

@@ -35,6 +35,7 @@ class GemmArgs(ctypes.Structure):
         ("batch_stride_a", c_i64), ("batch_stride_w", c_i64), ("batch_stride_c", c_i64),
         ("batch_stride_vec", c_i64), ("batch_stride_colmax", c_i64),
         ("W_split", c_vp), ("ldws", c_int), ("w_split_kind", c_int),
+        ("a_scale", c_vp), ("c_scale", c_vp), ("ksplit_chunk", c_int),
     ]
 
 
@@ -77,6 +78,10 @@ SIGNATURES = {
     "tgp_nbrmax_bwd": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_f32, c_vp, c_int, c_vp]),
     "tgp_iou3d_pairs": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "tgp_rt_error_pairs": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "tgp_absmax_scale": (c_int, [c_vp, c_int, c_i64, c_int, c_f32, c_vp, c_vp, c_vp]),
+    "tgp_transpose_scaled": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
+    "tgp_transpose_split_f16": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
+    "tgp_sum_slabs": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_int, c_vp]),
     "tgp_pose_terms_fwd": (c_int, [c_vp] * 11 + [c_int, c_int, c_int, c_f32, c_vp, c_vp]),
     "tgp_pose_terms_bwd": (c_int, [c_vp] * 11 + [c_int, c_int, c_int, c_f32] + [c_vp] * 8 + [c_vp]),
     "tgp_sym_recon_workspace_floats": (c_i64, [c_int, c_int]),

@@ -55,13 +55,22 @@ class _Linear(Function):
         dy2 = dy.reshape(-1, N)
         x2 = x.reshape(-1, K)
         dx = dW = db = None
+        rows = dy2.shape[0]
+        # both GEMMs of a large layer run on the fp16 split kernels with dy lifted into fp16's range by one power of two chosen
+        # on the device (ops.absmax_scale); small ones keep the bf16x3 / fp32 MFMA paths
+        dx_f16 = ctx.needs_input_grad[0] and ops.GEMM_MODE == "split16" and ops.TN_SPLIT and ops._routes_to_big_tile(rows, K)
+        dw_f16 = ctx.needs_input_grad[1] and ops.tn_split_ok(rows, N, K)
+        sc = ops.absmax_scale(dy2.contiguous()) if (dx_f16 or dw_f16) else None
         if ctx.needs_input_grad[0]:
             dyp = _pad4(dy2).contiguous()                       # the reduction dim of this GEMM is N
             wt = ops.transpose(W.contiguous())                  # (K, N)
             wt = _pad4(wt).contiguous()
-            dx = ops.linear_rows(dyp, wt, w_split=_split_if_big(wt, dyp.shape[0], grads=True)).view(x.shape)
+            if dx_f16:
+                dx = ops.linear_rows(dyp, wt, w_split=ops.split_f16(wt), a_scale=sc, c_scale=sc[1:]).view(x.shape)
+            else:
+                dx = ops.linear_rows(dyp, wt, w_split=_split_if_big(wt, dyp.shape[0], grads=True)).view(x.shape)
         if ctx.needs_input_grad[1]:
-            dW = ops.gemm_tn(dy2.contiguous(), x2)
+            dW = ops.gemm_tn(dy2.contiguous(), x2, scale=sc if dw_f16 else None)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.colsum(dy2.contiguous())
         return dx, dW, db

@@ -480,3 +480,140 @@ extern "C" int tgp_transpose(const float *src, int ld_src, int rows, int cols, f
                        rows, cols, dst, ld_dst);
     return TGP_LAUNCH_RESULT();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward GEMMs on the fp16 operand split.  A gradient tensor spans tens of binades below 1 -- outside fp16's range --
+// but within ONE tensor the elements that matter lie within ~2^30 of the largest.  So: find max|dy| on the device, pick the
+// power of two that puts it just under fp16's top, scale while transposing (exact), run the forward's split kernels
+// (3 MFMA terms per product instead of 6 for bf16x3, or the fp32 MFMA of gemm_tn_kernel), unscale when the K-split
+// partial sums are added up.  Elements below max * 2^-38 flush to zero, i.e. an error of 2^-38 relative to the largest
+// element -- fp32 addition loses more.  Everything stays on the device: the step remains capturable in a graph.
+// ---------------------------------------------------------------------------------------------------------------------
+#define AM_THREADS 256
+#define AM_BLOCKS 512
+
+__global__ __launch_bounds__(AM_THREADS) void absmax_partial_kernel(const float *__restrict__ x, int ld, int64_t rows, int cols,
+                                                                    uint32_t *__restrict__ partial)
+{
+    __shared__ uint32_t red[AM_THREADS];
+    const int64_t n = rows * cols;
+    uint32_t m = 0;
+    for (int64_t t = (int64_t)blockIdx.x * AM_THREADS + threadIdx.x; t < n; t += (int64_t)gridDim.x * AM_THREADS) {
+        const int64_t r = t / cols;
+        const uint32_t u = __float_as_uint(x[r * ld + (t - r * cols)]) & 0x7fffffffu;      // |x| orders as an integer
+        m = u > m ? u : m;
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = AM_THREADS / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// out = {s, 1 / s, max|x|}: s = 2^k with max|x| * s in [target / 2, target); s = 1 for an all-zero or non-finite tensor
+__global__ __launch_bounds__(AM_THREADS) void absmax_final_kernel(const uint32_t *__restrict__ partial, int n, float target,
+                                                                  float *__restrict__ out)
+{
+    __shared__ uint32_t red[AM_THREADS];
+    uint32_t m = 0;
+    for (int i = threadIdx.x; i < n; i += AM_THREADS) m = partial[i] > m ? partial[i] : m;
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = AM_THREADS / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mx = __uint_as_float(red[0]);
+        float s = 1.f;
+        if (mx > 0.f && mx < INFINITY) {
+            int e;
+            frexpf(target / mx, &e);                           // target / mx = f * 2^e, f in [0.5, 1)
+            e -= 1;                                            // 2^e <= target / mx
+            e = e > 126 ? 126 : (e < -126 ? -126 : e);
+            s = ldexpf(1.f, e);
+        }
+        out[0] = s, out[1] = 1.f / s, out[2] = mx;
+    }
+}
+
+extern "C" int tgp_absmax_scale(const float *x, int ld, int64_t rows, int cols, float target, uint32_t *workspace, float *out,
+                                tgp_stream_t stream)
+{
+    TGP_REQUIRE(x && workspace && out && rows > 0 && cols > 0 && ld >= cols && target > 0.f);
+    const int64_t n = rows * cols;
+    const int blocks = (int)(n / AM_THREADS + 1 < AM_BLOCKS ? n / AM_THREADS + 1 : AM_BLOCKS);
+    hipLaunchKernelGGL(absmax_partial_kernel, dim3(blocks), dim3(AM_THREADS), 0, tgp_hs(stream), x, ld, rows, cols, workspace);
+    hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(AM_THREADS), 0, tgp_hs(stream), workspace, blocks, target, out);
+    return TGP_LAUNCH_RESULT();
+}
+
+// dst (cols, rows_pad) = (src (rows, cols) * *scale)^T, columns rows..rows_pad-1 zero.  SPLIT: dst is the fp16 hi / lo plane
+// layout of tgp_split_f16 ([cols][rows_pad / 16][2][16]) instead of fp32.
+template <bool SPLIT>
+__global__ void transpose_scaled_kernel(const float *__restrict__ src, int lds_, int rows, int cols, const float *__restrict__ scale,
+                                        void *__restrict__ dst_, int rows_pad)
+{
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const float sc = scale ? scale[0] : 1.f;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + threadIdx.x;
+        tile[j][threadIdx.x] = (r < rows && c < cols) ? src[(int64_t)r * lds_ + c] * sc : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + threadIdx.x;
+        if (c < cols && r < rows_pad) {
+            const float v = tile[threadIdx.x][j];
+            if constexpr (SPLIT) {
+                const _Float16 hb = (_Float16)v;
+                const _Float16 lb = (_Float16)(v - (float)hb);
+                uint16_t *o = static_cast<uint16_t *>(dst_) + ((int64_t)c * (rows_pad / 16) + r / 16) * 32 + (r & 15);
+                o[0] = __builtin_bit_cast(uint16_t, hb);
+                o[16] = __builtin_bit_cast(uint16_t, lb);
+            } else {
+                static_cast<float *>(dst_)[(int64_t)c * rows_pad + r] = v;
+            }
+        }
+    }
+}
+
+extern "C" int tgp_transpose_scaled(const float *src, int ld_src, int rows, int cols, const float *scale, float *dst, int rows_pad,
+                                    tgp_stream_t stream)
+{
+    TGP_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_src >= cols && rows_pad >= rows);
+    hipLaunchKernelGGL((transpose_scaled_kernel<false>), dim3(tgp_cdiv(cols, 32), tgp_cdiv(rows_pad, 32)), dim3(32, 8), 0, tgp_hs(stream), src,
+                       ld_src, rows, cols, scale, dst, rows_pad);
+    return TGP_LAUNCH_RESULT();
+}
+
+extern "C" int tgp_transpose_split_f16(const float *src, int ld_src, int rows, int cols, const float *scale, uint16_t *dst, int rows_pad,
+                                       tgp_stream_t stream)
+{
+    TGP_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_src >= cols && rows_pad >= rows && (rows_pad & 15) == 0);
+    hipLaunchKernelGGL((transpose_scaled_kernel<true>), dim3(tgp_cdiv(cols, 32), tgp_cdiv(rows_pad, 32)), dim3(32, 8), 0, tgp_hs(stream), src,
+                       ld_src, rows, cols, scale, dst, rows_pad);
+    return TGP_LAUNCH_RESULT();
+}
+
+// out[i] (+)= *scale * sum_z parts[z * n + i], slabs added in order (deterministic)
+__global__ void sum_slabs_kernel(const float *__restrict__ parts, int Z, int64_t n, const float *__restrict__ scale, float *__restrict__ out,
+                                 int accumulate)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = parts[i];
+    for (int z = 1; z < Z; ++z) s += parts[(int64_t)z * n + i];
+    s *= scale ? scale[0] : 1.f;
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+extern "C" int tgp_sum_slabs(const float *parts, int Z, int64_t n, const float *scale, float *out, int accumulate, tgp_stream_t stream)
+{
+    TGP_REQUIRE(parts && out && Z > 0 && n > 0);
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3(tgp_cdiv(n, 256)), dim3(256), 0, tgp_hs(stream), parts, Z, n, scale, out, accumulate);
+    return TGP_LAUNCH_RESULT();
+}

@@ -54,6 +54,11 @@ struct GemmParams {
     int seg_end[8], seg_base[8];
     unsigned long long *stamps;  // development only: per block {start, loop start, loop end, end} of s_memrealtime (100 MHz)
     int64_t sWS;                 // per-batch stride of Wsplit in bf16 elements of one plane
+    // backward GEMMs on the fp16 split: A is multiplied by *a_scale (a power of two that lifts gradients into fp16's range)
+    // before it is split, the accumulators by *c_scale before the epilogue; ksplit: the batch index walks K-chunks of one
+    // problem (sA, sWS are K offsets), so the W descriptor's extent shrinks by the chunk offset
+    const float *a_scale, *c_scale;
+    int ksplit;
     int64_t plane;               // elements between planes
     // tile schedule of the main kernel: per batch, M-tile rows [0, mt_big) use 128x128 tiles, the rest 64x64
     int mt_big, tiles_n_big, tiles_big, tiles_m_small, tiles_n_small;
@@ -457,7 +462,8 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
     // and stay in flight across K-tiles (with per-lane guards the compiler wraps each load in a branch and has to drain
     // vmcnt to zero around it, which serialises the prefetch).  The K tail of A is masked when the tile is stored.
     const int64_t a_rows = p.M - m0, w_rows = p.N - n0;
-    const int64_t a_bytes = a_rows * p.lda * 4 - (p.lda - p.K) * 4, w_bytes = w_rows * wrow * 2;
+    const int64_t a_bytes = a_rows * p.lda * 4 - (p.lda - p.K) * 4, w_bytes = w_rows * wrow * 2 - (p.ksplit ? z * p.sWS * 2 : 0);
+    const float asc = p.a_scale ? p.a_scale[0] : 1.f;
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(A + (int64_t)m0 * p.lda), 0, (int)(a_bytes > 0x7fffffff ? 0x7fffffff : a_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
@@ -497,6 +503,7 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
                 const uint4 rbits = __builtin_bit_cast(uint4, ra_in[i]);
                 ra[i] = __builtin_bit_cast(float4, make_uint4(rbits.x & km, rbits.y & km, rbits.z & km, rbits.w & km));
                 if constexpr (F16) {
+                    ra[i].x *= asc, ra[i].y *= asc, ra[i].z *= asc, ra[i].w *= asc;       // exact: asc is 1 or a power of two
                     uint2 q0, q1;
                     split2(ra[i], q0, q1);
                     *reinterpret_cast<uint2 *>(dst) = q0;
@@ -659,6 +666,15 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
         hand(1, 0);
         if (KG == 4) hand(3, 2), hand(2, 0);
         if (kg != 0) return;
+    }
+    if (p.c_scale) {
+        const float cs = p.c_scale[0];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] *= cs;
     }
     if (!(p.rowbias || p.cm) || p.rows_per_obj >= WTM) gemm_epilogue_fast<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h);
     else gemm_epilogue<TM, TN, WTM, WTN, false>(p, acc, m0, n0, z, wm, wn, r, h);
@@ -1286,6 +1302,10 @@ extern "C" int tgp_gemm_f32(const tgp_gemm_args *a, tgp_stream_t stream)
     p.sCM = a->batch_stride_colmax;
     const bool plain = !a->rowbias && !a->res2 && !a->colmax_keys && !a->slope_vec && a->c_col0 == 0 &&
                        (p.batch == 1 || !a->res1);
+    // a_scale / c_scale / ksplit_chunk are implemented by the fp16 split tile kernels only: refuse launches that route elsewhere
+    TGP_REQUIRE(!(a->a_scale || a->c_scale || a->ksplit_chunk) ||
+                (a->W_split && a->w_split_kind == 1 && a->M > 32 && a->N > 64 &&
+                 (int64_t)tgp_cdiv(a->M, GEMM_MID) * tgp_cdiv(a->N, GEMM_MID) * p.batch >= resident_slots() / 2));
     if (a->M <= 32 && a->C && plain) {
         if ((int64_t)tgp_cdiv(a->N, 32) * p.batch >= resident_slots() / 2)
             hipLaunchKernelGGL((skinny_gemm_kernel<2, 8>), dim3(tgp_cdiv(a->N, 32), p.batch), dim3(512), 0, tgp_hs(stream), p);
@@ -1303,6 +1323,20 @@ extern "C" int tgp_gemm_f32(const tgp_gemm_args *a, tgp_stream_t stream)
             p.plane = 0;
             p.split_f16 = a->w_split_kind;
             p.sWS = (a->w_split_kind ? 2 : 3) * (int64_t)a->N * a->ldws;
+            if (a->a_scale || a->c_scale || a->ksplit_chunk) {
+                // the scaled / K-split forms exist in the fp16 tile kernels only (the backward's use)
+                TGP_REQUIRE(a->w_split_kind == 1);
+                p.a_scale = a->a_scale, p.c_scale = a->c_scale;
+                if (a->ksplit_chunk) {
+                    // batch b covers the K columns [b * chunk, b * chunk + K): chunk % 16 == 0, operands zero padded so that
+                    // every chunk holds K columns
+                    TGP_REQUIRE(a->ksplit_chunk % 16 == 0 && a->ksplit_chunk >= a->K &&
+                                (int64_t)a->ksplit_chunk * (p.batch - 1) + a->K <= a->ldws);
+                    p.ksplit = 1;
+                    p.sA = a->ksplit_chunk;
+                    p.sWS = 2 * (int64_t)a->ksplit_chunk;
+                }
+            }
             return launch_split(p, tgp_hs(stream));
         }
         return launch_main(p, tgp_hs(stream));

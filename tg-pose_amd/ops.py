@@ -244,7 +244,8 @@ def _big_tile_threshold():
 
 def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, bias=None, rowbias=None,
          rows_per_obj=0, res1=None, ldr1=0, res2=None, ldr2=0, scale=None, shift=None, act=0, slope=0.0,
-         colmax_keys=None, k_alg=None, slope_vec=None, cm_cols=0, c_col0=0, batch=1, batch_strides=None, w_split=None):
+         colmax_keys=None, k_alg=None, slope_vec=None, cm_cols=0, c_col0=0, batch=1, batch_strides=None, w_split=None,
+         a_scale=None, c_scale=None, ksplit_chunk=0):
     """Raw call into tgp_gemm_f32.  A/W/C/res* are tensors whose data_ptr is the first element of the
     operand (views into wider buffers are fine); all sizes/strides are explicit.  k_alg: the layer's
     true input width when K includes zero padding (only used for FLOP accounting in bench.py)."""
@@ -270,6 +271,7 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
     if w_split is not None and GEMM_MODE != "fp32":
         a.W_split, a.ldws = _p(w_split), w_split.shape[-3] * 16
         a.w_split_kind = 1 if w_split.shape[-2] == 2 else 0
+    a.a_scale, a.c_scale, a.ksplit_chunk = _p(a_scale), _p(c_scale), int(ksplit_chunk)
     check(_lib.lib().tgp_gemm_f32(ctypes.byref(a), _stream(A)), "tgp_gemm_f32")
     if timed:
         e1.record(torch.cuda.current_stream(A.device))
@@ -278,7 +280,8 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
 
 
 def linear_rows(x, weight, bias=None, scale=None, shift=None, act=0, slope=0.0, out=None, rowbias=None,
-                rows_per_obj=0, res1=None, res2=None, colmax_keys=None, want_out=True, k_alg=None, w_split=None):
+                rows_per_obj=0, res1=None, res2=None, colmax_keys=None, want_out=True, k_alg=None, w_split=None,
+                a_scale=None, c_scale=None):
     """x (..., K) rows (row stride >= K), weight (N, Kw>=K) -> (..., N).  Convenience over gemm()."""
     x, lda = _rows(x, "x")
     weight, ldw = _rows(weight, "weight")
@@ -298,7 +301,7 @@ def linear_rows(x, weight, bias=None, scale=None, shift=None, act=0, slope=0.0, 
         r2, l2 = _rows(res2, "res2")
     gemm(x, weight, out if want_out else None, M=M, N=N, K=K, lda=lda, ldw=ldw, ldc=ldc, bias=bias, rowbias=rowbias,
          rows_per_obj=rows_per_obj, res1=r1, ldr1=l1, res2=r2, ldr2=l2, scale=scale, shift=shift, act=act, slope=slope,
-         colmax_keys=colmax_keys, k_alg=k_alg, w_split=w_split)
+         colmax_keys=colmax_keys, k_alg=k_alg, w_split=w_split, a_scale=a_scale, c_scale=c_scale)
     return out
 
 
@@ -457,13 +460,80 @@ def _ws(floats, dev):
     return torch.empty(max(int(floats), 1), device=dev, dtype=torch.float32)
 
 
-def gemm_tn(a, b, out=None, accumulate=False):
-    """out (N, K) (+)= a^T b over the rows: a (rows, N), b (rows, K) row views (row stride >= width).  dW = dx^T x."""
+FP16_TOP = 32768.0           # scaled gradients peak in [2^14, 2^15): a factor of two under fp16's largest finite value
+TN_SPLIT = True              # weight gradients of large layers through the fp16 split kernels (False: fp32 MFMA kernel only)
+TN_SPLIT_MIN = 128 * 256     # smallest N * K routed to the split path
+
+
+def absmax_scale(x, target=FP16_TOP):
+    """-> device tensor {s, 1/s, max|x|}: s the largest power of two with max|x| * s <= target (chosen on the device)"""
+    x, ld = _rows(x, "x")
+    rows, cols = math.prod(x.shape[:-1]), x.shape[-1]
+    ws = torch.empty(512, device=x.device, dtype=torch.int32)
+    out = torch.empty(3, device=x.device, dtype=torch.float32)
+    check(_lib.lib().tgp_absmax_scale(_p(x), ld, rows, cols, float(target), _p(ws), _p(out), _stream(x)), "tgp_absmax_scale")
+    return out
+
+
+def _ksplit_plan(rows, tiles):
+    """number of K-chunks Z and chunk length for a reduction over `rows` feeding `tiles` output tiles: fill whole rounds of the
+    256 resident workgroups, keep a chunk >= 512 rows"""
+    best, best_eff = 1, 0.0
+    for Z in range(1, max(1, rows // 512) + 1):
+        t = tiles * Z
+        eff = t / (256.0 * ((t + 255) // 256))
+        if eff > best_eff + 0.02:
+            best, best_eff = Z, eff
+        if t >= 1024:
+            break
+    chunk = ((rows + best - 1) // best + 15) // 16 * 16
+    return best, chunk
+
+
+def gemm_tn_split(a, b, scale, out=None, accumulate=False):
+    """gemm_tn on the fp16 split kernels: out (N, K) (+)= a^T b, a = dy (rows, N) scaled into fp16's range by scale[0]
+    (absmax_scale(a)), b = x (rows, K) activations.  a^T is transposed + scaled in fp32 and split on the fly as the GEMM's A
+    operand, b^T transposed straight into fp16 planes; the reduction over the rows is cut into Z chunks whose partial
+    products are added in order and unscaled by scale[1]."""
+    a, lda = _rows(a.reshape(-1, a.shape[-1]) if a.dim() > 2 and a.is_contiguous() else a, "a")
+    b, ldb = _rows(b.reshape(-1, b.shape[-1]) if b.dim() > 2 and b.is_contiguous() else b, "b")
+    rows, N, K = math.prod(a.shape[:-1]), a.shape[-1], b.shape[-1]
+    dev = a.device
+    Z, chunk = _ksplit_plan(rows, ((N + 255) // 256) * ((K + 255) // 256))
+    pad = Z * chunk
+    at = torch.empty(N, pad, device=dev, dtype=torch.float32)
+    check(_lib.lib().tgp_transpose_scaled(_p(a), lda, rows, N, _p(scale), _p(at), pad, _stream(a)), "tgp_transpose_scaled")
+    bt = torch.empty(K, pad // 16, 2, 16, device=dev, dtype=torch.int16)
+    check(_lib.lib().tgp_transpose_split_f16(_p(b), ldb, rows, K, None, _p(bt), pad, _stream(a)), "tgp_transpose_split_f16")
+    parts = torch.empty(Z, N, K, device=dev, dtype=torch.float32)
+    gemm(at, at, parts, M=N, N=K, K=chunk, lda=pad, ldw=pad, ldc=K, batch=Z, batch_strides=(chunk, 0, N * K, 0, 0), w_split=bt,
+         ksplit_chunk=chunk)
+    if out is None:
+        out = torch.empty(N, K, device=dev, dtype=torch.float32)
+    if not out.is_contiguous():
+        raise ValueError("gemm_tn_split: out must be contiguous")
+    check(_lib.lib().tgp_sum_slabs(_p(parts), Z, N * K, _p(scale[1:]), _p(out), int(accumulate), _stream(a)), "tgp_sum_slabs")
+    return out
+
+
+def tn_split_ok(rows, N, K):
+    """does gemm_tn route (rows, N)^T (rows, K) to the fp16 split path?  Large enough for the tile kernels in both output dims."""
+    if not (TN_SPLIT and GEMM_MODE == "split16" and rows >= 2048 and N * K >= TN_SPLIT_MIN and N > 32 and K > 64):
+        return False
+    Z, _ = _ksplit_plan(rows, ((N + 255) // 256) * ((K + 255) // 256))
+    return _routes_to_big_tile(N, K, Z)
+
+
+def gemm_tn(a, b, out=None, accumulate=False, scale=None):
+    """out (N, K) (+)= a^T b over the rows: a (rows, N), b (rows, K) row views (row stride >= width).  dW = dx^T x.
+    scale: absmax_scale(a) if the caller already has it (the same dy feeds the dx GEMM)."""
     a, lda = _rows(a.reshape(-1, a.shape[-1]) if a.dim() > 2 and a.is_contiguous() else a, "a")
     b, ldb = _rows(b.reshape(-1, b.shape[-1]) if b.dim() > 2 and b.is_contiguous() else b, "b")
     rows, N, K = math.prod(a.shape[:-1]), a.shape[-1], b.shape[-1]
     if math.prod(b.shape[:-1]) != rows:
         raise ValueError("gemm_tn: row counts differ")
+    if tn_split_ok(rows, N, K) and (out is None or out.is_contiguous()):
+        return gemm_tn_split(a, b, absmax_scale(a) if scale is None else scale, out, accumulate)
     if out is None:
         out = torch.empty(N, K, device=a.device, dtype=torch.float32)
     out, ldc = _rows(out, "out")
