@@ -221,6 +221,18 @@ def main():
             graphed_bwd = GraphedBackward(net, pts, obj, loss_fn)
 
             def step():
+                if os.environ.get("TGP_BENCH_TRACE"):          # development: where a step's wall time goes
+                    torch.cuda.synchronize(dev); t0 = time.perf_counter()
+                    loss = graphed_bwd()
+                    torch.cuda.synchronize(dev); t1 = time.perf_counter()
+                    shard.allreduce_gradients(net.parameters())
+                    torch.cuda.synchronize(dev); t2 = time.perf_counter()
+                    torch.nn.utils.clip_grad_norm_(net.parameters(), 5.0)
+                    opt.step()
+                    torch.cuda.synchronize(dev); t3 = time.perf_counter()
+                    print("rank %d: replay %.1f ms, all-reduce %.1f ms, clip + SGD %.1f ms" % (rank, 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2)),
+                          file=sys.stderr, flush=True)
+                    return loss
                 loss = graphed_bwd()
                 finish()
                 return loss

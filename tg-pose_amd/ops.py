@@ -5,6 +5,7 @@ device tensors; nothing synchronises.  Inputs must be fp32 (indices int32), on a
 layouts documented in include/tgpose.h -- violations raise instead of being silently copied.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -461,7 +462,7 @@ def _ws(floats, dev):
 
 
 FP16_TOP = 32768.0           # scaled gradients peak in [2^14, 2^15): a factor of two under fp16's largest finite value
-TN_SPLIT = True              # weight gradients of large layers through the fp16 split kernels (False: fp32 MFMA kernel only)
+TN_SPLIT = os.environ.get("TGP_TN_SPLIT", "1") != "0"    # backward GEMMs of large layers on the scaled fp16 split (0: bf16x3 / fp32 MFMA)
 TN_SPLIT_MIN = 128 * 256     # smallest N * K routed to the split path
 
 

@@ -66,6 +66,11 @@ def allreduce_gradients(params, bucket_bytes=64 << 20, average=True):
             cur, size = [], 0
     if cur:
         buckets.append(cur)
+    if grads and grads[0].is_cuda and dist.get_backend() == "gloo":
+        # rehearsal path (CPU collectives over device tensors, ranks possibly sharing one GPU): gloo stages through the host
+        # anyway; draining the device first keeps two processes' deep queues from waiting on each other across the exchange
+        # (measured on the one-GPU box: 8.6 s -> 0.1 s per step with the backward replayed as a graph)
+        torch.cuda.current_stream(grads[0].device).synchronize()
     for b in buckets:
         flat = torch.cat([g.reshape(-1) for g in b])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
