@@ -326,10 +326,11 @@ int tgp_pose_transform_bwd(const float *points, const float *R, const float *t, 
 /* ---- backward GEMMs on the fp16 operand split: scale selection, scaled transposes, K-split partial sums ----------------- */
 
 /* out = {s, 1/s, max|x|} on the device: s = 2^k, the largest power of two with max|x| * s <= target (s = 1 for an all-zero
- * tensor).  x (rows, cols) row stride ld; workspace: 512 uint32. */
+ * tensor).  x (rows, cols) row stride ld; workspace: 2048 uint32. */
 int tgp_absmax_scale(const float *x, int ld, int64_t rows, int cols, float target, uint32_t *workspace, float *out,
                      tgp_stream_t stream);
-/* dst (cols, rows_pad) = (src (rows, cols) * *scale)^T as fp32 (scale may be NULL), columns rows.. zero */
+/* dst (cols, rows_pad) = (src (rows, cols) * *scale)^T as fp32 (scale may be NULL), columns rows.. zero; rows_pad % 4 == 0,
+ * dst 16-byte aligned */
 int tgp_transpose_scaled(const float *src, int ld_src, int rows, int cols, const float *scale, float *dst, int rows_pad,
                          tgp_stream_t stream);
 /* the same, written as the fp16 hi / lo planes of tgp_split_f16: dst [cols][rows_pad / 16][2][16]; rows_pad % 16 == 0 */

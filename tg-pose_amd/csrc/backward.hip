@@ -490,7 +490,7 @@ extern "C" int tgp_transpose(const float *src, int ld_src, int rows, int cols, f
 // element -- fp32 addition loses more.  Everything stays on the device: the step remains capturable in a graph.
 // ---------------------------------------------------------------------------------------------------------------------
 #define AM_THREADS 256
-#define AM_BLOCKS 512
+#define AM_BLOCKS 2048
 
 __global__ __launch_bounds__(AM_THREADS) void absmax_partial_kernel(const float *__restrict__ x, int ld, int64_t rows, int cols,
                                                                     uint32_t *__restrict__ partial)
@@ -498,10 +498,21 @@ __global__ __launch_bounds__(AM_THREADS) void absmax_partial_kernel(const float 
     __shared__ uint32_t red[AM_THREADS];
     const int64_t n = rows * cols;
     uint32_t m = 0;
-    for (int64_t t = (int64_t)blockIdx.x * AM_THREADS + threadIdx.x; t < n; t += (int64_t)gridDim.x * AM_THREADS) {
-        const int64_t r = t / cols;
-        const uint32_t u = __float_as_uint(x[r * ld + (t - r * cols)]) & 0x7fffffffu;      // |x| orders as an integer
-        m = u > m ? u : m;
+    if (ld == cols && (n & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {      // contiguous: 16-byte loads
+        const uint4 *x4 = reinterpret_cast<const uint4 *>(x);
+        for (int64_t t = (int64_t)blockIdx.x * AM_THREADS + threadIdx.x; t < n / 4; t += (int64_t)gridDim.x * AM_THREADS) {
+            const uint4 v = x4[t];
+            const uint32_t a = (v.x & 0x7fffffffu) > (v.y & 0x7fffffffu) ? (v.x & 0x7fffffffu) : (v.y & 0x7fffffffu);
+            const uint32_t b = (v.z & 0x7fffffffu) > (v.w & 0x7fffffffu) ? (v.z & 0x7fffffffu) : (v.w & 0x7fffffffu);
+            const uint32_t u = a > b ? a : b;
+            m = u > m ? u : m;
+        }
+    } else {
+        for (int64_t t = (int64_t)blockIdx.x * AM_THREADS + threadIdx.x; t < n; t += (int64_t)gridDim.x * AM_THREADS) {
+            const int64_t r = t / cols;
+            const uint32_t u = __float_as_uint(x[r * ld + (t - r * cols)]) & 0x7fffffffu;      // |x| orders as an integer
+            m = u > m ? u : m;
+        }
     }
     red[threadIdx.x] = m;
     __syncthreads();
@@ -551,32 +562,62 @@ extern "C" int tgp_absmax_scale(const float *x, int ld, int64_t rows, int cols, 
 }
 
 // dst (cols, rows_pad) = (src (rows, cols) * *scale)^T, columns rows..rows_pad-1 zero.  SPLIT: dst is the fp16 hi / lo plane
-// layout of tgp_split_f16 ([cols][rows_pad / 16][2][16]) instead of fp32.
+// layout of tgp_split_f16 ([cols][rows_pad / 16][2][16]) instead of fp32.  64 x 64 tiles through LDS: rows of src are read
+// as float4 along the columns; the transposed side is written in 16-byte pieces -- four consecutive source rows of one
+// column as fp32, or eight of them as one plane's half K-tile (a K-tile's hi and lo halves are 64 contiguous bytes).
+// rows_pad % 16 == 0 for the split form; fp32 form: rows_pad % 4 == 0.
+#define TS_TILE 64
 template <bool SPLIT>
-__global__ void transpose_scaled_kernel(const float *__restrict__ src, int lds_, int rows, int cols, const float *__restrict__ scale,
-                                        void *__restrict__ dst_, int rows_pad)
+__global__ __launch_bounds__(256) void transpose_scaled_kernel(const float *__restrict__ src, int lds_, int rows, int cols,
+                                                               const float *__restrict__ scale, void *__restrict__ dst_, int rows_pad)
 {
-    __shared__ float tile[32][33];
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    __shared__ float tile[TS_TILE][TS_TILE + 1];
+    const int c0 = blockIdx.x * TS_TILE, r0 = blockIdx.y * TS_TILE;
     const float sc = scale ? scale[0] : 1.f;
-    for (int j = threadIdx.y; j < 32; j += 8) {
-        const int r = r0 + j, c = c0 + threadIdx.x;
-        tile[j][threadIdx.x] = (r < rows && c < cols) ? src[(int64_t)r * lds_ + c] * sc : 0.f;
+    const bool vec = (lds_ & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    for (int t = threadIdx.x; t < TS_TILE * TS_TILE / 4; t += 256) {
+        const int j = t / (TS_TILE / 4), q = t % (TS_TILE / 4);
+        const int r = r0 + j, c = c0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rows) {
+            if (vec && c + 3 < cols) {
+                v = *reinterpret_cast<const float4 *>(src + (int64_t)r * lds_ + c);
+            } else {
+                if (c < cols) v.x = src[(int64_t)r * lds_ + c];
+                if (c + 1 < cols) v.y = src[(int64_t)r * lds_ + c + 1];
+                if (c + 2 < cols) v.z = src[(int64_t)r * lds_ + c + 2];
+                if (c + 3 < cols) v.w = src[(int64_t)r * lds_ + c + 3];
+            }
+        }
+        tile[j][4 * q] = v.x * sc, tile[j][4 * q + 1] = v.y * sc, tile[j][4 * q + 2] = v.z * sc, tile[j][4 * q + 3] = v.w * sc;
     }
     __syncthreads();
-    for (int j = threadIdx.y; j < 32; j += 8) {
-        const int c = c0 + j, r = r0 + threadIdx.x;
-        if (c < cols && r < rows_pad) {
-            const float v = tile[threadIdx.x][j];
-            if constexpr (SPLIT) {
+    if constexpr (SPLIT) {
+        // item = (column, 8-row half of a 16-row K-tile): 64 columns x 8 halves per tile
+        for (int t = threadIdx.x; t < TS_TILE * (TS_TILE / 8); t += 256) {
+            const int cc = t / (TS_TILE / 8), hf = t % (TS_TILE / 8);
+            const int c = c0 + cc, r = r0 + 8 * hf;
+            if (c >= cols || r >= rows_pad) continue;
+            alignas(16) uint16_t hi[8];
+            alignas(16) uint16_t lo[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = tile[8 * hf + e][cc];
                 const _Float16 hb = (_Float16)v;
-                const _Float16 lb = (_Float16)(v - (float)hb);
-                uint16_t *o = static_cast<uint16_t *>(dst_) + ((int64_t)c * (rows_pad / 16) + r / 16) * 32 + (r & 15);
-                o[0] = __builtin_bit_cast(uint16_t, hb);
-                o[16] = __builtin_bit_cast(uint16_t, lb);
-            } else {
-                static_cast<float *>(dst_)[(int64_t)c * rows_pad + r] = v;
+                hi[e] = __builtin_bit_cast(uint16_t, hb);
+                lo[e] = __builtin_bit_cast(uint16_t, (_Float16)(v - (float)hb));
             }
+            uint16_t *o = static_cast<uint16_t *>(dst_) + ((int64_t)c * (rows_pad / 16) + r / 16) * 32 + (r & 15);
+            *reinterpret_cast<uint4 *>(o) = *reinterpret_cast<const uint4 *>(hi);
+            *reinterpret_cast<uint4 *>(o + 16) = *reinterpret_cast<const uint4 *>(lo);
+        }
+    } else {
+        for (int t = threadIdx.x; t < TS_TILE * (TS_TILE / 4); t += 256) {
+            const int cc = t / (TS_TILE / 4), q = t % (TS_TILE / 4);
+            const int c = c0 + cc, r = r0 + 4 * q;
+            if (c >= cols || r >= rows_pad) continue;
+            *reinterpret_cast<float4 *>(static_cast<float *>(dst_) + (int64_t)c * rows_pad + r) =
+                make_float4(tile[4 * q][cc], tile[4 * q + 1][cc], tile[4 * q + 2][cc], tile[4 * q + 3][cc]);
         }
     }
 }
@@ -584,18 +625,20 @@ __global__ void transpose_scaled_kernel(const float *__restrict__ src, int lds_,
 extern "C" int tgp_transpose_scaled(const float *src, int ld_src, int rows, int cols, const float *scale, float *dst, int rows_pad,
                                     tgp_stream_t stream)
 {
-    TGP_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_src >= cols && rows_pad >= rows);
-    hipLaunchKernelGGL((transpose_scaled_kernel<false>), dim3(tgp_cdiv(cols, 32), tgp_cdiv(rows_pad, 32)), dim3(32, 8), 0, tgp_hs(stream), src,
-                       ld_src, rows, cols, scale, dst, rows_pad);
+    TGP_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_src >= cols && rows_pad >= rows && (rows_pad & 3) == 0 &&
+                (reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+    hipLaunchKernelGGL((transpose_scaled_kernel<false>), dim3(tgp_cdiv(cols, TS_TILE), tgp_cdiv(rows_pad, TS_TILE)), dim3(256), 0,
+                       tgp_hs(stream), src, ld_src, rows, cols, scale, dst, rows_pad);
     return TGP_LAUNCH_RESULT();
 }
 
 extern "C" int tgp_transpose_split_f16(const float *src, int ld_src, int rows, int cols, const float *scale, uint16_t *dst, int rows_pad,
                                        tgp_stream_t stream)
 {
-    TGP_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_src >= cols && rows_pad >= rows && (rows_pad & 15) == 0);
-    hipLaunchKernelGGL((transpose_scaled_kernel<true>), dim3(tgp_cdiv(cols, 32), tgp_cdiv(rows_pad, 32)), dim3(32, 8), 0, tgp_hs(stream), src,
-                       ld_src, rows, cols, scale, dst, rows_pad);
+    TGP_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_src >= cols && rows_pad >= rows && (rows_pad & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+    hipLaunchKernelGGL((transpose_scaled_kernel<true>), dim3(tgp_cdiv(cols, TS_TILE), tgp_cdiv(rows_pad, TS_TILE)), dim3(256), 0,
+                       tgp_hs(stream), src, ld_src, rows, cols, scale, dst, rows_pad);
     return TGP_LAUNCH_RESULT();
 }
 

@@ -470,7 +470,7 @@ def absmax_scale(x, target=FP16_TOP):
     """-> device tensor {s, 1/s, max|x|}: s the largest power of two with max|x| * s <= target (chosen on the device)"""
     x, ld = _rows(x, "x")
     rows, cols = math.prod(x.shape[:-1]), x.shape[-1]
-    ws = torch.empty(512, device=x.device, dtype=torch.int32)
+    ws = torch.empty(2048, device=x.device, dtype=torch.int32)
     out = torch.empty(3, device=x.device, dtype=torch.float32)
     check(_lib.lib().tgp_absmax_scale(_p(x), ld, rows, cols, float(target), _p(ws), _p(out), _stream(x)), "tgp_absmax_scale")
     return out
