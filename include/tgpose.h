@@ -157,6 +157,13 @@ typedef struct tgp_gemm_args {
      * caller adds up, tgp_sum_slabs); chunk % 16 == 0, operands zero-padded so that every chunk holds K columns. */
     const float *a_scale, *c_scale;
     int ksplit_chunk;
+    /* Gathered residuals (tile kernels only, M > 32): C[m, n] gains gres1[gidx1[m], n] + gres2[gidx2[m], n] before the
+     * per-object bias and the BatchNorm fold.  This is how a layer over `feat` = [fine | up(coarse1) | up(coarse2)] (nearest
+     * upsampling, FaceRecon.py:70-75) runs factored: W_coarse x coarse features is computed once per COARSE point (4x / 16x
+     * fewer rows) and each point fetches the rows of its nearest coarse points, instead of multiplying upsampled copies.
+     * gidx: int32 per output row, absolute row of gres; excludes res1 / res2; rows_per_obj >= 64 with rowbias / colmax. */
+    const float *gres1; int ldg1; const int32_t *gidx1;
+    const float *gres2; int ldg2; const int32_t *gidx2;
 } tgp_gemm_args;
 
 /* W (rows, K) fp32, row stride ld -> out[rows][ldo/16][3][16] bf16: per 16-wide K-tile the hi, mid and lo terms

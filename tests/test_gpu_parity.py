@@ -1368,6 +1368,99 @@ def test_gemm_epilogue_object_boundaries_and_tails(ops, M, N, K, rpo, gemm_mode)
     assert torch.equal(cm, torch.cat([out.cpu(), pad]).view(nobj, rpo, N).max(dim=1)[0])
 
 
+def _scalar_epilogue(on):
+    import ctypes
+    from tgpose_amd import _lib
+    ctypes.CDLL(_lib.LIB_PATH).tgp_debug_set_split_scalar_epilogue(int(on))
+
+
+@pytest.mark.parametrize("M,N,K,rpo", [(32896 // 8, 1024, 272, 1028), (1300, 640, 128, 100), (522, 384, 64, 64), (4112, 4096, 268, 1028)])
+def test_lds_epilogue_bit_identical_to_register_epilogue(ops, M, N, K, rpo):
+    """The LDS-staged 16-byte epilogue of the split kernels against the register-direct one (forced through the debug switch)
+    with every feature on -- bias, per-object bias, both residuals, BN fold, per-column leaky slope, a column range for the
+    store and a narrower one for the max over points: same bits in C and in the colmax keys."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    nobj = (M + rpo - 1) // rpo
+    A, W = g(torch.randn(M, K, generator=gen)), g(torch.randn(N, K, generator=gen) / K ** 0.5)
+    vec = lambda: g(torch.randn(N, generator=gen))
+    bias, scale, shift, slope = vec(), g(torch.rand(N, generator=gen) + 0.5), vec(), g(torch.rand(N, generator=gen) * 0.3)
+    rowbias, res1, res2 = g(torch.randn(nobj, N, generator=gen)), g(torch.randn(M, N, generator=gen)), g(torch.randn(M, N + 8, generator=gen))
+    c0, cmc = 128, N // 2
+    outs = []
+    for scalar in (True, False):
+        _scalar_epilogue(scalar)
+        try:
+            keys = torch.zeros(nobj, cmc, dtype=torch.int32, device=DEV)
+            C = torch.full((M, N - c0), 7.0, device=DEV)
+            ops.gemm(A, W, C, M=M, N=N, K=K, lda=K, ldw=K, ldc=N - c0, bias=bias, rowbias=rowbias, rows_per_obj=rpo, res1=res1, ldr1=N,
+                     res2=res2[:, 4:], ldr2=N + 8, scale=scale, shift=shift, act=1, slope_vec=slope, colmax_keys=keys, cm_cols=cmc,
+                     c_col0=c0, w_split=ops.split_w(W))
+        finally:
+            _scalar_epilogue(False)
+        outs.append((C.clone(), keys.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][1].ne(0).any() and outs[0][0].ne(7.0).all()
+
+
+@pytest.mark.parametrize("gemm_mode", ["split16", "fp32"], indirect=True)
+def test_gathered_residuals_vs_torch(ops, gemm_mode):
+    """C = act(BN(A W^T + bias + G1[idx1] + G2[idx2] + rowbias)) with the max over points: the factored wide layer's
+    epilogue (LDS-staged in the split kernels, register-direct in the fp32 ones and behind the debug switch)."""
+    gen = torch.Generator().manual_seed(77)
+    B, n, n1, n2, N, K = 5, 300, 75, 19, 512, 268
+    M = B * n
+    A, W = torch.randn(M, 272, generator=gen), torch.randn(N, 272, generator=gen) / K ** 0.5
+    P1, P2 = torch.randn(B * n1, N + 64, generator=gen), torch.randn(B * n2, N + 64, generator=gen)
+    i1 = torch.randint(0, n1, (B, n), generator=gen) + torch.arange(B).unsqueeze(1) * n1
+    i2 = torch.randint(0, n2, (B, n), generator=gen) + torch.arange(B).unsqueeze(1) * n2
+    bias, scale, shift = torch.randn(N, generator=gen), torch.rand(N, generator=gen) + 0.5, torch.randn(N, generator=gen)
+    rowbias = torch.randn(B, N, generator=gen)
+    lin = A[:, :K].double() @ W[:, :K].double().t() + bias.double() + P1[i1.reshape(-1), 32:32 + N].double() + \
+        P2[i2.reshape(-1), 32:32 + N].double() + rowbias.double().repeat_interleave(n, 0)
+    want = torch.nn.functional.leaky_relu(lin * scale.double() + shift.double(), 0.1)
+    dW = g(W)
+    res = []
+    for scalar in (False, True):
+        _scalar_epilogue(scalar)
+        try:
+            keys = torch.zeros(B, N, dtype=torch.int32, device=DEV)
+            C = torch.empty(M, N, device=DEV)
+            dP1, dP2 = g(P1), g(P2)
+            ops.gemm(g(A), dW, C, M=M, N=N, K=K, lda=272, ldw=272, ldc=N, bias=g(bias), rowbias=g(rowbias), rows_per_obj=n, scale=g(scale),
+                     shift=g(shift), act=1, slope=0.1, colmax_keys=keys, w_split=ops.split_w(dW),
+                     gather1=(dP1[:, 32:], N + 64, g(i1.int()).contiguous()), gather2=(dP2[:, 32:], N + 64, g(i2.int()).contiguous()))
+        finally:
+            _scalar_epilogue(False)
+        err = (C.cpu().double() - want).abs().max().item()
+        assert err < 2e-5 * want.abs().max().item(), (scalar, err)
+        assert torch.equal(ops.colmax_decode(keys).cpu(), C.cpu().view(B, n, N).max(dim=1)[0])
+        res.append(C.clone())
+    assert torch.equal(res[0], res[1])
+
+
+def test_factored_forward_equals_concat_forward(ops):
+    """engine.FACTORED: the layers over the concat buffer computed as W_fine x fine + gathered coarse products (rows sorted by
+    coarse parent) against the same layers over the materialised concat buffer -- same six outputs to rounding, B = 3 objects
+    of 1028 points, every GEMM mode's default path."""
+    from tgpose_amd import FLAGS, engine
+    net = _net(5)
+    FLAGS.train = 0
+    pts, obj = synth_points(3, 1028, 21)
+    torch.manual_seed(2)
+    i1 = torch.randperm(1028)[:257]
+    smp = (i1, torch.randperm(257)[:64])
+    outs = []
+    for fact in (True, False):
+        old, engine.FACTORED = engine.FACTORED, fact
+        try:
+            outs.append({k: v.clone() for k, v in net(g(pts), g(obj), sample_idx=smp).items()})
+        finally:
+            engine.FACTORED = old
+    for k in outs[0]:
+        d = (outs[0][k] - outs[1][k]).abs().max().item()
+        assert d <= 2e-5 * max(1.0, outs[1][k].abs().max().item()), (k, d)
+
+
 # ----------------------------------------------------------------------------------------- evaluation (f-2: mAP)
 def test_eval_pair_metrics_vs_oracle_and_reference(ops):
     """tgp_iou3d_pairs / tgp_rt_error_pairs (fp64) against the reference's values (fixture) and the numpy oracle."""

@@ -36,6 +36,8 @@ class GemmArgs(ctypes.Structure):
         ("batch_stride_vec", c_i64), ("batch_stride_colmax", c_i64),
         ("W_split", c_vp), ("ldws", c_int), ("w_split_kind", c_int),
         ("a_scale", c_vp), ("c_scale", c_vp), ("ksplit_chunk", c_int),
+        ("gres1", c_vp), ("ldg1", c_int), ("gidx1", c_vp),
+        ("gres2", c_vp), ("ldg2", c_int), ("gidx2", c_vp),
     ]
 
 

@@ -59,6 +59,12 @@ struct GemmParams {
     // problem (sA, sWS are K offsets), so the W descriptor's extent shrinks by the chunk offset
     const float *a_scale, *c_scale;
     int ksplit;
+    // gathered residuals: v += gres1[gidx1[row]][col] + gres2[gidx2[row]][col] (the factored wide layers: products of the
+    // coarse levels' features, computed once per coarse point and fetched by each point's nearest coarse point)
+    const float *gres1, *gres2;
+    const int32_t *gidx1, *gidx2;
+    int ldg1, ldg2;
+    int vec_epi;                 // every epilogue operand is 16-byte addressable: the split kernels use gemm_epilogue_lds
     int64_t plane;               // elements between planes
     // tile schedule of the main kernel: per batch, M-tile rows [0, mt_big) use 128x128 tiles, the rest 64x64
     int mt_big, tiles_n_big, tiles_big, tiles_m_small, tiles_n_small;
@@ -211,6 +217,202 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams &p, f32x16 (
     }
 }
 
+// The fast epilogue with gathered residuals (factored wide layers).  Row-block outermost so that the 16 gather indices a lane
+// needs for a 32-row block are loaded once and serve every column block; otherwise the same arithmetic, in the same order,
+// as gemm_epilogue_fast: bias, gathered residuals, per-object bias, BN scale / shift, activation, store, max over points.
+// Preconditions: no plain residuals (res1 / res2), rows_per_obj >= WTM when rowbias / colmax are used.
+template <int TM, int TN, int WTM, int WTN>
+__device__ __forceinline__ void gemm_epilogue_gather(const GemmParams &p, f32x16 (&acc)[TM][TN], const int m0, const int n0,
+                                                     const int z, const int wm, const int wn, const int r, const int h)
+{
+    const int64_t vo = (int64_t)z * p.sV;
+    const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;       // wave-uniform
+    const bool full_rows = row0 + WTM <= p.M;
+    int obj0 = 0, bound = 0x7fffffff;
+    if (p.rowbias || p.cm) {
+        obj0 = row0 / p.rows_per_obj;
+        bound = (obj0 + 1) * p.rows_per_obj;
+    }
+    const int last_row = (row0 + WTM < p.M ? row0 + WTM : p.M) - 1;
+    const bool two_objs = bound <= last_row;
+    float *Cb = p.C ? p.C + (int64_t)z * p.sC + (int64_t)row0 * p.ldc + (col0 - p.c_col0) : nullptr;
+    const int lane_c = 4 * h * p.ldc + r;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int g1[16], g2[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = row0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const bool ok = full_rows || row < p.M;
+            g1[e] = (p.gres1 && ok) ? p.gidx1[row] : 0;
+            g2[e] = (p.gres2 && ok) ? p.gidx2[row] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + j * 32 + r;
+            const bool colok = col < p.N;
+            const float bias = (colok && p.bias) ? p.bias[vo + col] : 0.f;
+            const float sc = (colok && p.scale) ? p.scale[vo + col] : 1.f;
+            const float sh = (colok && p.shift) ? p.shift[vo + col] : 0.f;
+            const float slope = (colok && p.slope_vec) ? p.slope_vec[vo + col] : p.slope;
+            const bool store_c = Cb && colok && col >= p.c_col0;
+            const bool do_cm = p.cm && colok && col < p.cm_cols;
+            float rb0 = 0.f, rb1 = 0.f;
+            if (p.rowbias && colok && row0 < p.M) {
+                rb0 = p.rowbias[(int64_t)obj0 * p.ldrb + col];
+                if (two_objs) rb1 = p.rowbias[(int64_t)(obj0 + 1) * p.ldrb + col];
+            }
+            const float *G1 = p.gres1 ? p.gres1 + col : nullptr;
+            const float *G2 = p.gres2 ? p.gres2 + col : nullptr;
+            uint32_t key0 = 0, key1 = 0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int roff = i * 32 + (e & 3) + 8 * (e >> 2);
+                const int row = row0 + roff + 4 * h;
+                const bool ok = full_rows || row < p.M;
+                const bool second = row >= bound;
+                float v = acc[i][j][e] + bias;
+                if (G1) v += (colok && ok) ? G1[(int64_t)g1[e] * p.ldg1] : 0.f;
+                if (G2) v += (colok && ok) ? G2[(int64_t)g2[e] * p.ldg2] : 0.f;
+                if (p.rowbias) v += second ? rb1 : rb0;
+                if (p.scale) v = v * sc + sh;
+                if (p.act == 1) v = v > 0.f ? v : v * slope;
+                if (store_c && ok) Cb[(int64_t)roff * p.ldc + (lane_c + j * 32)] = v;
+                if (do_cm && ok) {
+                    const uint32_t key = tgp_float_key(v);
+                    if (second) key1 = key > key1 ? key : key1;
+                    else key0 = key > key0 ? key : key0;
+                }
+            }
+            if (do_cm) {
+                uint32_t *cm = p.cm + (int64_t)z * p.sCM + col;
+                if (key0) atomicMax(cm + (int64_t)obj0 * p.ldcm, key0);
+                if (key1) atomicMax(cm + (int64_t)(obj0 + 1) * p.ldcm, key1);
+            }
+        }
+    }
+}
+
+// LDS-staged epilogue of the split kernels.  The MFMA accumulator layout gives a lane ONE column and 16 rows of a 32 x 32
+// block, so the register-direct epilogues move 4 bytes per lane and instruction: 64 stores (plus one load per residual) per
+// lane and tile, and gathered residuals -- two more loads per element whose rows differ from instruction to instruction --
+// cost 60-90 us per 256 x 256 tile that way.  Here each wave turns its blocks through a private 4 KB LDS region
+// (32 x 32 floats, unpadded: the 16-lane groups of ds_read_b128 cover two whole rows = all 64 banks): written in accumulator
+// layout, read back as lane = (row = pass * 8 + lane / 8, four consecutive columns), so every global access of the epilogue
+// -- bias / scale / shift vectors, residual rows, gathered rows, the store -- is 16 bytes per lane and there are a quarter as
+// many of them.  Arithmetic per element is that of gemm_epilogue_fast, in the same order (results are bit-identical).
+// The max over an object's points is reduced over the 8 lanes that share a column quad with 3 xor-shuffles before the
+// atomics.  Preconditions (host: vec_epi): N, ldc, c_col0, residual / gather / per-object-bias strides multiples of 4 and
+// their bases 16-byte aligned; rows_per_obj >= WTM with rowbias / colmax; all waves are past their last operand read.
+template <int TM, int TN, int WTM, int WTN>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams &p, f32x16 (&acc)[TM][TN], const int m0, const int n0, const int z,
+                                                  const int wm, const int wn, const int r, const int h, float *stage)
+{
+    const int lane = r + 32 * h;
+    const int64_t vo = (int64_t)z * p.sV;
+    const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;       // wave-uniform
+    int obj0 = 0, bound = 0x7fffffff;
+    if (p.rowbias || p.cm) {
+        obj0 = row0 / p.rows_per_obj;
+        bound = (obj0 + 1) * p.rows_per_obj;
+    }
+    const int last_row = (row0 + WTM < p.M ? row0 + WTM : p.M) - 1;
+    const bool two_objs = bound <= last_row;
+    const int lr = lane >> 3, cq = (lane & 7) * 4;               // row within a pass, first of the lane's four columns
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + j * 32 + cq;
+        const bool colok = col < p.N;                            // N % 4 == 0: the quad is wholly inside or outside
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 bias = (colok && p.bias) ? *reinterpret_cast<const float4 *>(p.bias + vo + col) : zero4;
+        const float4 sc = (colok && p.scale) ? *reinterpret_cast<const float4 *>(p.scale + vo + col) : one4;
+        const float4 sh = (colok && p.shift) ? *reinterpret_cast<const float4 *>(p.shift + vo + col) : zero4;
+        const float4 slope = (colok && p.slope_vec) ? *reinterpret_cast<const float4 *>(p.slope_vec + vo + col)
+                                                    : make_float4(p.slope, p.slope, p.slope, p.slope);
+        const bool store_c = p.C && colok && col >= p.c_col0;
+        const bool do_cm = p.cm && col < p.cm_cols;              // cm_cols % 4 == 0 (host)
+        float4 rb0 = zero4, rb1 = zero4;
+        if (p.rowbias && colok && row0 < p.M) {
+            rb0 = *reinterpret_cast<const float4 *>(p.rowbias + (int64_t)obj0 * p.ldrb + col);
+            if (two_objs) rb1 = *reinterpret_cast<const float4 *>(p.rowbias + (int64_t)(obj0 + 1) * p.ldrb + col);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            int gi1[4], gi2[4];                                  // fetched while the accumulators are being staged
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = row0 + i * 32 + q * 8 + lr;
+                gi1[q] = (p.gres1 && row < p.M) ? p.gidx1[row] : 0;
+                gi2[q] = (p.gres2 && row < p.M) ? p.gidx2[row] : 0;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) stage[((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + r] = acc[i][j][e];
+            uint32_t k0[4] = {0, 0, 0, 0}, k1[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = row0 + i * 32 + q * 8 + lr;
+                const bool ok = row < p.M;
+                const bool second = row >= bound;
+                float4 v = *reinterpret_cast<const float4 *>(stage + (q * 8 + lr) * 32 + cq);
+                v.x += bias.x, v.y += bias.y, v.z += bias.z, v.w += bias.w;
+                if (p.gres1 && colok && ok) {
+                    const float4 g = *reinterpret_cast<const float4 *>(p.gres1 + (int64_t)gi1[q] * p.ldg1 + col);
+                    v.x += g.x, v.y += g.y, v.z += g.z, v.w += g.w;
+                }
+                if (p.gres2 && colok && ok) {
+                    const float4 g = *reinterpret_cast<const float4 *>(p.gres2 + (int64_t)gi2[q] * p.ldg2 + col);
+                    v.x += g.x, v.y += g.y, v.z += g.z, v.w += g.w;
+                }
+                if (p.rowbias) {
+                    const float4 rb = second ? rb1 : rb0;
+                    v.x += rb.x, v.y += rb.y, v.z += rb.z, v.w += rb.w;
+                }
+                if (p.res1 && colok && ok) {
+                    const float4 g = *reinterpret_cast<const float4 *>(p.res1 + (int64_t)row * p.ldr1 + col);
+                    v.x += g.x, v.y += g.y, v.z += g.z, v.w += g.w;
+                }
+                if (p.res2 && colok && ok) {
+                    const float4 g = *reinterpret_cast<const float4 *>(p.res2 + (int64_t)row * p.ldr2 + col);
+                    v.x += g.x, v.y += g.y, v.z += g.z, v.w += g.w;
+                }
+                if (p.scale) v.x = v.x * sc.x + sh.x, v.y = v.y * sc.y + sh.y, v.z = v.z * sc.z + sh.z, v.w = v.w * sc.w + sh.w;
+                if (p.act == 1) {
+                    v.x = v.x > 0.f ? v.x : v.x * slope.x, v.y = v.y > 0.f ? v.y : v.y * slope.y;
+                    v.z = v.z > 0.f ? v.z : v.z * slope.z, v.w = v.w > 0.f ? v.w : v.w * slope.w;
+                }
+                if (store_c && ok)
+                    *reinterpret_cast<float4 *>(p.C + (int64_t)z * p.sC + (int64_t)row * p.ldc + (col - p.c_col0)) = v;
+                if (do_cm && colok && ok) {
+                    const uint32_t key[4] = {tgp_float_key(v.x), tgp_float_key(v.y), tgp_float_key(v.z), tgp_float_key(v.w)};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (second) k1[c] = key[c] > k1[c] ? key[c] : k1[c];
+                        else k0[c] = key[c] > k0[c] ? key[c] : k0[c];
+                    }
+                }
+            }
+            if (p.cm) {                                          // wave-uniform branch: the shuffles need every lane
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int m = 8; m < 64; m <<= 1) {
+                        const uint32_t o0 = (uint32_t)__shfl_xor((int)k0[c], m), o1 = (uint32_t)__shfl_xor((int)k1[c], m);
+                        k0[c] = o0 > k0[c] ? o0 : k0[c], k1[c] = o1 > k1[c] ? o1 : k1[c];
+                    }
+                }
+                if (do_cm && colok && lane < 8) {
+                    uint32_t *cm = p.cm + (int64_t)z * p.sCM + col;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (k0[c]) atomicMax(cm + (int64_t)obj0 * p.ldcm + c, k0[c]);
+                        if (k1[c]) atomicMax(cm + (int64_t)(obj0 + 1) * p.ldcm + c, k1[c]);
+                    }
+                }
+            }
+        }
+    }
+}
+
 #define GEMM_LDPAD 4
 
 // One BM x BN output tile at (m0, n0) of batch z, computed by 64*NWM*NWN threads (NWM x NWN waves, each
@@ -352,7 +554,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams &p, const int m0, con
     if constexpr (DIST) {
         gemm_epilogue<TM, TN, WTM, WTN, true>(p, acc, m0, n0, z, wm, wn, r, h);
     } else {
-        if (!(p.rowbias || p.cm) || p.rows_per_obj >= WTM) gemm_epilogue_fast<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h);
+        if (p.gres1 || p.gres2) gemm_epilogue_gather<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h);
+    else if (!(p.rowbias || p.cm) || p.rows_per_obj >= WTM) gemm_epilogue_fast<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h);
         else gemm_epilogue<TM, TN, WTM, WTN, false>(p, acc, m0, n0, z, wm, wn, r, h);
     }
 }
@@ -676,7 +879,10 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] *= cs;
     }
-    if (!(p.rowbias || p.cm) || p.rows_per_obj >= WTM) gemm_epilogue_fast<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h);
+    if (KG == 1 && p.vec_epi && (!(p.rowbias || p.cm) || p.rows_per_obj >= WTM))
+        gemm_epilogue_lds<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h, reinterpret_cast<float *>(smem) + wave * 1024);
+    else if (p.gres1 || p.gres2) gemm_epilogue_gather<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h);
+    else if (!(p.rowbias || p.cm) || p.rows_per_obj >= WTM) gemm_epilogue_fast<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h);
     else gemm_epilogue<TM, TN, WTM, WTN, false>(p, acc, m0, n0, z, wm, wn, r, h);
     if (p.stamps && threadIdx.x == 0) {
         unsigned long long *o = p.stamps + 5 * (size_t)blockIdx.x;
@@ -833,7 +1039,8 @@ __device__ __forceinline__ void gemm_split_tile32(const GemmParams &p, const int
         __syncthreads();
     }
     if (p.stamps) st2 = __builtin_amdgcn_s_memrealtime();
-    if (!(p.rowbias || p.cm) || p.rows_per_obj >= WTM) gemm_epilogue_fast<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h);
+    if (p.gres1 || p.gres2) gemm_epilogue_gather<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h);
+    else if (!(p.rowbias || p.cm) || p.rows_per_obj >= WTM) gemm_epilogue_fast<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h);
     else gemm_epilogue<TM, TN, WTM, WTN, false>(p, acc, m0, n0, z, wm, wn, r, h);
     if (p.stamps && threadIdx.x == 0) {
         unsigned long long *o = p.stamps + 5 * (size_t)blockIdx.x;
@@ -1157,6 +1364,7 @@ extern unsigned long long *tgp_split_stamps;
 // register prefetch; bf16: one K-tile, its registers allow no more), 0 single LDS stage, 1 / 2 double buffer with that
 // many K-tiles of prefetch, 4 = 2 + skewed waves (fp16 only); bit 3: staggered block order
 int tgp_split_variant = 7;
+static int tgp_split_scalar_epilogue = 0;   // development: force the register-direct epilogues (A/B, bit-identity tests)
 
 // Block order of the split kernel.  Default: all big tiles, then the half-size tail tiles.  With many rounds of equal
 // tiles every CU reaches its epilogue at the same moment and the chip alternates between "all CUs compute, HBM idle"
@@ -1186,8 +1394,16 @@ static void order_tiles(GemmParams &p, int64_t S, bool stagger)
     p.nseg = n;
 }
 
+static bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
 static int launch_split(GemmParams &p, hipStream_t stream)
 {
+    // LDS-staged vector epilogue: every operand it touches must be addressable in aligned 16-byte pieces
+    p.vec_epi = !tgp_split_scalar_epilogue && (p.N & 3) == 0 && (p.c_col0 & 3) == 0 && (p.cm_cols & 3) == 0 && (p.sV & 3) == 0 &&
+                (p.sC & 3) == 0 && (!p.C || ((p.ldc & 3) == 0 && al16(p.C))) && al16(p.bias) && al16(p.scale) && al16(p.shift) &&
+                al16(p.slope_vec) && (!p.rowbias || ((p.ldrb & 3) == 0 && al16(p.rowbias))) &&
+                (!p.res1 || ((p.ldr1 & 3) == 0 && al16(p.res1))) && (!p.res2 || ((p.ldr2 & 3) == 0 && al16(p.res2))) &&
+                (!p.gres1 || ((p.ldg1 & 3) == 0 && al16(p.gres1))) && (!p.gres2 || ((p.ldg2 & 3) == 0 && al16(p.gres2)));
     // few 256 x 256 tiles (N <= 256, or less than 1.5 rounds of them) leave CUs idle or half empty: such launches run as
     // 256 x 128 tiles on two 512-thread workgroups per CU.  Measured over the forward's 15 tile-kernel launches, each timed
     // alone: 139 us average against 154 us with square tiles only (the wide layer alone would lose: 1.04 -> 1.32 ms)
@@ -1249,6 +1465,7 @@ static int launch_split(GemmParams &p, hipStream_t stream)
 
 unsigned long long *tgp_split_stamps = nullptr;
 extern "C" void tgp_debug_set_split_variant(int v) { tgp_split_variant = v; }
+extern "C" void tgp_debug_set_split_scalar_epilogue(int on) { tgp_split_scalar_epilogue = on; }
 extern "C" void tgp_debug_set_split_stamps(unsigned long long *buf) { tgp_split_stamps = buf; }
 
 static int launch_main(GemmParams &p, hipStream_t stream)
@@ -1300,6 +1517,11 @@ extern "C" int tgp_gemm_f32(const tgp_gemm_args *a, tgp_stream_t stream)
     p.batch = a->batch > 0 ? a->batch : 1;
     p.sA = a->batch_stride_a, p.sW = a->batch_stride_w, p.sC = a->batch_stride_c, p.sV = a->batch_stride_vec;
     p.sCM = a->batch_stride_colmax;
+    const bool gather = a->gres1 || a->gres2;
+    TGP_REQUIRE(!gather || (a->M > 32 && !a->res1 && !a->res2 && (!a->gres1 || (a->gidx1 && a->ldg1 >= a->N)) &&
+                            (!a->gres2 || (a->gidx2 && a->ldg2 >= a->N)) &&
+                            (!(a->rowbias || a->colmax_keys) || a->rows_per_obj >= 64) && (a->batch <= 1)));
+    p.gres1 = a->gres1, p.ldg1 = a->ldg1, p.gidx1 = a->gidx1, p.gres2 = a->gres2, p.ldg2 = a->ldg2, p.gidx2 = a->gidx2;
     const bool plain = !a->rowbias && !a->res2 && !a->colmax_keys && !a->slope_vec && a->c_col0 == 0 &&
                        (p.batch == 1 || !a->res1);
     // a_scale / c_scale / ksplit_chunk are implemented by the fp16 split tile kernels only: refuse launches that route elsewhere

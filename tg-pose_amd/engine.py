@@ -175,6 +175,7 @@ class Packed(object):
             if with_heads:
                 self.wide = pack_wide(self.ph, [self.heads[h] for h in HEAD_ORDER],
                                       dict(conv5=face + "ph_pred.conv_5.1", heads=[h + "." for h in HEAD_ORDER]))
+                self.fact = pack_factored(self.wide, self.dec[0])
         finally:
             _FOLDS = None
 
@@ -186,6 +187,30 @@ class Packed(object):
             shift.copy_(sh)
 
 
+FINE_K = 268            # fm_0 | fm_1 | one-hot | xyz | 3 zero columns: the part of `feat` that differs from point to point
+FINE_LD = 272
+
+
+def _fine_cols(w):
+    """(rows, FEAT_LD) weight over the concat buffer -> its columns over the fine part, (rows, FINE_LD) zero padded"""
+    return _pad_cols(torch.cat([w[:, :256], w[:, 1280:FEAT_LD]], dim=1), FINE_LD).contiguous()
+
+
+def pack_factored(wide, dec0):
+    """Operands of the factored form of the two layers that read `feat` = [fm_0 | fm_1 | up(fm_2) | up(fm_3) | up(fm_4) | tail]
+    (the fused conv_5 + head conv1 GEMM and the decoder's first conv).  up() is nearest-neighbour upsampling
+    (FaceRecon.py:70-75), so W x feat = W_fine x fine + (W_1 x [fm_2 | fm_3])[near_1] + (W_2 x fm_4)[near_2]: the two coarse
+    products are taken once per COARSE point (N/4 and N/16 of them) and fetched per point by the fine GEMM's epilogue.
+    The coarse operands of both layers are stacked (4096 + 512 rows) so each level is one launch."""
+    W, w0 = wide["W"], dec0[0]
+    f = dict(Wa=_fine_cols(W), dec_a=_fine_cols(w0),
+             Wb=torch.cat([W[:, 256:768], w0[:, 256:768]], dim=0).contiguous(),
+             Wc=torch.cat([W[:, 768:1280], w0[:, 768:1280]], dim=0).contiguous())
+    for k in ("Wa", "dec_a", "Wb", "Wc"):
+        f[k + "_s"] = ops.split_w(f[k])
+    return f
+
+
 def _i32(idx, device):
     """injected graph (any int dtype, any device, (B,n,k) or (B,n,1)) -> contiguous int32 on device"""
     return idx.to(device=device, dtype=torch.int32).contiguous()
@@ -194,6 +219,7 @@ def _i32(idx, device):
 _PIN = {}
 _SIDE = {}
 BRANCH_STREAMS = True   # run the PH-tail -> decoder chain beside the head chain on a second HIP stream
+FACTORED = True         # eval forward: the layers over the concat buffer run factored over the upsampling (pack_factored)
 
 
 SIDE_TAG = 0            # GraphedForward gives each half batch its own side stream
@@ -301,12 +327,14 @@ def hs_layer(c, xyz, fmap, idx_rf, idx_orl, out, scale=None, shift=None, act=Non
     return out
 
 
-def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6):
-    """Face_Enc.forward (FaceRecon.py:39-86) -> feat buffer (B,N,FEAT_LD) and intermediates."""
+def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, factored=False):
+    """Face_Enc.forward (FaceRecon.py:39-86) -> feat buffer (B,N,FEAT_LD) and intermediates.
+    factored: the concat buffer is not built; returns the fine buffer (B,N,FINE_LD) = fm_0 | fm_1 | one-hot | xyz | 0 and,
+    in the intermediates, fm23 (B,N1,512), fm_4 and the absolute rows of each point's nearest coarse points."""
     dev = points_c.device
     B, N, _ = points_c.shape
     xyz = points_c
-    feat = torch.empty(B, N, FEAT_LD, device=dev, dtype=torch.float32)
+    feat = torch.empty(B, N, FINE_LD if factored else FEAT_LD, device=dev, dtype=torch.float32)
     N1, N2 = sample_idx[0].numel(), sample_idx[1].numel()
     s12 = _upload_i32(torch.cat([sample_idx[0].reshape(-1), sample_idx[1].reshape(-1)]), dev)
     s1, s2 = s12[:N1], s12[N1:]
@@ -328,10 +356,10 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6):
     v1, fp1 = ops.pool(xyz, fm1, graphs.get("pool_1.xyz", lambda: xyz_graph(0, xyz, kmax)), s1, kpool=4)
 
     k1 = min(kmax, N1 // 8)
-    fm2 = torch.empty(B, N1, 256, device=dev, dtype=torch.float32)
+    fm23 = torch.empty(B, N1, 512, device=dev, dtype=torch.float32)      # fm_2 | fm_3 side by side: one GEMM operand when factored
+    fm2, fm3 = fm23[:, :, :256], fm23[:, :, 256:]
     hs_layer(cv[2], v1, fp1, lambda: graphs.get("conv_2.rf", lambda: ops.knn_feat(fp1, k1)),
              lambda: graphs.get("conv_2.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm2, cv[2]["scale"], cv[2]["shift"], "relu")
-    fm3 = torch.empty(B, N1, 256, device=dev, dtype=torch.float32)
     hs_layer(cv[3], v1, fm2, lambda: graphs.get("conv_3.rf", lambda: ops.knn_feat(fm2, k1)),
              graphs.get("conv_3.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm3, cv[3]["scale"], cv[3]["shift"], "relu")
     v2, fp2 = ops.pool(v1, fm3, graphs.get("pool_2.xyz", lambda: xyz_graph(1, v1, k1)), s2, kpool=4)
@@ -343,11 +371,24 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6):
 
     near1 = graphs.get("up_1", lambda: ops.nn1(xyz, v1)).view(B, N)
     near2 = graphs.get("up_2", lambda: ops.nn1(xyz, v2)).view(B, N)
+    inter = dict(fm_2=fm2, fm_3=fm3, fm_4=fm4, v_pool_1=v1, v_pool_2=v2)
+    if factored:
+        ops.fill_tail(obj_id.reshape(-1).float(), xyz, feat, 256, n_cls)
+        # Everything downstream of the concat buffer in eval mode is a per-point layer followed by a max over the object's
+        # points, so the order of an object's rows is free: put the points that share their nearest coarse points next to each
+        # other.  A 64-row wave tile of the fine GEMM then fetches ~4 + ~16 distinct coarse rows instead of 128 scattered ones
+        # (the gathered rows are 18 KB each; unsorted they stream 1.1 GB through the fabric per forward).
+        order = torch.argsort(near2.long() * N1 + near1.long(), dim=1, stable=True)
+        near1, near2 = torch.gather(near1, 1, order), torch.gather(near2, 1, order)
+        fine = torch.empty_like(feat)
+        ops.gather_rows(feat, order.to(torch.int32), fine)
+        rows = torch.arange(B, device=dev, dtype=torch.int32).unsqueeze(1)
+        inter.update(fm23=fm23, near1=(near1 + rows * N1).contiguous(), near2=(near2 + rows * N2).contiguous(), order=order)
+        return fine, inter
     ops.gather_rows(fm2, near1, feat[:, :, 256:512])
     ops.gather_rows(fm3, near1, feat[:, :, 512:768])
     ops.gather_rows(fm4, near2, feat[:, :, 768:1280])
     ops.fill_tail(obj_id.reshape(-1).float(), xyz, feat, 1280, n_cls)
-    inter = dict(fm_2=fm2, fm_3=fm3, fm_4=fm4, v_pool_1=v1, v_pool_2=v2)
     return feat, inter
 
 
@@ -386,6 +427,47 @@ def wide_gemm(pk, feat, N):
              scale=w["scale"], shift=w["shift"], act=1, slope_vec=w["slope"], colmax_keys=keys5, cm_cols=1024,
              c_col0=1024, rows_per_obj=N, k_alg=w["k_alg"], w_split=w["Ws"])
     return keys5, H
+
+
+def coarse_products(pk, inter):
+    """W_1 x [fm_2 | fm_3] and W_2 x fm_4 for the 4096 columns of the wide layer and the 512 of the decoder's first conv, per
+    coarse point: (B*N1, 4608), (B*N2, 4608)"""
+    f = pk.fact
+    return (ops.linear_rows(inter["fm23"].reshape(-1, 512), f["Wb"], w_split=f["Wb_s"]),
+            ops.linear_rows(inter["fm_4"].reshape(-1, 512), f["Wc"], w_split=f["Wc_s"]))
+
+
+def wide_gemm_factored(pk, fine, inter, P1, P2, N):
+    """wide_gemm over the fine buffer with the coarse products fetched by the epilogue (same outputs)."""
+    B = fine.shape[0]
+    dev = fine.device
+    w, f = pk.wide, pk.fact
+    M = B * N
+    keys5 = torch.zeros(B, 1024, device=dev, dtype=torch.int32)
+    H = torch.empty(M, 3072, device=dev, dtype=torch.float32)
+    ops.gemm(fine, f["Wa"], H, M=M, N=4096, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=3072, bias=w["bias"],
+             scale=w["scale"], shift=w["shift"], act=1, slope_vec=w["slope"], colmax_keys=keys5, cm_cols=1024,
+             c_col0=1024, rows_per_obj=N, w_split=f["Wa_s"], gather1=(P1, P1.shape[1], inter["near1"]),
+             gather2=(P2, P2.shape[1], inter["near2"]))
+    return keys5, H
+
+
+def decoder_forward_factored(pk, fine, inter, P1, P2, back, N):
+    """decoder_forward with the first conv factored like the wide layer (its coarse products are columns 4096.. of P1 / P2)."""
+    w0, b0, sc0, sh0, _ = pk.dec[0]
+    f = pk.fact
+    B = fine.shape[0]
+    M = B * N
+    rb = ops.linear_rows(back, w0) if back is not None else None
+    x = torch.empty(B, N, 512, device=fine.device, dtype=torch.float32)
+    ops.gemm(fine, f["dec_a"], x, M=M, N=512, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=512, bias=b0, rowbias=rb, rows_per_obj=N,
+             scale=sc0, shift=sh0, act=1, w_split=f["dec_a_s"], gather1=(P1[:, 4096:], P1.shape[1], inter["near1"]),
+             gather2=(P2[:, 4096:], P2.shape[1], inter["near2"]))
+    for w, b, sc, sh, ws in pk.dec[1:]:
+        x = ops.linear_rows(x, w, bias=b, scale=sc, shift=sh, act=1, w_split=ws)
+    recon = ops.linear_rows(x, pk.dec_out[0], bias=pk.dec_out[1])
+    # rows are in the sorted order of encoder_forward(factored=True): put the (B,N,3) result back in point order
+    return torch.empty_like(recon).scatter_(1, inter["order"].unsqueeze(-1).expand(-1, -1, 3), recon)
 
 
 def head_chain(pk, H, B, N):
@@ -470,31 +552,40 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
     points = points.contiguous().float()
     xyz, mean = ops.center(points)
     graphs = Graphs(points.device, inject, record)
-    feat, inter = encoder_forward(pk, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
+    factored = FACTORED and not train_keys          # the concat buffer is an output only with the training keys
+    feat, inter = encoder_forward(pk, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls, factored=factored)
+    if factored:
+        P1, P2 = coarse_products(pk, inter)
+        wide = lambda: wide_gemm_factored(pk, feat, inter, P1, P2, N)
+        decode = lambda back: decoder_forward_factored(pk, feat, inter, P1, P2, back, N)
+    else:
+        P1 = P2 = None
+        wide = lambda: wide_gemm(pk, feat, N)
+        decode = lambda back: decoder_forward(pk, feat, back, N)
     if BRANCH_STREAMS:
         # after the fused wide GEMM the head chain (conv2 -> max -> conv3 -> conv4) and the PH tail -> decoder chain are
         # independent: the second runs on a side stream and fills the tail rounds / skinny launches of the first
         cur = torch.cuda.current_stream(points.device)
         side = _side_stream(points.device)
-        keys5, H = wide_gemm(pk, feat, N)
+        keys5, H = wide()
         fork = torch.cuda.Event()
         fork.record(cur)
         with torch.cuda.stream(side):
             side.wait_event(fork)
             h1, h2, back = ph_tail(pk.ph, keys5, B, points.device)
-            recon = decoder_forward(pk, feat, back, N)
+            recon = decode(back)
             join = torch.cuda.Event()
             join.record(side)
         if not torch.cuda.is_current_stream_capturing():      # a captured graph owns its pool: nothing to protect
-            for t in (keys5, H, feat, h1, h2, back, recon):
+            for t in (keys5, H, feat, h1, h2, back, recon) + ((P1, P2, inter["near1"], inter["near2"]) if factored else ()):
                 t.record_stream(side)
         green, red, ts = head_chain(pk, H, B, N)
         cur.wait_event(join)
     else:
-        keys5, H = wide_gemm(pk, feat, N)
+        keys5, H = wide()
         green, red, ts = head_chain(pk, H, B, N)
         h1, h2, back = ph_tail(pk.ph, keys5, B, points.device)
-        recon = decoder_forward(pk, feat, back, N)
+        recon = decode(back)
     pg, pr, fg, fr, pT, ps = ops.head_post(green, red, ts, mean)
     out = dict()
     if train_keys:
