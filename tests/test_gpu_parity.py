@@ -1405,7 +1405,7 @@ def test_lds_epilogue_bit_identical_to_register_epilogue(ops, M, N, K, rpo):
 @pytest.mark.parametrize("gemm_mode", ["split16", "fp32"], indirect=True)
 def test_gathered_residuals_vs_torch(ops, gemm_mode):
     """C = act(BN(A W^T + bias + G1[idx1] + G2[idx2] + rowbias)) with the max over points: the factored wide layer's
-    epilogue (LDS-staged in the split kernels, register-direct in the fp32 ones and behind the debug switch)."""
+    epilogue (LDS-staged in the split kernels, register-direct in the fp32 ones)."""
     gen = torch.Generator().manual_seed(77)
     B, n, n1, n2, N, K = 5, 300, 75, 19, 512, 268
     M = B * n
@@ -1419,23 +1419,15 @@ def test_gathered_residuals_vs_torch(ops, gemm_mode):
         P2[i2.reshape(-1), 32:32 + N].double() + rowbias.double().repeat_interleave(n, 0)
     want = torch.nn.functional.leaky_relu(lin * scale.double() + shift.double(), 0.1)
     dW = g(W)
-    res = []
-    for scalar in (False, True):
-        _scalar_epilogue(scalar)
-        try:
-            keys = torch.zeros(B, N, dtype=torch.int32, device=DEV)
-            C = torch.empty(M, N, device=DEV)
-            dP1, dP2 = g(P1), g(P2)
-            ops.gemm(g(A), dW, C, M=M, N=N, K=K, lda=272, ldw=272, ldc=N, bias=g(bias), rowbias=g(rowbias), rows_per_obj=n, scale=g(scale),
-                     shift=g(shift), act=1, slope=0.1, colmax_keys=keys, w_split=ops.split_w(dW),
-                     gather1=(dP1[:, 32:], N + 64, g(i1.int()).contiguous()), gather2=(dP2[:, 32:], N + 64, g(i2.int()).contiguous()))
-        finally:
-            _scalar_epilogue(False)
-        err = (C.cpu().double() - want).abs().max().item()
-        assert err < 2e-5 * want.abs().max().item(), (scalar, err)
-        assert torch.equal(ops.colmax_decode(keys).cpu(), C.cpu().view(B, n, N).max(dim=1)[0])
-        res.append(C.clone())
-    assert torch.equal(res[0], res[1])
+    keys = torch.zeros(B, N, dtype=torch.int32, device=DEV)
+    C = torch.empty(M, N, device=DEV)
+    dP1, dP2 = g(P1), g(P2)
+    ops.gemm(g(A), dW, C, M=M, N=N, K=K, lda=272, ldw=272, ldc=N, bias=g(bias), rowbias=g(rowbias), rows_per_obj=n, scale=g(scale),
+             shift=g(shift), act=1, slope=0.1, colmax_keys=keys, w_split=ops.split_w(dW),
+             gather1=(dP1[:, 32:], N + 64, g(i1.int()).contiguous()), gather2=(dP2[:, 32:], N + 64, g(i2.int()).contiguous()))
+    err = (C.cpu().double() - want).abs().max().item()
+    assert err < 2e-5 * want.abs().max().item(), err
+    assert torch.equal(ops.colmax_decode(keys).cpu(), C.cpu().view(B, n, N).max(dim=1)[0])
 
 
 def test_factored_forward_equals_concat_forward(ops):

@@ -881,7 +881,6 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
     }
     if (KG == 1 && p.vec_epi && (!(p.rowbias || p.cm) || p.rows_per_obj >= WTM))
         gemm_epilogue_lds<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h, reinterpret_cast<float *>(smem) + wave * 1024);
-    else if (p.gres1 || p.gres2) gemm_epilogue_gather<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h);
     else if (!(p.rowbias || p.cm) || p.rows_per_obj >= WTM) gemm_epilogue_fast<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h);
     else gemm_epilogue<TM, TN, WTM, WTN, false>(p, acc, m0, n0, z, wm, wn, r, h);
     if (p.stamps && threadIdx.x == 0) {
@@ -1039,8 +1038,7 @@ __device__ __forceinline__ void gemm_split_tile32(const GemmParams &p, const int
         __syncthreads();
     }
     if (p.stamps) st2 = __builtin_amdgcn_s_memrealtime();
-    if (p.gres1 || p.gres2) gemm_epilogue_gather<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h);
-    else if (!(p.rowbias || p.cm) || p.rows_per_obj >= WTM) gemm_epilogue_fast<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h);
+    if (!(p.rowbias || p.cm) || p.rows_per_obj >= WTM) gemm_epilogue_fast<TM, TN, WTM, WTN>(p, acc, m0, n0, z, wm, wn, r, h);
     else gemm_epilogue<TM, TN, WTM, WTN, false>(p, acc, m0, n0, z, wm, wn, r, h);
     if (p.stamps && threadIdx.x == 0) {
         unsigned long long *o = p.stamps + 5 * (size_t)blockIdx.x;
@@ -1404,6 +1402,8 @@ static int launch_split(GemmParams &p, hipStream_t stream)
                 al16(p.slope_vec) && (!p.rowbias || ((p.ldrb & 3) == 0 && al16(p.rowbias))) &&
                 (!p.res1 || ((p.ldr1 & 3) == 0 && al16(p.res1))) && (!p.res2 || ((p.ldr2 & 3) == 0 && al16(p.res2))) &&
                 (!p.gres1 || ((p.ldg1 & 3) == 0 && al16(p.gres1))) && (!p.gres2 || ((p.ldg2 & 3) == 0 && al16(p.gres2)));
+    // gathered residuals exist in the LDS-staged epilogue only (and in the fp32 kernels' register form): refuse the rest
+    TGP_REQUIRE(!(p.gres1 || p.gres2) || (p.vec_epi && !(tgp_split_variant != 7 && (tgp_split_variant & 64))));
     // few 256 x 256 tiles (N <= 256, or less than 1.5 rounds of them) leave CUs idle or half empty: such launches run as
     // 256 x 128 tiles on two 512-thread workgroups per CU.  Measured over the forward's 15 tile-kernel launches, each timed
     // alone: 139 us average against 154 us with square tiles only (the wide layer alone would lose: 1.04 -> 1.32 ms)
