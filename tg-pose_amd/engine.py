@@ -433,8 +433,8 @@ def coarse_products(pk, inter):
     """W_1 x [fm_2 | fm_3] and W_2 x fm_4 for the 4096 columns of the wide layer and the 512 of the decoder's first conv, per
     coarse point: (B*N1, 4608), (B*N2, 4608)"""
     f = pk.fact
-    return (ops.linear_rows(inter["fm23"].reshape(-1, 512), f["Wb"], w_split=f["Wb_s"]),
-            ops.linear_rows(inter["fm_4"].reshape(-1, 512), f["Wc"], w_split=f["Wc_s"]))
+    return (ops.linear_rows(inter["fm23"].reshape(-1, 512), f["Wb"], w_split=f["Wb_s"], flops_ref=0),
+            ops.linear_rows(inter["fm_4"].reshape(-1, 512), f["Wc"], w_split=f["Wc_s"], flops_ref=0))
 
 
 def wide_gemm_factored(pk, fine, inter, P1, P2, N):
@@ -448,7 +448,7 @@ def wide_gemm_factored(pk, fine, inter, P1, P2, N):
     ops.gemm(fine, f["Wa"], H, M=M, N=4096, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=3072, bias=w["bias"],
              scale=w["scale"], shift=w["shift"], act=1, slope_vec=w["slope"], colmax_keys=keys5, cm_cols=1024,
              c_col0=1024, rows_per_obj=N, w_split=f["Wa_s"], gather1=(P1, P1.shape[1], inter["near1"]),
-             gather2=(P2, P2.shape[1], inter["near2"]))
+             gather2=(P2, P2.shape[1], inter["near2"]), flops_ref=2.0 * M * 4096 * w["k_alg"])
     return keys5, H
 
 
@@ -462,7 +462,7 @@ def decoder_forward_factored(pk, fine, inter, P1, P2, back, N):
     x = torch.empty(B, N, 512, device=fine.device, dtype=torch.float32)
     ops.gemm(fine, f["dec_a"], x, M=M, N=512, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=512, bias=b0, rowbias=rb, rows_per_obj=N,
              scale=sc0, shift=sh0, act=1, w_split=f["dec_a_s"], gather1=(P1[:, 4096:], P1.shape[1], inter["near1"]),
-             gather2=(P2[:, 4096:], P2.shape[1], inter["near2"]))
+             gather2=(P2[:, 4096:], P2.shape[1], inter["near2"]), flops_ref=2.0 * M * 512 * FEAT_C)
     for w, b, sc, sh, ws in pk.dec[1:]:
         x = ops.linear_rows(x, w, bias=b, scale=sc, shift=sh, act=1, w_split=ws)
     recon = ops.linear_rows(x, pk.dec_out[0], bias=pk.dec_out[1])

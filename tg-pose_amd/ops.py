@@ -246,7 +246,7 @@ def _big_tile_threshold():
 def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, bias=None, rowbias=None,
          rows_per_obj=0, res1=None, ldr1=0, res2=None, ldr2=0, scale=None, shift=None, act=0, slope=0.0,
          colmax_keys=None, k_alg=None, slope_vec=None, cm_cols=0, c_col0=0, batch=1, batch_strides=None, w_split=None,
-         a_scale=None, c_scale=None, ksplit_chunk=0, gather1=None, gather2=None):
+         a_scale=None, c_scale=None, ksplit_chunk=0, gather1=None, gather2=None, flops_ref=None):
     """Raw call into tgp_gemm_f32.  A/W/C/res* are tensors whose data_ptr is the first element of the
     operand (views into wider buffers are fine); all sizes/strides are explicit.  k_alg: the layer's
     true input width when K includes zero padding (only used for FLOP accounting in bench.py)."""
@@ -280,13 +280,15 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
     check(_lib.lib().tgp_gemm_f32(ctypes.byref(a), _stream(A)), "tgp_gemm_f32")
     if timed:
         e1.record(torch.cuda.current_stream(A.device))
-        GEMM_TIMER.append((e0, e1, 2.0 * M * N * (k_alg or K) * batch, (M, N, K, batch)))
+        # flops_ref: what this launch stands for in the reference's formulation (the factored wide layers run fewer FLOPs)
+        fl = 2.0 * M * N * (k_alg or K) * batch
+        GEMM_TIMER.append((e0, e1, fl, (M, N, K, batch), fl if flops_ref is None else float(flops_ref)))
     return C
 
 
 def linear_rows(x, weight, bias=None, scale=None, shift=None, act=0, slope=0.0, out=None, rowbias=None,
                 rows_per_obj=0, res1=None, res2=None, colmax_keys=None, want_out=True, k_alg=None, w_split=None,
-                a_scale=None, c_scale=None):
+                a_scale=None, c_scale=None, flops_ref=None):
     """x (..., K) rows (row stride >= K), weight (N, Kw>=K) -> (..., N).  Convenience over gemm()."""
     x, lda = _rows(x, "x")
     weight, ldw = _rows(weight, "weight")
@@ -306,7 +308,7 @@ def linear_rows(x, weight, bias=None, scale=None, shift=None, act=0, slope=0.0, 
         r2, l2 = _rows(res2, "res2")
     gemm(x, weight, out if want_out else None, M=M, N=N, K=K, lda=lda, ldw=ldw, ldc=ldc, bias=bias, rowbias=rowbias,
          rows_per_obj=rows_per_obj, res1=r1, ldr1=l1, res2=r2, ldr2=l2, scale=scale, shift=shift, act=act, slope=slope,
-         colmax_keys=colmax_keys, k_alg=k_alg, w_split=w_split, a_scale=a_scale, c_scale=c_scale)
+         colmax_keys=colmax_keys, k_alg=k_alg, w_split=w_split, a_scale=a_scale, c_scale=c_scale, flops_ref=flops_ref)
     return out
 
 
