@@ -407,6 +407,36 @@ int tgp_iou3d_pairs(const double *RT1, const double *RT2, const double *scales1,
  * mode[t]: 0 general, 1 symmetric about y (angle between the y axes), 2 symmetric under a half turn about y. */
 int tgp_rt_error_pairs(const double *RT1, const double *RT2, const int *mode, int P, double *out, tgp_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Input side of the evaluation loader (evaluation/load_data_eval.py): depth image + detection
+ * mask + box -> the (n_pts, 3) camera-frame cloud PoseNet9D.forward is fed.  Byte / integer work, HBM-bound.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* One detection per workgroup, replacing load_data_eval.py:302-355 (ROI resampling of depth / mask / pixel grid by
+ * crop_resize_by_warp_affine with cv2.INTER_NEAREST, tools/dataset_utils.py:80-136; _depth_to_pcl :451-462; /1000; the cut
+ * of points within a quarter of the extent's diagonal of point number 25, :341-355).
+ *   depth   (I,H,W) uint16 millimetres          masks   the images' (H,W,n_i) byte masks (Mask-RCNN 'pred_masks'), any packing
+ *   mask_off[d]  byte offset of detection d's channel within masks; mask_stride[d] = n_i (bytes between neighbouring pixels)
+ *   det_img[d]   image of detection d           window[d] = {cmin+cmax, rmin+rmax, s}: get_bbox's window (tools.eval_utils),
+ *                                                s = min(max(rmax-rmin, cmax-cmin), max(H,W)) (:309-316)
+ *   camk    (I,4) fx, fy, cx, cy (float32, as the reference's intrinsics :158-161)
+ *   roi_size     FLAGS.img_size; must be a power of two in [32, 1024] (the fixed-point walk is then exact, see inputside.hip)
+ *   pts     (D, roi_size^2, 3) scratch: on return rows [0, counts[d][2]) hold detection d's cloud in ROI row-major order
+ *   counts  (D,3): depth-valid ROI pixels (:332), valid points (:336), points kept by the cut; the last is -1 when there are
+ *           fewer than 26 valid points (the reference raises IndexError at :350). */
+int tgp_roi_cloud(const uint16_t *depth, const uint8_t *masks, const int64_t *mask_off, const int *mask_stride, const int *det_img,
+                  const int *window, const float *camk, int D, int H, int W, int roi_size, float *pts, int *counts, tgp_stream_t stream);
+
+/* _sample_points (:404-417) as a gather with a host-drawn selection: out[d][i] = pts[d][sel[d][i]], out (D,n_pts,3).
+ * cap = rows per detection in pts (roi_size^2).  An index outside [0, cap) produces NaNs, never a fault. */
+int tgp_cloud_select(const float *pts, const int32_t *sel, int D, int64_t cap, int n_pts, float *out, tgp_stream_t stream);
+
+/* The same resampling drawn on the device (no read-back of counts): the first n_pts elements of a keyed pseudo-random
+ * permutation of each cloud (4-round Feistel bijection, cycle-walked); clouds with at most n_pts points are tiled exactly
+ * as :411-412.  Not the draw np.random would make -- a documented deviation for throughput runs.  Rows of detections
+ * whose count is <= 0 are NaN. */
+int tgp_cloud_sample(const float *pts, const int *counts, int D, int64_t cap, int n_pts, uint64_t seed, float *out, tgp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

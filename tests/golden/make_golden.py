@@ -462,7 +462,79 @@ def gen_eval_map():
     print("wrote eval_map.npz")
 
 
+# ----------------------------------------------------------------------------- input side (depth image -> cloud)
+def gen_input_side():
+    """The reference's own ``PoseDataset.__getitem__`` (evaluation/load_data_eval.py:239-400) run on synthetic frames written to
+    a temporary dataset directory in its on-disk layout (label / detection pickles written by this script).  Stand-ins, all
+    written for this repo: ``cv2`` (absent from the image) = imread from .npy twins + getAffineTransform / warpAffine as
+    restated in oracle/input_ref.py (so THOSE TWO functions are not pinned by this fixture; everything else -- box window,
+    affine set-up, back-projection, validity tests, outlier cut, np.random resampling -- is the reference executing);
+    ``tools.eval_utils`` (bytecode only in the reference) = load_depth / get_bbox of its source twin
+    network/point_sample/pc_sample_sphere.py, imported from there."""
+    import pickle
+    import tempfile
+    import types
+    from tests.util import synth_depth_scene
+    from oracle import input_ref as ir
+
+    store = {}
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_NEAREST, cv2.INTER_LINEAR = 0, 1
+    cv2.getAffineTransform = lambda src, dst: ir.get_affine_transform_cv(src, dst)
+
+    def warp_affine(img, M, dsize, flags=1):
+        assert flags == cv2.INTER_NEAREST
+        return ir.warp_affine_nearest(img, M, dsize)
+
+    def imread(path, flag=1):
+        return np.load(path + ".npy") if os.path.exists(path + ".npy") else None
+    cv2.warpAffine, cv2.imread = warp_affine, imread
+    sys.modules["cv2"] = cv2
+    for m in ("skimage", "skimage.color", "scipy.misc"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    twin = _load_by_path("ref_pc_sample_sphere", os.path.join(REF, "network/point_sample/pc_sample_sphere.py"))
+    eu = types.ModuleType("tools.eval_utils")
+    eu.load_depth, eu.get_bbox = twin.load_depth, twin.get_bbox
+    sys.modules["tools.eval_utils"] = eu
+    lde = _load_by_path("ref_load_data_eval", os.path.join(REF, "evaluation/load_data_eval.py"))
+
+    frames = [synth_depth_scene(21, 4), synth_depth_scene(22, 5, edge_cases=True), synth_depth_scene(23, 1)]
+    arrays = dict(n_frames=np.int64(len(frames)), scene_seeds=np.array([21, 22, 23]), scene_dets=np.array([4, 5, 1]),
+                  scene_edge=np.array([0, 1, 0]), np_seed=np.int64(77))
+    with tempfile.TemporaryDirectory() as tmp:
+        det_dir = os.path.join(tmp, "det")
+        os.makedirs(os.path.join(tmp, "Real", "test", "scene_1"))
+        os.makedirs(os.path.join(det_dir, "REAL275"))
+        ds = lde.PoseDataset.__new__(lde.PoseDataset)
+        ds.data_dir, ds.detection_dir, ds.per_obj_id, ds.invaild_list = tmp, det_dir, None, []
+        ds.camera_intrinsics = np.array([[577.5, 0, 319.5], [0, 577.5, 239.5], [0, 0, 1]], dtype=np.float32)
+        ds.real_intrinsics = np.array([[591.0125, 0, 322.525], [0, 590.16775, 244.11084], [0, 0, 1]], dtype=np.float32)
+        ds.id2cat_name = {'1': 'bottle', '2': 'bowl', '3': 'camera', '4': 'can', '5': 'laptop', '6': 'mug'}
+        ds.img_list = []
+        for i, fr in enumerate(frames):
+            stem = os.path.join("Real", "test", "scene_1", "%04d" % i)
+            ds.img_list.append(stem)
+            with open(os.path.join(tmp, stem + "_label.pkl"), "wb") as f:
+                pickle.dump(dict(instance_ids=[1, 2], class_ids=[1, 2]), f)
+            np.save(os.path.join(tmp, stem + "_color.png.npy"), np.zeros(fr["depth"].shape + (3,), np.uint8))
+            np.save(os.path.join(tmp, stem + "_depth.png.npy"), fr["depth"])
+            open(os.path.join(tmp, stem + "_depth.png"), "wb").close()          # __getitem__ tests os.path.exists on it
+            with open(os.path.join(det_dir, "REAL275", "results_test_scene_1_%04d.pkl" % i), "wb") as f:
+                pickle.dump({k: fr[k] for k in ("pred_masks", "pred_bboxes", "pred_class_ids", "pred_scores")}, f)
+        ds.length = len(ds.img_list)
+        np.random.seed(77)
+        for i in range(len(frames)):
+            data, det, _ = ds[i]
+            arrays["pcl_in.%d" % i] = data["pcl_in"].numpy()
+            arrays["cat_id.%d" % i] = data["cat_id"].numpy()
+            assert "pred_masks" not in det
+    np.savez_compressed(os.path.join(HERE, "input_side.npz"), **arrays)
+    print("wrote input_side.npz %.1f KB" % (os.path.getsize(os.path.join(HERE, "input_side.npz")) / 1024.0))
+
+
 def main():
+    if sys.argv[1:] == ["input_side"]:
+        return gen_input_side()
     gen_tda_loss()
     gen_eval_map()
     gen_pose_assembly()
@@ -476,6 +548,7 @@ def main():
     gen_forward_train("forward_train_b4_n256.npz", 4, 256, wseed=2, pseed=5, fseed=31)
     gen_backward("backward_b3_n256.npz", 3, 256, wseed=3, pseed=6, fseed=33)
     gen_chamfer()
+    gen_input_side()        # last: it installs a cv2 stand-in
 
 
 if __name__ == "__main__":

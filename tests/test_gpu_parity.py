@@ -1668,3 +1668,152 @@ def test_two_replays_in_flight_equal_serial(ops):
     for want, have in zip(serial, got):
         for k in want:
             assert torch.equal(want[k], have[k]), k
+
+
+# ----------------------------------------------------------------------------- input side (depth image -> cloud), SURVEY 8 f-4
+_K_REAL = np.array([[591.0125, 0, 322.525], [0, 590.16775, 244.11084], [0, 0, 1]], dtype=np.float32)
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.int32)
+
+
+def test_input_side_vs_reference_getitem(ops):
+    """clouds_from_frames(sampler='numpy') equals pcl_in of the reference's PoseDataset.__getitem__ bit for bit
+    (tests/golden/input_side.npz: three synthetic frames incl. a window pushed back inside the image, a mask tiled up to
+    1024 points and a box above the 440 window cap), with all frames in ONE launch and the same np.random stream."""
+    from tgpose_amd.evaluation.load_data_eval import clouds_from_frames
+    from tests.util import synth_depth_scene
+    gd = golden("input_side.npz")
+    frames = [synth_depth_scene(int(gd["scene_seeds"][i]), int(gd["scene_dets"][i]), edge_cases=bool(gd["scene_edge"][i]))
+              for i in range(int(gd["n_frames"]))]
+    np.random.seed(int(gd["np_seed"]))
+    out = clouds_from_frames(frames, _K_REAL, device=DEV)
+    for i, c in enumerate(out):
+        ref = gd["pcl_in.%d" % i]
+        assert c.shape == ref.shape and np.array_equal(_bits(c.cpu().numpy()), _bits(ref))
+
+
+def test_input_side_stages_vs_oracle(ops):
+    """tgp_roi_cloud's scratch (the cloud before resampling, in ROI order) and its three counts against the oracle, detection
+    by detection, on frames of another seed with the CAMERA intrinsics and per-frame matrices; then the draw order of a
+    custom RandomState."""
+    from oracle import input_ref as ir
+    from tgpose_amd.evaluation import load_data_eval as lde
+    from tests.util import synth_depth_scene
+    frames = [synth_depth_scene(101, 6, edge_cases=True), synth_depth_scene(102, 3), synth_depth_scene(103, 2)]
+    Ks = np.stack([lde.CAMERA_INTRINSICS, lde.REAL_INTRINSICS, lde.CAMERA_INTRINSICS])
+    rc = lde.build(frames, Ks, device=DEV)
+    pts, counts = rc.pts.cpu().numpy(), rc.counts.cpu().numpy()
+    d = 0
+    for i, fr in enumerate(frames):
+        for j in range(fr["pred_masks"].shape[2]):
+            pcl, n_depth, n_valid = ir.roi_cloud(fr["depth"], fr["pred_masks"][:, :, j], fr["pred_bboxes"][j], Ks[i])
+            assert tuple(counts[d, :2]) == (n_depth, n_valid)
+            assert counts[d, 2] == len(pcl) and np.array_equal(_bits(pts[d, :len(pcl)]), _bits(pcl))
+            d += 1
+    a = lde.clouds_from_frames(frames, Ks, rng=np.random.RandomState(5), device=DEV)
+    rs = np.random.RandomState(5)
+    for i, fr in enumerate(frames):
+        assert np.array_equal(_bits(a[i].cpu().numpy()), _bits(ir.image_clouds(fr["depth"], fr["pred_masks"], fr["pred_bboxes"], Ks[i], rng=rs)))
+
+
+def test_input_side_dropped_frames_and_errors(ops):
+    """The reference's exits: a detection whose ROI has no valid depth (:332-337) makes __getitem__ return None for the whole
+    frame AFTER the earlier detections of that frame drew from np.random; 2..25 valid points raise IndexError (:350)."""
+    from oracle import input_ref as ir
+    from tgpose_amd.evaluation.load_data_eval import clouds_from_frames
+    from tests.util import synth_depth_scene
+    good, bad, after = synth_depth_scene(201, 2), synth_depth_scene(202, 3), synth_depth_scene(203, 2)
+    bad["pred_masks"][:, :, 1] = False                       # second detection: mask empty -> frame dropped
+    frames = [good, bad, after]
+    out = clouds_from_frames(frames, _K_REAL, rng=np.random.RandomState(3), device=DEV)
+    rs = np.random.RandomState(3)
+    want = [ir.image_clouds(f["depth"], f["pred_masks"], f["pred_bboxes"], _K_REAL, rng=rs) for f in frames]
+    assert want[1] is None and out[1] is None
+    for i in (0, 2):
+        assert np.array_equal(_bits(out[i].cpu().numpy()), _bits(want[i]))
+    few = synth_depth_scene(204, 1)
+    few["pred_masks"][:] = False
+    y1, x1 = few["pred_bboxes"][0][:2]
+    few["pred_masks"][y1 + 20:y1 + 21, x1 + 20:x1 + 21, 0] = True          # one source pixel: a handful of ROI points
+    few["depth"][y1 + 20, x1 + 20] = 900
+    n = ir.roi_source_map(few["pred_bboxes"][0], 480, 640)
+    n_roi = int(((n[0] == x1 + 20) & (n[1] == y1 + 20)).sum())
+    assert 2 <= n_roi <= 25
+    with pytest.raises(IndexError):
+        ir.image_clouds(few["depth"], few["pred_masks"], few["pred_bboxes"], _K_REAL)
+    with pytest.raises(IndexError):
+        clouds_from_frames([few], _K_REAL, device=DEV)
+    empty = dict(depth=good["depth"], pred_masks=np.zeros((480, 640, 0), bool), pred_bboxes=np.zeros((0, 4), np.int32))
+    assert clouds_from_frames([empty], _K_REAL, device=DEV)[0].shape == (0, 1024, 3)
+    mixed = clouds_from_frames([empty, good], _K_REAL, rng=np.random.RandomState(3), device=DEV)
+    assert mixed[0].shape == (0, 1024, 3) and np.array_equal(_bits(mixed[1].cpu().numpy()), _bits(want[0]))
+
+
+def test_input_side_device_sampler_properties(ops):
+    """sampler='device' is a different draw by design; what must hold: every output row is a row of the detection's cloud, a
+    long cloud is sampled WITHOUT repetition of source rows, a short one is tiled exactly as the reference tiles, different
+    seeds give different subsets, the same seed the same one; invalid detections come back flagged and NaN."""
+    from tgpose_amd.evaluation import load_data_eval as lde
+    from tests.util import synth_depth_scene
+    frames = [synth_depth_scene(301, 5, edge_cases=True), synth_depth_scene(302, 4)]
+    frames[1]["pred_masks"][:, :, 2] = False
+    rc = lde.build(frames, _K_REAL, device=DEV)
+    out, ok = lde.clouds_from_frames(frames, _K_REAL, sampler="device", seed=11, device=DEV)
+    out2, _ = lde.clouds_from_frames(frames, _K_REAL, sampler="device", seed=11, device=DEV)
+    out3, _ = lde.clouds_from_frames(frames, _K_REAL, sampler="device", seed=12, device=DEV)
+    pts, counts = rc.pts.cpu().numpy(), rc.counts.cpu().numpy()
+    o = torch.cat(out).cpu().numpy()
+    okf = torch.cat(ok).cpu().numpy()
+    assert np.array_equal(_bits(o), _bits(torch.cat(out2).cpu().numpy()))
+    assert list(okf) == [True] * 5 + [True, True, False, True]
+    for d in range(len(o)):
+        total = counts[d, 2]
+        if not okf[d]:
+            assert np.isnan(o[d]).all()
+            continue
+        # recover source rows by (bit pattern of the row -> first index); rows of a ROI cloud may repeat (nearest upsampling),
+        # so check multiset containment through positions instead: every output row must occur in the cloud
+        cloud = {r.tobytes() for r in _bits(pts[d, :total])}
+        assert all(r.tobytes() in cloud for r in _bits(o[d]))
+        if total <= 1024:
+            assert np.array_equal(_bits(o[d]), _bits(pts[d, np.arange(1024) % total]))
+        else:
+            assert not np.array_equal(_bits(o[d]), _bits(torch.cat(out3).cpu().numpy()[d]))
+    # distinctness of the drawn INDICES on a cloud whose rows are all different
+    D, cap = 3, 256 * 256
+    uniq = torch.arange(D * cap * 3, dtype=torch.float32, device=DEV).reshape(D, cap, 3)
+    cnt = torch.tensor([[cap, cap, cap], [cap, 5000, 4099], [cap, 2000, 1025]], dtype=torch.int32, device=DEV)
+    s = ops.cloud_sample(uniq, cnt, 1024, 99).cpu().numpy()
+    for d in range(D):
+        idx = (s[d, :, 0] - d * cap * 3) / 3
+        assert len(np.unique(idx)) == 1024 and idx.min() >= 0 and idx.max() < int(cnt[d, 2])
+    # a rough uniformity check over many seeds: each quarter of a 4099-point cloud gets its share of the draws
+    hits = np.zeros(4)
+    for seed in range(40):
+        idx = (ops.cloud_sample(uniq, cnt, 1024, seed).cpu().numpy()[1, :, 0] - cap * 3) / 3
+        hits += np.histogram(idx, bins=4, range=(0, 4099))[0]
+    assert (np.abs(hits / hits.sum() - 0.25) < 0.02).all()
+
+
+def test_input_side_feeds_the_forward(ops):
+    """Depth frames -> clouds on the device -> PoseNet9D.forward without a host round trip of the points: same outputs as
+    feeding the oracle's clouds."""
+    from oracle import input_ref as ir
+    from tgpose_amd import PoseNet9D, seeded_state_dict
+    from tgpose_amd.evaluation.load_data_eval import clouds_from_frames
+    from tests.util import synth_depth_scene
+    frames = [synth_depth_scene(401, 3), synth_depth_scene(402, 2)]
+    clouds = clouds_from_frames(frames, _K_REAL, rng=np.random.RandomState(1), device=DEV)
+    rs = np.random.RandomState(1)
+    want = np.concatenate([ir.image_clouds(f["depth"], f["pred_masks"], f["pred_bboxes"], _K_REAL, rng=rs) for f in frames])
+    net = PoseNet9D().to(DEV).eval()
+    net.load_state_dict(seeded_state_dict(0))
+    cat = torch.cat([torch.as_tensor(f["pred_class_ids"] - 1) for f in frames]).float().reshape(-1, 1).to(DEV)
+    torch.manual_seed(3)
+    a = net(torch.cat(clouds), cat)
+    torch.manual_seed(3)
+    b = net(torch.as_tensor(want).to(DEV), cat)
+    for k in a:
+        assert torch.equal(a[k], b[k])

@@ -127,3 +127,36 @@ def synth_loss_batch(seed=41, B=10, N=96, D=50, C=70):
              "recon2": PC + 0.02 * torch.randn(B, N, 3, generator=g)}
     extra["feat2"][3] = 0.0                                # a row F.normalize clamps
     return pred, gt, sym, extra
+
+
+def synth_depth_scene(seed, n_det=4, H=480, W=640, edge_cases=False):
+    """A synthetic frame in the layout the evaluation loader reads (evaluation/load_data_eval.py:271-303): a uint16 depth
+    image in millimetres (sloped background, nearer blobs, zero-depth holes), Mask-RCNN style ``pred_masks`` (H,W,n) bool,
+    ``pred_bboxes`` (n,4) int32 as (y1,x1,y2,x2), ``pred_class_ids`` (n,) in 1..6.  ``edge_cases`` adds a box hanging over
+    the image border, a tiny mask (fewer than 1024 ROI points: the tiling branch) and a box larger than get_bbox's 440 cap."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    depth = 1400.0 + 0.4 * xx + 0.25 * yy + rng.randn(H, W) * 3.0
+    masks = np.zeros((H, W, n_det), dtype=bool)
+    boxes = np.zeros((n_det, 4), dtype=np.int32)
+    for j in range(n_det):
+        ry, rx = rng.randint(30, 110), rng.randint(30, 110)
+        cy, cx = rng.randint(60, H - 60), rng.randint(60, W - 60)
+        if edge_cases and j == 0:
+            cy, cx = 20, W - 25                                 # window pushed back inside the image by get_bbox
+        if edge_cases and j == 1:
+            ry, rx = 2, 3                                       # ~20 source pixels, ~800 ROI points -> tiled up to n_pts
+        if edge_cases and j == 2:
+            ry, rx, cy, cx = 235, 300, H // 2, W // 2           # wider than the 440 window cap
+        e = ((yy - cy) / float(ry)) ** 2 + ((xx - cx) / float(rx)) ** 2
+        m = e <= 1.0
+        masks[:, :, j] = m
+        depth = np.where(m, 700.0 + 60.0 * j + 90.0 * np.sqrt(np.clip(1.0 - e, 0, 1)) * -1.0 + rng.randn(H, W) * 1.5, depth)
+        ys, xs = np.where(m)
+        boxes[j] = [ys.min(), xs.min(), ys.max() + 1, xs.max() + 1]
+    holes = rng.rand(H, W) < 0.03
+    depth = np.where(holes, 0.0, depth)
+    depth[:, : W // 40] = 0.0                                   # a dead band, as structured-light sensors have
+    cls = rng.randint(1, 7, n_det).astype(np.int32)
+    return dict(depth=np.clip(depth, 0, 65535).astype(np.uint16), pred_masks=masks, pred_bboxes=boxes, pred_class_ids=cls,
+                pred_scores=rng.uniform(0.5, 1.0, n_det))

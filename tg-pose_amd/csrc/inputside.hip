@@ -1,0 +1,253 @@
+// Input side of the evaluation loader (evaluation/load_data_eval.py:302-357, 404-417, 451-462): depth image + detection
+// mask + box window -> the camera-frame cloud the network is fed.  HBM-bound byte/integer work: per detection 65536 ROI
+// pixels x (2 B depth + 1 B mask) in, 12 KB out.  One 1024-thread workgroup per detection walks the ROI in row-major
+// chunks of 1024 pixels and compacts in order (wave ballot + a 16-entry LDS table per chunk), because the reference's
+// boolean indexing keeps row-major order and its outlier cut is anchored on point number 25 of that order.
+//
+// The ROI resampling is cv2.warpAffine(..., INTER_NEAREST) of a pure scale + shift (tools/dataset_utils.py:80-136 with
+// rot = 0): OpenCV inverts the matrix in double and walks it in 10-bit fixed point,
+//     X = (cvRound((M1*y + M2)*1024) + 512 + cvRound(M0*x*1024)) >> 10.
+// For a roi_size that divides 1024 every product is an integer in exact arithmetic (M0 = s/roi_size, M2 = cx - s/2 with
+// cx a multiple of 1/2), far from a rounding tie, so the double-precision noise of OpenCV's inversion cannot change the
+// result and the source pixel is the integer expression in src_coord() below.
+#include "tgp_common.h"
+
+#define ROI_THREADS 1024
+#define ROI_WAVES (ROI_THREADS / TGP_WAVE)
+
+__device__ __forceinline__ int src_coord(int sum_lo_hi, int s, int x, int step)
+{
+    // 1024*centre - 512*s + 512 + x*s*(1024/roi_size), arithmetic shift = floor
+    return (512 * sum_lo_hi - 512 * s + 512 + x * s * step) >> 10;
+}
+
+// Ordered compaction step: returns this thread's output slot (base + rank among the chunk's keepers) and adds the chunk's
+// total to base.  One barrier per call; tot is double buffered by the caller's chunk parity.
+__device__ __forceinline__ int ordered_slot(bool keep, int (*tot)[ROI_WAVES], int parity, int &base)
+{
+    const unsigned long long bal = __ballot(keep);
+    const int lane = threadIdx.x & (TGP_WAVE - 1), wave = threadIdx.x / TGP_WAVE;
+    if (lane == 0) tot[parity][wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < ROI_WAVES; ++w) {
+        const int t = tot[parity][w];
+        before += (w < wave) ? t : 0;
+        all += t;
+    }
+    const int slot = base + before + __popcll(bal & ((1ull << lane) - 1ull));
+    base += all;
+    return slot;
+}
+
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int o = TGP_WAVE / 2; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = TGP_WAVE / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__global__ __launch_bounds__(ROI_THREADS) void roi_cloud_kernel(const uint16_t *__restrict__ depth, const uint8_t *__restrict__ masks,
+                                                                const int64_t *__restrict__ mask_off, const int *__restrict__ mask_stride,
+                                                                const int *__restrict__ det_img, const int *__restrict__ window,
+                                                                const float *__restrict__ camk, int H, int W, int roi_log2,
+                                                                float *pts, int *__restrict__ counts)
+{
+    __shared__ int tot[2][ROI_WAVES];
+    __shared__ float red[6][ROI_WAVES];
+    __shared__ int n_depth_waves[ROI_WAVES];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    const int roi = 1 << roi_log2, step = 1024 >> roi_log2;
+    const int64_t cap = (int64_t)roi * roi;
+    const int img = det_img[j];
+    const int sumc = window[j * 3], sumr = window[j * 3 + 1], s = window[j * 3 + 2];
+    const float fx = camk[img * 4], fy = camk[img * 4 + 1], cx = camk[img * 4 + 2], cy = camk[img * 4 + 3];
+    const uint16_t *dimg = depth + (size_t)img * H * W;
+    const uint8_t *mimg = masks + mask_off[j];
+    const int mstride = mask_stride[j];
+    float *out = pts + (size_t)j * cap * 3;
+
+    // ---- pass 1: ROI pixel -> source pixel -> (depth > 0) & mask -> back-projection, kept in ROI order
+    float lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
+    int base = 0, n_depth = 0;
+    const int chunks = (int)(cap / ROI_THREADS);
+    for (int c = 0; c < chunks; ++c) {
+        const int p = c * ROI_THREADS + tid;
+        const int y = p >> roi_log2, x = p & (roi - 1);
+        const int sx = src_coord(sumc, s, x, step), sy = src_coord(sumr, s, y, step);
+        const bool inb = sx >= 0 && sx < W && sy >= 0 && sy < H;
+        int d = 0, m = 0;
+        if (inb) {
+            const size_t q = (size_t)sy * W + sx;
+            d = dimg[q];
+            m = mimg[q * mstride];
+        }
+        n_depth += d > 0;
+        const bool keep = d > 0 && m != 0;
+        const int slot = ordered_slot(keep, tot, c & 1, base);
+        if (keep) {
+            // load_data_eval.py:451-462 then /1000.0 (:338); float32 step by step, IEEE division
+            const float dep = (float)d;
+            const float px = __fdiv_rn(__fdiv_rn(((float)sx - cx) * dep, fx), 1000.0f);
+            const float py = __fdiv_rn(__fdiv_rn(((float)sy - cy) * dep, fy), 1000.0f);
+            const float pz = __fdiv_rn(dep, 1000.0f);
+            out[(size_t)slot * 3] = px, out[(size_t)slot * 3 + 1] = py, out[(size_t)slot * 3 + 2] = pz;
+            lo0 = fminf(lo0, px), lo1 = fminf(lo1, py), lo2 = fminf(lo2, pz);
+            hi0 = fmaxf(hi0, px), hi1 = fmaxf(hi1, py), hi2 = fmaxf(hi2, pz);
+        }
+    }
+    const int n_valid = base;
+
+    // ---- extent of the cloud and the count of depth-valid ROI pixels
+    {
+        const int lane = tid & (TGP_WAVE - 1), wave = tid / TGP_WAVE;
+        lo0 = wave_min(lo0), lo1 = wave_min(lo1), lo2 = wave_min(lo2);
+        hi0 = wave_max(hi0), hi1 = wave_max(hi1), hi2 = wave_max(hi2);
+        int nd = n_depth;
+#pragma unroll
+        for (int o = TGP_WAVE / 2; o > 0; o >>= 1) nd += __shfl_xor(nd, o);
+        if (lane == 0) {
+            red[0][wave] = lo0, red[1][wave] = lo1, red[2][wave] = lo2;
+            red[3][wave] = hi0, red[4][wave] = hi1, red[5][wave] = hi2;
+            n_depth_waves[wave] = nd;
+        }
+    }
+    __syncthreads();        // also orders pass 1's global stores before pass 2's loads (same workgroup, same CU)
+    int nd_all = 0;
+#pragma unroll
+    for (int w = 0; w < ROI_WAVES; ++w) {
+        lo0 = fminf(lo0, red[0][w]), lo1 = fminf(lo1, red[1][w]), lo2 = fminf(lo2, red[2][w]);
+        hi0 = fmaxf(hi0, red[3][w]), hi1 = fmaxf(hi1, red[4][w]), hi2 = fmaxf(hi2, red[5][w]);
+        nd_all += n_depth_waves[w];
+    }
+    if (tid == 0) counts[j * 3] = nd_all, counts[j * 3 + 1] = n_valid;
+    if (n_valid < 26) {     // the reference indexes point 25 (:350) and raises; the host mirror raises for -1
+        if (tid == 0) counts[j * 3 + 2] = -1;
+        return;
+    }
+
+    // ---- pass 2: drop the points within a quarter of the extent's diagonal of point 25 (:345-355), in place
+    const float r0 = hi0 - lo0, r1 = hi1 - lo1, r2 = hi2 - lo2;
+    const float thr = __fsqrt_rn((r0 * r0 + r1 * r1) + r2 * r2) * 0.25f;
+    const float c0 = out[25 * 3], c1 = out[25 * 3 + 1], c2 = out[25 * 3 + 2];
+    __syncthreads();        // everyone holds point 25 before chunk 0 may overwrite it
+    base = 0;
+    const int chunks2 = (n_valid + ROI_THREADS - 1) / ROI_THREADS;
+    for (int c = 0; c < chunks2; ++c) {
+        const int i = c * ROI_THREADS + tid;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        bool keep = false;
+        if (i < n_valid) {
+            px = out[(size_t)i * 3], py = out[(size_t)i * 3 + 1], pz = out[(size_t)i * 3 + 2];
+            const float d0 = px - c0, d1 = py - c1, d2 = pz - c2;
+            keep = __fsqrt_rn((d0 * d0 + d1 * d1) + d2 * d2) > thr;       // numpy: sqrt(add.reduce(x*x)), left to right
+        }
+        // slot <= i and every load of this chunk precedes the barrier inside ordered_slot: in place is safe
+        const int slot = ordered_slot(keep, tot, c & 1, base);
+        if (keep) out[(size_t)slot * 3] = px, out[(size_t)slot * 3 + 1] = py, out[(size_t)slot * 3 + 2] = pz;
+    }
+    if (tid == 0) counts[j * 3 + 2] = base;
+}
+
+extern "C" int tgp_roi_cloud(const uint16_t *depth, const uint8_t *masks, const int64_t *mask_off, const int *mask_stride,
+                             const int *det_img, const int *window, const float *camk, int D, int H, int W, int roi_size, float *pts,
+                             int *counts, tgp_stream_t stream)
+{
+    TGP_REQUIRE(depth && masks && mask_off && mask_stride && det_img && window && camk && pts && counts);
+    TGP_REQUIRE(D > 0 && H > 0 && W > 0 && H < 32768 && W < 32768);
+    int lg = 0;
+    while ((1 << lg) < roi_size) ++lg;
+    if ((1 << lg) != roi_size || roi_size < 32 || roi_size > 1024) return TGP_EUNSUPPORTED;
+    hipLaunchKernelGGL(roi_cloud_kernel, dim3(D), dim3(ROI_THREADS), 0, tgp_hs(stream), depth, masks, mask_off, mask_stride, det_img, window,
+                       camk, H, W, lg, pts, counts);
+    return TGP_LAUNCH_RESULT();
+}
+
+// _sample_points (:404-417) as a gather: the host supplies the selection (tiled indices, or the prefix of the permutation
+// it drew from np.random in the reference's order), out[j, i] = pts[j, sel[j, i]].  An index outside [0, cap) yields NaNs.
+__global__ void cloud_select_kernel(const float *__restrict__ pts, const int *__restrict__ sel, int64_t total, int64_t cap, int n_pts,
+                                    float *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int64_t j = t / n_pts;
+    const int k = sel[t];
+    float a = NAN, b = NAN, c = NAN;
+    if (k >= 0 && k < cap) {
+        const float *p = pts + ((size_t)j * cap + k) * 3;
+        a = p[0], b = p[1], c = p[2];
+    }
+    out[t * 3] = a, out[t * 3 + 1] = b, out[t * 3 + 2] = c;
+}
+
+extern "C" int tgp_cloud_select(const float *pts, const int *sel, int D, int64_t cap, int n_pts, float *out, tgp_stream_t stream)
+{
+    TGP_REQUIRE(pts && sel && out && D > 0 && cap > 0 && n_pts > 0);
+    const int64_t total = (int64_t)D * n_pts;
+    hipLaunchKernelGGL(cloud_select_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), pts, sel, total, cap, n_pts, out);
+    return TGP_LAUNCH_RESULT();
+}
+
+// The same resampling without the host in the loop: a keyed bijection of [0, 2^b) (four Feistel rounds on b/2-bit
+// halves), cycle-walked into [0, total), gives element i of a pseudo-random permutation of the cloud statelessly; the
+// first n_pts elements are the sample.  Same distribution family as np.random.permutation(total)[:n_pts] (a uniformly
+// chosen ordered subset), not the same draw; a cloud shorter than n_pts is tiled exactly as the reference tiles it.
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16, x *= 0x7feb352du, x ^= x >> 15, x *= 0x846ca68bu, x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t feistel(uint32_t v, int half_bits, uint32_t key)
+{
+    const uint32_t mask = (1u << half_bits) - 1u;
+    uint32_t l = v >> half_bits, r = v & mask;
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {
+        const uint32_t f = mix32(r ^ (key + 0x9e3779b9u * (round + 1))) & mask;
+        const uint32_t nl = r;
+        r = l ^ f;
+        l = nl;
+    }
+    return (l << half_bits) | r;
+}
+
+__global__ void cloud_sample_kernel(const float *__restrict__ pts, const int *__restrict__ counts, int64_t total_out, int64_t cap, int n_pts,
+                                    uint64_t seed, float *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_out) return;
+    const int j = (int)(t / n_pts), i = (int)(t % n_pts);
+    const int total = counts[j * 3 + 2];
+    float a = NAN, b = NAN, c = NAN;
+    if (total > 0) {
+        uint32_t k;
+        if (total <= n_pts) {
+            k = (uint32_t)(i % total);
+        } else {
+            int half_bits = 1;
+            while ((1u << (2 * half_bits)) < (uint32_t)total) ++half_bits;
+            const uint32_t key = mix32((uint32_t)seed ^ mix32((uint32_t)(seed >> 32) + 0x632be5abu * (uint32_t)(j + 1)));
+            k = feistel((uint32_t)i, half_bits, key);
+            while (k >= (uint32_t)total) k = feistel(k, half_bits, key);      // a bijection of [0, 2^2h): the walk returns
+        }
+        const float *p = pts + ((size_t)j * cap + k) * 3;
+        a = p[0], b = p[1], c = p[2];
+    }
+    out[t * 3] = a, out[t * 3 + 1] = b, out[t * 3 + 2] = c;
+}
+
+extern "C" int tgp_cloud_sample(const float *pts, const int *counts, int D, int64_t cap, int n_pts, uint64_t seed, float *out,
+                                tgp_stream_t stream)
+{
+    TGP_REQUIRE(pts && counts && out && D > 0 && cap > 0 && cap <= (1ll << 30) && n_pts > 0);
+    const int64_t total = (int64_t)D * n_pts;
+    hipLaunchKernelGGL(cloud_sample_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), pts, counts, total, cap, n_pts, seed, out);
+    return TGP_LAUNCH_RESULT();
+}

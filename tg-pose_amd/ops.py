@@ -783,3 +783,49 @@ def feat_consistency_bwd(x1, x2, rows, gloss, need1, need2):
     check(_lib.lib().tgp_feat_consistency_bwd(_p(x1), _p(x2), _p(rows), _p(gloss), B, C, _p(d1), _p(d2), _stream(x1)),
           "tgp_feat_consistency_bwd")
     return d1, d2
+
+
+# ----------------------------------------------------------------------------- input side (depth image -> cloud)
+def roi_cloud(depth, masks, mask_off, mask_stride, det_img, window, camk, roi_size=256):
+    """tgp_roi_cloud.  depth (I,H,W) int16-viewed uint16, masks flat uint8, mask_off (D,) int64, mask_stride / det_img (D,) int32,
+    window (D,3) int32, camk (I,4) float32 -- all on the GPU.  -> pts (D, roi_size^2, 3) float32 scratch, counts (D,3) int32."""
+    if not (depth.is_cuda and depth.dtype in (torch.int16, torch.uint16) and depth.dim() == 3 and depth.is_contiguous()):
+        raise TypeError("depth must be a contiguous (I,H,W) 16-bit GPU tensor")
+    if not (masks.is_cuda and masks.dtype in (torch.uint8, torch.bool) and masks.is_contiguous()):
+        raise TypeError("masks must be a contiguous uint8 / bool GPU tensor")
+    if not (mask_off.is_cuda and mask_off.dtype == torch.int64 and mask_off.is_contiguous()):
+        raise TypeError("mask_off must be a contiguous int64 GPU tensor")
+    _i32(mask_stride, "mask_stride"), _i32(det_img, "det_img"), _i32(window, "window")
+    _f32(camk, "camk", 2)
+    I, H, W = depth.shape
+    D = det_img.numel()
+    if window.shape != (D, 3) or mask_off.numel() != D or mask_stride.numel() != D or camk.shape != (I, 4) or not camk.is_contiguous():
+        raise ValueError("roi_cloud: inconsistent shapes")
+    pts = torch.empty(D, roi_size * roi_size, 3, device=depth.device, dtype=torch.float32)
+    counts = torch.empty(D, 3, device=depth.device, dtype=torch.int32)
+    check(_lib.lib().tgp_roi_cloud(_p(depth), _p(masks), _p(mask_off), _p(mask_stride), _p(det_img), _p(window), _p(camk), D, H, W,
+                                   roi_size, _p(pts), _p(counts), _stream(depth)), "tgp_roi_cloud")
+    return pts, counts
+
+
+def cloud_select(pts, sel):
+    """out[d, i] = pts[d, sel[d, i]]; pts (D,cap,3) float32, sel (D,n_pts) int32 -> (D,n_pts,3)"""
+    _f32(pts, "pts", 3), _i32(sel, "sel")
+    D, cap, _ = pts.shape
+    if not pts.is_contiguous() or sel.shape[0] != D:
+        raise ValueError("cloud_select: pts must be contiguous and sel (D,n_pts)")
+    out = torch.empty(D, sel.shape[1], 3, device=pts.device, dtype=torch.float32)
+    check(_lib.lib().tgp_cloud_select(_p(pts), _p(sel), D, cap, sel.shape[1], _p(out), _stream(pts)), "tgp_cloud_select")
+    return out
+
+
+def cloud_sample(pts, counts, n_pts, seed):
+    """Device-drawn resampling (tgp_cloud_sample): (D,cap,3), counts (D,3) int32 -> (D,n_pts,3)"""
+    _f32(pts, "pts", 3), _i32(counts, "counts")
+    D, cap, _ = pts.shape
+    if not pts.is_contiguous() or counts.shape != (D, 3):
+        raise ValueError("cloud_sample: pts must be contiguous and counts (D,3)")
+    out = torch.empty(D, n_pts, 3, device=pts.device, dtype=torch.float32)
+    check(_lib.lib().tgp_cloud_sample(_p(pts), _p(counts), D, cap, n_pts, int(seed) & (2 ** 64 - 1), _p(out), _stream(pts)),
+          "tgp_cloud_sample")
+    return out
