@@ -76,6 +76,87 @@ def cpu_baseline(sd):
                       % (reps, pts.shape[0], N_POINTS, torch.__version__, threads, dt)}
 
 
+def bench_input_side(args, dev, rank, world, dist, share):
+    """a step turns `--frames` depth frames (480x640 uint16) with 6 detections each, already in HBM, into
+    (1024,3) clouds: one tgp_roi_cloud launch (a workgroup per detection) + one tgp_cloud_sample launch.  HBM-bound byte
+    work; algorithmic bytes per detection = 65536 ROI pixels x (2 B depth + 1 B mask) + 1024 x 12 B out = 208.9 KB."""
+    import numpy as np
+    from tgpose_amd import ops
+    from tgpose_amd.evaluation import load_data_eval as lde
+    from tests.util import synth_depth_scene
+    per_frame = 6
+    frames = [synth_depth_scene(1000 * rank + i, per_frame) for i in range(args.frames)]
+    packed = lde.upload(frames, lde.REAL_INTRINSICS, dev)
+    D = args.frames * per_frame
+    ev = []
+
+    def step(timed=False):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timed else None
+        if timed:
+            e[0].record()
+        pts, counts = ops.roi_cloud(*packed, roi_size=256)
+        if timed:
+            e[1].record()
+        out = ops.cloud_sample(pts, counts, 1024, 7)
+        if timed:
+            e[2].record()
+            ev.append(e)
+        return out
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        k_roi = sum(a.elapsed_time(b) for a, b, _ in ev) * 1e-3 / len(ev)
+        k_smp = sum(b.elapsed_time(c) for _, b, c in ev) * 1e-3 / len(ev)
+        alg = D * (65536 * 3 + 1024 * 12)
+        line = {"metric": "detections/sec depth frame -> cloud (256x256 ROI, 1024 pts)", "value": round(world * D * args.steps / elapsed, 1),
+                "unit": "detections/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "u16/u8 in, f32 out", "data": "synthetic",
+                "config": {"workload": "evaluation loader input side (load_data_eval.py:302-357): %d frames x %d detections per step, "
+                                       "frames resident in HBM, device-drawn resampling" % (args.frames, per_frame),
+                           "frames": args.frames, "detections": D, "replicas": world},
+                "roofline": {"bound": "hbm", "achieved": round(alg / k_roi / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                             "frac": round(alg / k_roi / 8e12, 4), "traffic": None, "kernel": "roi_cloud_kernel",
+                             "avg_launch_us": round(1e6 * k_roi, 1), "sample_launch_us": round(1e6 * k_smp, 1),
+                             "algorithmic_bytes_per_launch": alg,
+                             "note": "one workgroup per detection (%d workgroups on 256 CUs), each a chain of 16 + ~8 dependent "
+                                     "ordered-compaction rounds: latency- and issue-bound (SQ counters under profiles/), far from the "
+                                     "HBM roof by construction; 65536 pixels x ~40 VALU instructions per detection on one CU" % D}}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import input_ref as ir
+            t1 = time.perf_counter()
+            n = 0
+            rs = np.random.RandomState(0)
+            for fr in frames[:4]:
+                ir.image_clouds(fr["depth"], fr["pred_masks"], fr["pred_bboxes"], lde.REAL_INTRINSICS, rng=rs)
+                n += per_frame
+            dt = time.perf_counter() - t1
+            line["cpu_baseline"] = {"value": round(n / dt, 1), "unit": "detections/s", "cores": 1, "kind": "port",
+                                    "sample": "%d detections of 4 frames through oracle/input_ref.py (numpy, one thread; the reference's "
+                                              "loader runs the same passes per DataLoader worker), %.2f s" % (n, dt)}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,10 +175,12 @@ def main():
     ap.add_argument("--graph", type=int, choices=(0, 1, 2), default=1,
                     help="replay the forward as a captured hipGraph (default 1 = whole batch; 0 = eager launches; "
                          "2 = two half batches on forked streams, measured slower)")
-    ap.add_argument("--workload", choices=("forward", "train_step"), default="forward",
+    ap.add_argument("--frames", type=int, default=32, help="input_side: frames per step (6 detections each)")
+    ap.add_argument("--workload", choices=("forward", "train_step", "input_side"), default="forward",
                     help="forward: the headline metric (eval-mode forward).  train_step: BASELINE config 3/4 -- training-mode "
                          "forward with autograd, Chamfer (DCD) + pose regression loss, backward, gradient all-reduce over the "
-                         "ranks, clip, SGD step; objects/s of whole steps")
+                         "ranks, clip, SGD step; objects/s of whole steps.  input_side: SURVEY 8 f-4 -- depth frames + "
+                         "detection masks resident in HBM -> (1024,3) clouds (tgp_roi_cloud + device resampling); detections/s")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -125,6 +208,9 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.workload == "input_side":
+        return bench_input_side(args, dev, rank, world, dist, share)
 
     import tgpose_amd
     from tgpose_amd import PoseNet9D, FLAGS, ops, seeded_state_dict

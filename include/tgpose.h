@@ -416,11 +416,13 @@ int tgp_rt_error_pairs(const double *RT1, const double *RT2, const int *mode, in
  * crop_resize_by_warp_affine with cv2.INTER_NEAREST, tools/dataset_utils.py:80-136; _depth_to_pcl :451-462; /1000; the cut
  * of points within a quarter of the extent's diagonal of point number 25, :341-355).
  *   depth   (I,H,W) uint16 millimetres          masks   the images' (H,W,n_i) byte masks (Mask-RCNN 'pred_masks'), any packing
- *   mask_off[d]  byte offset of detection d's channel within masks; mask_stride[d] = n_i (bytes between neighbouring pixels)
+ *   mask_off[d]  byte offset of detection d's channel within masks; mask_stride[d] = n_i (bytes between neighbouring pixels,
+ *                < 128; H*W < 2^24: offsets inside one image's masks are 31-bit)
  *   det_img[d]   image of detection d           window[d] = {cmin+cmax, rmin+rmax, s}: get_bbox's window (tools.eval_utils),
  *                                                s = min(max(rmax-rmin, cmax-cmin), max(H,W)) (:309-316)
- *   camk    (I,4) fx, fy, cx, cy (float32, as the reference's intrinsics :158-161)
- *   roi_size     FLAGS.img_size; must be a power of two in [32, 1024] (the fixed-point walk is then exact, see inputside.hip)
+ *   camk    (I,4) fx, fy, cx, cy (float32, as the reference's intrinsics :158-161); fx, fy ordinary focal lengths (normal
+ *           floats far from overflow / underflow: the quotients are correctly rounded under that assumption)
+ *   roi_size     FLAGS.img_size; must be a power of two in [64, 1024] (the fixed-point walk is then exact, see inputside.hip)
  *   pts     (D, roi_size^2, 3) scratch: on return rows [0, counts[d][2]) hold detection d's cloud in ROI row-major order
  *   counts  (D,3): depth-valid ROI pixels (:332), valid points (:336), points kept by the cut; the last is -1 when there are
  *           fewer than 26 valid points (the reference raises IndexError at :350). */

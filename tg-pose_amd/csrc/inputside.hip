@@ -1,7 +1,7 @@
 // Input side of the evaluation loader (evaluation/load_data_eval.py:302-357, 404-417, 451-462): depth image + detection
 // mask + box window -> the camera-frame cloud the network is fed.  HBM-bound byte/integer work: per detection 65536 ROI
 // pixels x (2 B depth + 1 B mask) in, 12 KB out.  One 1024-thread workgroup per detection walks the ROI in row-major
-// chunks of 1024 pixels and compacts in order (wave ballot + a 16-entry LDS table per chunk), because the reference's
+// rounds of 4096 pixels and compacts in order (wave ballots + a 4 x 16-entry LDS table, one barrier per round), because the reference's
 // boolean indexing keeps row-major order and its outlier cut is anchored on point number 25 of that order.
 //
 // The ROI resampling is cv2.warpAffine(..., INTER_NEAREST) of a pure scale + shift (tools/dataset_utils.py:80-136 with
@@ -10,6 +10,8 @@
 // For a roi_size that divides 1024 every product is an integer in exact arithmetic (M0 = s/roi_size, M2 = cx - s/2 with
 // cx a multiple of 1/2), far from a rounding tie, so the double-precision noise of OpenCV's inversion cannot change the
 // result and the source pixel is the integer expression in src_coord() below.
+#include <stdlib.h>
+
 #include "tgp_common.h"
 
 #define ROI_THREADS 1024
@@ -21,24 +23,38 @@ __device__ __forceinline__ int src_coord(int sum_lo_hi, int s, int x, int step)
     return (512 * sum_lo_hi - 512 * s + 512 + x * s * step) >> 10;
 }
 
-// Ordered compaction step: returns this thread's output slot (base + rank among the chunk's keepers) and adds the chunk's
-// total to base.  One barrier per call; tot is double buffered by the caller's chunk parity.
-__device__ __forceinline__ int ordered_slot(bool keep, int (*tot)[ROI_WAVES], int parity, int &base)
+// ROI_SUB = sub-rounds per barrier: a round covers ROI_SUB * 1024 consecutive pixels, element (k, tid) = k*1024 + tid
+
+// Ordered compaction of one round: slot[k] = base + rank of element (k, tid) among the round's keepers in element order;
+// adds the round's total to base.  ONE barrier per round (tot is double buffered by the caller's round parity), so the 16
+// rounds of a 256 x 256 ROI cost 16 barriers while the 4 independent loads per thread overlap.
+template <int ROI_SUB>
+__device__ __forceinline__ void ordered_slots(const bool (&keep)[ROI_SUB], int (*tot)[ROI_SUB][ROI_WAVES], int parity, int &base,
+                                              int (&slot)[ROI_SUB])
 {
-    const unsigned long long bal = __ballot(keep);
-    const int lane = threadIdx.x & (TGP_WAVE - 1), wave = threadIdx.x / TGP_WAVE;
-    if (lane == 0) tot[parity][wave] = __popcll(bal);
-    __syncthreads();
-    int before = 0, all = 0;
+    const int lane = threadIdx.x & (TGP_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / TGP_WAVE);
+    unsigned long long bal[ROI_SUB];
 #pragma unroll
-    for (int w = 0; w < ROI_WAVES; ++w) {
-        const int t = tot[parity][w];
-        before += (w < wave) ? t : 0;
-        all += t;
+    for (int k = 0; k < ROI_SUB; ++k) {
+        bal[k] = __ballot(keep[k]);
+        if (lane == 0) tot[parity][k][wave] = __popcll(bal[k]);
     }
-    const int slot = base + before + __popcll(bal & ((1ull << lane) - 1ull));
-    base += all;
-    return slot;
+    __syncthreads();
+    // every wave scans the round's ROI_SUB * 16 wave totals across its own lanes (lane l holds entry l in element order):
+    // a dozen instructions per round instead of a 16-step loop per pixel -- the kernel is VALU-bound, not bandwidth-bound
+    const int own = lane < ROI_SUB * ROI_WAVES ? (&tot[parity][0][0])[lane] : 0;
+    int incl = own;
+#pragma unroll
+    for (int o = 1; o < ROI_SUB * ROI_WAVES; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        incl += lane >= o ? up : 0;
+    }
+    const int excl = incl - own;
+#pragma unroll
+    for (int k = 0; k < ROI_SUB; ++k)
+        slot[k] = base + __builtin_amdgcn_readlane(excl, k * ROI_WAVES + wave) + __popcll(bal[k] & ((1ull << lane) - 1ull));
+    base += __builtin_amdgcn_readlane(incl, ROI_SUB * ROI_WAVES - 1);
 }
 
 __device__ __forceinline__ float wave_min(float v)
@@ -54,13 +70,34 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// x / b for a divisor that is uniform over the launch: the refined reciprocal of the compiler's IEEE division sequence
+// (v_rcp_f32 + one Newton step) is computed once, and each quotient is that sequence's remaining five operations --
+// q = a*r; q += fma(-b,q,a)*r; q += fma(-b,q,a)*r -- i.e. exactly what `a / b` compiles to when v_div_scale / v_div_fixup
+// are no-ops (operands far from overflow / denormals: pixel coordinates x millimetres over focal lengths and 1000).
+// Correctly rounded there; the parity tests compare bit patterns with numpy's division over ~10^6 quotients.
+struct UniformDiv {
+    float b, r;
+    __device__ __forceinline__ explicit UniformDiv(float divisor) : b(divisor)
+    {
+        const float r0 = __builtin_amdgcn_rcpf(divisor);
+        r = fmaf(fmaf(-divisor, r0, 1.0f), r0, r0);
+    }
+    __device__ __forceinline__ float operator()(float a) const
+    {
+        float q = a * r;
+        q = fmaf(fmaf(-b, q, a), r, q);
+        return fmaf(fmaf(-b, q, a), r, q);
+    }
+};
+
+template <int ROI_SUB>
 __global__ __launch_bounds__(ROI_THREADS) void roi_cloud_kernel(const uint16_t *__restrict__ depth, const uint8_t *__restrict__ masks,
                                                                 const int64_t *__restrict__ mask_off, const int *__restrict__ mask_stride,
                                                                 const int *__restrict__ det_img, const int *__restrict__ window,
                                                                 const float *__restrict__ camk, int H, int W, int roi_log2,
                                                                 float *pts, int *__restrict__ counts)
 {
-    __shared__ int tot[2][ROI_WAVES];
+    __shared__ int tot[2][ROI_SUB][ROI_WAVES];
     __shared__ float red[6][ROI_WAVES];
     __shared__ int n_depth_waves[ROI_WAVES];
     const int j = blockIdx.x, tid = threadIdx.x;
@@ -72,36 +109,68 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_cloud_kernel(const uint16_t *
     const uint16_t *dimg = depth + (size_t)img * H * W;
     const uint8_t *mimg = masks + mask_off[j];
     const int mstride = mask_stride[j];
+    const UniformDiv div_fx(fx), div_fy(fy), div_k(1000.0f);
     float *out = pts + (size_t)j * cap * 3;
 
     // ---- pass 1: ROI pixel -> source pixel -> (depth > 0) & mask -> back-projection, kept in ROI order
     float lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
     int base = 0, n_depth = 0;
-    const int chunks = (int)(cap / ROI_THREADS);
-    for (int c = 0; c < chunks; ++c) {
-        const int p = c * ROI_THREADS + tid;
-        const int y = p >> roi_log2, x = p & (roi - 1);
-        const int sx = src_coord(sumc, s, x, step), sy = src_coord(sumr, s, y, step);
-        const bool inb = sx >= 0 && sx < W && sy >= 0 && sy < H;
-        int d = 0, m = 0;
-        if (inb) {
-            const size_t q = (size_t)sy * W + sx;
-            d = dimg[q];
-            m = mimg[q * mstride];
+    const int rounds = (int)(cap / (ROI_THREADS * ROI_SUB));
+    // 1024 threads are a whole number of ROI rows (or a fraction of one): a thread keeps its column for the whole walk and a
+    // wave sits inside one row, so everything that depends on x alone is hoisted and the row terms are wave-uniform
+    const int x = tid & (roi - 1);
+    const int sx = src_coord(sumc, s, x, step);
+    const bool inbx = sx >= 0 && sx < W;
+    const int colq = min(max(sx, 0), W - 1);
+    const float xm = (float)sx - cx;
+    const int row0 = __builtin_amdgcn_readfirstlane(tid >> roi_log2);      // this wave's row within a 1024-pixel sub-round
+    // The walk is a chain of dependent rounds (loads -> ballot -> barrier -> scan -> stores) on one CU, so what bounds it is
+    // latency, not bandwidth or issue (SQ counters: waves wait 69 % of their cycles).  Round c+1's loads are therefore issued
+    // before round c's barrier and stores: they do not depend on round c, and being older than the stores they can be waited
+    // for without waiting for the stores (vmcnt retires in order).
+    int d_next[ROI_SUB], m_next[ROI_SUB];
+    float ym_next[ROI_SUB];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < ROI_SUB; ++k) {
+            const int y = ((c * ROI_SUB + k) * ROI_THREADS >> roi_log2) + row0;        // = (round element index) / roi
+            const int sy = src_coord(sumr, s, y, step);
+            const bool inb = inbx && sy >= 0 && sy < H;
+            // border pixels read a clamped address and are zeroed afterwards: no branch round the loads, all 2*ROI_SUB in flight
+            const int q = min(max(sy, 0), H - 1) * W + colq;                            // < 2^24 (host-checked)
+            ym_next[k] = (float)sy - cy;
+            d_next[k] = inb ? (int)dimg[q] : 0;
+            m_next[k] = inb ? (int)mimg[q * mstride] : 0;
         }
-        n_depth += d > 0;
-        const bool keep = d > 0 && m != 0;
-        const int slot = ordered_slot(keep, tot, c & 1, base);
-        if (keep) {
-            // load_data_eval.py:451-462 then /1000.0 (:338); float32 step by step, IEEE division
-            const float dep = (float)d;
-            const float px = __fdiv_rn(__fdiv_rn(((float)sx - cx) * dep, fx), 1000.0f);
-            const float py = __fdiv_rn(__fdiv_rn(((float)sy - cy) * dep, fy), 1000.0f);
-            const float pz = __fdiv_rn(dep, 1000.0f);
-            out[(size_t)slot * 3] = px, out[(size_t)slot * 3 + 1] = py, out[(size_t)slot * 3 + 2] = pz;
-            lo0 = fminf(lo0, px), lo1 = fminf(lo1, py), lo2 = fminf(lo2, pz);
-            hi0 = fmaxf(hi0, px), hi1 = fmaxf(hi1, py), hi2 = fmaxf(hi2, pz);
+    };
+    fetch(0);
+    for (int c = 0; c < rounds; ++c) {
+        int d[ROI_SUB], m[ROI_SUB];
+        float ym[ROI_SUB];
+        bool keep[ROI_SUB];
+        int slot[ROI_SUB];
+#pragma unroll
+        for (int k = 0; k < ROI_SUB; ++k) d[k] = d_next[k], m[k] = m_next[k], ym[k] = ym_next[k];
+        if (c + 1 < rounds) fetch(c + 1);
+#pragma unroll
+        for (int k = 0; k < ROI_SUB; ++k) {
+            n_depth += d[k] > 0;
+            keep[k] = d[k] > 0 && m[k] != 0;
         }
+        ordered_slots(keep, tot, c & 1, base, slot);
+#pragma unroll
+        for (int k = 0; k < ROI_SUB; ++k)
+            if (keep[k]) {
+                // load_data_eval.py:451-462 then /1000.0 (:338); float32 step by step, correctly rounded quotients
+                const float dep = (float)d[k];
+                const float px = div_k(div_fx(xm * dep));
+                const float py = div_k(div_fy(ym[k] * dep));
+                const float pz = div_k(dep);
+                float *o = out + (size_t)slot[k] * 3;
+                o[0] = px, o[1] = py, o[2] = pz;
+                lo0 = fminf(lo0, px), lo1 = fminf(lo1, py), lo2 = fminf(lo2, pz);
+                hi0 = fmaxf(hi0, px), hi1 = fmaxf(hi1, py), hi2 = fmaxf(hi2, pz);
+            }
     }
     const int n_valid = base;
 
@@ -136,22 +205,53 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_cloud_kernel(const uint16_t *
     // ---- pass 2: drop the points within a quarter of the extent's diagonal of point 25 (:345-355), in place
     const float r0 = hi0 - lo0, r1 = hi1 - lo1, r2 = hi2 - lo2;
     const float thr = __fsqrt_rn((r0 * r0 + r1 * r1) + r2 * r2) * 0.25f;
+    // sqrt_rn is monotone, so sqrt_rn(v) > thr  <=>  v > v_max, v_max = the largest float whose rounded root is <= thr:
+    // found once per detection from thr*thr by stepping ulps; the per-point test is then a compare of the squared distance
+    float v_max = thr * thr;
+    for (int it = 0; it < 8 && __fsqrt_rn(v_max) > thr; ++it) v_max = __uint_as_float(__float_as_uint(v_max) - 1u);
+    for (int it = 0; it < 8; ++it) {
+        const float up = __uint_as_float(__float_as_uint(v_max) + 1u);
+        if (!(__fsqrt_rn(up) <= thr)) break;
+        v_max = up;
+    }
+    // (thr = 0, a cloud of one repeated point: v_max stays 0 and v > 0 is the same test; thr is never negative or NaN here)
     const float c0 = out[25 * 3], c1 = out[25 * 3 + 1], c2 = out[25 * 3 + 2];
-    __syncthreads();        // everyone holds point 25 before chunk 0 may overwrite it
+    __syncthreads();        // everyone holds point 25 before round 0 may overwrite it
     base = 0;
-    const int chunks2 = (n_valid + ROI_THREADS - 1) / ROI_THREADS;
-    for (int c = 0; c < chunks2; ++c) {
-        const int i = c * ROI_THREADS + tid;
-        float px = 0.f, py = 0.f, pz = 0.f;
-        bool keep = false;
-        if (i < n_valid) {
-            px = out[(size_t)i * 3], py = out[(size_t)i * 3 + 1], pz = out[(size_t)i * 3 + 2];
-            const float d0 = px - c0, d1 = py - c1, d2 = pz - c2;
-            keep = __fsqrt_rn((d0 * d0 + d1 * d1) + d2 * d2) > thr;       // numpy: sqrt(add.reduce(x*x)), left to right
+    const int rounds2 = (n_valid + ROI_THREADS * ROI_SUB - 1) / (ROI_THREADS * ROI_SUB);
+    // same pipelining: round c+1 reads rows >= (c+1)*4096, round c writes rows < (c+1)*4096
+    float nx[ROI_SUB], ny[ROI_SUB], nz[ROI_SUB];
+    auto fetch2 = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < ROI_SUB; ++k) {
+            const int i = (c * ROI_SUB + k) * ROI_THREADS + tid;
+            const float *q = out + (size_t)min(i, n_valid - 1) * 3;
+            nx[k] = q[0], ny[k] = q[1], nz[k] = q[2];
         }
-        // slot <= i and every load of this chunk precedes the barrier inside ordered_slot: in place is safe
-        const int slot = ordered_slot(keep, tot, c & 1, base);
-        if (keep) out[(size_t)slot * 3] = px, out[(size_t)slot * 3 + 1] = py, out[(size_t)slot * 3 + 2] = pz;
+    };
+    fetch2(0);
+    for (int c = 0; c < rounds2; ++c) {
+        float px[ROI_SUB], py[ROI_SUB], pz[ROI_SUB];
+        bool keep[ROI_SUB];
+        int slot[ROI_SUB];
+#pragma unroll
+        for (int k = 0; k < ROI_SUB; ++k) px[k] = nx[k], py[k] = ny[k], pz[k] = nz[k];
+        if (c + 1 < rounds2) fetch2(c + 1);
+#pragma unroll
+        for (int k = 0; k < ROI_SUB; ++k) {
+            const int i = (c * ROI_SUB + k) * ROI_THREADS + tid;
+            const float d0 = px[k] - c0, d1 = py[k] - c1, d2 = pz[k] - c2;
+            // numpy: sqrt(add.reduce(x*x)) > thr with the squares summed left to right
+            keep[k] = i < n_valid && (d0 * d0 + d1 * d1) + d2 * d2 > v_max;
+        }
+        // slot <= i, and every load of rows < (c+1)*4096 precedes the barrier inside ordered_slots: compacting in place is safe
+        ordered_slots(keep, tot, c & 1, base, slot);
+#pragma unroll
+        for (int k = 0; k < ROI_SUB; ++k)
+            if (keep[k]) {
+                float *o = out + (size_t)slot[k] * 3;
+                o[0] = px[k], o[1] = py[k], o[2] = pz[k];
+            }
     }
     if (tid == 0) counts[j * 3 + 2] = base;
 }
@@ -161,12 +261,14 @@ extern "C" int tgp_roi_cloud(const uint16_t *depth, const uint8_t *masks, const 
                              int *counts, tgp_stream_t stream)
 {
     TGP_REQUIRE(depth && masks && mask_off && mask_stride && det_img && window && camk && pts && counts);
-    TGP_REQUIRE(D > 0 && H > 0 && W > 0 && H < 32768 && W < 32768);
+    TGP_REQUIRE(D > 0 && H > 0 && W > 0 && H < 32768 && W < 32768 && (int64_t)H * W < (1ll << 24));   // x mask stride < 128: 31-bit offsets
     int lg = 0;
     while ((1 << lg) < roi_size) ++lg;
-    if ((1 << lg) != roi_size || roi_size < 32 || roi_size > 1024) return TGP_EUNSUPPORTED;
-    hipLaunchKernelGGL(roi_cloud_kernel, dim3(D), dim3(ROI_THREADS), 0, tgp_hs(stream), depth, masks, mask_off, mask_stride, det_img, window,
-                       camk, H, W, lg, pts, counts);
+    if ((1 << lg) != roi_size || roi_size < 64 || roi_size > 1024) return TGP_EUNSUPPORTED;   // whole rounds of 4096 pixels
+    static const int sub = [] { const char *e = getenv("TGP_ROI_SUB"); return e ? atoi(e) : 4; }();     // development A/B
+    auto kern = sub == 1 ? roi_cloud_kernel<1> : sub == 2 ? roi_cloud_kernel<2> : roi_cloud_kernel<4>;
+    hipLaunchKernelGGL(kern, dim3(D), dim3(ROI_THREADS), 0, tgp_hs(stream), depth, masks, mask_off, mask_stride, det_img, window, camk, H, W,
+                       lg, pts, counts);
     return TGP_LAUNCH_RESULT();
 }
 

@@ -55,6 +55,8 @@ def _windows(frames):
     pos = 0
     for i, fr in enumerate(frames):
         H, W, n = fr["pred_masks"].shape
+        if n >= 128:
+            raise ValueError("frame %d: %d mask channels; tgp_roi_cloud addresses masks with 31-bit offsets (n < 128)" % (i, n))
         if len(fr["pred_bboxes"]) != n:
             raise ValueError("frame %d: %d boxes for %d mask channels" % (i, len(fr["pred_bboxes"]), n))
         for j in range(n):
@@ -73,14 +75,9 @@ class RoiClouds:
         self.pts, self.counts, self.per_frame = pts, counts, per_frame
 
 
-def build(frames, camK=REAL_INTRINSICS, img_size=256, device="cuda"):
-    """Upload the frames and run the per-detection kernel.  frames: list of dicts with 'depth' (H,W) uint16,
-    'pred_masks' (H,W,n) bool / uint8, 'pred_bboxes' (n,4) (the detection pickle's layout, :271-303); camK one (3,3)
-    matrix or one per frame.  All frames must share (H,W).  Nothing synchronises."""
+def upload(frames, camK=REAL_INTRINSICS, device="cuda"):
+    """Pack and upload what tgp_roi_cloud reads: (depth, masks, mask_off, mask_stride, det_img, window, camk) on the device."""
     dev = torch.device(device)
-    per_frame = [fr["pred_masks"].shape[2] for fr in frames]
-    if sum(per_frame) == 0:
-        return RoiClouds(torch.zeros(0, img_size * img_size, 3, device=dev), torch.zeros(0, 3, dtype=torch.int32, device=dev), per_frame)
     H, W = frames[0]["depth"].shape
     for fr in frames:
         if fr["depth"].shape != (H, W) or fr["pred_masks"].shape[:2] != (H, W) or fr["depth"].dtype != np.uint16:
@@ -92,9 +89,19 @@ def build(frames, camK=REAL_INTRINSICS, img_size=256, device="cuda"):
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
     depth = up(np.stack([fr["depth"] for fr in frames]).view(np.int16))
     masks = up(np.concatenate([np.ascontiguousarray(fr["pred_masks"]).view(np.uint8).reshape(-1) for fr in frames if fr["pred_masks"].size]))
-    pts, counts = ops.roi_cloud(depth, masks, up(np.asarray(off, dtype=np.int64)), up(np.asarray(stride, dtype=np.int32)),
-                                up(np.asarray(det_img, dtype=np.int32)), up(np.asarray(win, dtype=np.int32).reshape(-1, 3)), up(camk),
-                                roi_size=img_size)
+    return (depth, masks, up(np.asarray(off, dtype=np.int64)), up(np.asarray(stride, dtype=np.int32)),
+            up(np.asarray(det_img, dtype=np.int32)), up(np.asarray(win, dtype=np.int32).reshape(-1, 3)), up(camk))
+
+
+def build(frames, camK=REAL_INTRINSICS, img_size=256, device="cuda"):
+    """Upload the frames and run the per-detection kernel.  frames: list of dicts with 'depth' (H,W) uint16,
+    'pred_masks' (H,W,n) bool / uint8, 'pred_bboxes' (n,4) (the detection pickle's layout, :271-303); camK one (3,3)
+    matrix or one per frame.  All frames must share (H,W).  Nothing synchronises."""
+    dev = torch.device(device)
+    per_frame = [fr["pred_masks"].shape[2] for fr in frames]
+    if sum(per_frame) == 0:
+        return RoiClouds(torch.zeros(0, img_size * img_size, 3, device=dev), torch.zeros(0, 3, dtype=torch.int32, device=dev), per_frame)
+    pts, counts = ops.roi_cloud(*upload(frames, camK, dev), roi_size=img_size)
     return RoiClouds(pts, counts, per_frame)
 
 
