@@ -76,6 +76,17 @@ def cpu_baseline(sd):
                       % (reps, pts.shape[0], N_POINTS, torch.__version__, threads, dt)}
 
 
+def _input_side_traffic(D):
+    """Memory-side bytes per launch of roi_cloud_kernel from the latest committed PMC passes (per detection x D), or None."""
+    try:
+        import glob
+        k = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_input_side_pmc_traffic.json")))[-1]))["kernels"]
+        k = next(v for n, v in k.items() if "roi_cloud" in n)
+        return int(k["bytes_per_launch"] / k["detections_per_launch"] * D)
+    except Exception:
+        return None
+
+
 def bench_input_side(args, dev, rank, world, dist, share):
     """a step turns `--frames` depth frames (480x640 uint16) with 6 detections each, already in HBM, into
     (1024,3) clouds: one tgp_roi_cloud launch (a workgroup per detection) + one tgp_cloud_sample launch.  HBM-bound byte
@@ -133,7 +144,7 @@ def bench_input_side(args, dev, rank, world, dist, share):
                                        "frames resident in HBM, device-drawn resampling" % (args.frames, per_frame),
                            "frames": args.frames, "detections": D, "replicas": world},
                 "roofline": {"bound": "hbm", "achieved": round(alg / k_roi / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                             "frac": round(alg / k_roi / 8e12, 4), "traffic": None, "kernel": "roi_cloud_kernel",
+                             "frac": round(alg / k_roi / 8e12, 4), "traffic": _input_side_traffic(D), "kernel": "roi_cloud_kernel",
                              "avg_launch_us": round(1e6 * k_roi, 1), "sample_launch_us": round(1e6 * k_smp, 1),
                              "algorithmic_bytes_per_launch": alg,
                              "note": "one workgroup per detection (%d workgroups on 256 CUs), each a chain of 16 + ~8 dependent "

@@ -1817,3 +1817,62 @@ def test_input_side_feeds_the_forward(ops):
     b = net(torch.as_tensor(want).to(DEV), cat)
     for k in a:
         assert torch.equal(a[k], b[k])
+
+
+def _eval_records(seeds, dets=3):
+    """Synthetic per-image records in the evaluater's format: the frame (depth + detection pickle fields) carrying the
+    ground-truth fields the NOCS result pickles hold."""
+    from tests.util import synth_depth_scene
+    recs = []
+    for s in seeds:
+        fr = synth_depth_scene(s, dets)
+        rng = np.random.RandomState(s)
+        G = dets
+        RT = np.tile(np.eye(4), (G, 1, 1))
+        RT[:, :3, 3] = rng.uniform(-0.2, 0.2, (G, 3)) + np.array([0, 0, 0.8])
+        fr.update(gt_class_ids=fr["pred_class_ids"].copy(), gt_RTs=RT, gt_scales=rng.uniform(0.1, 0.3, (G, 3)),
+                  gt_handle_visibility=np.ones(G, dtype=np.int32))
+        recs.append(dict(frame=fr))
+    return recs
+
+
+def test_evaluater_run_equals_stagewise_pipeline(ops, tmp_path):
+    """myEvaluater.run (frames -> clouds -> forward -> pose assembly, chunked over frames) returns, bit for bit, what the
+    stages give when called one after the other with the same np.random / torch seeds; a None record and a frame the loader
+    drops are skipped as the reference skips them; calc_pose_metric produces the reference's tables and log lines."""
+    from tgpose_amd import PoseNet9D, seeded_state_dict
+    from tgpose_amd.evaluater.RT_TDA_Evaluater import myEvaluater, calc_pose_metric, MEAN_SHAPE_MM, SYM_INFO
+    from tgpose_amd.evaluation.load_data_eval import clouds_from_frames
+    from tgpose_amd.pose import batched_inference
+    net = PoseNet9D().to(DEV).eval()
+    net.load_state_dict(seeded_state_dict(0))
+    recs = _eval_records([501, 502, 503, 504, 505])
+    recs[3]["frame"]["pred_masks"][:, :, 0] = False            # dropped by the loader (:336-337)
+    data = recs[:2] + [None] + recs[2:]
+    ev = myEvaluater(net, frames_per_batch=2)
+    np.random.seed(8)
+    torch.manual_seed(8)
+    got = ev.run(data)
+    assert len(got) == 4 and all("pred_masks" not in r and "depth" not in r for r in got)
+    np.random.seed(8)
+    torch.manual_seed(8)
+    want = []
+    for chunk in (recs[0:2], recs[2:4], recs[4:5]):
+        frames = [r["frame"] for r in chunk]
+        clouds = clouds_from_frames(frames, device=DEV)
+        keep = [i for i, c in enumerate(clouds) if c is not None]
+        ids = [frames[i]["pred_class_ids"] for i in keep]
+        t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).to(DEV)
+        with torch.no_grad():
+            want += batched_inference(net, [clouds[i] for i in keep], [t(c - 1).reshape(-1, 1) for c in ids],
+                                      [t([MEAN_SHAPE_MM[int(c)] for c in cs]) / 1000.0 for cs in ids],
+                                      [t([SYM_INFO[int(c)] for c in cs]) for cs in ids])
+    assert len(want) == 4
+    for a, b in zip(got, want):
+        assert np.array_equal(a["pred_RTs"], b["pred_RTs"]) and np.array_equal(a["pred_scales"], b["pred_scales"])
+        assert a["pred_RTs"].shape == (3, 4, 4) and np.isfinite(a["pred_RTs"]).all()
+    iou_aps, pose_aps, msg = calc_pose_metric(got, str(tmp_path))
+    assert iou_aps.shape == (7, 101) and pose_aps.shape == (7, 62, 22) and msg[0] == "average mAP:" and len(msg) == 14
+    assert os.path.exists(os.path.join(str(tmp_path), "mAP_data.npz"))
+    dev_res = myEvaluater(net, frames_per_batch=4, sampler="device", seed=3).run(recs)
+    assert len(dev_res) == 4 and all(np.isfinite(r["pred_RTs"]).all() for r in dev_res)
