@@ -1872,7 +1872,7 @@ def test_evaluater_run_equals_stagewise_pipeline(ops, tmp_path):
         assert np.array_equal(a["pred_RTs"], b["pred_RTs"]) and np.array_equal(a["pred_scales"], b["pred_scales"])
         assert a["pred_RTs"].shape == (3, 4, 4) and np.isfinite(a["pred_RTs"]).all()
     iou_aps, pose_aps, msg = calc_pose_metric(got, str(tmp_path))
-    assert iou_aps.shape == (7, 101) and pose_aps.shape == (7, 62, 22) and msg[0] == "average mAP:" and len(msg) == 14
+    assert iou_aps.shape == (8, 101) and pose_aps.shape == (8, 62, 22) and msg[0] == "average mAP:" and len(msg) == 14
     assert os.path.exists(os.path.join(str(tmp_path), "mAP_data.npz"))
     dev_res = myEvaluater(net, frames_per_batch=4, sampler="device", seed=3).run(recs)
     assert len(dev_res) == 4 and all(np.isfinite(r["pred_RTs"]).all() for r in dev_res)
