@@ -105,10 +105,10 @@ def bench_input_side(args, dev, rank, world, dist, share):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timed else None
         if timed:
             e[0].record()
-        pts, counts = ops.roi_cloud(*packed, roi_size=256)
+        rr = ops.roi_cloud(*packed, roi_size=256)
         if timed:
             e[1].record()
-        out = ops.cloud_sample(pts, counts, 1024, 7)
+        out = ops.cloud_sample(rr, 1024, 7)
         if timed:
             e[2].record()
             ev.append(e)

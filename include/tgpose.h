@@ -422,22 +422,28 @@ int tgp_rt_error_pairs(const double *RT1, const double *RT2, const int *mode, in
  *                                                s = min(max(rmax-rmin, cmax-cmin), max(H,W)) (:309-316)
  *   camk    (I,4) fx, fy, cx, cy (float32, as the reference's intrinsics :158-161); fx, fy ordinary focal lengths (normal
  *           floats far from overflow / underflow: the quotients are correctly rounded under that assumption)
- *   roi_size     FLAGS.img_size; must be a power of two in [64, 1024] (the fixed-point walk is then exact, see inputside.hip)
- *   pts     (D, roi_size^2, 3) scratch: on return rows [0, counts[d][2]) hold detection d's cloud in ROI row-major order
+ *   roi_size     FLAGS.img_size; a power of two in [64, 256] (the fixed-point walk is then exact and a pixel index fits 16 bits)
+ *   recs    (D, roi_size^2) uint32 scratch: on return entries [0, counts[d][2]) are detection d's cloud in ROI row-major order
+ *           as records (ROI pixel index << 16) | depth; a record and the detection's window / intrinsics determine its point,
+ *           which tgp_cloud_select / tgp_cloud_sample materialise (only the sampled points are ever written as floats)
  *   counts  (D,3): depth-valid ROI pixels (:332), valid points (:336), points kept by the cut; the last is -1 when there are
  *           fewer than 26 valid points (the reference raises IndexError at :350). */
 int tgp_roi_cloud(const uint16_t *depth, const uint8_t *masks, const int64_t *mask_off, const int *mask_stride, const int *det_img,
-                  const int *window, const float *camk, int D, int H, int W, int roi_size, float *pts, int *counts, tgp_stream_t stream);
+                  const int *window, const float *camk, int D, int H, int W, int roi_size, uint32_t *recs, int *counts,
+                  tgp_stream_t stream);
 
-/* _sample_points (:404-417) as a gather with a host-drawn selection: out[d][i] = pts[d][sel[d][i]], out (D,n_pts,3).
- * cap = rows per detection in pts (roi_size^2).  An index outside [0, cap) produces NaNs, never a fault. */
-int tgp_cloud_select(const float *pts, const int32_t *sel, int D, int64_t cap, int n_pts, float *out, tgp_stream_t stream);
+/* _sample_points (:404-417) as a gather with a host-drawn selection: out[d][i] = point(recs[d][sel[d][i]]), out (D,n_pts,3);
+ * det_img / window / camk as given to tgp_roi_cloud.  An index outside [0, roi_size^2) produces NaNs, never a fault.
+ * With sel[d] = 0..n-1 it materialises a cloud's first n points. */
+int tgp_cloud_select(const uint32_t *recs, const int32_t *sel, const int *det_img, const int *window, const float *camk, int D,
+                     int roi_size, int n_pts, float *out, tgp_stream_t stream);
 
 /* The same resampling drawn on the device (no read-back of counts): the first n_pts elements of a keyed pseudo-random
  * permutation of each cloud (4-round Feistel bijection, cycle-walked); clouds with at most n_pts points are tiled exactly
  * as :411-412.  Not the draw np.random would make -- a documented deviation for throughput runs.  Rows of detections
  * whose count is <= 0 are NaN. */
-int tgp_cloud_sample(const float *pts, const int *counts, int D, int64_t cap, int n_pts, uint64_t seed, float *out, tgp_stream_t stream);
+int tgp_cloud_sample(const uint32_t *recs, const int *counts, const int *det_img, const int *window, const float *camk, int D,
+                     int roi_size, int n_pts, uint64_t seed, float *out, tgp_stream_t stream);
 
 #ifdef __cplusplus
 }

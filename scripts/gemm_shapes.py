@@ -28,7 +28,7 @@ torch.cuda.synchronize()
 timer, ops.GEMM_TIMER = ops.GEMM_TIMER, None
 per = len(timer) // R
 acc = collections.OrderedDict()
-for i, (e0, e1, fl, shape) in enumerate(timer):
+for i, (e0, e1, fl, shape, *_) in enumerate(timer):
     k = (i % per, shape)
     acc.setdefault(k, [0.0, fl])[0] += e0.elapsed_time(e1) * 1e3 / R
 tot = 0.0

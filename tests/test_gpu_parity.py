@@ -1695,7 +1695,7 @@ def test_input_side_vs_reference_getitem(ops):
 
 
 def test_input_side_stages_vs_oracle(ops):
-    """tgp_roi_cloud's scratch (the cloud before resampling, in ROI order) and its three counts against the oracle, detection
+    """tgp_roi_cloud's records (the cloud before resampling, in ROI order, materialised) and its three counts against the oracle, detection
     by detection, on frames of another seed with the CAMERA intrinsics and per-frame matrices; then the draw order of a
     custom RandomState."""
     from oracle import input_ref as ir
@@ -1704,7 +1704,8 @@ def test_input_side_stages_vs_oracle(ops):
     frames = [synth_depth_scene(101, 6, edge_cases=True), synth_depth_scene(102, 3), synth_depth_scene(103, 2)]
     Ks = np.stack([lde.CAMERA_INTRINSICS, lde.REAL_INTRINSICS, lde.CAMERA_INTRINSICS])
     rc = lde.build(frames, Ks, device=DEV)
-    pts, counts = rc.pts.cpu().numpy(), rc.counts.cpu().numpy()
+    counts = rc.counts.cpu().numpy()
+    pts = rc.points(int(counts[:, 2].max())).cpu().numpy()          # records -> points (tgp_cloud_select with the identity)
     d = 0
     for i, fr in enumerate(frames):
         for j in range(fr["pred_masks"].shape[2]):
@@ -1763,7 +1764,8 @@ def test_input_side_device_sampler_properties(ops):
     out, ok = lde.clouds_from_frames(frames, _K_REAL, sampler="device", seed=11, device=DEV)
     out2, _ = lde.clouds_from_frames(frames, _K_REAL, sampler="device", seed=11, device=DEV)
     out3, _ = lde.clouds_from_frames(frames, _K_REAL, sampler="device", seed=12, device=DEV)
-    pts, counts = rc.pts.cpu().numpy(), rc.counts.cpu().numpy()
+    counts = rc.counts.cpu().numpy()
+    pts = rc.points(int(counts[:, 2].max())).cpu().numpy()
     o = torch.cat(out).cpu().numpy()
     okf = torch.cat(ok).cpu().numpy()
     assert np.array_equal(_bits(o), _bits(torch.cat(out2).cpu().numpy()))
@@ -1781,19 +1783,26 @@ def test_input_side_device_sampler_properties(ops):
             assert np.array_equal(_bits(o[d]), _bits(pts[d, np.arange(1024) % total]))
         else:
             assert not np.array_equal(_bits(o[d]), _bits(torch.cat(out3).cpu().numpy()[d]))
-    # distinctness of the drawn INDICES on a cloud whose rows are all different
+    # distinctness of the drawn INDICES: records whose pixel index is their position give points that identify the record
+    from tgpose_amd.ops import RoiRecords
     D, cap = 3, 256 * 256
-    uniq = torch.arange(D * cap * 3, dtype=torch.float32, device=DEV).reshape(D, cap, 3)
+    recs = ((torch.arange(cap, dtype=torch.int64) << 16) | 1000).to(torch.int32).repeat(D, 1).to(DEV).contiguous()
+    win = torch.tensor([[640, 480, 256]] * D, dtype=torch.int32, device=DEV)      # window = the ROI itself: source pixel = ROI pixel + 192 / 112
+    rr = RoiRecords(recs, None, torch.zeros(D, dtype=torch.int32, device=DEV), win,
+                    torch.tensor([[1000.0, 1000.0, 0.0, 0.0]], device=DEV), 256)
     cnt = torch.tensor([[cap, cap, cap], [cap, 5000, 4099], [cap, 2000, 1025]], dtype=torch.int32, device=DEV)
-    s = ops.cloud_sample(uniq, cnt, 1024, 99).cpu().numpy()
+
+    def drawn(seed):
+        pt = ops.cloud_sample(rr, 1024, seed, counts=cnt).cpu().numpy()            # px = sx * 1000 / 1000 / 1000, py likewise
+        sx, sy = np.rint(pt[:, :, 0] * 1000).astype(np.int64), np.rint(pt[:, :, 1] * 1000).astype(np.int64)
+        return (sy - 112) * 256 + (sx - 192)
+    idx = drawn(99)
     for d in range(D):
-        idx = (s[d, :, 0] - d * cap * 3) / 3
-        assert len(np.unique(idx)) == 1024 and idx.min() >= 0 and idx.max() < int(cnt[d, 2])
+        assert len(np.unique(idx[d])) == 1024 and idx[d].min() >= 0 and idx[d].max() < int(cnt[d, 2])
     # a rough uniformity check over many seeds: each quarter of a 4099-point cloud gets its share of the draws
     hits = np.zeros(4)
     for seed in range(40):
-        idx = (ops.cloud_sample(uniq, cnt, 1024, seed).cpu().numpy()[1, :, 0] - cap * 3) / 3
-        hits += np.histogram(idx, bins=4, range=(0, 4099))[0]
+        hits += np.histogram(drawn(seed)[1], bins=4, range=(0, 4099))[0]
     assert (np.abs(hits / hits.sum() - 0.25) < 0.02).all()
 
 

@@ -114,8 +114,8 @@ SIGNATURES = {
     "tgp_generate_rt": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "tgp_canonicalize": (c_int, [c_vp] * 9 + [c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_roi_cloud": (c_int, [c_vp] * 7 + [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
-    "tgp_cloud_select": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_vp]),
-    "tgp_cloud_sample": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, ctypes.c_uint64, c_vp, c_vp]),
+    "tgp_cloud_select": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, c_vp, c_vp]),
+    "tgp_cloud_sample": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, ctypes.c_uint64, c_vp, c_vp]),
 }
 
 ABI_VERSION = 1

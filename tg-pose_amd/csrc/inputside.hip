@@ -1,8 +1,14 @@
 // Input side of the evaluation loader (evaluation/load_data_eval.py:302-357, 404-417, 451-462): depth image + detection
-// mask + box window -> the camera-frame cloud the network is fed.  HBM-bound byte/integer work: per detection 65536 ROI
-// pixels x (2 B depth + 1 B mask) in, 12 KB out.  One 1024-thread workgroup per detection walks the ROI in row-major
-// rounds of 4096 pixels and compacts in order (wave ballots + a 4 x 16-entry LDS table, one barrier per round), because the reference's
+// mask + box window -> the camera-frame cloud the network is fed.  Byte / integer work: per detection 65536 ROI pixels x
+// (2 B depth + 1 B mask) in, 12 KB out.  One 1024-thread workgroup per detection walks the ROI in row-major rounds of 4096
+// pixels and compacts in order (wave ballots + a 4 x 16-entry LDS table, one barrier per round), because the reference's
 // boolean indexing keeps row-major order and its outlier cut is anchored on point number 25 of that order.
+//
+// What lives in HBM between the passes is a 4-byte RECORD per valid pixel, (ROI pixel index << 16) | depth, not the 12-byte
+// point: a point is a pure function of its record and the detection's window / intrinsics, so pass 2 and the resampling
+// kernels recompute it (25 FMAs) instead of moving it.  The first version wrote and re-read points (319 KB fetched +
+// 580 KB written per detection against 209 KB algorithmic, profiles/r01_k_input_side_sq_counters.txt); records cut the
+// scratch to a third (262 KB per detection, L2-resident) and only the n_pts sampled points are ever materialised.
 //
 // The ROI resampling is cv2.warpAffine(..., INTER_NEAREST) of a pure scale + shift (tools/dataset_utils.py:80-136 with
 // rot = 0): OpenCV inverts the matrix in double and walks it in 10-bit fixed point,
@@ -23,11 +29,9 @@ __device__ __forceinline__ int src_coord(int sum_lo_hi, int s, int x, int step)
     return (512 * sum_lo_hi - 512 * s + 512 + x * s * step) >> 10;
 }
 
-// ROI_SUB = sub-rounds per barrier: a round covers ROI_SUB * 1024 consecutive pixels, element (k, tid) = k*1024 + tid
-
+// ROI_SUB = sub-rounds per barrier: a round covers ROI_SUB * 1024 consecutive pixels, element (k, tid) = k*1024 + tid.
 // Ordered compaction of one round: slot[k] = base + rank of element (k, tid) among the round's keepers in element order;
-// adds the round's total to base.  ONE barrier per round (tot is double buffered by the caller's round parity), so the 16
-// rounds of a 256 x 256 ROI cost 16 barriers while the 4 independent loads per thread overlap.
+// adds the round's total to base.  ONE barrier per round (tot is double buffered by the caller's round parity).
 template <int ROI_SUB>
 __device__ __forceinline__ void ordered_slots(const bool (&keep)[ROI_SUB], int (*tot)[ROI_SUB][ROI_WAVES], int parity, int &base,
                                               int (&slot)[ROI_SUB])
@@ -42,7 +46,7 @@ __device__ __forceinline__ void ordered_slots(const bool (&keep)[ROI_SUB], int (
     }
     __syncthreads();
     // every wave scans the round's ROI_SUB * 16 wave totals across its own lanes (lane l holds entry l in element order):
-    // a dozen instructions per round instead of a 16-step loop per pixel -- the kernel is VALU-bound, not bandwidth-bound
+    // a dozen instructions per round instead of a 16-step loop per pixel
     const int own = lane < ROI_SUB * ROI_WAVES ? (&tot[parity][0][0])[lane] : 0;
     int incl = own;
 #pragma unroll
@@ -90,39 +94,60 @@ struct UniformDiv {
     }
 };
 
+// A detection's geometry: everything a record needs to become a point (load_data_eval.py:451-462 then /1000.0 at :338,
+// float32 step by step, correctly rounded quotients).
+struct RoiGeom {
+    int sumc, sumr, s, step, roi_log2;
+    float cx, cy;
+    UniformDiv div_fx, div_fy, div_k;
+    __device__ __forceinline__ RoiGeom(const int *__restrict__ window, const float *__restrict__ camk, int j, int img, int lg)
+        : sumc(window[j * 3]), sumr(window[j * 3 + 1]), s(window[j * 3 + 2]), step(1024 >> lg), roi_log2(lg), cx(camk[img * 4 + 2]),
+          cy(camk[img * 4 + 3]), div_fx(camk[img * 4]), div_fy(camk[img * 4 + 1]), div_k(1000.0f)
+    {
+    }
+    __device__ __forceinline__ void point(uint32_t rec, float &px, float &py, float &pz) const
+    {
+        const int p = (int)(rec >> 16), x = p & ((1 << roi_log2) - 1), y = p >> roi_log2;
+        const float dep = (float)(rec & 0xffffu);
+        px = div_k(div_fx(((float)src_coord(sumc, s, x, step) - cx) * dep));
+        py = div_k(div_fy(((float)src_coord(sumr, s, y, step) - cy) * dep));
+        pz = div_k(dep);
+    }
+};
+
 template <int ROI_SUB>
 __global__ __launch_bounds__(ROI_THREADS) void roi_cloud_kernel(const uint16_t *__restrict__ depth, const uint8_t *__restrict__ masks,
                                                                 const int64_t *__restrict__ mask_off, const int *__restrict__ mask_stride,
                                                                 const int *__restrict__ det_img, const int *__restrict__ window,
                                                                 const float *__restrict__ camk, int H, int W, int roi_log2,
-                                                                float *pts, int *__restrict__ counts)
+                                                                uint32_t *recs, int *__restrict__ counts)
 {
     __shared__ int tot[2][ROI_SUB][ROI_WAVES];
     __shared__ float red[6][ROI_WAVES];
     __shared__ int n_depth_waves[ROI_WAVES];
     const int j = blockIdx.x, tid = threadIdx.x;
-    const int roi = 1 << roi_log2, step = 1024 >> roi_log2;
-    const int64_t cap = (int64_t)roi * roi;
+    const int roi = 1 << roi_log2;
+    const int cap = roi * roi;
     const int img = det_img[j];
-    const int sumc = window[j * 3], sumr = window[j * 3 + 1], s = window[j * 3 + 2];
-    const float fx = camk[img * 4], fy = camk[img * 4 + 1], cx = camk[img * 4 + 2], cy = camk[img * 4 + 3];
+    const RoiGeom g(window, camk, j, img, roi_log2);
     const uint16_t *dimg = depth + (size_t)img * H * W;
     const uint8_t *mimg = masks + mask_off[j];
     const int mstride = mask_stride[j];
-    const UniformDiv div_fx(fx), div_fy(fy), div_k(1000.0f);
-    float *out = pts + (size_t)j * cap * 3;
+    uint32_t *rec = recs + (size_t)j * cap;
 
-    // ---- pass 1: ROI pixel -> source pixel -> (depth > 0) & mask -> back-projection, kept in ROI order
+    // ---- pass 1: ROI pixel -> source pixel -> (depth > 0) & mask -> record, kept in ROI order.
+    // The extent of the cloud (:341-344) is tracked on the dividends: p = div_k(div_f(t)) is monotone in t = (coord - c) * depth
+    // (rounding is monotone), so min / max over the points = the map of min / max over t -- no division per pixel here.
     float lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
     int base = 0, n_depth = 0;
-    const int rounds = (int)(cap / (ROI_THREADS * ROI_SUB));
+    const int rounds = cap / (ROI_THREADS * ROI_SUB);
     // 1024 threads are a whole number of ROI rows (or a fraction of one): a thread keeps its column for the whole walk and a
     // wave sits inside one row, so everything that depends on x alone is hoisted and the row terms are wave-uniform
     const int x = tid & (roi - 1);
-    const int sx = src_coord(sumc, s, x, step);
+    const int sx = src_coord(g.sumc, g.s, x, g.step);
     const bool inbx = sx >= 0 && sx < W;
     const int colq = min(max(sx, 0), W - 1);
-    const float xm = (float)sx - cx;
+    const float xm = (float)sx - g.cx;
     const int row0 = __builtin_amdgcn_readfirstlane(tid >> roi_log2);      // this wave's row within a 1024-pixel sub-round
     // The walk is a chain of dependent rounds (loads -> ballot -> barrier -> scan -> stores) on one CU, so what bounds it is
     // latency, not bandwidth or issue (SQ counters: waves wait 69 % of their cycles).  Round c+1's loads are therefore issued
@@ -134,11 +159,11 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_cloud_kernel(const uint16_t *
 #pragma unroll
         for (int k = 0; k < ROI_SUB; ++k) {
             const int y = ((c * ROI_SUB + k) * ROI_THREADS >> roi_log2) + row0;        // = (round element index) / roi
-            const int sy = src_coord(sumr, s, y, step);
+            const int sy = src_coord(g.sumr, g.s, y, g.step);
             const bool inb = inbx && sy >= 0 && sy < H;
             // border pixels read a clamped address and are zeroed afterwards: no branch round the loads, all 2*ROI_SUB in flight
             const int q = min(max(sy, 0), H - 1) * W + colq;                            // < 2^24 (host-checked)
-            ym_next[k] = (float)sy - cy;
+            ym_next[k] = (float)sy - g.cy;
             d_next[k] = inb ? (int)dimg[q] : 0;
             m_next[k] = inb ? (int)mimg[q * mstride] : 0;
         }
@@ -161,15 +186,11 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_cloud_kernel(const uint16_t *
 #pragma unroll
         for (int k = 0; k < ROI_SUB; ++k)
             if (keep[k]) {
-                // load_data_eval.py:451-462 then /1000.0 (:338); float32 step by step, correctly rounded quotients
-                const float dep = (float)d[k];
-                const float px = div_k(div_fx(xm * dep));
-                const float py = div_k(div_fy(ym[k] * dep));
-                const float pz = div_k(dep);
-                float *o = out + (size_t)slot[k] * 3;
-                o[0] = px, o[1] = py, o[2] = pz;
-                lo0 = fminf(lo0, px), lo1 = fminf(lo1, py), lo2 = fminf(lo2, pz);
-                hi0 = fmaxf(hi0, px), hi1 = fmaxf(hi1, py), hi2 = fmaxf(hi2, pz);
+                const int p = (c * ROI_SUB + k) * ROI_THREADS + tid;
+                rec[slot[k]] = ((uint32_t)p << 16) | (uint32_t)d[k];
+                const float dep = (float)d[k], tx = xm * dep, ty = ym[k] * dep;
+                lo0 = fminf(lo0, tx), lo1 = fminf(lo1, ty), lo2 = fminf(lo2, dep);
+                hi0 = fmaxf(hi0, tx), hi1 = fmaxf(hi1, ty), hi2 = fmaxf(hi2, dep);
             }
     }
     const int n_valid = base;
@@ -202,8 +223,13 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_cloud_kernel(const uint16_t *
         return;
     }
 
-    // ---- pass 2: drop the points within a quarter of the extent's diagonal of point 25 (:345-355), in place
-    const float r0 = hi0 - lo0, r1 = hi1 - lo1, r2 = hi2 - lo2;
+    // ---- pass 2: drop the points within a quarter of the extent's diagonal of point 25 (:345-355), compacting the records in place
+    float r0, r1, r2;
+    {
+        // the quotient maps are monotone, increasing or decreasing with the sign of the focal length: take both ends
+        const float a0 = g.div_k(g.div_fx(lo0)), b0 = g.div_k(g.div_fx(hi0)), a1 = g.div_k(g.div_fy(lo1)), b1 = g.div_k(g.div_fy(hi1));
+        r0 = fmaxf(a0, b0) - fminf(a0, b0), r1 = fmaxf(a1, b1) - fminf(a1, b1), r2 = g.div_k(hi2) - g.div_k(lo2);
+    }
     const float thr = __fsqrt_rn((r0 * r0 + r1 * r1) + r2 * r2) * 0.25f;
     // sqrt_rn is monotone, so sqrt_rn(v) > thr  <=>  v > v_max, v_max = the largest float whose rounded root is <= thr:
     // found once per detection from thr*thr by stepping ulps; the per-point test is then a compare of the squared distance
@@ -215,85 +241,91 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_cloud_kernel(const uint16_t *
         v_max = up;
     }
     // (thr = 0, a cloud of one repeated point: v_max stays 0 and v > 0 is the same test; thr is never negative or NaN here)
-    const float c0 = out[25 * 3], c1 = out[25 * 3 + 1], c2 = out[25 * 3 + 2];
+    float c0, c1, c2;
+    g.point(rec[25], c0, c1, c2);
     __syncthreads();        // everyone holds point 25 before round 0 may overwrite it
     base = 0;
     const int rounds2 = (n_valid + ROI_THREADS * ROI_SUB - 1) / (ROI_THREADS * ROI_SUB);
-    // same pipelining: round c+1 reads rows >= (c+1)*4096, round c writes rows < (c+1)*4096
-    float nx[ROI_SUB], ny[ROI_SUB], nz[ROI_SUB];
+    // same pipelining: round c+1 reads records >= (c+1)*4096, round c writes records < (c+1)*4096
+    uint32_t nrec[ROI_SUB];
     auto fetch2 = [&](int c) {
 #pragma unroll
-        for (int k = 0; k < ROI_SUB; ++k) {
-            const int i = (c * ROI_SUB + k) * ROI_THREADS + tid;
-            const float *q = out + (size_t)min(i, n_valid - 1) * 3;
-            nx[k] = q[0], ny[k] = q[1], nz[k] = q[2];
-        }
+        for (int k = 0; k < ROI_SUB; ++k) nrec[k] = rec[min((c * ROI_SUB + k) * ROI_THREADS + tid, n_valid - 1)];
     };
     fetch2(0);
     for (int c = 0; c < rounds2; ++c) {
-        float px[ROI_SUB], py[ROI_SUB], pz[ROI_SUB];
+        uint32_t cur[ROI_SUB];
         bool keep[ROI_SUB];
         int slot[ROI_SUB];
 #pragma unroll
-        for (int k = 0; k < ROI_SUB; ++k) px[k] = nx[k], py[k] = ny[k], pz[k] = nz[k];
+        for (int k = 0; k < ROI_SUB; ++k) cur[k] = nrec[k];
         if (c + 1 < rounds2) fetch2(c + 1);
 #pragma unroll
         for (int k = 0; k < ROI_SUB; ++k) {
             const int i = (c * ROI_SUB + k) * ROI_THREADS + tid;
-            const float d0 = px[k] - c0, d1 = py[k] - c1, d2 = pz[k] - c2;
+            float px, py, pz;
+            g.point(cur[k], px, py, pz);
+            const float d0 = px - c0, d1 = py - c1, d2 = pz - c2;
             // numpy: sqrt(add.reduce(x*x)) > thr with the squares summed left to right
             keep[k] = i < n_valid && (d0 * d0 + d1 * d1) + d2 * d2 > v_max;
         }
-        // slot <= i, and every load of rows < (c+1)*4096 precedes the barrier inside ordered_slots: compacting in place is safe
+        // slot <= i, and every load of records < (c+1)*4096 precedes the barrier inside ordered_slots: compacting in place is safe
         ordered_slots(keep, tot, c & 1, base, slot);
 #pragma unroll
         for (int k = 0; k < ROI_SUB; ++k)
-            if (keep[k]) {
-                float *o = out + (size_t)slot[k] * 3;
-                o[0] = px[k], o[1] = py[k], o[2] = pz[k];
-            }
+            if (keep[k]) rec[slot[k]] = cur[k];
     }
     if (tid == 0) counts[j * 3 + 2] = base;
 }
 
-extern "C" int tgp_roi_cloud(const uint16_t *depth, const uint8_t *masks, const int64_t *mask_off, const int *mask_stride,
-                             const int *det_img, const int *window, const float *camk, int D, int H, int W, int roi_size, float *pts,
-                             int *counts, tgp_stream_t stream)
+static int roi_log2_of(int roi_size)
 {
-    TGP_REQUIRE(depth && masks && mask_off && mask_stride && det_img && window && camk && pts && counts);
-    TGP_REQUIRE(D > 0 && H > 0 && W > 0 && H < 32768 && W < 32768 && (int64_t)H * W < (1ll << 24));   // x mask stride < 128: 31-bit offsets
     int lg = 0;
     while ((1 << lg) < roi_size) ++lg;
-    if ((1 << lg) != roi_size || roi_size < 64 || roi_size > 1024) return TGP_EUNSUPPORTED;   // whole rounds of 4096 pixels
+    // whole rounds of 4096 pixels; a pixel index must fit the record's 16 bits
+    return ((1 << lg) == roi_size && roi_size >= 64 && roi_size <= 256) ? lg : -1;
+}
+
+extern "C" int tgp_roi_cloud(const uint16_t *depth, const uint8_t *masks, const int64_t *mask_off, const int *mask_stride,
+                             const int *det_img, const int *window, const float *camk, int D, int H, int W, int roi_size, uint32_t *recs,
+                             int *counts, tgp_stream_t stream)
+{
+    TGP_REQUIRE(depth && masks && mask_off && mask_stride && det_img && window && camk && recs && counts);
+    TGP_REQUIRE(D > 0 && H > 0 && W > 0 && H < 32768 && W < 32768 && (int64_t)H * W < (1ll << 24));   // x mask stride < 128: 31-bit offsets
+    const int lg = roi_log2_of(roi_size);
+    if (lg < 0) return TGP_EUNSUPPORTED;
     static const int sub = [] { const char *e = getenv("TGP_ROI_SUB"); return e ? atoi(e) : 4; }();     // development A/B
     auto kern = sub == 1 ? roi_cloud_kernel<1> : sub == 2 ? roi_cloud_kernel<2> : roi_cloud_kernel<4>;
     hipLaunchKernelGGL(kern, dim3(D), dim3(ROI_THREADS), 0, tgp_hs(stream), depth, masks, mask_off, mask_stride, det_img, window, camk, H, W,
-                       lg, pts, counts);
+                       lg, recs, counts);
     return TGP_LAUNCH_RESULT();
 }
 
-// _sample_points (:404-417) as a gather: the host supplies the selection (tiled indices, or the prefix of the permutation
-// it drew from np.random in the reference's order), out[j, i] = pts[j, sel[j, i]].  An index outside [0, cap) yields NaNs.
-__global__ void cloud_select_kernel(const float *__restrict__ pts, const int *__restrict__ sel, int64_t total, int64_t cap, int n_pts,
+// _sample_points (:404-417) as a gather that materialises the selected points: the host supplies the selection (tiled indices,
+// or the prefix of the permutation it drew from np.random in the reference's order), out[j, i] = point(recs[j, sel[j, i]]).
+// An index outside [0, roi_size^2) yields NaNs.
+__global__ void cloud_select_kernel(const uint32_t *__restrict__ recs, const int *__restrict__ sel, const int *__restrict__ det_img,
+                                    const int *__restrict__ window, const float *__restrict__ camk, int64_t total, int roi_log2, int n_pts,
                                     float *__restrict__ out)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
-    const int64_t j = t / n_pts;
+    const int j = (int)(t / n_pts), cap = 1 << (2 * roi_log2);
     const int k = sel[t];
     float a = NAN, b = NAN, c = NAN;
-    if (k >= 0 && k < cap) {
-        const float *p = pts + ((size_t)j * cap + k) * 3;
-        a = p[0], b = p[1], c = p[2];
-    }
+    if (k >= 0 && k < cap) RoiGeom(window, camk, j, det_img[j], roi_log2).point(recs[(size_t)j * cap + k], a, b, c);
     out[t * 3] = a, out[t * 3 + 1] = b, out[t * 3 + 2] = c;
 }
 
-extern "C" int tgp_cloud_select(const float *pts, const int *sel, int D, int64_t cap, int n_pts, float *out, tgp_stream_t stream)
+extern "C" int tgp_cloud_select(const uint32_t *recs, const int32_t *sel, const int *det_img, const int *window, const float *camk, int D,
+                                int roi_size, int n_pts, float *out, tgp_stream_t stream)
 {
-    TGP_REQUIRE(pts && sel && out && D > 0 && cap > 0 && n_pts > 0);
+    TGP_REQUIRE(recs && sel && det_img && window && camk && out && D > 0 && n_pts > 0);
+    const int lg = roi_log2_of(roi_size);
+    if (lg < 0) return TGP_EUNSUPPORTED;
     const int64_t total = (int64_t)D * n_pts;
-    hipLaunchKernelGGL(cloud_select_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), pts, sel, total, cap, n_pts, out);
+    hipLaunchKernelGGL(cloud_select_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), recs, sel, det_img, window, camk, total,
+                       lg, n_pts, out);
     return TGP_LAUNCH_RESULT();
 }
 
@@ -320,13 +352,14 @@ __device__ __forceinline__ uint32_t feistel(uint32_t v, int half_bits, uint32_t 
     return (l << half_bits) | r;
 }
 
-__global__ void cloud_sample_kernel(const float *__restrict__ pts, const int *__restrict__ counts, int64_t total_out, int64_t cap, int n_pts,
+__global__ void cloud_sample_kernel(const uint32_t *__restrict__ recs, const int *__restrict__ counts, const int *__restrict__ det_img,
+                                    const int *__restrict__ window, const float *__restrict__ camk, int64_t total_out, int roi_log2, int n_pts,
                                     uint64_t seed, float *__restrict__ out)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total_out) return;
-    const int j = (int)(t / n_pts), i = (int)(t % n_pts);
-    const int total = counts[j * 3 + 2];
+    const int j = (int)(t / n_pts), i = (int)(t % n_pts), cap = 1 << (2 * roi_log2);
+    const int total = min(counts[j * 3 + 2], cap);
     float a = NAN, b = NAN, c = NAN;
     if (total > 0) {
         uint32_t k;
@@ -339,17 +372,19 @@ __global__ void cloud_sample_kernel(const float *__restrict__ pts, const int *__
             k = feistel((uint32_t)i, half_bits, key);
             while (k >= (uint32_t)total) k = feistel(k, half_bits, key);      // a bijection of [0, 2^2h): the walk returns
         }
-        const float *p = pts + ((size_t)j * cap + k) * 3;
-        a = p[0], b = p[1], c = p[2];
+        RoiGeom(window, camk, j, det_img[j], roi_log2).point(recs[(size_t)j * cap + k], a, b, c);
     }
     out[t * 3] = a, out[t * 3 + 1] = b, out[t * 3 + 2] = c;
 }
 
-extern "C" int tgp_cloud_sample(const float *pts, const int *counts, int D, int64_t cap, int n_pts, uint64_t seed, float *out,
-                                tgp_stream_t stream)
+extern "C" int tgp_cloud_sample(const uint32_t *recs, const int *counts, const int *det_img, const int *window, const float *camk, int D,
+                                int roi_size, int n_pts, uint64_t seed, float *out, tgp_stream_t stream)
 {
-    TGP_REQUIRE(pts && counts && out && D > 0 && cap > 0 && cap <= (1ll << 30) && n_pts > 0);
+    TGP_REQUIRE(recs && counts && det_img && window && camk && out && D > 0 && n_pts > 0);
+    const int lg = roi_log2_of(roi_size);
+    if (lg < 0) return TGP_EUNSUPPORTED;
     const int64_t total = (int64_t)D * n_pts;
-    hipLaunchKernelGGL(cloud_sample_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), pts, counts, total, cap, n_pts, seed, out);
+    hipLaunchKernelGGL(cloud_sample_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), recs, counts, det_img, window, camk, total,
+                       lg, n_pts, seed, out);
     return TGP_LAUNCH_RESULT();
 }

@@ -6,8 +6,8 @@ box, resamples depth / mask / pixel grid to ``FLAGS.img_size`` squared with near
 back-projects the valid pixels (``_depth_to_pcl`` :451-462), cuts the points near point number 25 (:341-355) and
 resamples to ``FLAGS.random_points`` (``_sample_points`` :404-417) -- about ten numpy / OpenCV passes over 65536 pixels per
 detection on a DataLoader worker.  Here the frames' depth images and masks are uploaded once and ONE launch
-(``tgp_roi_cloud``, a workgroup per detection) leaves every detection's cloud in HBM, in the reference's point order; the
-resampling is a gather.  The clouds never visit the host: they are the ``pcl_in`` that ``PoseNet9D.forward`` consumes
+(``tgp_roi_cloud``, a workgroup per detection) leaves every detection's cloud in HBM, in the reference's point order, as
+4-byte records (ROI pixel, depth); the resampling is a gather that materialises only the 1024 selected points.  The clouds never visit the host: they are the ``pcl_in`` that ``PoseNet9D.forward`` consumes
 (``pose.batched_inference``).
 
 ``sampler='numpy'`` reproduces the reference bit for bit, including its use of the global ``np.random`` stream: the
@@ -69,10 +69,17 @@ def _windows(frames):
 
 
 class RoiClouds:
-    """Device-side result of ``build``: ``pts`` (D, img_size^2, 3) scratch, ``counts`` (D,3) int32, detections per frame."""
+    """Device-side result of ``build``: ``records`` (ops.RoiRecords: 4-byte records + counts (D,3) + descriptors), detections per
+    frame.  ``points(n)`` materialises the first n points of every cloud (rows beyond a cloud's count are meaningless)."""
 
-    def __init__(self, pts, counts, per_frame):
-        self.pts, self.counts, self.per_frame = pts, counts, per_frame
+    def __init__(self, records, per_frame):
+        self.records, self.per_frame = records, per_frame
+        self.counts = None if records is None else records.counts
+
+    def points(self, n):
+        D = self.records.recs.shape[0]
+        sel = torch.arange(n, dtype=torch.int32, device=self.records.recs.device).repeat(D, 1)
+        return ops.cloud_select(self.records, sel)
 
 
 def upload(frames, camK=REAL_INTRINSICS, device="cuda"):
@@ -100,9 +107,8 @@ def build(frames, camK=REAL_INTRINSICS, img_size=256, device="cuda"):
     dev = torch.device(device)
     per_frame = [fr["pred_masks"].shape[2] for fr in frames]
     if sum(per_frame) == 0:
-        return RoiClouds(torch.zeros(0, img_size * img_size, 3, device=dev), torch.zeros(0, 3, dtype=torch.int32, device=dev), per_frame)
-    pts, counts = ops.roi_cloud(*upload(frames, camK, dev), roi_size=img_size)
-    return RoiClouds(pts, counts, per_frame)
+        return RoiClouds(None, per_frame)
+    return RoiClouds(ops.roi_cloud(*upload(frames, camK, dev), roi_size=img_size), per_frame)
 
 
 def clouds_from_frames(frames, camK=REAL_INTRINSICS, img_size=256, n_pts=1024, sampler="numpy", rng=np.random, seed=0, device="cuda"):
@@ -111,16 +117,18 @@ def clouds_from_frames(frames, camK=REAL_INTRINSICS, img_size=256, n_pts=1024, s
     points :350, an empty cloud after the cut :411).  With sampler='device' returns (list of tensors, list of bool masks)."""
     rc = build(frames, camK, img_size, device)
     D = sum(rc.per_frame)
+    dev = torch.device(device)
+    empty = torch.zeros(0, n_pts, 3, device=dev)
     if sampler == "device":
         if D == 0:
-            return [rc.pts[:0, :n_pts] for _ in rc.per_frame], [torch.zeros(0, dtype=torch.bool, device=rc.pts.device) for _ in rc.per_frame]
-        out = ops.cloud_sample(rc.pts, rc.counts, n_pts, seed)
+            return [empty for _ in rc.per_frame], [torch.zeros(0, dtype=torch.bool, device=dev) for _ in rc.per_frame]
+        out = ops.cloud_sample(rc.records, n_pts, seed)
         ok = (rc.counts[:, 2] > 0) & (rc.counts[:, 0] > 1) & (rc.counts[:, 1] > 1)
         return list(out.split(rc.per_frame)), list(ok.split(rc.per_frame))
     if sampler != "numpy":
         raise ValueError("sampler must be 'numpy' or 'device'")
     if D == 0:
-        return [rc.pts[:0, :n_pts] for _ in rc.per_frame]
+        return [empty for _ in rc.per_frame]
     counts = rc.counts.cpu().numpy()                         # the one read-back: 12 bytes per detection
     sel = np.zeros((D, n_pts), dtype=np.int32)
     keep_frame, d = [], 0
@@ -141,5 +149,5 @@ def clouds_from_frames(frames, camK=REAL_INTRINSICS, img_size=256, n_pts=1024, s
                 sel[d + j] = np.arange(n_pts)
         keep_frame.append(alive)
         d += n
-    out = ops.cloud_select(rc.pts, torch.from_numpy(sel).to(rc.pts.device))
+    out = ops.cloud_select(rc.records, torch.from_numpy(sel).to(dev))
     return [c if alive else None for c, alive in zip(out.split(rc.per_frame), keep_frame)]

@@ -786,9 +786,17 @@ def feat_consistency_bwd(x1, x2, rows, gloss, need1, need2):
 
 
 # ----------------------------------------------------------------------------- input side (depth image -> cloud)
+class RoiRecords:
+    """What tgp_roi_cloud leaves in HBM: ``recs`` (D, roi^2) int32-viewed records (ROI pixel index << 16 | depth), ``counts``
+    (D,3) int32, and the descriptor tensors a record needs to become a point (``det_img``, ``window``, ``camk``)."""
+
+    def __init__(self, recs, counts, det_img, window, camk, roi_size):
+        self.recs, self.counts, self.det_img, self.window, self.camk, self.roi_size = recs, counts, det_img, window, camk, roi_size
+
+
 def roi_cloud(depth, masks, mask_off, mask_stride, det_img, window, camk, roi_size=256):
     """tgp_roi_cloud.  depth (I,H,W) int16-viewed uint16, masks flat uint8, mask_off (D,) int64, mask_stride / det_img (D,) int32,
-    window (D,3) int32, camk (I,4) float32 -- all on the GPU.  -> pts (D, roi_size^2, 3) float32 scratch, counts (D,3) int32."""
+    window (D,3) int32, camk (I,4) float32 -- all on the GPU.  -> RoiRecords"""
     if not (depth.is_cuda and depth.dtype in (torch.int16, torch.uint16) and depth.dim() == 3 and depth.is_contiguous()):
         raise TypeError("depth must be a contiguous (I,H,W) 16-bit GPU tensor")
     if not (masks.is_cuda and masks.dtype in (torch.uint8, torch.bool) and masks.is_contiguous()):
@@ -801,31 +809,32 @@ def roi_cloud(depth, masks, mask_off, mask_stride, det_img, window, camk, roi_si
     D = det_img.numel()
     if window.shape != (D, 3) or mask_off.numel() != D or mask_stride.numel() != D or camk.shape != (I, 4) or not camk.is_contiguous():
         raise ValueError("roi_cloud: inconsistent shapes")
-    pts = torch.empty(D, roi_size * roi_size, 3, device=depth.device, dtype=torch.float32)
+    recs = torch.empty(D, roi_size * roi_size, device=depth.device, dtype=torch.int32)
     counts = torch.empty(D, 3, device=depth.device, dtype=torch.int32)
     check(_lib.lib().tgp_roi_cloud(_p(depth), _p(masks), _p(mask_off), _p(mask_stride), _p(det_img), _p(window), _p(camk), D, H, W,
-                                   roi_size, _p(pts), _p(counts), _stream(depth)), "tgp_roi_cloud")
-    return pts, counts
+                                   roi_size, _p(recs), _p(counts), _stream(depth)), "tgp_roi_cloud")
+    return RoiRecords(recs, counts, det_img, window, camk, roi_size)
 
 
-def cloud_select(pts, sel):
-    """out[d, i] = pts[d, sel[d, i]]; pts (D,cap,3) float32, sel (D,n_pts) int32 -> (D,n_pts,3)"""
-    _f32(pts, "pts", 3), _i32(sel, "sel")
-    D, cap, _ = pts.shape
-    if not pts.is_contiguous() or sel.shape[0] != D:
-        raise ValueError("cloud_select: pts must be contiguous and sel (D,n_pts)")
-    out = torch.empty(D, sel.shape[1], 3, device=pts.device, dtype=torch.float32)
-    check(_lib.lib().tgp_cloud_select(_p(pts), _p(sel), D, cap, sel.shape[1], _p(out), _stream(pts)), "tgp_cloud_select")
+def cloud_select(rr, sel):
+    """out[d, i] = point(recs[d, sel[d, i]]); rr RoiRecords, sel (D,n_pts) int32 -> (D,n_pts,3) float32"""
+    _i32(sel, "sel")
+    D = rr.recs.shape[0]
+    if sel.dim() != 2 or sel.shape[0] != D:
+        raise ValueError("cloud_select: sel must be (D,n_pts)")
+    out = torch.empty(D, sel.shape[1], 3, device=rr.recs.device, dtype=torch.float32)
+    check(_lib.lib().tgp_cloud_select(_p(rr.recs), _p(sel), _p(rr.det_img), _p(rr.window), _p(rr.camk), D, rr.roi_size, sel.shape[1],
+                                      _p(out), _stream(rr.recs)), "tgp_cloud_select")
     return out
 
 
-def cloud_sample(pts, counts, n_pts, seed):
-    """Device-drawn resampling (tgp_cloud_sample): (D,cap,3), counts (D,3) int32 -> (D,n_pts,3)"""
-    _f32(pts, "pts", 3), _i32(counts, "counts")
-    D, cap, _ = pts.shape
-    if not pts.is_contiguous() or counts.shape != (D, 3):
-        raise ValueError("cloud_sample: pts must be contiguous and counts (D,3)")
-    out = torch.empty(D, n_pts, 3, device=pts.device, dtype=torch.float32)
-    check(_lib.lib().tgp_cloud_sample(_p(pts), _p(counts), D, cap, n_pts, int(seed) & (2 ** 64 - 1), _p(out), _stream(pts)),
-          "tgp_cloud_sample")
+def cloud_sample(rr, n_pts, seed, counts=None):
+    """Device-drawn resampling (tgp_cloud_sample) -> (D,n_pts,3); ``counts`` overrides rr.counts (tests)."""
+    counts = rr.counts if counts is None else _i32(counts, "counts")
+    D = rr.recs.shape[0]
+    if counts.shape != (D, 3):
+        raise ValueError("cloud_sample: counts must be (D,3)")
+    out = torch.empty(D, n_pts, 3, device=rr.recs.device, dtype=torch.float32)
+    check(_lib.lib().tgp_cloud_sample(_p(rr.recs), _p(counts), _p(rr.det_img), _p(rr.window), _p(rr.camk), D, rr.roi_size, n_pts,
+                                      int(seed) & (2 ** 64 - 1), _p(out), _stream(rr.recs)), "tgp_cloud_sample")
     return out
