@@ -191,3 +191,31 @@ def test_gradient_allreduce_two_ranks_gloo():
             continue
         want = torch.full_like(a, 1.5) * (i + 1) + torch.arange(a.numel(), dtype=torch.float32).view_as(a) * 1e-3
         assert torch.allclose(a, want) and torch.equal(a, b)
+
+
+def test_input_side_host_packing_and_category_tables():
+    """Host logic of the input side that needs no GPU: window descriptors / mask offsets of a batch of frames, the refusal of
+    inconsistent frames, and the evaluater's per-category tables against the reference's values (load_data_eval.py:477-566)."""
+    import numpy as np
+    from tgpose_amd.evaluation import load_data_eval as lde
+    from tgpose_amd.evaluater.RT_TDA_Evaluater import MEAN_SHAPE_MM, SYM_INFO, SYNSET_NAMES
+    from tests.util import synth_depth_scene
+    frames = [synth_depth_scene(1, 3), synth_depth_scene(2, 0), synth_depth_scene(3, 2, edge_cases=True)]
+    frames[1]["pred_masks"] = np.zeros((480, 640, 0), bool)
+    frames[1]["pred_bboxes"] = np.zeros((0, 4), np.int32)
+    win, det_img, off, stride = lde._windows(frames)
+    assert det_img == [0, 0, 0, 2, 2] and stride == [3, 3, 3, 2, 2]
+    assert off == [0, 1, 2, 480 * 640 * 3, 480 * 640 * 3 + 1]
+    for (sumc, sumr, s), fr_i, j in zip(win, det_img, [0, 1, 2, 0, 1]):
+        rmin, rmax, cmin, cmax = lde.get_bbox(frames[fr_i]["pred_bboxes"][j])
+        assert (sumc, sumr, s) == (cmin + cmax, rmin + rmax, min(max(rmax - rmin, cmax - cmin), 640))
+        assert 0 <= rmin < rmax <= 480 and 0 <= cmin < cmax <= 640 and s % 40 == 0 and s <= 440
+    bad = synth_depth_scene(4, 2)
+    bad["pred_bboxes"] = bad["pred_bboxes"][:1]
+    import pytest
+    with pytest.raises(ValueError):
+        lde._windows([bad])
+    assert SYNSET_NAMES == ['BG', 'bottle', 'bowl', 'camera', 'can', 'laptop', 'mug']
+    assert MEAN_SHAPE_MM[1] == (87, 220, 89) and MEAN_SHAPE_MM[5] == (346, 200, 335) and MEAN_SHAPE_MM[6] == (146, 83, 114)
+    assert SYM_INFO[1] == SYM_INFO[2] == (1, 1, 0, 1) and SYM_INFO[4] == (1, 1, 1, 1) and SYM_INFO[3] == (0, 0, 0, 0)
+    assert SYM_INFO[5] == SYM_INFO[6] == (0, 1, 0, 0)

@@ -15,6 +15,8 @@
 //     neighbour order (DIST epilogue: fl(fl(-2*acc + q_col) + q_row)).
 // Skinny kernel: M <= 32 rows (per-object vectors: PH_Predictor linears, head conv3/conv4):
 // weight-streaming, one wave per 4 output columns, lanes split K, butterfly reduction.
+#include <stdlib.h>
+
 #include "tgp_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1412,7 +1414,11 @@ static int launch_split(GemmParams &p, hipStream_t stream)
     const bool force512 = tgp_split_variant != 7 && (tgp_split_variant & 16), forbid512 = tgp_split_variant != 7 && (tgp_split_variant & 32);
     // (per launch the narrow layers are 25 % faster this way; in the whole forward, where they overlap other branches,
     // the routing measured +-0: 8769 / 8730 vs 8782 / 8881 objects/s)
-    if (p.split_f16 && (force512 || (narrow && !forbid512))) {
+    // development A/B (TGP_GATHER_512=1): epilogue-bound launches -- gathered residuals, short K -- on two workgroups per CU,
+    // so that one workgroup's epilogue overlaps the other's K loop
+    static const int gather512 = [] { const char *e = getenv("TGP_GATHER_512"); return e ? atoi(e) : 0; }();
+    const bool epi_bound = gather512 && (p.gres1 || p.gres2) && p.K <= 512;
+    if (p.split_f16 && (force512 || epi_bound || (narrow && !forbid512))) {
         // two 512-thread workgroups per CU, 256 x 128 tiles (+ 128 x 128 tail tiles)
         plan_tiles(p, GEMM_BIG, 2 * (int64_t)resident_slots(), 0.55, 2, 128, 128);
         order_tiles(p, 2 * (int64_t)resident_slots(), false);
