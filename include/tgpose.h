@@ -445,6 +445,13 @@ int tgp_cloud_select(const uint32_t *recs, const int32_t *sel, const int *det_im
 int tgp_cloud_sample(const uint32_t *recs, const int *counts, const int *det_img, const int *window, const float *camk, int D,
                      int roi_size, int n_pts, uint64_t seed, float *out, tgp_stream_t stream);
 
+/* Row order of the factored wide layers (this repo's engine; no reference counterpart): per object, the n fine rows sorted by
+ * key = near2 * n1 + near1 with ties in point order -- torch.argsort(key, stable=True) -- and the sorted parents as global
+ * row numbers: order / order64 (B,n) the permutation (int32 for tgp_gather_rows, int64 for torch scatter), near1_out = sorted
+ * near1 + b*n1, near2_out = sorted near2 + b*n2.  n <= 2048, n1*n2 <= 2^21; near1 in [0,n1), near2 in [0,n2). */
+int tgp_sort_by_parent(const int32_t *near1, const int32_t *near2, int B, int n, int n1, int n2, int32_t *order, int64_t *order64,
+                       int32_t *near1_out, int32_t *near2_out, tgp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

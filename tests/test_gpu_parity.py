@@ -1885,3 +1885,20 @@ def test_evaluater_run_equals_stagewise_pipeline(ops, tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "mAP_data.npz"))
     dev_res = myEvaluater(net, frames_per_batch=4, sampler="device", seed=3).run(recs)
     assert len(dev_res) == 4 and all(np.isfinite(r["pred_RTs"]).all() for r in dev_res)
+
+
+@pytest.mark.parametrize("B,n,n1,n2", [(32, 1028, 257, 64), (3, 640, 160, 40), (2, 2048, 512, 128), (5, 64, 16, 4), (1, 1, 1, 1), (4, 1025, 300, 77)])
+def test_sort_by_parent_equals_stable_argsort(ops, B, n, n1, n2):
+    """tgp_sort_by_parent = torch.argsort(near2 * n1 + near1, stable=True) + the gathers and offsets it replaces, exactly
+    (many ties: n1 * n2 keys for n rows, and an all-equal case)."""
+    gen = torch.Generator().manual_seed(B * 1000 + n)
+    near1 = torch.randint(0, n1, (B, n), generator=gen).int()
+    near2 = torch.randint(0, n2, (B, n), generator=gen).int()
+    near1[0], near2[0] = 0, 0                                   # all keys equal: the order must be the identity
+    want = torch.argsort(near2.long() * n1 + near1.long(), dim=1, stable=True)
+    rows = torch.arange(B).unsqueeze(1)
+    o32, o64, a, b = ops.sort_by_parent(g(near1), g(near2), n1, n2)
+    assert torch.equal(o64.cpu(), want) and torch.equal(o32.cpu().long(), want) and o64.dtype == torch.int64
+    assert torch.equal(a.cpu().long(), torch.gather(near1.long(), 1, want) + rows * n1)
+    assert torch.equal(b.cpu().long(), torch.gather(near2.long(), 1, want) + rows * n2)
+    assert torch.equal(o64[0].cpu(), torch.arange(n))

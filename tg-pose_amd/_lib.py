@@ -113,6 +113,7 @@ SIGNATURES = {
     "tgp_dcd_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp]),
     "tgp_generate_rt": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "tgp_canonicalize": (c_int, [c_vp] * 9 + [c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "tgp_sort_by_parent": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tgp_roi_cloud": (c_int, [c_vp] * 7 + [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_cloud_select": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, c_vp, c_vp]),
     "tgp_cloud_sample": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, ctypes.c_uint64, c_vp, c_vp]),

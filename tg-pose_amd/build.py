@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["knn.hip", "gemm.hip", "gconv.hip", "chamfer.hip", "dcd.hip", "bn.hip", "backward.hip", "gconv_bwd.hip", "evalmetrics.hip", "tdaloss.hip", "inputside.hip", "version.hip", "gemm_variants.hip"]
+SOURCES = ["knn.hip", "gemm.hip", "gconv.hip", "chamfer.hip", "dcd.hip", "bn.hip", "backward.hip", "gconv_bwd.hip", "evalmetrics.hip", "tdaloss.hip", "inputside.hip", "rowsort.hip", "version.hip", "gemm_variants.hip"]
 LIB = os.path.join(HERE, "libtgpose_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

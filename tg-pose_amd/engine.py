@@ -378,12 +378,11 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, 
         # points, so the order of an object's rows is free: put the points that share their nearest coarse points next to each
         # other.  A 64-row wave tile of the fine GEMM then fetches ~4 + ~16 distinct coarse rows instead of 128 scattered ones
         # (the gathered rows are 18 KB each; unsorted they stream 1.1 GB through the fabric per forward).
-        order = torch.argsort(near2.long() * N1 + near1.long(), dim=1, stable=True)
-        near1, near2 = torch.gather(near1, 1, order), torch.gather(near2, 1, order)
+        # (one launch: torch.argsort(near2 * N1 + near1, stable=True), the two gathers and the offsets, ops.sort_by_parent)
+        order32, order, near1, near2 = ops.sort_by_parent(near1.contiguous(), near2.contiguous(), N1, N2)
         fine = torch.empty_like(feat)
-        ops.gather_rows(feat, order.to(torch.int32), fine)
-        rows = torch.arange(B, device=dev, dtype=torch.int32).unsqueeze(1)
-        inter.update(fm23=fm23, near1=(near1 + rows * N1).contiguous(), near2=(near2 + rows * N2).contiguous(), order=order)
+        ops.gather_rows(feat, order32, fine)
+        inter.update(fm23=fm23, near1=near1, near2=near2, order=order)
         return fine, inter
     ops.gather_rows(fm2, near1, feat[:, :, 256:512])
     ops.gather_rows(fm3, near1, feat[:, :, 512:768])

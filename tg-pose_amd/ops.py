@@ -179,6 +179,20 @@ def gather_rows(src, idx, dst):
     return dst
 
 
+def sort_by_parent(near1, near2, n1, n2):
+    """Rows of each object sorted by (near2, near1), ties in point order (= torch.argsort(near2 * n1 + near1, stable=True)).
+    near1, near2 (B,n) int32 -> order (B,n) int32, order64 (B,n) int64, near1 + b*n1 and near2 + b*n2 in the sorted order."""
+    _i32(near1, "near1"), _i32(near2, "near2")
+    B, n = near1.shape
+    if near2.shape != (B, n):
+        raise ValueError("sort_by_parent: near1 and near2 must both be (B,n)")
+    order, o1, o2 = torch.empty_like(near1), torch.empty_like(near1), torch.empty_like(near1)
+    order64 = torch.empty(B, n, device=near1.device, dtype=torch.int64)
+    check(_lib.lib().tgp_sort_by_parent(_p(near1), _p(near2), B, n, n1, n2, _p(order), _p(order64), _p(o1), _p(o2), _stream(near1)),
+          "tgp_sort_by_parent")
+    return order, order64, o1, o2
+
+
 def fill_tail(obj_id, xyz_c, feat, col0, n_cls):
     _f32(obj_id, "obj_id"), _f32(xyz_c, "xyz_c", 3)
     feat, ld = _rows(feat, "feat")
