@@ -411,7 +411,8 @@ def main():
         traffic = None
         try:   # HBM/fabric bytes per launch of the dominant kernel from the latest committed PMC passes (not a live measurement)
             import glob
-            pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))["kernels"]
+            files = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))) if "input_side" not in f]
+            pmc = json.load(open(files[-1]))["kernels"]
             if args.gemm == "fp32":
                 keys = [k for k in pmc if "gemm_main256_kernel" in k]
             else:   # gemm_split_kernel<prefetch depth, fp16?, interleaved?>; older files: <dbuf> (bf16) / <dbuf, fp16>

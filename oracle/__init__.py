@@ -6,7 +6,11 @@ implementation can be checked against it:
     oracle/csrc/tgp_oracle.c   exact-arithmetic kNN / 1-NN / Chamfer (C, gcc)
     oracle/gcn_ref.py          graph ops of network/fs_net_repo/gcn3d.py (torch CPU ops)
     oracle/posenet_ref.py      Face_Enc / PH_Predictor / Face_Dec / heads / PoseNet9D.forward
-    oracle/chamfer_ref.py      chamfer_3DDist forward/backward and calc_dcd
+    oracle/loss_ref.py         chamfer_3DDist forward/backward and calc_dcd
+    oracle/eval_ref.py         pairwise 3D IoU / pose error of the NOCS mAP
+    oracle/tda_loss_ref.py     the TDA loss bundle
+    oracle/input_ref.py        depth frame + mask + box -> cloud (evaluation loader input side; the two OpenCV calls it
+                               restates are the one piece whose parity is unpinned: cv2 is not installable here)
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
 import it -- as the checker, never as the thing measured or shipped.  The product package
