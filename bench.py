@@ -26,6 +26,9 @@ Extra objects in the line:
 
 `--workload train_step` times the trainer's step instead (training-mode forward with autograd, the
 fourteen-term TDA loss, backward, gradient all-reduce, clip, SGD), replayed as one hipGraph.
+`--workload input_side` times the evaluation loader's input side: `--frames` synthetic depth frames with 6
+detections each, resident in HBM, -> (1024,3) clouds (tgp_roi_cloud + tgp_cloud_sample); detections/s, with an HBM roofline
+block for roi_cloud_kernel and the numpy port as cpu_baseline.
 """
 import argparse
 import json
