@@ -1902,3 +1902,21 @@ def test_sort_by_parent_equals_stable_argsort(ops, B, n, n1, n2):
     assert torch.equal(a.cpu().long(), torch.gather(near1.long(), 1, want) + rows * n1)
     assert torch.equal(b.cpu().long(), torch.gather(near2.long(), 1, want) + rows * n2)
     assert torch.equal(o64[0].cpu(), torch.arange(n))
+
+
+@pytest.mark.parametrize("img_size", [64, 128])
+def test_input_side_other_roi_sizes_vs_oracle(ops, img_size):
+    """FLAGS.img_size other than 256: the fixed-point walk stays exact for every power of two the record format admits
+    (64, 128, 256); 512 is refused (a pixel index must fit the record's 16 bits)."""
+    from oracle import input_ref as ir
+    from tgpose_amd import _lib
+    from tgpose_amd.evaluation import load_data_eval as lde
+    from tests.util import synth_depth_scene
+    frames = [synth_depth_scene(601, 3, edge_cases=True), synth_depth_scene(602, 2)]
+    out = lde.clouds_from_frames(frames, _K_REAL, img_size=img_size, n_pts=256, rng=np.random.RandomState(2), device=DEV)
+    rs = np.random.RandomState(2)
+    for i, fr in enumerate(frames):
+        want = ir.image_clouds(fr["depth"], fr["pred_masks"], fr["pred_bboxes"], _K_REAL, img_size=img_size, n_pts=256, rng=rs)
+        assert np.array_equal(_bits(out[i].cpu().numpy()), _bits(want))
+    with pytest.raises(_lib.TgpError):
+        lde.clouds_from_frames(frames, _K_REAL, img_size=512, device=DEV)
