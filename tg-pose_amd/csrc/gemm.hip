@@ -1417,7 +1417,9 @@ static int launch_split(GemmParams &p, hipStream_t stream)
     // development A/B (TGP_GATHER_512=1): epilogue-bound launches -- gathered residuals, short K -- on two workgroups per CU,
     // so that one workgroup's epilogue overlaps the other's K loop
     static const int gather512 = [] { const char *e = getenv("TGP_GATHER_512"); return e ? atoi(e) : 0; }();
-    const bool epi_bound = gather512 && (p.gres1 || p.gres2) && p.K <= 512;
+    // development A/B (TGP_ROUTE512=1): every launch WITHOUT gathered residuals on the two-workgroups-per-CU form
+    static const int route512 = [] { const char *e = getenv("TGP_ROUTE512"); return e ? atoi(e) : 0; }();
+    const bool epi_bound = (gather512 && (p.gres1 || p.gres2) && p.K <= 512) || (route512 && !(p.gres1 || p.gres2));
     if (p.split_f16 && (force512 || epi_bound || (narrow && !forbid512))) {
         // two 512-thread workgroups per CU, 256 x 128 tiles (+ 128 x 128 tail tiles)
         plan_tiles(p, GEMM_BIG, 2 * (int64_t)resident_slots(), 0.55, 2, 128, 128);
