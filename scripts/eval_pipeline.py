@@ -26,8 +26,8 @@ net.load_state_dict(seeded_state_dict(0), strict=True)
 net = net.to(dev).eval()
 FLAGS.train = 0
 records = [dict(frame=synth_depth_scene(7000 + i, per)) for i in range(n_frames)]
-for sampler in ("numpy", "device"):
-    ev = myEvaluater(net, frames_per_batch=32, max_batch=192, sampler=sampler, seed=1)
+for sampler, graph in (("numpy", False), ("device", False), ("device", True)):
+    ev = myEvaluater(net, frames_per_batch=32, max_batch=192, sampler=sampler, seed=1, graph=graph)
     np.random.seed(0)
     torch.manual_seed(0)
     ev.run(records[:32])                                     # warm-up: allocator, first launches
@@ -37,8 +37,9 @@ for sampler in ("numpy", "device"):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     objs = sum(len(r["pred_RTs"]) for r in res)
-    print(json.dumps({"metric": "evaluation driver end to end (host frames -> pred_results)", "sampler": sampler, "frames": len(res),
+    print(json.dumps({"metric": "evaluation driver end to end (host frames -> pred_results)", "sampler": sampler, "hipgraph": graph, "frames": len(res),
                       "objects": objs, "seconds": round(dt, 4), "frames_per_s": round(len(res) / dt, 1), "objects_per_s": round(objs / dt, 1),
                       "frames_per_batch": 32, "max_batch": 192,
-                      "note": "PCIe upload of depth + masks, cloud building, eager (not graph-replayed) forwards of up to 192 objects, "
-                              "pose assembly and the device-to-host copy of the results are all inside the timed region"}), flush=True)
+                      "note": "PCIe upload of depth + masks, cloud building, forwards of up to 192 objects, pose assembly and the "
+                              "device-to-host copy of the results are all inside the timed region; a chunk's results are fetched "
+                              "after the next chunk has been enqueued"}), flush=True)

@@ -18,7 +18,7 @@ import torch
 
 from ..evaluation import load_data_eval as lde
 from ..evaluation.metrics import compute_degree_cm_mAP
-from ..pose import batched_inference
+from ..pose import infer_device
 
 SYNSET_NAMES = ['BG', 'bottle', 'bowl', 'camera', 'can', 'laptop', 'mug']                                   # :115
 MEAN_SHAPE_MM = {1: (87, 220, 89), 2: (165, 80, 165), 3: (88, 128, 156), 4: (68, 146, 72), 5: (346, 200, 335), 6: (146, 83, 114)}
@@ -26,48 +26,97 @@ SYM_INFO = {1: (1, 1, 0, 1), 2: (1, 1, 0, 1), 3: (0, 0, 0, 0), 4: (1, 1, 1, 1), 
 
 
 class myEvaluater:
-    def __init__(self, net, frames_per_batch=32, max_batch=256, sampler="numpy", seed=0):
+    """``sampler='numpy'``: the reference's draws (one small read-back per chunk for the point counts).  ``sampler='device'``:
+    nothing is read back until a chunk's poses are; with ``overlap`` (default) chunk c's results are fetched after chunk c+1
+    has been enqueued, so packing / uploading the next frames runs beside the GPU's work on the current ones."""
+
+    def __init__(self, net, frames_per_batch=32, max_batch=256, sampler="numpy", seed=0, overlap=True, graph=False):
         self.net1 = net.eval()
         self.device = next(net.parameters()).device
-        self.frames_per_batch, self.max_batch, self.sampler, self.seed = frames_per_batch, max_batch, sampler, seed
+        self.frames_per_batch, self.max_batch, self.sampler, self.seed, self.overlap = frames_per_batch, max_batch, sampler, seed, overlap
+        self.graph = graph                                   # replay the forward as a captured hipGraph (PoseNet9D.graph_replay)
 
-    def _chunk(self, records, camK):
+    def _launch(self, records, camK):
+        """Enqueue everything for a chunk of frames; returns what _finish needs.  No synchronisation on the device-sampler path."""
         frames = [r["frame"] for r in records]
+        per = [fr["pred_masks"].shape[2] for fr in frames]
         if self.sampler == "numpy":
             clouds = lde.clouds_from_frames(frames, camK, device=self.device)
-            alive = [c is not None for c in clouds]
+            alive, ok = [c is not None for c in clouds], None
         else:
             clouds, ok = lde.clouds_from_frames(frames, camK, sampler="device", seed=self.seed, device=self.device)
-            alive = [bool(o.all()) for o in ok]             # one small read-back per chunk: a frame with an invalid detection is dropped
-        kept = [i for i, a in enumerate(alive) if a]
+            alive = [True] * len(frames)                     # decided in _finish from `ok`
+            # an invalid detection's rows are NaN: zero them for the forward (objects are independent in eval mode) and drop
+            # the frame afterwards, as the reference drops it (load_data_eval.py:332-337)
+        kept = [i for i, a in enumerate(alive) if a and per[i] > 0]
+        if not kept:
+            return records, alive, ok, kept, None, None
         ids = [np.asarray(frames[i]["pred_class_ids"]).astype(np.int64) for i in kept]
-        t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).to(self.device)
-        cat = [t(c - 1).reshape(-1, 1) for c in ids]                                                       # cat_id_0base (:368)
-        mean = [t([MEAN_SHAPE_MM[int(c)] for c in cs]).reshape(-1, 3) / 1000.0 for cs in ids]              # :362
-        sym = [t([SYM_INFO[int(c)] for c in cs]).reshape(-1, 4) for cs in ids]
+        t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).to(self.device, non_blocking=True)
+        flat = np.concatenate(ids)
+        cat = t(flat - 1).reshape(-1, 1)                                                                   # cat_id_0base (:368)
+        mean = t([MEAN_SHAPE_MM[int(c)] for c in flat]).reshape(-1, 3) / 1000.0                            # :362
+        sym = t([SYM_INFO[int(c)] for c in flat]).reshape(-1, 4)
+        pts = torch.cat([clouds[i] for i in kept])
+        if ok is not None:
+            pts = torch.nan_to_num(pts, nan=0.0)
         with torch.no_grad():
-            poses = batched_inference(self.net1, [clouds[i] for i in kept], cat, mean, sym, max_batch=self.max_batch)
+            rts, scales = infer_device(self.net1, pts, cat, mean, sym, self.max_batch)
+        return records, alive, ok, kept, rts, scales
+
+    def _finish(self, launched):
+        records, alive, ok, kept, rts, scales = launched
+        if ok is not None:
+            okc = [bool(o.all()) for o in ok]                # first read-back of the chunk (device sampler)
+            alive = [a and b for a, b in zip(alive, okc)]
         out = []
-        for i, p in zip(kept, poses):
-            det = {k: v for k, v in frames[i].items() if k not in ("pred_masks", "depth")}
-            det.update(p)
-            det.update(records[i].get("gts", {}))
+        if rts is not None:
+            rts, scales = rts.cpu().numpy(), scales.cpu().numpy()
+        pos = 0
+        empty = dict(pred_RTs=np.zeros((0, 4, 4)), pred_scales=np.zeros((0, 4, 4)))                       # RT_TDA_Evaluater.py:70-71
+        for i, rec in enumerate(records):
+            fr = rec["frame"]
+            n = fr["pred_masks"].shape[2]
+            pose = empty
+            if i in kept:
+                pose = dict(pred_RTs=rts[pos:pos + n], pred_scales=scales[pos:pos + n])
+                pos += n
+            if not alive[i]:
+                continue
+            det = {k: v for k, v in fr.items() if k not in ("pred_masks", "depth")}
+            det.update(pose)
+            det.update(rec.get("gts", {}))
             out.append(det)
         return out
 
     def run(self, dataset, camK=lde.REAL_INTRINSICS):
         """dataset: iterable of {'frame': {'depth','pred_masks','pred_bboxes','pred_class_ids','pred_scores'}, 'gts': {...}}
         (None entries are skipped, as the reference skips them :66-67) -> pred_results list."""
-        results, chunk = [], []
+        results, chunk, pending = [], [], None
+        was = getattr(self.net1, "graph_replay", False)
+        self.net1.graph_replay = bool(self.graph) or was
+
+        def flush():
+            nonlocal pending, chunk
+            launched = self._launch(chunk, camK)
+            chunk = []
+            if pending is not None:
+                results.extend(self._finish(pending))
+            pending = launched
+            if not self.overlap:
+                results.extend(self._finish(pending))
+                pending = None
         for rec in dataset:
             if rec is None:
                 continue
             chunk.append(rec)
             if len(chunk) == self.frames_per_batch:
-                results += self._chunk(chunk, camK)
-                chunk = []
+                flush()
         if chunk:
-            results += self._chunk(chunk, camK)
+            flush()
+        if pending is not None:
+            results.extend(self._finish(pending))
+        self.net1.graph_replay = was
         return results
 
 

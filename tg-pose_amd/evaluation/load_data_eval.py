@@ -93,11 +93,30 @@ def upload(frames, camK=REAL_INTRINSICS, device="cuda"):
     camK = np.asarray(camK, dtype=np.float32)
     camK = np.broadcast_to(camK, (len(frames), 3, 3)) if camK.ndim == 2 else camK
     camk = np.stack([camK[:, 0, 0], camK[:, 1, 1], camK[:, 0, 2], camK[:, 1, 2]], axis=1).astype(np.float32)
-    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
-    depth = up(np.stack([fr["depth"] for fr in frames]).view(np.int16))
-    masks = up(np.concatenate([np.ascontiguousarray(fr["pred_masks"]).view(np.uint8).reshape(-1) for fr in frames if fr["pred_masks"].size]))
-    return (depth, masks, up(np.asarray(off, dtype=np.int64)), up(np.asarray(stride, dtype=np.int32)),
-            up(np.asarray(det_img, dtype=np.int32)), up(np.asarray(win, dtype=np.int32).reshape(-1, 3)), up(camk))
+    # The copies go out on their own stream: a host-to-device copy from pageable memory holds the host until it has run, and on
+    # the compute stream it would queue behind the previous chunk's forward -- the host would pack chunk c+1 only after chunk c
+    # had finished.  The compute stream waits for the copies' event; record_stream keeps the allocator from recycling the
+    # buffers before the compute stream is done with them.
+    cur = torch.cuda.current_stream(dev)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _COPY_STREAMS:
+        _COPY_STREAMS[key] = torch.cuda.Stream(device=dev)
+    cs = _COPY_STREAMS[key]
+    host = [np.stack([fr["depth"] for fr in frames]).view(np.int16),
+            np.concatenate([np.ascontiguousarray(fr["pred_masks"]).view(np.uint8).reshape(-1) for fr in frames if fr["pred_masks"].size]),
+            np.asarray(off, dtype=np.int64), np.asarray(stride, dtype=np.int32), np.asarray(det_img, dtype=np.int32),
+            np.asarray(win, dtype=np.int32).reshape(-1, 3), camk]
+    with torch.cuda.stream(cs):
+        out = [torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True) for a in host]
+    done = torch.cuda.Event()
+    done.record(cs)
+    cur.wait_event(done)
+    for t in out:
+        t.record_stream(cur)
+    return tuple(out)
+
+
+_COPY_STREAMS = {}
 
 
 def build(frames, camK=REAL_INTRINSICS, img_size=256, device="cuda"):

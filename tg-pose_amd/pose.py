@@ -18,6 +18,18 @@ def generate_RT(R, f, T, mode="vec", sym=None):
     return ops.generate_rt(R[0], R[1], f[0], f[1], T, sym)
 
 
+def infer_device(net, pts, cat, ms, sym, max_batch=256):
+    """One or more forwards over (n,N,3) clouds already on the device -> (pred_RTs (n,4,4), pred_scales (n,3)) device tensors;
+    nothing synchronises (the caller decides when to copy back)."""
+    rts, scales = [], []
+    for lo in range(0, pts.shape[0], max_batch):
+        out = net(pts[lo:lo + max_batch], cat[lo:lo + max_batch])
+        rts.append(generate_RT([out["p_green_R"], out["p_red_R"]], [out["f_green_R"], out["f_red_R"]], out["Pred_T"],
+                               mode="vec", sym=sym[lo:lo + max_batch]))
+        scales.append(out["Pred_s"] + ms[lo:lo + max_batch])
+    return torch.cat(rts), torch.cat(scales)
+
+
 def batched_inference(net, clouds, cat_ids, mean_shapes, syms, max_batch=256):
     """clouds: list over images of (n_det_i, N, 3) tensors (same N); cat_ids / mean_shapes / syms likewise.
     Returns a list over images of dicts {'pred_RTs': (n_det_i,4,4) ndarray, 'pred_scales': (n_det_i,3) ndarray}."""
@@ -31,13 +43,8 @@ def batched_inference(net, clouds, cat_ids, mean_shapes, syms, max_batch=256):
     cat = torch.cat([cat_ids[i].reshape(-1, 1) for i in keep]).to(dev).float()
     ms = torch.cat([mean_shapes[i] for i in keep]).to(dev).float()
     sym = torch.cat([syms[i] for i in keep]).to(dev).float()
-    rts, scales = [], []
-    for lo in range(0, pts.shape[0], max_batch):
-        out = net(pts[lo:lo + max_batch], cat[lo:lo + max_batch])
-        rts.append(generate_RT([out["p_green_R"], out["p_red_R"]], [out["f_green_R"], out["f_red_R"]], out["Pred_T"],
-                               mode="vec", sym=sym[lo:lo + max_batch]))
-        scales.append(out["Pred_s"] + ms[lo:lo + max_batch])
-    rts, scales = torch.cat(rts).cpu().numpy(), torch.cat(scales).cpu().numpy()     # the only device-to-host copies
+    rts, scales = infer_device(net, pts, cat, ms, sym, max_batch)
+    rts, scales = rts.cpu().numpy(), scales.cpu().numpy()                           # the only device-to-host copies
     pos = 0
     for i in keep:
         results[i] = dict(pred_RTs=rts[pos:pos + counts[i]], pred_scales=scales[pos:pos + counts[i]])
