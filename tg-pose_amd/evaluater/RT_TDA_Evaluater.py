@@ -35,6 +35,7 @@ class myEvaluater:
         self.device = next(net.parameters()).device
         self.frames_per_batch, self.max_batch, self.sampler, self.seed, self.overlap = frames_per_batch, max_batch, sampler, seed, overlap
         self.graph = graph                                   # replay the forward as a captured hipGraph (PoseNet9D.graph_replay)
+        self._fetch = torch.cuda.Stream(device=self.device)  # results come back on their own stream (see _finish)
 
     def _launch(self, records, camK):
         """Enqueue everything for a chunk of frames; returns what _finish needs.  No synchronisation on the device-sampler path."""
@@ -50,7 +51,7 @@ class myEvaluater:
             # the frame afterwards, as the reference drops it (load_data_eval.py:332-337)
         kept = [i for i, a in enumerate(alive) if a and per[i] > 0]
         if not kept:
-            return records, alive, ok, kept, None, None
+            return records, alive, ok, kept, None, None, None
         ids = [np.asarray(frames[i]["pred_class_ids"]).astype(np.int64) for i in kept]
         t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float32)).to(self.device, non_blocking=True)
         flat = np.concatenate(ids)
@@ -62,16 +63,27 @@ class myEvaluater:
             pts = torch.nan_to_num(pts, nan=0.0)
         with torch.no_grad():
             rts, scales = infer_device(self.net1, pts, cat, mean, sym, self.max_batch)
-        return records, alive, ok, kept, rts, scales
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        return records, alive, ok, kept, rts, scales, done
 
     def _finish(self, launched):
-        records, alive, ok, kept, rts, scales = launched
-        if ok is not None:
-            okc = [bool(o.all()) for o in ok]                # first read-back of the chunk (device sampler)
-            alive = [a and b for a, b in zip(alive, okc)]
+        records, alive, ok, kept, rts, scales, done = launched
+        # The copies back are stream-ordered: on the compute stream they would queue behind the NEXT chunk's forward, which
+        # has already been enqueued, and the overlap would be lost.  They run on a fetch stream that waits only for this
+        # chunk's event.
+        with torch.cuda.stream(self._fetch):
+            if done is not None:
+                self._fetch.wait_event(done)
+            if ok is not None and len(ok):
+                flags = torch.stack([o.all() if o.numel() else torch.ones((), dtype=torch.bool, device=self.device) for o in ok])
+                flags.record_stream(self._fetch)
+                okc = flags.cpu().tolist()                   # first read-back of the chunk (device sampler)
+                alive = [a and bool(b) for a, b in zip(alive, okc)]
+            if rts is not None:
+                rts.record_stream(self._fetch), scales.record_stream(self._fetch)
+                rts, scales = rts.cpu().numpy(), scales.cpu().numpy()
         out = []
-        if rts is not None:
-            rts, scales = rts.cpu().numpy(), scales.cpu().numpy()
         pos = 0
         empty = dict(pred_RTs=np.zeros((0, 4, 4)), pred_scales=np.zeros((0, 4, 4)))                       # RT_TDA_Evaluater.py:70-71
         for i, rec in enumerate(records):
