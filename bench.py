@@ -234,10 +234,6 @@ def main():
     net = net.to(dev).eval()
     FLAGS.train = 0
     ops.GEMM_MODE = args.gemm
-    if os.environ.get("TGP_SPLIT_VARIANT"):       # development A/B of split-GEMM variants (csrc/gemm.hip)
-        import ctypes
-        from tgpose_amd import _lib
-        ctypes.CDLL(_lib.LIB_PATH).tgp_debug_set_split_variant(int(os.environ["TGP_SPLIT_VARIANT"]))
     from tgpose_amd import engine as _engine
     _engine.BRANCH_STREAMS = not args.no_branch_streams
     B = args.batch

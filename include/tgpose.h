@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 1
+#define TGP_ABI_VERSION 2
 #define TGP_EINVAL (-1)       /* null pointer / non-positive size / misaligned stride */
 #define TGP_EUNSUPPORTED (-2) /* shape outside what the kernels are built for */
 
@@ -164,6 +164,10 @@ typedef struct tgp_gemm_args {
      * gidx: int32 per output row, absolute row of gres; excludes res1 / res2; rows_per_obj >= 64 with rowbias / colmax. */
     const float *gres1; int ldg1; const int32_t *gidx1;
     const float *gres2; int ldg2; const int32_t *gidx2;
+    /* 0: the library picks the epilogue form (LDS-staged 16-byte form when every operand is 16-byte addressable).
+     * 1: the register-direct form (4-byte accesses; same arithmetic in the same order, bit-identical results; slower --
+     *    a per-call A/B handle for tests, not a tuning knob; not available with gathered residuals). */
+    int epilogue;
 } tgp_gemm_args;
 
 /* W (rows, K) fp32, row stride ld -> out[rows][ldo/16][3][16] bf16: per 16-wide K-tile the hi, mid and lo terms

@@ -3,7 +3,8 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tgpose_amd import _lib, ops
-lib = ctypes.CDLL(_lib.LIB_PATH)
+from _dev import use_dev_lib
+lib = use_dev_lib()
 dev = "cuda:0"
 B, Np, N1, N2 = 32, 1028, 257, 64
 M, N, K, LD = B * Np, 4096, 268, 272

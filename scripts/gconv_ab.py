@@ -3,7 +3,8 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tgpose_amd import _lib, ops
-lib = ctypes.CDLL(_lib.LIB_PATH)
+from _dev import use_dev_lib
+lib = use_dev_lib()
 dev = "cuda:0"
 def timeit(f, reps=5, rounds=7):
     ts = []

@@ -8,7 +8,8 @@ from tgpose_amd import PoseNet9D, seeded_state_dict, FLAGS, ops, engine
 if os.environ.get("TGP_SPLIT_VARIANT"):       # development A/B of split-GEMM variants (csrc/gemm.hip)
     import ctypes
     from tgpose_amd import _lib
-    ctypes.CDLL(_lib.LIB_PATH).tgp_debug_set_split_variant(int(os.environ["TGP_SPLIT_VARIANT"]))
+    from _dev import use_dev_lib
+    use_dev_lib().tgp_debug_set_split_variant(int(os.environ["TGP_SPLIT_VARIANT"]))
 dev = "cuda:0"
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 net = PoseNet9D()

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tgpose_amd import _lib
 
-lib = ctypes.CDLL(_lib.LIB_PATH)
+from _dev import use_dev_lib
+lib = use_dev_lib()
 fn = lib.tgp_debug_gemm_variant
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p]

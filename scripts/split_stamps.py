@@ -3,7 +3,8 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tgpose_amd import _lib, ops
-lib = ctypes.CDLL(_lib.LIB_PATH)
+from _dev import use_dev_lib
+lib = use_dev_lib()
 dev = "cuda:0"
 M, N, K, LD = 32896, 4096, 1292, 1292
 mode = sys.argv[1] if len(sys.argv) > 1 else "split16"

@@ -1368,15 +1368,9 @@ def test_gemm_epilogue_object_boundaries_and_tails(ops, M, N, K, rpo, gemm_mode)
     assert torch.equal(cm, torch.cat([out.cpu(), pad]).view(nobj, rpo, N).max(dim=1)[0])
 
 
-def _scalar_epilogue(on):
-    import ctypes
-    from tgpose_amd import _lib
-    ctypes.CDLL(_lib.LIB_PATH).tgp_debug_set_split_scalar_epilogue(int(on))
-
-
 @pytest.mark.parametrize("M,N,K,rpo", [(32896 // 8, 1024, 272, 1028), (1300, 640, 128, 100), (522, 384, 64, 64), (4112, 4096, 268, 1028)])
 def test_lds_epilogue_bit_identical_to_register_epilogue(ops, M, N, K, rpo):
-    """The LDS-staged 16-byte epilogue of the split kernels against the register-direct one (forced through the debug switch)
+    """The LDS-staged 16-byte epilogue of the split kernels against the register-direct one (tgp_gemm_args.epilogue = 1)
     with every feature on -- bias, per-object bias, both residuals, BN fold, per-column leaky slope, a column range for the
     store and a narrower one for the max over points: same bits in C and in the colmax keys."""
     gen = torch.Generator().manual_seed(M + N + K)
@@ -1387,16 +1381,12 @@ def test_lds_epilogue_bit_identical_to_register_epilogue(ops, M, N, K, rpo):
     rowbias, res1, res2 = g(torch.randn(nobj, N, generator=gen)), g(torch.randn(M, N, generator=gen)), g(torch.randn(M, N + 8, generator=gen))
     c0, cmc = 128, N // 2
     outs = []
-    for scalar in (True, False):
-        _scalar_epilogue(scalar)
-        try:
-            keys = torch.zeros(nobj, cmc, dtype=torch.int32, device=DEV)
-            C = torch.full((M, N - c0), 7.0, device=DEV)
-            ops.gemm(A, W, C, M=M, N=N, K=K, lda=K, ldw=K, ldc=N - c0, bias=bias, rowbias=rowbias, rows_per_obj=rpo, res1=res1, ldr1=N,
-                     res2=res2[:, 4:], ldr2=N + 8, scale=scale, shift=shift, act=1, slope_vec=slope, colmax_keys=keys, cm_cols=cmc,
-                     c_col0=c0, w_split=ops.split_w(W))
-        finally:
-            _scalar_epilogue(False)
+    for scalar in (1, 0):
+        keys = torch.zeros(nobj, cmc, dtype=torch.int32, device=DEV)
+        C = torch.full((M, N - c0), 7.0, device=DEV)
+        ops.gemm(A, W, C, M=M, N=N, K=K, lda=K, ldw=K, ldc=N - c0, bias=bias, rowbias=rowbias, rows_per_obj=rpo, res1=res1, ldr1=N,
+                 res2=res2[:, 4:], ldr2=N + 8, scale=scale, shift=shift, act=1, slope_vec=slope, colmax_keys=keys, cm_cols=cmc,
+                 c_col0=c0, w_split=ops.split_w(W), epilogue=scalar)
         outs.append((C.clone(), keys.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert outs[0][1].ne(0).any() and outs[0][0].ne(7.0).all()

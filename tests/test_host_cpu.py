@@ -121,7 +121,7 @@ def test_product_never_imports_the_oracle():
                 assert "/root/reference" not in text, f
 
 
-def _shard_worker(rank, world, port, q):
+def _shard_worker(rank, world, port, q, done):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -129,32 +129,42 @@ def _shard_worker(rank, world, port, q):
     lo, hi = shard.object_range(67, rank, world)
     t = shard.max_over_ranks(0.5 + rank, device="cpu")
     gathered = shard.gather_rows_to_rank0(torch.arange(lo, hi, dtype=torch.float32).view(-1, 1), 67, device="cpu")
-    q.put((rank, lo, hi, t, None if gathered is None else gathered.view(-1).tolist()))
+    q.put((rank, lo, hi, t, None if gathered is None else gathered.view(-1).tolist()))      # plain Python values only
+    done.wait(timeout=120)                                  # the parent has received every rank's result
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _run_two_ranks(worker, port):
+    """two spawned ranks; results travel as plain lists / floats (no tensor fd-passing, which races with the sender's exit) and
+    the workers stay alive until the parent has read both"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q, done = ctx.Queue(), ctx.Event()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q, done)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    finally:
+        done.set()
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
 
 
 def test_object_sharding_two_ranks_gloo():
     """Eval objects are independent: rank r takes a contiguous slice, no data-path collective;
     timing is the max over ranks; rank 0 can collect the small per-object outputs."""
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _run_two_ranks(_shard_worker, 29500 + os.getpid() % 2000)
     (r0, lo0, hi0, t0, g0), (r1, lo1, hi1, t1, g1) = res
     assert (lo0, hi0, lo1, hi1) == (0, 34, 34, 67)
     assert t0 == t1 == 1.5
     assert g0 == [float(i) for i in range(67)] and g1 is None
 
 
-def _grad_worker(rank, world, port, q):
+def _grad_worker(rank, world, port, q, done):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -165,31 +175,22 @@ def _grad_worker(rank, world, port, q):
         p.grad = torch.full_like(p, float(rank + 1)) * (i + 1) + torch.arange(p.numel(), dtype=torch.float32).view_as(p) * 1e-3
     params[1].grad = None                                  # an unused parameter is skipped, not sent
     n = shard.allreduce_gradients(params, bucket_bytes=8192)
-    q.put((rank, n, [None if p.grad is None else p.grad.clone() for p in params]))
+    q.put((rank, n, [None if p.grad is None else p.grad.reshape(-1).tolist() for p in params]))
+    done.wait(timeout=120)
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_gradient_allreduce_two_ranks_gloo():
     """Data-parallel training step: after the exchange every rank holds the mean of the ranks' gradients, bucketed."""
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    (_, n0, g0), (_, n1, g1) = res
+    (_, n0, g0), (_, n1, g1) = _run_two_ranks(_grad_worker, 31500 + os.getpid() % 2000)
     assert n0 == n1 and n0 >= 2                            # 8 KB buckets: several messages
     for i, (a, b) in enumerate(zip(g0, g1)):
         if i == 1:
             assert a is None and b is None
             continue
-        want = torch.full_like(a, 1.5) * (i + 1) + torch.arange(a.numel(), dtype=torch.float32).view_as(a) * 1e-3
+        a, b = torch.tensor(a), torch.tensor(b)
+        want = torch.full_like(a, 1.5) * (i + 1) + torch.arange(a.numel(), dtype=torch.float32) * 1e-3
         assert torch.allclose(a, want) and torch.equal(a, b)
 
 

@@ -38,6 +38,7 @@ class GemmArgs(ctypes.Structure):
         ("a_scale", c_vp), ("c_scale", c_vp), ("ksplit_chunk", c_int),
         ("gres1", c_vp), ("ldg1", c_int), ("gidx1", c_vp),
         ("gres2", c_vp), ("ldg2", c_int), ("gidx2", c_vp),
+        ("epilogue", c_int),
     ]
 
 
@@ -119,7 +120,7 @@ SIGNATURES = {
     "tgp_cloud_sample": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, ctypes.c_uint64, c_vp, c_vp]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 

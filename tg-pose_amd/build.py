@@ -13,8 +13,10 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["knn.hip", "gemm.hip", "gconv.hip", "chamfer.hip", "dcd.hip", "bn.hip", "backward.hip", "gconv_bwd.hip", "evalmetrics.hip", "tdaloss.hip", "inputside.hip", "rowsort.hip", "version.hip", "gemm_variants.hip"]
+SOURCES = ["knn.hip", "gemm.hip", "gconv.hip", "chamfer.hip", "dcd.hip", "bn.hip", "backward.hip", "gconv_bwd.hip", "evalmetrics.hip", "tdaloss.hip", "inputside.hip", "rowsort.hip", "version.hip"]
+DEV_SOURCES = ["gemm_variants.hip"]     # development build only (--dev): micro-benchmark kernels + the tgp_debug_* switches
 LIB = os.path.join(HERE, "libtgpose_hip.so")
+DEV_LIB = os.path.join(HERE, "libtgpose_hip_dev.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-variable", "-Wno-unused-function"]
@@ -24,21 +26,40 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(HERE), "include", "tgpose.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [os.path.join(os.path.dirname(HERE), "include", "tgpose.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, dev=False):
+    """dev=True: libtgpose_hip_dev.so with -DTGP_DEV (kernel-variant switches for scripts/*_ab.py; never loaded by the
+    package itself -- a script points tgpose_amd._lib.LIB_PATH at it before the first call)."""
+    if dev:
+        return _build(DEV_LIB, SOURCES + DEV_SOURCES, ["-DTGP_DEV"], ".dev.o", verbose)
     if not force and not _stale():
         return LIB
-    objs = []
-    for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+    return _build(LIB, SOURCES, [], ".o", verbose)
+
+
+def _build(LIB, sources, extra, suffix, verbose):
+    """compile the sources whose object is older than the source or a header (in parallel: hipcc is one process per file), link"""
+    from concurrent.futures import ThreadPoolExecutor
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(os.path.dirname(HERE), "include", "tgpose.h")]
+    newest_hdr = max(os.path.getmtime(h) for h in hdrs)
+    objs, todo = [], []
+    for src in sources:
+        obj = os.path.join(CSRC, src.replace(".hip", suffix))
+        objs.append(obj)
+        path = os.path.join(CSRC, src)
+        if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(path), newest_hdr):
+            todo.append([HIPCC] + FLAGS + extra + ["-c", path, "-o", obj])
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        objs.append(obj)
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(run, todo))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -47,4 +68,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, dev="--dev" in sys.argv)

@@ -233,8 +233,12 @@ static int gconv_lds_go(const float *xyz, const int32_t *idx, const float *proj,
     return TGP_LAUNCH_RESULT();
 }
 
-int tgp_gconv_lds_mode = 1;   // development switch (scripts): 0 = always the gather-from-L2 kernel
+#ifdef TGP_DEV   // development builds only (scripts/gconv_ab.py): 0 = always the gather-from-L2 kernel
+int tgp_gconv_lds_mode = 1;
 extern "C" void tgp_debug_set_gconv_lds(int v) { tgp_gconv_lds_mode = v; }
+#else
+static constexpr int tgp_gconv_lds_mode = 1;
+#endif
 
 static int gconv_lds_launch(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B, int n, int k,
                             int C, float *out, int ldo, hipStream_t stream, bool &done)
@@ -395,8 +399,12 @@ __global__ __launch_bounds__(1024) void orl_lds_kernel(const float *__restrict__
     }
 }
 
-int tgp_orl_lds_mode = 1;   // development switch: 0 = always the gather-from-L2 kernel
+#ifdef TGP_DEV   // development builds only: 0 = always the gather-from-L2 kernel
+int tgp_orl_lds_mode = 1;
 extern "C" void tgp_debug_set_orl_lds(int v) { tgp_orl_lds_mode = v; }
+#else
+static constexpr int tgp_orl_lds_mode = 1;
+#endif
 
 // returns true when the LDS form was launched
 static bool orl_lds_launch(const float *feat, int ldf, const int32_t *idx, int B, int n, int k, int C, float *partial, int ptiles,

@@ -67,6 +67,7 @@ struct GemmParams {
     const int32_t *gidx1, *gidx2;
     int ldg1, ldg2;
     int vec_epi;                 // every epilogue operand is 16-byte addressable: the split kernels use gemm_epilogue_lds
+    int scalar_epi;              // caller asked for the register-direct epilogue (tgp_gemm_args.epilogue == 1)
     int64_t plane;               // elements between planes
     // tile schedule of the main kernel: per batch, M-tile rows [0, mt_big) use 128x128 tiles, the rest 64x64
     int mt_big, tiles_n_big, tiles_big, tiles_m_small, tiles_n_small;
@@ -1359,12 +1360,23 @@ static double plan_tiles(GemmParams &p, int big, int64_t S, double tail_cost, in
     return best;
 }
 
-extern unsigned long long *tgp_split_stamps;
-// development switch (scripts/split_ab.py).  low 3 bits: -1/7 = production choice (fp16: two LDS stages + two K-tiles of
-// register prefetch; bf16: one K-tile, its registers allow no more), 0 single LDS stage, 1 / 2 double buffer with that
-// many K-tiles of prefetch, 4 = 2 + skewed waves (fp16 only); bit 3: staggered block order
+// Kernel-variant switches exist in development builds only (-DTGP_DEV: `python -m tgpose_amd.build --dev` writes
+// libtgpose_hip_dev.so for scripts/*_ab.py); the product library has no process-global mutable state -- the variant is a
+// compile-time constant there and the setters are not exported.
+// low 3 bits: -1/7 = production choice (fp16: two LDS stages + two K-tiles of register prefetch; bf16: one K-tile, its
+// registers allow no more), 0 single LDS stage, 1 / 2 double buffer with that many K-tiles of prefetch, 4 = 2 + skewed waves
+// (fp16 only); bit 3: staggered block order
+#ifdef TGP_DEV
 int tgp_split_variant = 7;
-static int tgp_split_scalar_epilogue = 0;   // development: force the register-direct epilogues (A/B, bit-identity tests)
+unsigned long long *tgp_split_stamps = nullptr;
+extern "C" void tgp_debug_set_split_variant(int v) { tgp_split_variant = v; }
+extern "C" void tgp_debug_set_split_stamps(unsigned long long *buf) { tgp_split_stamps = buf; }
+static int dev_env(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
+#else
+static constexpr int tgp_split_variant = 7;
+static constexpr unsigned long long *tgp_split_stamps = nullptr;
+static constexpr int dev_env(const char *) { return 0; }
+#endif
 
 // Block order of the split kernel.  Default: all big tiles, then the half-size tail tiles.  With many rounds of equal
 // tiles every CU reaches its epilogue at the same moment and the chip alternates between "all CUs compute, HBM idle"
@@ -1399,7 +1411,7 @@ static bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 static int launch_split(GemmParams &p, hipStream_t stream)
 {
     // LDS-staged vector epilogue: every operand it touches must be addressable in aligned 16-byte pieces
-    p.vec_epi = !tgp_split_scalar_epilogue && (p.N & 3) == 0 && (p.c_col0 & 3) == 0 && (p.cm_cols & 3) == 0 && (p.sV & 3) == 0 &&
+    p.vec_epi = !p.scalar_epi && (p.N & 3) == 0 && (p.c_col0 & 3) == 0 && (p.cm_cols & 3) == 0 && (p.sV & 3) == 0 &&
                 (p.sC & 3) == 0 && (!p.C || ((p.ldc & 3) == 0 && al16(p.C))) && al16(p.bias) && al16(p.scale) && al16(p.shift) &&
                 al16(p.slope_vec) && (!p.rowbias || ((p.ldrb & 3) == 0 && al16(p.rowbias))) &&
                 (!p.res1 || ((p.ldr1 & 3) == 0 && al16(p.res1))) && (!p.res2 || ((p.ldr2 & 3) == 0 && al16(p.res2))) &&
@@ -1416,9 +1428,9 @@ static int launch_split(GemmParams &p, hipStream_t stream)
     // the routing measured +-0: 8769 / 8730 vs 8782 / 8881 objects/s)
     // development A/B (TGP_GATHER_512=1): epilogue-bound launches -- gathered residuals, short K -- on two workgroups per CU,
     // so that one workgroup's epilogue overlaps the other's K loop
-    static const int gather512 = [] { const char *e = getenv("TGP_GATHER_512"); return e ? atoi(e) : 0; }();
+    static const int gather512 = dev_env("TGP_GATHER_512");
     // development A/B (TGP_ROUTE512=1): every launch WITHOUT gathered residuals on the two-workgroups-per-CU form
-    static const int route512 = [] { const char *e = getenv("TGP_ROUTE512"); return e ? atoi(e) : 0; }();
+    static const int route512 = dev_env("TGP_ROUTE512");
     const bool epi_bound = (gather512 && (p.gres1 || p.gres2) && p.K <= 512) || (route512 && !(p.gres1 || p.gres2));
     if (p.split_f16 && (force512 || epi_bound || (narrow && !forbid512))) {
         // two 512-thread workgroups per CU, 256 x 128 tiles (+ 128 x 128 tail tiles)
@@ -1470,11 +1482,6 @@ static int launch_split(GemmParams &p, hipStream_t stream)
 #undef LAUNCH_SPLIT
     return TGP_LAUNCH_RESULT();
 }
-
-unsigned long long *tgp_split_stamps = nullptr;
-extern "C" void tgp_debug_set_split_variant(int v) { tgp_split_variant = v; }
-extern "C" void tgp_debug_set_split_scalar_epilogue(int on) { tgp_split_scalar_epilogue = on; }
-extern "C" void tgp_debug_set_split_stamps(unsigned long long *buf) { tgp_split_stamps = buf; }
 
 static int launch_main(GemmParams &p, hipStream_t stream)
 {
@@ -1530,6 +1537,8 @@ extern "C" int tgp_gemm_f32(const tgp_gemm_args *a, tgp_stream_t stream)
                             (!a->gres2 || (a->gidx2 && a->ldg2 >= a->N)) &&
                             (!(a->rowbias || a->colmax_keys) || a->rows_per_obj >= 64) && (a->batch <= 1)));
     p.gres1 = a->gres1, p.ldg1 = a->ldg1, p.gidx1 = a->gidx1, p.gres2 = a->gres2, p.ldg2 = a->ldg2, p.gidx2 = a->gidx2;
+    TGP_REQUIRE(a->epilogue == 0 || (a->epilogue == 1 && !gather));
+    p.scalar_epi = a->epilogue;
     const bool plain = !a->rowbias && !a->res2 && !a->colmax_keys && !a->slope_vec && a->c_col0 == 0 &&
                        (p.batch == 1 || !a->res1);
     // a_scale / c_scale / ksplit_chunk are implemented by the fp16 split tile kernels only: refuse launches that route elsewhere

@@ -260,7 +260,7 @@ def _big_tile_threshold():
 def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, bias=None, rowbias=None,
          rows_per_obj=0, res1=None, ldr1=0, res2=None, ldr2=0, scale=None, shift=None, act=0, slope=0.0,
          colmax_keys=None, k_alg=None, slope_vec=None, cm_cols=0, c_col0=0, batch=1, batch_strides=None, w_split=None,
-         a_scale=None, c_scale=None, ksplit_chunk=0, gather1=None, gather2=None, flops_ref=None):
+         a_scale=None, c_scale=None, ksplit_chunk=0, gather1=None, gather2=None, flops_ref=None, epilogue=0):
     """Raw call into tgp_gemm_f32.  A/W/C/res* are tensors whose data_ptr is the first element of the
     operand (views into wider buffers are fine); all sizes/strides are explicit.  k_alg: the layer's
     true input width when K includes zero padding (only used for FLOP accounting in bench.py)."""
@@ -291,6 +291,7 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
         a.gres1, a.ldg1, a.gidx1 = _p(gather1[0]), int(gather1[1]), _p(gather1[2])
     if gather2 is not None:
         a.gres2, a.ldg2, a.gidx2 = _p(gather2[0]), int(gather2[1]), _p(gather2[2])
+    a.epilogue = int(epilogue)
     check(_lib.lib().tgp_gemm_f32(ctypes.byref(a), _stream(A)), "tgp_gemm_f32")
     if timed:
         e1.record(torch.cuda.current_stream(A.device))
