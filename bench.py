@@ -24,8 +24,12 @@ Extra objects in the line:
   cpu_baseline  the CPU oracle (the build's restatement of the reference's torch op sequence,
                 oracle/posenet_ref.py mode='torch') timed on this host's cores on a bounded sample.
 
-`--workload train_step` times the trainer's step instead (training-mode forward with autograd, the
-fourteen-term TDA loss, backward, gradient all-reduce, clip, SGD), replayed as one hipGraph.
+`--workload train_step` times the reference's trainer step instead (trainer/RL_TDA.py:110-226 as composed by
+tgpose_amd.trainer.RL_TDA: net1 with autograd, net2 under no_grad on the augmented cloud, the three consistency
+terms, the fourteen-term TDA loss, total, backward, gradient all-reduce, clip, SGD), forward + loss + backward
+replayed as one hipGraph.
+The timed region is exactly --steps steps between fences; it is repeated until --min-seconds have been
+measured and `value` is taken from the median region (`timed_regions` carries min / median / max).
 `--workload input_side` times the evaluation loader's input side: `--frames` synthetic depth frames with 6
 detections each, resident in HBM, -> (1024,3) clouds (tgp_roi_cloud + tgp_cloud_sample); detections/s, with an HBM roofline
 block for roi_cloud_kernel and the numpy port as cpu_baseline.
@@ -57,25 +61,26 @@ def synth_batch(B, N, seed):
 
 
 def cpu_baseline(sd):
-    """Oracle forward (reference op sequence on torch CPU) on a bounded sample of the same workload.
-    The GPU box exposes every host core but grants a 16-core share per GPU, so at most 16 threads are used."""
+    """SURVEY 8(d) protocol: the oracle forward (the reference's op sequence on torch CPU ops) at B=32, N=1028, eval mode, one
+    warm-up + three timed forwards (bounded to ~30 s: fewer timed forwards on a slow host).  The GPU box exposes every host core
+    but grants a 16-core share per GPU, so at most 16 threads are used."""
     from oracle import posenet_ref
     threads = max(1, min(os.cpu_count() or 1, 16))
     torch.set_num_threads(threads)
-    pts, obj = synth_batch(8, N_POINTS, 1)
+    pts, obj = synth_batch(B_PER_GPU, N_POINTS, 1)
     with torch.no_grad():
-        posenet_ref.posenet_forward(sd, pts[:1], obj[:1], mode="torch")           # warm-up (thread pool, allocator)
+        posenet_ref.posenet_forward(sd, pts[:2], obj[:2], mode="torch")           # thread pool, allocator
         t0 = time.perf_counter()
-        posenet_ref.posenet_forward(sd, pts[:2], obj[:2], mode="torch")
-        probe = time.perf_counter() - t0                                         # seconds for 2 objects
-        reps = int(max(1, min(4, 15.0 / max(4.0 * probe, 1e-3))))                # aim at ~15 s of CPU work
+        posenet_ref.posenet_forward(sd, pts, obj, mode="torch")                   # warm-up at full size
+        probe = time.perf_counter() - t0
+        reps = int(max(1, min(3, 30.0 / max(probe, 1e-3) - 1)))
         t0 = time.perf_counter()
         for _ in range(reps):
             posenet_ref.posenet_forward(sd, pts, obj, mode="torch")
         dt = time.perf_counter() - t0
     return {"value": round(reps * pts.shape[0] / dt, 3), "unit": "objects/s", "cores": threads, "kind": "port",
-            "sample": "%d eval forward(s) of B=%d, N=%d on torch %s CPU ops with %d threads (oracle mode='torch': the "
-                      "reference's op sequence, bit-identical to the imported reference in the build container), %.1f s"
+            "sample": "1 warm-up + %d timed eval forward(s) of B=%d, N=%d on torch %s CPU ops with %d threads (oracle mode='torch': the "
+                      "reference's op sequence, bit-identical to the imported reference in the build container), %.1f s timed"
                       % (reps, pts.shape[0], N_POINTS, torch.__version__, threads, dt)}
 
 
@@ -171,6 +176,48 @@ def bench_input_side(args, dev, rank, world, dist, share):
         dist.destroy_process_group()
 
 
+# algorithmic work per object at N = 1028
+GRAPH_CLASS_BYTES = 45.03e6       # graph / HBM class: unique inputs read once + outputs written once
+HBM_PEAK = 8.0e12                 # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+FP16_MFMA_PEAK = 2500.0e12        # dense fp16 / bf16 MFMA
+
+
+def _latest_profile(pattern, skip=("input_side",)):
+    import glob
+    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))) if not any(s in f for s in skip)]
+    return files[-1] if files else None
+
+
+def _tile_kernel_traffic(gemm_mode):
+    """(bytes per launch, source file) of the dominant tile kernels from the latest COMMITTED PMC passes (FETCH_SIZE / WRITE_SIZE
+    collected in separate rocprofv3 --pmc runs and corrected as MI355X_MICROARCH.md prescribes; scripts/pmc_traffic.py) -- not a
+    measurement of this run, and labelled so in the line."""
+    try:
+        path = _latest_profile("r*_pmc_traffic.json")
+        pmc = json.load(open(path))["kernels"]
+        if gemm_mode == "fp32":
+            keys = [k for k in pmc if "gemm_main256_kernel" in k]
+        else:
+            f16 = lambda k: ", true" in k.split("<", 1)[-1]
+            keys = [k for k in pmc if "gemm_split" in k and "_kernel" in k and f16(k) == (gemm_mode == "split16")]
+        n_l = sum(pmc[k]["launches"] for k in keys)
+        if not n_l:
+            return None, None
+        return int(sum(pmc[k]["launches"] * pmc[k]["bytes_per_launch_corrected"] for k in keys) / n_l), os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
+
+
+def train_batch(B, N, seed):
+    """the trainer's batch dict (datasets/load_data.py:313-349) on BASELINE config 3/4's workload: the six obj_model category
+    clouds with their pdh1 / pdh2 priors (data recorded in tests/golden/category_clouds.npz), posed, scaled and sampled to N"""
+    import numpy as np
+    from tests.util import synth_train_db
+    gc = np.load(os.path.join(ROOT, "tests", "golden", "category_clouds.npz"))
+    return synth_train_db(torch.from_numpy(gc["points_category"]), torch.from_numpy(gc["pdh1_category"]),
+                          torch.from_numpy(gc["pdh2_category"]), gc["sym"].astype(int).tolist(), [i % 6 for i in range(B)], N, seed)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,6 +225,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="objects per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="the timed region (exactly --steps steps between fences) is repeated until this much time has been measured; "
+                         "the line reports the median region and the spread")
     ap.add_argument("--streams", type=int, default=2,
                     help="batches in flight per GPU: step i runs on HIP stream i %% S over its own batch (independent batches "
                          "overlap each other's tail rounds and small kernels); 1 = one forward at a time")
@@ -191,10 +241,11 @@ def main():
                          "2 = two half batches on forked streams, measured slower)")
     ap.add_argument("--frames", type=int, default=32, help="input_side: frames per step (6 detections each)")
     ap.add_argument("--workload", choices=("forward", "train_step", "input_side"), default="forward",
-                    help="forward: the headline metric (eval-mode forward).  train_step: BASELINE config 3/4 -- training-mode "
-                         "forward with autograd, Chamfer (DCD) + pose regression loss, backward, gradient all-reduce over the "
-                         "ranks, clip, SGD step; objects/s of whole steps.  input_side: SURVEY 8 f-4 -- depth frames + "
-                         "detection masks resident in HBM -> (1024,3) clouds (tgp_roi_cloud + device resampling); detections/s")
+                    help="forward: the headline metric (eval-mode forward).  train_step: BASELINE config 4's step on one rank's "
+                         "share -- the reference's RL_TDA_train_step (net1 with gradients, net2 under no_grad on the augmented cloud, "
+                         "three consistency terms, fourteen TDA terms, total as trainer/RL_TDA.py:214), backward, gradient all-reduce "
+                         "over the ranks, clip, optimizer step; objects/s of whole steps.  input_side: SURVEY 8 f-4 -- depth frames "
+                         "+ detection masks resident in HBM -> (1024,3) clouds; detections/s")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -228,120 +279,77 @@ def main():
 
     import tgpose_amd
     from tgpose_amd import PoseNet9D, FLAGS, ops, seeded_state_dict
-    sd = seeded_state_dict(0)
-    net = PoseNet9D()
-    net.load_state_dict(sd, strict=True)
-    net = net.to(dev).eval()
-    FLAGS.train = 0
-    ops.GEMM_MODE = args.gemm
     from tgpose_amd import engine as _engine
+    sd = seeded_state_dict(0)
+    ops.GEMM_MODE = args.gemm
     _engine.BRANCH_STREAMS = not args.no_branch_streams
     B = args.batch
-    pts, obj = synth_batch(B, N_POINTS, 100 + rank)
-    pts, obj = pts.to(dev), obj.to(dev)
     torch.manual_seed(rank)
-
-    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else [None]
     step_no = [0]
+    replayers, one_in_flight, trainer = None, None, None
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if (args.streams > 1 and args.workload == "forward") else [None]
 
-    def step():
-        st = streams[step_no[0] % len(streams)]
-        step_no[0] += 1
-        if st is None:
-            return net(pts, obj)
-        with torch.cuda.stream(st):
-            return net(pts, obj)
-
-    replayers, one_in_flight = None, None
-    if args.graph == 1 and args.workload == "forward" and args.streams == 1:
-        net.graph_replay = True                 # PoseNet9D.forward captures once, then replays
-    elif args.graph == 1 and args.workload == "forward":
-        # S batches in flight: one captured forward (own static buffers, own activation pool) per HIP stream; step i replays
-        # graph i % S on stream i % S over its own batch, so one batch's tail rounds and small kernels overlap the other's
-        # GEMMs.  Every step is still one whole forward of B objects; a batch's latency is S steps.
-        batches = [tuple(t.to(dev) for t in synth_batch(B, N_POINTS, 100 + rank + 1000 * i)) for i in range(len(streams))]
-        replayers = [_engine.GraphedForward(net.packed(dev), B, N_POINTS, dev, train_keys=False) for _ in streams]
-        for st in streams:
-            st.wait_stream(torch.cuda.current_stream(dev))
+    if args.workload == "forward":
+        net = PoseNet9D()
+        net.load_state_dict(sd, strict=True)
+        net = net.to(dev).eval()
+        FLAGS.train = 0
+        pts, obj = synth_batch(B, N_POINTS, 100 + rank)
+        pts, obj = pts.to(dev), obj.to(dev)
 
         def step():
-            i = step_no[0] % len(streams)
+            st = streams[step_no[0] % len(streams)]
             step_no[0] += 1
-            with torch.cuda.stream(streams[i]):
-                return replayers[i](*batches[i])
-    elif args.graph == 2 and args.workload == "forward":
-        graphed = _engine.GraphedForward(net.packed(dev), B, N_POINTS, dev, train_keys=False, parts=2)
+            if st is None:
+                return net(pts, obj)
+            with torch.cuda.stream(st):
+                return net(pts, obj)
 
-        def step():
-            return graphed(pts, obj)
-
-    if args.workload == "train_step":
-        from tgpose_amd import shard
-        from tgpose_amd.losses.TDA_loss_sym_recon import TDA_loss
-        net.train()
-        FLAGS.train = 1
-        opt = torch.optim.SGD(net.parameters(), lr=1e-5, momentum=0.9)
-        gen = torch.Generator().manual_seed(7 + rank)
-        # the trainer's TDA step (trainer/RL_TDA.py:139-178): all fourteen terms of engine/organize_loss.py's 'TDA' list against
-        # synthetic targets -- random poses, the cloud's own centre as translation, persistence images, a category prior
-        q = torch.randn(B, 4, generator=gen)
-        q = q / q.norm(dim=1, keepdim=True)
-        qw, qx, qy, qz = q.unbind(1)
-        gt_R = torch.stack([1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw), 2 * (qx * qy + qz * qw),
-                            1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw), 2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw),
-                            1 - 2 * (qx * qx + qy * qy)], 1).view(B, 3, 3).to(dev)
-        pats = torch.tensor([[1, 1, 0, 1], [1, 1, 0, 1], [0, 0, 0, 0], [1, 1, 1, 1], [0, 1, 0, 0], [0, 1, 0, 0]])   # sym_info per category
-        gt_list = {"Rot1": gt_R[:, :, 1].contiguous(), "Rot2": gt_R[:, :, 0].contiguous(), "Recon": pts, "R": gt_R,
-                   "Tran": pts.mean(1), "Size": (0.1 + 0.2 * torch.rand(B, 3, generator=gen)).to(dev), "proto": None,
-                   "points_category": (torch.randn(B, 1024, 3, generator=gen) * 0.1).to(dev)}
-        for k in ("h1", "h2", "pdh1_category", "pdh2_category"):
-            gt_list[k] = torch.rand(B, 2500, generator=gen).to(dev)
-        sym = pats[obj.reshape(-1).long().cpu() % 6].to(dev)
-        names = ['Rot1', 'Rot2', 'Rot1_cos', 'Rot2_cos', 'Rot_regular', 'Tran', 'Size', 'R_con', 'TDA_h1', 'TDA_h2', 'TDA_h1_cate',
-                 'TDA_h2_cate', 'Prop_sym', 'R_DCD_cate_pred']
-        tda = TDA_loss()
-
-        def loss_fn(out):
-            pred = {'Rot1': out['p_green_R'], 'Rot1_f': out['f_green_R'], 'Rot2': out['p_red_R'], 'Rot2_f': out['f_red_R'],
-                    'Recon': out['recon'], 'Tran': out['Pred_T'], 'Size': out['Pred_s'], 'TDA_h1': out['h1'], 'TDA_h2': out['h2']}
-            return 0.9 * sum(v.sum() for v in tda(names, pred, gt_list, sym).values())               # trainer/RL_TDA.py:212-213
-
-        def finish():
-            shard.allreduce_gradients(net.parameters())
-            torch.nn.utils.clip_grad_norm_(net.parameters(), 5.0)         # trainer/RL_TDA.py:223
-            opt.step()
-
-        if args.graph:
-            # forward + loss + backward replayed as one hipGraph; the collective, the clip and the optimizer step stay eager
-            from tgpose_amd.autograd import GraphedBackward
-            graphed_bwd = GraphedBackward(net, pts, obj, loss_fn)
+        if args.graph == 1 and args.streams == 1:
+            net.graph_replay = True                 # PoseNet9D.forward captures once, then replays
+        elif args.graph == 1:
+            # S batches in flight: one captured forward (own static buffers, own activation pool) per HIP stream; step i replays
+            # graph i % S on stream i % S over its own batch, so one batch's tail rounds and small kernels overlap the other's
+            # GEMMs.  Every step is still one whole forward of B objects; a batch's latency is S steps.
+            batches = [tuple(t.to(dev) for t in synth_batch(B, N_POINTS, 100 + rank + 1000 * i)) for i in range(len(streams))]
+            replayers = [_engine.GraphedForward(net.packed(dev), B, N_POINTS, dev, train_keys=False) for _ in streams]
+            for st in streams:
+                st.wait_stream(torch.cuda.current_stream(dev))
 
             def step():
-                if os.environ.get("TGP_BENCH_TRACE"):          # development: where a step's wall time goes
-                    torch.cuda.synchronize(dev); t0 = time.perf_counter()
-                    loss = graphed_bwd()
-                    torch.cuda.synchronize(dev); t1 = time.perf_counter()
-                    shard.allreduce_gradients(net.parameters())
-                    torch.cuda.synchronize(dev); t2 = time.perf_counter()
-                    torch.nn.utils.clip_grad_norm_(net.parameters(), 5.0)
-                    opt.step()
-                    torch.cuda.synchronize(dev); t3 = time.perf_counter()
-                    print("rank %d: replay %.1f ms, all-reduce %.1f ms, clip + SGD %.1f ms" % (rank, 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2)),
-                          file=sys.stderr, flush=True)
-                    return loss
-                loss = graphed_bwd()
-                finish()
+                i = step_no[0] % len(streams)
+                step_no[0] += 1
+                with torch.cuda.stream(streams[i]):
+                    return replayers[i](*batches[i])
+        elif args.graph == 2:
+            graphed = _engine.GraphedForward(net.packed(dev), B, N_POINTS, dev, train_keys=False, parts=2)
+
+            def step():
+                return graphed(pts, obj)
+    else:
+        # the reference's trainer step (trainer/RL_TDA.py:110-226) composed by tgpose_amd.trainer.RL_TDA on the category-cloud
+        # workload; dropout active as in the trainer (net.train()); SGD stands in for Ranger (optimizer zoo: out of scope)
+        from tgpose_amd.trainer.RL_TDA import RT_TDA_Trainer
+        trainer = RT_TDA_Trainer(device=dev)
+        trainer.init_network('RL_TDA')
+        trainer.init_loss()
+        trainer.net1.load_state_dict(sd, strict=True)
+        trainer.net2.load_state_dict(seeded_state_dict(1, only_encoder=True), strict=True)
+        trainer.net1.train(), trainer.net2.train()
+        trainer.optimizer = torch.optim.SGD(trainer.net1.parameters(), lr=1e-5, momentum=0.9)
+        net = trainer.net1
+        db = {k: v.to(dev) for k, v in train_batch(B, N_POINTS, 7 + rank).items()}
+        if args.graph:
+            # both forwards + losses + backward replayed as one hipGraph; the collective, the clip and the optimizer step stay eager
+            graphed_step = trainer.graphed_step(db)
+
+            def step():
+                loss = graphed_step()
+                trainer.finish_step()
                 return loss
         else:
             def step():
-                opt.zero_grad(set_to_none=True)
-                loss = loss_fn(net(pts, obj))
-                loss.backward()
-                finish()
-                return loss
-
-    for _ in range(max(args.warmup, len(streams))):
-        step()
+                return trainer.train_iteration(db)[0]
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -349,79 +357,72 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    fence()
-    ops.GEMM_TIMER = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    timer, ops.GEMM_TIMER = ops.GEMM_TIMER, None
-    roof_note = "HIP events around every tile-kernel launch of the timed region"
-    roof_elapsed = elapsed
-    if replayers is not None:
-        # the kernels of overlapping replays cannot be bracketed one by one: time them in serial eager launches of the same
-        # forward right after the timed region (same process, same weights)
-        def step():
-            return net(pts, obj)
-        k_roof = min(args.steps, 10)
-        step()
+    def timed_region():
+        """exactly --steps steps between fences; max over ranks"""
         fence()
-        ops.GEMM_TIMER = []
-        t1 = time.perf_counter()
-        for _ in range(k_roof):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
             step()
         fence()
-        roof_elapsed = time.perf_counter() - t1
-        timer, ops.GEMM_TIMER = ops.GEMM_TIMER, None
-        roof_note = ("HIP events around every tile-kernel launch of %d serial eager steps run after the timed region "
-                     "(%d graph replays in flight there)" % (k_roof, len(streams)))
-        # for reference: the same replayed forward with ONE batch in flight (what a latency-bound caller sees)
-        fence()
-        t2 = time.perf_counter()
-        with torch.cuda.stream(streams[0]):
-            for _ in range(args.steps):
-                replayers[0](*batches[0])
-        fence()
-        one_in_flight = world * B * args.steps / (time.perf_counter() - t2)
-    elif getattr(net, "graph_replay", False):
-        # a replayed graph has no launch to bracket with events: the same kernels are timed in an eager pass of the same
-        # steps right after the timed region (same process, same inputs); the rocprof summary covers both
-        net.graph_replay = False
-        k_roof = min(args.steps, 10)
-        step()
-        fence()
-        ops.GEMM_TIMER = []
-        t1 = time.perf_counter()
-        for _ in range(k_roof):
-            step()
-        fence()
-        roof_elapsed = time.perf_counter() - t1
-        timer, ops.GEMM_TIMER = ops.GEMM_TIMER, None
-        net.graph_replay = True
-        roof_note = "HIP events around every tile-kernel launch of %d eager steps run after the timed graph-replay region" % k_roof
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device="cpu" if share else dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
 
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    for _ in range(max(args.warmup, len(streams))):
+        step()
+    ops.GEMM_TIMER = [] if replayers is None and not getattr(net, "graph_replay", False) and not (trainer and args.graph) else None
+    regions = [timed_region()]
+    timer, ops.GEMM_TIMER = ops.GEMM_TIMER, None
+    # the same region again until --min-seconds have been measured (every rank takes the same decision: the times are reduced)
+    while sum(regions) < args.min_seconds and len(regions) < 200:
+        regions.append(timed_region())
+    regions_sorted = sorted(regions)
+    elapsed = regions_sorted[len(regions) // 2] if len(regions) % 2 else 0.5 * (regions_sorted[len(regions) // 2 - 1] + regions_sorted[len(regions) // 2])
+
+    # ---- roofline block: per-kernel durations need serial launches (graph replays have no launch to bracket, overlapping
+    # streams stretch each other's kernels): the same steps once more as serial eager launches on one stream, HIP events
+    # around every tile-kernel launch and every launch of the graph / HBM class
+    roof_note = "HIP events around every tile-kernel launch of the timed region (eager launches)"
+    graph_cls, roof_elapsed, k_roof = None, regions[0], args.steps
+    if timer is None:
+        branch, _engine.BRANCH_STREAMS = _engine.BRANCH_STREAMS, False
+        replay_flag = getattr(net, "graph_replay", False)
+        net.graph_replay = False
+        if trainer is not None:
+            def roof_step():
+                return trainer.train_iteration(db)[0]
+        else:
+            def roof_step():
+                return net(pts, obj)
+        k_roof = min(args.steps, 10)
+        roof_step()
+        fence()
+        ops.GEMM_TIMER, ops.CLASS_TIMER = [], {}
+        t1 = time.perf_counter()
+        for _ in range(k_roof):
+            roof_step()
+        fence()
+        roof_elapsed = time.perf_counter() - t1
+        timer, ops.GEMM_TIMER = ops.GEMM_TIMER, None
+        graph_cls, ops.CLASS_TIMER = ops.CLASS_TIMER.get("graph", []), None
+        _engine.BRANCH_STREAMS, net.graph_replay = branch, replay_flag
+        roof_note = ("HIP events around every tile-kernel launch of %d serial eager steps (one stream, no side branches) run after the "
+                     "timed region%s" % (k_roof, "" if replayers is None else " (%d graph replays in flight there)" % len(streams)))
+        if replayers is not None:
+            # for reference: the same replayed forward with ONE batch in flight (what a latency-bound caller sees)
+            fence()
+            t2 = time.perf_counter()
+            with torch.cuda.stream(streams[0]):
+                for _ in range(args.steps):
+                    replayers[0](*batches[0])
+            fence()
+            one_in_flight = world * B * args.steps / (time.perf_counter() - t2)
 
     if rank == 0:
-        traffic = None
-        try:   # HBM/fabric bytes per launch of the dominant kernel from the latest committed PMC passes (not a live measurement)
-            import glob
-            files = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))) if "input_side" not in f]
-            pmc = json.load(open(files[-1]))["kernels"]
-            if args.gemm == "fp32":
-                keys = [k for k in pmc if "gemm_main256_kernel" in k]
-            else:   # gemm_split_kernel<prefetch depth, fp16?, interleaved?>; older files: <dbuf> (bf16) / <dbuf, fp16>
-                f16 = lambda k: ", true" in k.split("<", 1)[-1]
-                keys = [k for k in pmc if "gemm_split" in k and "_kernel" in k and f16(k) == (args.gemm == "split16")]
-            # launch-weighted mean over the tile kernels the timed launches are routed to (square-tile and 512-thread forms)
-            n_l = sum(pmc[k]["launches"] for k in keys)
-            traffic = int(sum(pmc[k]["launches"] * pmc[k]["bytes_per_launch_corrected"] for k in keys) / n_l) if n_l else None
-        except Exception:
-            traffic = None
+        traffic, traffic_src = _tile_kernel_traffic(args.gemm)
         launches = len(timer)
         ksec = sum(e0.elapsed_time(e1) for e0, e1, *_ in timer) * 1e-3
         kflop = sum(f for _, _, f, *_ in timer)
@@ -441,28 +442,38 @@ def main():
             kernel_name = "gemm_main256_kernel / gemm_main_kernel"
             peak = PEAK_F32_MFMA_TFLOPS
             peak_basis = "fp32 MFMA (v_mfma_f32_32x32x2_f32) dense peak"
+        per_step = [1e3 * r / args.steps for r in regions]
+        fwd = args.workload == "forward"
         line = {
-            "metric": ("objects/sec forward (B=%d, N=%d pts)" % (B, N_POINTS) if args.workload == "forward"
-                       else "objects/sec training step (forward + loss + backward + optimizer, B=%d, N=%d pts)" % (B, N_POINTS)),
+            "metric": ("objects/sec forward (B=%d, N=%d pts)" % (B, N_POINTS) if fwd
+                       else "objects/sec training step (forward x2 + loss + backward + optimizer, B=%d, N=%d pts)" % (B, N_POINTS)),
             "value": round(world * B * args.steps / elapsed, 2),
             "unit": "objects/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "timed_regions": {"count": len(regions), "steps_each": args.steps, "value_from": "median region",
+                              "ms_per_step_min": round(min(per_step), 4), "ms_per_step_median": round(1e3 * elapsed / args.steps, 4),
+                              "ms_per_step_max": round(max(per_step), 4), "total_s": round(sum(regions), 3)},
             "gemm_mode": {"split": "fp32-accurate 3xbf16 operand split on the bf16 matrix cores, fp32 accumulate",
                           "split16": "fp32-accurate 2xfp16 operand split on the fp16 matrix cores, fp32 accumulate",
                           "fp32": "fp32 MFMA"}[args.gemm],
             "config": {"workload": ("PoseNet9D.forward eval mode, full forward (kNN graphs + 3D-GCN encoder + PH predictor "
                                     "+ decoder + R/t/s heads), B=%d objects per GPU, N=%d points, seeded random weights "
-                                    "of the reference architecture (27.43 M params)" % (B, N_POINTS)) if args.workload == "forward"
-                       else ("training step: PoseNet9D training-mode forward with autograd, the trainer's fourteen-term TDA loss, "
-                             "backward, gradient all-reduce, clip, SGD; B=%d objects per GPU, N=%d points" % (B, N_POINTS)),
+                                    "of the reference architecture (27.43 M params)" % (B, N_POINTS)) if fwd
+                       else ("the reference's RL_TDA_train_step (trainer/RL_TDA.py:110-226): net1 = PoseNet9D training-mode forward "
+                             "with autograd, net2 = PoseNet9D(only_encoder) under no_grad on the augmented cloud, feat_consistency + 2x "
+                             "prop_sym_matching, the 14 control_loss('TDA') terms, total = 0.1 (con + recon_1 + recon_cons) + 0.9 sum(TDA), "
+                             "backward, gradient all-reduce, clip_grad_norm_(5), SGD step; B=%d objects per GPU, N=%d points sampled "
+                             "from the six obj_model category clouds with their pdh1/pdh2 priors" % (B, N_POINTS)),
                        "objects_per_gpu": B, "points": N_POINTS, "replicas": world, "batches_in_flight": len(streams),
                        "hipgraph": {0: "off", 1: "whole batch" if replayers is None else "whole batch, one captured forward per stream",
                                     2: "two half batches on forked streams"}[args.graph]},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "traffic_source": (traffic_src + " (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same "
+                                                          "launches; not measured by this run)") if traffic_src else None,
                          "kernel": kernel_name, "peak_basis": peak_basis,
                          "launches_timed": launches, "avg_launch_us": round(1e6 * ksec / max(launches, 1), 2),
                          "share_of_step": round(ksec / roof_elapsed, 4), "measured": roof_note},
@@ -474,6 +485,24 @@ def main():
             line["roofline"]["flops_counted"] = "executed (factored formulation)"
             line["roofline"]["executed_over_reference_formulation_flops"] = round(kflop / kflop_ref, 4)
             line["roofline"]["rate_in_reference_formulation_flops"] = round(kflop_ref / ksec / 1e12, 2)
+        if fwd and graph_cls:
+            # second class: the graph / HBM-bound kernels (45.03 MB of unique traffic per object) and the bound of the
+            # whole path as it now executes: executed dense FLOPs at the split kernels' roof + the graph class at HBM speed
+            gsec = sum(e0.elapsed_time(e1) for e0, e1, _ in graph_cls) * 1e-3 / k_roof            # per forward
+            ach = GRAPH_CLASS_BYTES * B / gsec
+            line["roofline_graph_class"] = {
+                "bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4),
+                "algorithmic_bytes_per_object": GRAPH_CLASS_BYTES, "ms_per_forward": round(1e3 * gsec, 4), "launches_per_forward": len(graph_cls) // k_roof,
+                "kernels": "kNN (xyz + feature space incl. the distance GEMM), graph convolution, ORL pooling, pooling, gathers, "
+                           "row sort, tails, per-object post-processing; serial launches as for `roofline`"}
+            flop_fwd = kflop / k_roof
+            mfma_roof = {"split16": FP16_MFMA_PEAK / 3.0, "split": FP16_MFMA_PEAK / 6.0, "fp32": PEAK_F32_MFMA_TFLOPS * 1e12}[args.gemm]
+            bound_s = flop_fwd / mfma_roof + GRAPH_CLASS_BYTES * B / HBM_PEAK
+            line["roofline_path"] = {
+                "bound_ms_per_step": round(1e3 * bound_s, 4), "measured_ms_per_step": round(1e3 * elapsed / args.steps, 4),
+                "frac": round(bound_s / (elapsed / args.steps), 4),
+                "basis": "executed tile-kernel FLOPs per forward (%.1f GFLOP) / MFMA roof of the GEMM mode + %.0f MB x %d objects / 8 TB/s"
+                         % (flop_fwd / 1e9, GRAPH_CLASS_BYTES / 1e6, B)}
         if one_in_flight is not None:
             line["config"]["objects_per_s_one_batch_in_flight"] = round(one_in_flight, 1)     # this rank's clock, not max-over-ranks
         if world == 1 and not args.no_cpu_baseline:

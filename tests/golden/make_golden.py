@@ -419,6 +419,159 @@ def gen_pose_assembly():
     save("pose_assembly.npz", p_g=p_g, p_r=p_r, f_g=f_g, f_r=f_r, T=T, sym=sym, R_plain=R_plain, R_sym=R_sym)
 
 
+# ----------------------------------------------------------------------------- the trainer's step
+CATS = ["bottle", "bowl", "camera", "can", "laptop", "mug"]
+SYM_INFO = [[1, 1, 0, 1], [1, 1, 0, 1], [0, 0, 0, 0], [1, 1, 1, 1], [0, 1, 0, 0], [0, 1, 0, 0]]   # datasets/load_data.py:521-566 get_sym_info
+
+
+def category_tables():
+    """the six obj_model clouds and their persistence-image priors as the loader reads them (datasets/load_data.py:303-311, 327-329)"""
+    pts = torch.stack([torch.from_numpy(np.load(os.path.join(REF, "obj_model/points_%s.npy" % c)).astype(np.float32)) for c in CATS])
+    h1 = torch.stack([torch.from_numpy(np.load(os.path.join(REF, "obj_model/pdh1_%s.npy" % c)).astype(np.float32)) for c in CATS])
+    h2 = torch.stack([torch.from_numpy(np.load(os.path.join(REF, "obj_model/pdh2_%s.npy" % c)).astype(np.float32)) for c in CATS])
+    return pts, h1, h2
+
+
+def load_reference_trainer():
+    """Import trainer/RL_TDA.py unmodified.  Beyond load_reference_loss()'s two stand-ins it needs `tools.training_utils`, which the
+    reference ships as py3.8 bytecode only: get_gt_v is restated from its disassembly (bmm(R, [[0,0,1],[0,1,0],[0,0,0]])
+    -> green = R[:, :, 1], red = R[:, :, 0]); build_optimizer / build_lr_rate are not reached by RL_TDA_train_step."""
+    import types
+    load_reference_loss()
+    tu = types.ModuleType("tools.training_utils")
+
+    def get_gt_v(Rs, axis=2):
+        bs = Rs.shape[0]
+        corners = torch.tensor([[0, 0, 1], [0, 1, 0], [0, 0, 0]], dtype=Rs.dtype).to(Rs.device).view(1, 3, 3).repeat(bs, 1, 1)
+        v = torch.bmm(Rs, corners).transpose(2, 1).reshape(bs, -1)
+        return v[:, 3:6], v[:, 6:9]
+
+    tu.get_gt_v = get_gt_v
+    tu.build_lr_rate = tu.build_optimizer = None
+    sys.modules["tools.training_utils"] = tu
+    import trainer.RL_TDA as ref_tr
+    return ref_tr
+
+
+def synth_train_batch(cat_ids, N, seed):
+    """A batch in the train loader's format (datasets/load_data.py:313-349): clouds = posed, scaled, noisy samples of the
+    categories' obj_model clouds; aug_pcl_in = the same object under the loader's kind of perturbation (jitter + a small rigid
+    motion); pdh1 / pdh2 = the category priors with noise."""
+    from tests.util import synth_train_db
+    pts, h1, h2 = category_tables()
+    return synth_train_db(pts, h1, h2, SYM_INFO, cat_ids, N, seed)
+
+
+def gen_train_step(name="train_step_b4_n256.npz", cat_ids=(0, 2, 3, 4), N=256, wseed=4, dseed=8, fseed=35):
+    """The reference's own RL_TDA_train_step (trainer/RL_TDA.py:110-200) + the loop body's total loss and backward (:205-222) on a
+    seeded batch: net1 = PoseNet9D(), net2 = PoseNet9D(only_encoder=True) under no_grad on the augmented cloud, the three
+    consistency terms, the fourteen control_loss('TDA') terms.  Dropout p = 0 (host-generator masks cannot be reproduced on the
+    device).  Recorded: every loss term, the total, per net1 parameter the gradient's norm / sum / 16 samples, the BatchNorm
+    buffers of both nets after the step, both nets' neighbour graphs and subsamples."""
+    ref_tr = load_reference_trainer()
+    FLAGS.train = 1
+    FLAGS.fsnet_loss_type = "l1"
+    tr = ref_tr.RT_TDA_Trainer(logger=None)
+    tr.device = torch.device("cpu")
+    tr.init_network("RL_TDA")
+    tr.init_loss()
+    assert tr.name_TDA_list == ['Rot1', 'Rot2', 'Rot1_cos', 'Rot2_cos', 'Rot_regular', 'Tran', 'Size', 'R_con', 'TDA_h1', 'TDA_h2',
+                                'TDA_h1_cate', 'TDA_h2_cate', 'Prop_sym', 'R_DCD_cate_pred']
+    tr.net1.load_state_dict(iw.seeded_state_dict(wseed), strict=True)
+    tr.net2.load_state_dict(iw.seeded_state_dict(wseed + 1, only_encoder=True), strict=True)
+    for net in (tr.net1, tr.net2):
+        net.train()
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+    db = synth_train_batch(list(cat_ids), N, dseed)
+    knn_rec, nn_rec = [], []
+    o_knn, o_nn = ref_gcn.get_neighbor_index, ref_gcn.get_nearest_index
+    ref_gcn.get_neighbor_index = lambda v, k: (knn_rec.append(o_knn(v, k)), knn_rec[-1])[1]
+    ref_gcn.get_nearest_index = lambda t, s_: (nn_rec.append(o_nn(t, s_)), nn_rec[-1])[1]
+    try:
+        torch.manual_seed(fseed)
+        _, loss_dict = tr.RL_TDA_train_step(db)
+    finally:
+        ref_gcn.get_neighbor_index, ref_gcn.get_nearest_index = o_knn, o_nn
+    tda = loss_dict['TDA_loss']
+    total = 0.1 * loss_dict['RL_loss'] + 0.1 * loss_dict['recon_1_loss'] + 0.1 * loss_dict['recon_consistency_loss'] + 0.9 * sum(tda.values())
+    total.backward()                                                                    # trainer/RL_TDA.py:214,222
+    names = ["conv_0.rf", "conv_0.orl_xyz", "conv_1.rf", "conv_1.orl_xyz", "pool_1.xyz", "conv_2.rf",
+             "conv_2.orl_xyz", "conv_3.rf", "conv_3.orl_xyz", "pool_2.xyz", "conv_4.rf", "conv_4.orl_xyz"]
+    assert len(knn_rec) == 2 * len(names) and len(nn_rec) == 4
+    torch.manual_seed(fseed)
+    draws = [torch.randperm(N)[: N // 4], None, None, None]
+    draws[1] = torch.randperm(N // 4)[: N // 16]
+    draws[2] = torch.randperm(N)[: N // 4]
+    draws[3] = torch.randperm(N // 4)[: N // 16]
+    arrays = dict(weight_seed=np.int64(wseed), data_seed=np.int64(dseed), forward_seed=np.int64(fseed), cat_ids=np.array(cat_ids),
+                  n_points=np.int64(N), total=total.detach().reshape(1))
+    for k, v in db.items():
+        arrays["db." + k] = v
+    for i, d in enumerate(draws):
+        arrays["sample.%d" % i] = small_idx(d)
+    for j, pre in enumerate(("face_all.encoder.", "face_enc.encoder.")):
+        for n_, r in zip(names, knn_rec[j * len(names):(j + 1) * len(names)]):
+            arrays["idx." + pre + n_] = small_idx(r)
+        arrays["idx." + pre + "up_1"], arrays["idx." + pre + "up_2"] = small_idx(nn_rec[2 * j]), small_idx(nn_rec[2 * j + 1])
+    for k in ("RL_loss", "recon_1_loss", "recon_consistency_loss"):
+        arrays["loss." + k] = loss_dict[k].detach().reshape(1)
+    for k, v in tda.items():
+        arrays["loss.TDA." + k] = v.detach().reshape(1)
+    for k, p_ in tr.net1.named_parameters():
+        if p_.grad is None:
+            continue
+        gflat = p_.grad.reshape(-1)
+        pick = torch.linspace(0, gflat.numel() - 1, 16).long()
+        arrays["grad." + k] = torch.cat([gflat.norm().view(1), gflat.double().sum().float().view(1), gflat[pick]])
+    assert all(p_.grad is None for p_ in tr.net2.parameters())
+    for tag, net in (("net1", tr.net1), ("net2", tr.net2)):
+        for k, v in net.state_dict().items():
+            if "running_" in k or "num_batches" in k:
+                arrays["bn.%s.%s" % (tag, k)] = v
+    save(name, **arrays)
+
+
+def gen_category_clouds():
+    """BASELINE config 3's workload as data: the six obj_model clouds (float64 on disk -> float32 as the loader casts them,
+    datasets/load_data.py:329) with their pdh1 / pdh2 priors, and -- on a B = 6 batch of them under seeded random rotations --
+    the reference's TRAINING-mode forward (dropout p = 0) and its R_DCD loss against the category clouds."""
+    ref_loss = load_reference_loss()
+    pts, h1, h2 = category_tables()
+    from tests.util import rand_rotations
+    B, wseed, fseed = 6, 5, 37
+    R = rand_rotations(B, 51)
+    g = torch.Generator().manual_seed(52)
+    t = torch.randn(B, 3, generator=g) * 0.1 + torch.tensor([0.0, 0.0, 1.0])
+    s = torch.rand(B, 3, generator=g) * 0.1 + 0.25
+    clouds = torch.matmul(pts * s.unsqueeze(1), R.transpose(1, 2)) + t.unsqueeze(1)       # (6, 1024, 3) camera frame
+    obj = torch.arange(6).float().view(6, 1)
+    net = RefPoseNet9D().train()
+    net.load_state_dict(iw.seeded_state_dict(wseed), strict=True)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    out, idx = run_reference(net, clouds, obj, fseed, train=1)
+    i1, i2 = sample_indices(1024, fseed)
+    sym = torch.tensor(SYM_INFO, dtype=torch.float32)
+    mod = ref_loss.TDA_loss()
+    with torch.no_grad():
+        r_dcd = mod.R_DCD(pts, out["recon"], R, out["p_green_R"], out["f_green_R"], out["p_red_R"], out["f_red_R"], out["Pred_T"],
+                          out["Pred_s"], sym)
+    arrays = dict(weight_seed=np.int64(wseed), forward_seed=np.int64(fseed), points_category=pts, pdh1_category=h1, pdh2_category=h2,
+                  sym=sym, gt_R=R, gt_t=t, gt_s=s, points=clouds, obj_id=obj, sample_idx_1=small_idx(i1), sample_idx_2=small_idx(i2),
+                  r_dcd=r_dcd.reshape(1))
+    for k, v in out.items():
+        if k == "feat":
+            arrays["train.feat_rowsum"] = v.double().sum(dim=2).float()
+        else:
+            arrays["train." + k] = v
+    for k, v in idx.items():
+        arrays["idx." + k] = small_idx(v)
+    save("category_clouds.npz", **arrays)
+
+
 # ----------------------------------------------------------------------------- evaluation metrics (mAP)
 from tests.util import synth_eval_results  # noqa: E402  (pure numpy; shared with the GPU tests)
 
@@ -535,6 +688,11 @@ def gen_input_side():
 def main():
     if sys.argv[1:] == ["input_side"]:
         return gen_input_side()
+    if sys.argv[1:] == ["train_step"]:
+        gen_train_step()
+        return gen_category_clouds()
+    gen_train_step()
+    gen_category_clouds()
     gen_tda_loss()
     gen_eval_map()
     gen_pose_assembly()

@@ -1202,6 +1202,110 @@ def test_surface_layer_backward_vs_oracle_autograd(ops):
         assert err <= 1e-4 * ref + 1e-6, (k_, err, ref)
 
 
+def test_encoder_from_seam_operators_trains_like_the_reference(ops, monkeypatch):
+    """Operator seam #2 under autograd: an encoder written the way the reference's Face_Enc is (FaceRecon.py:20-26,57-73)
+    from ONLY the gcn3d seam names -- HSlayer_surface, HS_layer, Pool_layer, get_nearest_index, indexing_neighbor_new -- plus
+    torch's own BatchNorm1d / relu / cat, in .train(), forward + backward.  Outputs are graph-attached like the reference's;
+    values and every parameter gradient are compared with torch autograd over the CPU oracle's restatement of the same
+    operators walking the same neighbour graphs (the lists the HIP kNN kernels produced are recorded in call order and handed
+    to the oracle).  Tolerances as in the per-layer tests: 1e-4 of each gradient's largest entry per layer without
+    BatchNorm; with three BatchNorm + ReLU stages in between, 2e-3."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from tgpose_amd import seeded_state_dict
+    from tgpose_amd.network.fs_net_repo import gcn3d
+    _, G, _ = _oracle()
+    rec = {"knn": [], "nn1": []}
+    for fn, key in (("knn_xyz", "knn"), ("knn_feat", "knn"), ("nn1", "nn1")):
+        orig = getattr(ops, fn)
+        monkeypatch.setattr(ops, fn, (lambda o, k_: lambda *a, **kw: (rec[k_].append(o(*a, **kw)), rec[k_][-1])[1])(orig, key))
+
+    class Enc(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv_0 = gcn3d.HSlayer_surface(kernel_num=128, support_num=7)
+            self.conv_1 = gcn3d.HS_layer(128, 128, support_num=7)
+            self.pool_1 = gcn3d.Pool_layer(pooling_rate=4, neighbor_num=4)
+            self.conv_2 = gcn3d.HS_layer(128, 256, support_num=7)
+            self.conv_3 = gcn3d.HS_layer(256, 256, support_num=7)
+            self.pool_2 = gcn3d.Pool_layer(pooling_rate=4, neighbor_num=4)
+            self.conv_4 = gcn3d.HS_layer(256, 512, support_num=7)
+            self.bn1, self.bn2, self.bn3 = nn.BatchNorm1d(128), nn.BatchNorm1d(256), nn.BatchNorm1d(256)
+
+        def forward(self, vertices, k=20):
+            bn = lambda m, x: F.relu(m(x.transpose(1, 2)).transpose(1, 2))
+            fm_0 = F.relu(self.conv_0(vertices, k))
+            fm_1 = bn(self.bn1, self.conv_1(vertices, fm_0, k))
+            v1, fp1 = self.pool_1(vertices, fm_1)
+            k1 = min(k, v1.shape[1] // 8)
+            fm_2 = bn(self.bn2, self.conv_2(v1, fp1, k1))
+            fm_3 = bn(self.bn3, self.conv_3(v1, fm_2, k1))
+            v2, fp2 = self.pool_2(v1, fm_3)
+            fm_4 = self.conv_4(v2, fp2, min(k, v2.shape[1] // 8))
+            n1, n2 = gcn3d.get_nearest_index(vertices, v1), gcn3d.get_nearest_index(vertices, v2)
+            up = lambda f, n_: gcn3d.indexing_neighbor_new(f, n_).squeeze(2)
+            return torch.cat([fm_0, fm_1, up(fm_2, n1), up(fm_3, n1), up(fm_4, n2)], dim=2)
+
+    B, N = 3, 512
+    sd = seeded_state_dict(12)
+    pre = "face_all.encoder."
+    enc = Enc()
+    enc.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre) and "proj_layer" not in k})
+    enc = enc.to(DEV).train()
+    pts, _ = synth_points(B, N, 12)
+    xyz = pts - pts.mean(dim=1, keepdim=True)
+    wgt = torch.randn(B, N, 1280, generator=torch.Generator().manual_seed(1)) * 0.1
+    torch.manual_seed(99)
+    out = enc(g(xyz))
+    assert out.requires_grad and out.grad_fn is not None and out.shape == (B, N, 1280)
+    (out * g(wgt)).sum().backward()
+    # the same composition on the CPU oracle, with the recorded graphs
+    names = ["conv_0.rf", "conv_1.rf", "conv_1.orl_xyz", "pool_1.xyz", "conv_2.rf", "conv_2.orl_xyz", "conv_3.rf", "conv_3.orl_xyz",
+             "pool_2.xyz", "conv_4.rf", "conv_4.orl_xyz"]
+    assert len(rec["knn"]) == len(names) and len(rec["nn1"]) == 2
+    inject = {n_: t.cpu().long() for n_, t in zip(names, rec["knn"])}
+    inject["conv_0.orl_xyz"] = inject["conv_0.rf"]
+    cache = G.GraphCache(mode="exact", inject=inject)
+    P = {k[len(pre):]: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()
+         if k.startswith(pre) and "proj_layer" not in k}
+    P["_support_num"] = 7
+    bnr = lambda i, x: F.relu(F.batch_norm(x.transpose(1, 2), None, None, P["bn%d.weight" % i], P["bn%d.bias" % i], True, 0.1, 1e-5).transpose(1, 2))
+    torch.manual_seed(99)
+    s1 = G.draw_sample_idx(N)
+    s2 = G.draw_sample_idx(s1.numel())
+    f0 = F.relu(G.surface_conv(P, "conv_0", xyz, 20, cache))
+    f1 = bnr(1, G.hs_conv(P, "conv_1", xyz, f0, 20, cache))
+    v1, fp1 = G.pool(xyz, f1, s1, cache, "pool_1")
+    f2 = bnr(2, G.hs_conv(P, "conv_2", v1, fp1, 16, cache))
+    f3 = bnr(3, G.hs_conv(P, "conv_3", v1, f2, 16, cache))
+    v2, fp2 = G.pool(v1, f3, s2, cache, "pool_2")
+    f4 = G.hs_conv(P, "conv_4", v2, fp2, 4, cache)
+    n1, n2 = rec["nn1"][0].cpu().long().unsqueeze(-1), rec["nn1"][1].cpu().long().unsqueeze(-1)
+    assert torch.equal(n1, G.nearest_index(xyz, v1)) and torch.equal(n2, G.nearest_index(xyz, v2))
+    want = torch.cat([f0, f1, G.gather_rows(f2, n1).squeeze(2), G.gather_rows(f3, n1).squeeze(2), G.gather_rows(f4, n2).squeeze(2)], 2)
+    err = (out.detach().cpu() - want.detach()).abs().max().item()
+    assert err <= 1e-4 * max(1.0, want.abs().max().item()), err
+    (want * wgt).sum().backward()
+    got = dict(enc.named_parameters())
+    worst = 0.0
+    for k, v in P.items():
+        if k == "_support_num" or not v.requires_grad:
+            continue
+        a, r = got[k].grad.cpu(), v.grad
+        rel = (a - r).norm().item() / max(r.norm().item(), 1e-12)
+        worst = max(worst, rel)
+        assert rel <= 2e-3, (k, rel)
+    # and under no_grad the same modules run the fused kernels and return plain tensors
+    torch.manual_seed(99)
+    rm = {k: v.clone() for k, v in enc.state_dict().items() if "running" in k or "num_batches" in k}
+    with torch.no_grad():
+        enc.load_state_dict(rm, strict=False)
+        plain = enc(g(xyz))
+    assert not plain.requires_grad and plain.grad_fn is None
+    d = (plain - out.detach()).abs()          # xyz graphs are identical; feature-space graphs may swap near-tied neighbours
+    assert d[:, :, :128].max().item() <= 1e-4 and d.mean().item() <= 1e-3
+
+
 def test_pool_and_upsample_backward_vs_autograd(ops):
     """Pool_layer's neighbour max at the sampled points and the nearest-neighbour upsampling (FaceRecon.py:66-72)."""
     from tgpose_amd import autograd as AG
@@ -1338,6 +1442,39 @@ def test_graphed_backward_equals_eager(ops):
                     continue
                 ref = p.grad.abs().max().item()
                 assert (grads_g[k] - p.grad).abs().max().item() <= 1e-5 * ref + 1e-7, k
+    finally:
+        FLAGS.train = 0
+
+
+def test_graphed_backward_refuses_a_live_eager_graph(ops):
+    """The documented misuse -- capturing the training step while the loss of an earlier EAGER step over the same parameters is
+    still referenced -- must raise before anything is captured (it used to end in a crash inside hipStreamEndCapture); once
+    the stale loss is dropped the same constructor works and replays reproducibly."""
+    from tgpose_amd import FLAGS
+    from tgpose_amd.autograd import GraphedBackward
+    net = _train_net(6)
+    B, N = 3, 512
+    pts, obj = synth_points(B, N, 6)
+    loss_fn = lambda out: (out["recon"] ** 2).mean() + out["Pred_T"].abs().mean() + out["h2"].mean()
+    FLAGS.train = 1
+    try:
+        stale = loss_fn(net(g(pts), g(obj)))                  # eager step on the default stream; `stale` keeps its graph alive
+        stale.backward()
+        with pytest.raises(RuntimeError, match="earlier eager step"):
+            GraphedBackward(net, g(pts), g(obj), loss_fn)
+        assert not torch.cuda.is_current_stream_capturing()
+        del stale
+        gb = GraphedBackward(net, g(pts), g(obj), loss_fn)
+        torch.manual_seed(3)
+        i1 = torch.randperm(N)[: N // 4]
+        sample = (i1, torch.randperm(i1.numel())[: i1.numel() // 4])
+        runs = []
+        for _ in range(2):
+            loss = gb(sample_idx=sample).item()
+            runs.append((loss, {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+        assert runs[0][0] == runs[1][0] and not gb.loss.requires_grad
+        for k, v in runs[0][1].items():                       # the float-atomic scatters may reorder sums between replays
+            assert (v - runs[1][1][k]).abs().max().item() <= 1e-5 * v.abs().max().item() + 1e-7, k
     finally:
         FLAGS.train = 0
 
@@ -1910,3 +2047,242 @@ def test_input_side_other_roi_sizes_vs_oracle(ops, img_size):
         assert np.array_equal(_bits(out[i].cpu().numpy()), _bits(want))
     with pytest.raises(_lib.TgpError):
         lde.clouds_from_frames(frames, _K_REAL, img_size=512, device=DEV)
+
+
+# ------------------------------------------------------------------------- the trainer's step (BASELINE config 4, one rank)
+def _trainer(wseed):
+    from tgpose_amd import seeded_state_dict
+    from tgpose_amd.trainer.RL_TDA import RT_TDA_Trainer
+    tr = RT_TDA_Trainer(device=DEV)
+    tr.init_network('RL_TDA')
+    tr.init_loss()
+    tr.net1.load_state_dict(seeded_state_dict(wseed), strict=True)
+    tr.net2.load_state_dict(seeded_state_dict(wseed + 1, only_encoder=True), strict=True)
+    for net in (tr.net1, tr.net2):
+        net.train()
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+    return tr
+
+
+def _check_step_grads(named_params, want, tol=GRAD_TOL):
+    """want: {name: full gradient tensor} or {name: summary (norm, sum, 16 samples)}; relative L2 per parameter"""
+    from tests.test_oracle_golden import grad_summary
+    worst = {}
+    for k, w in want.items():
+        got = named_params[k].grad
+        assert got is not None, k
+        if w.numel() == 18 and got.numel() != 18:
+            gs, ws = grad_summary(got.cpu()).numpy(), np.asarray(w)
+            scale = max(abs(ws[0]), GRAD_ATOL)
+            assert abs(gs[0] - ws[0]) <= tol * scale, (k, gs[0], ws[0])
+            assert np.abs(gs[2:] - ws[2:]).max() <= tol * scale, (k, gs[2:6], ws[2:6])
+        else:
+            worst[k] = (got.cpu() - w).norm().item() / (w.norm().item() + GRAD_ATOL)
+    bad = {k: v for k, v in worst.items() if v > tol}
+    assert not bad, bad
+    return worst
+
+
+def test_train_step_vs_reference_trainer(ops):
+    """RT_TDA_Trainer.RL_TDA_train_step + total loss + backward on the HIP path against the REFERENCE's own step (fixture
+    tests/golden/train_step_b4_n256.npz: trainer/RL_TDA.py imported unmodified, net1 + net2 under no_grad + three consistency
+    terms + fourteen TDA terms, total as :214), teacher-forced on the reference's graphs and subsamples.  Loss terms 2e-4
+    relative (fp32 forwards agree to 1e-4), gradients 3 % relative L2 (see test_backward_full_network_vs_oracle_autograd),
+    BatchNorm buffers of both nets 1e-5."""
+    from tgpose_amd import FLAGS
+    from tgpose_amd.trainer.RL_TDA import total_loss
+    from tests.test_oracle_golden import golden_train_step_case
+    gd, db, samples, inj = golden_train_step_case()
+    tr = _trainer(int(gd["weight_seed"]))
+    try:
+        out, ld = tr.RL_TDA_train_step(db, sample_idx=samples, inject={k: v.int() for k, v in inj.items()})
+        total = total_loss(ld)
+        total.backward()
+    finally:
+        FLAGS.train = 0
+    assert set(out) >= {"enc_feat_1", "enc_feat_2", "PC", "recon", "h1", "h2", "Pred_T"}
+    for k in ("RL_loss", "recon_1_loss", "recon_consistency_loss"):
+        assert np.allclose(ld[k].detach().cpu().numpy().reshape(-1), gd["loss." + k], rtol=2e-4, atol=2e-6), (k, ld[k], gd["loss." + k])
+    names = [k[9:] for k in gd.files if k.startswith("loss.TDA.")]
+    assert sorted(names) == sorted(ld["TDA_loss"]) and len(names) == 14
+    for k in names:
+        assert np.allclose(ld["TDA_loss"][k].detach().cpu().numpy().reshape(-1), gd["loss.TDA." + k], rtol=2e-4, atol=2e-6), (k, ld["TDA_loss"][k])
+    assert abs(total.item() - float(gd["total"])) <= 2e-4 * abs(float(gd["total"]))
+    _check_step_grads(dict(tr.net1.named_parameters()), {k[5:]: torch.from_numpy(gd[k]) for k in gd.files if k.startswith("grad.")})
+    assert all(p.grad is None for p in tr.net2.parameters())
+    for tag, net in (("net1", tr.net1), ("net2", tr.net2)):
+        sd = net.state_dict()
+        for k in gd.files:
+            if k.startswith("bn.%s." % tag):
+                assert np.allclose(sd[k[8:]].cpu().numpy(), gd[k], rtol=1e-5, atol=1e-6), k
+
+
+def _step_db(cat_ids, N, seed, golden_name="category_clouds.npz"):
+    from tests.util import synth_train_db
+    gc = golden(golden_name)
+    sym = gc["sym"].astype(np.int64).tolist()
+    return synth_train_db(torch.from_numpy(gc["points_category"]), torch.from_numpy(gc["pdh1_category"]),
+                          torch.from_numpy(gc["pdh2_category"]), sym, cat_ids, N, seed)
+
+
+def test_train_step_vs_oracle_full_cloud_size(ops):
+    """The same step at N = 1028 (the benchmark's cloud size), B = 8 with every category, against the CPU oracle's composition
+    (oracle/train_step_ref.py, itself pinned to the reference's trainer by tests/test_oracle_golden.py) on the oracle's graphs."""
+    from oracle import train_step_ref as TS
+    from tgpose_amd import FLAGS, seeded_state_dict
+    from tgpose_amd.trainer.RL_TDA import total_loss
+    from tests.test_oracle_golden import leaves
+    B, N, wseed = 8, 1028, 9
+    db = _step_db([0, 1, 2, 3, 4, 5, 3, 0], N, 19)
+    torch.manual_seed(5)
+    samples = []
+    for _ in range(2):
+        i1 = torch.randperm(N)[: N // 4]
+        samples.append((i1, torch.randperm(i1.numel())[: i1.numel() // 4]))
+    P1 = leaves(seeded_state_dict(wseed))
+    ld_ref, r1, r2, graphs = TS.train_step(P1, seeded_state_dict(wseed + 1, only_encoder=True), db, samples)
+    ld_ref["total"].backward()
+    tr = _trainer(wseed)
+    try:
+        _, ld = tr.RL_TDA_train_step(db, sample_idx=samples, inject={k: v.int() for k, v in graphs.items()})
+        total = total_loss(ld)
+        total.backward()
+    finally:
+        FLAGS.train = 0
+    for k in ("RL_loss", "recon_1_loss", "recon_consistency_loss"):
+        assert abs(ld[k].item() - ld_ref[k].item()) <= 2e-4 * max(abs(ld_ref[k].item()), 1e-2), (k, ld[k].item(), ld_ref[k].item())
+    for k, v in ld_ref["TDA_loss"].items():
+        assert abs(ld["TDA_loss"][k].sum().item() - v.item()) <= 2e-4 * max(abs(v.item()), 1e-2), (k, ld["TDA_loss"][k], v)
+    assert abs(total.item() - ld_ref["total"].item()) <= 2e-4 * abs(ld_ref["total"].item())
+    want = {k: v.grad for k, v in P1.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None}
+    worst = _check_step_grads(dict(tr.net1.named_parameters()), want)
+    for k in sorted(worst, key=worst.get, reverse=True)[:5]:
+        print("|dg|_2 / |g|_2  %-50s %.2e" % (k, worst[k]))
+
+
+def test_train_step_one_rank_of_config_4(ops):
+    """BASELINE config 4, one rank: B = 128 objects of N = 1028 points through the whole trainer step.  The CPU oracle needs
+    ~80 GB and minutes at this size, so the check is by properties that do not depend on size:
+      * the captured step (trainer.graphed_step: both forwards + losses + backward as one hipGraph) reproduces the eager step
+        -- same total to 1e-6, same gradients up to the float-atomic scatters;
+      * the step is invariant under a permutation of the objects of the batch (BatchNorm statistics, the means over objects in
+        every loss term and the gradient sums are symmetric in the objects): total to 1e-3 relative, gradient norms to 3 %
+        (a permutation reorders fp32 sums, and a last-bit change of a BatchNorm statistic can swap near-tied feature-space
+        neighbours);
+      * net2 receives no gradient and every net1 parameter but the unused proj_layer a finite one."""
+    from tgpose_amd import FLAGS
+    from tgpose_amd.trainer.RL_TDA import total_loss
+    B, N = 128, 1028
+    cats = [i % 6 for i in range(B)]
+    db = {k: g(v) for k, v in _step_db(cats, N, 23).items()}
+    torch.manual_seed(7)
+    samples = []
+    for _ in range(2):
+        i1 = torch.randperm(N)[: N // 4]
+        samples.append((i1, torch.randperm(i1.numel())[: i1.numel() // 4]))
+    tr = _trainer(10)
+    bn0 = [{k: v.clone() for k, v in net.state_dict().items() if "running" in k or "num_batches" in k} for net in (tr.net1, tr.net2)]
+
+    def reset():
+        for net, b in zip((tr.net1, tr.net2), bn0):
+            net.load_state_dict(b, strict=False)
+        for p in tr.net1.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+
+    def eager(batch):
+        reset()
+        _, ld = tr.RL_TDA_train_step(batch, sample_idx=samples)
+        t = total_loss(ld)
+        t.backward()
+        grads = {k: p.grad.clone() for k, p in tr.net1.named_parameters() if p.grad is not None}
+        return t.item(), grads
+
+    try:
+        t0, g0 = eager(db)
+        assert math.isfinite(t0) and all(torch.isfinite(v).all() for v in g0.values())
+        assert all(p.grad is None for p in tr.net2.parameters())
+        assert {k for k, p in tr.net1.named_parameters() if p.grad is None} == {k for k, _ in tr.net1.named_parameters() if "proj_layer" in k}
+        perm = torch.arange(B - 1, -1, -1, device=DEV)
+        t1, g1 = eager({k: v[perm].contiguous() for k, v in db.items()})
+        assert abs(t1 - t0) <= 1e-3 * abs(t0), (t0, t1)
+        for k in g0:
+            n0, n1 = g0[k].norm().item(), g1[k].norm().item()
+            assert abs(n0 - n1) <= GRAD_TOL * (n0 + GRAD_ATOL), (k, n0, n1)
+        reset()
+        step = tr.graphed_step(db)
+        reset()
+        t2 = step(sample_idx=samples).item()
+        assert abs(t2 - t0) <= 1e-6 * abs(t0), (t0, t2)
+        for k, p in tr.net1.named_parameters():
+            if p.grad is not None and k in g0:
+                assert (p.grad - g0[k]).abs().max().item() <= 1e-5 * g0[k].abs().max().item() + 1e-7, k
+    finally:
+        FLAGS.train = 0
+
+
+# ------------------------------------------------------------------------- BASELINE config 3: the six category clouds
+def test_config3_category_clouds_vs_reference(ops):
+    """BASELINE config 3 on its real workload: the six obj_model category clouds (fixture data recorded by make_golden.py from
+    /root/reference/obj_model, float32 as the loader casts them) under seeded rotations.  B = 6: training-mode forward (dropout
+    p = 0) on the reference's graphs against the reference's outputs at 1e-4, then TDA_loss.R_DCD of the reconstruction against
+    the category clouds against the reference's value.  B = 256 (the config's batch: the six clouds tiled under 256 rotations):
+    size-independent properties -- the batched R_DCD equals the mean of its per-chunk evaluations, Chamfer's two directions swap
+    under an exchange of the clouds, the eval-mode forward of an object does not depend on its batch, and the training-mode
+    forward + R_DCD + backward is finite and repeatable."""
+    from tgpose_amd import FLAGS
+    from tgpose_amd.losses import dcd as D
+    from tgpose_amd.losses.TDA_loss_sym_recon import TDA_loss
+    from tests.util import rand_rotations
+    gc = golden("category_clouds.npz")
+    t = lambda k: g(gc[k])
+    net = _train_net(int(gc["weight_seed"]))
+    sample = (torch.from_numpy(gc["sample_idx_1"].astype(np.int64)), torch.from_numpy(gc["sample_idx_2"].astype(np.int64)))
+    inj = {k[4:]: torch.from_numpy(gc[k].astype(np.int32)) for k in gc.files if k.startswith("idx.")}
+    mod = TDA_loss()
+    FLAGS.train = 1
+    try:
+        with torch.no_grad():
+            out = net(t("points"), t("obj_id"), sample_idx=sample, inject=inj)
+        for k in ("recon", "p_green_R", "p_red_R", "f_green_R", "f_red_R", "Pred_T", "Pred_s", "h1", "h2", "feat_global"):
+            err = (out[k].cpu().numpy() - gc["train." + k])
+            assert np.abs(err).max() <= 1e-4, (k, np.abs(err).max())
+        assert np.abs(out["feat"].double().sum(dim=2).float().cpu().numpy() - gc["train.feat_rowsum"]).max() <= 2e-3
+        r = mod.R_DCD(t("points_category"), out["recon"], t("gt_R"), out["p_green_R"], out["f_green_R"], out["p_red_R"], out["f_red_R"],
+                      out["Pred_T"], out["Pred_s"], t("sym"))
+        assert abs(r.item() - float(gc["r_dcd"])) <= 1e-4 * abs(float(gc["r_dcd"])), (r.item(), float(gc["r_dcd"]))
+        # ---- B = 256
+        B = 256
+        cid = torch.arange(B) % 6
+        R = rand_rotations(B, 61)
+        gen = torch.Generator().manual_seed(62)
+        tt = torch.randn(B, 3, generator=gen) * 0.1 + torch.tensor([0.0, 0.0, 1.0])
+        ss = torch.rand(B, 3, generator=gen) * 0.1 + 0.25
+        prior = torch.from_numpy(gc["points_category"])[cid]
+        clouds = g(torch.matmul(prior * ss.unsqueeze(1), R.transpose(1, 2)) + tt.unsqueeze(1))
+        obj, sym, prior, Rg = g(cid.float().view(B, 1)), g(torch.from_numpy(gc["sym"])[cid]), g(prior), g(R)
+        net.train()
+        torch.manual_seed(3)
+        out = net(clouds, obj, sample_idx=sample)                   # with gradients: the trainer's net1 path
+        args = lambda o, sl=slice(None): (prior[sl], o["recon"][sl], Rg[sl], o["p_green_R"][sl], o["f_green_R"][sl], o["p_red_R"][sl],
+                                          o["f_red_R"][sl], o["Pred_T"][sl], o["Pred_s"][sl], sym[sl])
+        loss = mod.R_DCD(*args(out))
+        loss.backward()
+        assert math.isfinite(loss.item()) and all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+        det = {k: v.detach() for k, v in out.items()}
+        chunks = [mod.R_DCD(*args(det, slice(i, min(i + 6, B)))).item() * (min(i + 6, B) - i) for i in range(0, B, 6)]
+        assert abs(sum(chunks) / B - loss.item()) <= 2e-6 * max(1.0, abs(loss.item()))
+        d1, d2, i1, i2 = D.calc_dcd(det["recon"], prior, alpha=70, n_lambda=0.3, return_raw=True)[1:]
+        e1, e2, j1, j2 = D.calc_dcd(prior, det["recon"], alpha=70, n_lambda=0.3, return_raw=True)[1:]
+        assert torch.equal(d1, e2) and torch.equal(d2, e1) and torch.equal(i1, j2) and torch.equal(i2, j1)
+        net.eval()
+        FLAGS.train = 0
+        with torch.no_grad():
+            big = net(clouds, obj, sample_idx=sample)
+            one = net(clouds[7:9], obj[7:9], sample_idx=sample)
+        for k in big:
+            assert torch.equal(big[k][7:9], one[k]), k
+    finally:
+        FLAGS.train = 0

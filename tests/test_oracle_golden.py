@@ -344,3 +344,64 @@ def test_input_side_host_window_rule_matches_oracle():
         x = np.sort(rng.randint(0, 641, 2))
         b = (y[0], x[0], y[1], x[1])
         assert tuple(int(v) for v in ir.get_bbox(b)) == get_bbox(b)
+
+
+# ----------------------------------------------------------------------------- the trainer's step (BASELINE config 4, one rank)
+def golden_train_step_case():
+    """-> (fixture, db dict, samples [(net1), (net2)], graphs of both nets) from the reference's own RL_TDA_train_step run"""
+    g = golden("train_step_b4_n256.npz")
+    db = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("db.")}
+    s = [torch.from_numpy(g["sample.%d" % i].astype(np.int64)) for i in range(4)]
+    inj = {k[4:]: torch.from_numpy(g[k].astype(np.int64)) for k in g.files if k.startswith("idx.")}
+    return g, db, [(s[0], s[1]), (s[2], s[3])], inj
+
+
+def leaves(sd):
+    return {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running_" not in k else v.clone()) for k, v in sd.items()}
+
+
+def test_train_step_oracle_vs_reference_trainer():
+    """oracle/train_step_ref.py against the reference's RL_TDA_train_step + total loss + backward (tests/golden/make_golden.py
+    ::gen_train_step imports trainer/RL_TDA.py unmodified): the three consistency terms, all fourteen TDA terms, the total, the
+    gradient of every net1 parameter (norm, sum, 16 samples), the BatchNorm buffers of both nets after the step."""
+    from oracle import train_step_ref as TS
+    g, db, samples, inj = golden_train_step_case()
+    P1 = leaves(seeded_state_dict(int(g["weight_seed"])))
+    P2 = seeded_state_dict(int(g["weight_seed"]) + 1, only_encoder=True)
+    ld, r1, r2, graphs = TS.train_step(P1, P2, db, samples, inject=inj)
+    for k in ("RL_loss", "recon_1_loss", "recon_consistency_loss"):
+        assert np.allclose(ld[k].detach().numpy(), g["loss." + k], rtol=2e-5, atol=1e-6), (k, ld[k], g["loss." + k])
+    tda = [k[9:] for k in g.files if k.startswith("loss.TDA.")]
+    assert sorted(tda) == sorted(ld["TDA_loss"]) and len(tda) == 14
+    for k in tda:
+        assert np.allclose(ld["TDA_loss"][k].detach().numpy(), g["loss.TDA." + k], rtol=5e-5, atol=1e-6), (k, ld["TDA_loss"][k], g["loss.TDA." + k])
+    assert np.allclose(ld["total"].detach().numpy(), g["total"], rtol=2e-5)
+    ld["total"].backward()
+    keys = [k for k in g.files if k.startswith("grad.")]
+    assert len(keys) == 103
+    for k in keys:
+        got, want = grad_summary(P1[k[5:]].grad).numpy(), g[k]
+        assert np.allclose(got, want, rtol=2e-3, atol=2e-4 * max(1.0, abs(want[0]))), (k, got[:3], want[:3])
+    for tag, r in (("net1", r1), ("net2", r2)):
+        for k, v in r["_bn_new"].items():
+            assert np.allclose(v.detach().numpy(), g["bn.%s.%s" % (tag, k)], rtol=1e-5, atol=1e-6), (tag, k)
+
+
+def test_category_cloud_fixture_is_the_references_data():
+    """BASELINE config 3's workload as data (tests/golden/category_clouds.npz): six (1024,3) clouds and (2500,) priors per
+    category, the oracle's training-mode forward on them under the reference's graphs, and R_DCD against the category clouds."""
+    from oracle import loss_ref as L
+    g = golden("category_clouds.npz")
+    assert g["points_category"].shape == (6, 1024, 3) and g["pdh1_category"].shape == (6, 2500) and g["pdh2_category"].shape == (6, 2500)
+    assert g["points_category"].dtype == np.float32 and 0.0 <= g["pdh1_category"].min() and g["pdh2_category"].max() <= 1.0
+    sd = seeded_state_dict(int(g["weight_seed"]))
+    pts, obj = torch.from_numpy(g["points"]), torch.from_numpy(g["obj_id"])
+    sample = (torch.from_numpy(g["sample_idx_1"].astype(np.int64)), torch.from_numpy(g["sample_idx_2"].astype(np.int64)))
+    inj = {k[4:]: torch.from_numpy(g[k].astype(np.int64)) for k in g.files if k.startswith("idx.")}
+    with torch.no_grad():
+        out = PR.posenet_forward(sd, pts, obj, sample_idx=sample, train_keys=True, mode="exact", inject=inj, bn_train=True)
+        for k in ("recon", "p_green_R", "p_red_R", "f_green_R", "f_red_R", "Pred_T", "Pred_s", "h1", "h2", "feat_global"):
+            assert np.allclose(out[k].numpy(), g["train." + k], rtol=1e-4, atol=2e-5), k
+        r = L.r_dcd(torch.from_numpy(g["points_category"]), out["recon"], torch.from_numpy(g["gt_R"]), out["p_green_R"], out["f_green_R"],
+                    out["p_red_R"], out["f_red_R"], out["Pred_T"], out["Pred_s"], torch.from_numpy(g["sym"]))
+    assert np.allclose(r.numpy(), g["r_dcd"], rtol=1e-4)

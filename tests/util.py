@@ -129,6 +129,41 @@ def synth_loss_batch(seed=41, B=10, N=96, D=50, C=70):
     return pred, gt, sym, extra
 
 
+def rand_rotations(B, seed):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(B, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    w, x, y, z = q.unbind(1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                        2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1).view(B, 3, 3)
+
+
+def synth_train_db(cat_points, cat_h1, cat_h2, sym_table, cat_ids, N, seed):
+    """A batch dict in the train loader's format (datasets/load_data.py:313-349) built from per-category tables: cat_points
+    (6,1024,3), cat_h1 / cat_h2 (6,2500), sym_table 6 x 4.  Clouds are posed, scaled, noisy samples of the category clouds;
+    aug_pcl_in is the same object jittered and slightly moved; pdh1 / pdh2 the category priors with noise, clipped to [0, 1]."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    B = len(cat_ids)
+    cid = torch.tensor(cat_ids)
+    R = rand_rotations(B, seed + 1)
+    t = torch.randn(B, 3, generator=g) * 0.1 + torch.tensor([0.0, 0.0, 0.9])
+    s = torch.rand(B, 3, generator=g) * 0.1 + 0.2
+    pick = torch.stack([torch.randperm(cat_points.shape[1], generator=g)[:N] for _ in range(B)])           # (B, N)
+    cano = torch.gather(cat_points[cid], 1, pick.unsqueeze(-1).expand(B, N, 3))
+    pcl = torch.matmul(cano * s.unsqueeze(1), R.transpose(1, 2)) + t.unsqueeze(1) + 0.002 * torch.randn(B, N, 3, generator=g)
+    dR = rand_rotations(B, seed + 2)
+    dR = torch.eye(3) + 0.05 * (dR - dR.transpose(1, 2))                                                    # a small motion
+    ctr = pcl.mean(1, keepdim=True)
+    aug = torch.matmul(pcl - ctr, dR.transpose(1, 2)) + ctr + 0.01 * torch.randn(B, 1, 3, generator=g) + 0.003 * torch.randn(B, N, 3, generator=g)
+    noisy = lambda h: (h[cid] + 0.05 * torch.randn(B, h.shape[1], generator=g)).clamp(0, 1)
+    return {"pcl_in": pcl.contiguous(), "aug_pcl_in": aug.contiguous(), "cat_id": cid.float().view(B, 1), "rotation": R, "translation": t,
+            "fsnet_scale": s, "sym_info": torch.tensor([sym_table[c] for c in cat_ids], dtype=torch.float32),
+            "pdh1": noisy(cat_h1), "pdh2": noisy(cat_h2), "pdh1_category": cat_h1[cid].clone(), "pdh2_category": cat_h2[cid].clone(),
+            "points_category": cat_points[cid].clone()}
+
+
 def synth_depth_scene(seed, n_det=4, H=480, W=640, edge_cases=False):
     """A synthetic frame in the layout the evaluation loader reads (evaluation/load_data_eval.py:271-303): a uint16 depth
     image in millimetres (sloped background, nearer blobs, zero-depth holes), Mask-RCNN style ``pred_masks`` (H,W,n) bool,

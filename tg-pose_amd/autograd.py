@@ -187,20 +187,20 @@ class _NbrMaxMean(Function):
 
 
 class _PoolMax(Function):
-    """Pool_layer's feature half: max over the 4 nearest neighbours at the sampled points"""
+    """Pool_layer's feature half: max over the kpool nearest neighbours at the sampled points"""
 
     @staticmethod
-    def forward(ctx, xyz, fm, idx, sample):
+    def forward(ctx, xyz, fm, idx, sample, kpool=4):
         fm = fm.contiguous()
-        v, f = ops.pool(xyz, fm, idx, sample, kpool=4)
-        ctx.save_for_backward(fm, idx[:, sample.long(), :4].contiguous())
+        v, f = ops.pool(xyz, fm, idx, sample, kpool=kpool)
+        ctx.save_for_backward(fm, idx[:, sample.long(), :kpool].contiguous())
         ctx.mark_non_differentiable(v)
         return v, f
 
     @staticmethod
     def backward(ctx, _dv, df):
         fm, idx_s = ctx.saved_tensors
-        return None, ops.nbrmax_bwd(fm, idx_s, df.contiguous()), None, None
+        return None, ops.nbrmax_bwd(fm, idx_s, df.contiguous()), None, None, None
 
 
 class _GatherRows(Function):
@@ -374,67 +374,107 @@ def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=Non
     return out
 
 
-class GraphedBackward(object):
-    """Training-mode forward + loss + backward of one (batch, cloud size) captured as a single hipGraph and replayed.
+class GraphedStep(object):
+    """Forward(s) + loss + backward of one training step captured as a single hipGraph and replayed.
 
-    The unfused training graph is ~700 kernel launches per step; replayed from a graph their launch overhead and the gaps
-    between dependent kernels are gone (bench.py --workload train_step: 28.1 -> 26.8 ms per B=32 step).  Gradients land in
-    the parameters' static ``.grad`` buffers (zeroed in place before each replay -- never set them to None afterwards, the
-    graph writes to those very tensors); the gradient all-reduce, the clip and the optimizer step stay with the caller.  ``loss_fn(out) -> scalar`` must be built from ops that can be captured (no host
-    synchronisation); inputs are copied into static buffers, the per-forward subsample is drawn on the host as usual.
+    ``step_fn(samples) -> scalar loss`` runs every forward of the step (the trainer's net1 with gradients and net2 under
+    no_grad, trainer/RL_TDA.py:116-118) and the loss on STATIC input buffers it owns; ``samples[i] = (pool_1, pool_2)`` are the
+    device-resident subsample indices of forward i (cloud size ``cloud_sizes[i]``), redrawn on the host before every replay in
+    the reference's order (gcn3d.py:241-242: torch's global CPU generator, forward by forward) and copied in through a pinned
+    ring.  The unfused training graph is ~700 kernel launches per step; replayed from a graph their launch overhead and the
+    gaps between dependent kernels are gone.  Gradients land in the parameters' static ``.grad`` buffers (zeroed in place
+    before each replay -- never set them to None afterwards, the graph writes to those very tensors); the gradient all-reduce,
+    the clip and the optimizer step stay with the caller.  step_fn must be built from ops that can be captured (no host
+    synchronisation).
 
-    Drop every loss / output of earlier EAGER steps over the same parameters before constructing this: a live autograd graph
-    keeps its AccumulateGrad nodes, which are bound to the stream they were created on; the captured backward would hand its
-    gradients across to that stream, pulling it into the capture, and HIP crashes in hipStreamEndCapture instead of raising
-    (scripts/capture_probe.py reproduces it)."""
+    Losses / outputs of earlier EAGER steps over the same parameters must be dropped first: a live autograd graph keeps its
+    AccumulateGrad nodes, which are bound to the stream they were created on, and a captured backward that handed its gradients
+    to such a node would pull that (default) stream into the capture, which hipStreamEndCapture does not survive.  The
+    constructor detects this during its warm-up backward -- outside any capture -- and raises RuntimeError instead of capturing
+    (torch reports the foreign node as a warning; here it is an error).  The nodes the captured step itself needs are created
+    inside the capture, on the capture stream, and freed with it (the returned loss is detached)."""
 
-    def __init__(self, net, points, obj_id, loss_fn):
-        dev = points.device
-        B, N, _ = points.shape
-        self.net, self.N = net, N
-        n1 = N // 4
-        self.points, self.obj = points.clone(), obj_id.clone().float()
-        self.s1 = torch.zeros(n1, dtype=torch.int32, device=dev)
-        self.s2 = torch.zeros(n1 // 4, dtype=torch.int32, device=dev)
-        self._pins = engine.PinnedRing(n1 + n1 // 4)
-        self._s12 = torch.zeros(n1 + n1 // 4, dtype=torch.int32, device=dev)
+    _FOREIGN = "AccumulateGrad node's stream does not match"
+
+    def __init__(self, params, step_fn, cloud_sizes, device):
+        import warnings
+        dev = torch.device(device)
+        self.params, self.sizes = list(params), [int(n) for n in cloud_sizes]
+        self.counts = [(n // 4, n // 4 // 4) for n in self.sizes]
+        total = sum(a + b for a, b in self.counts)
+        self._pins = engine.PinnedRing(total)
+        self._s12 = torch.zeros(total, dtype=torch.int32, device=dev)
+        self.samples = [(torch.zeros(a, dtype=torch.int32, device=dev), torch.zeros(b, dtype=torch.int32, device=dev))
+                        for a, b in self.counts]
 
         def run():
-            self.s1.copy_(self._s12[:n1])
-            self.s2.copy_(self._s12[n1:])
-            loss = loss_fn(net(self.points, self.obj, sample_idx=(self.s1, self.s2)))
+            o = 0
+            for (a, b), (s1, s2) in zip(self.counts, self.samples):
+                s1.copy_(self._s12[o:o + a])
+                s2.copy_(self._s12[o + a:o + a + b])
+                o += a + b
+            loss = step_fn(self.samples)
             loss.backward()
-            return loss
+            return loss.detach()         # nothing keeps the step's autograd graph (and its AccumulateGrad nodes) alive
 
         warm = torch.cuda.Stream(device=dev)
         warm.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(warm):
-            for _ in range(2):
-                self._draw(None)
-                self._zero()
-                run()
+        always = torch.is_warn_always_enabled()
+        torch.set_warn_always(True)      # the engine reports a foreign node once per process otherwise
+        try:
+            with torch.cuda.stream(warm), warnings.catch_warnings():
+                warnings.filterwarnings("error", message=".*" + self._FOREIGN)
+                for _ in range(2):
+                    self._draw(None)
+                    self._zero()
+                    try:
+                        run()
+                    except (UserWarning, RuntimeError) as e:
+                        if self._FOREIGN not in str(e):
+                            raise
+                        raise RuntimeError(
+                            "GraphedStep: an autograd graph of an earlier eager step over these parameters is still alive (a "
+                            "loss or output tensor is being kept); its AccumulateGrad nodes belong to another stream and cannot "
+                            "be captured.  Drop those tensors (del / .detach() / float()) before capturing the step.") from None
+        finally:
+            torch.set_warn_always(always)
         torch.cuda.current_stream(dev).wait_stream(warm)
         torch.cuda.synchronize(dev)
         self._zero()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=warm):     # the stream the warm-up ran on
             self.loss = run()
 
     def _zero(self):
-        for p in self.net.parameters():
+        for p in self.params:
             if p.grad is not None:
                 p.grad.zero_()
 
     def _draw(self, sample_idx):
-        i1, i2 = sample_idx if sample_idx is not None else engine.draw_sample_idx(self.N)
-        self._pins.upload(torch.cat([i1.reshape(-1), i2.reshape(-1)]), self._s12)
+        if sample_idx is None:
+            sample_idx = [engine.draw_sample_idx(n) for n in self.sizes]
+        self._pins.upload(torch.cat([t.reshape(-1) for pair in sample_idx for t in pair]), self._s12)
+
+    def __call__(self, sample_idx=None):
+        self._draw(sample_idx)
+        self._zero()
+        self.graph.replay()
+        return self.loss
+
+
+class GraphedBackward(GraphedStep):
+    """GraphedStep for a single network: ``loss_fn(net(points, obj_id)) -> scalar`` with the inputs in static buffers
+    (bench.py's forward-plus-loss workloads and the tests; the trainer's two-network step is trainer/RL_TDA.graphed_step)."""
+
+    def __init__(self, net, points, obj_id, loss_fn):
+        self.net, self.N = net, points.shape[1]
+        self.points, self.obj = points.clone(), obj_id.clone().float()
+        super().__init__(net.parameters(), lambda samples: loss_fn(net(self.points, self.obj, sample_idx=samples[0])),
+                         [self.N], points.device)
 
     def __call__(self, points=None, obj_id=None, sample_idx=None):
         if points is not None:
             self.points.copy_(points, non_blocking=True)
         if obj_id is not None:
             self.obj.copy_(obj_id.reshape(self.obj.shape).float(), non_blocking=True)
-        self._draw(sample_idx)
-        self._zero()
-        self.graph.replay()
-        return self.loss
+        return super().__call__(None if sample_idx is None else [sample_idx])

@@ -29,6 +29,7 @@ _DEFAULTS = dict(
     feat_consist_w=2.0,  # :83
     DCD_align=1.0,       # :101
     prop_sym_w=1.0,      # :114
+    lr=1e-4, lr_pose=1.0,  # :118-120 (the trainer's parameter group)
 )
 
 

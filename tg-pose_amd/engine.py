@@ -610,9 +610,9 @@ def encoder_only_forward(pk, points, obj_id, sample_idx=None, inject=None, recor
 
 
 # =====================================================================================================
-# Training-mode forward (module.training == True): BatchNorm uses batch statistics and updates its running
-# statistics, dropout is active.  Forward only (what the reference's net2 runs under torch.no_grad() every step,
-# trainer/RL_TDA.py:117-118, and the forward half of net1's step); the backward pass is not built yet.
+# Training-mode forward (module.training == True) without autograd: BatchNorm uses batch statistics and updates its
+# running statistics, dropout is active.  This is what the reference's net2 runs under torch.no_grad() every step
+# (trainer/RL_TDA.py:117-118); with gradients recorded (net1) the differentiable path of autograd.py runs instead.
 # The dense layers run the same GEMM kernels without the folded scale/shift; tgp_bn_stats / tgp_bn_apply then
 # normalise in place (two deterministic reduction passes + one apply pass over the activation).
 # =====================================================================================================

@@ -1,8 +1,10 @@
 """Drop-in for ``network/fs_net_repo/FaceRecon.py``: encoder, topology (PH) predictor, decoder.
 
 The classes keep the reference's attribute names so that ``state_dict()`` keys match a reference
-checkpoint exactly (Face_Enc :12, Face_Dec :89, PH_Predictor :120, FaceNet :170); their forwards
-run the eval-mode HIP pipeline of ``tgpose_amd.engine``.
+checkpoint exactly (Face_Enc :12, Face_Dec :89, PH_Predictor :120, FaceNet :170).  Called stand-alone,
+their forwards run the fused eval-mode HIP pipeline of ``tgpose_amd.engine`` in ``.eval()`` and the
+differentiable one of ``tgpose_amd.autograd`` (batch-statistics BatchNorm, dropout, HIP backward) in
+``.train()`` -- graph-attached outputs when gradients are being recorded, as in the reference.
 """
 import torch
 import torch.nn as nn
@@ -10,7 +12,12 @@ import torch.nn as nn
 from ... import engine, ops
 from ...config import FLAGS
 from . import gcn3d
-from .gcn3d import _Packable, _need_eval
+from .gcn3d import _Packable, _xyz
+
+
+def _pad_rows(x, C):
+    """(B, N, C) rows -> (B, N, FEAT_LD) zero padded (the row stride every layer over the concat buffer reads)"""
+    return torch.nn.functional.pad(x.float(), (0, engine.FEAT_LD - C))
 
 
 class _WithBuffers(_Packable):
@@ -39,10 +46,16 @@ class Face_Enc(_WithBuffers):
 
     def forward(self, vertices, cat_id, enable_proj=False):
         """vertices (B,N,3) already centred, cat_id (B,1) -> feat (B,N,1286), feat_global (B,1286,N)."""
-        _need_eval(self)
         if enable_proj:
             raise NotImplementedError("enable_proj=True is never used by the reference's train/eval path")
         dev = vertices.device
+        if self.training:
+            from ... import autograd as tgp_autograd
+            xyz = _xyz(vertices)
+            feat = tgp_autograd.encoder(self, xyz, cat_id.to(dev), engine.draw_sample_idx(xyz.shape[1]),
+                                        tgp_autograd._GraphSource(dev, None, None, ""), self.neighbor_num, FLAGS.obj_c)
+            feat = feat[:, :, : engine.FEAT_C]
+            return feat, feat.permute(0, 2, 1)
         conv = self._packed(lambda: engine.pack_encoder(engine._dev_sd(self.state_dict(), dev), "", dev))
         pk = type("EncPack", (), dict(conv=conv))
         xyz = vertices.detach().float().contiguous()
@@ -65,9 +78,11 @@ class Face_Dec(_WithBuffers):
 
     def forward(self, x):
         """x (B,1286,N) -> recon (B,N,3)"""
-        _need_eval(self)
         B, C, N = x.shape
         dev = x.device
+        if self.training:
+            from ... import autograd as tgp_autograd
+            return tgp_autograd.decoder(self, _pad_rows(x.transpose(1, 2), C), None)
         dec, dec_out = self._packed(lambda: engine.pack_decoder(engine._dev_sd(self.state_dict(), dev), ""))
         pk = type("DecPack", (), dict(dec=dec, dec_out=dec_out))
         rows = torch.zeros(B, N, engine.FEAT_LD, device=dev, dtype=torch.float32)
@@ -93,9 +108,12 @@ class PH_Predictor(_WithBuffers):
 
     def forward(self, feat):
         """feat (B,N,1286) -> feat + back-projected topology code (B,1286,N), h1, h2 (B,2500)."""
-        _need_eval(self)
         B, N, C = feat.shape
         dev = feat.device
+        if self.training:
+            from ... import autograd as tgp_autograd
+            back, h1, h2 = tgp_autograd.ph_predictor(self, _pad_rows(feat, C))
+            return feat.permute(0, 2, 1) + back[:, :C].unsqueeze(-1), h1, h2
         ph = self._packed(lambda: engine.pack_ph(engine._dev_sd(self.state_dict(), dev), ""))
         pk = type("PhPack", (), dict(ph=ph))
         rows = torch.zeros(B, N, engine.FEAT_LD, device=dev, dtype=torch.float32)
@@ -113,10 +131,20 @@ class FaceNet(_WithBuffers):
 
     def forward(self, vertices, cat_id, enable_proj=False, pred_PH=True):
         """-> recon (B,N,3), feat (B,N,1286), feat_global (B,1286,N), h1, h2   (FaceRecon.py:178-200)"""
-        _need_eval(self)
         if enable_proj:
             raise NotImplementedError("enable_proj=True is never used by the reference's train/eval path")
         dev = vertices.device
+        if self.training:
+            from ... import autograd as tgp_autograd
+            xyz = _xyz(vertices)
+            featp = tgp_autograd.encoder(self.encoder, xyz, cat_id.to(dev), engine.draw_sample_idx(xyz.shape[1]),
+                                         tgp_autograd._GraphSource(dev, None, None, "encoder."), self.encoder.neighbor_num, FLAGS.obj_c)
+            h1 = h2 = back = None
+            if pred_PH:
+                back, h1, h2 = tgp_autograd.ph_predictor(self.ph_pred, featp)
+            recon = tgp_autograd.decoder(self.decoder, featp, back)
+            f = featp[:, :, : engine.FEAT_C]
+            return recon, f, f.permute(0, 2, 1), h1, h2
         pk = self._packed(lambda: engine.Packed(self.state_dict(), dev, face="", with_heads=False))
         xyz = vertices.detach().float().contiguous()
         N = xyz.shape[1]

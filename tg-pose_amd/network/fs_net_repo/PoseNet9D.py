@@ -4,9 +4,10 @@
 reference's key sets (PoseNet9D.py:69-90: 11 keys when FLAGS.train, 6 otherwise), submodule
 names (face_all / face_enc, rot_green, rot_red, ts) and therefore state-dict keys, so
 ``load_state_dict(checkpoint['net1_state_dict'])`` (evaluater/RT_TDA_Evaluater.py:39) works
-unchanged.  The forward is the HIP pipeline of ``tgpose_amd.engine`` -- eval mode, or training mode
-(batch-statistics BatchNorm, dropout) without autograd; extra keyword-only arguments let tests
-pin the random subsample and inject / record neighbour graphs.
+unchanged.  The forward is the fused HIP pipeline of ``tgpose_amd.engine`` in eval mode and in training
+mode under ``no_grad`` (batch-statistics BatchNorm, dropout: the trainer's net2), and the differentiable
+one of ``tgpose_amd.autograd`` in training mode with gradients recorded (net1); extra keyword-only
+arguments let tests pin the random subsample and inject / record neighbour graphs.
 """
 import torch
 import torch.nn as nn
@@ -14,7 +15,6 @@ import torch.nn as nn
 from ... import engine, ops
 from ...config import FLAGS
 from .FaceRecon import FaceNet, _WithBuffers
-from .gcn3d import _need_eval
 from .PoseR import Rot_green, Rot_red
 from .PoseTs import Pose_Ts
 
@@ -40,7 +40,7 @@ class PoseNet9D(_WithBuffers):
             face = "face_enc." if self.only_encoder else "face_all."
             self._pk = engine.Packed(self.state_dict(), device, face=face, with_heads=not self.only_encoder)
             self._pk_psig, self._pk_bsig = psig, bsig
-        elif self._pk_bsig != bsig:
+        elif self._pk_bsig != bsig and not self.training:    # training mode never reads the folds: refresh them on the next eval call
             self._pk.refold(self.state_dict())
             self._pk_bsig = tuple((b.data_ptr(), b._version) for b in self.buffers())
         return self._pk

@@ -8,11 +8,12 @@ import torch.nn as nn
 
 from ... import engine
 from ...config import FLAGS
-from .gcn3d import _Packable, _need_eval
+from .gcn3d import _Packable
 
 
 class _PointHead(_Packable):
-    """Parameter container with the reference's names (conv1..4, bn1..3, drop1) and an eval forward."""
+    """Parameter container with the reference's names (conv1..4, bn1..3, drop1); fused eval forward, differentiable
+    training forward (tgpose_amd.autograd.point_head: batch-statistics BatchNorm, dropout, HIP backward)."""
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
@@ -31,8 +32,10 @@ class _PointHead(_Packable):
 
     def _run(self, x):
         """x: (B, C, N) as in the reference -> (B, k).  C may be 1286 or 1289."""
-        _need_eval(self)
         B, C, N = x.shape
+        if self.training:
+            from ... import autograd as tgp_autograd
+            return tgp_autograd.point_head(self, torch.nn.functional.pad(x.float().transpose(1, 2), (0, engine.FEAT_LD - C)))
         pk = self._packed(lambda: engine.pack_head(engine._dev_sd(self.state_dict(), x.device), ""))
         rows = torch.zeros(B, N, engine.FEAT_LD, device=x.device, dtype=torch.float32)
         rows[:, :, :C].copy_(x.detach().float().transpose(1, 2))

@@ -2,8 +2,13 @@
 
 Same names, arguments and return conventions as the reference (int64 indices, freshly allocated
 channel-last tensors on the input's device); each call enqueues gfx950 kernels through the C ABI
-(include/tgpose.h).  Inference only in this round: parameters keep the reference's names and
-shapes so checkpoints load, but the layers refuse to run in training mode or under autograd.
+(include/tgpose.h).  As in the reference the operators are autograd-tracked: when gradients are
+being recorded and a feature input or a layer parameter requires them, the call runs as the
+``torch.autograd.Function``s of ``tgpose_amd.autograd`` (HIP forward AND HIP backward) and returns a
+graph-attached tensor; otherwise the fused no-autograd kernels of ``tgpose_amd.engine`` run.  The
+layers hold no BatchNorm / dropout, so ``.train()`` / ``.eval()`` make no difference to them.
+Gradients with respect to the point coordinates (``vertices``) are not produced -- the trainer's
+clouds are data (trainer/RL_TDA.py:111-116) -- and a ``vertices`` that requires grad is refused.
 
 Reference: get_neighbor_index :14, get_nearest_index :26, indexing_neighbor_new :38,
 HSlayer_surface :60, HS_layer :115, get_ORL_global :210, Pool_layer :219.
@@ -17,14 +22,43 @@ from ... import engine, ops
 
 
 def _need_eval(module):
+    """modules with BatchNorm whose fused forward exists for eval mode only (FaceRecon.py's stand-alone forwards)"""
     if module.training:
         raise NotImplementedError(
-            "%s: the HIP path implements eval-mode forward only (call .eval()); training-mode "
-            "BatchNorm/dropout and backward are not built yet" % type(module).__name__)
+            "%s.forward stand-alone runs the fused eval-mode pipeline; in training mode call it through "
+            "PoseNet9D.forward (batch-statistics BatchNorm, dropout and autograd live there)" % type(module).__name__)
+
+
+def _tracked(*tensors):
+    """does this call have to be recorded by autograd?"""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _xyz(vertices):
+    if vertices.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("gradients with respect to the point coordinates are not implemented (the clouds are data)")
+    return vertices.detach().float().contiguous()
+
+
+class _SeamGraphs(object):
+    """neighbour lists of one layer call, in the calling convention of tgpose_amd.autograd's layer functions:
+    level None = feature-space kNN of x, otherwise the xyz kNN (computed once per call and shared, where the reference
+    recomputes it: gcn3d.py:85/213)"""
+
+    def __init__(self):
+        self.xyz = None
+
+    def __call__(self, name, level, x, k):
+        with torch.no_grad():
+            if level is None:
+                return ops.knn_feat(x.detach().float().contiguous(), k)
+            if self.xyz is None:
+                self.xyz = ops.knn_xyz(x.detach().float().contiguous(), k)
+            return self.xyz
 
 
 def get_neighbor_index(vertices, neighbor_num):
-    """(bs, v, d) -> (bs, v, neighbor_num) int64; d == 3 or a multiple of 32 (feature space)."""
+    """(bs, v, d) -> (bs, v, neighbor_num) int64; d == 3 or a multiple of 32 (feature space).  Integer output: no gradient."""
     v = vertices.detach().float()
     idx = ops.knn_xyz(v.contiguous(), neighbor_num) if v.shape[2] == 3 else ops.knn_feat(v, neighbor_num)
     return idx.long()
@@ -36,18 +70,26 @@ def get_nearest_index(target, source):
 
 
 def indexing_neighbor_new(tensor, index):
-    """(bs, v, C), (bs, m, k) -> (bs, m, k, C): row gather (C a multiple of 4)."""
+    """(bs, v, C), (bs, m, k) -> (bs, m, k, C): row gather (C a multiple of 4); differentiable in `tensor`."""
     bs, v, C = tensor.shape
     _, m, k = index.shape
+    flat = index.reshape(bs, m * k).to(torch.int32).contiguous()
+    if _tracked(tensor):
+        from ... import autograd as tgp_autograd
+        return tgp_autograd._GatherRows.apply(tensor.float(), flat).view(bs, m, k, C)
     out = torch.empty(bs, m * k, C, device=tensor.device, dtype=torch.float32)
-    ops.gather_rows(tensor.detach().float().contiguous(), index.reshape(bs, m * k).to(torch.int32).contiguous(), out)
+    ops.gather_rows(tensor.detach().float().contiguous(), flat, out)
     return out.view(bs, m, k, C)
 
 
 def get_ORL_global(feature, vertices, neighbor_num):
-    """(bs, v, C), (bs, v, 3) -> (bs, v, C): neighbour max, mean over points, repeated per point."""
-    idx = ops.knn_xyz(vertices.detach().float().contiguous(), neighbor_num)
-    g = ops.orl_global(feature.detach().float().contiguous(), idx)
+    """(bs, v, C), (bs, v, 3) -> (bs, v, C): neighbour max, mean over points, repeated per point; differentiable in `feature`."""
+    idx = ops.knn_xyz(_xyz(vertices), neighbor_num)
+    if _tracked(feature):
+        from ... import autograd as tgp_autograd
+        g = tgp_autograd._NbrMaxMean.apply(feature.float(), idx)
+    else:
+        g = ops.orl_global(feature.detach().float().contiguous(), idx)
     return g.unsqueeze(1).repeat(1, feature.shape[1], 1)
 
 
@@ -82,8 +124,10 @@ class HSlayer_surface(_Packable):
                     w1=w2[:, :C].contiguous(), w2=w2[:, C:].contiguous())
 
     def forward(self, vertices, neighbor_num):
-        _need_eval(self)
-        xyz = vertices.detach().float().contiguous()
+        xyz = _xyz(vertices)
+        if _tracked(*self.parameters()):
+            from ... import autograd as tgp_autograd
+            return tgp_autograd._surface(self, xyz, _SeamGraphs(), neighbor_num)
         idx = ops.knn_xyz(xyz, neighbor_num)
         out = torch.empty(xyz.shape[0], xyz.shape[1], self.kernel_num, device=xyz.device, dtype=torch.float32)
         return engine.surface_layer(self._packed(self._build), xyz, idx, idx, out)
@@ -112,8 +156,10 @@ class HS_layer(_Packable):
                     w1=w2[:, :C].contiguous(), w2=w2[:, C:].contiguous())
 
     def forward(self, vertices, feature_map, neighbor_num):
-        _need_eval(self)
-        xyz = vertices.detach().float().contiguous()
+        xyz = _xyz(vertices)
+        if _tracked(feature_map, *self.parameters()):
+            from ... import autograd as tgp_autograd
+            return tgp_autograd._hs(self, "conv", xyz, feature_map.float(), _SeamGraphs(), 0, neighbor_num)
         fmap = feature_map.detach().float().contiguous()
         out = torch.empty(xyz.shape[0], xyz.shape[1], self.out_channel, device=xyz.device, dtype=torch.float32)
         return engine.hs_layer(self._packed(self._build), xyz, fmap, ops.knn_feat(fmap, neighbor_num),
@@ -126,9 +172,12 @@ class Pool_layer(nn.Module):
         self.pooling_rate, self.neighbor_num = pooling_rate, neighbor_num
 
     def forward(self, vertices, feature_map):
-        xyz = vertices.detach().float().contiguous()
+        xyz = _xyz(vertices)
         n = xyz.shape[1]
         idx = ops.knn_xyz(xyz, self.neighbor_num)
         sample = torch.randperm(n)[: int(n / self.pooling_rate)]      # global CPU generator, as gcn3d.py:242
-        return ops.pool(xyz, feature_map.detach().float().contiguous(), idx,
-                        sample.to(device=xyz.device, dtype=torch.int32), kpool=self.neighbor_num)
+        sample = sample.to(device=xyz.device, dtype=torch.int32)
+        if _tracked(feature_map):
+            from ... import autograd as tgp_autograd
+            return tgp_autograd._PoolMax.apply(xyz, feature_map.float(), idx, sample, self.neighbor_num)
+        return ops.pool(xyz, feature_map.detach().float().contiguous(), idx, sample, kpool=self.neighbor_num)

@@ -5,6 +5,7 @@ device tensors; nothing synchronises.  Inputs must be fp32 (indices int32), on a
 layouts documented in include/tgpose.h -- violations raise instead of being silently copied.
 """
 import ctypes
+import functools
 import os
 import math
 
@@ -16,6 +17,29 @@ from ._lib import GemmArgs, check
 
 def _stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+# bench.py sets this to a dict to time, with HIP events on the launch stream, every launch of the graph / HBM-bound kernel
+# class (kNN, graph convolution, ORL pooling, pooling, gathers, row sort, tails, per-object post-processing): class name ->
+# list of (start event, end event).  None (the default) adds nothing to a call.
+CLASS_TIMER = None
+
+
+def _timed(cls):
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrap(*a, **kw):
+            if CLASS_TIMER is None:
+                return fn(*a, **kw)
+            st = torch.cuda.current_stream(next(t for t in a if torch.is_tensor(t)).device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            r = fn(*a, **kw)
+            e1.record(st)
+            CLASS_TIMER.setdefault(cls, []).append((e0, e1, fn.__name__))
+            return r
+        return wrap
+    return deco
 
 
 def _p(t):
@@ -47,6 +71,7 @@ def _i32(t, name):
     return t
 
 
+@_timed("graph")
 def center(points):
     """points (B,n,3) -> (xyz_c (B,n,3), mean (B,3))"""
     _f32(points, "points", 3)
@@ -58,6 +83,7 @@ def center(points):
     return xyz, mean
 
 
+@_timed("graph")
 def knn_xyz(xyz, k):
     """xyz (B,n,3) contiguous -> idx (B,n,k) int32"""
     _f32(xyz, "xyz", 3)
@@ -69,6 +95,7 @@ def knn_xyz(xyz, k):
     return idx
 
 
+@_timed("graph")
 def knn_feat(feat, k, workspace=None):
     """feat (B,n,d) rows contiguous (row stride may exceed d) -> idx (B,n,k) int32"""
     feat, ld = _rows(feat, "feat")
@@ -82,6 +109,7 @@ def knn_feat(feat, k, workspace=None):
     return idx
 
 
+@_timed("graph")
 def nn1(target, source):
     """(B,n,3),(B,m,3) -> idx (B,n) int32"""
     _f32(target, "target", 3), _f32(source, "source", 3)
@@ -102,6 +130,7 @@ def normalize_dirs(directions):
     return out
 
 
+@_timed("graph")
 def gconv_surface(xyz, idx, sdn, S, C, out=None):
     _f32(xyz, "xyz", 3), _i32(idx, "idx")
     B, n, k = idx.shape
@@ -113,6 +142,7 @@ def gconv_surface(xyz, idx, sdn, S, C, out=None):
     return out
 
 
+@_timed("graph")
 def gconv_hs(xyz, idx, proj, sdn, S, C, out=None):
     _f32(xyz, "xyz", 3), _i32(idx, "idx")
     proj, ldp = _rows(proj, "proj")
@@ -125,6 +155,7 @@ def gconv_hs(xyz, idx, proj, sdn, S, C, out=None):
     return out
 
 
+@_timed("graph")
 def orl_global(feat, idx):
     """feat (B,n,C), idx (B,n,k) -> (B,C)"""
     feat, ldf = _rows(feat, "feat")
@@ -138,6 +169,7 @@ def orl_global(feat, idx):
     return out
 
 
+@_timed("graph")
 def orl_rowbias(feat, idx, w2t):
     """feat (B,n,C), idx (B,n,k), w2t (C,C) = W2^T -> rb (B,C) = mean_i max_j feat[idx] @ W2^T"""
     feat, ldf = _rows(feat, "feat")
@@ -151,6 +183,7 @@ def orl_rowbias(feat, idx, w2t):
     return rb
 
 
+@_timed("graph")
 def pool(xyz, feat, idx, sample, kpool=4, out_f=None):
     """xyz (B,n,3), feat (B,n,C), idx (B,n,>=kpool) int32, sample (n_out,) int32 -> (xyz_p, feat_p)"""
     _f32(xyz, "xyz", 3)
@@ -167,6 +200,7 @@ def pool(xyz, feat, idx, sample, kpool=4, out_f=None):
     return out_xyz, out_f
 
 
+@_timed("graph")
 def gather_rows(src, idx, dst):
     """dst[b,i,:C] = src[b, idx[b,i], :C]; src (B,n_src,C), idx (B,n_out) int32, dst (B,n_out,C) view"""
     src, lds = _rows(src, "src")
@@ -179,6 +213,7 @@ def gather_rows(src, idx, dst):
     return dst
 
 
+@_timed("graph")
 def sort_by_parent(near1, near2, n1, n2):
     """Rows of each object sorted by (near2, near1), ties in point order (= torch.argsort(near2 * n1 + near1, stable=True)).
     near1, near2 (B,n) int32 -> order (B,n) int32, order64 (B,n) int64, near1 + b*n1 and near2 + b*n2 in the sorted order."""
@@ -193,6 +228,7 @@ def sort_by_parent(near1, near2, n1, n2):
     return order, order64, o1, o2
 
 
+@_timed("graph")
 def fill_tail(obj_id, xyz_c, feat, col0, n_cls):
     _f32(obj_id, "obj_id"), _f32(xyz_c, "xyz_c", 3)
     feat, ld = _rows(feat, "feat")
@@ -327,6 +363,7 @@ def linear_rows(x, weight, bias=None, scale=None, shift=None, act=0, slope=0.0, 
     return out
 
 
+@_timed("graph")
 def colmax_decode(keys, out2=False):
     rows, N = keys.shape
     out = torch.empty(rows, 2 * N if out2 else N, device=keys.device, dtype=torch.float32)
@@ -336,6 +373,7 @@ def colmax_decode(keys, out2=False):
     return out
 
 
+@_timed("graph")
 def colmax(x):
     """x (B,n,C) rows -> (B,C) max over n"""
     x, ld = _rows(x, "x")
@@ -345,6 +383,7 @@ def colmax(x):
     return out
 
 
+@_timed("graph")
 def sigmoid(x):
     _f32(x, "x")
     x = x.contiguous()
@@ -353,6 +392,7 @@ def sigmoid(x):
     return y
 
 
+@_timed("graph")
 def head_post(green, red, ts, mean):
     B = green.shape[0]
     dev = green.device
@@ -364,6 +404,7 @@ def head_post(green, red, ts, mean):
     return pg, pr, fg, fr, pT, ps
 
 
+@_timed("graph")
 def add_mean_(recon, mean):
     B, n, _ = recon.shape
     check(_lib.lib().tgp_add_mean(_p(recon), _p(mean), B, n, _stream(recon)), "tgp_add_mean")
