@@ -296,6 +296,11 @@ int tgp_colmax_arg(const float *x, int ld, int objects, int n, int C, const floa
                    const float *gamma, const float *beta, int act, float slope, const float *slope_vec, float *out, int ldo,
                    int *argrow, int lda, tgp_stream_t stream);
 
+/* Backward of tgp_colmax_arg without BatchNorm (PoseNet9D.py:50 feat_global = feat.max over points): dx (objects*rows_per_obj, C)
+ * = dpool[o][c] on the recorded winning row, 0 elsewhere; written densely, deterministic. */
+int tgp_colmax_bwd(const float *dpool, int ldp, const int *argrow, int lda, int objects, int rows_per_obj, int C, float *dx, int lddx,
+                   tgp_stream_t stream);
+
 /* dst (cols, rows) = src (rows, cols)^T. */
 int tgp_transpose(const float *src, int ld_src, int rows, int cols, float *dst, int ld_dst, tgp_stream_t stream);
 

@@ -405,8 +405,11 @@ def test_layer_modules_vs_reference_golden(ops):
     conv0.load_state_dict({k[len(pre + "conv_0."):]: v for k, v in sd.items() if k.startswith(pre + "conv_0.")})
     conv0 = conv0.to(DEV).eval()
     xyz = g(gd["xyz"])
-    f0 = conv0(xyz, 20)
-    assert np.allclose(f0.cpu().numpy(), gd["conv0_out"], atol=1e-5, rtol=0)
+    with torch.no_grad():                                   # as the fixture was recorded: the fused kernels
+        f0 = conv0(xyz, 20)
+    assert not f0.requires_grad and np.allclose(f0.cpu().numpy(), gd["conv0_out"], atol=1e-5, rtol=0)
+    f0g = conv0(xyz, 20)                                    # gradients recorded: the differentiable path, graph-attached
+    assert f0g.requires_grad and np.allclose(f0g.detach().cpu().numpy(), gd["conv0_out"], atol=1e-5, rtol=0)
     conv1 = gcn3d.HS_layer(128, 128, 7)
     conv1.load_state_dict({k[len(pre + "conv_1."):]: v for k, v in sd.items() if k.startswith(pre + "conv_1.")})
     conv1 = conv1.to(DEV).eval()
@@ -417,7 +420,7 @@ def test_layer_modules_vs_reference_golden(ops):
                     ops.knn_xyz(xyz, 20), out)
     assert np.allclose(out.cpu().numpy(), gd["conv1_out"], atol=2e-5, rtol=0)
     # free running: same result wherever the graph has no tie at the boundary
-    free = conv1(xyz, fin, 20).cpu().numpy()
+    free = conv1(xyz, fin, 20).detach().cpu().numpy()
     assert (np.abs(free - gd["conv1_out"]).max(axis=2) < 2e-5).mean() > 0.98
     idx = gcn3d.get_neighbor_index(xyz, 4)
     assert idx.dtype == torch.int64
@@ -2109,7 +2112,7 @@ def test_train_step_vs_reference_trainer(ops):
     assert sorted(names) == sorted(ld["TDA_loss"]) and len(names) == 14
     for k in names:
         assert np.allclose(ld["TDA_loss"][k].detach().cpu().numpy().reshape(-1), gd["loss.TDA." + k], rtol=2e-4, atol=2e-6), (k, ld["TDA_loss"][k])
-    assert abs(total.item() - float(gd["total"])) <= 2e-4 * abs(float(gd["total"]))
+    assert abs(total.item() - float(gd["total"][0])) <= 2e-4 * abs(float(gd["total"][0]))
     _check_step_grads(dict(tr.net1.named_parameters()), {k[5:]: torch.from_numpy(gd[k]) for k in gd.files if k.startswith("grad.")})
     assert all(p.grad is None for p in tr.net2.parameters())
     for tag, net in (("net1", tr.net1), ("net2", tr.net2)):
@@ -2218,7 +2221,7 @@ def test_train_step_one_rank_of_config_4(ops):
         assert abs(t2 - t0) <= 1e-6 * abs(t0), (t0, t2)
         for k, p in tr.net1.named_parameters():
             if p.grad is not None and k in g0:
-                assert (p.grad - g0[k]).abs().max().item() <= 1e-5 * g0[k].abs().max().item() + 1e-7, k
+                assert (p.grad - g0[k]).abs().max().item() <= 1e-4 * g0[k].abs().max().item() + 1e-7, k   # float-atomic scatters reorder sums
     finally:
         FLAGS.train = 0
 
@@ -2252,7 +2255,7 @@ def test_config3_category_clouds_vs_reference(ops):
         assert np.abs(out["feat"].double().sum(dim=2).float().cpu().numpy() - gc["train.feat_rowsum"]).max() <= 2e-3
         r = mod.R_DCD(t("points_category"), out["recon"], t("gt_R"), out["p_green_R"], out["f_green_R"], out["p_red_R"], out["f_red_R"],
                       out["Pred_T"], out["Pred_s"], t("sym"))
-        assert abs(r.item() - float(gc["r_dcd"])) <= 1e-4 * abs(float(gc["r_dcd"])), (r.item(), float(gc["r_dcd"]))
+        assert abs(r.item() - float(gc["r_dcd"][0])) <= 1e-4 * abs(float(gc["r_dcd"][0])), (r.item(), float(gc["r_dcd"][0]))
         # ---- B = 256
         B = 256
         cid = torch.arange(B) % 6
@@ -2280,9 +2283,71 @@ def test_config3_category_clouds_vs_reference(ops):
         net.eval()
         FLAGS.train = 0
         with torch.no_grad():
-            big = net(clouds, obj, sample_idx=sample)
-            one = net(clouds[7:9], obj[7:9], sample_idx=sample)
+            rec = {}
+            big = net(clouds, obj, sample_idx=sample, record=rec)
+            one = net(clouds[7:9], obj[7:9], sample_idx=sample, inject={k: v[7:9].contiguous() for k, v in rec.items()})
+        # on the same graphs; not bit for bit: a two-object batch runs the small-tile fp32 kernels, and per-object vectors of more
+        # than 32 objects leave the weight-streaming kernel for the tile kernels (another summation order)
         for k in big:
-            assert torch.equal(big[k][7:9], one[k]), k
+            assert (big[k][7:9] - one[k]).abs().max().item() <= 2e-5, k
     finally:
         FLAGS.train = 0
+
+
+def test_graphed_training_follows_eager_training(ops):
+    """Three consecutive optimizer steps with the step replayed from ONE captured hipGraph (weights, BatchNorm statistics and
+    momentum change between replays; the graph must read the current values and leave no stale state) against the same three
+    steps launched eagerly from the same initial state with the same subsamples: first total to 1e-6 and the weights after the
+    first optimizer step to 1e-6 of their largest entry, later totals to 2e-3 (two fp32 trajectories).  (The first version of the step kept torch's max-with-indices for feat_global in the graph; its backward
+    scatter asserted on the second replay -- the feature now uses tgp_colmax_arg / tgp_colmax_bwd like every other pooled max.)"""
+    from tgpose_amd import FLAGS
+    B, N = 8, 512
+    db = {k: g(v) for k, v in _step_db([0, 1, 2, 3, 4, 5, 1, 4], N, 31).items()}
+    torch.manual_seed(11)
+    draws = []
+    for _ in range(3):
+        pair = []
+        for _ in range(2):
+            i1 = torch.randperm(N)[: N // 4]
+            pair.append((i1, torch.randperm(i1.numel())[: i1.numel() // 4]))
+        draws.append(pair)
+    try:
+        from tgpose_amd.trainer.RL_TDA import total_loss
+        totals, weights = {"eager": []}, {}
+        tr = _trainer(13)
+        tr.optimizer = torch.optim.SGD(tr.net1.parameters(), lr=1e-3, momentum=0.9)
+        for i in range(3):
+            tr.optimizer.zero_grad(set_to_none=True)
+            _, ld = tr.RL_TDA_train_step(db, sample_idx=draws[i])
+            t = total_loss(ld)
+            t.backward()
+            tr.finish_step()
+            totals["eager"].append(t.item())
+            if i == 0:
+                weights["eager"] = {k: v.detach().clone() for k, v in tr.net1.state_dict().items()}
+        del t, ld
+        # graph: one trainer owns both the capture and the training (static .grad buffers belong to its parameters)
+        tr = _trainer(13)
+        state0 = {k: v.detach().clone() for k, v in tr.net1.state_dict().items()}
+        state2 = {k: v.detach().clone() for k, v in tr.net2.state_dict().items()}
+        step = tr.graphed_step(db)
+        tr.net1.load_state_dict(state0), tr.net2.load_state_dict(state2)
+        tr.optimizer = torch.optim.SGD(tr.net1.parameters(), lr=1e-3, momentum=0.9)
+        totals["graph"] = []
+        for i in range(3):
+            totals["graph"].append(step(sample_idx=draws[i]).item())
+            tr.finish_step()
+            if i == 0:
+                weights["graph"] = {k: v.detach().clone() for k, v in tr.net1.state_dict().items()}
+    finally:
+        FLAGS.train = 0
+    # step 0 starts from identical state: same total, and the same weights after the optimizer step; from then on the two runs
+    # are two fp32 trajectories (float-atomic scatters order their sums differently) whose feature-space neighbour lists may
+    # swap near-tied entries: their totals stay within 2e-3 of each other while the loss moves by 25 %
+    assert abs(totals["eager"][0] - totals["graph"][0]) <= 1e-6 * abs(totals["eager"][0]), (totals["eager"], totals["graph"])
+    for a, b in zip(totals["eager"][1:], totals["graph"][1:]):
+        assert abs(a - b) <= 2e-3 * abs(a), (totals["eager"], totals["graph"])
+    assert totals["graph"][2] < 0.9 * totals["graph"][0]
+    for k, w in weights["eager"].items():
+        if w.dtype.is_floating_point:
+            assert (weights["graph"][k] - w).abs().max().item() <= 1e-6 * max(w.abs().max().item(), 1.0), k

@@ -150,7 +150,9 @@ def synth_train_db(cat_points, cat_h1, cat_h2, sym_table, cat_ids, N, seed):
     R = rand_rotations(B, seed + 1)
     t = torch.randn(B, 3, generator=g) * 0.1 + torch.tensor([0.0, 0.0, 0.9])
     s = torch.rand(B, 3, generator=g) * 0.1 + 0.2
-    pick = torch.stack([torch.randperm(cat_points.shape[1], generator=g)[:N] for _ in range(B)])           # (B, N)
+    P = cat_points.shape[1]                       # N <= P: distinct points; beyond that the surplus is drawn with replacement
+    pick = torch.stack([torch.cat([torch.randperm(P, generator=g), torch.randint(0, P, (max(N - P, 0),), generator=g)])[:N]
+                        for _ in range(B)])                                                                  # (B, N)
     cano = torch.gather(cat_points[cid], 1, pick.unsqueeze(-1).expand(B, N, 3))
     pcl = torch.matmul(cano * s.unsqueeze(1), R.transpose(1, 2)) + t.unsqueeze(1) + 0.002 * torch.randn(B, N, 3, generator=g)
     dR = rand_rotations(B, seed + 2)

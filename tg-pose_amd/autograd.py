@@ -220,6 +220,29 @@ class _GatherRows(Function):
         return ops.gather_rows_bwd(dy.contiguous(), near, ctx.n_src), None
 
 
+class _ColMax(Function):
+    """feat_global = feat.max over an object's points (PoseNet9D.py:50): x (B, n, C) rows (row stride >= C) -> (B, C); first row
+    wins ties and NaN propagates, as torch.max; the gradient lands on the winning row"""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, n, C = x.shape
+        out, arg = ops.colmax_arg(x, B, n)
+        ctx.save_for_backward(arg)
+        ctx.shape = (B, n, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dpool):
+        (arg,) = ctx.saved_tensors
+        B, n, C = ctx.shape
+        return ops.colmax_bwd(dpool.contiguous(), arg, n).view(B, n, C)
+
+
+def colmax(x):
+    return _ColMax.apply(x)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def _orl(layer, g, idx_orl):
     """ORL_forward (gcn3d.py:108-112,182-186): conv2(cat[g, global]) + g, with the concatenation split into the two
@@ -349,7 +372,7 @@ def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=Non
         face = net.face_enc
         graphs = _GraphSource(points.device, inject, record, "face_enc.encoder.")
         feat = encoder(face.encoder, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
-        return dict(feat_global=feat[:, :, :FEAT_C].max(1)[0], recon=decoder(face.decoder, feat, None))
+        return dict(feat_global=colmax(feat[:, :, :FEAT_C]), recon=decoder(face.decoder, feat, None))
     face = net.face_all
     graphs = _GraphSource(points.device, inject, record, "face_all.encoder.")
     feat = encoder(face.encoder, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
@@ -370,7 +393,7 @@ def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=Non
     if train_keys:
         out["h1"], out["h2"] = h1, h2
         out["feat"] = feat[:, :, :FEAT_C]
-        out["feat_global"] = feat[:, :, :FEAT_C].max(1)[0]
+        out["feat_global"] = colmax(feat[:, :, :FEAT_C])
     return out
 
 

@@ -457,6 +457,32 @@ extern "C" int tgp_colmax_arg(const float *x, int ld, int objects, int n, int C,
     return TGP_LAUNCH_RESULT();
 }
 
+// backward of out[o][c] = max over the object's rows of x: dx[r][c] = dpool[o][c] where r is the recorded winning row, 0 elsewhere.
+// Dense write (every element exactly once: no atomics, no zero-fill pass), coalesced across channels.
+__global__ __launch_bounds__(256) void colmax_bwd_kernel(const float *__restrict__ dpool, int ldp, const int *__restrict__ argrow, int lda,
+                                                         int64_t rows, int rows_per_obj, int C, float *__restrict__ dx, int lddx)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int slice = threadIdx.x >> 6;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * BW_CHUNK;
+    const int64_t r1 = r0 + BW_CHUNK < rows ? r0 + BW_CHUNK : rows;
+    for (int64_t r = r0 + slice; r < r1; r += 4) {
+        const int64_t o = r / rows_per_obj;
+        dx[r * lddx + c] = argrow[o * lda + c] == r ? dpool[o * ldp + c] : 0.f;
+    }
+}
+
+extern "C" int tgp_colmax_bwd(const float *dpool, int ldp, const int *argrow, int lda, int objects, int rows_per_obj, int C, float *dx,
+                              int lddx, tgp_stream_t stream)
+{
+    TGP_REQUIRE(dpool && argrow && dx && objects > 0 && rows_per_obj > 0 && C > 0 && ldp >= C && lda >= C && lddx >= C);
+    const int64_t rows = (int64_t)objects * rows_per_obj;
+    hipLaunchKernelGGL(colmax_bwd_kernel, dim3(tgp_cdiv(C, 64), tgp_cdiv(rows, (int64_t)BW_CHUNK)), dim3(256), 0, tgp_hs(stream), dpool,
+                       ldp, argrow, lda, rows, rows_per_obj, C, dx, lddx);
+    return TGP_LAUNCH_RESULT();
+}
+
 // dst (cols, rows) = src (rows, cols)^T   (weights, once per step, for da = dx W through the forward GEMM kernels)
 __global__ void transpose_kernel(const float *__restrict__ src, int lds_, int rows, int cols, float *__restrict__ dst, int ldd)
 {

@@ -659,6 +659,17 @@ def colmax_arg(x, objects, n, bn=None, act=0, slope=0.0, slope_vec=None, eps=1e-
     return out, arg
 
 
+def colmax_bwd(dpool, argrow, rows_per_obj, dx=None):
+    """backward of colmax_arg(x) without BatchNorm: dpool (objects, C), argrow (objects, C) int32 -> dense dx (objects * n, C)"""
+    objects, C = dpool.shape
+    if dx is None:
+        dx = torch.empty(objects * rows_per_obj, C, device=dpool.device, dtype=torch.float32)
+    dx, lddx = _rows(dx, "dx")
+    check(_lib.lib().tgp_colmax_bwd(_p(dpool), dpool.stride(0), _p(argrow), argrow.stride(0), objects, rows_per_obj, C, _p(dx), lddx,
+                                    _stream(dpool)), "tgp_colmax_bwd")
+    return dx
+
+
 def transpose(w):
     """(rows, cols) -> contiguous (cols, rows)"""
     w, ld = _rows(w, "w")
