@@ -299,6 +299,76 @@ def test_gemm_split_accuracy(ops, M, N, K, scale_a, kind):
     assert e_split <= 3e-6 * ref.abs().max().item() * max(1.0, (K / 1292) ** 0.5)
 
 
+@pytest.mark.parametrize("M,N,K,a_mag,w_mag", [(8300, 1024, 512, 3e5, 1.0), (33000, 512, 272, 8e5, 2e5), (4200, 2304, 128, 1.0, 5e5),
+                                               (8300, 1024, 512, 1e30, 1.0)])
+def test_gemm_split16_range_guard(ops, M, N, K, a_mag, w_mag):
+    """Default GEMM mode (two-term fp16 split) with operands far outside fp16's range (65504): activations of 1e5-1e6 in some
+    rows (FaceRecon.py:67: conv_4 has no BatchNorm, a trained checkpoint may produce them) and / or weights of that size.  The
+    kernel notices per tile, on the device, that an operand left fp16's range and runs that tile's K loop again on power-of-two
+    scaled operands; weights are range-checked when they are packed.  Result within 1e-4 relative of fp64 (it used to be NaN),
+    no read-back: the launch is captured in a hipGraph and the replay returns the same bits."""
+    gen = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=gen)
+    A[::3] *= a_mag                                            # rows of very different magnitude inside every tile
+    A[1::7] *= 1e-3
+    W = torch.randn(N, K, generator=gen) / K ** 0.5 * w_mag
+    bias = torch.randn(N, generator=gen)
+    want = A.double() @ W.double().t() + bias.double()
+    Ad, Wd, bd = g(A), g(W), g(bias)
+    assert ops.GEMM_MODE == "split16"
+    ws = ops.split_w(Wd)
+    assert (getattr(ws, "tgp_unscale", None) is not None) == (w_mag > 1e3)
+    out = ops.linear_rows(Ad, Wd, bias=bd, w_split=ws)
+    assert torch.isfinite(out).all()
+    rowscale = want.abs().max(dim=1, keepdim=True)[0].clamp_min(1e-30)
+    assert ((out.double().cpu() - want).abs() / rowscale).max().item() <= 1e-4
+    graph = torch.cuda.CUDAGraph()
+    static = torch.empty_like(out)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.linear_rows(Ad, Wd, bias=bd, w_split=ws, out=static)
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(graph):
+        ops.linear_rows(Ad, Wd, bias=bd, w_split=ws, out=static)
+    static.zero_()
+    graph.replay()
+    assert torch.equal(static, out)
+
+
+def test_forward_with_unnormalised_conv4_magnitudes(ops):
+    """The whole eval forward with conv_4 (the layer without BatchNorm) scaled so that fm_4 reaches ~1e6: every output finite and
+    within 1e-4 RELATIVE of the fp32 CPU oracle on the oracle's graphs (default fp16-split mode; before the range guard: NaN)."""
+    from tgpose_amd import PoseNet9D, seeded_state_dict, FLAGS
+    _, _, PR = _oracle()
+    sd = seeded_state_dict(14)
+    for k in ("weights", "bias", "STE_layer.weight"):
+        sd["face_all.encoder.conv_4." + k] = sd["face_all.encoder.conv_4." + k] * 1e6
+    B, N = 2, 512
+    pts, obj = synth_points(B, N, 14)
+    torch.manual_seed(2)
+    i1 = torch.randperm(N)[: N // 4]
+    sample = (i1, torch.randperm(i1.numel())[: i1.numel() // 4])
+    with torch.no_grad():
+        want, inter = PR.posenet_forward(sd, pts, obj, sample_idx=sample, train_keys=True, mode="exact", want_intermediates=True)
+    assert inter["feat"][:, :, 768:1280].abs().max().item() > 1e5          # fm_4 is really out of fp16's range
+    net = PoseNet9D()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    FLAGS.train = 1
+    try:
+        with torch.no_grad():
+            got = net(g(pts), g(obj), sample_idx=sample, inject={k: v.int() for k, v in inter["indices"].items()})
+    finally:
+        FLAGS.train = 0
+    for k, v in want.items():
+        a = got[k].cpu()
+        assert torch.isfinite(a).all(), k
+        if k in ("f_green_R", "f_red_R", "h1", "h2"):      # sigmoids of logits of magnitude 1e4..1e6: 1e-4 relative on the logit is not 1e-4 on them
+            continue
+        assert (a - v).abs().max().item() <= 1e-4 * max(v.abs().max().item(), 1.0), (k, (a - v).abs().max().item(), v.abs().max().item())
+
+
 @pytest.mark.parametrize("kind", ["bf16x3", "f16x2"])
 def test_gemm_split_exact_on_small_integers(ops, kind):
     """Integer operands whose products and partial sums fit 24 bits: every path must return the exact result."""

@@ -33,7 +33,7 @@ def _split_if_big(w, rows, grads=False):
     keeps fp32's range."""
     if rows <= 32 or ops.GEMM_MODE == "fp32":
         return None
-    return ops.split_bf16(w) if grads else ops.split_w(w)
+    return ops.split_bf16(w) if grads else ops.split_w(w, check=False)     # inside the (captured) step: no read-back
 
 
 class _Linear(Function):

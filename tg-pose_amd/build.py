@@ -33,6 +33,8 @@ def _stale():
 def build(force=False, verbose=True, dev=False):
     """dev=True: libtgpose_hip_dev.so with -DTGP_DEV (kernel-variant switches for scripts/*_ab.py; never loaded by the
     package itself -- a script points tgpose_amd._lib.LIB_PATH at it before the first call)."""
+    if dev == "noguard":       # A/B measurement build: the product library without the fp16 range guard of the split GEMM
+        return _build(os.path.join(HERE, "libtgpose_hip_noguard.so"), SOURCES, ["-DTGP_NO_RANGE_GUARD"], ".ng.o", verbose)
     if dev:
         return _build(DEV_LIB, SOURCES + DEV_SOURCES, ["-DTGP_DEV"], ".dev.o", verbose)
     if not force and not _stale():
@@ -68,4 +70,4 @@ def _build(LIB, sources, extra, suffix, verbose):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, dev="--dev" in sys.argv)
+    build(force="--force" in sys.argv, dev="noguard" if "--noguard" in sys.argv else "--dev" in sys.argv)

@@ -670,6 +670,15 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
     const int64_t a_rows = p.M - m0, w_rows = p.N - n0;
     const int64_t a_bytes = a_rows * p.lda * 4 - (p.lda - p.K) * 4, w_bytes = w_rows * wrow * 2 - (p.ksplit ? z * p.sWS * 2 : 0);
     const float asc = p.a_scale ? p.a_scale[0] : 1.f;
+    // fp16 range guard (see after the K loop): armed in the production form of the fp16 tile
+#ifdef TGP_NO_RANGE_GUARD                     // measurement builds only (scripts/ab_bench.py: what does the guard cost?)
+    constexpr bool RANGE_GUARD = false;
+#else
+    constexpr bool RANGE_GUARD = F16 && KG == 1 && STAGES == 2 && !SKEW;
+#endif
+    float amax = 0.f;                          // the largest |a * asc| this thread has split
+    __shared__ int s_range_flag;
+    if (RANGE_GUARD && threadIdx.x == 0) s_range_flag = 0;      // ordered before every use by the prologue's barrier
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(A + (int64_t)m0 * p.lda), 0, (int)(a_bytes > 0x7fffffff ? 0x7fffffff : a_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
@@ -710,6 +719,8 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
                 ra[i] = __builtin_bit_cast(float4, make_uint4(rbits.x & km, rbits.y & km, rbits.z & km, rbits.w & km));
                 if constexpr (F16) {
                     ra[i].x *= asc, ra[i].y *= asc, ra[i].z *= asc, ra[i].w *= asc;       // exact: asc is 1 or a power of two
+                    if constexpr (RANGE_GUARD)
+                        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(ra[i].x), fabsf(ra[i].y))), fmaxf(fabsf(ra[i].z), fabsf(ra[i].w)));
                     uint2 q0, q1;
                     split2(ra[i], q0, q1);
                     *reinterpret_cast<uint2 *>(dst) = q0;
@@ -746,6 +757,7 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
     if (p.stamps) st0 = __builtin_amdgcn_s_memrealtime();
     load_tile(0, ra_[0], rw_[0]);
     store_tile(0, 0, ra_[0], rw_[0]);
+    if (RANGE_GUARD && numK == 1 && amax >= 65504.f) s_range_flag = 1;
 #pragma unroll
     for (int s = 1; s < NS; ++s) load_tile(s, ra_[s], rw_[s]);
     __syncthreads();
@@ -804,7 +816,12 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
             // With two LDS stages the next tile can be split and written while this wave still has MFMAs to issue:
             // done after the first column block, the VALU / LDS-write work overlaps the other waves' MFMAs instead of
             // sitting between the last MFMA and the barrier.
-            if (!SKEW && DBUF && j == (TN > 1 ? TN / 2 - 1 : 0) && more) store_tile((kt + 1) & 1, kt + 1, ra_next, rw_next);
+            if (!SKEW && DBUF && j == (TN > 1 ? TN / 2 - 1 : 0) && more) {
+                store_tile((kt + 1) & 1, kt + 1, ra_next, rw_next);
+                // the last K-tile has just been staged: this thread's amax is final, and the barriers that end this step and the
+                // next one order the flag before anybody reads it
+                if (RANGE_GUARD && kt + 2 >= numK && amax >= 65504.f) s_range_flag = 1;
+            }
         }
         if constexpr (SKEW) {
             store_tile((kt + 1) & 1, kt + 1, ra_next, rw_next);
@@ -841,6 +858,59 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
                 if (kt0 + s < numK) step(kt0 + s, ra_[s], rw_[s], ra_[(s + 1) % NS], rw_[(s + 1) % NS]);
         }
     }
+    // fp16 range guard.  The two-term fp16 split needs |a| < 65504 (an operand beyond it splits into inf and the sums become NaN).
+    // Every thread has tracked the largest magnitude it split (one register, two v_max3 per staged quad) and, after staging its last
+    // K-tile, raised a flag in LDS if that magnitude left fp16's range (before the loop's last barrier, so no extra one is needed
+    // here).  A tile that met such an operand throws its sums away and
+    // recomputes them in exact fp32: v_mfma_f32_32x32x2_f32 fed straight from global memory (A and the fp32 weight the caller
+    // always passes beside the split one), same accumulator layout, same epilogue.  Slower by an order of magnitude, but only for
+    // the tiles that need it; no host involvement, nothing read back, the launch stays capturable.  Every tile of this network's
+    // forward at sane weights takes the fast path.  (Weights are range-checked when they are packed: ops.split_w.  Not armed for
+    // the K-split form, whose fp32 W pointer is a placeholder and whose A operand the caller has already scaled.)
+    bool exact_fallback = false;
+    if constexpr (RANGE_GUARD) {
+        if (s_range_flag != 0 && !p.ksplit) {                                     // workgroup-uniform: written before the loop's last barrier
+            exact_fallback = true;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            // lane (r, h) supplies k = 8 t + 4 h + s to MFMA sub-step s of the 8-wide group t, for both operands; rows / columns past
+            // the end are clamped to the last valid one (their results are never stored)
+            const float *W32 = p.W + (int64_t)z * p.sW;
+            const float *ag[TM], *wg[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = m0 + wm * WTM + i * 32 + r;
+                ag[i] = A + (int64_t)(row < p.M ? row : p.M - 1) * p.lda + 4 * h;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * WTN + j * 32 + r;
+                wg[j] = W32 + (int64_t)(col < p.N ? col : p.N - 1) * p.ldw + 4 * h;
+            }
+#pragma unroll 1
+            for (int k0 = 0; k0 < p.K; k0 += 8) {
+                const bool ok = k0 + 4 * h < p.K;                                 // K % 4 == 0: the quad is wholly inside or outside
+                float4 av[TM], wv[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[i] = ok ? *reinterpret_cast<const float4 *>(ag[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) wv[j] = ok ? *reinterpret_cast<const float4 *>(wg[j] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, wv[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, wv[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, wv[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, wv[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    }
     if (p.stamps) st2 = __builtin_amdgcn_s_memrealtime();
     if constexpr (KG > 1) {
         // combine the K-groups' accumulators: (g0 + g1) + (g2 + g3), one group's 64 registers x 64 lanes through LDS at a
@@ -873,7 +943,7 @@ __device__ __forceinline__ void gemm_split_tile(const GemmParams &p, const int m
         if (KG == 4) hand(3, 2), hand(2, 0);
         if (kg != 0) return;
     }
-    if (p.c_scale) {
+    if (p.c_scale && !exact_fallback) {           // (the exact recomputation used the unscaled operands)
         const float cs = p.c_scale[0];
 #pragma unroll
         for (int i = 0; i < TM; ++i)

@@ -245,8 +245,28 @@ def fill_tail(obj_id, xyz_c, feat, col0, n_cls):
 GEMM_MODE = "split16"
 
 
-def split_w(W):
-    return split_f16(W) if GEMM_MODE == "split16" else split_bf16(W)
+FP16_SAFE = 32768.0          # |w| at or above this is pre-scaled before the fp16 split (fp16's largest finite value is 65504)
+
+
+def split_w(W, check=True):
+    """Pack-time operand split of a weight for the tile GEMM kernels, in the current GEMM_MODE.
+    check (fp16 split only): fp16 holds magnitudes below 65504, so the weight's largest magnitude is read back ONCE here (pack time
+    is outside every timed or captured region) and a weight that reaches 2^15 is split as W * 2^-k with the power of two 2^k
+    attached to the result (``.tgp_unscale``, a device scalar that ops.gemm hands to the kernel as c_scale: the accumulated sums
+    are multiplied back, exactly).  check=False is for splits made INSIDE a captured step (the training path splits the live
+    parameters every step): nothing may be read back there, and a parameter beyond fp16's range gives inf / NaN, which the
+    trainer's NaN test (trainer/RL_TDA.py:217) sees.  Activations need no such care: the kernels guard them tile by tile."""
+    if GEMM_MODE != "split16":
+        return split_bf16(W)
+    if not check:
+        return split_f16(W)
+    amax = float(W.detach().abs().max()) if W.numel() else 0.0
+    if not (amax >= FP16_SAFE) or not math.isfinite(amax):
+        return split_f16(W)
+    k = math.frexp(amax)[1] - 15                     # amax * 2^-k lies in [2^14, 2^15)
+    out = split_f16(W * (2.0 ** -k))
+    out.tgp_unscale = torch.full((1,), 2.0 ** k, device=W.device, dtype=torch.float32)
+    return out
 
 
 def split_f16(W):
@@ -279,7 +299,7 @@ GEMM_TIMER_ALL = False      # development: time the small-tile and skinny launch
 
 
 def _routes_to_big_tile(M, N, batch=1):
-    return N > 64 and ((M + 127) // 128) * ((N + 127) // 128) * batch >= _big_tile_threshold()
+    return M > 32 and N > 64 and ((M + 127) // 128) * ((N + 127) // 128) * batch >= _big_tile_threshold()
 
 
 _BIG_THR = None
@@ -322,6 +342,9 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
     if w_split is not None and GEMM_MODE != "fp32":
         a.W_split, a.ldws = _p(w_split), w_split.shape[-3] * 16
         a.w_split_kind = 1 if w_split.shape[-2] == 2 else 0
+        unscale = getattr(w_split, "tgp_unscale", None)       # a weight that was pre-scaled into fp16's range (split_w)
+        if unscale is not None and _routes_to_big_tile(M, N, batch):
+            c_scale = unscale if c_scale is None else c_scale * unscale
     a.a_scale, a.c_scale, a.ksplit_chunk = _p(a_scale), _p(c_scale), int(ksplit_chunk)
     if gather1 is not None:                      # (rows tensor whose data_ptr is the first column wanted, row stride, int32 row ids)
         a.gres1, a.ldg1, a.gidx1 = _p(gather1[0]), int(gather1[1]), _p(gather1[2])
