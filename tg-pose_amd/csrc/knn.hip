@@ -249,6 +249,112 @@ __device__ __forceinline__ void wave_select(float (&d)[NT], int lane, int k, int
     if (lane < k) out_row[lane] = mine;
 }
 
+// Wave-wide unsigned maximum (same DPP steps as wave_umin)
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v)
+{
+    uint32_t o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);
+    v = o > v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);
+    v = o > v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false);
+    v = o > v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false);
+    v = o > v ? o : v;
+    const uint32_t r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+    return a > b ? a : b;
+}
+
+// Top-(k+1) of one row WITHOUT a serial chain of k+1 wave reductions (the fused feature-space kernel's consumers run one wave
+// per SIMD: a chain of dependent cross-lane steps would leave the vector pipe idle most of the time).  key[t] is the
+// order-preserving key of candidate lane + 64 t; the order is (key, index), as in wave_select.
+//   1. every lane takes the minimum of its own keys; its rank among the 64 lane minima is a count of smaller ones (the minima
+//      go through LDS, every lane reads all 64: no dependency between the compares);
+//   2. tau = the largest lane minimum of rank <= k: at least k + 1 candidates are <= tau, so nothing above tau can be among the
+//      k + 1 nearest; on average ~26 of the 1028 candidates survive;
+//   3. the survivors are compacted into a per-wave list in LDS (ballot prefix sums), lane l takes survivor l and counts the
+//      survivors that precede it in (key, index) order: that count is its rank; ranks 1 .. k are written out.
+// Returns false (wave-uniform, nothing written) if more than 64 candidates survive; the caller then runs wave_select.
+template <int NT>
+__device__ __forceinline__ bool wave_select_ranked(const uint32_t (&key)[NT], int lane, int k, int32_t *__restrict__ out_row,
+                                                   uint32_t *__restrict__ lmin, uint2 *__restrict__ list /* 72 entries, 16-byte aligned */)
+{
+    uint32_t mn = key[0];
+#pragma unroll
+    for (int t = 1; t < NT; ++t) mn = key[t] < mn ? key[t] : mn;
+    lmin[lane] = mn;
+    __builtin_amdgcn_s_waitcnt(0xc07f);                               // lgkmcnt(0): the wave's own LDS writes have landed
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint4 v = reinterpret_cast<const uint4 *>(lmin)[j];     // broadcast reads
+        rank += (v.x < mn) + (v.y < mn) + (v.z < mn) + (v.w < mn);
+    }
+    const uint32_t tau = wave_umax(rank <= k ? mn : 0u);
+    int cnt = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) cnt += key[t] <= tau;
+    // exclusive prefix sum of cnt over the lanes, bit by bit (cnt <= NT < 32): ballots and bit counts, no cross-lane data movement
+    int pos = 0, total = 0;
+#pragma unroll
+    for (int bit = 0; bit < 5; ++bit) {
+        const unsigned long long m = __ballot((cnt >> bit) & 1);
+        pos += (int)(__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) << bit;
+        total += __popcll(m) << bit;
+    }
+    if (total > 64) return false;                                     // wave-uniform
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (key[t] <= tau) {
+            list[pos] = make_uint2(key[t], (uint32_t)(lane + (t << 6)));
+            ++pos;
+        }
+    }
+    if (lane < 8) list[total + lane] = make_uint2(0xffffffffu, 0xffffffffu);     // sentinels: the rank loop reads whole groups of 8
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const uint2 mine = list[lane < total ? lane : 0];
+    int r = 0;
+    for (int j = 0; j < total; j += 8) {                              // wave-uniform trip count; broadcast reads, issued together
+        uint4 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = reinterpret_cast<const uint4 *>(list + j)[u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            r += (e[u].x < mine.x) || (e[u].x == mine.x && e[u].y < mine.y);
+            r += (e[u].z < mine.x) || (e[u].z == mine.x && e[u].w < mine.y);
+        }
+    }
+    if (lane < total && r >= 1 && r <= k) out_row[r - 1] = (int32_t)mine.y;
+    return true;
+}
+
+// The serial form on keys, compact (a runtime loop of k + 1 rounds, each a lane-local scan for the smallest key after the last
+// one emitted plus two wave reductions): the fall-back of wave_select_ranked, rare, so size matters more than speed.
+template <int NT>
+__device__ __forceinline__ void wave_select_serial_keys(const uint32_t (&key)[NT], int lane, int k, int32_t *__restrict__ out_row)
+{
+    uint32_t lastk = 0;
+    int lastj = -1, mine = 0;
+    for (int r = 0; r <= k; ++r) {
+        uint32_t bk = 0xffffffffu;
+        int bj = 0x7fffffff;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = lane + (t << 6);
+            const bool after = key[t] > lastk || (key[t] == lastk && j > lastj);
+            const bool better = after && (key[t] < bk || (key[t] == bk && j < bj));
+            bk = better ? key[t] : bk;
+            bj = better ? j : bj;
+        }
+        lastk = wave_umin(bk);
+        lastj = (int)wave_umin(bk == lastk ? (uint32_t)bj : 0x7fffffffu);
+        if (r >= 1 && lane == r - 1) mine = lastj;
+    }
+    if (lane < k) out_row[lane] = mine;
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void knn_xyz_kernel(const float *__restrict__ xyz, int B, int n, int k,
                                                       int32_t *__restrict__ idx, int tiles_per_obj, int rpb)
@@ -378,14 +484,157 @@ __global__ __launch_bounds__(256) void sqnorm_aten_kernel(const float *__restric
     if (live && l8 == 0) q[row] = 0.f + fin;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Feature-space kNN WITHOUT the (B, n, n) matrix (gcn3d.py:14-23 with d = 128 / 256).  One 512-thread workgroup per 32-row
+// block of an object's distance matrix, two phases:
+//   1. all eight waves compute the block's 32 x n distances on the fp32 matrix cores -- the block's own 32 feature rows stay
+//      in registers as the A operand (lane (r, h) holds x[i0 + r][2 s + h] for every MFMA step s), the object's other rows
+//      stream past as the B operand straight from the XCD's L2 (an object's features are 0.5 MB; all its row blocks run on one
+//      XCD), prefetched one chunk ahead -- in the same ascending-k FMA chain and the same three roundings as the stored-matrix
+//      form (bit-identical distances), and leave them in LDS (32 x n floats, 135 KB at n = 1028);
+//   2. every wave takes four rows out of LDS and selects their k + 1 nearest by (distance, index) with wave_select_ranked.
+// The distances never leave the CU: HBM sees the features once (16.8 MB at B = 32, n = 1028, d = 128) and the index lists
+// (2.6 MB) instead of 2 x 135 MB of matrix.
+typedef float knn_f32x16 __attribute__((ext_vector_type(16)));
+
+#define KF_ROWS 32
+#define KF_MAX_LDW 1184      // 32 x 1184 x 4 B = 148 KiB of LDS
+
+// xt: the object's features transposed, (B, DIM, ldw) with ldw = 32 * ncb columns (zero beyond n): lane (r, h) of a 32-wide
+// block then reads xt[k = 2 s + h][32 cb + r] -- 32 consecutive floats per half wave, a fully used 128-byte line -- where a
+// row-major operand would make every lane walk its own row (32 lines touched per load instruction for 16 useful bytes each;
+// measured: the vector-memory pipe, not the matrix cores, then sets the pace: 43 instead of 18 us per row block).
+template <int DIM, int NT, int CH>   // CH: MFMA steps (k pairs) per prefetched chunk
+__global__ __launch_bounds__(512, 2) void knn_feat_fused_kernel(const float *__restrict__ xt, const float *__restrict__ q, int B, int n, int k,
+                                                                int32_t *__restrict__ idx, int nrb, int ncb, int ldw,
+                                                                unsigned long long *stamps)
+{
+    extern __shared__ __attribute__((aligned(16))) float dblk[];      // [32][ldw]
+    __shared__ uint32_t s_lmin[8][64];
+    __shared__ __attribute__((aligned(16))) uint2 s_list[8][72];
+    constexpr int STEPS = DIM / 2;                                    // MFMA steps per column block (k pairs)
+    constexpr int NCHUNK = STEPS / CH;
+    static_assert(NCHUNK % 2 == 0, "the chunk ring alternates two register buffers");
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int b, rb;
+    if (!tgp_xcd_object_tile(blockIdx.x, B, nrb, b, rb)) return;
+    const int i0 = rb * KF_ROWS;
+    const float *xb = xt + (size_t)b * DIM * ldw + (size_t)h * ldw + r;      // + 2 s ldw + 32 cb: the lane's element of step s, block cb
+    const float *qb = q + (size_t)b * n;
+    unsigned long long *st = (stamps && threadIdx.x == 0) ? stamps + 4 * (size_t)blockIdx.x : nullptr;   // development builds
+    if (st) st[0] = __builtin_amdgcn_s_memrealtime();
+    {
+        // ---- phase 1: distances of rows [i0, i0 + 32) against the column blocks cb = wave, wave + 8, ...
+        float a[STEPS];
+#pragma unroll
+        for (int s2 = 0; s2 < STEPS; ++s2) a[s2] = xb[(size_t)2 * s2 * ldw + i0];
+        float qrow[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) qrow[e] = qb[min(i0 + (e & 3) + 8 * (e >> 2) + 4 * h, n - 1)];
+        float buf[2][CH];
+        auto fetch = [&](int cb, int c, float (&dst)[CH]) {
+            const float *br = xb + (size_t)2 * c * CH * ldw + cb * 32;
+#pragma unroll
+            for (int t = 0; t < CH; ++t) dst[t] = br[(size_t)2 * t * ldw];
+        };
+        if (wave < ncb) fetch(wave, 0, buf[0]);
+        for (int cb = wave; cb < ncb; cb += 8) {
+            knn_f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCHUNK; ++c) {                        // compile-time chunk index: a[] stays in registers
+                if (c + 1 < NCHUNK) fetch(cb, c + 1, buf[(c + 1) & 1]);
+                else if (cb + 8 < ncb) fetch(cb + 8, 0, buf[0]);      // NCHUNK is even: the next block's first chunk lands in buf[0]
+#pragma unroll
+                for (int t = 0; t < CH; ++t)                          // ascending k: step s = c CH + t takes k = 2 s + h
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c * CH + t], buf[c & 1][t], acc, 0, 0, 0);
+            }
+            const int col = cb * 32 + r;
+            const float qc = qb[min(col, n - 1)];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float t1 = acc[e] * -2.0f;                      // inner * (-2)
+                const float t2 = t1 + qc;                             // + quadratic.unsqueeze(1)
+                dblk[row * ldw + col] = col < n ? t2 + qrow[e] : INFINITY;           // + quadratic.unsqueeze(2)
+            }
+        }
+    }
+    if (st) st[1] = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();
+    if (st) st[2] = __builtin_amdgcn_s_memrealtime();
+    // ---- phase 2: four rows per wave
+#pragma unroll 1
+    for (int rr = 0; rr < 4; ++rr) {
+        const int lrow = wave * 4 + rr, i = i0 + lrow;
+        if (i >= n) break;                                            // wave-uniform
+        uint32_t key[NT];
+        const float *row = dblk + lrow * ldw;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = lane + (t << 6);
+            key[t] = tgp_float_key(j < n ? row[j] : INFINITY);
+        }
+        int32_t *out = idx + ((size_t)b * n + i) * k;
+        if (!wave_select_ranked<NT>(key, lane, k, out, s_lmin[wave], s_list[wave]))
+            wave_select_serial_keys<NT>(key, lane, k, out);           // more than 64 candidates under the bound (rare)
+    }
+    if (st) st[3] = __builtin_amdgcn_s_memrealtime();
+}
+
+#ifdef TGP_DEV
+static unsigned long long *tgp_knn_stamps = nullptr;
+extern "C" void tgp_debug_set_knn_stamps(unsigned long long *buf) { tgp_knn_stamps = buf; }
+#else
+static constexpr unsigned long long *tgp_knn_stamps = nullptr;
+#endif
+
 // implemented in gemm.hip: D[b,i,j] = fl(fl(-2*<x_i,x_j> + q_j) + q_i), natural-k MFMA chain
 int tgp_launch_dist_gemm(const float *x, int ld, const float *q, int B, int n, int d, float *D, hipStream_t stream);
 
+// xt[b][c][j] = x[b][j][c] for j < n, 0 for n <= j < ldt (32 x 32 tiles through LDS)
+__global__ __launch_bounds__(256) void knn_transpose_kernel(const float *__restrict__ x, int ld, int n, int d, float *__restrict__ xt, int ldt)
+{
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, j0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int rr = ty; rr < 32; rr += 8) tile[rr][tx] = (j0 + rr < n) ? x[((size_t)b * n + j0 + rr) * ld + c0 + tx] : 0.f;
+    __syncthreads();
+    for (int cc = ty; cc < 32; cc += 8) xt[((size_t)b * d + c0 + cc) * ldt + j0 + tx] = tile[tx][cc];
+}
+
+// does the fused (matrix-free) kernel serve this shape?
+static bool knn_feat_fused_ok(int n, int d)
+{
+    return (d == 128 || d == 256) && tgp_cdiv(n, 32) * 32 <= KF_MAX_LDW;
+}
+
 extern "C" int64_t tgp_knn_feat_workspace_bytes(int B, int n, int d)
 {
-    (void)d;
     if (B <= 0 || n <= 0) return 0;
-    return ((int64_t)B * n * n + (int64_t)B * n) * (int64_t)sizeof(float);
+    // the squared norms always; beside them the transposed features (fused kernel) or the (B, n, n) distance matrix (the shapes the
+    // fused kernel does not serve)
+    const int64_t extra = knn_feat_fused_ok(n, d) ? (int64_t)B * d * (tgp_cdiv(n, 32) * 32) : (int64_t)B * n * n;
+    return (extra + (int64_t)B * n) * (int64_t)sizeof(float);
+}
+
+template <int DIM, int NT, int CH>
+static int launch_knn_fused(const float *xt, const float *q, int B, int n, int k, int32_t *idx, hipStream_t stream)
+{
+    const int nrb = tgp_cdiv(n, KF_ROWS), ncb = tgp_cdiv(n, 32), ldw = ncb * 32;
+    const size_t lds = (size_t)KF_ROWS * ldw * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(knn_feat_fused_kernel<DIM, NT, CH>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, KF_ROWS * KF_MAX_LDW * (int)sizeof(float));
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((knn_feat_fused_kernel<DIM, NT, CH>), dim3(tgp_xcd_grid(B, nrb)), dim3(512), lds, stream, xt, q, B, n, k, idx, nrb, ncb,
+                       ldw, tgp_knn_stamps);
+    return TGP_LAUNCH_RESULT();
 }
 
 extern "C" int tgp_knn_feat(const float *feat, int ld, int B, int n, int d, int k, int32_t *idx, void *workspace,
@@ -397,17 +646,31 @@ extern "C" int tgp_knn_feat(const float *feat, int ld, int B, int n, int d, int 
     if (d <= 0 || (d & 31) || (d >> 5) >= 16) return TGP_EUNSUPPORTED;
     TGP_REQUIRE(ld >= d && (ld & 3) == 0);
     TGP_REQUIRE(workspace_bytes >= tgp_knn_feat_workspace_bytes(B, n, d));
-    float *D = reinterpret_cast<float *>(workspace);   // (B,n,n) distance matrix, then (B,n) squared norms
-    float *q = D + (size_t)B * n * n;
+    const bool fused = knn_feat_fused_ok(n, d);
+    const int ldt = tgp_cdiv(n, 32) * 32;
+    float *D = reinterpret_cast<float *>(workspace);   // the transposed features or the (B,n,n) distance matrix, then (B,n) squared norms
+    float *q = D + (fused ? (size_t)B * d * ldt : (size_t)B * n * n);
     const int64_t rows = (int64_t)B * n;
     hipLaunchKernelGGL(sqnorm_aten_kernel, dim3(tgp_cdiv(rows * 8, 256)), dim3(256), 0, tgp_hs(stream), feat, ld, rows,
                        d, q);
+    const int nt = tgp_cdiv(n, 64);
+    if (fused) {
+        hipLaunchKernelGGL(knn_transpose_kernel, dim3(ldt / 32, d / 32, B), dim3(256), 0, tgp_hs(stream), feat, ld, n, d, D, ldt);
+#define LAUNCH_FUSED(NT) \
+    (d == 128 ? launch_knn_fused<128, NT, 16>(D, q, B, n, k, idx, tgp_hs(stream)) : launch_knn_fused<256, NT, 16>(D, q, B, n, k, idx, tgp_hs(stream)))
+        if (nt <= 1) return LAUNCH_FUSED(1);
+        if (nt <= 2) return LAUNCH_FUSED(2);
+        if (nt <= 5) return LAUNCH_FUSED(5);
+        if (nt <= 8) return LAUNCH_FUSED(8);
+        if (nt <= 17) return LAUNCH_FUSED(17);
+        return LAUNCH_FUSED(19);
+#undef LAUNCH_FUSED
+    }
     int rc = tgp_launch_dist_gemm(feat, ld, q, B, n, d, D, tgp_hs(stream));
     if (rc) return rc;
     const int rpb = knn_rows_per_block(B, n);
     const int tiles = tgp_cdiv(n, rpb);
     const dim3 grid(tgp_xcd_grid(B, tiles)), block(256);
-    const int nt = tgp_cdiv(n, 64);
 #define LAUNCH_MAT(NT) hipLaunchKernelGGL(knn_matrix_kernel<NT>, grid, block, 0, tgp_hs(stream), D, B, n, k, idx, tiles, rpb)
     if (nt <= 1) LAUNCH_MAT(1);
     else if (nt <= 2) LAUNCH_MAT(2);
