@@ -341,7 +341,8 @@ def main():
         db = {k: v.to(dev) for k, v in train_batch(B, N_POINTS, 7 + rank).items()}
         if args.graph:
             # both forwards + losses + backward replayed as one hipGraph; the collective, the clip and the optimizer step stay eager
-            graphed_step = trainer.graphed_step(db)
+            # (two graphs split at the encoder's output: the late layers' gradient bucket is exchanged while the encoder's backward runs)
+            graphed_step = trainer.graphed_step(db, overlap=True)
 
             def step():
                 loss = graphed_step()
@@ -465,7 +466,8 @@ def main():
                        else ("the reference's RL_TDA_train_step (trainer/RL_TDA.py:110-226): net1 = PoseNet9D training-mode forward "
                              "with autograd, net2 = PoseNet9D(only_encoder) under no_grad on the augmented cloud, feat_consistency + 2x "
                              "prop_sym_matching, the 14 control_loss('TDA') terms, total = 0.1 (con + recon_1 + recon_cons) + 0.9 sum(TDA), "
-                             "backward, gradient all-reduce, clip_grad_norm_(5), SGD step; B=%d objects per GPU, N=%d points sampled "
+                             "backward in two captured segments with the bucketed gradient exchange (reduce-scatter + all-gather) overlapping the second, "
+                             "clip_grad_norm_(5), SGD step; B=%d objects per GPU, N=%d points sampled "
                              "from the six obj_model category clouds with their pdh1/pdh2 priors" % (B, N_POINTS)),
                        "objects_per_gpu": B, "points": N_POINTS, "replicas": world, "batches_in_flight": len(streams),
                        "hipgraph": {0: "off", 1: "whole batch" if replayers is None else "whole batch, one captured forward per stream",

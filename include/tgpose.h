@@ -296,6 +296,10 @@ int tgp_colmax_arg(const float *x, int ld, int objects, int n, int C, const floa
                    const float *gamma, const float *beta, int act, float slope, const float *slope_vec, float *out, int ldo,
                    int *argrow, int lda, tgp_stream_t stream);
 
+/* out[o][c] = sum over object o's n rows of dy (objects*n, C): gradient of a per-object bias broadcast over the object's points
+ * (gcn3d.py:108-112 ORL_forward's global half; FaceRecon.py:165); fixed summation order. */
+int tgp_colsum_objects(const float *dy, int ld, int objects, int n, int C, float *out, int ldo, tgp_stream_t stream);
+
 /* Backward of tgp_colmax_arg without BatchNorm (PoseNet9D.py:50 feat_global = feat.max over points): dx (objects*rows_per_obj, C)
  * = dpool[o][c] on the recorded winning row, 0 elsewhere; written densely, deterministic. */
 int tgp_colmax_bwd(const float *dpool, int ldp, const int *argrow, int lda, int objects, int rows_per_obj, int C, float *dx, int lddx,

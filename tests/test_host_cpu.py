@@ -33,7 +33,10 @@ def test_c_abi_argument_errors_do_not_launch():
     from tgpose_amd import _lib
     h = _lib.lib()
     assert h.tgp_knn_xyz(None, 1, 64, 8, None, None) == -1
-    assert h.tgp_knn_feat_workspace_bytes(2, 100, 128) == (2 * 100 * 100 + 2 * 100) * 4
+    # fused (matrix-free) shapes need the transposed features + the squared norms; the others the (B, n, n) matrix + the norms
+    assert h.tgp_knn_feat_workspace_bytes(2, 100, 128) == (2 * 128 * 128 + 2 * 100) * 4
+    assert h.tgp_knn_feat_workspace_bytes(2, 100, 64) == (2 * 100 * 100 + 2 * 100) * 4
+    assert h.tgp_knn_feat_workspace_bytes(32, 1028, 128) < 32 * 1028 * 1028
     assert h.tgp_orl_partial_floats(2, 1028, 128) == 2 * 17 * 128
     a = _lib.GemmArgs()
     assert h.tgp_gemm_f32(a, None) == -1
@@ -192,6 +195,48 @@ def test_gradient_allreduce_two_ranks_gloo():
         a, b = torch.tensor(a), torch.tensor(b)
         want = torch.full_like(a, 1.5) * (i + 1) + torch.arange(a.numel(), dtype=torch.float32) * 1e-3
         assert torch.allclose(a, want) and torch.equal(a, b)
+
+
+def _bucket_worker(rank, world, port, q, done):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tgpose_amd import shard
+    names = ["face_all.encoder.conv_1.weights", "face_all.encoder.proj_layer.0.weight", "face_all.ph_pred.linear1.weight",
+             "rot_green.conv1.weight", "face_all.encoder.bn1.bias", "ts.conv4.bias", "face_all.decoder.recon_head.3.weight"]
+    shapes = [(128, 1024), (40, 40), (64, 257), (33, 7), (128,), (6,), (3, 128)]
+    params = [(n, torch.nn.Parameter(torch.zeros(s))) for n, s in zip(names, shapes)]
+    late = ("face_all.ph_pred.", "face_all.decoder.", "rot_green.", "rot_red.", "ts.")
+    b = shard.GradBuckets(params, late)
+    assert all(p.grad is not None for _, p in params)
+    for i, (n, p) in enumerate(params):                      # what a backward pass does: accumulate into the existing .grad (a view)
+        p.grad += torch.full_like(p, float(rank + 1)) * (i + 1) + torch.arange(p.numel(), dtype=torch.float32).view_as(p) * 1e-3
+    h0 = b.reduce(0)                                         # the late layers' bucket travels ...
+    dummy = sum(float(p.sum()) for _, p in params[:1])       # ... while this rank keeps computing
+    h1 = b.reduce(1)
+    b.wait(h0), b.wait(h1)
+    views_ok = all(p.grad.data_ptr() >= f.data_ptr() and p.grad.data_ptr() < f.data_ptr() + f.numel() * 4
+                   for f, ps in zip(b.flat, b.params) for p in ps)
+    q.put((rank, [p.grad.reshape(-1).tolist() for _, p in params], views_ok, [f.numel() for f in b.flat], dummy))
+    done.wait(timeout=120)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_overlapped_gradient_exchange_two_ranks_gloo():
+    """shard.GradBuckets as the overlapped step uses it: gradients accumulate into views of two flat buckets (late layers /
+    encoder), bucket 0's exchange is started before bucket 1's "backward" is over, both ranks end with the same averaged
+    gradients; the never-used proj_layer is not sent (each rank keeps its own)."""
+    res = _run_two_ranks(_bucket_worker, 33500 + os.getpid() % 2000)
+    (_, g0, ok0, n0, _), (_, g1, ok1, n1, _) = res
+    assert ok0 and ok1 and n0 == n1 and all(n % 8 == 0 for n in n0)
+    for i, (a, b) in enumerate(zip(g0, g1)):
+        a, b = torch.tensor(a), torch.tensor(b)
+        base = torch.arange(a.numel(), dtype=torch.float32) * 1e-3
+        if i == 1:                                            # proj_layer: not exchanged
+            assert torch.allclose(a, base + 2.0) and torch.allclose(b, base + 4.0)
+            continue
+        assert torch.allclose(a, base + 1.5 * (i + 1)) and torch.equal(a, b), i
 
 
 def test_input_side_host_packing_and_category_tables():

@@ -73,6 +73,7 @@ SIGNATURES = {
                                   c_int, c_f32, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "tgp_colmax_arg": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_int, c_f32, c_vp, c_vp,
                                c_int, c_vp, c_int, c_vp]),
+    "tgp_colsum_objects": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     "tgp_colmax_bwd": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     "tgp_transpose": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     "tgp_gconv_bwd_workspace_floats": (c_i64, [c_int, c_int, c_int]),

@@ -220,6 +220,23 @@ class _GatherRows(Function):
         return ops.gather_rows_bwd(dy.contiguous(), near, ctx.n_src), None
 
 
+class _AddRowBias(Function):
+    """x (B, n, C) + rb (B, C) broadcast over each object's points.  The backward's sum over the points is tgp_colsum_objects,
+    not torch's sum: a multi-block torch reduction inside the captured step did not replay reliably."""
+
+    @staticmethod
+    def forward(ctx, x, rb):
+        return x + rb.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, ops.colsum_objects(dy.contiguous())
+
+
+def add_row_bias(x, rb):
+    return _AddRowBias.apply(x, rb)
+
+
 class _ColMax(Function):
     """feat_global = feat.max over an object's points (PoseNet9D.py:50): x (B, n, C) rows (row stride >= C) -> (B, C); first row
     wins ties and NaN propagates, as torch.max; the gradient lands on the winning row"""
@@ -250,7 +267,7 @@ def _orl(layer, g, idx_orl):
     C = g.shape[-1]
     w = layer.conv2.weight[:, :, 0]
     glob = _NbrMaxMean.apply(g, idx_orl)                                  # (B, C)
-    return linear(g, w[:, :C]) + linear(glob, w[:, C:]).unsqueeze(1) + g
+    return add_row_bias(linear(g, w[:, :C]), linear(glob, w[:, C:])) + g
 
 
 def _surface(layer, xyz, graphs, kmax):
@@ -340,7 +357,7 @@ def decoder(dec, feat, back):
     w0 = _w_feat(blk[0])
     x = linear(feat, w0, blk[0].bias)
     if back is not None:
-        x = x + linear(F.pad(back, (0, FEAT_LD - back.shape[1])), w0).unsqueeze(1)
+        x = add_row_bias(x, linear(F.pad(back, (0, FEAT_LD - back.shape[1])), w0))
     x = bn_act(x, blk[1])
     x = bn_act(linear(x, blk[3].weight[:, :, 0], blk[3].bias), blk[4])
     x = bn_act(linear(x, blk[6].weight[:, :, 0], blk[6].bias), blk[7])
@@ -357,17 +374,19 @@ def point_head(hd, feat):
     return linear(x, hd.conv4.weight[:, :, 0], hd.conv4.bias)
 
 
-def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6):
-    """PoseNet9D.forward (PoseNet9D.py:33-91) with autograd; net is the drop-in module (training mode)."""
+def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6, cut=None):
+    """PoseNet9D.forward (PoseNet9D.py:33-91) with autograd; net is the drop-in module (training mode).
+    cut: an EncoderCut to split the backward at the encoder's output `feat` (GraphedStep's two-segment form: everything after
+    `feat` is differentiated first, the encoder afterwards, so that the late layers' gradients can travel meanwhile)."""
     B, N, _ = points.shape
     if B < 2:
         raise ValueError("Expected more than 1 value per channel when training, got input size [%d, 256]" % B)
     if sample_idx is None:
         sample_idx = engine.draw_sample_idx(N)
     points = points.contiguous().float()
-    mean = points.mean(dim=1, keepdim=True)
-    with torch.no_grad():
-        xyz, _ = ops.center(points)            # bit-identical to the reference's centring (kNN indices depend on it)
+    with torch.no_grad():                      # the clouds are data: no gradient flows to them
+        xyz, mean = ops.center(points)         # bit-identical to the reference's centring (kNN indices depend on it)
+        mean = mean.unsqueeze(1)
     if net.only_encoder:
         face = net.face_enc
         graphs = _GraphSource(points.device, inject, record, "face_enc.encoder.")
@@ -376,6 +395,8 @@ def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=Non
     face = net.face_all
     graphs = _GraphSource(points.device, inject, record, "face_all.encoder.")
     feat = encoder(face.encoder, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
+    if cut is not None:
+        feat = cut.split(feat)
     back, h1, h2 = ph_predictor(face.ph_pred, feat)
     recon = decoder(face.decoder, feat, back)
     green = point_head(net.rot_green, feat)
@@ -395,6 +416,30 @@ def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=Non
         out["feat"] = feat[:, :, :FEAT_C]
         out["feat_global"] = colmax(feat[:, :, :FEAT_C])
     return out
+
+
+class EncoderCut(object):
+    """Splits one backward pass at the encoder's output: the layers after `feat` see a detached copy that collects d loss / d feat;
+    ``backward_encoder()`` then pushes that gradient through the encoder.  Two calls instead of one ``loss.backward()``, same
+    gradients (the encoder's only consumer is `feat`)."""
+
+    def __init__(self):
+        self.feat = self.leaf = None
+
+    def split(self, feat):
+        self.feat = feat
+        self.leaf = feat.detach().requires_grad_(True)
+        return self.leaf
+
+    def backward_encoder(self):
+        self.feat.backward(self.leaf.grad)
+
+    def clear(self):
+        self.feat = self.leaf = None
+
+
+# parameters whose gradients are complete when the first backward segment (everything after the encoder) ends
+LATE_PREFIXES = ("face_all.ph_pred.", "face_all.decoder.", "rot_green.", "rot_red.", "ts.")
 
 
 class GraphedStep(object):
@@ -419,7 +464,11 @@ class GraphedStep(object):
 
     _FOREIGN = "AccumulateGrad node's stream does not match"
 
-    def __init__(self, params, step_fn, cloud_sizes, device):
+    def __init__(self, params, step_fn, cloud_sizes, device, cut=None, between=None, after=None):
+        """cut: an EncoderCut that step_fn hands to net1's forward.  The step is then captured as TWO graphs sharing one memory
+        pool -- (1) forwards + loss + backward of everything after the encoder, (2) the encoder's backward -- and replayed with
+        ``between()`` called after the first has been enqueued (the data-parallel trainer starts the late layers' gradient
+        exchange there: it overlaps the encoder's backward) and ``after()`` after the second."""
         import warnings
         dev = torch.device(device)
         self.params, self.sizes = list(params), [int(n) for n in cloud_sizes]
@@ -429,6 +478,7 @@ class GraphedStep(object):
         self._s12 = torch.zeros(total, dtype=torch.int32, device=dev)
         self.samples = [(torch.zeros(a, dtype=torch.int32, device=dev), torch.zeros(b, dtype=torch.int32, device=dev))
                         for a, b in self.counts]
+        self.cut, self.between, self.after = cut, between, after
 
         def run():
             o = 0
@@ -439,6 +489,9 @@ class GraphedStep(object):
             loss = step_fn(self.samples)
             loss.backward()
             return loss.detach()         # nothing keeps the step's autograd graph (and its AccumulateGrad nodes) alive
+
+        def run2():
+            cut.backward_encoder()
 
         warm = torch.cuda.Stream(device=dev)
         warm.wait_stream(torch.cuda.current_stream(dev))
@@ -452,6 +505,9 @@ class GraphedStep(object):
                     self._zero()
                     try:
                         run()
+                        if cut is not None:
+                            run2()
+                            cut.clear()
                     except (UserWarning, RuntimeError) as e:
                         if self._FOREIGN not in str(e):
                             raise
@@ -467,6 +523,13 @@ class GraphedStep(object):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=warm):     # the stream the warm-up ran on
             self.loss = run()
+        self.graph2 = None
+        if cut is not None:
+            # the encoder's saved activations live in the first graph's pool: the second graph shares it and always replays after the first
+            self.graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph2, stream=warm, pool=self.graph.pool()):
+                run2()
+            cut.clear()
 
     def _zero(self):
         for p in self.params:
@@ -482,6 +545,12 @@ class GraphedStep(object):
         self._draw(sample_idx)
         self._zero()
         self.graph.replay()
+        if self.graph2 is not None:
+            if self.between is not None:
+                self.between()
+            self.graph2.replay()
+        if self.after is not None:
+            self.after()
         return self.loss
 
 

@@ -457,6 +457,34 @@ extern "C" int tgp_colmax_arg(const float *x, int ld, int objects, int n, int C,
     return TGP_LAUNCH_RESULT();
 }
 
+// out[o][c] = sum over the object's n rows of dy: the gradient of a per-object bias that was broadcast over the object's points
+// (ORL_forward's global half, gcn3d.py:108-112; the PH back-projection in front of the decoder, FaceRecon.py:165).  64 channels x 4
+// contiguous row slices per workgroup, the four partial sums combined in slice order: deterministic.  (torch's own sum over the
+// point dimension is a multi-block reduction with semaphores, which did not survive hipGraph replay reliably: the backward of the
+// captured step keeps to this library's kernels.)
+__global__ __launch_bounds__(256) void colsum_objects_kernel(const float *__restrict__ dy, int ld, int n, int C, float *__restrict__ out, int ldo)
+{
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int slice = threadIdx.x >> 6;
+    const int o = blockIdx.y;
+    const int64_t r0 = (int64_t)o * n;
+    const int64_t ra = r0 + (int64_t)n * slice / 4, rb = r0 + (int64_t)n * (slice + 1) / 4;
+    float acc = 0.f;
+    if (c < C)
+        for (int64_t r = ra; r < rb; ++r) acc += dy[r * ld + c];
+    part[slice][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (slice == 0 && c < C) out[(int64_t)o * ldo + c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+}
+
+extern "C" int tgp_colsum_objects(const float *dy, int ld, int objects, int n, int C, float *out, int ldo, tgp_stream_t stream)
+{
+    TGP_REQUIRE(dy && out && objects > 0 && n > 0 && C > 0 && ld >= C && ldo >= C);
+    hipLaunchKernelGGL(colsum_objects_kernel, dim3(tgp_cdiv(C, 64), objects), dim3(256), 0, tgp_hs(stream), dy, ld, n, C, out, ldo);
+    return TGP_LAUNCH_RESULT();
+}
+
 // backward of out[o][c] = max over the object's rows of x: dx[r][c] = dpool[o][c] where r is the recorded winning row, 0 elsewhere.
 // Dense write (every element exactly once: no atomics, no zero-fill pass), coalesced across channels.
 __global__ __launch_bounds__(256) void colmax_bwd_kernel(const float *__restrict__ dpool, int ldp, const int *__restrict__ argrow, int lda,

@@ -45,7 +45,7 @@ class PoseNet9D(_WithBuffers):
             self._pk_bsig = tuple((b.data_ptr(), b._version) for b in self.buffers())
         return self._pk
 
-    def forward(self, points, obj_id, enable_proj=False, *, sample_idx=None, inject=None, record=None):
+    def forward(self, points, obj_id, enable_proj=False, *, sample_idx=None, inject=None, record=None, cut=None):
         if enable_proj:
             raise NotImplementedError("enable_proj=True is never used by the reference's train/eval path")
         if not points.is_cuda:
@@ -54,7 +54,7 @@ class PoseNet9D(_WithBuffers):
             # differentiable path: the same kernels composed as torch.autograd.Functions (tgpose_amd/autograd.py)
             from ... import autograd as tgp_autograd
             return tgp_autograd.posenet_forward(self, points, obj_id, bool(FLAGS.train), sample_idx, inject, record,
-                                                FLAGS.gcn_n_num, FLAGS.obj_c)
+                                                FLAGS.gcn_n_num, FLAGS.obj_c, cut=cut)
         pk = self.packed(points.device)
         with torch.no_grad():
             if self.training:

@@ -682,6 +682,15 @@ def colmax_arg(x, objects, n, bn=None, act=0, slope=0.0, slope_vec=None, eps=1e-
     return out, arg
 
 
+def colsum_objects(dy):
+    """dy (B, n, C) rows -> (B, C): sum over each object's points, fixed order"""
+    dy, ld = _rows(dy, "dy")
+    B, n, C = dy.shape
+    out = torch.empty(B, C, device=dy.device, dtype=torch.float32)
+    check(_lib.lib().tgp_colsum_objects(_p(dy), ld, B, n, C, _p(out), C, _stream(dy)), "tgp_colsum_objects")
+    return out
+
+
 def colmax_bwd(dpool, argrow, rows_per_obj, dx=None):
     """backward of colmax_arg(x) without BatchNorm: dpool (objects, C), argrow (objects, C) int32 -> dense dx (objects * n, C)"""
     objects, C = dpool.shape

@@ -81,3 +81,72 @@ def allreduce_gradients(params, bucket_bytes=64 << 20, average=True):
             g.copy_(flat[o:o + g.numel()].view_as(g))
             o += g.numel()
     return len(buckets)
+
+
+class GradBuckets(object):
+    """Flat gradient storage for the data-parallel step, in the order the backward pass completes it.
+
+    Bucket 0 holds the layers AFTER the encoder (PH predictor 60 MB, the three heads 20 MB, the decoder 4 MB: 77 % of the
+    109.7 MB); their gradients are final when the first backward segment ends, so their exchange runs on RCCL's stream WHILE
+    the encoder's backward (bucket 1: 12 MB + the never-used proj_layer's 13 MB, which stays zero and is not sent) is still
+    computing (autograd.GraphedStep's two-segment form).  Every ``p.grad`` is a view into its bucket's flat fp32 buffer: one
+    collective per bucket, no packing copies.
+
+    The exchange is reduce-scatter + all-gather on the flat buffer (each rank averages its 1/world slice in between): with RCCL
+    over xGMI both halves move (world-1)/world of the bucket per GPU spread over all peers' links, where a call per tensor would
+    pay 164 launch latencies and a ring over one link.  Backends without reduce_scatter_tensor (gloo: the CPU rehearsal and
+    the tests) use one all-reduce per bucket.  Unmeasured on more than one GPU in this repository (no multi-GPU box is available
+    to the build): correctness is covered by the two-rank gloo test, the overlap by construction."""
+
+    def __init__(self, named_params, late_prefixes, skip=("proj_layer",)):
+        named = [(n, p) for n, p in named_params if p.requires_grad]
+        groups = [[(n, p) for n, p in named if n.startswith(tuple(late_prefixes)) and not any(s in n for s in skip)],
+                  [(n, p) for n, p in named if not n.startswith(tuple(late_prefixes)) and not any(s in n for s in skip)]]
+        self.unsent = [p for n, p in named if any(s in n for s in skip)]
+        self.flat, self.params = [], []
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        for g in groups:
+            numel = sum(p.numel() for _, p in g)
+            pad = (-numel) % (world * 4)                       # equal 16-byte-aligned slices for reduce-scatter
+            dev = g[0][1].device if g else "cpu"
+            flat = torch.zeros(numel + pad, device=dev, dtype=torch.float32)
+            o = 0
+            for _, p in g:
+                p.grad = flat[o:o + p.numel()].view_as(p)
+                o += p.numel()
+            self.flat.append(flat)
+            self.params.append([p for _, p in g])
+        for p in self.unsent:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+
+    def zero_(self):
+        for f in self.flat:
+            f.zero_()
+
+    def reduce(self, i, async_op=True):
+        """start the exchange of bucket i (average over the ranks); returns a handle for wait().  No-op without a process group."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return None
+        flat, world, rank = self.flat[i], dist.get_world_size(), dist.get_rank()
+        if dist.get_backend() == "nccl":
+            shard = flat.view(world, -1)[rank]
+            w1 = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, async_op=True)
+            return ("rs", i, w1, shard)
+        if flat.is_cuda:
+            torch.cuda.current_stream(flat.device).synchronize()     # gloo stages device tensors through the host (rehearsal only)
+        return ("ar", i, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op), None)
+
+    def wait(self, handle):
+        if handle is None:
+            return
+        kind, i, work, shard = handle
+        world = dist.get_world_size()
+        if kind == "rs":
+            work.wait()                                          # the compute stream now waits for the reduce-scatter
+            shard.div_(world)
+            dist.all_gather_into_tensor(self.flat[i], shard)
+        else:
+            if work is not None:
+                work.wait()
+            self.flat[i].div_(world)

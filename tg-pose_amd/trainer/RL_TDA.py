@@ -52,6 +52,7 @@ class RT_TDA_Trainer(object):
         self.optimizer = None
         self.scheduler = None
         self._graphed = None
+        self._buckets = None
 
     def setup(self, mode, optimizer=None, scheduler=None):
         self.init_network(mode)
@@ -93,7 +94,7 @@ class RT_TDA_Trainer(object):
         loss_dict['TDA_loss'] = self.loss_tda_net(self.name_TDA_list, pred_TDA_list, gt_TDA_list, sym, gt_pred_flag)
         return loss_dict
 
-    def RL_TDA_train_step(self, db, only_TDA=False, gt_pred_flag=False, *, sample_idx=None, inject=None):
+    def RL_TDA_train_step(self, db, only_TDA=False, gt_pred_flag=False, *, sample_idx=None, inject=None, cut=None):
         """trainer/RL_TDA.py:110-200.  db: the loader's batch dict (tensors on any device).  sample_idx: optionally the
         subsamples of the two forwards, [(pool_1, pool_2) of net1, (pool_1, pool_2) of net2] (drawn from torch's global CPU
         generator in that order otherwise, as the reference does); inject: neighbour graphs for parity tests."""
@@ -102,7 +103,7 @@ class RT_TDA_Trainer(object):
         PC, obj_id = db['pcl_in'], db['cat_id']
         FLAGS.train = 1                                           # the trainer runs with FLAGS.train set (engine/train.py)
         s = sample_idx if sample_idx is not None else [None, None]
-        results = self.net1(PC, obj_id, sample_idx=s[0], inject=inject)
+        results = self.net1(PC, obj_id, sample_idx=s[0], inject=inject, cut=cut)
         results_2 = None
         if not only_TDA:
             with torch.no_grad():
@@ -119,9 +120,11 @@ class RT_TDA_Trainer(object):
     # -------------------------------------------------------------------------------------------------------------------
     def finish_step(self):
         """what follows total_loss.backward() in the loop (:223-226), with the data-parallel gradient exchange in front: the
-        clip must see the averaged gradients"""
+        clip must see the averaged gradients.  After a graphed_step(overlap=True) replay the exchange has already
+        run (bucket by bucket, overlapped with the backward)."""
         from .. import shard
-        shard.allreduce_gradients(self.net1.parameters())
+        if self._buckets is None:
+            shard.allreduce_gradients(self.net1.parameters())
         torch.nn.utils.clip_grad_norm_(self.net1.parameters(), 5)
         if self.optimizer is not None:
             self.optimizer.step()
@@ -138,21 +141,41 @@ class RT_TDA_Trainer(object):
         self.finish_step()
         return total.detach(), loss_dict
 
-    def graphed_step(self, db):
-        """Capture forward (both nets) + losses + backward for batches of db's shapes as ONE hipGraph; returns a callable
+    def graphed_step(self, db, overlap=False, _debug=""):
+        """Capture forward (both nets) + losses + backward for batches of db's shapes as hipGraphs; returns a callable
         ``step(db=None, sample_idx=None) -> total loss`` that copies a new batch into the static buffers, replays, and leaves the
         gradients in net1's ``.grad`` buffers (then call finish_step()).  The NaN test of the loop (:217-220) is the caller's:
-        the returned loss is a device scalar."""
-        from ..autograd import GraphedStep
+        the returned loss is a device scalar.
+
+        overlap=True (the data-parallel form): the backward is captured in two segments split at the encoder's output, net1's
+        gradients live in two flat buckets (shard.GradBuckets), and the exchange of the late layers' bucket (84 of 97 MB) is
+        started between the segments, so it runs while the encoder's backward computes; the encoder's bucket follows.  With one
+        process the exchanges are no-ops and the step computes exactly what overlap=False computes."""
+        from ..autograd import GraphedStep, EncoderCut, LATE_PREFIXES
+        from .. import shard
         dev = self.device
         static = {k: v.to(dev).clone() for k, v in db.items() if torch.is_tensor(v)}
         N = static['pcl_in'].shape[1]
+        cut = EncoderCut() if (overlap and "nocut" not in _debug) else None
+        pending = []
 
         def step_fn(samples):
-            _, loss_dict = self.RL_TDA_train_step(static, sample_idx=samples)
+            _, loss_dict = self.RL_TDA_train_step(static, sample_idx=samples, cut=cut)
             return total_loss(loss_dict)
 
-        g = GraphedStep(list(self.net1.parameters()), step_fn, [N, N], dev)
+        between = after = None
+        if overlap and "nobuckets" not in _debug:
+            self._buckets = buckets = shard.GradBuckets(self.net1.named_parameters(), LATE_PREFIXES)
+
+            def between():
+                pending.append(buckets.reduce(0))                 # travels while the encoder's backward computes
+
+            def after():
+                pending.append(buckets.reduce(1))
+                while pending:
+                    buckets.wait(pending.pop(0))
+
+        g = GraphedStep(list(self.net1.parameters()), step_fn, [N, N], dev, cut=cut, between=between, after=after)
 
         def step(db=None, sample_idx=None):
             if db is not None:
