@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 2
+#define TGP_ABI_VERSION 3
 #define TGP_EINVAL (-1)       /* null pointer / non-positive size / misaligned stride */
 #define TGP_EUNSUPPORTED (-2) /* shape outside what the kernels are built for */
 
@@ -74,9 +74,11 @@ int tgp_gconv_surface_fwd(const float *xyz, const int32_t *idx, const float *sdn
 
 /* gcn3d.py:157-180 HS_layer.graph_conv after the dense projection.  proj (B*n, (S+1)*C) row stride
  * ldp holds [centre | support] = feature_map @ weights + bias; idx is the feature-space graph.
- * out = centre + mean_s max_j relu(<dir_j, sdn>) * support[idx_j]. */
+ * out = centre + mean_s max_j relu(<dir_j, sdn>) * support[idx_j].
+ * dirs_ws: scratch of B*n*k*4 floats (16-byte aligned) for the unit neighbour directions (gcn3d.py:48-58), or NULL;
+ * with it, clouds whose support table fits LDS in channel slices take the LDS-staged kernel (same results). */
 int tgp_gconv_hs_fwd(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B,
-                     int n, int k, int S, int C, float *out, int ldo, tgp_stream_t stream);
+                     int n, int k, int S, int C, float *out, int ldo, float *dirs_ws, tgp_stream_t stream);
 
 /* gcn3d.py:210-217 get_ORL_global: g[b,c] = mean_i max_j feat[b, idx[b,i,j], c].
  * partial: scratch of tgp_orl_partial_floats(B,n,C) floats.  out (B,C). */

@@ -31,6 +31,12 @@ extern "C" int tgp_normalize_dirs(const float *directions, int SC, float *out, t
     return TGP_LAUNCH_RESULT();
 }
 
+// Two fp32 lanes per instruction (v_pk_mul_f32 / v_pk_fma_f32 run at the full VALU rate on gfx950, so the <direction, support
+// direction> products cost half the issue slots); each component is the same IEEE operation as the scalar fmaf / multiply.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(const f32x2 a, const f32x2 b, const f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_max(const f32x2 a, const f32x2 b) { return __builtin_elementwise_max(a, b); }
+
 // Lane layout shared by the gather kernels: a row of C floats is covered by C/4 lanes (float4 each).
 //   C = 128: 32 lanes per row, the two wave halves take alternate neighbours (SPLIT = 2)
 //   C = 256: 64 lanes per row
@@ -42,6 +48,10 @@ struct RowLanes {
     static constexpr int CHUNKS = (C / 4 + 63) / 64;
 };
 
+// (Measured and dropped: conv_1's 3.7 MB per-object support table does not quite fit an XCD's 4 MB L2 next to the streams passing
+// through -- FETCH_SIZE shows every row fetched ~6 times, 682 MB per launch -- but splitting the row into two 64-column chunks
+// processed one after the other, so that 1.8 MB stays resident, was slower: 188 vs 134 us.  Half rows mean 256-byte gathers,
+// twice the per-point index / direction work and a padded neighbour slot.)
 template <int C, bool SURFACE>
 __global__ __launch_bounds__(256) void gconv_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ idx,
                                                     const float *__restrict__ proj, int ldp,
@@ -89,40 +99,47 @@ __global__ __launch_bounds__(256) void gconv_kernel(const float *__restrict__ xy
 #pragma unroll
         for (int s = 0; s < GC_S; ++s) m[s] = make_float4(init, init, init, init);
 
-        for (int jj = 0; jj * RL::SPLIT < k; ++jj) {
-            const int j = jj * RL::SPLIT + half;
-            const bool valid = j < k;
-            const int src = valid ? j : 0;
-            const float ux = __shfl(dx, src, 64), uy = __shfl(dy, src, 64), uz = __shfl(dz, src, 64);
-            const int nb = __shfl(nj, src, 64);
-            float4 sup[GC_S];
+        // two neighbours per lane group and iteration, so that the running maxima take both candidates in one v_max3_f32; a slot
+        // past k repeats neighbour 0 (a duplicate candidate cannot change a maximum): no branches, no selects
+        const f32x2 zero2 = {0.f, 0.f};
+        for (int jj = 0; jj * RL::SPLIT < k; jj += 2) {
+            const int j0 = jj * RL::SPLIT + half, j1 = j0 + RL::SPLIT;
+            const int src0 = j0 < k ? j0 : 0, src1 = j1 < k ? j1 : 0;
+            const float ux0 = __shfl(dx, src0, 64), uy0 = __shfl(dy, src0, 64), uz0 = __shfl(dz, src0, 64);
+            const float ux1 = __shfl(dx, src1, 64), uy1 = __shfl(dy, src1, 64), uz1 = __shfl(dz, src1, 64);
+            float4 sup0[GC_S], sup1[GC_S];
             if (!SURFACE) {
-                const float *prow = proj + ((int64_t)b * n + nb) * ldp + C + cb;
+                const float *prow0 = proj + ((int64_t)b * n + __shfl(nj, src0, 64)) * ldp + C + cb;
+                const float *prow1 = proj + ((int64_t)b * n + __shfl(nj, src1, 64)) * ldp + C + cb;
 #pragma unroll
-                for (int s = 0; s < GC_S; ++s) sup[s] = *reinterpret_cast<const float4 *>(prow + s * C);
-            }
-            if (valid) {
+                for (int s = 0; s < GC_S; ++s) sup0[s] = *reinterpret_cast<const float4 *>(prow0 + s * C);
 #pragma unroll
-                for (int s = 0; s < GC_S; ++s) {
-                    float4 t;
-                    t.x = fmaf(uz, sd[s][2].x, fmaf(uy, sd[s][1].x, ux * sd[s][0].x));
-                    t.y = fmaf(uz, sd[s][2].y, fmaf(uy, sd[s][1].y, ux * sd[s][0].y));
-                    t.z = fmaf(uz, sd[s][2].z, fmaf(uy, sd[s][1].z, ux * sd[s][0].z));
-                    t.w = fmaf(uz, sd[s][2].w, fmaf(uy, sd[s][1].w, ux * sd[s][0].w));
-                    t.x = fmaxf(t.x, 0.f), t.y = fmaxf(t.y, 0.f), t.z = fmaxf(t.z, 0.f), t.w = fmaxf(t.w, 0.f);
-                    if (!SURFACE) t.x *= sup[s].x, t.y *= sup[s].y, t.z *= sup[s].z, t.w *= sup[s].w;
-                    m[s].x = fmaxf(m[s].x, t.x), m[s].y = fmaxf(m[s].y, t.y);
-                    m[s].z = fmaxf(m[s].z, t.z), m[s].w = fmaxf(m[s].w, t.w);
-                }
+                for (int s = 0; s < GC_S; ++s) sup1[s] = *reinterpret_cast<const float4 *>(prow1 + s * C);
             }
-        }
-        if (RL::SPLIT == 2) {
+            const f32x2 vx0 = {ux0, ux0}, vy0 = {uy0, uy0}, vz0 = {uz0, uz0}, vx1 = {ux1, ux1}, vy1 = {uy1, uy1}, vz1 = {uz1, uz1};
 #pragma unroll
             for (int s = 0; s < GC_S; ++s) {
-                m[s].x = fmaxf(m[s].x, __shfl_xor(m[s].x, 32, 64));
-                m[s].y = fmaxf(m[s].y, __shfl_xor(m[s].y, 32, 64));
-                m[s].z = fmaxf(m[s].z, __shfl_xor(m[s].z, 32, 64));
-                m[s].w = fmaxf(m[s].w, __shfl_xor(m[s].w, 32, 64));
+                // theta = relu(ux * sx + uy * sy + uz * sz) in the reference's order, channels (x, y) and (z, w) in pairs
+                const f32x2 sxa = {sd[s][0].x, sd[s][0].y}, sya = {sd[s][1].x, sd[s][1].y}, sza = {sd[s][2].x, sd[s][2].y};
+                const f32x2 sxb = {sd[s][0].z, sd[s][0].w}, syb = {sd[s][1].z, sd[s][1].w}, szb = {sd[s][2].z, sd[s][2].w};
+                f32x2 ta0 = pk_fma(vz0, sza, pk_fma(vy0, sya, vx0 * sxa)), tb0 = pk_fma(vz0, szb, pk_fma(vy0, syb, vx0 * sxb));
+                f32x2 ta1 = pk_fma(vz1, sza, pk_fma(vy1, sya, vx1 * sxa)), tb1 = pk_fma(vz1, szb, pk_fma(vy1, syb, vx1 * sxb));
+                if (!SURFACE) {
+                    ta0 = pk_max(ta0, zero2) * f32x2{sup0[s].x, sup0[s].y}, tb0 = pk_max(tb0, zero2) * f32x2{sup0[s].z, sup0[s].w};
+                    ta1 = pk_max(ta1, zero2) * f32x2{sup1[s].x, sup1[s].y}, tb1 = pk_max(tb1, zero2) * f32x2{sup1[s].z, sup1[s].w};
+                }   // (SURFACE: the maxima start at 0, so max(m, relu(t)) = max(m, t))
+                m[s].x = fmaxf(m[s].x, fmaxf(ta0.x, ta1.x)), m[s].y = fmaxf(m[s].y, fmaxf(ta0.y, ta1.y));
+                m[s].z = fmaxf(m[s].z, fmaxf(tb0.x, tb1.x)), m[s].w = fmaxf(m[s].w, fmaxf(tb0.y, tb1.y));
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= RL::LPR; off >>= 1) {           // combine the lane groups that took alternate neighbours
+#pragma unroll
+            for (int s = 0; s < GC_S; ++s) {
+                m[s].x = fmaxf(m[s].x, __shfl_xor(m[s].x, off, 64));
+                m[s].y = fmaxf(m[s].y, __shfl_xor(m[s].y, off, 64));
+                m[s].z = fmaxf(m[s].z, __shfl_xor(m[s].z, off, 64));
+                m[s].w = fmaxf(m[s].w, __shfl_xor(m[s].w, off, 64));
             }
         }
         if (half == 0) {
@@ -143,11 +160,28 @@ __global__ __launch_bounds__(256) void gconv_kernel(const float *__restrict__ xy
 // The wave-per-point kernel above gathers k rows of 7C floats per point from L2: every support row is fetched ~k times
 // (conv_1: 2.4 GB of L2 -> CU traffic per forward for a 118 MB table), and the L2's bandwidth bounds it.  Here a workgroup
 // owns (object, CH channels): it loads that channel slice of the object's table -- [n][7][CH] floats, each element of the
-// table read from global memory exactly once per forward -- plus the object's xyz into LDS, then every thread (point,
-// channel quad) walks its k neighbours with ds_read_b128.  Same per-element arithmetic and order as gconv_kernel (fmaf
-// chain, max over neighbours, sequential mean over the 7 supports): results are bit-identical.
+// table read from global memory exactly once per forward -- into LDS, then every thread (point, channel pair) walks its k
+// neighbours with ds_read_b64.  Same per-element arithmetic and order as gconv_kernel (fmaf chain, max over neighbours,
+// sequential mean over the 7 supports): results are bit-identical.
+// The unit neighbour directions (gcn3d.py:48-58 get_neighbor_direction_norm: a square root and three IEEE divisions per
+// neighbour) do not depend on the channel: computed per thread they were half of this kernel's vector instructions, repeated by
+// the C / 2 threads that share a point.  nbr_dirs_kernel writes them once per (point, neighbour) as float4 into the caller's
+// scratch; the four threads of a point then read the same 16 bytes from L2.
+__global__ void nbr_dirs_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ idx, int B, int n, int k, float4 *__restrict__ dirs)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)B * n * k) return;
+    const int64_t rowi = t / k;
+    const int b = (int)(rowi / n);
+    const float *pc = xyz + rowi * 3;
+    const float *pn = xyz + ((int64_t)b * n + idx[t]) * 3;
+    float dx = pn[0] - pc[0], dy = pn[1] - pc[1], dz = pn[2] - pc[2];
+    const float nrm = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-12f);
+    dirs[t] = make_float4(dx / nrm, dy / nrm, dz / nrm, 0.f);
+}
+
 template <int CH>
-__global__ __launch_bounds__(1024) void gconv_lds_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ idx,
+__global__ __launch_bounds__(1024) void gconv_lds_kernel(const float4 *__restrict__ dirs, const int32_t *__restrict__ idx,
                                                          const float *__restrict__ proj, int ldp, const float *__restrict__ sdn,
                                                          int B, int n, int k, int C, float *__restrict__ out, int ldo)
 {
@@ -155,17 +189,12 @@ __global__ __launch_bounds__(1024) void gconv_lds_kernel(const float *__restrict
     constexpr int QC = CH / 4;                 // float4 chunks per table row segment (fill)
     constexpr int PC = CH / 2;                 // channel pairs per workgroup: a thread owns (point, pair) -- 42 direction
     constexpr int ROW = GC_S * CH;             // registers instead of 84, which keeps 4 waves per SIMD
-    float4 *s_xyz = reinterpret_cast<float4 *>(gl_smem);
-    float *s_tab = gl_smem + 4 * n;
+    float *s_tab = gl_smem;
     int b, chunk;
     if (!tgp_xcd_object_tile(blockIdx.x, B, C / CH, b, chunk)) return;
     const int c0 = chunk * CH;
     const int SC = GC_S * C;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    for (int i = tid; i < n; i += nthr) {
-        const float *pt = xyz + ((int64_t)b * n + i) * 3;
-        s_xyz[i] = make_float4(pt[0], pt[1], pt[2], 0.f);
-    }
     for (int e = tid; e < n * GC_S * QC; e += nthr) {
         const int row = e / (GC_S * QC), rem = e - row * (GC_S * QC);
         const int sidx = rem / QC, q = rem - sidx * QC;
@@ -182,26 +211,23 @@ __global__ __launch_bounds__(1024) void gconv_lds_kernel(const float *__restrict
     __syncthreads();
     for (int i = pl; i < n; i += pstep) {
         const int64_t rowi = (int64_t)b * n + i;
-        const float4 pc = s_xyz[i];
         float2 m[GC_S];
 #pragma unroll
         for (int sidx = 0; sidx < GC_S; ++sidx) m[sidx] = make_float2(-INFINITY, -INFINITY);
         const int32_t *nbrs = idx + rowi * k;
+        const float4 *udir = dirs + rowi * k;
 #pragma unroll 4
         for (int j = 0; j < k; ++j) {
             const int nb = nbrs[j];
-            const float4 pn = s_xyz[nb];
-            float dx = pn.x - pc.x, dy = pn.y - pc.y, dz = pn.z - pc.z;
-            const float nrm = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-12f);
-            const float ux = dx / nrm, uy = dy / nrm, uz = dz / nrm;
+            const float4 u = udir[j];
+            const float ux = u.x, uy = u.y, uz = u.z;
             const float *trow = s_tab + nb * ROW + q * 2;
 #pragma unroll
             for (int sidx = 0; sidx < GC_S; ++sidx) {
                 const float2 sup = *reinterpret_cast<const float2 *>(trow + sidx * CH);
-                float2 t;
-                t.x = fmaf(uz, sd[sidx][2].x, fmaf(uy, sd[sidx][1].x, ux * sd[sidx][0].x));
-                t.y = fmaf(uz, sd[sidx][2].y, fmaf(uy, sd[sidx][1].y, ux * sd[sidx][0].y));
-                t.x = fmaxf(t.x, 0.f) * sup.x, t.y = fmaxf(t.y, 0.f) * sup.y;
+                f32x2 t = pk_fma(f32x2{uz, uz}, f32x2{sd[sidx][2].x, sd[sidx][2].y},
+                                 pk_fma(f32x2{uy, uy}, f32x2{sd[sidx][1].x, sd[sidx][1].y}, f32x2{ux, ux} * f32x2{sd[sidx][0].x, sd[sidx][0].y}));
+                t = pk_max(t, f32x2{0.f, 0.f}) * f32x2{sup.x, sup.y};
                 m[sidx].x = fmaxf(m[sidx].x, t.x), m[sidx].y = fmaxf(m[sidx].y, t.y);
             }
         }
@@ -218,7 +244,7 @@ __global__ __launch_bounds__(1024) void gconv_lds_kernel(const float *__restrict
 // picks the widest channel slice whose table fits with two workgroups per CU (<= 72 KB): measured 137 -> 88 us (n = 257,
 // C = 256), 37 -> 25 us (n = 64, C = 512); larger clouds keep the L2 gather
 template <int CH>
-static int gconv_lds_go(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B, int n, int k,
+static int gconv_lds_go(const float4 *dirs, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B, int n, int k,
                         int C, float *out, int ldo, size_t lds, hipStream_t stream)
 {
     auto fn = gconv_lds_kernel<CH>;
@@ -229,7 +255,7 @@ static int gconv_lds_go(const float *xyz, const int32_t *idx, const float *proj,
         attr_set = true;
     }
     const int threads = lds > 72 * 1024 ? 1024 : 512;
-    hipLaunchKernelGGL(fn, dim3(tgp_xcd_grid(B, C / CH)), dim3(threads), lds, stream, xyz, idx, proj, ldp, sdn, B, n, k, C, out, ldo);
+    hipLaunchKernelGGL(fn, dim3(tgp_xcd_grid(B, C / CH)), dim3(threads), lds, stream, dirs, idx, proj, ldp, sdn, B, n, k, C, out, ldo);
     return TGP_LAUNCH_RESULT();
 }
 
@@ -241,18 +267,22 @@ static constexpr int tgp_gconv_lds_mode = 1;
 #endif
 
 static int gconv_lds_launch(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B, int n, int k,
-                            int C, float *out, int ldo, hipStream_t stream, bool &done)
+                            int C, float *out, int ldo, float *dirs_ws, hipStream_t stream, bool &done)
 {
     done = false;
-    if (!tgp_gconv_lds_mode) return 0;
-    auto bytes = [&](int ch) { return (size_t)n * (GC_S * ch + 4) * sizeof(float); };
+    if (!tgp_gconv_lds_mode || !dirs_ws) return 0;          // without the directions' scratch: the L2-gather kernel
+    auto bytes = [&](int ch) { return (size_t)n * GC_S * ch * sizeof(float); };
+    const int ch = (bytes(16) <= 72 * 1024 && C % 16 == 0) ? 16 : (bytes(8) <= 72 * 1024 && C % 8 == 0) ? 8
+                   // a 4-channel slice (n = 1028: 115 KB, one workgroup per CU) measured slower than the L2 gather: 208 vs 168 us
+                   : (tgp_gconv_lds_mode == 2 && bytes(4) <= 150 * 1024) ? 4 : 0;
+    if (!ch) return 0;
     done = true;
-    if (bytes(16) <= 72 * 1024 && C % 16 == 0) return gconv_lds_go<16>(xyz, idx, proj, ldp, sdn, B, n, k, C, out, ldo, bytes(16), stream);
-    if (bytes(8) <= 72 * 1024 && C % 8 == 0) return gconv_lds_go<8>(xyz, idx, proj, ldp, sdn, B, n, k, C, out, ldo, bytes(8), stream);
-    // a 4-channel slice (n = 1028: 131 KB, one workgroup per CU) measured slower than the L2 gather: 208 vs 168 us
-    if (tgp_gconv_lds_mode == 2 && bytes(4) <= 150 * 1024) return gconv_lds_go<4>(xyz, idx, proj, ldp, sdn, B, n, k, C, out, ldo, bytes(4), stream);
-    done = false;
-    return 0;
+    float4 *dirs = reinterpret_cast<float4 *>(dirs_ws);
+    const int64_t nd = (int64_t)B * n * k;
+    hipLaunchKernelGGL(nbr_dirs_kernel, dim3(tgp_cdiv(nd, 256)), dim3(256), 0, stream, xyz, idx, B, n, k, dirs);
+    if (ch == 16) return gconv_lds_go<16>(dirs, idx, proj, ldp, sdn, B, n, k, C, out, ldo, bytes(16), stream);
+    if (ch == 8) return gconv_lds_go<8>(dirs, idx, proj, ldp, sdn, B, n, k, C, out, ldo, bytes(8), stream);
+    return gconv_lds_go<4>(dirs, idx, proj, ldp, sdn, B, n, k, C, out, ldo, bytes(4), stream);
 }
 
 static int gconv_check(const void *xyz, const void *idx, const void *sdn, const void *out, int B, int n, int k, int S,
@@ -290,13 +320,14 @@ extern "C" int tgp_gconv_surface_fwd(const float *xyz, const int32_t *idx, const
 }
 
 extern "C" int tgp_gconv_hs_fwd(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B,
-                                int n, int k, int S, int C, float *out, int ldo, tgp_stream_t stream)
+                                int n, int k, int S, int C, float *out, int ldo, float *dirs_ws, tgp_stream_t stream)
 {
     const int chk = gconv_check(xyz, idx, sdn, out, B, n, k, S, C, ldo);
     if (chk) return chk;
     TGP_REQUIRE(proj && ldp >= (S + 1) * C && (ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(proj) & 15) == 0);
+    TGP_REQUIRE((reinterpret_cast<uintptr_t>(dirs_ws) & 15) == 0);
     bool done = false;
-    const int rc = gconv_lds_launch(xyz, idx, proj, ldp, sdn, B, n, k, C, out, ldo, tgp_hs(stream), done);
+    const int rc = gconv_lds_launch(xyz, idx, proj, ldp, sdn, B, n, k, C, out, ldo, dirs_ws, tgp_hs(stream), done);
     if (done || rc) return rc;
     return gconv_launch<false>(xyz, idx, proj, ldp, sdn, B, n, k, C, out, ldo, tgp_hs(stream));
 }

@@ -150,8 +150,10 @@ def gconv_hs(xyz, idx, proj, sdn, S, C, out=None):
     if out is None:
         out = torch.empty(B, n, C, device=xyz.device, dtype=torch.float32)
     out, ldo = _rows(out, "out")
+    # scratch for the unit neighbour directions: only the LDS-staged kernel (pooled levels) uses it
+    dirs = torch.empty(B * n * k * 4, device=xyz.device, dtype=torch.float32) if n * 7 * 8 * 4 <= 72 * 1024 else None
     check(_lib.lib().tgp_gconv_hs_fwd(_p(xyz), _p(idx), _p(proj), ldp, _p(sdn), B, n, k, S, C, _p(out), ldo,
-                                      _stream(xyz)), "tgp_gconv_hs_fwd")
+                                      _p(dirs), _stream(xyz)), "tgp_gconv_hs_fwd")
     return out
 
 
