@@ -361,6 +361,8 @@ __global__ __launch_bounds__(256) void knn_xyz_kernel(const float *__restrict__ 
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *pts = reinterpret_cast<float4 *>(smem);
+    uint2 *s_list = reinterpret_cast<uint2 *>(smem + (size_t)n * sizeof(float4));          // [4 waves][72]
+    uint32_t *s_lmin = reinterpret_cast<uint32_t *>(s_list + 4 * 72);                         // [4 waves][64]
     int b, tile;
     if (!tgp_xcd_object_tile(blockIdx.x, B, tiles_per_obj, b, tile)) return;
     const float *xb = xyz + (size_t)b * n * 3;
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256) void knn_xyz_kernel(const float *__restrict__ 
         const int i = tile * rpb + r;
         if (i >= n) break;
         const float4 pi = pts[i];
-        float d[NT];
+        uint32_t key[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int j = lane + (t << 6);
@@ -391,9 +393,13 @@ __global__ __launch_bounds__(256) void knn_xyz_kernel(const float *__restrict__ 
                 const float t2 = t1 + pj.w;        // + quadratic.unsqueeze(1)  (column term)
                 dv = t2 + pi.w;                    // + quadratic.unsqueeze(2)  (row term)
             }
-            d[t] = dv;
+            key[t] = tgp_float_key(dv);
         }
-        wave_select<NT>(d, lane, k, idx + ((size_t)b * n + i) * k);
+        // rank-counting selection (no chain of k + 1 wave reductions); clouds with many coincident points can leave more than 64
+        // candidates under its bound: those rows take the serial form
+        int32_t *out = idx + ((size_t)b * n + i) * k;
+        if (!wave_select_ranked<NT>(key, lane, k, out, s_lmin + wave * 64, s_list + wave * 72))
+            wave_select_serial_keys<NT>(key, lane, k, out);
     }
 }
 
@@ -442,7 +448,7 @@ extern "C" int tgp_knn_xyz(const float *xyz, int B, int n, int k, int32_t *idx, 
     const int rpb = knn_rows_per_block(B, n);
     const int tiles = tgp_cdiv(n, rpb);
     const dim3 grid(tgp_xcd_grid(B, tiles)), block(256);
-    const size_t lds = (size_t)n * sizeof(float4);
+    const size_t lds = (size_t)n * sizeof(float4) + 4 * (72 * sizeof(uint2) + 64 * sizeof(uint32_t));
     const int nt = tgp_cdiv(n, 64);
 #define LAUNCH_XYZ(NT) \
     hipLaunchKernelGGL(knn_xyz_kernel<NT>, grid, block, lds, tgp_hs(stream), xyz, B, n, k, idx, tiles, rpb)
