@@ -501,10 +501,15 @@ __global__ __launch_bounds__(256) void sqnorm_aten_kernel(const float *__restric
 //   2. every wave takes four rows out of LDS and selects their k + 1 nearest by (distance, index) with wave_select_ranked.
 // The distances never leave the CU: HBM sees the features once (16.8 MB at B = 32, n = 1028, d = 128) and the index lists
 // (2.6 MB) instead of 2 x 135 MB of matrix.
+// Tail rows.  The LDS block admits one workgroup per CU, so the launch runs in rounds of 256 row blocks, and the network's
+// clouds are 32 m + 4 (1028) or 32 m + 1 (257) rows: a 33rd / 9th block per object with 4 / 1 live rows cost a whole extra
+// round (1056 blocks = 4.1 rounds, 288 = 1.1).  When the tail is that short (n_extra <= 8 rows) those rows ride along instead:
+// block rb < n_extra also takes row 32 * nrb + rb, its distances computed on the vector pipe (the same ascending-k FMA chain,
+// one column per thread and pass) into a 33rd LDS row, selected by wave 7 after its four rows.
 typedef float knn_f32x16 __attribute__((ext_vector_type(16)));
 
 #define KF_ROWS 32
-#define KF_MAX_LDW 1184      // 32 x 1184 x 4 B = 148 KiB of LDS
+#define KF_MAX_LDW 1152      // 33 x 1152 x 4 B = 148.5 KiB of LDS (+ 6.5 KiB of selection scratch)
 
 // xt: the object's features transposed, (B, DIM, ldw) with ldw = 32 * ncb columns (zero beyond n): lane (r, h) of a 32-wide
 // block then reads xt[k = 2 s + h][32 cb + r] -- 32 consecutive floats per half wave, a fully used 128-byte line -- where a
@@ -512,23 +517,27 @@ typedef float knn_f32x16 __attribute__((ext_vector_type(16)));
 // measured: the vector-memory pipe, not the matrix cores, then sets the pace: 43 instead of 18 us per row block).
 template <int DIM, int NT, int CH>   // CH: MFMA steps (k pairs) per prefetched chunk
 __global__ __launch_bounds__(512, 2) void knn_feat_fused_kernel(const float *__restrict__ xt, const float *__restrict__ q, int B, int n, int k,
-                                                                int32_t *__restrict__ idx, int nrb, int ncb, int ldw,
+                                                                int32_t *__restrict__ idx, int nrb, int ncb, int ldw, int n_extra,
                                                                 unsigned long long *stamps)
 {
-    extern __shared__ __attribute__((aligned(16))) float dblk[];      // [32][ldw]
+    extern __shared__ __attribute__((aligned(16))) float dblk[];      // [32 (+ 1 with tail rows)][ldw]
     __shared__ uint32_t s_lmin[8][64];
     __shared__ __attribute__((aligned(16))) uint2 s_list[8][72];
     constexpr int STEPS = DIM / 2;                                    // MFMA steps per column block (k pairs)
     constexpr int NCHUNK = STEPS / CH;
-    static_assert(NCHUNK % 2 == 0, "the chunk ring alternates two register buffers");
+    constexpr int RING = 4;                                           // B-operand chunks in flight: three ahead of the MFMAs
+    static_assert(NCHUNK % RING == 0, "the chunk ring's phase must repeat per column block");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
     int b, rb;
     if (!tgp_xcd_object_tile(blockIdx.x, B, nrb, b, rb)) return;
     const int i0 = rb * KF_ROWS;
+    const bool has_extra = rb < n_extra;                              // workgroup-uniform
+    const int ix = nrb * KF_ROWS + rb;                                // the tail row this block takes along
     const float *xb = xt + (size_t)b * DIM * ldw + (size_t)h * ldw + r;      // + 2 s ldw + 32 cb: the lane's element of step s, block cb
     const float *qb = q + (size_t)b * n;
-    unsigned long long *st = (stamps && threadIdx.x == 0) ? stamps + 4 * (size_t)blockIdx.x : nullptr;   // development builds
+    // development builds: 12 stamps per workgroup -- start, wave 0's phase 1 end, after the barrier, end; then each wave's phase-1 end
+    unsigned long long *st = (stamps && threadIdx.x == 0) ? stamps + 12 * (size_t)blockIdx.x : nullptr;
     if (st) st[0] = __builtin_amdgcn_s_memrealtime();
     {
         // ---- phase 1: distances of rows [i0, i0 + 32) against the column blocks cb = wave, wave + 8, ...
@@ -538,24 +547,30 @@ __global__ __launch_bounds__(512, 2) void knn_feat_fused_kernel(const float *__r
         float qrow[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) qrow[e] = qb[min(i0 + (e & 3) + 8 * (e >> 2) + 4 * h, n - 1)];
-        float buf[2][CH];
+        // a chunk of CH MFMA steps is CH x 64 cycles of matrix work (0.27 us at CH = 8) against ~1 us of loaded L2 latency: with one
+        // chunk of lookahead the matrix cores waited for operands 40 % of this phase; three chunks ahead they do not
+        float buf[RING][CH];
         auto fetch = [&](int cb, int c, float (&dst)[CH]) {
             const float *br = xb + (size_t)2 * c * CH * ldw + cb * 32;
 #pragma unroll
             for (int t = 0; t < CH; ++t) dst[t] = br[(size_t)2 * t * ldw];
         };
-        if (wave < ncb) fetch(wave, 0, buf[0]);
+        if (wave < ncb) {
+#pragma unroll
+            for (int c = 0; c < RING - 1; ++c) fetch(wave, c, buf[c]);
+        }
         for (int cb = wave; cb < ncb; cb += 8) {
             knn_f32x16 acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-            for (int c = 0; c < NCHUNK; ++c) {                        // compile-time chunk index: a[] stays in registers
-                if (c + 1 < NCHUNK) fetch(cb, c + 1, buf[(c + 1) & 1]);
-                else if (cb + 8 < ncb) fetch(cb + 8, 0, buf[0]);      // NCHUNK is even: the next block's first chunk lands in buf[0]
+            for (int c = 0; c < NCHUNK; ++c) {                        // compile-time chunk index: a[] and the ring stay in registers
+                constexpr int AHEAD = RING - 1;
+                if (c + AHEAD < NCHUNK) fetch(cb, c + AHEAD, buf[(c + AHEAD) % RING]);
+                else if (cb + 8 < ncb) fetch(cb + 8, c + AHEAD - NCHUNK, buf[(c + AHEAD) % RING]);   // NCHUNK % RING == 0: same slot
 #pragma unroll
                 for (int t = 0; t < CH; ++t)                          // ascending k: step s = c CH + t takes k = 2 s + h
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c * CH + t], buf[c & 1][t], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c * CH + t], buf[c % RING][t], acc, 0, 0, 0);
             }
             const int col = cb * 32 + r;
             const float qc = qb[min(col, n - 1)];
@@ -568,13 +583,44 @@ __global__ __launch_bounds__(512, 2) void knn_feat_fused_kernel(const float *__r
             }
         }
     }
+    if (has_extra && wave != 0) {
+        // the tail row against every column: inner = x[0] y[0], then fmaf in ascending k -- what the MFMA chain computes.  Done by
+        // waves 1-7, which have one column block less than wave 0 (33 = 8 x 4 + 1): three columns per thread, their chains
+        // interleaved so that 48 loads are in flight, in the shadow of wave 0's fifth block
+        const float *xo = xt + (size_t)b * DIM * ldw;
+        const float qx = qb[ix];
+        const int t0 = (wave - 1) * 64 + lane;
+        for (int cbase = t0; cbase < ldw; cbase += 3 * 448) {
+            const int c0 = cbase, c1 = cbase + 448, c2 = cbase + 896;
+            const int l0 = c0, l1 = min(c1, ldw - 1), l2 = min(c2, ldw - 1);
+            const float x0 = xo[ix];
+            float in0 = x0 * xo[l0], in1 = x0 * xo[l1], in2 = x0 * xo[l2];
+#pragma unroll 16
+            for (int kk = 1; kk < DIM; ++kk) {
+                const float xv = xo[(size_t)kk * ldw + ix];
+                in0 = fmaf(xv, xo[(size_t)kk * ldw + l0], in0);
+                in1 = fmaf(xv, xo[(size_t)kk * ldw + l1], in1);
+                in2 = fmaf(xv, xo[(size_t)kk * ldw + l2], in2);
+            }
+            auto put = [&](int col, float inner) {
+                if (col < ldw) {
+                    const float t1 = inner * -2.0f;
+                    const float t2 = t1 + qb[min(col, n - 1)];
+                    dblk[KF_ROWS * ldw + col] = col < n ? t2 + qx : INFINITY;
+                }
+            };
+            put(c0, in0), put(c1, in1), put(c2, in2);
+        }
+    }
     if (st) st[1] = __builtin_amdgcn_s_memrealtime();
+    if (stamps && lane == 0) stamps[12 * (size_t)blockIdx.x + 4 + wave] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
     if (st) st[2] = __builtin_amdgcn_s_memrealtime();
     // ---- phase 2: four rows per wave
 #pragma unroll 1
-    for (int rr = 0; rr < 4; ++rr) {
-        const int lrow = wave * 4 + rr, i = i0 + lrow;
+    for (int rr = 0; rr < 5; ++rr) {
+        if (rr == 4 && !(has_extra && wave == 7)) break;              // wave-uniform: the tail row is wave 7's fifth
+        const int lrow = rr == 4 ? KF_ROWS : wave * 4 + rr, i = rr == 4 ? ix : i0 + lrow;
         if (i >= n) break;                                            // wave-uniform
         uint32_t key[NT];
         const float *row = dblk + lrow * ldw;
@@ -629,17 +675,20 @@ extern "C" int64_t tgp_knn_feat_workspace_bytes(int B, int n, int d)
 template <int DIM, int NT, int CH>
 static int launch_knn_fused(const float *xt, const float *q, int B, int n, int k, int32_t *idx, hipStream_t stream)
 {
-    const int nrb = tgp_cdiv(n, KF_ROWS), ncb = tgp_cdiv(n, 32), ldw = ncb * 32;
-    const size_t lds = (size_t)KF_ROWS * ldw * sizeof(float);
+    const int ncb = tgp_cdiv(n, 32), ldw = ncb * 32;
+    // a tail of at most 8 rows (and fewer than there are full blocks) rides along with the first blocks instead of forming its own
+    const int tail = n % KF_ROWS, n_extra = (tail > 0 && tail <= 8 && tail <= n / KF_ROWS) ? tail : 0;
+    const int nrb = n_extra ? n / KF_ROWS : tgp_cdiv(n, KF_ROWS);
+    const size_t lds = (size_t)(KF_ROWS + (n_extra ? 1 : 0)) * ldw * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(knn_feat_fused_kernel<DIM, NT, CH>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, KF_ROWS * KF_MAX_LDW * (int)sizeof(float));
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (KF_ROWS + 1) * KF_MAX_LDW * (int)sizeof(float));
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     hipLaunchKernelGGL((knn_feat_fused_kernel<DIM, NT, CH>), dim3(tgp_xcd_grid(B, nrb)), dim3(512), lds, stream, xt, q, B, n, k, idx, nrb, ncb,
-                       ldw, tgp_knn_stamps);
+                       ldw, n_extra, tgp_knn_stamps);
     return TGP_LAUNCH_RESULT();
 }
 
@@ -663,7 +712,7 @@ extern "C" int tgp_knn_feat(const float *feat, int ld, int B, int n, int d, int 
     if (fused) {
         hipLaunchKernelGGL(knn_transpose_kernel, dim3(ldt / 32, d / 32, B), dim3(256), 0, tgp_hs(stream), feat, ld, n, d, D, ldt);
 #define LAUNCH_FUSED(NT) \
-    (d == 128 ? launch_knn_fused<128, NT, 16>(D, q, B, n, k, idx, tgp_hs(stream)) : launch_knn_fused<256, NT, 16>(D, q, B, n, k, idx, tgp_hs(stream)))
+    (d == 128 ? launch_knn_fused<128, NT, 8>(D, q, B, n, k, idx, tgp_hs(stream)) : launch_knn_fused<256, NT, 8>(D, q, B, n, k, idx, tgp_hs(stream)))
         if (nt <= 1) return LAUNCH_FUSED(1);
         if (nt <= 2) return LAUNCH_FUSED(2);
         if (nt <= 5) return LAUNCH_FUSED(5);
