@@ -467,6 +467,30 @@ int tgp_cloud_sample(const uint32_t *recs, const int *counts, const int *det_img
 int tgp_sort_by_parent(const int32_t *near1, const int32_t *near2, int B, int n, int n1, int n2, int32_t *order, int64_t *order64,
                        int32_t *near1_out, int32_t *near2_out, tgp_stream_t stream);
 
+/* The pose heads' conv1 -> BatchNorm(eval) -> ReLU -> conv2 -> BatchNorm(eval) -> ReLU -> max over each object's points as one
+ * kernel (PoseR.py:26-36 Rot_green / Rot_red, PoseTs.py:31-42 Pose_Ts; eval mode), on the factored form of conv1 (this repo's
+ * engine): conv1(feat)[m] = W_fine . fine[m] + p1[idx1[m]] + p2[idx2[m]].  The (M, heads * 1024) activation is never written.
+ *   fine (M, ldf) fp32, K = its live columns (256 < K <= 272 = ldf's first 17 K-tiles); wa_s = tgp_split_f16 planes of the heads'
+ *   conv1 weights over fine, (heads * 1024) rows with ldo = 272; p1 / p2: rows of per-coarse-point products, columns
+ *   head * 1024 + channel at the pointers given, row strides ldp1 / ldp2; idx1 / idx2 (M) rows of p1 / p2 per point;
+ *   bias1 / scale1 / shift1 (heads * 1024): conv1 bias and BatchNorm fold; w2p = tgp_heads_pack_w2(conv2 weights);
+ *   bias2 / scale2 / shift2 (heads * 256); keys (heads, B, 256) order-preserving keys of the maxima (tgp_colmax_decode), zeroed by
+ *   the caller; M = B * rows_per_obj.  Operands beyond fp16's range (65504) give NaN outputs. */
+typedef struct tgp_heads_fused_args {
+    const float *fine; int ldf; int K;
+    const void *wa_s;
+    const float *p1; int ldp1; const int32_t *idx1;
+    const float *p2; int ldp2; const int32_t *idx2;
+    const float *bias1; const float *scale1; const float *shift1;
+    const void *w2p;
+    const float *bias2; const float *scale2; const float *shift2;
+    uint32_t *keys;
+    int M; int rows_per_obj; int B; int heads;
+} tgp_heads_fused_args;
+int tgp_heads_fused(const tgp_heads_fused_args *args, tgp_stream_t stream);
+/* w2 (heads, 256, 1024) fp32 -> heads * 1024 * 256 * 2 fp16 in the kernel's operand order (hi / lo planes, K permuted). */
+int tgp_heads_pack_w2(const float *w2, int heads, void *out, tgp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,7 +88,11 @@ def test_knn_xyz_vs_reference_golden(ops, key, k):
 
 @pytest.mark.parametrize("B,n,d,k,ld", [(2, 1028, 128, 20, 128), (2, 1028, 128, 20, 1292), (3, 257, 128, 20, 128),
                                         (3, 257, 256, 20, 256), (4, 64, 256, 8, 256), (1, 200, 64, 5, 64),
-                                        (1, 96, 448, 8, 448)])
+                                        (1, 96, 448, 8, 448),
+                                        # the fused kernel's tail-row cases: 8 tail rows riding along, 9 in their own block, a tail longer
+                                        # than the number of full blocks, two tail rows on two blocks, the widest cloud it serves
+                                        (2, 264, 128, 20, 128), (2, 265, 128, 20, 128), (2, 40, 256, 8, 256), (2, 66, 128, 8, 128),
+                                        (1, 1152, 128, 20, 128)])
 def test_knn_feat_bit_exact_vs_oracle(ops, B, n, d, k, ld):
     _clib, _, _ = _oracle()
     gen = torch.Generator().manual_seed(n + d)
@@ -1651,6 +1655,31 @@ def test_factored_forward_equals_concat_forward(ops):
     for k in outs[0]:
         d = (outs[0][k] - outs[1][k]).abs().max().item()
         assert d <= 2e-5 * max(1.0, outs[1][k].abs().max().item()), (k, d)
+
+
+@pytest.mark.parametrize("B,N", [(3, 1028), (2, 256), (5, 1028)])
+def test_fused_heads_kernel_equals_two_launch_heads(ops, B, N):
+    """engine.HEADS_FUSED: the heads' conv1 -> BN -> ReLU -> conv2 -> BN -> ReLU -> max as one kernel (csrc/heads_fused.hip)
+    against the same layers as two tile-GEMM launches with the activation in HBM: the pose outputs agree to rounding (conv2 sums
+    its 1024 channels in another order), the other outputs are bit-identical (they do not pass through the heads)."""
+    from tgpose_amd import FLAGS, engine
+    net = _net(7)
+    FLAGS.train = 0
+    pts, obj = synth_points(B, N, 33)
+    torch.manual_seed(3)
+    i1 = torch.randperm(N)[: N // 4]
+    smp = (i1, torch.randperm(N // 4)[: N // 16])
+    outs = []
+    for fused in (True, False):
+        old, engine.HEADS_FUSED = engine.HEADS_FUSED, fused
+        try:
+            outs.append({k: v.clone() for k, v in net(g(pts), g(obj), sample_idx=smp).items()})
+        finally:
+            engine.HEADS_FUSED = old
+    assert net.packed("cuda:0").fact["w2p"] is not None  # the fused kernel did run
+    for k in outs[0]:
+        d = (outs[0][k] - outs[1][k]).abs().max().item()
+        assert d <= 1e-5 * max(1.0, outs[1][k].abs().max().item()), (k, d)
 
 
 # ----------------------------------------------------------------------------------------- evaluation (f-2: mAP)

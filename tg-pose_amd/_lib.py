@@ -43,6 +43,21 @@ class GemmArgs(ctypes.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/tgpose.h declares
+class HeadsFusedArgs(ctypes.Structure):
+    """struct tgp_heads_fused_args (include/tgpose.h)"""
+    _fields_ = [
+        ("fine", c_vp), ("ldf", c_int), ("K", c_int),
+        ("wa_s", c_vp),
+        ("p1", c_vp), ("ldp1", c_int), ("idx1", c_vp),
+        ("p2", c_vp), ("ldp2", c_int), ("idx2", c_vp),
+        ("bias1", c_vp), ("scale1", c_vp), ("shift1", c_vp),
+        ("w2p", c_vp),
+        ("bias2", c_vp), ("scale2", c_vp), ("shift2", c_vp),
+        ("keys", c_vp),
+        ("M", c_int), ("rows_per_obj", c_int), ("B", c_int), ("heads", c_int),
+    ]
+
+
 SIGNATURES = {
     "tgp_version": (c_int, []),
     "tgp_knn_max_points": (c_int, []),
@@ -116,6 +131,8 @@ SIGNATURES = {
     "tgp_dcd_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp]),
     "tgp_generate_rt": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "tgp_canonicalize": (c_int, [c_vp] * 9 + [c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "tgp_heads_fused": (c_int, [ctypes.POINTER(HeadsFusedArgs), c_vp]),
+    "tgp_heads_pack_w2": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "tgp_sort_by_parent": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tgp_roi_cloud": (c_int, [c_vp] * 7 + [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_cloud_select": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, c_vp, c_vp]),

@@ -1,0 +1,296 @@
+// The three pose heads' conv1 -> BatchNorm -> ReLU -> conv2 -> BatchNorm -> ReLU -> max over points as ONE kernel
+// (network/fs_net_repo/PoseR.py:26-36, PoseTs.py:31-42 in eval mode, on the factored form of conv1: DESIGN.md section 3).
+//
+// As two launches the path writes and re-reads the (B*N, 3 x 1024) activation (404 MB at B = 32) and spends most of its time in
+// the first launch's gather epilogue.  Here the activation never leaves the CU.  A wave owns 32 points of one head:
+//   phase 1, per block of 32 conv1 channels:  acc1[channel][point] = W_fine[channel][:] . fine[point][:]   (K = 268, 17 steps of
+//            v_mfma_f32_32x32x16_f16 x 3 split terms; the weights' fp16 planes come from LDS, the points' from registers);
+//   epilogue 1 in registers: + bias + P1[near1(point)] + P2[near2(point)] (the coarse products of the factored layer), BatchNorm
+//            fold, ReLU -- in the two-launch form's order -- then split into fp16 hi / lo;
+//   phase 2: the MFMA accumulator layout gives lane (point r, half h) channels {4h + (e & 3) + 8 (e >> 2)} of the block: exactly a
+//            32x32x16 A-operand fragment (8 k-values per lane) if conv2's K order is permuted accordingly.  The permutation is
+//            applied to W2 when it is packed (heads_pack_w2_kernel), so the 16 values feed two MFMA steps of
+//            acc2[point][out] += H[point][channels] . W2[out][channels] without touching LDS;
+//   after the 32 channel blocks: + bias2, BatchNorm fold, ReLU, max over the object's points as order-preserving keys (atomicMax).
+// One wave per SIMD (the points' fine features as B fragments: 136 registers, conv2's accumulators: 128), four waves per
+// workgroup sharing the LDS-staged weight blocks (double buffered: 2 x (34.5 + 36 KB)).
+#include "tgp_common.h"
+#include "../../include/tgpose.h"
+
+typedef _Float16 hf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hf16x4 __attribute__((ext_vector_type(4)));
+typedef float hf32x4 __attribute__((ext_vector_type(4)));
+typedef float hf32x16 __attribute__((ext_vector_type(16)));
+
+#define HF_STEPS 17                 // K steps of conv1: 272 / 16
+#define HF_C1 1024                  // conv1 channels per head
+#define HF_C2 256                   // conv2 channels per head
+#define HF_NCB (HF_C1 / 32)
+#define HF_AROW (HF_STEPS * 64 + 16)      // LDS row of the conv1 weight block: 17 steps x 2 planes x 32 B, + 16 B (conflict-free b128)
+#define HF_WROW (2 * 64 + 16)             // LDS row of the conv2 weight block: 2 steps x 2 planes x 32 B, + 16 B
+#define HF_ABYTES (32 * HF_AROW)          // 35328
+#define HF_PBYTES 384                     // bias | scale | shift of the block's 32 channels
+#define HF_WBYTES (HF_C2 * HF_WROW)       // 36864
+#define HF_BUF ((HF_ABYTES + HF_PBYTES + HF_WBYTES + 1023) / 1024 * 1024)   // whole kilobytes: the DMA's unit
+
+struct HeadsParams {
+    const float *fine; int ldf, K;
+    const uint16_t *wa_s;                 // [heads * 1024][17][2][16] fp16
+    const float *p1; int ldp1; const int32_t *idx1;
+    const float *p2; int ldp2; const int32_t *idx2;
+    const float *bias1, *scale1, *shift1; // heads * 1024
+    const uint16_t *w2p;                  // [heads][32][256][2][2][16] fp16
+    const float *bias2, *scale2, *shift2; // heads * 256
+    uint32_t *keys;                       // (heads, B, 256)
+    int M, rows_per_obj, B, heads, tiles;
+};
+
+__device__ __forceinline__ void hf_split(const float4 v, uint2 &hi, uint2 &lo)
+{
+    const hf32x4 x = {v.x, v.y, v.z, v.w};
+    const hf16x4 h = __builtin_convertvector(x, hf16x4);
+    const hf32x4 rest = x - __builtin_convertvector(h, hf32x4);
+    const hf16x4 l = __builtin_convertvector(rest, hf16x4);
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+}
+
+__global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char hf_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int hd = blockIdx.x / p.tiles, ptile = blockIdx.x % p.tiles;
+    const int m0 = ptile * 128 + wave * 32;                     // the wave's first point (may lie past M: then the wave only helps staging)
+    const int row = min(m0 + r, p.M - 1);
+
+    // ---- the wave's points as B fragments: fp16 hi / lo planes of fine[row][16 s + 8 h .. + 7]
+    uint4 bh[HF_STEPS], bl[HF_STEPS];
+    {
+        const float *fr = p.fine + (int64_t)row * p.ldf + 8 * h;
+#pragma unroll
+        for (int s = 0; s < HF_STEPS; ++s) {
+            float4 v0 = *reinterpret_cast<const float4 *>(fr + 16 * s), v1 = *reinterpret_cast<const float4 *>(fr + 16 * s + 4);
+            if (s == HF_STEPS - 1) {                            // the K tail: columns >= K are not the caller's to define
+                const int k0 = 16 * s + 8 * h;
+                v0.x = k0 + 0 < p.K ? v0.x : 0.f, v0.y = k0 + 1 < p.K ? v0.y : 0.f, v0.z = k0 + 2 < p.K ? v0.z : 0.f, v0.w = k0 + 3 < p.K ? v0.w : 0.f;
+                v1.x = k0 + 4 < p.K ? v1.x : 0.f, v1.y = k0 + 5 < p.K ? v1.y : 0.f, v1.z = k0 + 6 < p.K ? v1.z : 0.f, v1.w = k0 + 7 < p.K ? v1.w : 0.f;
+            }
+            uint2 h0, l0, h1, l1;
+            hf_split(v0, h0, l0), hf_split(v1, h1, l1);
+            bh[s] = make_uint4(h0.x, h0.y, h1.x, h1.y), bl[s] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
+    }
+    const int i1 = p.idx1[row], i2 = p.idx2[row];
+    const float *g1p = p.p1 + (int64_t)i1 * p.ldp1 + hd * HF_C1 + 4 * h;       // + cb * 32 + 8 m: four channels of the lane
+    const float *g2p = p.p2 + (int64_t)i2 * p.ldp2 + hd * HF_C1 + 4 * h;
+
+    hf32x16 acc2[HF_C2 / 32];
+#pragma unroll
+    for (int ob = 0; ob < HF_C2 / 32; ++ob)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[ob][e] = 0.f;
+
+    // ---- staging of channel block cb: conv1 weight rows, their epilogue vectors, the permuted conv2 weight block, by LDS-DMA
+    // (global_load_lds_dwordx4: no register destination -- through registers the 17 staged 16-byte pieces per thread did not fit
+    // beside the operand fragments and accumulators, the compiler parked them in scratch and serialised every load: 1.6 ms).
+    // A wave-instruction fills 1 KB of LDS linearly (wave-uniform base + 16 x lane), so the padded image is written as it lies:
+    // chunk c of the buffer -> (region, row, piece); a lane that lands on a row's padding piece re-reads the row's last piece.
+    constexpr int A_IMG = 32 * (HF_AROW / 16);                  // 2208 chunks: 32 rows of 68 pieces + 1 of padding
+    constexpr int P_IMG = HF_PBYTES / 16;                       // 24
+    constexpr int W_IMG = HF_C2 * (HF_WROW / 16);               // 2304: 256 rows of 8 pieces + 1 of padding
+    constexpr int N_INS = (A_IMG + P_IMG + W_IMG + 63) / 64;    // 71 wave-instructions per block, 17-18 per wave
+    auto stage = [&](int cb, int buf) {
+        const char *srcA = reinterpret_cast<const char *>(p.wa_s) + ((int64_t)hd * HF_C1 + cb * 32) * (HF_STEPS * 64);
+        const char *srcW = reinterpret_cast<const char *>(p.w2p) + ((int64_t)hd * HF_NCB + cb) * (HF_C2 * 128);
+        const int c0 = hd * HF_C1 + cb * 32;
+        char *dst = hf_smem + buf * HF_BUF;
+#pragma unroll
+        for (int j0 = 0; j0 < (N_INS + 3) / 4; ++j0) {
+            const int j = j0 * 4 + wave;                          // wave-uniform
+            if (j < N_INS) {
+                const int c = j * 64 + lane;
+                const char *src;
+                if (c < A_IMG) {
+                    const int rw = c / (HF_AROW / 16), pc = c % (HF_AROW / 16);
+                    src = srcA + (size_t)(rw * (HF_STEPS * 4) + (pc < HF_STEPS * 4 ? pc : HF_STEPS * 4 - 1)) * 16;
+                } else if (c < A_IMG + P_IMG) {
+                    const int q = c - A_IMG, which = q >> 3, off = (q & 7) * 4;
+                    src = reinterpret_cast<const char *>((which == 0 ? p.bias1 : which == 1 ? p.scale1 : p.shift1) + c0 + off);
+                } else if (c < A_IMG + P_IMG + W_IMG) {
+                    const int w = c - A_IMG - P_IMG, rw = w / (HF_WROW / 16), pc = w % (HF_WROW / 16);
+                    src = srcW + (size_t)(rw * 8 + (pc < 8 ? pc : 7)) * 16;
+                } else src = srcA;                                // the image's last, partial kilobyte
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
+            }
+        }
+    };
+    stage(0, 0);
+    __syncthreads();                                            // (drains the DMA: vmcnt(0) before the barrier)
+
+    for (int cb = 0; cb < HF_NCB; ++cb) {
+        const char *base = hf_smem + (cb & 1) * HF_BUF;
+        // the lane's gathered coarse products for this block: consumed after phase 1
+        float4 g1[4], g2[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            g1[m] = *reinterpret_cast<const float4 *>(g1p + cb * 32 + 8 * m);
+            g2[m] = *reinterpret_cast<const float4 *>(g2p + cb * 32 + 8 * m);
+        }
+        // ---- phase 1: conv1, 32 channels x 32 points
+        hf32x16 acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
+        const char *arow = base + r * HF_AROW + h * 16;
+        {
+            // fragments two steps ahead of their MFMAs: with one wave per SIMD nothing else hides the LDS latency
+            uint4 fh0 = *reinterpret_cast<const uint4 *>(arow), fl0 = *reinterpret_cast<const uint4 *>(arow + 32);
+            uint4 fh1 = *reinterpret_cast<const uint4 *>(arow + 64), fl1 = *reinterpret_cast<const uint4 *>(arow + 64 + 32);
+#pragma unroll
+            for (int s = 0; s < HF_STEPS; ++s) {
+                uint4 fh2 = fh1, fl2 = fl1;
+                if (s + 2 < HF_STEPS) {
+                    fh2 = *reinterpret_cast<const uint4 *>(arow + (s + 2) * 64);
+                    fl2 = *reinterpret_cast<const uint4 *>(arow + (s + 2) * 64 + 32);
+                }
+                // smallest terms first, as in the tile kernel: lo x hi, hi x lo, hi x hi
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, fl0), __builtin_bit_cast(hf16x8, bh[s]), acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, fh0), __builtin_bit_cast(hf16x8, bl[s]), acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, fh0), __builtin_bit_cast(hf16x8, bh[s]), acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);                // keep the lookahead: do not sink the reads to their uses
+                fh0 = fh1, fl0 = fl1, fh1 = fh2, fl1 = fl2;
+            }
+        }
+        // ---- epilogue 1: element e of the lane is channel 4 h + (e & 3) + 8 (e >> 2) of the block, point r
+        uint4 a2h[2], a2l[2];
+        {
+            const float *pv = reinterpret_cast<const float *>(base + HF_ABYTES) + 4 * h;
+            uint2 hh[4], ll[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float4 b = *reinterpret_cast<const float4 *>(pv + 8 * m), sc = *reinterpret_cast<const float4 *>(pv + 32 + 8 * m),
+                             sh = *reinterpret_cast<const float4 *>(pv + 64 + 8 * m);
+                float4 v = make_float4(acc1[4 * m], acc1[4 * m + 1], acc1[4 * m + 2], acc1[4 * m + 3]);
+                v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+                v.x += g1[m].x, v.y += g1[m].y, v.z += g1[m].z, v.w += g1[m].w;
+                v.x += g2[m].x, v.y += g2[m].y, v.z += g2[m].z, v.w += g2[m].w;
+                v.x = v.x * sc.x + sh.x, v.y = v.y * sc.y + sh.y, v.z = v.z * sc.z + sh.z, v.w = v.w * sc.w + sh.w;
+                v.x = v.x > 0.f ? v.x : v.x * 0.f, v.y = v.y > 0.f ? v.y : v.y * 0.f;
+                v.z = v.z > 0.f ? v.z : v.z * 0.f, v.w = v.w > 0.f ? v.w : v.w * 0.f;
+                hf_split(v, hh[m], ll[m]);
+            }
+            a2h[0] = make_uint4(hh[0].x, hh[0].y, hh[1].x, hh[1].y), a2h[1] = make_uint4(hh[2].x, hh[2].y, hh[3].x, hh[3].y);
+            a2l[0] = make_uint4(ll[0].x, ll[0].y, ll[1].x, ll[1].y), a2l[1] = make_uint4(ll[2].x, ll[2].y, ll[3].x, ll[3].y);
+        }
+        // the next block's operands: issued once the epilogue has consumed its ordinary loads (a DMA in flight makes the compiler
+        // drain vmcnt at their next use), landing behind phase 2's 48 MFMAs; the other buffer's last readers passed the barrier
+        if (cb + 1 < HF_NCB) stage(cb + 1, (cb + 1) & 1);
+        // ---- phase 2: conv2 partial sums over this block's 32 channels, 32 points x 256 outputs
+        const char *wrow = base + HF_ABYTES + HF_PBYTES + r * HF_WROW + h * 16;
+        {
+            constexpr int NOB = HF_C2 / 32;
+            auto wfrag = [&](int q, int plane) {                  // q = s2 * NOB + ob
+                return *reinterpret_cast<const uint4 *>(wrow + (q % NOB) * 32 * HF_WROW + (q / NOB) * 64 + plane * 32);
+            };
+            uint4 wh0 = wfrag(0, 0), wl0 = wfrag(0, 1), wh1 = wfrag(1, 0), wl1 = wfrag(1, 1);
+#pragma unroll
+            for (int q = 0; q < 2 * NOB; ++q) {
+                uint4 wh2 = wh1, wl2 = wl1;
+                if (q + 2 < 2 * NOB) wh2 = wfrag(q + 2, 0), wl2 = wfrag(q + 2, 1);
+                const int s2 = q / NOB, ob = q % NOB;
+                acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2h[s2]), __builtin_bit_cast(hf16x8, wl0), acc2[ob], 0, 0, 0);
+                acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2l[s2]), __builtin_bit_cast(hf16x8, wh0), acc2[ob], 0, 0, 0);
+                acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2h[s2]), __builtin_bit_cast(hf16x8, wh0), acc2[ob], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                wh0 = wh1, wl0 = wl1, wh1 = wh2, wl1 = wl2;
+            }
+        }
+        __syncthreads();                                         // drains the DMA (vmcnt(0)) and retires this buffer's readers
+    }
+
+    // ---- epilogue 2: lane (out column r of block ob, half h) holds points (e & 3) + 8 (e >> 2) + 4 h of the wave's 32
+    if (m0 >= p.M) return;
+    const int obj0 = m0 / p.rows_per_obj, bound = (obj0 + 1) * p.rows_per_obj;
+#pragma unroll
+    for (int ob = 0; ob < HF_C2 / 32; ++ob) {
+        const int o = hd * HF_C2 + ob * 32 + r;
+        const float b2 = p.bias2[o], sc2 = p.scale2[o], sh2 = p.shift2[o];
+        uint32_t k0 = 0, k1 = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int prow = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            float v = acc2[ob][e] + b2;
+            v = v * sc2 + sh2;
+            v = v > 0.f ? v : v * 0.f;
+            const uint32_t key = prow < p.M ? tgp_float_key(v) : 0u;
+            if (prow >= bound) k1 = key > k1 ? key : k1;
+            else k0 = key > k0 ? key : k0;
+        }
+        const uint32_t o0 = (uint32_t)__shfl_xor((int)k0, 32, 64), o1 = (uint32_t)__shfl_xor((int)k1, 32, 64);
+        k0 = o0 > k0 ? o0 : k0, k1 = o1 > k1 ? o1 : k1;
+        if (h == 0) {
+            uint32_t *kp = p.keys + ((int64_t)hd * p.B + obj0) * HF_C2 + ob * 32 + r;
+            if (k0) atomicMax(kp, k0);
+            if (k1) atomicMax(kp + HF_C2, k1);
+        }
+    }
+}
+
+// W2 (heads, 256, 1024) fp32 -> [head][channel block][out][step][plane][16] fp16 with conv2's K order permuted to the layout the
+// conv1 accumulators leave the channels in: slot 8 h + t of step s2 is channel 32 cb + 16 s2 + 8 (t >> 2) + 4 h + (t & 3)
+__global__ void heads_pack_w2_kernel(const float *__restrict__ w2, int heads, uint16_t *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)heads * HF_NCB * HF_C2 * 32;
+    if (t >= total) return;
+    const int slot = (int)(t & 15), s2 = (int)((t >> 4) & 1), o = (int)((t >> 5) % HF_C2);
+    const int cb = (int)((t >> 5) / HF_C2 % HF_NCB), hd = (int)((t >> 5) / HF_C2 / HF_NCB);
+    const int hh = slot >> 3, tt = slot & 7;
+    const int ch = 32 * cb + 16 * s2 + 8 * (tt >> 2) + 4 * hh + (tt & 3);
+    const float v = w2[((int64_t)hd * HF_C2 + o) * HF_C1 + ch];
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    uint16_t *dst = out + ((((int64_t)hd * HF_NCB + cb) * HF_C2 + o) * 2 + s2) * 32;
+    dst[slot] = __builtin_bit_cast(uint16_t, hi);
+    dst[16 + slot] = __builtin_bit_cast(uint16_t, lo);
+}
+
+extern "C" int tgp_heads_pack_w2(const float *w2, int heads, void *out, tgp_stream_t stream)
+{
+    TGP_REQUIRE(w2 && out && heads > 0);
+    const int64_t total = (int64_t)heads * HF_NCB * HF_C2 * 32;
+    hipLaunchKernelGGL(heads_pack_w2_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), w2, heads,
+                       reinterpret_cast<uint16_t *>(out));
+    return TGP_LAUNCH_RESULT();
+}
+
+extern "C" int tgp_heads_fused(const tgp_heads_fused_args *a, tgp_stream_t stream)
+{
+    TGP_REQUIRE(a && a->fine && a->wa_s && a->p1 && a->p2 && a->idx1 && a->idx2 && a->bias1 && a->scale1 && a->shift1 && a->w2p &&
+                a->bias2 && a->scale2 && a->shift2 && a->keys);
+    TGP_REQUIRE(a->M > 0 && a->B > 0 && a->heads > 0 && a->rows_per_obj >= 32 && (int64_t)a->B * a->rows_per_obj == a->M);
+    TGP_REQUIRE(a->K > 0 && a->K <= 16 * HF_STEPS && a->K > 16 * (HF_STEPS - 1) && a->ldf >= 16 * HF_STEPS && (a->ldf & 3) == 0);
+    TGP_REQUIRE((a->ldp1 & 3) == 0 && (a->ldp2 & 3) == 0 && a->ldp1 >= a->heads * HF_C1 && a->ldp2 >= a->heads * HF_C1);
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    TGP_REQUIRE(al16(a->fine) && al16(a->wa_s) && al16(a->p1) && al16(a->p2) && al16(a->bias1) && al16(a->scale1) && al16(a->shift1) &&
+                al16(a->w2p));
+    HeadsParams p;
+    p.fine = a->fine, p.ldf = a->ldf, p.K = a->K;
+    p.wa_s = reinterpret_cast<const uint16_t *>(a->wa_s);
+    p.p1 = a->p1, p.ldp1 = a->ldp1, p.idx1 = a->idx1, p.p2 = a->p2, p.ldp2 = a->ldp2, p.idx2 = a->idx2;
+    p.bias1 = a->bias1, p.scale1 = a->scale1, p.shift1 = a->shift1;
+    p.w2p = reinterpret_cast<const uint16_t *>(a->w2p);
+    p.bias2 = a->bias2, p.scale2 = a->scale2, p.shift2 = a->shift2;
+    p.keys = a->keys;
+    p.M = a->M, p.rows_per_obj = a->rows_per_obj, p.B = a->B, p.heads = a->heads, p.tiles = tgp_cdiv(a->M, 128);
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(heads_fused_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HF_BUF);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(heads_fused_kernel, dim3(p.heads * p.tiles), dim3(256), 2 * HF_BUF, tgp_hs(stream), p);
+    return TGP_LAUNCH_RESULT();
+}

@@ -208,6 +208,11 @@ def pack_factored(wide, dec0):
              Wc=torch.cat([W[:, 768:1280], w0[:, 768:1280]], dim=0).contiguous())
     for k in ("Wa", "dec_a", "Wb", "Wc"):
         f[k + "_s"] = ops.split_w(f[k])
+    # the fused heads kernel (conv1 -> conv2 -> max in one launch) takes fp16 operands without a pack-time rescale
+    f["w2p"] = None
+    if (ops.GEMM_MODE == "split16" and getattr(f["Wa_s"], "tgp_unscale", None) is None
+            and float(wide["W2"].abs().max()) < ops.FP16_SAFE):
+        f["w2p"] = ops.heads_pack_w2(wide["W2"])
     return f
 
 
@@ -220,6 +225,7 @@ _PIN = {}
 _SIDE = {}
 BRANCH_STREAMS = True   # run the PH-tail -> decoder chain beside the head chain on a second HIP stream
 FACTORED = True         # eval forward: the layers over the concat buffer run factored over the upsampling (pack_factored)
+HEADS_FUSED = True      # ... and the heads' conv1 -> conv2 -> max as one kernel (csrc/heads_fused.hip) instead of two GEMM launches
 
 
 SIDE_TAG = 0            # GraphedForward gives each half batch its own side stream
@@ -443,6 +449,17 @@ def wide_gemm_factored(pk, fine, inter, P1, P2, N):
     w, f = pk.wide, pk.fact
     M = B * N
     keys5 = torch.zeros(B, 1024, device=dev, dtype=torch.int32)
+    if HEADS_FUSED and f["w2p"] is not None:
+        # conv_5 alone on the tile kernel (N = 1024, nothing stored: only the max over points); the heads in the fused kernel
+        ops.gemm(fine, f["Wa"], None, M=M, N=1024, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=0, bias=w["bias"],
+                 scale=w["scale"], shift=w["shift"], act=1, slope_vec=w["slope"], colmax_keys=keys5, cm_cols=1024,
+                 rows_per_obj=N, w_split=f["Wa_s"], gather1=(P1, P1.shape[1], inter["near1"]),
+                 gather2=(P2, P2.shape[1], inter["near2"]), flops_ref=2.0 * M * 1024 * w["k_alg"])
+        # (returned as a thunk: the caller forks the PH / decoder branch, which needs only keys5, before the long heads kernel)
+        heads = lambda: ops.heads_fused(fine.view(M, -1), FINE_K, f["Wa_s"][1024:], P1[:, 1024:], inter["near1"], P2[:, 1024:],
+                                        inter["near2"], w["bias"][1024:], w["scale"][1024:], w["shift"][1024:], f["w2p"], w["b2"],
+                                        w["scale2"], w["shift2"], B, N, k_alg=w["k_alg"])
+        return keys5, heads
     H = torch.empty(M, 3072, device=dev, dtype=torch.float32)
     ops.gemm(fine, f["Wa"], H, M=M, N=4096, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=3072, bias=w["bias"],
              scale=w["scale"], shift=w["shift"], act=1, slope_vec=w["slope"], colmax_keys=keys5, cm_cols=1024,
@@ -475,10 +492,13 @@ def head_chain(pk, H, B, N):
     dev = H.device
     w = pk.wide
     M = B * N
-    keys2 = torch.zeros(3, B, 256, device=dev, dtype=torch.int32)
-    ops.gemm(H, w["W2"], None, M=M, N=256, K=1024, lda=3072, ldw=1024, ldc=0, bias=w["b2"], scale=w["scale2"],
-             shift=w["shift2"], act=1, slope=0.0, colmax_keys=keys2, rows_per_obj=N, batch=3,
-             batch_strides=(1024, 256 * 1024, 0, 256, B * 256), w_split=w["W2s"])
+    if H.dtype == torch.int32:      # wide_gemm_factored ran the fused heads kernel: H is already conv2's pooled keys (3, B, 256)
+        keys2 = H
+    else:
+        keys2 = torch.zeros(3, B, 256, device=dev, dtype=torch.int32)
+        ops.gemm(H, w["W2"], None, M=M, N=256, K=1024, lda=3072, ldw=1024, ldc=0, bias=w["b2"], scale=w["scale2"],
+                 shift=w["shift2"], act=1, slope=0.0, colmax_keys=keys2, rows_per_obj=N, batch=3,
+                 batch_strides=(1024, 256 * 1024, 0, 256, B * 256), w_split=w["W2s"])
     pooled = ops.colmax_decode(keys2.view(3 * B, 256))                          # (3B, 256)
     # conv3 (+BN, ReLU), dropout(eval) = identity, conv4: two batched launches for the three heads
     x3 = torch.empty(3, B, 256, device=dev, dtype=torch.float32)
@@ -575,6 +595,8 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
             recon = decode(back)
             join = torch.cuda.Event()
             join.record(side)
+        if callable(H):
+            H = H()                                           # the fused heads kernel, beside the side branch
         if not torch.cuda.is_current_stream_capturing():      # a captured graph owns its pool: nothing to protect
             for t in (keys5, H, feat, h1, h2, back, recon) + ((P1, P2, inter["near1"], inter["near2"]) if factored else ()):
                 t.record_stream(side)
@@ -582,6 +604,8 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
         cur.wait_event(join)
     else:
         keys5, H = wide()
+        if callable(H):
+            H = H()
         green, red, ts = head_chain(pk, H, B, N)
         h1, h2, back = ph_tail(pk.ph, keys5, B, points.device)
         recon = decode(back)

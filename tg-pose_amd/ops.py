@@ -388,6 +388,47 @@ def linear_rows(x, weight, bias=None, scale=None, shift=None, act=0, slope=0.0, 
     return out
 
 
+def heads_pack_w2(W2):
+    """conv2 weights of the heads (heads, 256, 1024) fp32 -> the fused heads kernel's operand (fp16 hi / lo planes, K permuted)"""
+    W2 = W2.contiguous()
+    heads = W2.shape[0]
+    if tuple(W2.shape[1:]) != (256, 1024):
+        raise ValueError("heads_pack_w2: (heads, 256, 1024) expected")
+    out = torch.empty(heads, 32, 256, 2, 2, 16, device=W2.device, dtype=torch.int16)
+    check(_lib.lib().tgp_heads_pack_w2(_p(W2), heads, _p(out), _stream(W2)), "tgp_heads_pack_w2")
+    return out
+
+
+def heads_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias1, scale1, shift1, w2p, bias2, scale2, shift2, B, rows_per_obj, k_alg=None):
+    """conv1 -> BN -> ReLU -> conv2 -> BN -> ReLU -> max over points of the three heads (tgp_heads_fused): keys (heads, B, 256).
+    fine (M, ldf); p1 / p2: 2-D views whose column 0 is the first head's first channel (row stride = their .stride(0))."""
+    fine, ldf = _rows(fine, "fine")
+    heads = w2p.shape[0]
+    M = B * rows_per_obj
+    keys = torch.zeros(heads, B, 256, device=fine.device, dtype=torch.int32)
+    timed = GEMM_TIMER is not None
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(fine.device))
+    a = _lib.HeadsFusedArgs()
+    a.fine, a.ldf, a.K = _p(fine), ldf, K
+    a.wa_s = _p(wa_s)
+    a.p1, a.ldp1, a.idx1 = _p(p1), p1.stride(0), _p(idx1)
+    a.p2, a.ldp2, a.idx2 = _p(p2), p2.stride(0), _p(idx2)
+    a.bias1, a.scale1, a.shift1 = _p(bias1), _p(scale1), _p(shift1)
+    a.w2p = _p(w2p)
+    a.bias2, a.scale2, a.shift2 = _p(bias2), _p(scale2), _p(shift2)
+    a.keys = _p(keys)
+    a.M, a.rows_per_obj, a.B, a.heads = M, rows_per_obj, B, heads
+    check(_lib.lib().tgp_heads_fused(ctypes.byref(a), _stream(fine)), "tgp_heads_fused")
+    if timed:
+        e1.record(torch.cuda.current_stream(fine.device))
+        conv2 = 2.0 * M * 256 * 1024 * heads
+        GEMM_TIMER.append((e0, e1, 2.0 * M * heads * 1024 * K + conv2, (M, heads * 1024, K, 1),
+                           2.0 * M * heads * 1024 * (k_alg or K) + conv2))
+    return keys
+
+
 @_timed("graph")
 def colmax_decode(keys, out2=False):
     rows, N = keys.shape
