@@ -28,10 +28,12 @@ typedef float hf32x16 __attribute__((ext_vector_type(16)));
 #define HF_NCB (HF_C1 / 32)
 #define HF_AROW (HF_STEPS * 64 + 16)      // LDS row of the conv1 weight block: 17 steps x 2 planes x 32 B, + 16 B (conflict-free b128)
 #define HF_WROW (2 * 64 + 16)             // LDS row of the conv2 weight block: 2 steps x 2 planes x 32 B, + 16 B
-#define HF_ABYTES (32 * HF_AROW)          // 35328
-#define HF_PBYTES 384                     // bias | scale | shift of the block's 32 channels
-#define HF_WBYTES (HF_C2 * HF_WROW)       // 36864
-#define HF_BUF ((HF_ABYTES + HF_PBYTES + HF_WBYTES + 1023) / 1024 * 1024)   // whole kilobytes: the DMA's unit
+// every region a whole number of kilobytes: one LDS-DMA wave-instruction (64 lanes x 16 B) then lies inside one region
+#define HF_ABYTES (35 * 1024)             // 32 rows x 1104 B = 35328, padded
+#define HF_PBYTES 1024                    // bias | scale | shift of the block's 32 channels (384 B used)
+#define HF_WBYTES (HF_C2 * HF_WROW)       // 36864 = 36 KB
+#define HF_BUF (HF_ABYTES + HF_PBYTES + HF_WBYTES)
+#define HF_NDMA (HF_BUF / 1024 / 4)       // 18 wave-instructions per wave and block
 
 struct HeadsParams {
     const float *fine; int ldf, K;
@@ -43,6 +45,7 @@ struct HeadsParams {
     const float *bias2, *scale2, *shift2; // heads * 256
     uint32_t *keys;                       // (heads, B, 256)
     int M, rows_per_obj, B, heads, tiles;
+    unsigned long long *stamps;           // development builds: per workgroup, wave 0's accumulated time per phase
 };
 
 __device__ __forceinline__ void hf_split(const float4 v, uint2 &hi, uint2 &lo)
@@ -95,40 +98,50 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
     // (global_load_lds_dwordx4: no register destination -- through registers the 17 staged 16-byte pieces per thread did not fit
     // beside the operand fragments and accumulators, the compiler parked them in scratch and serialised every load: 1.6 ms).
     // A wave-instruction fills 1 KB of LDS linearly (wave-uniform base + 16 x lane), so the padded image is written as it lies:
-    // chunk c of the buffer -> (region, row, piece); a lane that lands on a row's padding piece re-reads the row's last piece.
-    constexpr int A_IMG = 32 * (HF_AROW / 16);                  // 2208 chunks: 32 rows of 68 pieces + 1 of padding
-    constexpr int P_IMG = HF_PBYTES / 16;                       // 24
-    constexpr int W_IMG = HF_C2 * (HF_WROW / 16);               // 2304: 256 rows of 8 pieces + 1 of padding
-    constexpr int N_INS = (A_IMG + P_IMG + W_IMG + 63) / 64;    // 71 wave-instructions per block, 17-18 per wave
-    auto stage = [&](int cb, int buf) {
-        const char *srcA = reinterpret_cast<const char *>(p.wa_s) + ((int64_t)hd * HF_C1 + cb * 32) * (HF_STEPS * 64);
-        const char *srcW = reinterpret_cast<const char *>(p.w2p) + ((int64_t)hd * HF_NCB + cb) * (HF_C2 * 128);
-        const int c0 = hd * HF_C1 + cb * 32;
-        char *dst = hf_smem + buf * HF_BUF;
+    // kilobyte j of the buffer is wave (j % 4)'s instruction j / 4; a lane that lands on a row's padding piece re-reads the row's
+    // last piece.  The 72 instructions of a block are 1152 cycles of the CU's vector-memory path (64 B per clock): issued in one
+    // burst they stalled the waves for 23 of a workgroup's 125 us, so they are issued one at a time between phase 2's MFMA groups.
+    static_assert(HF_NDMA == 18 && HF_ABYTES / 1024 == 35, "the region tests below");
+    int dma_off[HF_NDMA];                                       // the lane's source offset of its j0-th instruction (block-invariant)
 #pragma unroll
-        for (int j0 = 0; j0 < (N_INS + 3) / 4; ++j0) {
-            const int j = j0 * 4 + wave;                          // wave-uniform
-            if (j < N_INS) {
-                const int c = j * 64 + lane;
-                const char *src;
-                if (c < A_IMG) {
-                    const int rw = c / (HF_AROW / 16), pc = c % (HF_AROW / 16);
-                    src = srcA + (size_t)(rw * (HF_STEPS * 4) + (pc < HF_STEPS * 4 ? pc : HF_STEPS * 4 - 1)) * 16;
-                } else if (c < A_IMG + P_IMG) {
-                    const int q = c - A_IMG, which = q >> 3, off = (q & 7) * 4;
-                    src = reinterpret_cast<const char *>((which == 0 ? p.bias1 : which == 1 ? p.scale1 : p.shift1) + c0 + off);
-                } else if (c < A_IMG + P_IMG + W_IMG) {
-                    const int w = c - A_IMG - P_IMG, rw = w / (HF_WROW / 16), pc = w % (HF_WROW / 16);
-                    src = srcW + (size_t)(rw * 8 + (pc < 8 ? pc : 7)) * 16;
-                } else src = srcA;                                // the image's last, partial kilobyte
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
-            }
+    for (int j0 = 0; j0 < HF_NDMA; ++j0) {
+        const int j = j0 * 4 + wave;
+        if (j < 35) {                                            // conv1 weight rows: 69 pieces per LDS row, 68 in memory
+            const int c = j * 64 + lane, rw = c / 69, pc = c % 69;
+            dma_off[j0] = rw < 32 ? (rw * 68 + (pc < 68 ? pc : 67)) * 16 : 0;
+        } else if (j == 35) {                                    // bias | scale | shift: 8 pieces each
+            dma_off[j0] = lane < 24 ? (lane & 7) * 16 : 0;
+        } else {                                                 // conv2 weight rows: 9 pieces per LDS row, 8 in memory
+            const int c = (j - 36) * 64 + lane, rw = c / 9, pc = c % 9;
+            dma_off[j0] = (rw * 8 + (pc < 8 ? pc : 7)) * 16;
         }
+    }
+    auto dma = [&](int cb, int buf, int j0) {
+        const int j = j0 * 4 + wave;                             // wave-uniform
+        const char *src;
+        if (j < 35) src = reinterpret_cast<const char *>(p.wa_s) + ((int64_t)hd * HF_C1 + cb * 32) * (HF_STEPS * 64);
+        else if (j == 35) {
+            const float *v = lane < 8 ? p.bias1 : lane < 16 ? p.scale1 : p.shift1;
+            src = reinterpret_cast<const char *>(v + hd * HF_C1 + cb * 32);
+        } else src = reinterpret_cast<const char *>(p.w2p) + ((int64_t)hd * HF_NCB + cb) * (HF_C2 * 128);
+        // As inline assembly: through the builtin the compiler, which cannot know that the DMA fills the OTHER buffer, drained
+        // vmcnt before every LDS read that followed one (phase 2: 52 -> 182 us).  Opaque to its counters, so the waits are written
+        // by hand: vmcnt(0) before the barrier that ends the block; no compiler-visible vector load is in flight meanwhile.
+        const uint32_t lds = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)(hf_smem + buf * HF_BUF + j * 1024));
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + dma_off[j0]), "s"(lds) : "memory", "m0");
     };
-    stage(0, 0);
-    __syncthreads();                                            // (drains the DMA: vmcnt(0) before the barrier)
+#pragma unroll
+    for (int j0 = 0; j0 < HF_NDMA; ++j0) dma(0, 0, j0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0): this wave's DMA has landed
+    __syncthreads();
 
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, t_prev = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+#define HF_STAMP(i)                                                  \
+    if (p.stamps) {                                                  \
+        const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); \
+        tph[i] += t_now - t_prev, t_prev = t_now;                    \
+    }
     for (int cb = 0; cb < HF_NCB; ++cb) {
         const char *base = hf_smem + (cb & 1) * HF_BUF;
         // the lane's gathered coarse products for this block: consumed after phase 1
@@ -162,6 +175,7 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
                 fh0 = fh1, fl0 = fl1, fh1 = fh2, fl1 = fl2;
             }
         }
+        HF_STAMP(0)
         // ---- epilogue 1: element e of the lane is channel 4 h + (e & 3) + 8 (e >> 2) of the block, point r
         uint4 a2h[2], a2l[2];
         {
@@ -183,9 +197,11 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
             a2h[0] = make_uint4(hh[0].x, hh[0].y, hh[1].x, hh[1].y), a2h[1] = make_uint4(hh[2].x, hh[2].y, hh[3].x, hh[3].y);
             a2l[0] = make_uint4(ll[0].x, ll[0].y, ll[1].x, ll[1].y), a2l[1] = make_uint4(ll[2].x, ll[2].y, ll[3].x, ll[3].y);
         }
-        // the next block's operands: issued once the epilogue has consumed its ordinary loads (a DMA in flight makes the compiler
-        // drain vmcnt at their next use), landing behind phase 2's 48 MFMAs; the other buffer's last readers passed the barrier
-        if (cb + 1 < HF_NCB) stage(cb + 1, (cb + 1) & 1);
+        HF_STAMP(1)
+        // the next block's operands: issued from here on (the epilogue has consumed its ordinary loads: a DMA in flight makes the
+        // compiler drain vmcnt at their next use); the other buffer's last readers passed the barrier
+        if (cb + 1 < HF_NCB) dma(cb + 1, (cb + 1) & 1, 16), dma(cb + 1, (cb + 1) & 1, 17);
+        HF_STAMP(2)
         // ---- phase 2: conv2 partial sums over this block's 32 channels, 32 points x 256 outputs
         const char *wrow = base + HF_ABYTES + HF_PBYTES + r * HF_WROW + h * 16;
         {
@@ -202,13 +218,22 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
                 acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2h[s2]), __builtin_bit_cast(hf16x8, wl0), acc2[ob], 0, 0, 0);
                 acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2l[s2]), __builtin_bit_cast(hf16x8, wh0), acc2[ob], 0, 0, 0);
                 acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2h[s2]), __builtin_bit_cast(hf16x8, wh0), acc2[ob], 0, 0, 0);
+                if (cb + 1 < HF_NCB) dma(cb + 1, (cb + 1) & 1, q);   // 16 of the 18, one per MFMA group
                 __builtin_amdgcn_sched_barrier(0);
                 wh0 = wh1, wl0 = wl1, wh1 = wh2, wl1 = wl2;
             }
         }
-        __syncthreads();                                         // drains the DMA (vmcnt(0)) and retires this buffer's readers
+        HF_STAMP(3)
+        __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): this wave's share of the next block has landed
+        __syncthreads();                                         // ... everybody's has, and this buffer's readers are done
+        HF_STAMP(4)
     }
 
+    if (p.stamps && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) p.stamps[6 * (size_t)blockIdx.x + i] = tph[i];
+        p.stamps[6 * (size_t)blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
+    }
     // ---- epilogue 2: lane (out column r of block ob, half h) holds points (e & 3) + 8 (e >> 2) + 4 h of the wave's 32
     if (m0 >= p.M) return;
     const int obj0 = m0 / p.rows_per_obj, bound = (obj0 + 1) * p.rows_per_obj;
@@ -265,6 +290,13 @@ extern "C" int tgp_heads_pack_w2(const float *w2, int heads, void *out, tgp_stre
     return TGP_LAUNCH_RESULT();
 }
 
+#ifdef TGP_DEV
+static unsigned long long *tgp_heads_stamps = nullptr;
+extern "C" void tgp_debug_set_heads_stamps(unsigned long long *buf) { tgp_heads_stamps = buf; }
+#else
+static constexpr unsigned long long *tgp_heads_stamps = nullptr;
+#endif
+
 extern "C" int tgp_heads_fused(const tgp_heads_fused_args *a, tgp_stream_t stream)
 {
     TGP_REQUIRE(a && a->fine && a->wa_s && a->p1 && a->p2 && a->idx1 && a->idx2 && a->bias1 && a->scale1 && a->shift1 && a->w2p &&
@@ -284,6 +316,7 @@ extern "C" int tgp_heads_fused(const tgp_heads_fused_args *a, tgp_stream_t strea
     p.bias2 = a->bias2, p.scale2 = a->scale2, p.shift2 = a->shift2;
     p.keys = a->keys;
     p.M = a->M, p.rows_per_obj = a->rows_per_obj, p.B = a->B, p.heads = a->heads, p.tiles = tgp_cdiv(a->M, 128);
+    p.stamps = tgp_heads_stamps;
     static bool attr_set = false;
     if (!attr_set) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(heads_fused_kernel),
