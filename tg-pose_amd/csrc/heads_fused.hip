@@ -171,6 +171,9 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, fl0), __builtin_bit_cast(hf16x8, bh[s]), acc1, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, fh0), __builtin_bit_cast(hf16x8, bl[s]), acc1, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, fh0), __builtin_bit_cast(hf16x8, bh[s]), acc1, 0, 0, 0);
+                // the next block's operands, 8 of the 18 pieces here (the rest in phase 2): they target the other buffer, whose
+                // last readers passed the barrier; the epilogue's wait for its gathered rows covers them too (they are older by then)
+                if (s >= 1 && s <= 8 && cb + 1 < HF_NCB) dma(cb + 1, (cb + 1) & 1, s - 1);
                 __builtin_amdgcn_sched_barrier(0);                // keep the lookahead: do not sink the reads to their uses
                 fh0 = fh1, fl0 = fl1, fh1 = fh2, fl1 = fl2;
             }
@@ -198,9 +201,6 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
             a2l[0] = make_uint4(ll[0].x, ll[0].y, ll[1].x, ll[1].y), a2l[1] = make_uint4(ll[2].x, ll[2].y, ll[3].x, ll[3].y);
         }
         HF_STAMP(1)
-        // the next block's operands: issued from here on (the epilogue has consumed its ordinary loads: a DMA in flight makes the
-        // compiler drain vmcnt at their next use); the other buffer's last readers passed the barrier
-        if (cb + 1 < HF_NCB) dma(cb + 1, (cb + 1) & 1, 16), dma(cb + 1, (cb + 1) & 1, 17);
         HF_STAMP(2)
         // ---- phase 2: conv2 partial sums over this block's 32 channels, 32 points x 256 outputs
         const char *wrow = base + HF_ABYTES + HF_PBYTES + r * HF_WROW + h * 16;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
                 acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2h[s2]), __builtin_bit_cast(hf16x8, wl0), acc2[ob], 0, 0, 0);
                 acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2l[s2]), __builtin_bit_cast(hf16x8, wh0), acc2[ob], 0, 0, 0);
                 acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2h[s2]), __builtin_bit_cast(hf16x8, wh0), acc2[ob], 0, 0, 0);
-                if (cb + 1 < HF_NCB) dma(cb + 1, (cb + 1) & 1, q);   // 16 of the 18, one per MFMA group
+                if (q < HF_NDMA - 8 && cb + 1 < HF_NCB) dma(cb + 1, (cb + 1) & 1, q + 8);   // the other 10, one per MFMA group
                 __builtin_amdgcn_sched_barrier(0);
                 wh0 = wh1, wl0 = wl1, wh1 = wh2, wl1 = wl2;
             }
