@@ -170,6 +170,10 @@ typedef struct tgp_gemm_args {
      * 1: the register-direct form (4-byte accesses; same arithmetic in the same order, bit-identical results; slower --
      *    a per-call A/B handle for tests, not a tuning knob; not available with gathered residuals). */
     int epilogue;
+    /* Predicate (may be NULL): a device int; while it is 0 the launch does nothing (every workgroup returns at once).  For
+     * repair launches whose condition is raised on the device -- tgp_heads_fused's overflow flag -- without a host read.
+     */
+    const int *pred;
 } tgp_gemm_args;
 
 /* W (rows, K) fp32, row stride ld -> out[rows][ldo/16][3][16] bf16: per 16-wide K-tile the hi, mid and lo terms
@@ -475,7 +479,7 @@ int tgp_sort_by_parent(const int32_t *near1, const int32_t *near2, int B, int n,
  *   head * 1024 + channel at the pointers given, row strides ldp1 / ldp2; idx1 / idx2 (M) rows of p1 / p2 per point;
  *   bias1 / scale1 / shift1 (heads * 1024): conv1 bias and BatchNorm fold; w2p = tgp_heads_pack_w2(conv2 weights);
  *   bias2 / scale2 / shift2 (heads * 256); keys (heads, B, 256) order-preserving keys of the maxima (tgp_colmax_decode), zeroed by
- *   the caller; M = B * rows_per_obj.  Operands beyond fp16's range (65504) give NaN outputs. */
+ *   the caller; M = B * rows_per_obj. */
 typedef struct tgp_heads_fused_args {
     const float *fine; int ldf; int K;
     const void *wa_s;
@@ -486,6 +490,10 @@ typedef struct tgp_heads_fused_args {
     const float *bias2; const float *scale2; const float *shift2;
     uint32_t *keys;
     int M; int rows_per_obj; int B; int heads;
+    /* fp16 range: a wave that meets a fine feature or a conv1 activation of magnitude >= 65504 (or a NaN) writes no keys for its
+     * 32 points and sets *overflow = 1 (device int, zeroed by the caller; NULL: such waves write NaN keys).  The caller then runs
+     * the two-launch form predicated on the flag (tgp_gemm_args.pred), which recomputes every key in guarded arithmetic. */
+    int *overflow;
 } tgp_heads_fused_args;
 int tgp_heads_fused(const tgp_heads_fused_args *args, tgp_stream_t stream);
 /* w2 (heads, 256, 1024) fp32 -> heads * 1024 * 256 * 2 fp16 in the kernel's operand order (hi / lo planes, K permuted). */

@@ -1682,6 +1682,38 @@ def test_fused_heads_kernel_equals_two_launch_heads(ops, B, N):
         assert d <= 1e-5 * max(1.0, outs[1][k].abs().max().item()), (k, d)
 
 
+def test_fused_heads_kernel_range_guard(ops):
+    """The fused heads kernel splits the fine features and the conv1 activations into fp16: a magnitude beyond 65504 must not
+    reach the outputs as NaN.  The wave that meets one raises a device flag instead of writing its keys and the predicated
+    two-launch form (whose tiles guard themselves) supplies them -- no host read.  conv_1 scaled by 1e6 puts fm_1 (columns
+    128-255 of the fine buffer) far outside fp16's range; the outputs must be finite and equal the two-launch path's (HEADS_FUSED
+    off) to rounding.  With sane weights the flag stays 0 and the repair launches return at once (every other forward test)."""
+    from tgpose_amd import PoseNet9D, seeded_state_dict, FLAGS, engine
+    sd = seeded_state_dict(15)
+    for k in ("weights", "bias", "STE_layer.weight"):
+        sd["face_all.encoder.conv_1." + k] = sd["face_all.encoder.conv_1." + k] * 1e6
+    net = PoseNet9D()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    FLAGS.train = 0
+    pts, obj = synth_points(3, 1028, 41)
+    torch.manual_seed(4)
+    i1 = torch.randperm(1028)[:257]
+    smp = (i1, torch.randperm(257)[:64])
+    outs = []
+    for fused in (True, False):
+        old, engine.HEADS_FUSED = engine.HEADS_FUSED, fused
+        try:
+            with torch.no_grad():
+                outs.append({k: v.clone() for k, v in net(g(pts), g(obj), sample_idx=smp).items()})
+        finally:
+            engine.HEADS_FUSED = old
+    for k in outs[0]:
+        assert torch.isfinite(outs[0][k]).all(), k
+        d = (outs[0][k] - outs[1][k]).abs().max().item()
+        assert d <= 2e-5 * max(1.0, outs[1][k].abs().max().item()), (k, d)
+
+
 # ----------------------------------------------------------------------------------------- evaluation (f-2: mAP)
 def test_eval_pair_metrics_vs_oracle_and_reference(ops):
     """tgp_iou3d_pairs / tgp_rt_error_pairs (fp64) against the reference's values (fixture) and the numpy oracle."""

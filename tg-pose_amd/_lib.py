@@ -38,7 +38,7 @@ class GemmArgs(ctypes.Structure):
         ("a_scale", c_vp), ("c_scale", c_vp), ("ksplit_chunk", c_int),
         ("gres1", c_vp), ("ldg1", c_int), ("gidx1", c_vp),
         ("gres2", c_vp), ("ldg2", c_int), ("gidx2", c_vp),
-        ("epilogue", c_int),
+        ("epilogue", c_int), ("pred", c_vp),
     ]
 
 
@@ -55,6 +55,7 @@ class HeadsFusedArgs(ctypes.Structure):
         ("bias2", c_vp), ("scale2", c_vp), ("shift2", c_vp),
         ("keys", c_vp),
         ("M", c_int), ("rows_per_obj", c_int), ("B", c_int), ("heads", c_int),
+        ("overflow", c_vp),
     ]
 
 

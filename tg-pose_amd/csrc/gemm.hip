@@ -68,6 +68,7 @@ struct GemmParams {
     int ldg1, ldg2;
     int vec_epi;                 // every epilogue operand is 16-byte addressable: the split kernels use gemm_epilogue_lds
     int scalar_epi;              // caller asked for the register-direct epilogue (tgp_gemm_args.epilogue == 1)
+    const int *pred;             // device flag: the launch does nothing while *pred == 0 (tgp_gemm_args.pred; split tile kernels)
     int64_t plane;               // elements between planes
     // tile schedule of the main kernel: per batch, M-tile rows [0, mt_big) use 128x128 tiles, the rest 64x64
     int mt_big, tiles_n_big, tiles_big, tiles_m_small, tiles_n_small;
@@ -969,6 +970,7 @@ __global__ __launch_bounds__(1024) void gemm_split_kernel(GemmParams p)
 {
     // two stages of the 256 x 256 tile = one stage of the split-K quarter tile (4 x (128 + 128) virtual rows)
     __shared__ __attribute__((aligned(16))) char smem[2 * (F16 ? 2 : 3) * ((256 + 256) * 48 + 64)];
+    if (p.pred && *p.pred == 0) return;      // a repair launch whose condition did not arise (workgroup-uniform)
     int seg = 0;
     while (seg < p.nseg - 1 && (int)blockIdx.x >= p.seg_end[seg]) ++seg;
     int L = p.seg_base[seg] + (int)blockIdx.x - (seg ? p.seg_end[seg - 1] : 0);
@@ -1121,6 +1123,7 @@ __device__ __forceinline__ void gemm_split_tile32(const GemmParams &p, const int
 
 __global__ __launch_bounds__(1024) void gemm_split32_kernel(GemmParams p)
 {
+    if (p.pred && *p.pred == 0) return;      // a repair launch whose condition did not arise (workgroup-uniform)
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * (256 + 256) * 64];
     int seg = 0;
     while (seg < p.nseg - 1 && (int)blockIdx.x >= p.seg_end[seg]) ++seg;
@@ -1146,6 +1149,7 @@ template <int PD, bool F16>
 __global__ __launch_bounds__(512, 4) void gemm_split512_kernel(GemmParams p)
 {
     __shared__ __attribute__((aligned(16))) char smem[(PD > 0 ? 2 : 1) * (F16 ? 2 : 3) * ((256 + 128) * 48 + 64)];
+    if (p.pred && *p.pred == 0) return;      // a repair launch whose condition did not arise (workgroup-uniform)
     int seg = 0;
     while (seg < p.nseg - 1 && (int)blockIdx.x >= p.seg_end[seg]) ++seg;
     int L = p.seg_base[seg] + (int)blockIdx.x - (seg ? p.seg_end[seg - 1] : 0);
@@ -1219,6 +1223,7 @@ extern "C" int tgp_split_f16(const float *W, int rows, int K, int ld, uint16_t *
 #define GEMM_MID 128
 __global__ __launch_bounds__(1024) void gemm_main_kernel(GemmParams p)
 {
+    if (p.pred && *p.pred == 0) return;      // a repair launch whose condition did not arise (workgroup-uniform)
     __shared__ __attribute__((aligned(16))) float smem[(GEMM_BIG + GEMM_BIG) * (16 + GEMM_LDPAD)];
     int L = blockIdx.x;
     if (L < p.tiles_big) {
@@ -1242,6 +1247,7 @@ __global__ __launch_bounds__(1024) void gemm_main_kernel(GemmParams p)
 // resident workgroup overlaps another one's prologue/epilogue).
 __global__ __launch_bounds__(256) void gemm_main256_kernel(GemmParams p)
 {
+    if (p.pred && *p.pred == 0) return;      // a repair launch whose condition did not arise (workgroup-uniform)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int L = blockIdx.x;
     if (L < p.tiles_big) {
@@ -1262,6 +1268,7 @@ __global__ __launch_bounds__(256) void gemm_main256_kernel(GemmParams p)
 // fp32 MFMA chain (bit-identical to the CPU sgemm the reference's neighbour order depends on).
 __global__ __launch_bounds__(1024) void gemm_dist_kernel(GemmParams p)
 {
+    if (p.pred && *p.pred == 0) return;      // a repair launch whose condition did not arise (workgroup-uniform)
     __shared__ __attribute__((aligned(16))) float smem[(128 + 128) * (16 + GEMM_LDPAD)];
     gemm_tile<128, 128, 4, 4, 16, false, true, true>(p, blockIdx.y * 128, blockIdx.x * 128, blockIdx.z, smem);
 }
@@ -1269,6 +1276,7 @@ __global__ __launch_bounds__(1024) void gemm_dist_kernel(GemmParams p)
 template <bool NAT, bool DIST>
 __global__ __launch_bounds__(256) void gemm_small_kernel(GemmParams p)
 {
+    if (p.pred && *p.pred == 0) return;      // a repair launch whose condition did not arise (workgroup-uniform)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     gemm_tile<64, 64, 2, 2, 32, true, NAT, DIST>(p, blockIdx.y * 64, blockIdx.x * 64, blockIdx.z, smem);
 }
@@ -1288,6 +1296,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int NT, int SKINNY_WAVES>   // NT 16-column tiles per workgroup
 __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmParams p)
 {
+    if (p.pred && *p.pred == 0) return;      // a repair launch whose condition did not arise (workgroup-uniform)
     constexpr int SKINNY_COLS = 16 * NT;
     __shared__ float red[SKINNY_WAVES][32][SKINNY_COLS + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1609,6 +1618,7 @@ extern "C" int tgp_gemm_f32(const tgp_gemm_args *a, tgp_stream_t stream)
     p.gres1 = a->gres1, p.ldg1 = a->ldg1, p.gidx1 = a->gidx1, p.gres2 = a->gres2, p.ldg2 = a->ldg2, p.gidx2 = a->gidx2;
     TGP_REQUIRE(a->epilogue == 0 || (a->epilogue == 1 && !gather));
     p.scalar_epi = a->epilogue;
+    p.pred = a->pred;
     const bool plain = !a->rowbias && !a->res2 && !a->colmax_keys && !a->slope_vec && a->c_col0 == 0 &&
                        (p.batch == 1 || !a->res1);
     // a_scale / c_scale / ksplit_chunk are implemented by the fp16 split tile kernels only: refuse launches that route elsewhere

@@ -44,6 +44,7 @@ struct HeadsParams {
     const uint16_t *w2p;                  // [heads][32][256][2][2][16] fp16
     const float *bias2, *scale2, *shift2; // heads * 256
     uint32_t *keys;                       // (heads, B, 256)
+    int *overflow;
     int M, rows_per_obj, B, heads, tiles;
     unsigned long long *stamps;           // development builds: per workgroup, wave 0's accumulated time per phase
 };
@@ -69,6 +70,8 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
 
     // ---- the wave's points as B fragments: fp16 hi / lo planes of fine[row][16 s + 8 h .. + 7]
     uint4 bh[HF_STEPS], bl[HF_STEPS];
+    float amax = 0.f, poison = 0.f;                             // range guard: the largest magnitude this lane splits into fp16; NaN once
+                                                                // it has met a NaN or an infinity (0 x inf = NaN; fmaxf drops NaNs)
     {
         const float *fr = p.fine + (int64_t)row * p.ldf + 8 * h;
 #pragma unroll
@@ -79,6 +82,9 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
                 v0.x = k0 + 0 < p.K ? v0.x : 0.f, v0.y = k0 + 1 < p.K ? v0.y : 0.f, v0.z = k0 + 2 < p.K ? v0.z : 0.f, v0.w = k0 + 3 < p.K ? v0.w : 0.f;
                 v1.x = k0 + 4 < p.K ? v1.x : 0.f, v1.y = k0 + 5 < p.K ? v1.y : 0.f, v1.z = k0 + 6 < p.K ? v1.z : 0.f, v1.w = k0 + 7 < p.K ? v1.w : 0.f;
             }
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))));
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w))));
+            poison += 0.f * (((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w)));
             uint2 h0, l0, h1, l1;
             hf_split(v0, h0, l0), hf_split(v1, h1, l1);
             bh[s] = make_uint4(h0.x, h0.y, h1.x, h1.y), bl[s] = make_uint4(l0.x, l0.y, l1.x, l1.y);
@@ -195,6 +201,8 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
                 v.x = v.x * sc.x + sh.x, v.y = v.y * sc.y + sh.y, v.z = v.z * sc.z + sh.z, v.w = v.w * sc.w + sh.w;
                 v.x = v.x > 0.f ? v.x : v.x * 0.f, v.y = v.y > 0.f ? v.y : v.y * 0.f;
                 v.z = v.z > 0.f ? v.z : v.z * 0.f, v.w = v.w > 0.f ? v.w : v.w * 0.f;
+                poison += 0.f * ((v.x + v.y) + (v.z + v.w));
+                amax = fmaxf(amax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));     // (v >= 0 after the ReLU)
                 hf_split(v, hh[m], ll[m]);
             }
             a2h[0] = make_uint4(hh[0].x, hh[0].y, hh[1].x, hh[1].y), a2h[1] = make_uint4(hh[2].x, hh[2].y, hh[3].x, hh[3].y);
@@ -236,6 +244,12 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
     }
     // ---- epilogue 2: lane (out column r of block ob, half h) holds points (e & 3) + 8 (e >> 2) + 4 h of the wave's 32
     if (m0 >= p.M) return;
+    // fp16 range guard: a lane that split a magnitude >= 65504 (or met a NaN) spoils its wave's sums.  With a flag to raise, the wave
+    // writes no keys and the caller's predicated two-launch form (guarded arithmetic) supplies them; without one, NaN keys are loud.
+    if (p.overflow && __ballot(!(amax < 65504.f) || poison != poison) != 0ull) {
+        if (lane == 0) atomicOr(p.overflow, 1);
+        return;
+    }
     const int obj0 = m0 / p.rows_per_obj, bound = (obj0 + 1) * p.rows_per_obj;
 #pragma unroll
     for (int ob = 0; ob < HF_C2 / 32; ++ob) {
@@ -315,6 +329,7 @@ extern "C" int tgp_heads_fused(const tgp_heads_fused_args *a, tgp_stream_t strea
     p.w2p = reinterpret_cast<const uint16_t *>(a->w2p);
     p.bias2 = a->bias2, p.scale2 = a->scale2, p.shift2 = a->shift2;
     p.keys = a->keys;
+    p.overflow = a->overflow;
     p.M = a->M, p.rows_per_obj = a->rows_per_obj, p.B = a->B, p.heads = a->heads, p.tiles = tgp_cdiv(a->M, 128);
     p.stamps = tgp_heads_stamps;
     static bool attr_set = false;

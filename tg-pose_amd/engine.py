@@ -456,9 +456,22 @@ def wide_gemm_factored(pk, fine, inter, P1, P2, N):
                  rows_per_obj=N, w_split=f["Wa_s"], gather1=(P1, P1.shape[1], inter["near1"]),
                  gather2=(P2, P2.shape[1], inter["near2"]), flops_ref=2.0 * M * 1024 * w["k_alg"])
         # (returned as a thunk: the caller forks the PH / decoder branch, which needs only keys5, before the long heads kernel)
-        heads = lambda: ops.heads_fused(fine.view(M, -1), FINE_K, f["Wa_s"][1024:], P1[:, 1024:], inter["near1"], P2[:, 1024:],
-                                        inter["near2"], w["bias"][1024:], w["scale"][1024:], w["shift"][1024:], f["w2p"], w["b2"],
-                                        w["scale2"], w["shift2"], B, N, k_alg=w["k_alg"])
+        def heads():
+            keys2, overflow = ops.heads_fused(fine.view(M, -1), FINE_K, f["Wa_s"][1024:], P1[:, 1024:], inter["near1"], P2[:, 1024:],
+                                              inter["near2"], w["bias"][1024:], w["scale"][1024:], w["shift"][1024:], f["w2p"],
+                                              w["b2"], w["scale2"], w["shift2"], B, N, k_alg=w["k_alg"])
+            # fp16 range repair, decided on the device: a wave of the fused kernel that met a magnitude beyond fp16's range wrote no
+            # keys and raised `overflow`; the two-launch form (whose tiles guard themselves) then supplies every key.  While the
+            # flag is 0 -- always, for sane weights -- both launches return at once (tgp_gemm_args.pred).
+            H = torch.empty(M, 3072, device=dev, dtype=torch.float32)
+            ops.gemm(fine, f["Wa"][1024:], H, M=M, N=3072, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=3072, bias=w["bias"][1024:],
+                     scale=w["scale"][1024:], shift=w["shift"][1024:], act=1, slope=0.0, rows_per_obj=N, w_split=f["Wa_s"][1024:],
+                     gather1=(P1[:, 1024:], P1.shape[1], inter["near1"]), gather2=(P2[:, 1024:], P2.shape[1], inter["near2"]),
+                     flops_ref=0, pred=overflow)
+            ops.gemm(H, w["W2"], None, M=M, N=256, K=1024, lda=3072, ldw=1024, ldc=0, bias=w["b2"], scale=w["scale2"],
+                     shift=w["shift2"], act=1, slope=0.0, colmax_keys=keys2, rows_per_obj=N, batch=3,
+                     batch_strides=(1024, 256 * 1024, 0, 256, B * 256), w_split=w["W2s"], flops_ref=0, pred=overflow)
+            return keys2
         return keys5, heads
     H = torch.empty(M, 3072, device=dev, dtype=torch.float32)
     ops.gemm(fine, f["Wa"], H, M=M, N=4096, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=3072, bias=w["bias"],

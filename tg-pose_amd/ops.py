@@ -318,11 +318,12 @@ def _big_tile_threshold():
 def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, bias=None, rowbias=None,
          rows_per_obj=0, res1=None, ldr1=0, res2=None, ldr2=0, scale=None, shift=None, act=0, slope=0.0,
          colmax_keys=None, k_alg=None, slope_vec=None, cm_cols=0, c_col0=0, batch=1, batch_strides=None, w_split=None,
-         a_scale=None, c_scale=None, ksplit_chunk=0, gather1=None, gather2=None, flops_ref=None, epilogue=0):
+         a_scale=None, c_scale=None, ksplit_chunk=0, gather1=None, gather2=None, flops_ref=None, epilogue=0, pred=None):
     """Raw call into tgp_gemm_f32.  A/W/C/res* are tensors whose data_ptr is the first element of the
     operand (views into wider buffers are fine); all sizes/strides are explicit.  k_alg: the layer's
     true input width when K includes zero padding (only used for FLOP accounting in bench.py)."""
-    timed = GEMM_TIMER is not None and (GEMM_TIMER_ALL or _routes_to_big_tile(M, N, batch))
+    timed = GEMM_TIMER is not None and pred is None and (GEMM_TIMER_ALL or _routes_to_big_tile(M, N, batch))   # (a predicated
+    # launch is a repair path that normally does nothing: it has no place in a FLOP rate)
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(A.device))
@@ -353,6 +354,7 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
     if gather2 is not None:
         a.gres2, a.ldg2, a.gidx2 = _p(gather2[0]), int(gather2[1]), _p(gather2[2])
     a.epilogue = int(epilogue)
+    a.pred = _p(pred)
     check(_lib.lib().tgp_gemm_f32(ctypes.byref(a), _stream(A)), "tgp_gemm_f32")
     if timed:
         e1.record(torch.cuda.current_stream(A.device))
@@ -400,12 +402,14 @@ def heads_pack_w2(W2):
 
 
 def heads_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias1, scale1, shift1, w2p, bias2, scale2, shift2, B, rows_per_obj, k_alg=None):
-    """conv1 -> BN -> ReLU -> conv2 -> BN -> ReLU -> max over points of the three heads (tgp_heads_fused): keys (heads, B, 256).
+    """conv1 -> BN -> ReLU -> conv2 -> BN -> ReLU -> max over points of the three heads (tgp_heads_fused): keys (heads, B, 256)
+    and the device flag (1,) int32 that a wave raises instead of writing keys when it met a magnitude beyond fp16's range.
     fine (M, ldf); p1 / p2: 2-D views whose column 0 is the first head's first channel (row stride = their .stride(0))."""
     fine, ldf = _rows(fine, "fine")
     heads = w2p.shape[0]
     M = B * rows_per_obj
     keys = torch.zeros(heads, B, 256, device=fine.device, dtype=torch.int32)
+    overflow = torch.zeros(1, device=fine.device, dtype=torch.int32)
     timed = GEMM_TIMER is not None
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -420,13 +424,14 @@ def heads_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias1, scale1, shift1, w2p, b
     a.bias2, a.scale2, a.shift2 = _p(bias2), _p(scale2), _p(shift2)
     a.keys = _p(keys)
     a.M, a.rows_per_obj, a.B, a.heads = M, rows_per_obj, B, heads
+    a.overflow = _p(overflow)
     check(_lib.lib().tgp_heads_fused(ctypes.byref(a), _stream(fine)), "tgp_heads_fused")
     if timed:
         e1.record(torch.cuda.current_stream(fine.device))
         conv2 = 2.0 * M * 256 * 1024 * heads
         GEMM_TIMER.append((e0, e1, 2.0 * M * heads * 1024 * K + conv2, (M, heads * 1024, K, 1),
                            2.0 * M * heads * 1024 * (k_alg or K) + conv2))
-    return keys
+    return keys, overflow
 
 
 @_timed("graph")
