@@ -496,6 +496,22 @@ typedef struct tgp_heads_fused_args {
     int *overflow;
 } tgp_heads_fused_args;
 int tgp_heads_fused(const tgp_heads_fused_args *args, tgp_stream_t stream);
+/* conv -> BatchNorm(eval) -> LeakyReLU -> max over each object's points of a factored layer whose activation only feeds the max
+ * (FaceRecon.py:76-77 conv_5 and the `feat.max(1)` that follows, on the factored form of this repo's engine): operands as for
+ * tgp_heads_fused with one "head" of C channels (C % 32 == 0; wa_s / bias / scale / shift / p1 / p2 point at its first channel),
+ * slope = the LeakyReLU slope, keys (B, C) row stride ldk zeroed by the caller; p1_rows / p2_rows: rows of p1 / p2 (their
+ * element offsets must fit 31 bits); overflow as in tgp_heads_fused (the caller's repair is tgp_gemm_f32 with `pred`). */
+typedef struct tgp_conv_max_fused_args {
+    const float *fine; int ldf; int K;
+    const void *wa_s;
+    const float *p1; int ldp1; int p1_rows; const int32_t *idx1;
+    const float *p2; int ldp2; int p2_rows; const int32_t *idx2;
+    const float *bias; const float *scale; const float *shift; float slope;
+    uint32_t *keys; int ldk;
+    int M; int rows_per_obj; int C;
+    int *overflow;
+} tgp_conv_max_fused_args;
+int tgp_conv_max_fused(const tgp_conv_max_fused_args *args, tgp_stream_t stream);
 /* w2 (heads, 256, 1024) fp32 -> heads * 1024 * 256 * 2 fp16 in the kernel's operand order (hi / lo planes, K permuted). */
 int tgp_heads_pack_w2(const float *w2, int heads, void *out, tgp_stream_t stream);
 

@@ -43,6 +43,20 @@ class GemmArgs(ctypes.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/tgpose.h declares
+class ConvMaxFusedArgs(ctypes.Structure):
+    """struct tgp_conv_max_fused_args (include/tgpose.h)"""
+    _fields_ = [
+        ("fine", c_vp), ("ldf", c_int), ("K", c_int),
+        ("wa_s", c_vp),
+        ("p1", c_vp), ("ldp1", c_int), ("p1_rows", c_int), ("idx1", c_vp),
+        ("p2", c_vp), ("ldp2", c_int), ("p2_rows", c_int), ("idx2", c_vp),
+        ("bias", c_vp), ("scale", c_vp), ("shift", c_vp), ("slope", ctypes.c_float),
+        ("keys", c_vp), ("ldk", c_int),
+        ("M", c_int), ("rows_per_obj", c_int), ("C", c_int),
+        ("overflow", c_vp),
+    ]
+
+
 class HeadsFusedArgs(ctypes.Structure):
     """struct tgp_heads_fused_args (include/tgpose.h)"""
     _fields_ = [
@@ -133,6 +147,7 @@ SIGNATURES = {
     "tgp_generate_rt": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "tgp_canonicalize": (c_int, [c_vp] * 9 + [c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_heads_fused": (c_int, [ctypes.POINTER(HeadsFusedArgs), c_vp]),
+    "tgp_conv_max_fused": (c_int, [ctypes.POINTER(ConvMaxFusedArgs), c_vp]),
     "tgp_heads_pack_w2": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "tgp_sort_by_parent": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tgp_roi_cloud": (c_int, [c_vp] * 7 + [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),

@@ -276,6 +276,208 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// conv -> BatchNorm -> LeakyReLU -> max over points of a factored layer whose activation only feeds the max (conv_5 of Face_Enc,
+// FaceRecon.py:76-77 `conv_5` + `feat.max(1)`): the fused heads kernel's phase 1 with the operands' roles swapped -- the points'
+// fragments are the A operand, the weight rows the B operand -- so that a lane holds ONE channel and 16 points: the epilogue's
+// vectors are scalars per lane, the gathered coarse products are 4-byte loads coalesced over the channels, and the max over the
+// points is 15 in-lane maxima + one cross-half shuffle.  No conv2 accumulators: ~190 registers, two waves per SIMD; a workgroup
+// takes 128 points and CBW of the channel blocks (70 KB of LDS: two workgroups per CU).  Same products in the same order as the
+// tile kernel (activation hi x weight lo, lo x hi, hi x hi; K ascending), same epilogue order.
+#define CM_BUF (36 * 1024)                // conv weight rows (35 KB incl. padding) + 1 KB of epilogue vectors
+#define CM_NDMA 9                         // wave-instructions per wave and block
+
+struct ConvMaxParams {
+    const float *fine; int ldf, K;
+    const uint16_t *wa_s;
+    const float *p1; int ldp1; const int32_t *idx1;
+    const float *p2; int ldp2; const int32_t *idx2;
+    const float *bias, *scale, *shift;
+    float slope;
+    uint32_t *keys; int ldk;              // (B, C) keys, row stride ldk
+    int *overflow;
+    int M, rows_per_obj, C, tiles, chunks;
+    int main_tiles;                       // tiles [0, main_tiles) are cut into `chunks` channel chunks, the others into one per block
+};
+
+__global__ __launch_bounds__(256, 2) void conv_max_fused_kernel(ConvMaxParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char hf_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    // The benchmark's 32896 points are 257 tiles of 128: in two chunks each that is 514 workgroups for 512 resident slots, and two of
+    // them would run alone for a whole second round.  The tiles past the last full round are cut into single channel blocks
+    // instead: many short workgroups that drain in a fraction of a round.
+    const int ncb = p.C / 32;
+    int ptile, cb0, cb1;
+    if ((int)blockIdx.x < p.main_tiles * p.chunks) {
+        ptile = blockIdx.x / p.chunks;
+        const int cbw = (ncb + p.chunks - 1) / p.chunks;
+        cb0 = (blockIdx.x % p.chunks) * cbw, cb1 = min(cb0 + cbw, ncb);
+    } else {
+        const int rest = blockIdx.x - p.main_tiles * p.chunks;
+        ptile = p.main_tiles + rest / ncb;
+        cb0 = rest % ncb, cb1 = cb0 + 1;
+    }
+    const int m0 = ptile * 128 + wave * 32;
+    const int row = min(m0 + r, p.M - 1);
+
+    uint4 ah[HF_STEPS], al[HF_STEPS];     // the wave's points: A fragments, fp16 hi / lo planes of fine[row][16 s + 8 h .. + 7]
+    float amax = 0.f, poison = 0.f;
+    {
+        const float *fr = p.fine + (int64_t)row * p.ldf + 8 * h;
+#pragma unroll
+        for (int s = 0; s < HF_STEPS; ++s) {
+            float4 v0 = *reinterpret_cast<const float4 *>(fr + 16 * s), v1 = *reinterpret_cast<const float4 *>(fr + 16 * s + 4);
+            if (s == HF_STEPS - 1) {
+                const int k0 = 16 * s + 8 * h;
+                v0.x = k0 + 0 < p.K ? v0.x : 0.f, v0.y = k0 + 1 < p.K ? v0.y : 0.f, v0.z = k0 + 2 < p.K ? v0.z : 0.f, v0.w = k0 + 3 < p.K ? v0.w : 0.f;
+                v1.x = k0 + 4 < p.K ? v1.x : 0.f, v1.y = k0 + 5 < p.K ? v1.y : 0.f, v1.z = k0 + 6 < p.K ? v1.z : 0.f, v1.w = k0 + 7 < p.K ? v1.w : 0.f;
+            }
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))));
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w))));
+            poison += 0.f * (((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w)));
+            uint2 h0, l0, h1, l1;
+            hf_split(v0, h0, l0), hf_split(v1, h1, l1);
+            ah[s] = make_uint4(h0.x, h0.y, h1.x, h1.y), al[s] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
+    }
+    // the lane's 16 points (accumulator rows (e & 3) + 8 (e >> 2) + 4 h): element offsets of their coarse products' rows.  They
+    // depend on (h, e) only, so they live in 256 bytes of LDS per wave instead of 32 registers per lane.
+    __shared__ __attribute__((aligned(16))) int s_off[4][2][2][16];
+    {
+        const int lvl = lane >> 5, hh = (lane >> 4) & 1, e = lane & 15;
+        const int pr = min(m0 + (e & 3) + 8 * (e >> 2) + 4 * hh, p.M - 1);
+        s_off[wave][lvl][hh][e] = lvl ? p.idx2[pr] * p.ldp2 : p.idx1[pr] * p.ldp1;
+    }
+    const bool live = m0 < p.M;
+    const bool bad = __ballot(!(amax < 65504.f) || poison != poison) != 0ull;      // fp16 range guard, as in the heads kernel
+    if (live && bad && p.overflow && lane == 0) atomicOr(p.overflow, 1);
+    const int obj0 = m0 / p.rows_per_obj, bound = (obj0 + 1) * p.rows_per_obj;
+
+    int dma_off[CM_NDMA];
+#pragma unroll
+    for (int j0 = 0; j0 < CM_NDMA; ++j0) {
+        const int j = j0 * 4 + wave;
+        if (j < 35) {
+            const int c = j * 64 + lane, rw = c / 69, pc = c % 69;
+            dma_off[j0] = rw < 32 ? (rw * 68 + (pc < 68 ? pc : 67)) * 16 : 0;
+        } else dma_off[j0] = lane < 24 ? (lane & 7) * 16 : 0;
+    }
+    auto dma = [&](int cb, int buf, int j0) {
+        const int j = j0 * 4 + wave;
+        const char *src;
+        if (j < 35) src = reinterpret_cast<const char *>(p.wa_s) + (int64_t)cb * 32 * (HF_STEPS * 64);
+        else {
+            const float *v = lane < 8 ? p.bias : lane < 16 ? p.scale : p.shift;
+            src = reinterpret_cast<const char *>(v + cb * 32);
+        }
+        const uint32_t lds = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)(hf_smem + buf * CM_BUF + j * 1024));
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + dma_off[j0]), "s"(lds) : "memory", "m0");
+    };
+#pragma unroll
+    for (int j0 = 0; j0 < CM_NDMA; ++j0) dma(cb0, 0, j0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+
+    for (int cb = cb0; cb < cb1; ++cb) {
+        const int buf = (cb - cb0) & 1;
+        const char *base = hf_smem + buf * CM_BUF;
+        float g1[16], g2[16];
+        {
+            const int4 *o1 = reinterpret_cast<const int4 *>(s_off[wave][0][h]), *o2 = reinterpret_cast<const int4 *>(s_off[wave][1][h]);
+            const float *q1 = p.p1 + cb * 32 + r, *q2 = p.p2 + cb * 32 + r;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int4 a = o1[m], c = o2[m];
+                g1[4 * m] = q1[a.x], g1[4 * m + 1] = q1[a.y], g1[4 * m + 2] = q1[a.z], g1[4 * m + 3] = q1[a.w];
+                g2[4 * m] = q2[c.x], g2[4 * m + 1] = q2[c.y], g2[4 * m + 2] = q2[c.z], g2[4 * m + 3] = q2[c.w];
+            }
+        }
+        hf32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const char *wrow = base + r * HF_AROW + h * 16;
+        {
+            uint4 fh0 = *reinterpret_cast<const uint4 *>(wrow), fl0 = *reinterpret_cast<const uint4 *>(wrow + 32);
+            uint4 fh1 = *reinterpret_cast<const uint4 *>(wrow + 64), fl1 = *reinterpret_cast<const uint4 *>(wrow + 64 + 32);
+#pragma unroll
+            for (int s = 0; s < HF_STEPS; ++s) {
+                uint4 fh2 = fh1, fl2 = fl1;
+                if (s + 2 < HF_STEPS) {
+                    fh2 = *reinterpret_cast<const uint4 *>(wrow + (s + 2) * 64);
+                    fl2 = *reinterpret_cast<const uint4 *>(wrow + (s + 2) * 64 + 32);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, ah[s]), __builtin_bit_cast(hf16x8, fl0), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, al[s]), __builtin_bit_cast(hf16x8, fh0), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, ah[s]), __builtin_bit_cast(hf16x8, fh0), acc, 0, 0, 0);
+                if (s >= 1 && s <= CM_NDMA && cb + 1 < cb1) dma(cb + 1, buf ^ 1, s - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                fh0 = fh1, fl0 = fl1, fh1 = fh2, fl1 = fl2;
+            }
+        }
+        // epilogue: the lane's channel is 32 cb + r, its 16 accumulator elements are 16 points
+        const float *pv = reinterpret_cast<const float *>(base + 35 * 1024);
+        const float b = pv[r], sc = pv[32 + r], sh = pv[64 + r];
+        uint32_t k0 = 0, k1 = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int prow = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            float v = acc[e] + b;
+            v += g1[e];
+            v += g2[e];
+            v = v * sc + sh;
+            v = v > 0.f ? v : v * p.slope;
+            const uint32_t key = prow < p.M ? tgp_float_key(v) : 0u;
+            if (prow >= bound) k1 = key > k1 ? key : k1;
+            else k0 = key > k0 ? key : k0;
+        }
+        const uint32_t o0 = (uint32_t)__shfl_xor((int)k0, 32, 64), o1 = (uint32_t)__shfl_xor((int)k1, 32, 64);
+        k0 = o0 > k0 ? o0 : k0, k1 = o1 > k1 ? o1 : k1;
+        if (live && h == 0 && !(bad && p.overflow)) {
+            uint32_t *kp = p.keys + (int64_t)obj0 * p.ldk + cb * 32 + r;
+            if (k0) atomicMax(kp, k0);
+            if (k1) atomicMax(kp + p.ldk, k1);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+    }
+}
+
+extern "C" int tgp_conv_max_fused(const tgp_conv_max_fused_args *a, tgp_stream_t stream)
+{
+    TGP_REQUIRE(a && a->fine && a->wa_s && a->p1 && a->p2 && a->idx1 && a->idx2 && a->bias && a->scale && a->shift && a->keys);
+    TGP_REQUIRE(a->M > 0 && a->C > 0 && (a->C & 31) == 0 && a->rows_per_obj >= 32 && a->M % a->rows_per_obj == 0 && a->ldk >= a->C);
+    TGP_REQUIRE(a->K > 0 && a->K <= 16 * HF_STEPS && a->K > 16 * (HF_STEPS - 1) && a->ldf >= 16 * HF_STEPS && (a->ldf & 3) == 0);
+    TGP_REQUIRE(a->ldp1 >= a->C && a->ldp2 >= a->C);
+    // the coarse products' rows are addressed with 32-bit element offsets
+    TGP_REQUIRE((int64_t)a->p1_rows * a->ldp1 < (1ll << 31) && (int64_t)a->p2_rows * a->ldp2 < (1ll << 31));
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    TGP_REQUIRE(al16(a->fine) && al16(a->wa_s) && al16(a->bias) && al16(a->scale) && al16(a->shift));
+    ConvMaxParams p;
+    p.fine = a->fine, p.ldf = a->ldf, p.K = a->K;
+    p.wa_s = reinterpret_cast<const uint16_t *>(a->wa_s);
+    p.p1 = a->p1, p.ldp1 = a->ldp1, p.idx1 = a->idx1, p.p2 = a->p2, p.ldp2 = a->ldp2, p.idx2 = a->idx2;
+    p.bias = a->bias, p.scale = a->scale, p.shift = a->shift, p.slope = a->slope;
+    p.keys = a->keys, p.ldk = a->ldk, p.overflow = a->overflow;
+    p.M = a->M, p.rows_per_obj = a->rows_per_obj, p.C = a->C, p.tiles = tgp_cdiv(a->M, 128);
+    // channel chunks: enough workgroups for two per CU; a few tiles past a whole number of rounds go in single channel blocks
+    p.chunks = (p.C / 32) >= 2 && p.tiles < 512 ? 2 : 1;
+    const int round_tiles = 512 / p.chunks, over = p.tiles % round_tiles;
+    p.main_tiles = (p.tiles > round_tiles && over > 0 && over <= 8) ? p.tiles - over : p.tiles;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_max_fused_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CM_BUF);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int grid = p.main_tiles * p.chunks + (p.tiles - p.main_tiles) * (p.C / 32);
+    hipLaunchKernelGGL(conv_max_fused_kernel, dim3(grid), dim3(256), 2 * CM_BUF, tgp_hs(stream), p);
+    return TGP_LAUNCH_RESULT();
+}
+
 // W2 (heads, 256, 1024) fp32 -> [head][channel block][out][step][plane][16] fp16 with conv2's K order permuted to the layout the
 // conv1 accumulators leave the channels in: slot 8 h + t of step s2 is channel 32 cb + 16 s2 + 8 (t >> 2) + 4 h + (t & 3)
 __global__ void heads_pack_w2_kernel(const float *__restrict__ w2, int heads, uint16_t *__restrict__ out)

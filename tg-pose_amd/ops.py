@@ -434,6 +434,33 @@ def heads_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias1, scale1, shift1, w2p, b
     return keys, overflow
 
 
+def conv_max_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias, scale, shift, slope, B, rows_per_obj, k_alg=None):
+    """conv -> BN -> LeakyReLU -> max over points of a factored layer (tgp_conv_max_fused): keys (B, C) and the overflow flag."""
+    fine, ldf = _rows(fine, "fine")
+    C = bias.numel()
+    M = B * rows_per_obj
+    keys = torch.zeros(B, C, device=fine.device, dtype=torch.int32)
+    overflow = torch.zeros(1, device=fine.device, dtype=torch.int32)
+    timed = GEMM_TIMER is not None
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(fine.device))
+    a = _lib.ConvMaxFusedArgs()
+    a.fine, a.ldf, a.K = _p(fine), ldf, K
+    a.wa_s = _p(wa_s)
+    a.p1, a.ldp1, a.p1_rows, a.idx1 = _p(p1), p1.stride(0), p1.shape[0], _p(idx1)
+    a.p2, a.ldp2, a.p2_rows, a.idx2 = _p(p2), p2.stride(0), p2.shape[0], _p(idx2)
+    a.bias, a.scale, a.shift, a.slope = _p(bias), _p(scale), _p(shift), float(slope)
+    a.keys, a.ldk = _p(keys), C
+    a.M, a.rows_per_obj, a.C = M, rows_per_obj, C
+    a.overflow = _p(overflow)
+    check(_lib.lib().tgp_conv_max_fused(ctypes.byref(a), _stream(fine)), "tgp_conv_max_fused")
+    if timed:
+        e1.record(torch.cuda.current_stream(fine.device))
+        GEMM_TIMER.append((e0, e1, 2.0 * M * C * K, (M, C, K, 1), 2.0 * M * C * (k_alg or K)))
+    return keys, overflow
+
+
 @_timed("graph")
 def colmax_decode(keys, out2=False):
     rows, N = keys.shape
