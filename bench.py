@@ -200,6 +200,8 @@ def _tile_kernel_traffic(gemm_mode):
         else:
             f16 = lambda k: ", true" in k.split("<", 1)[-1]
             keys = [k for k in pmc if "gemm_split" in k and "_kernel" in k and f16(k) == (gemm_mode == "split16")]
+            if gemm_mode == "split16":
+                keys += [k for k in pmc if "heads_fused_kernel" in k or "conv_max_fused_kernel" in k]
         n_l = sum(pmc[k]["launches"] for k in keys)
         if not n_l:
             return None, None
@@ -435,7 +437,7 @@ def main():
             peak_basis = ("algorithmic fp32 FLOPs; each fp32 product costs 6 bf16 MFMA terms (3-term operand split), so "
                           "the bound is the dense bf16 MFMA peak 2500 TFLOP/s / 6; for scale, the fp32 MFMA peak is 157.3")
         elif args.gemm == "split16":
-            kernel_name = "gemm_split_kernel<f16>"
+            kernel_name = "gemm_split_kernel<f16> (+ heads_fused_kernel / conv_max_fused_kernel: the same 3-term fp16 MFMA arithmetic)"
             peak = PEAK_BF16_MFMA_TFLOPS / 3.0
             peak_basis = ("algorithmic fp32 FLOPs; each fp32 product costs 3 fp16 MFMA terms (2-term operand split), so the "
                           "bound is the dense fp16 MFMA peak 2500 TFLOP/s / 3; for scale, the fp32 MFMA peak is 157.3")
