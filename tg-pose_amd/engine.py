@@ -452,12 +452,15 @@ def wide_gemm_factored(pk, fine, inter, P1, P2, N):
     if HEADS_FUSED and f["w2p"] is not None:
         # conv_5 (N = 1024, only its max over points is used) on the light fused kernel, the heads on theirs; the tile-kernel form
         # of conv_5 follows predicated on the range flag (it normally returns at once)
-        keys5, over5 = ops.conv_max_fused(fine.view(M, -1), FINE_K, f["Wa_s"], P1, inter["near1"], P2, inter["near2"],
-                                          w["bias"][:1024], w["scale"][:1024], w["shift"][:1024], 0.2, B, N, k_alg=w["k_alg"])
+        light = P1.numel() < 2 ** 31 and P2.numel() < 2 ** 31      # the light kernel addresses the coarse products with 32-bit offsets
+        over5 = None
+        if light:
+            keys5, over5 = ops.conv_max_fused(fine.view(M, -1), FINE_K, f["Wa_s"], P1, inter["near1"], P2, inter["near2"],
+                                              w["bias"][:1024], w["scale"][:1024], w["shift"][:1024], 0.2, B, N, k_alg=w["k_alg"])
         ops.gemm(fine, f["Wa"], None, M=M, N=1024, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=0, bias=w["bias"],
                  scale=w["scale"], shift=w["shift"], act=1, slope_vec=w["slope"], colmax_keys=keys5, cm_cols=1024,
                  rows_per_obj=N, w_split=f["Wa_s"], gather1=(P1, P1.shape[1], inter["near1"]),
-                 gather2=(P2, P2.shape[1], inter["near2"]), flops_ref=0, pred=over5)
+                 gather2=(P2, P2.shape[1], inter["near2"]), flops_ref=0 if light else 2.0 * M * 1024 * w["k_alg"], pred=over5)
         # (returned as a thunk: the caller forks the PH / decoder branch, which needs only keys5, before the long heads kernel)
         def heads():
             keys2, overflow = ops.heads_fused(fine.view(M, -1), FINE_K, f["Wa_s"][1024:], P1[:, 1024:], inter["near1"], P2[:, 1024:],
