@@ -40,6 +40,8 @@ def test_c_abi_argument_errors_do_not_launch():
     assert h.tgp_orl_partial_floats(2, 1028, 128) == 2 * 17 * 128
     a = _lib.GemmArgs()
     assert h.tgp_gemm_f32(a, None) == -1
+    assert h.tgp_heads_fused(_lib.HeadsFusedArgs(), None) == -1 and h.tgp_conv_max_fused(_lib.ConvMaxFusedArgs(), None) == -1
+    assert h.tgp_heads_pack_w2(None, 3, None, None) == -1
 
 
 def test_gemm_args_struct_matches_header_layout():
@@ -59,6 +61,25 @@ def test_gemm_args_struct_matches_header_layout():
     G = _lib.GemmArgs
     assert [int(x) for x in out] == [ctypes.sizeof(G), G.M.offset, G.rowbias.offset, G.slope.offset, G.ldcm.offset,
                                      G.c_col0.offset, G.batch_stride_colmax.offset]
+
+
+def test_fused_kernel_arg_structs_match_header_layout():
+    """ctypes mirrors of tgp_heads_fused_args / tgp_conv_max_fused_args against the C compiler's layout of the header's structs."""
+    import ctypes
+    import subprocess
+    import tempfile
+    from tgpose_amd import _lib
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "tgpose.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",' \
+          'sizeof(tgp_heads_fused_args),offsetof(tgp_heads_fused_args,idx2),offsetof(tgp_heads_fused_args,keys),' \
+          'offsetof(tgp_heads_fused_args,overflow),sizeof(tgp_conv_max_fused_args),offsetof(tgp_conv_max_fused_args,idx2),' \
+          'offsetof(tgp_conv_max_fused_args,slope),offsetof(tgp_conv_max_fused_args,overflow));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        out = [int(x) for x in subprocess.check_output([os.path.join(d, "t")]).decode().split()]
+    H, C = _lib.HeadsFusedArgs, _lib.ConvMaxFusedArgs
+    assert out == [ctypes.sizeof(H), H.idx2.offset, H.keys.offset, H.overflow.offset,
+                   ctypes.sizeof(C), C.idx2.offset, C.slope.offset, C.overflow.offset]
 
 
 def test_state_dict_contract_matches_reference_checkpoint_names():
