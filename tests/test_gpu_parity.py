@@ -1682,6 +1682,37 @@ def test_fused_heads_kernel_equals_two_launch_heads(ops, B, N):
         assert d <= 1e-5 * max(1.0, outs[1][k].abs().max().item()), (k, d)
 
 
+def test_factored_and_fused_decoder_and_ph_branch_equal_concat_path(ops):
+    """The eval result has six keys; the decoder's reconstruction and the PH codes are computed too (they are what the trainer's
+    net would return) but not returned.  engine.posenet_forward's probe exposes them: the factored path with the fused kernels
+    (conv_5, whose keys feed the PH branch and through it the decoder's per-object bias, on the light fused kernel), the factored
+    path on tile GEMMs only, and the concat path must agree on recon / h1 / h2 to rounding."""
+    from tgpose_amd import FLAGS, engine
+    net = _net(8)
+    FLAGS.train = 0
+    B, N = 3, 1028
+    pts, obj = synth_points(B, N, 35)
+    torch.manual_seed(5)
+    i1 = torch.randperm(N)[: N // 4]
+    smp = (i1, torch.randperm(N // 4)[: N // 16])
+    pk = net.packed(DEV)
+    got = []
+    for fact, fused in ((True, True), (True, False), (False, False)):
+        old = engine.FACTORED, engine.HEADS_FUSED
+        engine.FACTORED, engine.HEADS_FUSED = fact, fused
+        try:
+            probe = {}
+            with torch.no_grad():
+                engine.posenet_forward(pk, g(pts), g(obj), False, sample_idx=smp, probe=probe)
+            got.append({k: probe[k].clone() for k in ("recon", "h1", "h2")})
+        finally:
+            engine.FACTORED, engine.HEADS_FUSED = old
+    for other in got[1:]:
+        for k in ("recon", "h1", "h2"):
+            d = (got[0][k] - other[k]).abs().max().item()
+            assert d <= 2e-5 * max(1.0, other[k].abs().max().item()), (k, d)
+
+
 def test_fused_heads_kernel_range_guard(ops):
     """The fused heads kernel splits the fine features and the conv1 activations into fp16: a magnitude beyond 65504 must not
     reach the outputs as NaN.  The wave that meets one raises a device flag instead of writing its keys and the predicated

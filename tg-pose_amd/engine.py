@@ -494,6 +494,8 @@ def decoder_forward_factored(pk, fine, inter, P1, P2, back, N):
     B = fine.shape[0]
     M = B * N
     rb = ops.linear_rows(back, w0) if back is not None else None
+    # (the light fused kernel in a storing form was measured for this layer: 110 us against 96 us on the tile kernel -- with 512
+    # channels a workgroup has 8 channel blocks to amortise its set-up over, and 4-byte stores of 16 points per lane)
     x = torch.empty(B, N, 512, device=fine.device, dtype=torch.float32)
     ops.gemm(fine, f["dec_a"], x, M=M, N=512, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=512, bias=b0, rowbias=rb, rows_per_obj=N,
              scale=sc0, shift=sh0, act=1, w_split=f["dec_a_s"], gather1=(P1[:, 4096:], P1.shape[1], inter["near1"]),
@@ -578,8 +580,10 @@ def draw_sample_idx(N):
     return i1, i2
 
 
-def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6):
-    """PoseNet9D(only_encoder=False).forward in eval mode (PoseNet9D.py:46-91)."""
+def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6, probe=None):
+    """PoseNet9D(only_encoder=False).forward in eval mode (PoseNet9D.py:46-91).
+    probe (tests): a dict that receives what the six-key eval result does not return -- recon (with the cloud's mean added), h1,
+    h2, feat_global -- so that the factored / fused eval paths' decoder and PH branch can be compared with the concat path's."""
     if points.dim() != 3 or points.shape[2] != 3:
         raise ValueError("points must be (B,N,3)")
     B, N, _ = points.shape
@@ -630,6 +634,8 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
         recon = decode(back)
     pg, pr, fg, fr, pT, ps = ops.head_post(green, red, ts, mean)
     out = dict()
+    if probe is not None:
+        probe.update(recon=recon + mean.view(B, 1, 3), h1=h1, h2=h2, keys5=keys5)
     if train_keys:
         out["recon"] = ops.add_mean_(recon, mean)
     out.update(p_green_R=pg, p_red_R=pr, f_green_R=fg, f_red_R=fr, Pred_T=pT, Pred_s=ps)
