@@ -448,13 +448,14 @@ def wide_gemm_factored(pk, fine, inter, P1, P2, N):
     dev = fine.device
     w, f = pk.wide, pk.fact
     M = B * N
-    keys5 = torch.zeros(B, 1024, device=dev, dtype=torch.int32)
     if HEADS_FUSED and f["w2p"] is not None:
         # conv_5 (N = 1024, only its max over points is used) on the light fused kernel, the heads on theirs; the tile-kernel form
         # of conv_5 follows predicated on the range flag (it normally returns at once)
         light = P1.numel() < 2 ** 31 and P2.numel() < 2 ** 31      # the light kernel addresses the coarse products with 32-bit offsets
         over5 = None
-        if light:
+        if not light:
+            keys5 = torch.zeros(B, 1024, device=dev, dtype=torch.int32)
+        else:
             keys5, over5 = ops.conv_max_fused(fine.view(M, -1), FINE_K, f["Wa_s"], P1, inter["near1"], P2, inter["near2"],
                                               w["bias"][:1024], w["scale"][:1024], w["shift"][:1024], 0.2, B, N, k_alg=w["k_alg"])
         ops.gemm(fine, f["Wa"], None, M=M, N=1024, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=0, bias=w["bias"],
@@ -479,6 +480,7 @@ def wide_gemm_factored(pk, fine, inter, P1, P2, N):
                      batch_strides=(1024, 256 * 1024, 0, 256, B * 256), w_split=w["W2s"], flops_ref=0, pred=overflow)
             return keys2
         return keys5, heads
+    keys5 = torch.zeros(B, 1024, device=dev, dtype=torch.int32)
     H = torch.empty(M, 3072, device=dev, dtype=torch.float32)
     ops.gemm(fine, f["Wa"], H, M=M, N=4096, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=3072, bias=w["bias"],
              scale=w["scale"], shift=w["shift"], act=1, slope_vec=w["slope"], colmax_keys=keys5, cm_cols=1024,
