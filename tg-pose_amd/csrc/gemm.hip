@@ -1497,11 +1497,14 @@ static int launch_split(GemmParams &p, hipStream_t stream)
                 (!p.gres1 || ((p.ldg1 & 3) == 0 && al16(p.gres1))) && (!p.gres2 || ((p.ldg2 & 3) == 0 && al16(p.gres2)));
     // gathered residuals exist in the LDS-staged epilogue only (and in the fp32 kernels' register form): refuse the rest
     TGP_REQUIRE(!(p.gres1 || p.gres2) || (p.vec_epi && !(tgp_split_variant != 7 && (tgp_split_variant & 64))));
-    // few 256 x 256 tiles (N <= 256, or less than 1.5 rounds of them) leave CUs idle or half empty: such launches run as
+    // few 256 x 256 tiles (N <= 256, or less than one round of them) leave CUs idle or half empty: such launches run as
     // 256 x 128 tiles on two 512-thread workgroups per CU.  Measured over the forward's 15 tile-kernel launches, each timed
     // alone: 139 us average against 154 us with square tiles only (the wide layer alone would lose: 1.04 -> 1.32 ms)
     const int64_t sq_tiles = (int64_t)tgp_cdiv(p.M, GEMM_BIG) * tgp_cdiv(p.N, GEMM_BIG) * p.batch;
-    const bool narrow = p.N <= 256 || sq_tiles * 2 < 3 * (int64_t)resident_slots();
+    // (round 2, re-measured on the forward's shapes with the current epilogues, scripts/route_ab.py: between one and 1.5 rounds of
+    // square tiles the 1024-thread form is the faster one -- M = 32896, N = 512, K = 512: 85 vs 97 us; M = 8224, N = 2304,
+    // K = 256: 54 vs 58 us -- below one round the two-workgroups-per-CU form wins by 25-30 %)
+    const bool narrow = p.N <= 256 || sq_tiles < (int64_t)resident_slots();
     const bool force512 = tgp_split_variant != 7 && (tgp_split_variant & 16), forbid512 = tgp_split_variant != 7 && (tgp_split_variant & 32);
     // (per launch the narrow layers are 25 % faster this way; in the whole forward, where they overlap other branches,
     // the routing measured +-0: 8769 / 8730 vs 8782 / 8881 objects/s)
