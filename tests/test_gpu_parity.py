@@ -1682,6 +1682,46 @@ def test_fused_heads_kernel_equals_two_launch_heads(ops, B, N):
         assert d <= 1e-5 * max(1.0, outs[1][k].abs().max().item()), (k, d)
 
 
+@pytest.mark.parametrize("B,N", [(3, 1028), (2, 160), (5, 256)])
+def test_fused_kernels_vs_fp64(ops, B, N):
+    """tgp_heads_fused and tgp_conv_max_fused at the operator level: random operands, fp64 torch restatement of
+    max_points relu(bn2(conv2(relu(bn1(W_fine . fine + P1[idx1] + P2[idx2] + bias))))) resp. max_points lrelu(bn(conv ...)).
+    Objects of N rows with N % 32 != 0 (waves straddle objects), M % 128 != 0 (a partial last tile), K = 268 of 272 columns
+    with garbage in the padding.  Accuracy bar: that of the split GEMM (3e-6 of the output scale per layer; two layers)."""
+    gen = torch.Generator().manual_seed(B * 1000 + N)
+    M, K, heads = B * N, 268, 3
+    fine = torch.randn(M, 272, generator=gen)
+    fine[:, K:] = float("nan")                                     # the padding columns are not the caller's to define
+    fine[:, :K][:, ::9] *= 30.0
+    Wa = torch.randn((heads + 1) * 1024, 272, generator=gen) / K ** 0.5       # conv_5's 1024 rows, then the heads'
+    Wa[:, K:] = 0
+    n1, n2 = max(M // 4, 1), max(M // 16, 1)
+    P1, P2 = torch.randn(n1, 4096, generator=gen), torch.randn(n2, 4096, generator=gen)
+    idx1 = torch.randint(0, n1, (M,), generator=gen, dtype=torch.int32)
+    idx2 = torch.randint(0, n2, (M,), generator=gen, dtype=torch.int32)
+    bias, scale, shift = (torch.randn(4096, generator=gen) * 0.1, torch.rand(4096, generator=gen) + 0.5, torch.randn(4096, generator=gen) * 0.1)
+    W2 = torch.randn(heads, 256, 1024, generator=gen) / 32.0
+    b2, sc2, sh2 = (torch.randn(heads, 256, generator=gen) * 0.1, torch.rand(heads, 256, generator=gen) + 0.5, torch.randn(heads, 256, generator=gen) * 0.1)
+    d = lambda t: g(t.contiguous())
+    was = ops.split_f16(d(Wa))
+    keys2, over = ops.heads_fused(d(fine), K, was[1024:], d(P1)[:, 1024:], d(idx1), d(P2)[:, 1024:], d(idx2), d(bias)[1024:], d(scale)[1024:],
+                                  d(shift)[1024:], ops.heads_pack_w2(d(W2)), d(b2), d(sc2), d(sh2), B, N)
+    keys5, over5 = ops.conv_max_fused(d(fine), K, was, d(P1), d(idx1), d(P2), d(idx2), d(bias)[:1024], d(scale)[:1024], d(shift)[:1024],
+                                      0.2, B, N)
+    assert int(over.item()) == 0 and int(over5.item()) == 0
+    got2 = ops.colmax_decode(keys2.view(heads * B, 256)).view(heads, B, 256).cpu().double()
+    got5 = ops.colmax_decode(keys5).cpu().double()
+    f64 = fine[:, :K].double()
+    pre = f64 @ Wa[:, :K].double().t() + bias.double() + P1.double()[idx1.long()] + P2.double()[idx2.long()]
+    pre = pre * scale.double() + shift.double()
+    c5 = torch.nn.functional.leaky_relu(pre[:, :1024], 0.2).view(B, N, 1024).max(1)[0]
+    assert (got5 - c5).abs().max().item() <= 3e-6 * c5.abs().max().item()
+    H = torch.relu(pre[:, 1024:]).view(M, heads, 1024)
+    for hd in range(heads):
+        y = torch.relu((H[:, hd] @ W2[hd].double().t() + b2[hd].double()) * sc2[hd].double() + sh2[hd].double()).view(B, N, 256).max(1)[0]
+        assert (got2[hd] - y).abs().max().item() <= 6e-6 * y.abs().max().item(), hd
+
+
 def test_factored_and_fused_decoder_and_ph_branch_equal_concat_path(ops):
     """The eval result has six keys; the decoder's reconstruction and the PH codes are computed too (they are what the trainer's
     net would return) but not returned.  engine.posenet_forward's probe exposes them: the factored path with the fused kernels
