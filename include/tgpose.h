@@ -33,6 +33,10 @@ extern "C" {
 typedef void *tgp_stream_t; /* hipStream_t */
 
 int tgp_version(void);
+/* Node census of a captured hipGraph (hipGraph_t): counts[0..3] = kernel, memcpy, memset, other nodes.  Host-only, nothing is
+ * launched.  No reference counterpart (the reference never captures); the step capture of this repo refuses a graph that holds
+ * a MEMSET node -- the mark of an ATen multi-block reduction inside the capture ("captured step"). */
+int tgp_graph_node_counts(void *hip_graph, int *counts);
 /* largest point count per object / neighbour count the kNN kernels accept */
 int tgp_knn_max_points(void);
 int tgp_knn_max_k(void);

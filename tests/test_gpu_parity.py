@@ -69,6 +69,28 @@ def test_knn_xyz_duplicates_follow_index_order(ops):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("n,k,kind", [(2048, 20, "identical"), (2046, 20, "identical"), (1028, 20, "identical"),
+                                      (1028, 20, "zero_padded"), (2048, 8, "zero_padded"), (1028, 20, "x40"), (300, 20, "x100")])
+def test_knn_xyz_coincident_points_take_the_serial_selection(ops, n, k, kind):
+    """Clouds with many coincident points leave more than 64 candidates under the rank-counting bound, so rows fall back to
+    wave_select_serial_keys; at n > 1088 (32 candidates per lane) a lane can hold 32 survivors, which the ballot prefix sum
+    must count (round-2 advisor finding: five ballot bits counted such a lane as empty).  Order = (distance, index)."""
+    _clib, _, _ = _oracle()
+    base, _ = synth_points(2, n, seed=n + k)
+    xyz = (base - base.mean(dim=1, keepdim=True)).contiguous()
+    if kind == "identical":
+        xyz[:] = xyz[:, :1]                      # every point the same: each row has n candidates at distance 0 (or one rounding of it)
+    elif kind == "zero_padded":
+        xyz[:, n // 3:] = 0.0                    # a cloud padded with zeros: two thirds of the candidates coincide
+    else:
+        rep = int(kind[1:])                      # every point repeated `rep` times, interleaved
+        m = -(-n // rep)
+        xyz = xyz[:, :m].repeat(1, rep, 1)[:, :n].contiguous()
+    want = _clib.knn(xyz.numpy(), k)
+    got = ops.knn_xyz(g(xyz), k).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("key,k", [("xyz", 20), ("xyz", 4), ("bottle", 20), ("dup", 8)])
 def test_knn_xyz_vs_reference_golden(ops, key, k):
     _clib, _, _ = _oracle()
@@ -101,6 +123,20 @@ def test_knn_feat_bit_exact_vs_oracle(ops, B, n, d, k, ld):
     buf[:, :, :d] = x
     want = _clib.knn(x.numpy(), k)
     got = ops.knn_feat(g(buf)[:, :, :d], k).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("B,n,d,k", [(2, 1028, 128, 20), (2, 257, 256, 20), (1, 1152, 128, 20)])
+def test_knn_feat_coincident_rows_take_the_serial_selection(ops, B, n, d, k):
+    """dead features (all-zero rows after a ReLU) and repeated rows: hundreds of exactly tied distances per row, so the rank-counting
+    selection hands the row to the serial form; order = (distance, index), as the oracle's."""
+    _clib, _, _ = _oracle()
+    gen = torch.Generator().manual_seed(n * 3 + d)
+    x = torch.relu(torch.randn(B, n, d, generator=gen) * 0.7 + 0.2)
+    x[:, n // 2:] = 0.0                           # half of the cloud has dead features
+    x[:, : n // 4] = x[:, :1]                     # a quarter repeats one row
+    want = _clib.knn(x.numpy(), k)
+    got = ops.knn_feat(g(x), k).cpu().numpy()
     assert np.array_equal(got, want)
 
 
@@ -2599,3 +2635,100 @@ def test_overlapped_two_segment_step_equals_single_graph(ops):
                 continue
             assert (g1[k] - v).abs().max().item() <= 1e-4 * v.abs().max().item() + 1e-7, k
     assert out[True][0][0] != out[True][1][0]
+
+
+def test_rccl_exchange_branch_world_size_one(ops):
+    """The RCCL branch of the data-parallel step, executed (round-2 verdict: it had never run anywhere): a process group on the
+    `nccl` backend with ONE rank, shard.GradBuckets.force_collectives so that the collectives are issued although they move no
+    data.  What runs is exactly the multi-rank code path: in-place reduce_scatter_tensor on a view of the flat bucket, the
+    slice's division, all_gather_into_tensor, all on the exchange stream between the two captured segments, the compute stream
+    joining through the recorded event.  Against the same step without collectives: the late bucket (heads, PH predictor,
+    decoder: fixed-order sums) bit for bit, the encoder's bucket up to its float-atomic scatters; the NaN-aware finish_step steps."""
+    import socket
+    import torch.distributed as dist
+    from tgpose_amd import FLAGS, shard
+    from tgpose_amd.autograd import LATE_PREFIXES
+    assert not dist.is_initialized()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    B, N = 6, 512
+    db = {k: g(v) for k, v in _step_db([0, 1, 2, 3, 4, 5], N, 41).items()}
+    torch.manual_seed(23)
+    draws = []
+    for _ in range(2):
+        pair = []
+        for _ in range(2):
+            i1 = torch.randperm(N)[: N // 4]
+            pair.append((i1, torch.randperm(i1.numel())[: i1.numel() // 4]))
+        draws.append(pair)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        out = {}
+        for force in (False, True):
+            shard.GradBuckets.force_collectives = force
+            tr = _trainer(29)
+            tr.optimizer = torch.optim.SGD(tr.net1.parameters(), lr=1e-6)
+            state = [{k: v.detach().clone() for k, v in net.state_dict().items()} for net in (tr.net1, tr.net2)]
+            step = tr.graphed_step(db, overlap=True)
+            res = []
+            for d in draws:
+                tr.net1.load_state_dict(state[0]), tr.net2.load_state_dict(state[1])
+                total = step(sample_idx=d)
+                assert tr._exchanged                                   # the replay ran its exchange hooks
+                res.append((total.item(), {k: p.grad.detach().clone() for k, p in tr.net1.named_parameters() if p.grad is not None}))
+                assert tr.finish_step(total=total) is True and not tr._exchanged
+            assert (tr._buckets._xstream is not None) == force         # the RCCL branch ran only when forced
+            out[force] = res
+    finally:
+        shard.GradBuckets.force_collectives = False
+        dist.destroy_process_group()
+        FLAGS.train = 0
+    for (t0, g0), (t1, g1) in zip(out[False], out[True]):
+        assert t0 == t1
+        for k, v in g0.items():
+            if "proj_layer" in k:
+                continue
+            if k.startswith(tuple(LATE_PREFIXES)):
+                assert torch.equal(g1[k], v), k
+            else:
+                assert (g1[k] - v).abs().max().item() <= 1e-4 * v.abs().max().item() + 1e-7, k
+
+
+def test_nan_step_is_skipped_like_the_reference_loop(ops):
+    """trainer/RL_TDA.py:217-220: a NaN total skips backward, clip and the optimizer step.  Eager: weights and gradients untouched;
+    captured step: finish_step(total=...) zeroes the gradients the replay produced and leaves the weights alone."""
+    from tgpose_amd import FLAGS
+    B, N = 4, 256
+    db = {k: g(v) for k, v in _step_db([0, 1, 2, 3], N, 43).items()}
+    bad = dict(db)
+    bad["translation"] = db["translation"].clone()
+    bad["translation"][1, 0] = float("nan")                             # a NaN ground truth reaches the Tran term and the total
+    try:
+        tr = _trainer(31)
+        tr.optimizer = torch.optim.SGD(tr.net1.parameters(), lr=1e-3)
+        before = {k: v.detach().clone() for k, v in tr.net1.state_dict().items() if v.dtype.is_floating_point and "running" not in k}
+        total, _ = tr.train_iteration(bad)
+        assert math.isnan(total.item())
+        for k, v in tr.net1.state_dict().items():
+            if k in before:
+                assert torch.equal(v, before[k]), k
+        assert all(p.grad is None or not torch.isnan(p.grad).any() for p in tr.net1.parameters())
+        total, _ = tr.train_iteration(db)                               # a sane batch steps
+        assert math.isfinite(total.item())
+        assert any(not torch.equal(v, before[k]) for k, v in tr.net1.state_dict().items() if k in before)
+        del total
+        tr2 = _trainer(31)
+        tr2.optimizer = torch.optim.SGD(tr2.net1.parameters(), lr=1e-3)
+        step = tr2.graphed_step(db)
+        w0 = {k: v.detach().clone() for k, v in tr2.net1.state_dict().items() if k in before}
+        t_bad = step(db=bad)
+        assert tr2.finish_step(total=t_bad) is False
+        assert all(torch.equal(v, w0[k]) for k, v in tr2.net1.state_dict().items() if k in w0)
+        assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in tr2.net1.parameters())
+        t_ok = step(db=db)
+        assert tr2.finish_step(total=t_ok) is True
+        assert any(not torch.equal(v, w0[k]) for k, v in tr2.net1.state_dict().items() if k in w0)
+    finally:
+        FLAGS.train = 0

@@ -75,6 +75,7 @@ class HeadsFusedArgs(ctypes.Structure):
 
 SIGNATURES = {
     "tgp_version": (c_int, []),
+    "tgp_graph_node_counts": (c_int, [c_vp, c_vp]),
     "tgp_knn_max_points": (c_int, []),
     "tgp_knn_max_k": (c_int, []),
     "tgp_center": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),

@@ -133,9 +133,12 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
         // As inline assembly: through the builtin the compiler, which cannot know that the DMA fills the OTHER buffer, drained
         // vmcnt before every LDS read that followed one (phase 2: 52 -> 182 us).  Opaque to its counters, so the waits are written
         // by hand: vmcnt(0) before the barrier that ends the block; no compiler-visible vector load is in flight meanwhile.
+        // The LDS base travels in m0 as a register-constrained INPUT ("{m0}"): the compiler writes m0 itself and knows it is
+        // live here (round 2 wrote it inside the asm and listed it as a clobber, which the compiler does not promise to honour
+        // for a reserved register); the s_nop covers the one wait state between an m0 write and an LDS-DMA instruction.
         const uint32_t lds = __builtin_amdgcn_readfirstlane(
             (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)(hf_smem + buf * HF_BUF + j * 1024));
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + dma_off[j0]), "s"(lds) : "memory", "m0");
+        asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + dma_off[j0]), "{m0}"(lds) : "memory");
     };
 #pragma unroll
     for (int j0 = 0; j0 < HF_NDMA; ++j0) dma(0, 0, j0);
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void conv_max_fused_kernel(ConvMaxParams p)
         }
         const uint32_t lds = __builtin_amdgcn_readfirstlane(
             (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)(hf_smem + buf * CM_BUF + j * 1024));
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + dma_off[j0]), "s"(lds) : "memory", "m0");
+        asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + dma_off[j0]), "{m0}"(lds) : "memory");
     };
 #pragma unroll
     for (int j0 = 0; j0 < CM_NDMA; ++j0) dma(cb0, 0, j0);

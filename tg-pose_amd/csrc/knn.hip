@@ -296,10 +296,14 @@ __device__ __forceinline__ bool wave_select_ranked(const uint32_t (&key)[NT], in
     int cnt = 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) cnt += key[t] <= tau;
-    // exclusive prefix sum of cnt over the lanes, bit by bit (cnt <= NT < 32): ballots and bit counts, no cross-lane data movement
+    // exclusive prefix sum of cnt over the lanes, bit by bit: ballots and bit counts, no cross-lane data movement.  cnt <= NT
+    // INCLUSIVE (a lane whose NT candidates all lie under tau: coincident points), so the loop covers the bits of NT itself --
+    // knn_xyz_kernel<32> needs six; with five a full lane counted as empty and `total` wrapped below the 64-survivor test.
+    constexpr int CNT_BITS = NT >= 32 ? 6 : NT >= 16 ? 5 : NT >= 8 ? 4 : NT >= 4 ? 3 : NT >= 2 ? 2 : 1;
+    static_assert(NT < (1 << CNT_BITS) && NT <= 32, "cnt must fit the ballot prefix sum");
     int pos = 0, total = 0;
 #pragma unroll
-    for (int bit = 0; bit < 5; ++bit) {
+    for (int bit = 0; bit < CNT_BITS; ++bit) {
         const unsigned long long m = __ballot((cnt >> bit) & 1);
         pos += (int)(__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) << bit;
         total += __popcll(m) << bit;

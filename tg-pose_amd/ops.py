@@ -71,6 +71,14 @@ def _i32(t, name):
     return t
 
 
+def graph_node_counts(raw_graph):
+    """(kernel, memcpy, memset, other) node counts of a captured hipGraph; raw_graph = torch.cuda.CUDAGraph(keep_graph=True)
+    .raw_cuda_graph() after the capture (host-only census, tgp_graph_node_counts)"""
+    counts = (ctypes.c_int * 4)()
+    check(_lib.lib().tgp_graph_node_counts(ctypes.c_void_p(int(raw_graph)), counts), "tgp_graph_node_counts")
+    return tuple(int(c) for c in counts)
+
+
 @_timed("graph")
 def center(points):
     """points (B,n,3) -> (xyz_c (B,n,3), mean (B,3))"""

@@ -96,7 +96,9 @@ class GradBuckets(object):
     over xGMI both halves move (world-1)/world of the bucket per GPU spread over all peers' links, where a call per tensor would
     pay 164 launch latencies and a ring over one link.  Backends without reduce_scatter_tensor (gloo: the CPU rehearsal and
     the tests) use one all-reduce per bucket.  Unmeasured on more than one GPU in this repository (no multi-GPU box is available
-    to the build): correctness is covered by the two-rank gloo test, the overlap by construction."""
+    to the build): correctness is covered by the two-rank gloo test; the RCCL branch itself (in-place reduce-scatter on a view
+    of the flat buffer, all-gather, exchange-stream ordering against the second graph) executes on the one-GPU box at world
+    size 1 under ``force_collectives`` (tests/test_gpu_parity.py::test_rccl_exchange_branch_world_size_one)."""
 
     def __init__(self, named_params, late_prefixes, skip=("proj_layer",)):
         named = [(n, p) for n, p in named_params if p.requires_grad]
@@ -104,6 +106,7 @@ class GradBuckets(object):
                   [(n, p) for n, p in named if not n.startswith(tuple(late_prefixes)) and not any(s in n for s in skip)]]
         self.unsent = [p for n, p in named if any(s in n for s in skip)]
         self.flat, self.params = [], []
+        self._xstream = None
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         for g in groups:
             numel = sum(p.numel() for _, p in g)
@@ -124,28 +127,55 @@ class GradBuckets(object):
         for f in self.flat:
             f.zero_()
 
+    # tests / rehearsal: run the collectives even when the process group has a single rank (they then move no data but execute
+    # the same calls on the same streams in the same order), so that the RCCL branch is exercised on a one-GPU box
+    force_collectives = False
+
+    def _active(self):
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size() > 1 or self.force_collectives
+
     def reduce(self, i, async_op=True):
-        """start the exchange of bucket i (average over the ranks); returns a handle for wait().  No-op without a process group."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        """Start the exchange of bucket i (average over the ranks) behind the work already enqueued on the current stream;
+        returns a handle for wait().  No-op without a process group.
+
+        RCCL: the WHOLE exchange -- reduce-scatter into this rank's 1/world slice, the slice's division by world, all-gather
+        back into the flat buffer -- is enqueued here on a dedicated exchange stream that first waits for the current stream
+        (the gradients are complete there).  The calling stream is not blocked: whatever it enqueues next (the encoder's
+        backward, graph 2 of the overlapped step) runs beside all three pieces; wait() only makes it wait for the recorded
+        end event.  (Round 2 issued the all-gather from wait(), i.e. after the encoder's backward: only the reduce-scatter
+        half was overlapped.)"""
+        if not self._active():
             return None
         flat, world, rank = self.flat[i], dist.get_world_size(), dist.get_rank()
         if dist.get_backend() == "nccl":
-            shard = flat.view(world, -1)[rank]
-            w1 = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, async_op=True)
-            return ("rs", i, w1, shard)
+            cur = torch.cuda.current_stream(flat.device)
+            if self._xstream is None:
+                self._xstream = torch.cuda.Stream(device=flat.device)
+            xs = self._xstream
+            xs.wait_stream(cur)
+            with torch.cuda.stream(xs):
+                shard = flat.view(world, -1)[rank]
+                # blocking form = "the current (exchange) stream waits for the collective": nothing blocks on the host
+                dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
+                shard.div_(world)
+                dist.all_gather_into_tensor(flat, shard)
+                done = torch.cuda.Event()
+                done.record(xs)
+            return ("rs", i, done, None)
         if flat.is_cuda:
             torch.cuda.current_stream(flat.device).synchronize()     # gloo stages device tensors through the host (rehearsal only)
         return ("ar", i, dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op), None)
 
     def wait(self, handle):
+        """the current stream (clip_grad_norm_ and the optimizer run on it next) waits for the exchange started by reduce()"""
         if handle is None:
             return
-        kind, i, work, shard = handle
+        kind, i, work, _ = handle
         world = dist.get_world_size()
         if kind == "rs":
-            work.wait()                                          # the compute stream now waits for the reduce-scatter
-            shard.div_(world)
-            dist.all_gather_into_tensor(self.flat[i], shard)
+            torch.cuda.current_stream(self.flat[i].device).wait_event(work)
         else:
             if work is not None:
                 work.wait()

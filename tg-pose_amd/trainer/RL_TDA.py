@@ -51,8 +51,9 @@ class RT_TDA_Trainer(object):
         self.loss_tda_net = None
         self.optimizer = None
         self.scheduler = None
-        self._graphed = None
-        self._buckets = None
+        self._graphed = None          # the last GraphedStep captured over net1 (its static .grad buffers must stay in place)
+        self._buckets = None          # shard.GradBuckets of a graphed_step(overlap=True): p.grad are views into its flat buffers
+        self._exchanged = False       # set by a replay whose gradient exchange has already run, cleared by finish_step
 
     def setup(self, mode, optimizer=None, scheduler=None):
         self.init_network(mode)
@@ -118,34 +119,65 @@ class RT_TDA_Trainer(object):
         return output_dict, loss_dict
 
     # -------------------------------------------------------------------------------------------------------------------
-    def finish_step(self):
+    def loss_is_nan(self, total):
+        """the loop's NaN test (:217-220) -- one host read of the device scalar.  Data parallel: the ranks must skip or step
+        TOGETHER (a rank that skipped would miss the collective the others wait in), so the flag is max-reduced first."""
+        import torch.distributed as dist
+        bad = torch.isnan(total.detach()).reshape(-1).any().to(torch.int32)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            bad = bad.to(self.device) if dist.get_backend() == "nccl" else bad.cpu()
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        return bool(bad.item())
+
+    def finish_step(self, total=None):
         """what follows total_loss.backward() in the loop (:223-226), with the data-parallel gradient exchange in front: the
         clip must see the averaged gradients.  After a graphed_step(overlap=True) replay the exchange has already
-        run (bucket by bucket, overlapped with the backward)."""
+        run (bucket by bucket, overlapped with the backward): the replay says so through ``_exchanged``.
+
+        total: the replayed step's loss (graphed_step's return value).  When given, the reference's NaN test (:217-220) is
+        applied here -- a captured step has run its backward before anyone can look at the loss, so a NaN step is undone by
+        zeroing the gradients instead of skipping backward(): no clip, no optimizer / scheduler step, weights untouched.
+        Returns False for such a skipped step."""
         from .. import shard
-        if self._buckets is None:
+        if total is not None and self.loss_is_nan(total):
+            print('Found nan in total loss')
+            self._exchanged = False
+            for p in self.net1.parameters():
+                if p.grad is not None:
+                    p.grad.zero_()
+            return False
+        if not self._exchanged:
             shard.allreduce_gradients(self.net1.parameters())
+        self._exchanged = False
         torch.nn.utils.clip_grad_norm_(self.net1.parameters(), 5)
         if self.optimizer is not None:
             self.optimizer.step()
         if self.scheduler is not None:
             self.scheduler.step()
+        return True
 
     def train_iteration(self, db):
-        """one eager iteration of RL_TDA_train's loop body (:205-226); returns (total loss, loss_dict)"""
+        """one eager iteration of RL_TDA_train's loop body (:205-226); returns (total loss, loss_dict).  A NaN total skips
+        backward, clip and the optimizer step, as the reference's loop does (:217-220)."""
         if self.optimizer is not None:
-            self.optimizer.zero_grad(set_to_none=True)
+            # once a captured step or flat gradient buckets exist, .grad tensors are static storage: zero them in place
+            self.optimizer.zero_grad(set_to_none=self._graphed is None and self._buckets is None)
         _, loss_dict = self.RL_TDA_train_step(db)
         total = total_loss(loss_dict)
+        if self.loss_is_nan(total):
+            print('Found nan in total loss')
+            return total.detach(), loss_dict
         total.backward()
+        self._exchanged = False
         self.finish_step()
         return total.detach(), loss_dict
 
     def graphed_step(self, db, overlap=False, _debug=""):
         """Capture forward (both nets) + losses + backward for batches of db's shapes as hipGraphs; returns a callable
         ``step(db=None, sample_idx=None) -> total loss`` that copies a new batch into the static buffers, replays, and leaves the
-        gradients in net1's ``.grad`` buffers (then call finish_step()).  The NaN test of the loop (:217-220) is the caller's:
-        the returned loss is a device scalar.
+        gradients in net1's ``.grad`` buffers; then call ``finish_step(total=loss)``, which applies the loop's NaN test
+        (:217-220) to the returned device scalar and skips clip + optimizer for a NaN step (``finish_step()`` without the loss
+        steps unconditionally and reads nothing back).
 
         overlap=True (the data-parallel form): the backward is captured in two segments split at the encoder's output, net1's
         gradients live in two flat buckets (shard.GradBuckets), and the exchange of the late layers' bucket (84 of 97 MB) is
@@ -168,14 +200,20 @@ class RT_TDA_Trainer(object):
             self._buckets = buckets = shard.GradBuckets(self.net1.named_parameters(), LATE_PREFIXES)
 
             def between():
-                pending.append(buckets.reduce(0))                 # travels while the encoder's backward computes
+                # reduce-scatter, the shard's average and the all-gather of the late bucket are all enqueued here, on the
+                # exchange stream: the whole exchange travels while the encoder's backward (graph 2) computes
+                pending.append(buckets.reduce(0))
 
             def after():
                 pending.append(buckets.reduce(1))
                 while pending:
                     buckets.wait(pending.pop(0))
+                self._exchanged = True                            # finish_step must not exchange again
+        else:
+            self._buckets = None                                  # an earlier overlap capture's buckets no longer describe this step
 
         g = GraphedStep(list(self.net1.parameters()), step_fn, [N, N], dev, cut=cut, between=between, after=after)
+        self._graphed = g
 
         def step(db=None, sample_idx=None):
             if db is not None:
