@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 3
+#define TGP_ABI_VERSION 4
 #define TGP_EINVAL (-1)       /* null pointer / non-positive size / misaligned stride */
 #define TGP_EUNSUPPORTED (-2) /* shape outside what the kernels are built for */
 
@@ -72,9 +72,11 @@ int tgp_nn1(const float *target, const float *source, int B, int n, int m, int32
 int tgp_normalize_dirs(const float *directions, int SC, float *out, tgp_stream_t stream);
 
 /* gcn3d.py:91-106 HSlayer_surface.graph_conv.  xyz (B,n,3), idx (B,n,k), sdn (3,S*C) unit support
- * directions -> out (B,n,C) row stride ldo:  mean_s max_j relu(<dir_j, sdn[:, s*C+c]>). */
+ * directions -> out (B,n,C) row stride ldo:  mean_s max_j relu(<dir_j, sdn[:, s*C+c]>).
+ * xyz_pad != 0 (ldo >= C + 4): the row's columns C..C+3 also receive the point (x, y, z, 0), so that the caller's next GEMM can
+ * take HSlayer_surface's STE convolution of xyz (gcn3d.py:79,87) as four more K columns (ABI 4). */
 int tgp_gconv_surface_fwd(const float *xyz, const int32_t *idx, const float *sdn, int B, int n, int k, int S,
-                          int C, float *out, int ldo, tgp_stream_t stream);
+                          int C, float *out, int ldo, int xyz_pad, tgp_stream_t stream);
 
 /* gcn3d.py:157-180 HS_layer.graph_conv after the dense projection.  proj (B*n, (S+1)*C) row stride
  * ldp holds [centre | support] = feature_map @ weights + bias; idx is the feature-space graph.
@@ -178,6 +180,11 @@ typedef struct tgp_gemm_args {
      * repair launches whose condition is raised on the device -- tgp_heads_fused's overflow flag -- without a host read.
      */
     const int *pred;
+    /* (ABI 4) The launch covers rows [row_base, row_base + M) of a batch whose objects are rows_per_obj rows each: the
+     * per-object bias and the max over an object's points address object (row + row_base) / rows_per_obj.  A / C / residual /
+     * gather-index pointers are those of the launch's first row, as always.  0 for whole-batch launches.  (The eval forward
+     * hands the last rows of the heads' layers to the tile kernels beside the fused kernel: engine.wide_gemm_factored.) */
+    int row_base;
 } tgp_gemm_args;
 
 /* W (rows, K) fp32, row stride ld -> out[rows][ldo/16][3][16] bf16: per 16-wide K-tile the hi, mid and lo terms
@@ -202,9 +209,10 @@ int tgp_colmax(const float *x, int ld, int B, int n, int C, float *out, tgp_stre
 int tgp_sigmoid(const float *x, float *y, int64_t count, tgp_stream_t stream);
 
 /* PoseNet9D.py:57-66: green/red (B,4) -> unit axes p_* (B,3) and confidences f_* (B); ts (B,6) + mean
- * -> Pred_T (B,3), Pred_s (B,3). */
-int tgp_head_post(const float *green, const float *red, const float *ts, const float *mean, int B, float *p_green,
-                  float *p_red, float *f_green, float *f_red, float *pred_T, float *pred_s, tgp_stream_t stream);
+ * -> Pred_T (B,3), Pred_s (B,3).  ldg / ldr / ldt: row strides of green / red / ts (ABI 4: the batched head tail writes the three
+ * heads' outputs as rows of one (3, B, 8) buffer, read here in place). */
+int tgp_head_post(const float *green, const float *red, const float *ts, int ldg, int ldr, int ldt, const float *mean, int B,
+                  float *p_green, float *p_red, float *f_green, float *f_red, float *pred_T, float *pred_s, tgp_stream_t stream);
 
 /* PoseNet9D.py:71 recon + mean, in place on recon (B,n,3). */
 int tgp_add_mean(float *recon, const float *mean, int B, int n, tgp_stream_t stream);
@@ -455,6 +463,24 @@ int tgp_roi_cloud(const uint16_t *depth, const uint8_t *masks, const int64_t *ma
                   const int *window, const float *camk, int D, int H, int W, int roi_size, uint32_t *recs, int *counts,
                   tgp_stream_t stream);
 
+/* The same kernel for the TRAINING loader's device half (datasets/load_data.py:235-290, 395-407):
+ *   tables    (D, 2, roi_size) int32 or NULL.  The training window comes from aug_bbox_DZI (tools/dataset_utils.py:24-61): a
+ *             real-valued centre and scale, for which OpenCV's 10-bit fixed-point walk has no integer closed form.  The host
+ *             evaluates the walk once per detection in double (as cv2.warpAffine does): tables[d][0][x] = source column of ROI
+ *             column x, tables[d][1][y] = source row of ROI row y (rot = 0, so the map is separable).  With tables, `window` is
+ *             not read (may be NULL).
+ *   mask_val  (D) int32 or NULL: v > 0 -> a pixel is inside when its mask byte EQUALS v (the ground-truth instance mask
+ *             `mask == inst_id`, :245-247, with mask_stride 1 and mask_off = the image's offset); 0 / NULL -> any non-zero byte.
+ *   cut_frac  the outlier cut keeps the points farther than cut_frac x the extent's diagonal from point number 25: 0.25 in the
+ *             evaluation loader (load_data_eval.py:352), 0.15 in the training loader (load_data.py:283); float32 product.
+ * tgp_roi_cloud = tgp_roi_cloud_ex(..., NULL, NULL, 0.25f). */
+int tgp_roi_cloud_ex(const uint16_t *depth, const uint8_t *masks, const int64_t *mask_off, const int *mask_stride, const int *det_img,
+                     const int *window, const float *camk, int D, int H, int W, int roi_size, uint32_t *recs, int *counts,
+                     const int *tables, const int *mask_val, float cut_frac, tgp_stream_t stream);
+/* tgp_cloud_select with the detections' source-pixel tables (NULL: the window's closed form). */
+int tgp_cloud_select_ex(const uint32_t *recs, const int32_t *sel, const int *det_img, const int *window, const float *camk, int D,
+                        int roi_size, int n_pts, float *out, const int *tables, tgp_stream_t stream);
+
 /* _sample_points (:404-417) as a gather with a host-drawn selection: out[d][i] = point(recs[d][sel[d][i]]), out (D,n_pts,3);
  * det_img / window / camk as given to tgp_roi_cloud.  An index outside [0, roi_size^2) produces NaNs, never a fault.
  * With sel[d] = 0..n-1 it materialises a cloud's first n points. */
@@ -498,6 +524,11 @@ typedef struct tgp_heads_fused_args {
      * 32 points and sets *overflow = 1 (device int, zeroed by the caller; NULL: such waves write NaN keys).  The caller then runs
      * the two-launch form predicated on the flag (tgp_gemm_args.pred), which recomputes every key in guarded arithmetic. */
     int *overflow;
+    /* (ABI 4) rows > 0: only the first `rows` rows (a multiple of 128) of every head are processed here; the caller supplies the
+     * keys of rows [rows, M) through tgp_gemm_f32 (row_base = rows), merging into the same key buffer.  The grid is
+     * heads x 128-point workgroups, one per CU and round: B = 32, N = 1028 is 771 workgroups = 3.01 rounds of 256, and the
+     * three workgroups of the fourth round cost a quarter of the kernel's time (profiles/r02_g_heads_fused_stamps.txt). */
+    int rows;
 } tgp_heads_fused_args;
 int tgp_heads_fused(const tgp_heads_fused_args *args, tgp_stream_t stream);
 /* conv -> BatchNorm(eval) -> LeakyReLU -> max over each object's points of a factored layer whose activation only feeds the max

@@ -1162,8 +1162,9 @@ def _loss_weights(out, seed):
     return {k: torch.randn(v.shape, generator=gen) * scale.get(k, 1.0) for k, v in out.items()}
 
 
+@pytest.mark.parametrize("gemm_mode", ["fp32", "split16"], indirect=True)
 @pytest.mark.parametrize("B,N,seed", [(3, 256, 41), (3, 1028, 42)])
-def test_backward_full_network_vs_oracle_autograd(ops, B, N, seed):
+def test_backward_full_network_vs_oracle_autograd(ops, B, N, seed, gemm_mode):
     """loss.backward() through PoseNet9D (training mode, dropout p = 0) against torch autograd of the CPU oracle on the same
     graphs: every parameter's gradient, for a loss that weights every output tensor.
 
@@ -1175,7 +1176,10 @@ def test_backward_full_network_vs_oracle_autograd(ops, B, N, seed):
     flips, not the kernels.  The kernels themselves are checked tightly (1e-4 .. 1e-6) where no such decision separates
     the two sides: test_gemm_tn_vs_fp64, test_bn_backward_vs_autograd, test_pooled_bn_backward_vs_autograd,
     test_hs_layer_backward_vs_oracle_autograd, test_surface_layer_backward_vs_oracle_autograd,
-    test_pool_and_upsample_backward_vs_autograd."""
+    test_pool_and_upsample_backward_vs_autograd.
+    Round 3: run in the exact-fp32 GEMM mode (3 %) and in the default fp16-split mode (5 %: its activations sit ~3e-7 further from
+    the CPU's, so a few more decisions flip), and the visible part of the flipped decisions is counted: ReLU outputs of the four
+    BatchNorm / ReLU feature maps inside `feat` that are zero on one side and positive on the other."""
     from tgpose_amd import FLAGS, seeded_state_dict
     _, _, PR = _oracle()
     sd = seeded_state_dict(seed)
@@ -1196,6 +1200,11 @@ def test_backward_full_network_vs_oracle_autograd(ops, B, N, seed):
         FLAGS.train = 0
     for k, v in want_out.items():
         assert torch.allclose(out[k].detach().cpu(), v.detach(), atol=1e-4, rtol=0), k
+    relu_cols = out["feat"].detach().cpu()[:, :, :768], want_out["feat"].detach()[:, :, :768]      # fm_0 .. fm_3: ReLU outputs
+    flipped = int(((relu_cols[0] == 0) != (relu_cols[1] == 0)).sum())
+    print("full-network backward %s (B=%d, N=%d): %d of %d visible ReLU decisions differ from the oracle's"
+          % (gemm_mode, B, N, flipped, relu_cols[0].numel()))
+    assert flipped <= 1e-4 * relu_cols[0].numel()
     loss = sum((out[k] * g(weights[k])).sum() for k in weights)
     loss.backward()
     got = {k: p.grad for k, p in net.named_parameters()}
@@ -1206,7 +1215,7 @@ def test_backward_full_network_vs_oracle_autograd(ops, B, N, seed):
         rel[k] = (got[k].cpu() - w).norm().item() / (w.norm().item() + GRAD_ATOL)
     for k in sorted(rel, key=rel.get, reverse=True)[:8]:
         print("|dg|_2 / |g|_2  %-50s %.2e   (|g|_2 %.3e)" % (k, rel[k], want[k].norm().item()))
-    bad = {k: v for k, v in rel.items() if v > GRAD_TOL}
+    bad = {k: v for k, v in rel.items() if v > (GRAD_TOL if gemm_mode == "fp32" else 5e-2)}
     assert not bad, bad
     unused = [k for k in got if k not in want and got[k] is not None and got[k].abs().max() > 0]
     assert not unused, unused
@@ -1241,11 +1250,17 @@ def _layer_params(sd, prefix):
     return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
 
 
+@pytest.mark.parametrize("gemm_mode", ["fp32", "split16"], indirect=True)
 @pytest.mark.parametrize("name,cin,cout,n,k", [("conv_1", 128, 128, 257, 20), ("conv_4", 256, 512, 64, 8), ("conv_2", 128, 256, 100, 12)])
-def test_hs_layer_backward_vs_oracle_autograd(ops, name, cin, cout, n, k):
+def test_hs_layer_backward_vs_oracle_autograd(ops, name, cin, cout, n, k, gemm_mode):
     """One HS_layer (gcn3d.py:142-186) forward + backward: d(feature map), d(weights), d(bias), d(directions), d(STE),
     d(conv2) against torch autograd of the CPU oracle on the same graphs.  No BatchNorm / ReLU on the activations here, so
-    the comparison is tight: 1e-4 of each gradient's largest entry."""
+    the comparison is tight: 1e-4 of each gradient's largest entry -- in the exact-fp32 GEMM mode, whose projections agree with
+    the CPU's to the last bits, so both sides take the same winner in every max over neighbours.  In the default mode (two-term
+    fp16 split; since round 3 also for these test-sized launches, csrc/gemm.hip gemm_split256_kernel) the projections differ by
+    ~3e-7 relative, a few of the 7 x C x n neighbour maxima change winner, and each changed winner moves one gradient entry by
+    O(1e-3) of the largest: bounded at 5e-3 of the largest entry and 2e-3 in relative L2, with the number of entries beyond the
+    tight bar reported."""
     from tgpose_amd import seeded_state_dict, autograd as AG
     from tgpose_amd.network.fs_net_repo.gcn3d import HS_layer
     _, G, _ = _oracle()
@@ -1273,8 +1288,15 @@ def test_hs_layer_backward_vs_oracle_autograd(ops, name, cin, cout, n, k):
     (out * g(w)).sum().backward()
     pairs = [("fm", fm_g.grad, fm_ref.grad)] + [(k_, dict(layer.named_parameters())[k_].grad, P["L." + k_].grad) for k_ in lp]
     for nm, a, r in pairs:
-        err, ref = (a.cpu() - r).abs().max().item(), r.abs().max().item()
-        assert err <= 1e-4 * ref + 1e-6, (nm, err, ref)
+        d = (a.cpu() - r).abs()
+        err, ref = d.max().item(), r.abs().max().item()
+        if gemm_mode == "fp32":
+            assert err <= 1e-4 * ref + 1e-6, (nm, err, ref)
+        else:
+            moved = int((d > 1e-4 * ref + 1e-6).sum())
+            print("hs layer %s d(%s): %d of %d entries beyond the tight bar (changed neighbour winners), max %.2e of %.2e"
+                  % (name, nm, moved, d.numel(), err, ref))
+            assert err <= 5e-3 * ref + 1e-6 and d.norm().item() <= 2e-3 * r.norm().item() + 1e-6, (nm, err, ref, moved)
 
 
 class _Renamer(object):
@@ -1315,7 +1337,8 @@ def test_surface_layer_backward_vs_oracle_autograd(ops):
         assert err <= 1e-4 * ref + 1e-6, (k_, err, ref)
 
 
-def test_encoder_from_seam_operators_trains_like_the_reference(ops, monkeypatch):
+@pytest.mark.parametrize("gemm_mode", ["fp32", "split16"], indirect=True)
+def test_encoder_from_seam_operators_trains_like_the_reference(ops, monkeypatch, gemm_mode):
     """Operator seam #2 under autograd: an encoder written the way the reference's Face_Enc is (FaceRecon.py:20-26,57-73)
     from ONLY the gcn3d seam names -- HSlayer_surface, HS_layer, Pool_layer, get_nearest_index, indexing_neighbor_new -- plus
     torch's own BatchNorm1d / relu / cat, in .train(), forward + backward.  Outputs are graph-attached like the reference's;
@@ -1407,7 +1430,9 @@ def test_encoder_from_seam_operators_trains_like_the_reference(ops, monkeypatch)
         a, r = got[k].grad.cpu(), v.grad
         rel = (a - r).norm().item() / max(r.norm().item(), 1e-12)
         worst = max(worst, rel)
-        assert rel <= 2e-3, (k, rel)
+        # default mode: a few neighbour winners change (test_hs_layer_backward_vs_oracle_autograd); the HS layers' biases, whose
+        # gradient exists only through those winners, feel it most: the network-level bar (GRAD_TOL) applies there
+        assert rel <= (2e-3 if gemm_mode == "fp32" else GRAD_TOL), (k, rel)
     # and under no_grad the same modules run the fused kernels and return plain tensors
     torch.manual_seed(99)
     rm = {k: v.clone() for k, v in enc.state_dict().items() if "running" in k or "num_batches" in k}
@@ -2732,3 +2757,37 @@ def test_nan_step_is_skipped_like_the_reference_loop(ops):
         assert any(not torch.equal(v, w0[k]) for k, v in tr2.net1.state_dict().items() if k in w0)
     finally:
         FLAGS.train = 0
+
+
+def test_captured_step_refuses_memset_nodes(ops):
+    """Root cause of the round-2 replay fault, kept as a guard: hipGraph MEMSET nodes are not ordered against their neighbours on
+    replay on this stack (scripts/capture_memset_probe.py), and ATen's multi-block reductions zero their semaphores with one.
+    A captured step that contains such an op is refused at capture time (engine.check_capture); the library's own kernels put
+    no memset node into a graph."""
+    from tgpose_amd import PoseNet9D, seeded_state_dict, FLAGS, engine
+    from tgpose_amd.autograd import GraphedBackward
+    B, N = 4, 256
+    pts, obj = synth_points(B, N, 77)
+    net = PoseNet9D()
+    net.load_state_dict(seeded_state_dict(5), strict=True)
+    net = net.to(DEV).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    big = torch.randn(32, 1028, 1292, device=DEV)
+    FLAGS.train = 1
+    try:
+        small = lambda out: out["recon"].square().mean() + out["Pred_T"].abs().mean() + out["h1"].mean()
+        ok = GraphedBackward(net, g(pts), g(obj), small)
+        kernels, memcpys, memsets, other = ok.nodes
+        assert memsets == 0 and kernels > 300
+        for p in net.parameters():
+            p.grad = None
+        with pytest.raises(RuntimeError, match="memset node"):
+            GraphedBackward(net, g(pts), g(obj), lambda out: small(out) + 0.0 * big[:, :, :1286].max(1)[0].sum())
+    finally:
+        FLAGS.train = 0
+    # the eval forward's graph holds none either
+    net.eval()
+    gf = engine.GraphedForward(net.packed(torch.device(DEV)), B, N, torch.device(DEV))
+    assert gf.nodes[2] == 0 and gf.nodes[0] > 50

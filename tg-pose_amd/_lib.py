@@ -39,6 +39,7 @@ class GemmArgs(ctypes.Structure):
         ("gres1", c_vp), ("ldg1", c_int), ("gidx1", c_vp),
         ("gres2", c_vp), ("ldg2", c_int), ("gidx2", c_vp),
         ("epilogue", c_int), ("pred", c_vp),
+        ("row_base", c_int),
     ]
 
 
@@ -70,6 +71,7 @@ class HeadsFusedArgs(ctypes.Structure):
         ("keys", c_vp),
         ("M", c_int), ("rows_per_obj", c_int), ("B", c_int), ("heads", c_int),
         ("overflow", c_vp),
+        ("rows", c_int),
     ]
 
 
@@ -84,7 +86,7 @@ SIGNATURES = {
     "tgp_knn_feat": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp]),
     "tgp_nn1": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "tgp_normalize_dirs": (c_int, [c_vp, c_int, c_vp, c_vp]),
-    "tgp_gconv_surface_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
+    "tgp_gconv_surface_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
     "tgp_gconv_hs_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "tgp_orl_partial_floats": (c_i64, [c_int, c_int, c_int]),
     "tgp_orl_global": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
@@ -134,7 +136,7 @@ SIGNATURES = {
     "tgp_colmax_decode": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "tgp_colmax": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "tgp_sigmoid": (c_int, [c_vp, c_vp, c_i64, c_vp]),
-    "tgp_head_post": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "tgp_head_post": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tgp_add_mean": (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
     "tgp_bn_workspace_floats": (c_i64, [c_i64, c_int]),
     "tgp_bn_stats": (c_int, [c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),
@@ -153,10 +155,12 @@ SIGNATURES = {
     "tgp_sort_by_parent": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tgp_roi_cloud": (c_int, [c_vp] * 7 + [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_cloud_select": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, c_vp, c_vp]),
+    "tgp_roi_cloud_ex": (c_int, [c_vp] * 7 + [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp]),
+    "tgp_cloud_select_ex": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_cloud_sample": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, ctypes.c_uint64, c_vp, c_vp]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 

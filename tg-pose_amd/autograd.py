@@ -464,7 +464,7 @@ class GraphedStep(object):
 
     _FOREIGN = "AccumulateGrad node's stream does not match"
 
-    def __init__(self, params, step_fn, cloud_sizes, device, cut=None, between=None, after=None):
+    def __init__(self, params, step_fn, cloud_sizes, device, cut=None, between=None, after=None, own_pool=False):
         """cut: an EncoderCut that step_fn hands to net1's forward.  The step is then captured as TWO graphs sharing one memory
         pool -- (1) forwards + loss + backward of everything after the encoder, (2) the encoder's backward -- and replayed with
         ``between()`` called after the first has been enqueued (the data-parallel trainer starts the late layers' gradient
@@ -520,15 +520,18 @@ class GraphedStep(object):
         torch.cuda.current_stream(dev).wait_stream(warm)
         torch.cuda.synchronize(dev)
         self._zero()
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = engine.new_graph()
         with torch.cuda.graph(self.graph, stream=warm):     # the stream the warm-up ran on
             self.loss = run()
+        # no memset node may be part of a captured step (engine.check_capture: the root cause of the round-2 replay fault)
+        self.nodes = engine.check_capture(self.graph, "GraphedStep")
         self.graph2 = None
         if cut is not None:
             # the encoder's saved activations live in the first graph's pool: the second graph shares it and always replays after the first
-            self.graph2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph2, stream=warm, pool=self.graph.pool()):
+            self.graph2 = engine.new_graph()
+            with torch.cuda.graph(self.graph2, stream=warm, pool=None if own_pool else self.graph.pool()):
                 run2()
+            self.nodes2 = engine.check_capture(self.graph2, "GraphedStep (encoder backward segment)")
             cut.clear()
 
     def _zero(self):

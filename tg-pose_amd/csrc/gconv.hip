@@ -56,7 +56,7 @@ template <int C, bool SURFACE>
 __global__ __launch_bounds__(256) void gconv_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ idx,
                                                     const float *__restrict__ proj, int ldp,
                                                     const float *__restrict__ sdn, int B, int n, int k,
-                                                    float *__restrict__ out, int ldo, int tiles_per_obj)
+                                                    float *__restrict__ out, int ldo, int tiles_per_obj, int xyz_pad)
 {
     using RL = RowLanes<C>;
     int b, tile;
@@ -152,6 +152,12 @@ __global__ __launch_bounds__(256) void gconv_kernel(const float *__restrict__ xy
                 acc.x = ctr.x + acc.x, acc.y = ctr.y + acc.y, acc.z = ctr.z + acc.z, acc.w = ctr.w + acc.w;
             }
             *reinterpret_cast<float4 *>(out + rowi * ldo + cb) = acc;
+            // xyz_pad: the point itself as columns C .. C+3 = (x, y, z, 0) of the output row, so that the layer's last GEMM takes
+            // the STE convolution (Conv1d 3 -> C on xyz, gcn3d.py:79,87) as four more K columns instead of a GEMM of its own
+            if (SURFACE && xyz_pad && chunk == 0 && lane == 0) {
+                const float *pc = xyz + rowi * 3;
+                *reinterpret_cast<float4 *>(out + rowi * ldo + C) = make_float4(pc[0], pc[1], pc[2], 0.f);
+            }
         }
     }
 }
@@ -297,14 +303,14 @@ static int gconv_check(const void *xyz, const void *idx, const void *sdn, const 
 
 template <bool SURFACE>
 static int gconv_launch(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B, int n,
-                        int k, int C, float *out, int ldo, hipStream_t stream)
+                        int k, int C, float *out, int ldo, hipStream_t stream, int xyz_pad = 0)
 {
     const int ptiles = tgp_cdiv(n, GC_PTS);
 #define GC_GO(CC)                                                                                                     \
     {                                                                                                                 \
         const int tiles = ptiles * RowLanes<CC>::CHUNKS;                                                              \
         hipLaunchKernelGGL((gconv_kernel<CC, SURFACE>), dim3(tgp_xcd_grid(B, tiles)), dim3(256), 0, stream, xyz, idx, \
-                           proj, ldp, sdn, B, n, k, out, ldo, tiles);                                                 \
+                           proj, ldp, sdn, B, n, k, out, ldo, tiles, xyz_pad);                                        \
     }
     if (C == 128) GC_GO(128) else if (C == 256) GC_GO(256) else GC_GO(512)
 #undef GC_GO
@@ -312,11 +318,12 @@ static int gconv_launch(const float *xyz, const int32_t *idx, const float *proj,
 }
 
 extern "C" int tgp_gconv_surface_fwd(const float *xyz, const int32_t *idx, const float *sdn, int B, int n, int k, int S,
-                                     int C, float *out, int ldo, tgp_stream_t stream)
+                                     int C, float *out, int ldo, int xyz_pad, tgp_stream_t stream)
 {
     const int chk = gconv_check(xyz, idx, sdn, out, B, n, k, S, C, ldo);
     if (chk) return chk;
-    return gconv_launch<true>(xyz, idx, nullptr, 0, sdn, B, n, k, C, out, ldo, tgp_hs(stream));
+    TGP_REQUIRE(!xyz_pad || ldo >= C + 4);
+    return gconv_launch<true>(xyz, idx, nullptr, 0, sdn, B, n, k, C, out, ldo, tgp_hs(stream), xyz_pad);
 }
 
 extern "C" int tgp_gconv_hs_fwd(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B,

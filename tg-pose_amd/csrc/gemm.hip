@@ -29,6 +29,7 @@ struct GemmParams {
     const float *bias;
     const float *rowbias;
     int ldrb, rows_per_obj;
+    int row_base;    // row r of this launch is row r + row_base of the batch for the per-object bias / max (tgp_gemm_args.row_base)
     const float *res1;
     int ldr1;
     const float *res2;
@@ -113,8 +114,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
                 const int rbase = m0 + wm * WTM + i * 32 + 4 * h;
                 int obj = 0, bound = 0x7fffffff;
                 if (p.rowbias || p.cm) {
-                    obj = rbase / p.rows_per_obj;
-                    bound = (obj + 1) * p.rows_per_obj;
+                    obj = (rbase + p.row_base) / p.rows_per_obj;
+                    bound = (obj + 1) * p.rows_per_obj - p.row_base;
                 }
                 uint32_t run_key = 0;
                 int run_obj = -1;
@@ -166,8 +167,8 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams &p, f32x16 (
     const bool full_rows = row0 + WTM <= p.M;
     int obj0 = 0, bound = 0x7fffffff;
     if (p.rowbias || p.cm) {
-        obj0 = row0 / p.rows_per_obj;
-        bound = (obj0 + 1) * p.rows_per_obj;                     // rows >= bound belong to object obj0 + 1
+        obj0 = (row0 + p.row_base) / p.rows_per_obj;
+        bound = (obj0 + 1) * p.rows_per_obj - p.row_base;                     // rows >= bound belong to object obj0 + 1
     }
     const int last_row = (row0 + WTM < p.M ? row0 + WTM : p.M) - 1;
     const bool two_objs = bound <= last_row;
@@ -234,8 +235,8 @@ __device__ __forceinline__ void gemm_epilogue_gather(const GemmParams &p, f32x16
     const bool full_rows = row0 + WTM <= p.M;
     int obj0 = 0, bound = 0x7fffffff;
     if (p.rowbias || p.cm) {
-        obj0 = row0 / p.rows_per_obj;
-        bound = (obj0 + 1) * p.rows_per_obj;
+        obj0 = (row0 + p.row_base) / p.rows_per_obj;
+        bound = (obj0 + 1) * p.rows_per_obj - p.row_base;
     }
     const int last_row = (row0 + WTM < p.M ? row0 + WTM : p.M) - 1;
     const bool two_objs = bound <= last_row;
@@ -317,8 +318,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams &p, f32x16 (&
     const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;       // wave-uniform
     int obj0 = 0, bound = 0x7fffffff;
     if (p.rowbias || p.cm) {
-        obj0 = row0 / p.rows_per_obj;
-        bound = (obj0 + 1) * p.rows_per_obj;
+        obj0 = (row0 + p.row_base) / p.rows_per_obj;
+        bound = (obj0 + 1) * p.rows_per_obj - p.row_base;
     }
     const int last_row = (row0 + WTM < p.M ? row0 + WTM : p.M) - 1;
     const bool two_objs = bound <= last_row;
@@ -1167,6 +1168,25 @@ __global__ __launch_bounds__(512, 4) void gemm_split512_kernel(GemmParams p)
     }
 }
 
+// Few-tile launches (round 3): the HS layers' last GEMM (M x C x C with C = 128 .. 512), the decoder's 256 -> 128 layer.  On the
+// 256 x 128 tiles above they are 32 .. 129 workgroups for 512 resident slots, each a prologue + 8-32 K-steps + epilogue in
+// sequence: 25-40 us per launch at 3-5 % of the matrix roof (profiles/r02_g: six such launches = 180 us for 7.5 GFLOP).  Here the
+// same tile template runs 64 x 128 outputs on 256 threads (2 x 2 waves of 32 x 64), four workgroups per CU (37 KB of LDS, <= 128
+// registers): four times as many, four times shorter workgroups, and BN = 128 keeps the whole output row of the C = 128 layers
+// in one workgroup, so the large operand (the activations) is still read once.  Same K order per output element (16-wide steps,
+// three terms): results are bit-identical to the larger tiles'.
+template <int PD, bool F16>
+__global__ __launch_bounds__(256, 4) void gemm_split256_kernel(GemmParams p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[(PD > 0 ? 2 : 1) * (F16 ? 2 : 3) * ((64 + 128) * 48 + 64)];
+    if (p.pred && *p.pred == 0) return;      // a repair launch whose condition did not arise (workgroup-uniform)
+    int L = (int)blockIdx.x;
+    const int per_batch = p.tiles_m_small * p.tiles_n_small;
+    const int z = L / per_batch;
+    L -= z * per_batch;
+    gemm_split_tile<64, 128, 2, 2, PD, F16, false>(p, (L / p.tiles_n_small) * 64, (L % p.tiles_n_small) * 128, z, smem);
+}
+
 // W (rows, K) fp32 row stride ld -> out[rows][ldo / 16][3][16] bf16 (hi, mid, lo per K-tile), zero padded to ldo
 __global__ void split_bf16_kernel(const float *__restrict__ W, int rows, int K, int ld, uint16_t *__restrict__ out, int ldo)
 {
@@ -1514,6 +1534,17 @@ static int launch_split(GemmParams &p, hipStream_t stream)
     // development A/B (TGP_ROUTE512=1): every launch WITHOUT gathered residuals on the two-workgroups-per-CU form
     static const int route512 = dev_env("TGP_ROUTE512");
     const bool epi_bound = (gather512 && (p.gres1 || p.gres2) && p.K <= 512) || (route512 && !(p.gres1 || p.gres2));
+    // fewer than ~0.3 rounds of the 256 x 128 tiles: the 64 x 128 form on 256 threads (gemm_split256_kernel)
+    const int64_t tiles512 = (int64_t)tgp_cdiv(p.M, GEMM_BIG) * tgp_cdiv(p.N, 128) * p.batch;
+    if (p.split_f16 && !p.ksplit && !p.gres1 && !p.gres2 && !force512 && tgp_split_variant == 7 &&
+        tiles512 * 10 < 3 * 2 * (int64_t)resident_slots()) {
+        p.mt_big = 0, p.tiles_big = 0, p.tiles_n_big = 1;
+        p.tiles_m_small = tgp_cdiv(p.M, 64), p.tiles_n_small = tgp_cdiv(p.N, 128);
+        p.nseg = 0, p.seg_small = 0;
+        p.stamps = nullptr;
+        hipLaunchKernelGGL((gemm_split256_kernel<2, true>), dim3(p.tiles_m_small * p.tiles_n_small * p.batch), dim3(256), 0, stream, p);
+        return TGP_LAUNCH_RESULT();
+    }
     if (p.split_f16 && (force512 || epi_bound || (narrow && !forbid512))) {
         // two 512-thread workgroups per CU, 256 x 128 tiles (+ 128 x 128 tail tiles)
         plan_tiles(p, GEMM_BIG, 2 * (int64_t)resident_slots(), 0.55, 2, 128, 128);
@@ -1606,6 +1637,8 @@ extern "C" int tgp_gemm_f32(const tgp_gemm_args *a, tgp_stream_t stream)
     p.A = a->A, p.W = a->W, p.C = a->C;
     p.lda = a->lda, p.ldw = a->ldw, p.ldc = a->ldc, p.M = a->M, p.N = a->N, p.K = a->K;
     p.bias = a->bias, p.rowbias = a->rowbias, p.ldrb = a->ldrb, p.rows_per_obj = a->rows_per_obj > 0 ? a->rows_per_obj : 1;
+    TGP_REQUIRE(a->row_base >= 0);
+    p.row_base = a->row_base;
     p.res1 = a->res1, p.ldr1 = a->ldr1, p.res2 = a->res2, p.ldr2 = a->ldr2;
     p.scale = a->scale, p.shift = a->shift, p.slope_vec = a->slope_vec, p.act = a->act, p.slope = a->slope;
     p.cm = a->colmax_keys, p.ldcm = a->ldcm;
@@ -1624,10 +1657,15 @@ extern "C" int tgp_gemm_f32(const tgp_gemm_args *a, tgp_stream_t stream)
     p.pred = a->pred;
     const bool plain = !a->rowbias && !a->res2 && !a->colmax_keys && !a->slope_vec && a->c_col0 == 0 &&
                        (p.batch == 1 || !a->res1);
+    const int64_t mid_tiles = (int64_t)tgp_cdiv(a->M, GEMM_MID) * tgp_cdiv(a->N, GEMM_MID) * p.batch;
+    // (round 3) launches below half a round of 128 x 128 tiles used to fall to the exact-fp32 64 x 64 kernel whatever their
+    // size (conv_4's last GEMM, M = 2048, N = K = 512: 41 us); with a fp16-split weight and at least 32 of the 64 x 128 tiles
+    // they now take the small-tile split kernel
+    const bool small_split = a->W_split && a->w_split_kind == 1 && a->M > 32 && a->N > 64 && !a->ksplit_chunk &&
+                             (int64_t)tgp_cdiv(a->M, 64) * tgp_cdiv(a->N, 128) * p.batch >= 32;
     // a_scale / c_scale / ksplit_chunk are implemented by the fp16 split tile kernels only: refuse launches that route elsewhere
     TGP_REQUIRE(!(a->a_scale || a->c_scale || a->ksplit_chunk) ||
-                (a->W_split && a->w_split_kind == 1 && a->M > 32 && a->N > 64 &&
-                 (int64_t)tgp_cdiv(a->M, GEMM_MID) * tgp_cdiv(a->N, GEMM_MID) * p.batch >= resident_slots() / 2));
+                (a->W_split && a->w_split_kind == 1 && a->M > 32 && a->N > 64 && (mid_tiles >= resident_slots() / 2 || small_split)));
     if (a->M <= 32 && a->C && plain) {
         if ((int64_t)tgp_cdiv(a->N, 32) * p.batch >= resident_slots() / 2)
             hipLaunchKernelGGL((skinny_gemm_kernel<2, 8>), dim3(tgp_cdiv(a->N, 32), p.batch), dim3(512), 0, tgp_hs(stream), p);
@@ -1635,8 +1673,7 @@ extern "C" int tgp_gemm_f32(const tgp_gemm_args *a, tgp_stream_t stream)
             hipLaunchKernelGGL((skinny_gemm_kernel<1, 16>), dim3(tgp_cdiv(a->N, 16), p.batch), dim3(1024), 0, tgp_hs(stream), p);
         return TGP_LAUNCH_RESULT();
     }
-    const int64_t mid_tiles = (int64_t)tgp_cdiv(a->M, GEMM_MID) * tgp_cdiv(a->N, GEMM_MID) * p.batch;
-    if (mid_tiles >= resident_slots() / 2 && a->N > 64) {
+    if ((mid_tiles >= resident_slots() / 2 && a->N > 64) || small_split) {
         if (a->W_split) {
             TGP_REQUIRE(a->ldws >= ((a->K + 15) & ~15) && (a->ldws & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(a->W_split) & 15) == 0);
@@ -1748,13 +1785,14 @@ extern "C" int tgp_sigmoid(const float *x, float *y, int64_t count, tgp_stream_t
 }
 
 __global__ void head_post_kernel(const float *__restrict__ green, const float *__restrict__ red,
-                                 const float *__restrict__ ts, const float *__restrict__ mean, int B,
+                                 const float *__restrict__ ts, int ldg, int ldr, int ldt, const float *__restrict__ mean, int B,
                                  float *__restrict__ pg, float *__restrict__ pr, float *__restrict__ fg,
                                  float *__restrict__ fr, float *__restrict__ pT, float *__restrict__ ps)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const float *g = green + b * 4, *rd = red + b * 4;
+    const float *g = green + b * ldg, *rd = red + b * ldr;
+    ts += b * ldt - b * 6;
     // torch.norm(v, dim=1): sqrt of the sum of squares; PoseNet9D.py:57-58 divides by (norm + 1e-6)
     float ng = sqrtf((g[1] * g[1] + g[2] * g[2]) + g[3] * g[3]) + 1e-6f;
     float nr = sqrtf((rd[1] * rd[1] + rd[2] * rd[2]) + rd[3] * rd[3]) + 1e-6f;
@@ -1768,12 +1806,13 @@ __global__ void head_post_kernel(const float *__restrict__ green, const float *_
     fr[b] = 1.0f / (1.0f + expf(-rd[0]));
 }
 
-extern "C" int tgp_head_post(const float *green, const float *red, const float *ts, const float *mean, int B,
-                             float *p_green, float *p_red, float *f_green, float *f_red, float *pred_T, float *pred_s,
+extern "C" int tgp_head_post(const float *green, const float *red, const float *ts, int ldg, int ldr, int ldt, const float *mean,
+                             int B, float *p_green, float *p_red, float *f_green, float *f_red, float *pred_T, float *pred_s,
                              tgp_stream_t stream)
 {
     TGP_REQUIRE(green && red && ts && mean && p_green && p_red && f_green && f_red && pred_T && pred_s && B > 0);
-    hipLaunchKernelGGL(head_post_kernel, dim3(tgp_cdiv(B, 64)), dim3(64), 0, tgp_hs(stream), green, red, ts, mean, B,
+    TGP_REQUIRE(ldg >= 4 && ldr >= 4 && ldt >= 6);
+    hipLaunchKernelGGL(head_post_kernel, dim3(tgp_cdiv(B, 64)), dim3(64), 0, tgp_hs(stream), green, red, ts, ldg, ldr, ldt, mean, B,
                        p_green, p_red, f_green, f_red, pred_T, pred_s);
     return TGP_LAUNCH_RESULT();
 }

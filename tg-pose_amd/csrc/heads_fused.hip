@@ -536,6 +536,10 @@ extern "C" int tgp_heads_fused(const tgp_heads_fused_args *a, tgp_stream_t strea
     p.keys = a->keys;
     p.overflow = a->overflow;
     p.M = a->M, p.rows_per_obj = a->rows_per_obj, p.B = a->B, p.heads = a->heads, p.tiles = tgp_cdiv(a->M, 128);
+    if (a->rows > 0) {          // the first a->rows rows only (the caller covers the rest through the tile kernels)
+        TGP_REQUIRE(a->rows <= a->M && a->rows % 128 == 0);
+        p.M = a->rows, p.tiles = a->rows / 128;
+    }
     p.stamps = tgp_heads_stamps;
     static bool attr_set = false;
     if (!attr_set) {

@@ -96,21 +96,31 @@ struct UniformDiv {
 
 // A detection's geometry: everything a record needs to become a point (load_data_eval.py:451-462 then /1000.0 at :338,
 // float32 step by step, correctly rounded quotients).
+//
+// tab (training loader, datasets/load_data.py:235-250): the window comes from the box augmentation aug_bbox_DZI
+// (tools/dataset_utils.py:24-61) -- a real-valued centre and scale -- so OpenCV's fixed-point walk has no integer closed form.
+// The host evaluates it once per detection in double, as OpenCV does, into tab[0 .. roi) = source column of ROI column x and
+// tab[roi .. 2 roi) = source row of ROI row y (rot = 0: the map is separable); the kernels then look the source pixel up.
 struct RoiGeom {
     int sumc, sumr, s, step, roi_log2;
     float cx, cy;
     UniformDiv div_fx, div_fy, div_k;
-    __device__ __forceinline__ RoiGeom(const int *__restrict__ window, const float *__restrict__ camk, int j, int img, int lg)
-        : sumc(window[j * 3]), sumr(window[j * 3 + 1]), s(window[j * 3 + 2]), step(1024 >> lg), roi_log2(lg), cx(camk[img * 4 + 2]),
-          cy(camk[img * 4 + 3]), div_fx(camk[img * 4]), div_fy(camk[img * 4 + 1]), div_k(1000.0f)
+    const int *tab;
+    __device__ __forceinline__ RoiGeom(const int *__restrict__ window, const float *__restrict__ camk, int j, int img, int lg,
+                                       const int *__restrict__ tables = nullptr)
+        : sumc(tables ? 0 : window[j * 3]), sumr(tables ? 0 : window[j * 3 + 1]), s(tables ? 0 : window[j * 3 + 2]), step(1024 >> lg),
+          roi_log2(lg), cx(camk[img * 4 + 2]), cy(camk[img * 4 + 3]), div_fx(camk[img * 4]), div_fy(camk[img * 4 + 1]), div_k(1000.0f),
+          tab(tables ? tables + ((size_t)j << (lg + 1)) : nullptr)
     {
     }
+    __device__ __forceinline__ int src_x(int x) const { return tab ? tab[x] : src_coord(sumc, s, x, step); }
+    __device__ __forceinline__ int src_y(int y) const { return tab ? tab[(1 << roi_log2) + y] : src_coord(sumr, s, y, step); }
     __device__ __forceinline__ void point(uint32_t rec, float &px, float &py, float &pz) const
     {
         const int p = (int)(rec >> 16), x = p & ((1 << roi_log2) - 1), y = p >> roi_log2;
         const float dep = (float)(rec & 0xffffu);
-        px = div_k(div_fx(((float)src_coord(sumc, s, x, step) - cx) * dep));
-        py = div_k(div_fy(((float)src_coord(sumr, s, y, step) - cy) * dep));
+        px = div_k(div_fx(((float)src_x(x) - cx) * dep));
+        py = div_k(div_fy(((float)src_y(y) - cy) * dep));
         pz = div_k(dep);
     }
 };
@@ -120,7 +130,8 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_cloud_kernel(const uint16_t *
                                                                 const int64_t *__restrict__ mask_off, const int *__restrict__ mask_stride,
                                                                 const int *__restrict__ det_img, const int *__restrict__ window,
                                                                 const float *__restrict__ camk, int H, int W, int roi_log2,
-                                                                uint32_t *recs, int *__restrict__ counts)
+                                                                uint32_t *recs, int *__restrict__ counts, const int *__restrict__ tables,
+                                                                const int *__restrict__ mask_val, float cut_frac)
 {
     __shared__ int tot[2][ROI_SUB][ROI_WAVES];
     __shared__ float red[6][ROI_WAVES];
@@ -129,7 +140,8 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_cloud_kernel(const uint16_t *
     const int roi = 1 << roi_log2;
     const int cap = roi * roi;
     const int img = det_img[j];
-    const RoiGeom g(window, camk, j, img, roi_log2);
+    const RoiGeom g(window, camk, j, img, roi_log2, tables);
+    const int mval = mask_val ? mask_val[j] : 0;       // 0: any non-zero mask byte (a detection's own channel); v > 0: the byte equals v
     const uint16_t *dimg = depth + (size_t)img * H * W;
     const uint8_t *mimg = masks + mask_off[j];
     const int mstride = mask_stride[j];
@@ -144,7 +156,7 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_cloud_kernel(const uint16_t *
     // 1024 threads are a whole number of ROI rows (or a fraction of one): a thread keeps its column for the whole walk and a
     // wave sits inside one row, so everything that depends on x alone is hoisted and the row terms are wave-uniform
     const int x = tid & (roi - 1);
-    const int sx = src_coord(g.sumc, g.s, x, g.step);
+    const int sx = g.src_x(x);
     const bool inbx = sx >= 0 && sx < W;
     const int colq = min(max(sx, 0), W - 1);
     const float xm = (float)sx - g.cx;
@@ -159,7 +171,7 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_cloud_kernel(const uint16_t *
 #pragma unroll
         for (int k = 0; k < ROI_SUB; ++k) {
             const int y = ((c * ROI_SUB + k) * ROI_THREADS >> roi_log2) + row0;        // = (round element index) / roi
-            const int sy = src_coord(g.sumr, g.s, y, g.step);
+            const int sy = g.src_y(y);
             const bool inb = inbx && sy >= 0 && sy < H;
             // border pixels read a clamped address and are zeroed afterwards: no branch round the loads, all 2*ROI_SUB in flight
             const int q = min(max(sy, 0), H - 1) * W + colq;                            // < 2^24 (host-checked)
@@ -180,7 +192,7 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_cloud_kernel(const uint16_t *
 #pragma unroll
         for (int k = 0; k < ROI_SUB; ++k) {
             n_depth += d[k] > 0;
-            keep[k] = d[k] > 0 && m[k] != 0;
+            keep[k] = d[k] > 0 && (mval ? m[k] == mval : m[k] != 0);
         }
         ordered_slots(keep, tot, c & 1, base, slot);
 #pragma unroll
@@ -230,7 +242,7 @@ __global__ __launch_bounds__(ROI_THREADS) void roi_cloud_kernel(const uint16_t *
         const float a0 = g.div_k(g.div_fx(lo0)), b0 = g.div_k(g.div_fx(hi0)), a1 = g.div_k(g.div_fy(lo1)), b1 = g.div_k(g.div_fy(hi1));
         r0 = fmaxf(a0, b0) - fminf(a0, b0), r1 = fmaxf(a1, b1) - fminf(a1, b1), r2 = g.div_k(hi2) - g.div_k(lo2);
     }
-    const float thr = __fsqrt_rn((r0 * r0 + r1 * r1) + r2 * r2) * 0.25f;
+    const float thr = __fsqrt_rn((r0 * r0 + r1 * r1) + r2 * r2) * cut_frac;     // float32 product, as numpy's (0.25 eval, 0.15 training)
     // sqrt_rn is monotone, so sqrt_rn(v) > thr  <=>  v > v_max, v_max = the largest float whose rounded root is <= thr:
     // found once per detection from thr*thr by stepping ulps; the per-point test is then a compare of the squared distance
     float v_max = thr * thr;
@@ -286,19 +298,29 @@ static int roi_log2_of(int roi_size)
     return ((1 << lg) == roi_size && roi_size >= 64 && roi_size <= 256) ? lg : -1;
 }
 
-extern "C" int tgp_roi_cloud(const uint16_t *depth, const uint8_t *masks, const int64_t *mask_off, const int *mask_stride,
-                             const int *det_img, const int *window, const float *camk, int D, int H, int W, int roi_size, uint32_t *recs,
-                             int *counts, tgp_stream_t stream)
+extern "C" int tgp_roi_cloud_ex(const uint16_t *depth, const uint8_t *masks, const int64_t *mask_off, const int *mask_stride,
+                                const int *det_img, const int *window, const float *camk, int D, int H, int W, int roi_size, uint32_t *recs,
+                                int *counts, const int *tables, const int *mask_val, float cut_frac, tgp_stream_t stream)
 {
-    TGP_REQUIRE(depth && masks && mask_off && mask_stride && det_img && window && camk && recs && counts);
+    TGP_REQUIRE(depth && masks && mask_off && mask_stride && det_img && (window || tables) && camk && recs && counts);
+    TGP_REQUIRE(cut_frac >= 0.f && cut_frac <= 1.f);
     TGP_REQUIRE(D > 0 && H > 0 && W > 0 && H < 32768 && W < 32768 && (int64_t)H * W < (1ll << 24));   // x mask stride < 128: 31-bit offsets
     const int lg = roi_log2_of(roi_size);
     if (lg < 0) return TGP_EUNSUPPORTED;
     static const int sub = [] { const char *e = getenv("TGP_ROI_SUB"); return e ? atoi(e) : 4; }();     // development A/B
     auto kern = sub == 1 ? roi_cloud_kernel<1> : sub == 2 ? roi_cloud_kernel<2> : roi_cloud_kernel<4>;
     hipLaunchKernelGGL(kern, dim3(D), dim3(ROI_THREADS), 0, tgp_hs(stream), depth, masks, mask_off, mask_stride, det_img, window, camk, H, W,
-                       lg, recs, counts);
+                       lg, recs, counts, tables, mask_val, cut_frac);
     return TGP_LAUNCH_RESULT();
+}
+
+extern "C" int tgp_roi_cloud(const uint16_t *depth, const uint8_t *masks, const int64_t *mask_off, const int *mask_stride,
+                             const int *det_img, const int *window, const float *camk, int D, int H, int W, int roi_size, uint32_t *recs,
+                             int *counts, tgp_stream_t stream)
+{
+    TGP_REQUIRE(window);
+    return tgp_roi_cloud_ex(depth, masks, mask_off, mask_stride, det_img, window, camk, D, H, W, roi_size, recs, counts, nullptr, nullptr,
+                            0.25f, stream);
 }
 
 // _sample_points (:404-417) as a gather that materialises the selected points: the host supplies the selection (tiled indices,
@@ -306,27 +328,34 @@ extern "C" int tgp_roi_cloud(const uint16_t *depth, const uint8_t *masks, const 
 // An index outside [0, roi_size^2) yields NaNs.
 __global__ void cloud_select_kernel(const uint32_t *__restrict__ recs, const int *__restrict__ sel, const int *__restrict__ det_img,
                                     const int *__restrict__ window, const float *__restrict__ camk, int64_t total, int roi_log2, int n_pts,
-                                    float *__restrict__ out)
+                                    float *__restrict__ out, const int *__restrict__ tables)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const int j = (int)(t / n_pts), cap = 1 << (2 * roi_log2);
     const int k = sel[t];
     float a = NAN, b = NAN, c = NAN;
-    if (k >= 0 && k < cap) RoiGeom(window, camk, j, det_img[j], roi_log2).point(recs[(size_t)j * cap + k], a, b, c);
+    if (k >= 0 && k < cap) RoiGeom(window, camk, j, det_img[j], roi_log2, tables).point(recs[(size_t)j * cap + k], a, b, c);
     out[t * 3] = a, out[t * 3 + 1] = b, out[t * 3 + 2] = c;
+}
+
+extern "C" int tgp_cloud_select_ex(const uint32_t *recs, const int32_t *sel, const int *det_img, const int *window, const float *camk, int D,
+                                   int roi_size, int n_pts, float *out, const int *tables, tgp_stream_t stream)
+{
+    TGP_REQUIRE(recs && sel && det_img && (window || tables) && camk && out && D > 0 && n_pts > 0);
+    const int lg = roi_log2_of(roi_size);
+    if (lg < 0) return TGP_EUNSUPPORTED;
+    const int64_t total = (int64_t)D * n_pts;
+    hipLaunchKernelGGL(cloud_select_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), recs, sel, det_img, window, camk, total,
+                       lg, n_pts, out, tables);
+    return TGP_LAUNCH_RESULT();
 }
 
 extern "C" int tgp_cloud_select(const uint32_t *recs, const int32_t *sel, const int *det_img, const int *window, const float *camk, int D,
                                 int roi_size, int n_pts, float *out, tgp_stream_t stream)
 {
-    TGP_REQUIRE(recs && sel && det_img && window && camk && out && D > 0 && n_pts > 0);
-    const int lg = roi_log2_of(roi_size);
-    if (lg < 0) return TGP_EUNSUPPORTED;
-    const int64_t total = (int64_t)D * n_pts;
-    hipLaunchKernelGGL(cloud_select_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), recs, sel, det_img, window, camk, total,
-                       lg, n_pts, out);
-    return TGP_LAUNCH_RESULT();
+    TGP_REQUIRE(window);
+    return tgp_cloud_select_ex(recs, sel, det_img, window, camk, D, roi_size, n_pts, out, nullptr, stream);
 }
 
 // The same resampling without the host in the loop: a keyed bijection of [0, 2^b) (four Feistel rounds on b/2-bit

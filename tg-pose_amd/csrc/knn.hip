@@ -661,6 +661,47 @@ __global__ __launch_bounds__(256) void knn_transpose_kernel(const float *__restr
     for (int cc = ty; cc < 32; cc += 8) xt[((size_t)b * d + c0 + cc) * ldt + j0 + tx] = tile[tx][cc];
 }
 
+// Both pre-passes of the fused kernel in ONE launch (round 3; they were two: 4 feature-space graphs x 2 launches per forward): a
+// workgroup takes 32 rows of an object and walks their d / 32 column tiles; each tile goes through LDS once and leaves as a
+// transposed block of xt AND as the next four terms of the rows' squared norms, accumulated in sqnorm_aten_kernel's order (thread
+// (row, l8) holds ATen's four interleaved accumulators over the columns 8 kk + l8 of every 32-column group, groups ascending;
+// then acc0 + acc1 + acc2 + acc3, then the eight lanes in order): bit-identical norms.
+__global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__ x, int ld, int n, int d, float *__restrict__ xt, int ldt,
+                                                       float *__restrict__ q)
+{
+    __shared__ float tile[4][32][33];          // four 32-column groups per pass (d = 128: one pass)
+    const int b = blockIdx.y, j0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < d; c0 += 128) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            for (int rr = ty; rr < 32; rr += 8)
+                tile[g][rr][tx] = (j0 + rr < n && c0 + g * 32 < d) ? x[((size_t)b * n + j0 + rr) * ld + c0 + g * 32 + tx] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (c0 + g * 32 >= d) break;
+            for (int cc = ty; cc < 32; cc += 8) xt[((size_t)b * d + c0 + g * 32 + cc) * ldt + j0 + tx] = tile[g][tx][cc];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {       // groups ascending, then ATen's four interleaved accumulators
+                const float v = tile[g][r][kk * 8 + l8];
+                acc[kk] = acc[kk] + v * v;
+            }
+        }
+        __syncthreads();
+    }
+    float p = acc[0] + acc[1];
+    p = p + acc[2];
+    p = p + acc[3];
+    float fin = 0.f;
+    const int base = (threadIdx.x & 63) & ~7;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) fin = fin + __shfl(p, base + l, 64);
+    if (l8 == 0 && j0 + r < n) q[(size_t)b * n + j0 + r] = 0.f + fin;
+}
+
 // does the fused (matrix-free) kernel serve this shape?
 static bool knn_feat_fused_ok(int n, int d)
 {
@@ -710,11 +751,9 @@ extern "C" int tgp_knn_feat(const float *feat, int ld, int B, int n, int d, int 
     float *D = reinterpret_cast<float *>(workspace);   // the transposed features or the (B,n,n) distance matrix, then (B,n) squared norms
     float *q = D + (fused ? (size_t)B * d * ldt : (size_t)B * n * n);
     const int64_t rows = (int64_t)B * n;
-    hipLaunchKernelGGL(sqnorm_aten_kernel, dim3(tgp_cdiv(rows * 8, 256)), dim3(256), 0, tgp_hs(stream), feat, ld, rows,
-                       d, q);
     const int nt = tgp_cdiv(n, 64);
     if (fused) {
-        hipLaunchKernelGGL(knn_transpose_kernel, dim3(ldt / 32, d / 32, B), dim3(256), 0, tgp_hs(stream), feat, ld, n, d, D, ldt);
+        hipLaunchKernelGGL(knn_prep_kernel, dim3(ldt / 32, B), dim3(256), 0, tgp_hs(stream), feat, ld, n, d, D, ldt, q);
 #define LAUNCH_FUSED(NT) \
     (d == 128 ? launch_knn_fused<128, NT, 8>(D, q, B, n, k, idx, tgp_hs(stream)) : launch_knn_fused<256, NT, 8>(D, q, B, n, k, idx, tgp_hs(stream)))
         if (nt <= 1) return LAUNCH_FUSED(1);
@@ -725,6 +764,8 @@ extern "C" int tgp_knn_feat(const float *feat, int ld, int B, int n, int d, int 
         return LAUNCH_FUSED(19);
 #undef LAUNCH_FUSED
     }
+    hipLaunchKernelGGL(sqnorm_aten_kernel, dim3(tgp_cdiv(rows * 8, 256)), dim3(256), 0, tgp_hs(stream), feat, ld, rows,
+                       d, q);
     int rc = tgp_launch_dist_gemm(feat, ld, q, B, n, d, D, tgp_hs(stream));
     if (rc) return rc;
     const int rpb = knn_rows_per_block(B, n);

@@ -26,3 +26,12 @@ extern "C" int tgp_graph_node_counts(void *graph, int *counts)
     delete[] nodes;
     return (int)e;
 }
+
+#ifdef TGP_DEV
+// development library only (scripts/capture_memset_probe.py): hipMemsetAsync on the caller's stream, so that a Python probe can
+// put a MEMSET node between two kernel nodes of a captured graph and test how hipGraph orders it
+extern "C" int tgp_debug_memset_async(void *ptr, int value, size_t bytes, tgp_stream_t stream)
+{
+    return (int)hipMemsetAsync(ptr, value, bytes, tgp_hs(stream));
+}
+#endif

@@ -16,6 +16,7 @@ Data layout in HBM (fp32, row-major, rows = points):
   proj9  (B*n, 9*Cout) per HS layer: [centre | 7 support blocks | STE] from ONE GEMM.
 """
 import math
+import os
 
 import torch
 
@@ -70,6 +71,11 @@ def pack_encoder(sd, e, device):
     c0["w1"], c0["w2"] = w2[:, :128].contiguous(), w2[:, 128:].contiguous()
     c0["w1_s"] = ops.split_w(c0["w1"])
     c0["w2t"] = c0["w2"].t().contiguous()
+    # conv2's feature half and the STE convolution as ONE operand over [g | x y z 0] (K = 132): the graph convolution writes the
+    # point behind its 128 outputs (tgp_gconv_surface_fwd xyz_pad), so STE(xyz) costs four K columns instead of a fill, a copy
+    # and a GEMM launch of its own (30 us of the serial forward)
+    c0["w1x"] = torch.cat([c0["w1"], c0["ste"]], dim=1).contiguous()                   # (128, 132)
+    c0["w1x_s"] = ops.split_w(c0["w1x"])
     conv.append(c0)
     for i, (cin, cout) in enumerate(LEVEL_CH, start=1):
         p = e + "conv_%d." % i
@@ -226,6 +232,15 @@ _SIDE = {}
 BRANCH_STREAMS = True   # run the PH-tail -> decoder chain beside the head chain on a second HIP stream
 FACTORED = True         # eval forward: the layers over the concat buffer run factored over the upsampling (pack_factored)
 HEADS_FUSED = True      # ... and the heads' conv1 -> conv2 -> max as one kernel (csrc/heads_fused.hip) instead of two GEMM launches
+# Two more side branches, built and measured in round 3 (scripts/branch_ab.py, scripts/queues_ab.py; profiles/r03_branch_ab.txt) and
+# left OFF: the level-1 coarse product beside conv_4, and the rows behind the fused heads kernel's last full round (771 workgroups
+# = 3.01 rounds of 256) on the tile kernels beside it.  One batch in flight: +1 .. 3 % (a chip-filling GEMM beside a chain of small
+# launches does not shorten the chain -- its workgroups hold every CU, and the small launches wait for them).  Two batches in
+# flight (the bench default): 17.7 k -> 15.3 k objects/s.  hipGraph runs a graph's extra branches on ONE pool of internal streams
+# per device shared by every graph in flight (DEBUG_HIP_FORCE_GRAPH_QUEUES / GPU_MAX_HW_QUEUES = 8 / 16 changed nothing), so the
+# branches of two replays queue behind each other.
+COARSE_SIDE = os.environ.get("TGP_COARSE_SIDE", "0") != "0"
+HEADS_TAIL = os.environ.get("TGP_HEADS_TAIL", "0") != "0"
 
 
 SIDE_TAG = 0            # GraphedForward gives each half batch its own side stream
@@ -280,13 +295,12 @@ def surface_layer(c, xyz, idx_rf, idx_orl, out, scale=None, shift=None, act=None
     """HSlayer_surface.forward (gcn3d.py:78-89) + the caller's activation, written to `out` (B,n,C) view."""
     B, n, _ = xyz.shape
     C = c["C"]
-    g = ops.gconv_surface(xyz, idx_rf, c["sdn"], 7, C)
+    gx = torch.empty(B, n, C + 4, device=xyz.device, dtype=torch.float32)          # [g | x y z 0]
+    g = ops.gconv_surface(xyz, idx_rf, c["sdn"], 7, C, out=gx[:, :, :C], xyz_pad=True)
     rb = ops.orl_rowbias(g, idx_orl, c["w2t"]) if "w2t" in c else ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
-    xyz4 = torch.zeros(B, n, 4, device=xyz.device, dtype=torch.float32)
-    xyz4[:, :, :3].copy_(xyz)
-    ste = ops.linear_rows(xyz4, c["ste"])
-    ops.linear_rows(g, c["w1"], out=out, rowbias=rb, rows_per_obj=n, res1=g, res2=ste, scale=scale, shift=shift,
-                    act=0 if act is None else 1, slope=0.0, w_split=c.get("w1_s"))
+    # conv2(cat[g, global]) + g + STE(xyz) (gcn3d.py:87-89,108-112): W1 g + STE xyz is one product over the padded row
+    ops.linear_rows(gx, c["w1x"], out=out, rowbias=rb, rows_per_obj=n, res1=g, scale=scale, shift=shift,
+                    act=0 if act is None else 1, slope=0.0, w_split=c.get("w1x_s"), k_alg=C + 3)
     return out
 
 
@@ -370,6 +384,22 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, 
              graphs.get("conv_3.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm3, cv[3]["scale"], cv[3]["shift"], "relu")
     v2, fp2 = ops.pool(v1, fm3, graphs.get("pool_2.xyz", lambda: xyz_graph(1, v1, k1)), s2, kpool=4)
 
+    P1 = P1_join = None
+    if factored and getattr(pk, "fact", None) is not None:
+        # the level-1 coarse product W_1 x [fm_2 | fm_3] of the factored wide layers (coarse_products) needs nothing beyond conv_3:
+        # on a side stream it runs beside conv_4, the two nearest-point searches, the row sort and the gather -- 160 us of small
+        # launches that leave most CUs idle -- instead of in front of conv_5 on the critical path
+        f = pk.fact
+        p1_fn = lambda: ops.linear_rows(fm23.reshape(-1, 512), f["Wb"], w_split=f["Wb_s"], flops_ref=0)
+        if not COARSE_SIDE:
+            pass                                   # coarse_products computes it in line
+        elif BRANCH_STREAMS:
+            P1, P1_join = _beside(dev, p1_fn, tag="coarse")
+            if not torch.cuda.is_current_stream_capturing():
+                fm23.record_stream(_side_stream(dev, (SIDE_TAG, "coarse")))
+        else:
+            P1 = p1_fn()
+
     k2 = min(kmax, N2 // 8)
     fm4 = torch.empty(B, N2, 512, device=dev, dtype=torch.float32)
     hs_layer(cv[4], v2, fp2, lambda: graphs.get("conv_4.rf", lambda: ops.knn_feat(fp2, k2)),
@@ -388,7 +418,7 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, 
         order32, order, near1, near2 = ops.sort_by_parent(near1.contiguous(), near2.contiguous(), N1, N2)
         fine = torch.empty_like(feat)
         ops.gather_rows(feat, order32, fine)
-        inter.update(fm23=fm23, near1=near1, near2=near2, order=order)
+        inter.update(fm23=fm23, near1=near1, near2=near2, order=order, P1=P1, P1_join=P1_join)
         return fine, inter
     ops.gather_rows(fm2, near1, feat[:, :, 256:512])
     ops.gather_rows(fm3, near1, feat[:, :, 512:768])
@@ -397,12 +427,28 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, 
     return feat, inter
 
 
-def ph_tail(ph, keys, B, dev):
+class Arena(object):
+    """Everything one eval forward needs zero-initialised -- the order-preserving max keys of conv_5 and of the heads' conv2, the two
+    fp16-range flags, the zero-padded topology back-projection -- carved out of ONE buffer zeroed by ONE fill (round 2: five
+    fills of 4-5 us each per forward)."""
+
+    def __init__(self, B, dev):
+        n5, n2, nb = B * 1024, 3 * B * 256, B * FEAT_LD
+        buf = torch.zeros(n5 + n2 + 8 + nb, device=dev, dtype=torch.int32)
+        self.keys5 = buf[:n5].view(B, 1024)
+        self.keys2 = buf[n5:n5 + n2].view(3, B, 256)
+        self.over5 = buf[n5 + n2:n5 + n2 + 1]
+        self.over2 = buf[n5 + n2 + 4:n5 + n2 + 5]
+        self.back = buf[n5 + n2 + 8:].view(torch.float32).view(B, FEAT_LD)
+
+
+def ph_tail(ph, keys, B, dev, back=None):
     """PH_Predictor after the max over points (FaceRecon.py:145-165): keys = colmax keys of conv_5."""
     g = ops.colmax_decode(keys, out2=True)                                       # cat((max, max), 1)
     fa = ops.linear_rows(g, ph["l1"], scale=ph["bn5"][0], shift=ph["bn5"][1], act=1, slope=0.2)
     pi = ops.linear_rows(fa, ph["l23"][0], bias=ph["l23"][1])                    # (B, 5000) = [pi1 | pi2]
-    back = torch.zeros(B, FEAT_LD, device=dev, dtype=torch.float32)
+    if back is None:
+        back = torch.zeros(B, FEAT_LD, device=dev, dtype=torch.float32)
     ops.linear_rows(pi, ph["l45"][0], bias=ph["l45"][1], out=back[:, :FEAT_C])   # pi1_1 + pi2_1
     h = ops.sigmoid(pi)
     nc = ph["n_code"]
@@ -438,35 +484,74 @@ def coarse_products(pk, inter):
     """W_1 x [fm_2 | fm_3] and W_2 x fm_4 for the 4096 columns of the wide layer and the 512 of the decoder's first conv, per
     coarse point: (B*N1, 4608), (B*N2, 4608)"""
     f = pk.fact
-    return (ops.linear_rows(inter["fm23"].reshape(-1, 512), f["Wb"], w_split=f["Wb_s"], flops_ref=0),
-            ops.linear_rows(inter["fm_4"].reshape(-1, 512), f["Wc"], w_split=f["Wc_s"], flops_ref=0))
+    P1 = inter.get("P1")
+    if P1 is None:
+        P1 = ops.linear_rows(inter["fm23"].reshape(-1, 512), f["Wb"], w_split=f["Wb_s"], flops_ref=0)
+    elif inter.get("P1_join") is not None:        # computed beside conv_4 (encoder_forward): join before the first consumer
+        torch.cuda.current_stream(P1.device).wait_event(inter["P1_join"])
+    return P1, ops.linear_rows(inter["fm_4"].reshape(-1, 512), f["Wc"], w_split=f["Wc_s"], flops_ref=0)
 
 
-def wide_gemm_factored(pk, fine, inter, P1, P2, N):
+def wide_gemm_factored(pk, fine, inter, P1, P2, N, arena=None):
     """wide_gemm over the fine buffer with the coarse products fetched by the epilogue (same outputs)."""
     B = fine.shape[0]
     dev = fine.device
     w, f = pk.wide, pk.fact
     M = B * N
+    if arena is None:
+        arena = Arena(B, dev)
     if HEADS_FUSED and f["w2p"] is not None:
         # conv_5 (N = 1024, only its max over points is used) on the light fused kernel, the heads on theirs; the tile-kernel form
         # of conv_5 follows predicated on the range flag (it normally returns at once)
         light = P1.numel() < 2 ** 31 and P2.numel() < 2 ** 31      # the light kernel addresses the coarse products with 32-bit offsets
         over5 = None
-        if not light:
-            keys5 = torch.zeros(B, 1024, device=dev, dtype=torch.int32)
-        else:
+        keys5 = arena.keys5
+        if light:
             keys5, over5 = ops.conv_max_fused(fine.view(M, -1), FINE_K, f["Wa_s"], P1, inter["near1"], P2, inter["near2"],
-                                              w["bias"][:1024], w["scale"][:1024], w["shift"][:1024], 0.2, B, N, k_alg=w["k_alg"])
+                                              w["bias"][:1024], w["scale"][:1024], w["shift"][:1024], 0.2, B, N, k_alg=w["k_alg"],
+                                              keys=arena.keys5, overflow=arena.over5)
         ops.gemm(fine, f["Wa"], None, M=M, N=1024, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=0, bias=w["bias"],
                  scale=w["scale"], shift=w["shift"], act=1, slope_vec=w["slope"], colmax_keys=keys5, cm_cols=1024,
                  rows_per_obj=N, w_split=f["Wa_s"], gather1=(P1, P1.shape[1], inter["near1"]),
                  gather2=(P2, P2.shape[1], inter["near2"]), flops_ref=0 if light else 2.0 * M * 1024 * w["k_alg"], pred=over5)
         # (returned as a thunk: the caller forks the PH / decoder branch, which needs only keys5, before the long heads kernel)
         def heads():
+            # The fused kernel's grid is heads x 128-point workgroups, one per CU and round.  When the last round would hold only
+            # a few of them (B = 32, N = 1028: 771 = 3 x 256 + 3) the rows behind the last full round go to the two-launch tile
+            # form instead -- 128 rows per head here, two launches of ~10 us on a side stream while the fused kernel runs -- and
+            # merge into the same keys (atomicMax on order-preserving keys is exact and order-free).
+            wg = 3 * ((M + 127) // 128)
+            slots = ops._big_tile_threshold() * 2                         # CUs = resident workgroups of the fused kernel
+            rows = 0
+            if HEADS_TAIL and wg > slots and wg % slots and (wg % slots) * 8 <= slots:
+                rows = ((wg // slots) * slots // 3) * 128
+            tail = None
+            if rows and rows < M:
+                def tail_rows():
+                    Mt = M - rows
+                    Ht = torch.empty(Mt, 3072, device=dev, dtype=torch.float32)
+                    ft = fine.view(M, -1)[rows:]
+                    ops.gemm(ft, f["Wa"][1024:], Ht, M=Mt, N=3072, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=3072, bias=w["bias"][1024:],
+                             scale=w["scale"][1024:], shift=w["shift"][1024:], act=1, slope=0.0, rows_per_obj=N, w_split=f["Wa_s"][1024:],
+                             gather1=(P1[:, 1024:], P1.shape[1], inter["near1"].view(-1)[rows:]),
+                             gather2=(P2[:, 1024:], P2.shape[1], inter["near2"].view(-1)[rows:]), flops_ref=0, row_base=rows)
+                    ops.gemm(Ht, w["W2"], None, M=Mt, N=256, K=1024, lda=3072, ldw=1024, ldc=0, bias=w["b2"], scale=w["scale2"],
+                             shift=w["shift2"], act=1, slope=0.0, colmax_keys=arena.keys2, rows_per_obj=N, batch=3,
+                             batch_strides=(1024, 256 * 1024, 0, 256, B * 256), w_split=w["W2s"], flops_ref=0, row_base=rows)
+                    return Ht
+                if BRANCH_STREAMS:
+                    Ht, tail = _beside(dev, tail_rows, tag="heads_tail")
+                    if not torch.cuda.is_current_stream_capturing():
+                        for t in (fine, P1, P2, inter["near1"], inter["near2"], arena.keys2):
+                            t.record_stream(_side_stream(dev, (SIDE_TAG, "heads_tail")))
+                else:
+                    tail_rows()
             keys2, overflow = ops.heads_fused(fine.view(M, -1), FINE_K, f["Wa_s"][1024:], P1[:, 1024:], inter["near1"], P2[:, 1024:],
                                               inter["near2"], w["bias"][1024:], w["scale"][1024:], w["shift"][1024:], f["w2p"],
-                                              w["b2"], w["scale2"], w["shift2"], B, N, k_alg=w["k_alg"])
+                                              w["b2"], w["scale2"], w["shift2"], B, N, k_alg=w["k_alg"], keys=arena.keys2,
+                                              overflow=arena.over2, rows=rows)
+            if tail is not None:
+                torch.cuda.current_stream(dev).wait_event(tail)
             # fp16 range repair, decided on the device: a wave of the fused kernel that met a magnitude beyond fp16's range wrote no
             # keys and raised `overflow`; the two-launch form (whose tiles guard themselves) then supplies every key.  While the
             # flag is 0 -- always, for sane weights -- both launches return at once (tgp_gemm_args.pred).
@@ -480,7 +565,7 @@ def wide_gemm_factored(pk, fine, inter, P1, P2, N):
                      batch_strides=(1024, 256 * 1024, 0, 256, B * 256), w_split=w["W2s"], flops_ref=0, pred=overflow)
             return keys2
         return keys5, heads
-    keys5 = torch.zeros(B, 1024, device=dev, dtype=torch.int32)
+    keys5 = arena.keys5
     H = torch.empty(M, 3072, device=dev, dtype=torch.float32)
     ops.gemm(fine, f["Wa"], H, M=M, N=4096, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=3072, bias=w["bias"],
              scale=w["scale"], shift=w["shift"], act=1, slope_vec=w["slope"], colmax_keys=keys5, cm_cols=1024,
@@ -530,7 +615,7 @@ def head_chain(pk, H, B, N):
     o4 = torch.empty(3, B, 8, device=dev, dtype=torch.float32)
     ops.gemm(x3, w["W4"], o4, M=B, N=8, K=256, lda=256, ldw=256, ldc=8, bias=w["b4"], batch=3,
              batch_strides=(B * 256, 8 * 256, B * 8, 8, 0))
-    return [o4[i, :, : w["n_out"][i]].contiguous() for i in range(3)]
+    return [o4[i, :, : w["n_out"][i]] for i in range(3)]          # views of the (3, B, 8) buffer: tgp_head_post takes row strides
 
 
 def wide_forward(pk, feat, N):
@@ -598,9 +683,11 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
     graphs = Graphs(points.device, inject, record)
     factored = FACTORED and not train_keys          # the concat buffer is an output only with the training keys
     feat, inter = encoder_forward(pk, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls, factored=factored)
+    arena = None
     if factored:
+        arena = Arena(B, points.device)          # zeroed on this stream before any branch forks
         P1, P2 = coarse_products(pk, inter)
-        wide = lambda: wide_gemm_factored(pk, feat, inter, P1, P2, N)
+        wide = lambda: wide_gemm_factored(pk, feat, inter, P1, P2, N, arena)
         decode = lambda back: decoder_forward_factored(pk, feat, inter, P1, P2, back, N)
     else:
         P1 = P2 = None
@@ -616,7 +703,7 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
         fork.record(cur)
         with torch.cuda.stream(side):
             side.wait_event(fork)
-            h1, h2, back = ph_tail(pk.ph, keys5, B, points.device)
+            h1, h2, back = ph_tail(pk.ph, keys5, B, points.device, arena.back if arena is not None else None)
             recon = decode(back)
             join = torch.cuda.Event()
             join.record(side)
@@ -632,7 +719,7 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
         if callable(H):
             H = H()
         green, red, ts = head_chain(pk, H, B, N)
-        h1, h2, back = ph_tail(pk.ph, keys5, B, points.device)
+        h1, h2, back = ph_tail(pk.ph, keys5, B, points.device, arena.back if arena is not None else None)
         recon = decode(back)
     pg, pr, fg, fr, pT, ps = ops.head_post(green, red, ts, mean)
     out = dict()
@@ -846,6 +933,33 @@ def encoder_only_forward_train(pk, sd, points, obj_id, sample_idx=None, inject=N
 # Inputs are copied into static buffers before a replay; the returned tensors are the graph's static outputs, valid
 # until the next replay (the usual contract of graph replay).
 # =====================================================================================================
+def new_graph():
+    """a CUDAGraph that keeps its hipGraph after capture, so that check_capture can take the node census"""
+    return torch.cuda.CUDAGraph(keep_graph=True)
+
+
+def check_capture(graph, what):
+    """Refuse a captured graph that holds a MEMSET node, then instantiate it.
+
+    Root cause of the round-2 device fault (scripts/capture_memset_probe.py is the 30-line reproducer): on
+    this ROCm stack a hipMemsetAsync captured into a hipGraph is, from the second launch of the graph on, NOT ordered against
+    the kernel node in front of it -- half of its words still hold what that kernel wrote.  ATen's multi-block reductions
+    (max-with-indices over a long dimension, sums over broadcast dimensions) zero their semaphores exactly that way; inside a
+    captured step their semaphore block is recycled pool memory that earlier kernels of the same graph wrote, so from the second
+    replay on the reduction's last-block logic does not fire and its outputs keep stale bytes (arg-max "indices" that are really
+    fp16 weight planes -> the out-of-bounds scatter of r02a).  Nothing in this library issues a memset; a memset node therefore
+    means a torch op of that kind slipped into the captured region, which is refused here instead of being found as a fault."""
+    kernels, memcpys, memsets, other = ops.graph_node_counts(graph.raw_cuda_graph())
+    if memsets and not os.environ.get("TGP_ALLOW_GRAPH_MEMSET"):
+        raise RuntimeError(
+            "%s: the captured graph holds %d memset node(s) (and %d kernel nodes).  hipGraph memset nodes are not ordered against "
+            "the neighbouring kernels on replay on this ROCm stack; they come from torch ops that call hipMemsetAsync (ATen's "
+            "multi-block reductions: x.max(dim) / x.sum(dim) over a long dimension).  Replace that op by a library kernel "
+            "(ops.colmax_arg, ops.colsum_objects, ...) or move it out of the captured region." % (what, memsets, kernels))
+    graph.instantiate()
+    return kernels, memcpys, memsets, other
+
+
 class PinnedRing(object):
     """Host staging for the per-forward subsample indices.  A replay is enqueued asynchronously, so the host may be several
     steps ahead of the device: each upload takes the next of `slots` pinned buffers and first waits for the copy that last
@@ -917,9 +1031,10 @@ class GraphedForward(object):
             run()
         torch.cuda.current_stream(device).wait_stream(warm)
         torch.cuda.synchronize(device)
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = new_graph()
         with torch.cuda.graph(self.graph):
             self.out = run()
+        self.nodes = check_capture(self.graph, "GraphedForward")
 
     def __call__(self, points, obj_id, sample_idx=None):
         if tuple(points.shape) != (self.B, self.N, 3):

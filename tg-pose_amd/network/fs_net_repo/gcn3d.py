@@ -119,9 +119,10 @@ class HSlayer_surface(_Packable):
     def _build(self):
         C = self.kernel_num
         w2 = self.conv2.weight.detach()[:, :, 0]
-        return dict(C=C, sdn=ops.normalize_dirs(self.directions.detach()),
-                    ste=engine._pad_cols(self.STE_layer.weight.detach()[:, :, 0], 4),
-                    w1=w2[:, :C].contiguous(), w2=w2[:, C:].contiguous())
+        ste = engine._pad_cols(self.STE_layer.weight.detach()[:, :, 0], 4)
+        # conv2's feature half and the STE convolution as one operand over [g | x y z 0] (engine.surface_layer)
+        return dict(C=C, sdn=ops.normalize_dirs(self.directions.detach()), ste=ste,
+                    w1=w2[:, :C].contiguous(), w2=w2[:, C:].contiguous(), w1x=torch.cat([w2[:, :C], ste], dim=1).contiguous())
 
     def forward(self, vertices, neighbor_num):
         xyz = _xyz(vertices)

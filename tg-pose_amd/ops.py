@@ -139,14 +139,16 @@ def normalize_dirs(directions):
 
 
 @_timed("graph")
-def gconv_surface(xyz, idx, sdn, S, C, out=None):
+def gconv_surface(xyz, idx, sdn, S, C, out=None, xyz_pad=False):
+    """xyz_pad: `out` is a (B, n, C) view of a buffer whose rows are at least C + 4 floats long; columns C..C+3 of every row
+    receive the point (x, y, z, 0) -- the STE convolution's operand for the layer's last GEMM"""
     _f32(xyz, "xyz", 3), _i32(idx, "idx")
     B, n, k = idx.shape
     if out is None:
         out = torch.empty(B, n, C, device=xyz.device, dtype=torch.float32)
     out, ldo = _rows(out, "out")
-    check(_lib.lib().tgp_gconv_surface_fwd(_p(xyz), _p(idx), _p(sdn), B, n, k, S, C, _p(out), ldo, _stream(xyz)),
-          "tgp_gconv_surface_fwd")
+    check(_lib.lib().tgp_gconv_surface_fwd(_p(xyz), _p(idx), _p(sdn), B, n, k, S, C, _p(out), ldo, 1 if xyz_pad else 0,
+                                           _stream(xyz)), "tgp_gconv_surface_fwd")
     return out
 
 
@@ -308,8 +310,15 @@ GEMM_TIMER = None
 GEMM_TIMER_ALL = False      # development: time the small-tile and skinny launches too (scripts/gemm_shapes.py)
 
 
-def _routes_to_big_tile(M, N, batch=1):
-    return M > 32 and N > 64 and ((M + 127) // 128) * ((N + 127) // 128) * batch >= _big_tile_threshold()
+def _routes_to_big_tile(M, N, batch=1, split16=False):
+    """does tgp_gemm_f32 send this launch to a tile kernel that reads the SPLIT weight (rather than to the exact-fp32 64 x 64 or the
+    skinny kernel, which read the fp32 weight)?  split16: a two-term fp16 split weight is passed -- such launches also take the
+    64 x 128 small-tile split kernel from 32 tiles on (round 3, csrc/gemm.hip `small_split`)."""
+    if not (M > 32 and N > 64):
+        return False
+    if ((M + 127) // 128) * ((N + 127) // 128) * batch >= _big_tile_threshold():
+        return True
+    return bool(split16) and ((M + 63) // 64) * ((N + 127) // 128) * batch >= 32
 
 
 _BIG_THR = None
@@ -326,11 +335,13 @@ def _big_tile_threshold():
 def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, bias=None, rowbias=None,
          rows_per_obj=0, res1=None, ldr1=0, res2=None, ldr2=0, scale=None, shift=None, act=0, slope=0.0,
          colmax_keys=None, k_alg=None, slope_vec=None, cm_cols=0, c_col0=0, batch=1, batch_strides=None, w_split=None,
-         a_scale=None, c_scale=None, ksplit_chunk=0, gather1=None, gather2=None, flops_ref=None, epilogue=0, pred=None):
+         a_scale=None, c_scale=None, ksplit_chunk=0, gather1=None, gather2=None, flops_ref=None, epilogue=0, pred=None,
+         row_base=0):
     """Raw call into tgp_gemm_f32.  A/W/C/res* are tensors whose data_ptr is the first element of the
     operand (views into wider buffers are fine); all sizes/strides are explicit.  k_alg: the layer's
     true input width when K includes zero padding (only used for FLOP accounting in bench.py)."""
-    timed = GEMM_TIMER is not None and pred is None and (GEMM_TIMER_ALL or _routes_to_big_tile(M, N, batch))   # (a predicated
+    split16 = w_split is not None and GEMM_MODE != "fp32" and w_split.shape[-2] == 2 and not ksplit_chunk
+    timed = GEMM_TIMER is not None and pred is None and (GEMM_TIMER_ALL or _routes_to_big_tile(M, N, batch, split16))   # (a predicated
     # launch is a repair path that normally does nothing: it has no place in a FLOP rate)
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -354,7 +365,7 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
         a.W_split, a.ldws = _p(w_split), w_split.shape[-3] * 16
         a.w_split_kind = 1 if w_split.shape[-2] == 2 else 0
         unscale = getattr(w_split, "tgp_unscale", None)       # a weight that was pre-scaled into fp16's range (split_w)
-        if unscale is not None and _routes_to_big_tile(M, N, batch):
+        if unscale is not None and _routes_to_big_tile(M, N, batch, split16):
             c_scale = unscale if c_scale is None else c_scale * unscale
     a.a_scale, a.c_scale, a.ksplit_chunk = _p(a_scale), _p(c_scale), int(ksplit_chunk)
     if gather1 is not None:                      # (rows tensor whose data_ptr is the first column wanted, row stride, int32 row ids)
@@ -363,6 +374,7 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
         a.gres2, a.ldg2, a.gidx2 = _p(gather2[0]), int(gather2[1]), _p(gather2[2])
     a.epilogue = int(epilogue)
     a.pred = _p(pred)
+    a.row_base = int(row_base)
     check(_lib.lib().tgp_gemm_f32(ctypes.byref(a), _stream(A)), "tgp_gemm_f32")
     if timed:
         e1.record(torch.cuda.current_stream(A.device))
@@ -409,15 +421,18 @@ def heads_pack_w2(W2):
     return out
 
 
-def heads_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias1, scale1, shift1, w2p, bias2, scale2, shift2, B, rows_per_obj, k_alg=None):
+def heads_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias1, scale1, shift1, w2p, bias2, scale2, shift2, B, rows_per_obj, k_alg=None,
+                keys=None, overflow=None, rows=0):
     """conv1 -> BN -> ReLU -> conv2 -> BN -> ReLU -> max over points of the three heads (tgp_heads_fused): keys (heads, B, 256)
     and the device flag (1,) int32 that a wave raises instead of writing keys when it met a magnitude beyond fp16's range.
     fine (M, ldf); p1 / p2: 2-D views whose column 0 is the first head's first channel (row stride = their .stride(0))."""
     fine, ldf = _rows(fine, "fine")
     heads = w2p.shape[0]
     M = B * rows_per_obj
-    keys = torch.zeros(heads, B, 256, device=fine.device, dtype=torch.int32)
-    overflow = torch.zeros(1, device=fine.device, dtype=torch.int32)
+    if keys is None:          # (the eval forward hands in zeroed slices of its one per-forward arena instead)
+        keys = torch.zeros(heads, B, 256, device=fine.device, dtype=torch.int32)
+    if overflow is None:
+        overflow = torch.zeros(1, device=fine.device, dtype=torch.int32)
     timed = GEMM_TIMER is not None
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -433,22 +448,26 @@ def heads_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias1, scale1, shift1, w2p, b
     a.keys = _p(keys)
     a.M, a.rows_per_obj, a.B, a.heads = M, rows_per_obj, B, heads
     a.overflow = _p(overflow)
+    a.rows = int(rows)
     check(_lib.lib().tgp_heads_fused(ctypes.byref(a), _stream(fine)), "tgp_heads_fused")
     if timed:
         e1.record(torch.cuda.current_stream(fine.device))
-        conv2 = 2.0 * M * 256 * 1024 * heads
-        GEMM_TIMER.append((e0, e1, 2.0 * M * heads * 1024 * K + conv2, (M, heads * 1024, K, 1),
-                           2.0 * M * heads * 1024 * (k_alg or K) + conv2))
+        Mk = rows if rows else M                                     # rows this launch processed
+        conv2 = 2.0 * Mk * 256 * 1024 * heads
+        GEMM_TIMER.append((e0, e1, 2.0 * Mk * heads * 1024 * K + conv2, (Mk, heads * 1024, K, 1),
+                           2.0 * Mk * heads * 1024 * (k_alg or K) + conv2))
     return keys, overflow
 
 
-def conv_max_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias, scale, shift, slope, B, rows_per_obj, k_alg=None):
+def conv_max_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias, scale, shift, slope, B, rows_per_obj, k_alg=None, keys=None, overflow=None):
     """conv -> BN -> LeakyReLU -> max over points of a factored layer (tgp_conv_max_fused): keys (B, C) and the overflow flag."""
     fine, ldf = _rows(fine, "fine")
     C = bias.numel()
     M = B * rows_per_obj
-    keys = torch.zeros(B, C, device=fine.device, dtype=torch.int32)
-    overflow = torch.zeros(1, device=fine.device, dtype=torch.int32)
+    if keys is None:
+        keys = torch.zeros(B, C, device=fine.device, dtype=torch.int32)
+    if overflow is None:
+        overflow = torch.zeros(1, device=fine.device, dtype=torch.int32)
     timed = GEMM_TIMER is not None
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -500,13 +519,17 @@ def sigmoid(x):
 
 @_timed("graph")
 def head_post(green, red, ts, mean):
+    """green / red (B, >=4), ts (B, >=6): 2-D views with contiguous rows (their row strides are passed on)"""
     B = green.shape[0]
     dev = green.device
+    for t in (green, red, ts):
+        if t.dim() != 2 or t.stride(1) != 1:
+            raise ValueError("head_post: 2-D inputs with contiguous rows expected")
     pg, pr = torch.empty(B, 3, device=dev), torch.empty(B, 3, device=dev)
     fg, fr = torch.empty(B, device=dev), torch.empty(B, device=dev)
     pT, ps = torch.empty(B, 3, device=dev), torch.empty(B, 3, device=dev)
-    check(_lib.lib().tgp_head_post(_p(green), _p(red), _p(ts), _p(mean), B, _p(pg), _p(pr), _p(fg), _p(fr), _p(pT),
-                                   _p(ps), _stream(green)), "tgp_head_post")
+    check(_lib.lib().tgp_head_post(_p(green), _p(red), _p(ts), green.stride(0), red.stride(0), ts.stride(0), _p(mean), B, _p(pg),
+                                   _p(pr), _p(fg), _p(fr), _p(pT), _p(ps), _stream(green)), "tgp_head_post")
     return pg, pr, fg, fr, pT, ps
 
 

@@ -212,7 +212,8 @@ class RT_TDA_Trainer(object):
         else:
             self._buckets = None                                  # an earlier overlap capture's buckets no longer describe this step
 
-        g = GraphedStep(list(self.net1.parameters()), step_fn, [N, N], dev, cut=cut, between=between, after=after)
+        g = GraphedStep(list(self.net1.parameters()), step_fn, [N, N], dev, cut=cut, between=between, after=after,
+                        own_pool="ownpool" in _debug)
         self._graphed = g
 
         def step(db=None, sample_idx=None):
