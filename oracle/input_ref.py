@@ -167,3 +167,48 @@ def image_clouds(depth, masks, bboxes, K, img_size=256, n_pts=1024, rng=np.rando
             return None
         out.append(pcl[sample_selection(len(pcl), n_pts, rng)])
     return np.array(out, dtype=np.float32).reshape(len(out), n_pts, 3)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Training loader, the same stages with the ground-truth instance mask (datasets/load_data.py:232-290, 335-336, 366-380, 395-407).
+# Augmentation (aug_bbox_DZI's random window, defor_2D, PC_BasicAugment, the custom operators) is the caller's: the window is an
+# argument here, the point-cloud augmentations are identity.
+def dzi_window_off(bbox, im_H, im_W):
+    """load_data.py:235-238 with FLAGS.DZI_TYPE set to none of the augmenting kinds (tools/dataset_utils.py:57-61):
+    get_bbox's window -> (bbox_center (cx, cy), scale)."""
+    rmin, rmax, cmin, cmax = get_bbox(bbox)
+    x1, y1, x2, y2 = cmin, rmin, cmax, rmax
+    return np.array([0.5 * (x1 + x2), 0.5 * (y1 + y2)]), min(max(y2 - y1, x2 - x1), max(im_H, im_W)) * 1.0
+
+
+def train_roi_cloud(depth, mask, inst_id, bbox_center, scale, K, img_size=256):
+    """One training item up to the subsampling (load_data.py:239-290): ROI resampling of pixel grid / instance mask / depth with the
+    given window, validity tests (:260-265), _depth_to_pcl (:395-407) / 1000, the cut of the points within 0.15 x the extent's
+    diagonal of point number 25 (:276-286).  -> (cloud or None where __getitem__ retries, n_depth_valid, n_valid)."""
+    im_H, im_W = depth.shape
+    sx, sy = nearest_source_map(roi_affine(np.asarray(bbox_center), scale, img_size), (img_size, img_size))
+    inb = (sx >= 0) & (sx < im_W) & (sy >= 0) & (sy < im_H)
+    sxc, syc = np.where(inb, sx, 0), np.where(inb, sy, 0)
+    roi_depth = np.where(inb, depth[syc, sxc], 0)
+    mask_target = (mask == inst_id).astype(np.float32)                                  # :245-247
+    roi_mask = np.where(inb, mask_target[syc, sxc], 0).astype(np.float32)
+    xymap = np.stack([np.where(inb, sx, 0), np.where(inb, sy, 0)]).astype(np.float32)
+    n_depth = int((roi_depth > 0).sum())
+    n_valid = int(((roi_depth > 0) & (roi_mask != 0)).sum())
+    if n_depth <= 1 or n_valid <= 1:
+        return None, n_depth, n_valid
+    pcl = depth_to_pcl(roi_depth, K, xymap, roi_mask) / 1000.0
+    ranges = pcl.max(axis=0) - pcl.min(axis=0)
+    diag = np.sqrt(np.sum(ranges ** 2))
+    dist = np.linalg.norm(pcl - pcl[np.array([25])], axis=1)
+    pcl = pcl[dist > (diag * 0.15)]                                                     # float32 product (NumPy 2 promotion)
+    return (pcl if len(pcl) >= 50 else None), n_depth, n_valid                          # :288-289
+
+
+def train_item_clouds(depth, mask, inst_id, bbox_center, scale, K, img_size=256, rng=np.random):
+    """-> (PC (2048,3), pcl_in (1024,3)) as load_data.py:335-336 draws them (two _sample_points calls, :366-380), or None."""
+    pcl, _, _ = train_roi_cloud(depth, mask, inst_id, bbox_center, scale, K, img_size)
+    if pcl is None:
+        return None
+    PC = pcl[sample_selection(len(pcl), 2048, rng)]
+    return PC, PC[sample_selection(2048, 1024, rng)]

@@ -685,7 +685,131 @@ def gen_input_side():
     print("wrote input_side.npz %.1f KB" % (os.path.getsize(os.path.join(HERE, "input_side.npz")) / 1024.0))
 
 
+def gen_train_loader():
+    """The reference's own TRAINING ``PoseDataset.__getitem__`` (datasets/load_data.py:170-351) run on synthetic frames written to a
+    temporary dataset directory in its on-disk layout.  Augmentation is switched off through the reference's own FLAGS where it
+    is optional (roi_mask_pro = 0: defor_2D returns the mask; aug_*_pro = 0: PC_BasicAugment leaves the cloud alone); the box
+    augmentation aug_bbox_DZI runs as configured per item -- 'uniform' (the reference's default: its drawn window is recorded,
+    the build takes windows as an input) or switched off.  Stand-ins written for this repo, none of them on the pinned path
+    except cv2's two functions (as for the evaluation loader: oracle/input_ref.py's restatement of getAffineTransform /
+    warpAffine): ``cv2`` (imread from .npy twins), ``mmengine`` (load = pickle.load), ``tools.eval_utils`` (load_depth / get_bbox
+    of the source twin network/point_sample/pc_sample_sphere.py), ``datasets.compute_pd`` (gudhi + persim: returns zeros).
+    Recorded per item: the window aug_bbox_DZI returned, NumPy's generator state at the first _sample_points call (the build
+    replays the two permutations from there), pcl_in."""
+    import pickle
+    import tempfile
+    import types
+    from tests.util import synth_depth_scene
+    from oracle import input_ref as ir
+
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_NEAREST, cv2.INTER_LINEAR = 0, 1
+    cv2.getAffineTransform = lambda src, dst: ir.get_affine_transform_cv(src, dst)
+
+    def warp_affine(img, M, dsize, flags=1):
+        assert flags == cv2.INTER_NEAREST
+        return ir.warp_affine_nearest(img, M, dsize)
+
+    def imread(path, flag=1):
+        return np.load(path + ".npy") if os.path.exists(path + ".npy") else None
+    cv2.warpAffine, cv2.imread = warp_affine, imread
+    sys.modules["cv2"] = cv2
+    mm = types.ModuleType("mmengine")
+    mm.load = lambda path: pickle.load(open(path, "rb"))
+    sys.modules["mmengine"] = mm
+    twin = _load_by_path("ref_pc_sample_sphere", os.path.join(REF, "network/point_sample/pc_sample_sphere.py"))
+    eu = types.ModuleType("tools.eval_utils")
+    eu.load_depth, eu.get_bbox = twin.load_depth, twin.get_bbox
+    sys.modules["tools.eval_utils"] = eu
+    import datasets as ref_datasets                      # the reference's package (REF precedes site-packages on sys.path)
+    assert ref_datasets.__file__.startswith(REF), ref_datasets.__file__
+    cpd = types.ModuleType("datasets.compute_pd")
+    cpd.compute_pd = lambda pts: (torch.zeros(2500), torch.zeros(2500))
+    sys.modules["datasets.compute_pd"] = cpd
+    ld = _load_by_path("ref_load_data_train", os.path.join(REF, "datasets/load_data.py"))
+    F = ld.FLAGS
+    F.train, F.roi_mask_pro, F.aug_pc_pro, F.aug_rt_pro, F.aug_bb_pro, F.aug_bc_pro = 1, 0.0, 0.0, 0.0, 0.0, 0.0
+    windows = []
+    real_dzi = ld.aug_bbox_DZI
+
+    def dzi_spy(flags_, bbox_xyxy, im_H, im_W):
+        c, sc = real_dzi(flags_, bbox_xyxy, im_H, im_W)
+        windows.append((np.asarray(c, dtype=np.float64).copy(), float(sc)))
+        return c, sc
+    ld.aug_bbox_DZI = dzi_spy
+
+    # items: (scene seed, detection index inside the scene, DZI type, np.random seed)
+    items = [(31, 0, "uniform", 5), (31, 2, "uniform", 6), (32, 1, "none", 7), (33, 0, "uniform", 8), (33, 3, "none", 9),
+             (34, 1, "uniform", 10)]
+    arrays = dict(n_items=np.int64(len(items)), item_scene=np.array([i[0] for i in items]), item_det=np.array([i[1] for i in items]),
+                  item_dzi=np.array([i[2] == "uniform" for i in items]), scene_dets=np.int64(4))
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "Real", "train", "scene_1"))
+        try:
+            os.chdir(REF)                                  # __getitem__ reads ./obj_model/points_{cat}.npy (:303-311)
+            for n, (sseed, j, dzi, npseed) in enumerate(items):
+                fr = synth_depth_scene(sseed, 4)
+                inst_mask = np.zeros(fr["depth"].shape, np.uint8)
+                for q in range(4):
+                    inst_mask[fr["pred_masks"][:, :, q]] = q + 1                      # instance ids 1..4 (later blobs on top)
+                stem = os.path.join("Real", "train", "scene_1", "%04d" % n)
+                cls = int(fr["pred_class_ids"][j])
+                if cls == 6:
+                    cls = 5                                                           # (mug needs the handle-visibility table)
+                rot = np.eye(3, dtype=np.float32)
+                with open(os.path.join(tmp, stem + "_label.pkl"), "wb") as f:
+                    pickle.dump(dict(class_ids=[cls], instance_ids=[j + 1], bboxes=[fr["pred_bboxes"][j]], model_list=["m0"],
+                                     scales=[0.3], rotations=[rot], translations=[np.array([0.0, 0.0, 0.8], np.float32)]), f)
+                np.save(os.path.join(tmp, stem + "_color.png.npy"), np.zeros(fr["depth"].shape + (3,), np.uint8))
+                np.save(os.path.join(tmp, stem + "_depth.png.npy"), fr["depth"])
+                open(os.path.join(tmp, stem + "_depth.png"), "wb").close()
+                np.save(os.path.join(tmp, stem + "_mask.png.npy"), np.repeat(inst_mask[:, :, None], 3, axis=2))
+                ds = ld.PoseDataset.__new__(ld.PoseDataset)
+                ds.source, ds.mode, ds.data_dir, ds.per_obj, ds.per_obj_id = "Real", "train", tmp, "", None
+                ds.img_list, ds.length, ds.invaild_list = [stem], 1, []
+                ds.camera_intrinsics = np.array([[577.5, 0, 319.5], [0, 577.5, 239.5], [0, 0, 1]], dtype=np.float32)
+                ds.real_intrinsics = np.array([[591.0125, 0, 322.525], [0, 590.16775, 244.11084], [0, 0, 1]], dtype=np.float32)
+                ds.cat_names = ['bottle', 'bowl', 'camera', 'can', 'laptop', 'mug']
+                ds.id2cat_name = {'1': 'bottle', '2': 'bowl', '3': 'camera', '4': 'can', '5': 'laptop', '6': 'mug'}
+                ds.models = {"m0": np.random.RandomState(1).rand(64, 3).astype(np.float32) - 0.5}
+                ds.mug_sym = {}
+                ds.base_aug = ld.PC_BasicAugment()
+                ds.operator_name = ['Jitter', 'RandomCutout', 'RandomCrop', 'RandomDropout']
+                ds.custom_aug_operator = [ld.PcJitter(std=0.005, clip=0.05, p=0.6), ld.PcRandomCutout(p=0.9, min_num_points=1024),
+                                          ld.PcRandomCrop(p=0.9, min_num_points=1024), ld.PcRandomDropout(p=0.9, max_dropout_ratio=0.5)]
+                F.DZI_TYPE = dzi
+                states = []
+                real_sample = ds._sample_points
+
+                def sample_spy(pcl, n_pts, _s=states, _r=real_sample):
+                    if not _s:
+                        _s.append(np.random.get_state())
+                    return _r(pcl, n_pts)
+                ds._sample_points = sample_spy
+                del windows[:]
+                np.random.seed(npseed)
+                torch.manual_seed(npseed)
+                import random as _random
+                _random.seed(npseed)
+                data = ds[0]
+                assert len(windows) == 1 and len(states) == 1
+                st = states[0]
+                arrays["pcl_in.%d" % n] = data["pcl_in"].numpy()
+                arrays["window.%d" % n] = np.array([windows[0][0][0], windows[0][0][1], windows[0][1]], dtype=np.float64)
+                arrays["rng_keys.%d" % n] = np.asarray(st[1], dtype=np.uint32)
+                arrays["rng_pos.%d" % n] = np.array([st[2], st[3]], dtype=np.int64)
+                arrays["rng_gauss.%d" % n] = np.float64(st[4])
+                arrays["cat_id.%d" % n] = data["cat_id"].numpy()
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, "train_loader.npz"), **arrays)
+    print("wrote train_loader.npz %.1f KB" % (os.path.getsize(os.path.join(HERE, "train_loader.npz")) / 1024.0))
+
+
 def main():
+    if sys.argv[1:] == ["train_loader"]:
+        return gen_train_loader()
     if sys.argv[1:] == ["input_side"]:
         return gen_input_side()
     if sys.argv[1:] == ["train_step"]:
@@ -707,6 +831,7 @@ def main():
     gen_backward("backward_b3_n256.npz", 3, 256, wseed=3, pseed=6, fseed=33)
     gen_chamfer()
     gen_input_side()        # last: it installs a cv2 stand-in
+    gen_train_loader()
 
 
 if __name__ == "__main__":

@@ -2791,3 +2791,42 @@ def test_captured_step_refuses_memset_nodes(ops):
     net.eval()
     gf = engine.GraphedForward(net.packed(torch.device(DEV)), B, N, torch.device(DEV))
     assert gf.nodes[2] == 0 and gf.nodes[0] > 50
+
+
+def test_train_loader_vs_reference_getitem(ops):
+    """SURVEY section 8 row f-4, the training loader's device half (tgpose_amd.datasets.load_data.train_clouds: tgp_roi_cloud_ex with
+    source tables / ground-truth mask value / the 0.15 cut + tgp_cloud_select_ex): pcl_in bit for bit the reference's own training
+    PoseDataset.__getitem__ (datasets/load_data.py:170-351, tests/golden/train_loader.npz) -- four items whose window aug_bbox_DZI
+    drew, two un-augmented, the two _sample_points permutations replayed from NumPy's recorded generator state -- and the
+    (2048, 3) intermediate cloud bit for bit the oracle's.  Then a batch of all items in one launch against the oracle drawing
+    from one generator, an item whose mask is empty, and the refusals."""
+    from oracle import input_ref as ir
+    from tests.test_oracle_golden import train_loader_items
+    from tgpose_amd.datasets.load_data import train_clouds
+    import copy
+    cases = train_loader_items()
+    for item, rng, ref, dzi in cases:
+        rng2 = copy.deepcopy(rng)
+        full = dict(item)
+        if not dzi:
+            item = {k: v for k, v in item.items() if k not in ("bbox_center", "scale")}      # the window rule runs on the host
+        (pc2k, pcl), = train_clouds([item], rng=rng, device=DEV)
+        assert np.array_equal(pcl.cpu().numpy().view(np.int32), ref.view(np.int32))
+        want2k, want1k = ir.train_item_clouds(full["depth"], full["mask"], full["inst_id"], full["bbox_center"], full["scale"],
+                                               full["camK"], rng=rng2)
+        assert np.array_equal(pc2k.cpu().numpy().view(np.int32), want2k.view(np.int32))
+        assert np.array_equal(want1k.view(np.int32), ref.view(np.int32))
+    # one launch for the whole batch, one generator for all draws; plus an item whose instance is absent from its mask
+    items = [c[0] for c in cases]
+    ghost = dict(items[0], inst_id=9)
+    got = train_clouds(items[:3] + [ghost] + items[3:], rng=np.random.RandomState(4), device=DEV)
+    assert got[3] is None
+    rng = np.random.RandomState(4)
+    for it, g_ in zip(items, got[:3] + got[4:]):
+        w2k, w1k = ir.train_item_clouds(it["depth"], it["mask"], it["inst_id"], it["bbox_center"], it["scale"], it["camK"], rng=rng)
+        assert np.array_equal(g_[0].cpu().numpy().view(np.int32), w2k.view(np.int32))
+        assert np.array_equal(g_[1].cpu().numpy().view(np.int32), w1k.view(np.int32))
+    with pytest.raises(ValueError):
+        train_clouds([dict(items[0], inst_id=0)], device=DEV)
+    with pytest.raises(ValueError):
+        train_clouds([dict(items[0], mask=items[0]["mask"].astype(np.int32))], device=DEV)

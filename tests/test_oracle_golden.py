@@ -346,6 +346,59 @@ def test_input_side_host_window_rule_matches_oracle():
         assert tuple(int(v) for v in ir.get_bbox(b)) == get_bbox(b)
 
 
+def train_loader_items():
+    """-> list of (item dict for tgpose_amd.datasets.load_data.train_clouds, RandomState at the first _sample_points call, reference
+    pcl_in) from tests/golden/train_loader.npz (the reference's training __getitem__ on synthetic frames)"""
+    from tests.util import synth_depth_scene
+    gd = golden("train_loader.npz")
+    out = []
+    for n in range(int(gd["n_items"])):
+        fr = synth_depth_scene(int(gd["item_scene"][n]), int(gd["scene_dets"]))
+        mask = np.zeros(fr["depth"].shape, np.uint8)
+        for q in range(int(gd["scene_dets"])):
+            mask[fr["pred_masks"][:, :, q]] = q + 1
+        j = int(gd["item_det"][n])
+        w = gd["window.%d" % n]
+        rng = np.random.RandomState()
+        pos = gd["rng_pos.%d" % n]
+        rng.set_state(("MT19937", gd["rng_keys.%d" % n], int(pos[0]), int(pos[1]), float(gd["rng_gauss.%d" % n])))
+        item = dict(depth=fr["depth"], mask=mask, inst_id=j + 1, camK=_K_REAL, bbox=fr["pred_bboxes"][j], bbox_center=w[:2].copy(),
+                    scale=float(w[2]))
+        out.append((item, rng, gd["pcl_in.%d" % n], bool(gd["item_dzi"][n])))
+    return out
+
+
+def test_train_loader_oracle_vs_reference_getitem():
+    """oracle/input_ref.py's training-loader restatement against pcl_in of the reference's own training PoseDataset.__getitem__
+    (datasets/load_data.py:170-351; tests/golden/train_loader.npz), bit for bit: windows as aug_bbox_DZI drew them (four items) or
+    un-augmented (two), the two _sample_points permutations replayed from NumPy's recorded generator state.  As for the evaluation
+    loader the fixture's cv2 is the oracle's restatement: those two OpenCV calls are parity-unpinned."""
+    from oracle import input_ref as ir
+    for item, rng, ref, dzi in train_loader_items():
+        if not dzi:      # the un-augmented window is get_bbox's (tools/dataset_utils.py:57-61)
+            c, s = ir.dzi_window_off(item["bbox"], *item["depth"].shape)
+            assert np.array_equal(c, item["bbox_center"]) and s == item["scale"]
+        PC, pcl = ir.train_item_clouds(item["depth"], item["mask"], item["inst_id"], item["bbox_center"], item["scale"], item["camK"], rng=rng)
+        assert PC.shape == (2048, 3) and pcl.shape == ref.shape == (1024, 3)
+        assert np.array_equal(pcl.view(np.int32), ref.view(np.int32))
+
+
+def test_train_loader_host_tables_match_opencv_restatement():
+    """tgpose_amd.datasets.load_data.source_tables (host code of the product: OpenCV's fixed-point walk for an augmented window)
+    equals the oracle's general getAffineTransform + warpAffine restatement, on the fixture's windows and on random ones."""
+    from oracle import input_ref as ir
+    from tgpose_amd.datasets.load_data import source_tables, window_without_dzi
+    rng = np.random.RandomState(3)
+    wins = [(it["bbox_center"], it["scale"]) for it, _, _, _ in train_loader_items()]
+    wins += [(np.array([rng.uniform(0, 640), rng.uniform(0, 480)]), rng.uniform(20, 640)) for _ in range(200)]
+    wins += [window_without_dzi(b, 480, 640) for b in ((0, 0, 480, 640), (100, 100, 117, 122), (3, 7, 4, 8))]
+    for c, s in wins:
+        for size in (256, 128):
+            sx, sy = ir.nearest_source_map(ir.roi_affine(np.asarray(c), s, size), (size, size))
+            t = source_tables(c, s, size)
+            assert (sx == t[0][None, :]).all() and (sy == t[1][:, None]).all(), (c, s, size)
+
+
 # ----------------------------------------------------------------------------- the trainer's step (BASELINE config 4, one rank)
 def golden_train_step_case():
     """-> (fixture, db dict, samples [(net1), (net2)], graphs of both nets) from the reference's own RL_TDA_train_step run"""

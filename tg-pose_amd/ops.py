@@ -995,30 +995,46 @@ class RoiRecords:
     """What tgp_roi_cloud leaves in HBM: ``recs`` (D, roi^2) int32-viewed records (ROI pixel index << 16 | depth), ``counts``
     (D,3) int32, and the descriptor tensors a record needs to become a point (``det_img``, ``window``, ``camk``)."""
 
-    def __init__(self, recs, counts, det_img, window, camk, roi_size):
+    def __init__(self, recs, counts, det_img, window, camk, roi_size, tables=None):
         self.recs, self.counts, self.det_img, self.window, self.camk, self.roi_size = recs, counts, det_img, window, camk, roi_size
+        self.tables = tables
 
 
-def roi_cloud(depth, masks, mask_off, mask_stride, det_img, window, camk, roi_size=256):
-    """tgp_roi_cloud.  depth (I,H,W) int16-viewed uint16, masks flat uint8, mask_off (D,) int64, mask_stride / det_img (D,) int32,
-    window (D,3) int32, camk (I,4) float32 -- all on the GPU.  -> RoiRecords"""
+def roi_cloud(depth, masks, mask_off, mask_stride, det_img, window, camk, roi_size=256, tables=None, mask_val=None, cut_frac=0.25):
+    """tgp_roi_cloud / tgp_roi_cloud_ex.  depth (I,H,W) int16-viewed uint16, masks flat uint8, mask_off (D,) int64, mask_stride /
+    det_img (D,) int32, window (D,3) int32 (None with tables), camk (I,4) float32 -- all on the GPU.  tables (D,2,roi_size) int32:
+    host-evaluated source pixels (the training loader's augmented windows); mask_val (D,) int32: mask byte to match (ground-truth
+    instance masks); cut_frac: the outlier cut's share of the diagonal (0.25 evaluation, 0.15 training).  -> RoiRecords"""
     if not (depth.is_cuda and depth.dtype in (torch.int16, torch.uint16) and depth.dim() == 3 and depth.is_contiguous()):
         raise TypeError("depth must be a contiguous (I,H,W) 16-bit GPU tensor")
     if not (masks.is_cuda and masks.dtype in (torch.uint8, torch.bool) and masks.is_contiguous()):
         raise TypeError("masks must be a contiguous uint8 / bool GPU tensor")
     if not (mask_off.is_cuda and mask_off.dtype == torch.int64 and mask_off.is_contiguous()):
         raise TypeError("mask_off must be a contiguous int64 GPU tensor")
-    _i32(mask_stride, "mask_stride"), _i32(det_img, "det_img"), _i32(window, "window")
+    _i32(mask_stride, "mask_stride"), _i32(det_img, "det_img")
     _f32(camk, "camk", 2)
     I, H, W = depth.shape
     D = det_img.numel()
-    if window.shape != (D, 3) or mask_off.numel() != D or mask_stride.numel() != D or camk.shape != (I, 4) or not camk.is_contiguous():
+    if window is None and tables is None:
+        raise ValueError("roi_cloud: a window or source tables are needed")
+    if window is not None and _i32(window, "window").shape != (D, 3):
+        raise ValueError("roi_cloud: window must be (D,3)")
+    if tables is not None and _i32(tables, "tables").shape != (D, 2, roi_size):
+        raise ValueError("roi_cloud: tables must be (D,2,roi_size)")
+    if mask_val is not None and _i32(mask_val, "mask_val").numel() != D:
+        raise ValueError("roi_cloud: mask_val must be (D,)")
+    if mask_off.numel() != D or mask_stride.numel() != D or camk.shape != (I, 4) or not camk.is_contiguous():
         raise ValueError("roi_cloud: inconsistent shapes")
     recs = torch.empty(D, roi_size * roi_size, device=depth.device, dtype=torch.int32)
     counts = torch.empty(D, 3, device=depth.device, dtype=torch.int32)
-    check(_lib.lib().tgp_roi_cloud(_p(depth), _p(masks), _p(mask_off), _p(mask_stride), _p(det_img), _p(window), _p(camk), D, H, W,
-                                   roi_size, _p(recs), _p(counts), _stream(depth)), "tgp_roi_cloud")
-    return RoiRecords(recs, counts, det_img, window, camk, roi_size)
+    if tables is None and mask_val is None and cut_frac == 0.25:
+        check(_lib.lib().tgp_roi_cloud(_p(depth), _p(masks), _p(mask_off), _p(mask_stride), _p(det_img), _p(window), _p(camk), D, H, W,
+                                       roi_size, _p(recs), _p(counts), _stream(depth)), "tgp_roi_cloud")
+    else:
+        check(_lib.lib().tgp_roi_cloud_ex(_p(depth), _p(masks), _p(mask_off), _p(mask_stride), _p(det_img), _p(window), _p(camk), D, H, W,
+                                          roi_size, _p(recs), _p(counts), _p(tables), _p(mask_val), float(cut_frac), _stream(depth)),
+              "tgp_roi_cloud_ex")
+    return RoiRecords(recs, counts, det_img, window, camk, roi_size, tables)
 
 
 def cloud_select(rr, sel):
@@ -1028,8 +1044,12 @@ def cloud_select(rr, sel):
     if sel.dim() != 2 or sel.shape[0] != D:
         raise ValueError("cloud_select: sel must be (D,n_pts)")
     out = torch.empty(D, sel.shape[1], 3, device=rr.recs.device, dtype=torch.float32)
-    check(_lib.lib().tgp_cloud_select(_p(rr.recs), _p(sel), _p(rr.det_img), _p(rr.window), _p(rr.camk), D, rr.roi_size, sel.shape[1],
-                                      _p(out), _stream(rr.recs)), "tgp_cloud_select")
+    if getattr(rr, "tables", None) is None:
+        check(_lib.lib().tgp_cloud_select(_p(rr.recs), _p(sel), _p(rr.det_img), _p(rr.window), _p(rr.camk), D, rr.roi_size, sel.shape[1],
+                                          _p(out), _stream(rr.recs)), "tgp_cloud_select")
+    else:
+        check(_lib.lib().tgp_cloud_select_ex(_p(rr.recs), _p(sel), _p(rr.det_img), _p(rr.window), _p(rr.camk), D, rr.roi_size,
+                                             sel.shape[1], _p(out), _p(rr.tables), _stream(rr.recs)), "tgp_cloud_select_ex")
     return out
 
 
@@ -1037,6 +1057,8 @@ def cloud_sample(rr, n_pts, seed, counts=None):
     """Device-drawn resampling (tgp_cloud_sample) -> (D,n_pts,3); ``counts`` overrides rr.counts (tests)."""
     counts = rr.counts if counts is None else _i32(counts, "counts")
     D = rr.recs.shape[0]
+    if getattr(rr, "tables", None) is not None:
+        raise ValueError("cloud_sample: records built from source tables are resampled with cloud_select (tgp_cloud_select_ex)")
     if counts.shape != (D, 3):
         raise ValueError("cloud_sample: counts must be (D,3)")
     out = torch.empty(D, n_pts, 3, device=rr.recs.device, dtype=torch.float32)
