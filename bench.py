@@ -8,9 +8,9 @@
 One "step" = one full forward of the hot path (kNN graphs, 3D-GCN encoder, PH predictor, decoder,
 three heads, pose post-processing) over one batch of B synthetic clouds already resident in HBM
 (BASELINE.json configs[1] extended to the whole forward, which is what `metric` is quoted on).
-The forward is replayed as a captured hipGraph; by default two batches are in flight (`--streams 2`:
-one captured forward per HIP stream, step i on stream i % 2 over its own batch), `--streams 1` keeps
-one.  Objects are independent in eval mode, so N GPUs run N replicas on their own batches with no
+The forward is replayed as a captured hipGraph; by default four batches are in flight (`--streams 4`:
+one captured forward per HIP stream, step i on stream i % 4 over its own batch; with three or more in
+flight the captured forwards are branch-free -- see `--branch-streams`), `--streams 1` keeps one.  Objects are independent in eval mode, so N GPUs run N replicas on their own batches with no
 data-path collective (weak scaling); the only RCCL traffic is the barrier / max-time reduction
 around the timed region.  Rank 0 prints ONE JSON line.
 
@@ -188,24 +188,38 @@ def _latest_profile(pattern, skip=("input_side",)):
     return files[-1] if files else None
 
 
-def _tile_kernel_traffic(gemm_mode):
-    """(bytes per launch, source file) of the dominant tile kernels from the latest COMMITTED PMC passes (FETCH_SIZE / WRITE_SIZE
-    collected in separate rocprofv3 --pmc runs and corrected as MI355X_MICROARCH.md prescribes; scripts/pmc_traffic.py) -- not a
-    measurement of this run, and labelled so in the line."""
+# Algorithmic bytes per launch (B = 32, N = 1028) of the kernels that serve ONE shape per forward: unique inputs read once + outputs
+# written once (SURVEY.md 8d's rule), fp32 unless noted.  Kernels that serve several shapes (the tile GEMMs) carry no single figure.
+ALGO_BYTES_B32 = {
+    # fine (32896 x 272) + the heads' columns of both coarse products (8224 + 2048 rows x 3072) + fp16 weight planes
+    # (3 x 1024 x 272 + 3 x 256 x 1024, two planes) + keys: 35.8 + 101.1 + 25.2 + 6.5 MB
+    "heads_fused_kernel": 35.8e6 + 101.1e6 + 25.2e6 + 6.5e6,
+    # fine + conv_5's 1024 columns of the coarse products + weights: 35.8 + 33.7 + 8.4 + 1.1 MB
+    "conv_max_fused_kernel": 35.8e6 + 33.7e6 + 8.4e6 + 1.1e6,
+    "void gconv_kernel<128, false>": 4.83e6 * 32,       # conv_1's graph convolution, SURVEY 8d: 4.83 MB per object
+    "void gconv_kernel<128, true>": 0.62e6 * 32,        # conv_0
+    "void knn_feat_fused_kernel<128, 17, 8>": 0.61e6 * 32,
+    "void knn_xyz_kernel<17>": 0.10e6 * 32,
+}
+
+
+def _kernel_traffic():
+    """Per-kernel HBM-side traffic from the latest COMMITTED PMC passes (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs,
+    corrected as MI355X_MICROARCH.md prescribes: bytes = (2 FETCH + WRITE) KB; scripts/pmc_traffic.py) -- not a measurement of this
+    run, and labelled so in the line.  -> ([{kernel, launches, bytes_per_launch, algorithmic_bytes_per_launch, ratio}], source)"""
     try:
         path = _latest_profile("r*_pmc_traffic.json")
         pmc = json.load(open(path))["kernels"]
-        if gemm_mode == "fp32":
-            keys = [k for k in pmc if "gemm_main256_kernel" in k]
-        else:
-            f16 = lambda k: ", true" in k.split("<", 1)[-1]
-            keys = [k for k in pmc if "gemm_split" in k and "_kernel" in k and f16(k) == (gemm_mode == "split16")]
-            if gemm_mode == "split16":
-                keys += [k for k in pmc if "heads_fused_kernel" in k or "conv_max_fused_kernel" in k]
-        n_l = sum(pmc[k]["launches"] for k in keys)
-        if not n_l:
-            return None, None
-        return int(sum(pmc[k]["launches"] * pmc[k]["bytes_per_launch_corrected"] for k in keys) / n_l), os.path.relpath(path, ROOT)
+        rows = []
+        for k, v in pmc.items():
+            if "at::native" in k or "rocclr" in k or v["bytes_per_launch_corrected"] < 2e6:
+                continue
+            algo = ALGO_BYTES_B32.get(k)
+            rows.append({"kernel": k, "launches": v["launches"], "bytes_per_launch": v["bytes_per_launch_corrected"],
+                         "algorithmic_bytes_per_launch": int(algo) if algo else None,
+                         "ratio": round(v["bytes_per_launch_corrected"] / algo, 2) if algo else None})
+        rows.sort(key=lambda r: -r["bytes_per_launch"] * r["launches"])
+        return rows, os.path.relpath(path, ROOT)
     except Exception:
         return None, None
 
@@ -230,10 +244,15 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=1.0,
                     help="the timed region (exactly --steps steps between fences) is repeated until this much time has been measured; "
                          "the line reports the median region and the spread")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=4,
                     help="batches in flight per GPU: step i runs on HIP stream i %% S over its own batch (independent batches "
                          "overlap each other's tail rounds and small kernels); 1 = one forward at a time")
-    ap.add_argument("--no-branch-streams", action="store_true", help="run the decoder branch in line instead of on a side stream")
+    ap.add_argument("--branch-streams", choices=("auto", "on", "off"), default="auto",
+                    help="side branches inside a forward (feature-space kNN beside the projection GEMM, PH tail + decoder beside the "
+                         "heads).  hipGraph runs a graph's extra branches on ONE pool of internal streams per device, shared by every "
+                         "graph in flight, so the branches of concurrent replays queue behind each other: with three or more batches "
+                         "in flight branch-free (linear) graphs are faster (profiles/r03_streams_ab.txt).  auto: on up to 2 in flight")
+    ap.add_argument("--no-branch-streams", action="store_true", help="same as --branch-streams off")
     ap.add_argument("--gemm", choices=("split16", "split", "fp32"), default="split16",
                     help="split16: fp32-accurate GEMM on the fp16 matrix cores (2-term operand split, 3 MFMA terms); "
                          "split: the same on the bf16 matrix cores (3-term split, 6 MFMA terms, full fp32 range); "
@@ -284,7 +303,10 @@ def main():
     from tgpose_amd import engine as _engine
     sd = seeded_state_dict(0)
     ops.GEMM_MODE = args.gemm
-    _engine.BRANCH_STREAMS = not args.no_branch_streams
+    if args.no_branch_streams:
+        args.branch_streams = "off"
+    _engine.BRANCH_STREAMS = args.branch_streams == "on" or (args.branch_streams == "auto" and (args.streams <= 2 or args.workload != "forward"
+                                                                                                  or args.graph != 1))
     B = args.batch
     torch.manual_seed(rank)
     step_no = [0]
@@ -415,17 +437,26 @@ def main():
         roof_note = ("HIP events around every tile-kernel launch of %d serial eager steps (one stream, no side branches) run after the "
                      "timed region%s" % (k_roof, "" if replayers is None else " (%d graph replays in flight there)" % len(streams)))
         if replayers is not None:
-            # for reference: the same replayed forward with ONE batch in flight (what a latency-bound caller sees)
+            # for reference: the same replayed forward with ONE batch in flight (what a latency-bound caller sees) -- captured with
+            # its side branches, which is the faster form when nothing else is in flight
+            solo = replayers[0]
+            if not branch:
+                _engine.BRANCH_STREAMS = True
+                solo = _engine.GraphedForward(net.packed(dev), B, N_POINTS, dev, train_keys=False)
+                _engine.BRANCH_STREAMS = branch
+            with torch.cuda.stream(streams[0]):
+                for _ in range(3):
+                    solo(*batches[0])
             fence()
             t2 = time.perf_counter()
             with torch.cuda.stream(streams[0]):
                 for _ in range(args.steps):
-                    replayers[0](*batches[0])
+                    solo(*batches[0])
             fence()
             one_in_flight = world * B * args.steps / (time.perf_counter() - t2)
 
     if rank == 0:
-        traffic, traffic_src = _tile_kernel_traffic(args.gemm)
+        traffic, traffic_src = _kernel_traffic()
         launches = len(timer)
         ksec = sum(e0.elapsed_time(e1) for e0, e1, *_ in timer) * 1e-3
         kflop = sum(f for _, _, f, *_ in timer)
@@ -472,12 +503,15 @@ def main():
                              "clip_grad_norm_(5), SGD step; B=%d objects per GPU, N=%d points sampled "
                              "from the six obj_model category clouds with their pdh1/pdh2 priors" % (B, N_POINTS)),
                        "objects_per_gpu": B, "points": N_POINTS, "replicas": world, "batches_in_flight": len(streams),
+                       "side_branches_in_a_forward": bool(_engine.BRANCH_STREAMS),
                        "hipgraph": {0: "off", 1: "whole batch" if replayers is None else "whole batch, one captured forward per stream",
                                     2: "two half batches on forked streams"}[args.graph]},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "traffic_source": (traffic_src + " (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same "
-                                                          "launches; not measured by this run)") if traffic_src else None,
+                         "traffic_source": (traffic_src + " (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over serial eager "
+                                                          "forwards of this workload, per kernel and launch, bytes = (2 FETCH + WRITE) KB; "
+                                                          "algorithmic bytes where a kernel serves one shape; not measured by this run)")
+                         if traffic_src else None,
                          "kernel": kernel_name, "peak_basis": peak_basis,
                          "launches_timed": launches, "avg_launch_us": round(1e6 * ksec / max(launches, 1), 2),
                          "share_of_step": round(ksec / roof_elapsed, 4), "measured": roof_note},

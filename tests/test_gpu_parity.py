@@ -376,6 +376,31 @@ def test_gemm_split16_range_guard(ops, M, N, K, a_mag, w_mag):
     assert torch.equal(static, out)
 
 
+@pytest.mark.parametrize("M,N,K", [(8300, 1024, 512), (33000, 512, 272), (1024, 512, 512), (32896, 128, 128)])
+@pytest.mark.parametrize("a_mag,mixed", [(1e-6, False), (1e-3, False), (1e-2, False), (3e-2, False), (1e-6, True), (3e-8, False)])
+def test_gemm_split16_small_magnitude_guard(ops, M, N, K, a_mag, mixed):
+    """The small side of fp16's range (round-2 verdict): activations of 1e-6 split into a subnormal hi plane and a vanished lo
+    plane, percent-level relative error per product; at 1e-3 the lo plane is a few subnormal bits (3e-5 of the output scale,
+    measured).  A tile whose largest |a| is below 2^-4 recomputes in exact fp32 on the device, like an overflowing one: the result
+    is within 3e-6 of the OUTPUT's scale of an fp64 product (it is ~1e-7).  `mixed`:
+    the lower half of the rows is ordinary, so only the tiny rows' tiles take the exact path and the others keep the split;
+    every row is then held to 3e-6 of ITS OWN output scale.  Tile shapes: 256 x 256, 256 x 128 and the 64 x 128 small tile."""
+    gen = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=gen) * a_mag
+    if mixed:
+        A[M // 2 // 256 * 256:] = torch.randn(M - M // 2 // 256 * 256, K, generator=gen)
+    W = torch.randn(N, K, generator=gen) / K ** 0.5
+    b = torch.zeros(N)
+    ref = A.double() @ W.double().t()
+    dW = g(W)
+    out = ops.linear_rows(g(A), dW, bias=g(b), w_split=ops.split_f16(dW))
+    err = (out.cpu().double() - ref).abs()
+    assert torch.isfinite(out).all()
+    row_scale = ref.abs().max(dim=1, keepdim=True)[0]
+    worst = (err / row_scale).max().item()
+    assert worst <= 3e-6, (worst, a_mag)
+
+
 def test_forward_with_unnormalised_conv4_magnitudes(ops):
     """The whole eval forward with conv_4 (the layer without BatchNorm) scaled so that fm_4 reaches ~1e6: every output finite and
     within 1e-4 RELATIVE of the fp32 CPU oracle on the oracle's graphs (default fp16-split mode; before the range guard: NaN)."""
@@ -1781,6 +1806,32 @@ def test_fused_kernels_vs_fp64(ops, B, N):
     for hd in range(heads):
         y = torch.relu((H[:, hd] @ W2[hd].double().t() + b2[hd].double()) * sc2[hd].double() + sh2[hd].double()).view(B, N, 256).max(1)[0]
         assert (got2[hd] - y).abs().max().item() <= 6e-6 * y.abs().max().item(), hd
+
+
+def test_fused_kernels_flag_tiny_inputs(ops):
+    """Small side of the fused kernels' fp16 range guard: a wave whose input features all lie below 2^-4 raises the device flag
+    (and writes no keys), so the caller's predicated tile-kernel launches -- which guard themselves -- supply every key;
+    ordinary features leave the flag at 0 (test_fused_kernels_vs_fp64)."""
+    gen = torch.Generator().manual_seed(5)
+    B, N, K, heads = 2, 160, 268, 3
+    M = B * N
+    fine = torch.randn(M, 272, generator=gen) * 1e-6
+    fine[:, K:] = 0
+    Wa = torch.randn((heads + 1) * 1024, 272, generator=gen) / K ** 0.5
+    n1, n2 = M // 4, M // 16
+    P1, P2 = torch.randn(n1, 4096, generator=gen), torch.randn(n2, 4096, generator=gen)
+    idx1 = torch.randint(0, n1, (M,), generator=gen, dtype=torch.int32)
+    idx2 = torch.randint(0, n2, (M,), generator=gen, dtype=torch.int32)
+    z, o = torch.zeros(4096), torch.ones(4096)
+    W2 = torch.randn(heads, 256, 1024, generator=gen) / 32.0
+    d = lambda t: g(t.contiguous())
+    was = ops.split_f16(d(Wa))
+    keys2, over = ops.heads_fused(d(fine), K, was[1024:], d(P1)[:, 1024:], d(idx1), d(P2)[:, 1024:], d(idx2), d(z)[1024:], d(o)[1024:],
+                                  d(z)[1024:], ops.heads_pack_w2(d(W2)), d(z)[:768].view(3, 256), d(o)[:768].view(3, 256),
+                                  d(z)[:768].view(3, 256), B, N)
+    keys5, over5 = ops.conv_max_fused(d(fine), K, was, d(P1), d(idx1), d(P2), d(idx2), d(z)[:1024], d(o)[:1024], d(z)[:1024], 0.2, B, N)
+    assert int(over.item()) == 1 and int(over5.item()) == 1
+    assert int(keys2.abs().max().item()) == 0 and int(keys5.abs().max().item()) == 0        # flagged waves wrote nothing
 
 
 def test_factored_and_fused_decoder_and_ph_branch_equal_concat_path(ops):

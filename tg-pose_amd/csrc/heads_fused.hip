@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
             bh[s] = make_uint4(h0.x, h0.y, h1.x, h1.y), bl[s] = make_uint4(l0.x, l0.y, l1.x, l1.y);
         }
     }
+    const float amax_in = amax;                                 // the largest magnitude among this lane's input features
     const int i1 = p.idx1[row], i2 = p.idx2[row];
     const float *g1p = p.p1 + (int64_t)i1 * p.ldp1 + hd * HF_C1 + 4 * h;       // + cb * 32 + 8 m: four channels of the lane
     const float *g2p = p.p2 + (int64_t)i2 * p.ldp2 + hd * HF_C1 + 4 * h;
@@ -249,7 +250,10 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
     if (m0 >= p.M) return;
     // fp16 range guard: a lane that split a magnitude >= 65504 (or met a NaN) spoils its wave's sums.  With a flag to raise, the wave
     // writes no keys and the caller's predicated two-launch form (guarded arithmetic) supplies them; without one, NaN keys are loud.
-    if (p.overflow && __ballot(!(amax < 65504.f) || poison != poison) != 0ull) {
+    // (round 3) and the small side: a wave whose input features are ALL below 2^-4 (and not all zero) would lose relative precision
+    // in every product of conv1 (fp16 reproduces an operand to an absolute 3e-8 at best: gemm.hip, small side of the range guard): same treatment.
+    const bool tiny_in = __ballot(amax_in >= 0.0625f) == 0ull && __ballot(amax_in > 0.f) != 0ull;
+    if (p.overflow && (tiny_in || __ballot(!(amax < 65504.f) || poison != poison) != 0ull)) {
         if (lane == 0) atomicOr(p.overflow, 1);
         return;
     }
@@ -354,7 +358,8 @@ __global__ __launch_bounds__(256, 2) void conv_max_fused_kernel(ConvMaxParams p)
         s_off[wave][lvl][hh][e] = lvl ? p.idx2[pr] * p.ldp2 : p.idx1[pr] * p.ldp1;
     }
     const bool live = m0 < p.M;
-    const bool bad = __ballot(!(amax < 65504.f) || poison != poison) != 0ull;      // fp16 range guard, as in the heads kernel
+    const bool bad = __ballot(!(amax < 65504.f) || poison != poison) != 0ull ||      // fp16 range guard, as in the heads kernel
+                     (__ballot(amax >= 0.0625f) == 0ull && __ballot(amax > 0.f) != 0ull);   // ... and its small side (all inputs < 2^-4)
     if (live && bad && p.overflow && lane == 0) atomicOr(p.overflow, 1);
     const int obj0 = m0 / p.rows_per_obj, bound = (obj0 + 1) * p.rows_per_obj;
 
