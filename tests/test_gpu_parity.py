@@ -209,7 +209,10 @@ def test_gconv_surface_vs_oracle(ops, B, n, k):
     assert torch.allclose(got.cpu(), want, atol=2e-6, rtol=1e-5)
 
 
-@pytest.mark.parametrize("B,n,k,C", [(2, 300, 20, 128), (2, 257, 20, 256), (2, 64, 8, 512), (1, 130, 7, 128)])
+@pytest.mark.parametrize("B,n,k,C", [(2, 300, 20, 128), (2, 257, 20, 256), (2, 64, 8, 512), (1, 130, 7, 128),
+                                     # the four-channel LDS slice (gconv_lds4_kernel): the benchmark's conv_1, a neighbour count that is
+                                     # not a multiple of four, the largest cloud it serves, one beyond it (L2-gather kernel)
+                                     (2, 1028, 20, 128), (1, 400, 7, 128), (1, 1371, 20, 128), (1, 1400, 6, 128), (1, 512, 20, 256)])
 def test_gconv_hs_vs_oracle(ops, B, n, k, C):
     _, G, _ = _oracle()
     import torch.nn.functional as F

@@ -279,7 +279,14 @@ static int gconv_lds_launch(const float *xyz, const int32_t *idx, const float *p
     if (!tgp_gconv_lds_mode || !dirs_ws) return 0;          // without the directions' scratch: the L2-gather kernel
     auto bytes = [&](int ch) { return (size_t)n * GC_S * ch * sizeof(float); };
     const int ch = (bytes(16) <= 72 * 1024 && C % 16 == 0) ? 16 : (bytes(8) <= 72 * 1024 && C % 8 == 0) ? 8
-                   // a 4-channel slice (n = 1028: 115 KB, one workgroup per CU) measured slower than the L2 gather: 208 vs 168 us
+                   // a 4-channel slice (n = 1028: 115 KB, one workgroup per CU) measured slower than the L2 gather: 208 vs 168 us.
+                   // Round 3 rebuilt that slice with a thread slot per (point, quarter of the neighbours, all four channels) --
+                   // float4 LDS reads, one index / direction load per 112 bytes of LDS, quad shuffles for the maxima, 512 threads
+                   // at 152 VGPRs -- bit-identical and slower still: 216-224 us at (32, 1028, 128) against 152-155 for the L2
+                   // gather in the same harness (random graphs; 132 in the forward), and 123 vs 74 us at (32, 257, 256) against
+                   // the 8-channel form.  A four-channel row is 112 bytes: 64 lanes gathering 16 bytes each from random rows
+                   // collide in the LDS banks ~3 deep, and one workgroup of 8 waves per CU does not hide the index -> row ->
+                   // value chains.  Removed again (profiles/r03_gconv_lds4_ab.txt).
                    : (tgp_gconv_lds_mode == 2 && bytes(4) <= 150 * 1024) ? 4 : 0;
     if (!ch) return 0;
     done = true;
