@@ -352,6 +352,22 @@ def gen_dcd():
          dcd=dcd, cd_p=cd_p, cd_t=cd_t, r_dcd=r_dcd, new_y=ny, new_x=nx, p_R=pR, dcd_grad=rr.grad)
 
 
+def gen_recon_completion():
+    """recon_completion (losses/TDA_loss_sym_recon.py:453-490) and TDA_loss.recon_completion_loss (:344-348): value and gradient
+    w.r.t. both clouds, on the dcd fixture's clouds (the reference's chamfer_python stands in for the CUDA extension)."""
+    ref_loss = load_reference_loss()
+    gd = np.load(os.path.join(HERE, "dcd.npz"))
+    recon, prior = torch.from_numpy(gd["recon"]), torch.from_numpy(gd["prior"])
+    a, b = recon.clone().requires_grad_(True), prior.clone().requires_grad_(True)
+    val = ref_loss.recon_completion(a, b, alpha=70, n_lambda=0.3)
+    val.backward()
+    loss_mod = ref_loss.TDA_loss()
+    with torch.no_grad():
+        via_module = loss_mod.recon_completion_loss(recon, prior)
+        plain = ref_loss.recon_completion(recon[:, :700], prior, alpha=0.1, n_lambda=0.3, non_reg=True)
+    save("recon_completion.npz", value=val.detach(), grad_a=a.grad, grad_b=b.grad, via_module=via_module, non_reg_700=plain)
+
+
 def gen_tda_loss():
     """TDA_loss.forward with the trainer's 'TDA' name list minus R_DCD (covered by dcd.npz), and the two functions of
     losses/consistency_loss.py, on a seeded batch that holds every symmetry pattern; values and gradients w.r.t. every prediction."""
@@ -810,6 +826,8 @@ def gen_train_loader():
 def main():
     if sys.argv[1:] == ["train_loader"]:
         return gen_train_loader()
+    if sys.argv[1:] == ["recon_completion"]:
+        return gen_recon_completion()
     if sys.argv[1:] == ["input_side"]:
         return gen_input_side()
     if sys.argv[1:] == ["train_step"]:
@@ -821,6 +839,7 @@ def main():
     gen_eval_map()
     gen_pose_assembly()
     gen_dcd()
+    gen_recon_completion()
     gen_knn()
     gen_layers()
     bottle = torch.from_numpy(np.load(os.path.join(REF, "obj_model/points_bottle.npy"))).float()[None]

@@ -1013,6 +1013,28 @@ def test_dcd_and_r_dcd_vs_reference_golden(ops):
     assert torch.allclose(y.grad.cpu(), yr.grad, atol=2e-6, rtol=1e-4)
 
 
+def test_recon_completion_vs_reference_golden(ops):
+    """recon_completion / TDA_loss.recon_completion_loss (losses/TDA_loss_sym_recon.py:453-490, 344-348; round 2 raised
+    NotImplementedError) against values and gradients w.r.t. BOTH clouds produced by the imported reference
+    (tests/golden/recon_completion.npz); the non_reg branch with unequal cloud sizes; the term through TDA_loss.forward."""
+    from tgpose_amd import FLAGS
+    from tgpose_amd.losses import dcd as D
+    from tgpose_amd.losses.TDA_loss_sym_recon import TDA_loss
+    gd, gr = golden("dcd.npz"), golden("recon_completion.npz")
+    a, b = g(gd["recon"]).clone().requires_grad_(True), g(gd["prior"]).clone().requires_grad_(True)
+    val = D.recon_completion(a, b, alpha=70, n_lambda=0.3)
+    assert abs(val.item() - float(gr["value"])) < 2e-6
+    val.backward()
+    assert np.allclose(a.grad.cpu().numpy(), gr["grad_a"], atol=1e-7, rtol=1e-4)
+    assert np.allclose(b.grad.cpu().numpy(), gr["grad_b"], atol=1e-7, rtol=1e-4)
+    plain = D.recon_completion(g(gd["recon"])[:, :700].contiguous(), g(gd["prior"]), alpha=0.1, n_lambda=0.3, non_reg=True)
+    assert abs(plain.item() - float(gr["non_reg_700"])) < 2e-6
+    mod = TDA_loss()
+    assert abs(mod.recon_completion_loss(g(gd["recon"]), g(gd["prior"])).item() - float(gr["via_module"])) < 2e-6
+    out = mod(["recon_completion"], {"Recon": g(gd["prior"])}, {"Recon": g(gd["recon"])}, g(gd["sym"]))
+    assert abs(out["recon_completion"].item() - FLAGS.recon_w * float(gr["via_module"])) < 2e-6 * max(1.0, FLAGS.recon_w)
+
+
 def test_generate_rt_vs_reference_golden(ops):
     """Pose assembly against the rotations tools/rot_utils.to_R_matrices produced in the reference (sym and non-sym)."""
     from tgpose_amd.pose import generate_RT

@@ -17,7 +17,7 @@ from torch.autograd import Function
 from .. import ops
 from ..config.flags import FLAGS
 from .consistency_loss import feat_consistency, prop_sym_matching_loss as _prop_sym
-from .dcd import calc_cd, calc_dcd, R_DCD as _r_dcd, _vertical_axes, _rodrigues  # noqa: F401  (re-exports)
+from .dcd import calc_cd, calc_dcd, recon_completion, R_DCD as _r_dcd, _vertical_axes, _rodrigues  # noqa: F401  (re-exports)
 
 POSE_TERMS = ("Rot1", "Rot1_cos", "Rot2", "Rot2_cos", "Rot_regular", "Tran", "Size", "R_con")
 
@@ -108,8 +108,8 @@ class TDA_loss(nn.Module):
             loss_list["Prop_sym"] = FLAGS.prop_sym_w * self.prop_sym_matching_loss(
                 gt_list['Recon'], pred_list['Recon'], pred_list['Rot1'], pred_list['Rot2'], pred_list['Tran'], gt_list['R'],
                 gt_list['Tran'], sym)
-        if "recon_completion" in name_list and (FLAGS.recon_w > 0):
-            raise NotImplementedError("recon_completion is not part of any name list engine/organize_loss.py builds")
+        if "recon_completion" in name_list and (FLAGS.recon_w > 0):      # (:70-72; in none of organize_loss's lists)
+            loss_list["recon_completion"] = FLAGS.recon_w * self.recon_completion_loss(gt_list['Recon'], pred_list['Recon'])
         if "Tran" in name_list:
             loss_list["Tran"] = FLAGS.tran_w * t["Tran"]
         if "Size" in name_list:
@@ -182,6 +182,10 @@ class TDA_loss(nn.Module):
 
     def ph_loss_fn_cate(self, ph, gt_ph, cate_ph):
         return self.ph_loss_fn(ph, gt_ph) * self.omega(gt_ph, cate_ph, 2, 1)
+
+    def recon_completion_loss(self, pcl_in, recon):
+        """:344-348 (argument order as there: the observed cloud is the `pred_recon` argument of recon_completion)"""
+        return torch.mean(recon_completion(pcl_in, recon, alpha=70, n_lambda=0.3, return_raw=False, non_reg=False))
 
     def R_DCD(self, cate_ori, points, g_R, p_g_vec, f_g_vec, p_r_vec, f_r_vec, p_t, p_s, sym):
         return _r_dcd(cate_ori, points, g_R, p_g_vec, f_g_vec, p_r_vec, f_r_vec, p_t, p_s, sym)
