@@ -33,6 +33,8 @@ def _stale():
 def build(force=False, verbose=True, dev=False):
     """dev=True: libtgpose_hip_dev.so with -DTGP_DEV (kernel-variant switches for scripts/*_ab.py; never loaded by the
     package itself -- a script points tgpose_amd._lib.LIB_PATH at it before the first call)."""
+    if dev == "bnscalar":      # A/B measurement build: BatchNorm passes on the scalar kernels
+        return _build(os.path.join(HERE, "libtgpose_hip_bnscalar.so"), SOURCES, ["-DTGP_BN_SCALAR"], ".bs.o", verbose)
     if dev == "noguard":       # A/B measurement build: the product library without the fp16 range guard of the split GEMM
         return _build(os.path.join(HERE, "libtgpose_hip_noguard.so"), SOURCES, ["-DTGP_NO_RANGE_GUARD"], ".ng.o", verbose)
     if dev:
@@ -70,4 +72,4 @@ def _build(LIB, sources, extra, suffix, verbose):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, dev="noguard" if "--noguard" in sys.argv else "--dev" in sys.argv)
+    build(force="--force" in sys.argv, dev="noguard" if "--noguard" in sys.argv else "bnscalar" if "--bnscalar" in sys.argv else "--dev" in sys.argv)

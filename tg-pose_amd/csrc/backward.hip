@@ -261,6 +261,100 @@ __global__ __launch_bounds__(256) void bw_partial_kernel(const float *__restrict
     }
 }
 
+// (round 3) the same sums with a column quad per thread: 16-byte loads, 256 columns per workgroup, BWV_CHUNK = 256 rows per
+// workgroup.  (First attempt: the scalar kernels' 1024-row chunks -- a quarter of the workgroups, 8 waves per CU -- and every
+// 16-byte kernel was SLOWER than its 4-byte twin, bn_bwd_apply 405 -> 949 us per step: these passes live on latency hiding.)
+// Deterministic: fixed slice and chunk order (not the scalar kernels' order: the chunks are shorter).
+#define BWV_CHUNK 256
+template <int MODE>
+__global__ __launch_bounds__(256) void bw_partial_v4_kernel(const float *__restrict__ dy, int lddy, const float *__restrict__ x, int ld,
+                                                            int64_t rows, int C, const float *__restrict__ mean,
+                                                            const float *__restrict__ var, float eps, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, int act, float slope,
+                                                            const float *__restrict__ slope_vec, float *__restrict__ p1,
+                                                            float *__restrict__ p2)
+{
+    __shared__ float4 red[2][4][64];
+    const int quad = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + quad * 4;
+    const int64_t r0 = (int64_t)blockIdx.y * BWV_CHUNK;
+    const int64_t r1 = r0 + BWV_CHUNK < rows ? r0 + BWV_CHUNK : rows;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        float mu[4] = {0.f, 0.f, 0.f, 0.f}, inv[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f},
+              sl[4] = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                mu[q] = mean[c + q], inv[q] = 1.0f / sqrtf(var[c + q] + eps), g[q] = gamma[c + q], b[q] = beta[c + q],
+                sl[q] = slope_vec ? slope_vec[c + q] : slope;
+        }
+#pragma unroll 4
+        for (int64_t r = r0 + slice; r < r1; r += 4) {
+            const float4 dv = *reinterpret_cast<const float4 *>(dy + r * lddy + c);
+            float d[4] = {dv.x, dv.y, dv.z, dv.w};
+            if (MODE == 1) {
+                const float4 xv = *reinterpret_cast<const float4 *>(x + r * ld + c);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float xh = (xs[q] - mu[q]) * inv[q];
+                    d[q] *= act_grad(xh * g[q] + b[q], act, sl[q]);
+                    s2[q] += d[q] * xh;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s1[q] += d[q];
+        }
+    }
+    red[0][slice][quad] = make_float4(s1[0], s1[1], s1[2], s1[3]);
+    red[1][slice][quad] = make_float4(s2[0], s2[1], s2[2], s2[3]);
+    __syncthreads();
+    if (slice == 0 && c < C) {
+        auto comb = [&](int w) {
+            const float4 a0 = red[w][0][quad], a1 = red[w][1][quad], a2 = red[w][2][quad], a3 = red[w][3][quad];
+            return make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y, ((a0.z + a1.z) + a2.z) + a3.z,
+                               ((a0.w + a1.w) + a2.w) + a3.w);
+        };
+        *reinterpret_cast<float4 *>(p1 + (int64_t)blockIdx.y * C + c) = comb(0);
+        if (MODE == 1) *reinterpret_cast<float4 *>(p2 + (int64_t)blockIdx.y * C + c) = comb(1);
+    }
+}
+
+// both BatchNorm sums finished by one launch (was two): 64 columns x 4 chunk groups per workgroup, groups added in order
+__global__ __launch_bounds__(256) void bw_finish2_kernel(const float *__restrict__ p1, const float *__restrict__ p2, int chunks, int C,
+                                                         float *__restrict__ o1, float *__restrict__ o2, int accumulate)
+{
+    __shared__ float sa[4][64], sb[4][64];
+    const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l;
+    const int per = (chunks + 3) / 4;
+    float a = 0.f, b = 0.f;
+    if (c < C) {
+        const int k1 = (g + 1) * per < chunks ? (g + 1) * per : chunks;
+#pragma unroll 4
+        for (int k = g * per; k < k1; ++k) {
+            a += p1[(int64_t)k * C + c];
+            if (p2) b += p2[(int64_t)k * C + c];
+        }
+    }
+    sa[g][l] = a, sb[g][l] = b;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        a = ((sa[0][l] + sa[1][l]) + sa[2][l]) + sa[3][l];
+        o1[c] = accumulate ? o1[c] + a : a;
+        if (p2) o2[c] = ((sb[0][l] + sb[1][l]) + sb[2][l]) + sb[3][l];
+    }
+}
+
+static bool bw_vec_ok(const void *a, int lda, const void *b, int ldb, int C)
+{
+#ifdef TGP_BN_SCALAR        // measurement builds only
+    return false;
+#endif
+    return (C & 3) == 0 && (lda & 3) == 0 && (ldb & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+}
+
 __global__ void bw_finish_kernel(const float *__restrict__ partial, int chunks, int C, float *__restrict__ out, int accumulate)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -270,13 +364,22 @@ __global__ void bw_finish_kernel(const float *__restrict__ partial, int chunks, 
     out[c] = accumulate ? out[c] + s : s;
 }
 
-extern "C" int64_t tgp_bw_workspace_floats(int64_t rows, int C) { return rows > 0 && C > 0 ? 2 * (int64_t)tgp_cdiv(rows, BW_CHUNK) * C : 0; }
+extern "C" int64_t tgp_bw_workspace_floats(int64_t rows, int C) { return rows > 0 && C > 0 ? 2 * (int64_t)tgp_cdiv(rows, BWV_CHUNK) * C : 0; }
 
 extern "C" int tgp_colsum(const float *dy, int lddy, int64_t rows, int C, float *out, int accumulate, float *workspace,
                           tgp_stream_t stream)
 {
     TGP_REQUIRE(dy && out && workspace && rows > 0 && C > 0 && lddy >= C);
     const int chunks = tgp_cdiv(rows, BW_CHUNK);
+    if (bw_vec_ok(dy, lddy, workspace, 0, C)) {
+        const int vchunks = tgp_cdiv(rows, BWV_CHUNK);
+        hipLaunchKernelGGL(bw_partial_v4_kernel<0>, dim3(tgp_cdiv(C, 256), vchunks), dim3(256), 0, tgp_hs(stream), dy, lddy,
+                           (const float *)nullptr, 0, rows, C, (const float *)nullptr, (const float *)nullptr, 0.f,
+                           (const float *)nullptr, (const float *)nullptr, 0, 0.f, (const float *)nullptr, workspace, (float *)nullptr);
+        hipLaunchKernelGGL(bw_finish2_kernel, dim3(tgp_cdiv(C, 64)), dim3(256), 0, tgp_hs(stream), workspace, (const float *)nullptr, vchunks, C,
+                           out, (float *)nullptr, accumulate);
+        return TGP_LAUNCH_RESULT();
+    }
     hipLaunchKernelGGL(bw_partial_kernel<0>, dim3(tgp_cdiv(C, 64), chunks), dim3(256), 0, tgp_hs(stream), dy, lddy,
                        (const float *)nullptr, 0, rows, C, (const float *)nullptr, (const float *)nullptr, 0.f,
                        (const float *)nullptr, (const float *)nullptr, 0, 0.f, (const float *)nullptr, workspace, (float *)nullptr);
@@ -308,6 +411,42 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
     }
 }
 
+__global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float *__restrict__ dy, int lddy, const float *__restrict__ x, int ld,
+                                                              int64_t rows, int C, const float *__restrict__ mean,
+                                                              const float *__restrict__ var, float eps, const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, int act, float slope,
+                                                              const float *__restrict__ slope_vec, const float *__restrict__ s1,
+                                                              const float *__restrict__ s2, float *__restrict__ dx, int lddx)
+{
+    const int c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
+    const int slice = threadIdx.x >> 6;
+    if (c >= C) return;
+    const float inv_n = (float)(1.0 / (double)rows);
+    float mu[4], inv[4], g[4], b[4], sl[4], m1[4], m2[4], scale[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        mu[q] = mean[c + q], inv[q] = 1.0f / sqrtf(var[c + q] + eps), g[q] = gamma[c + q], b[q] = beta[c + q];
+        sl[q] = slope_vec ? slope_vec[c + q] : slope;
+        m1[q] = s1[c + q] * inv_n, m2[q] = s2[c + q] * inv_n, scale[q] = g[q] * inv[q];
+    }
+    const int64_t r0 = (int64_t)blockIdx.y * BWV_CHUNK;
+    const int64_t r1 = r0 + BWV_CHUNK < rows ? r0 + BWV_CHUNK : rows;
+#pragma unroll 4
+    for (int64_t r = r0 + slice; r < r1; r += 4) {
+        const float4 xv = *reinterpret_cast<const float4 *>(x + r * ld + c);
+        const float4 dv = *reinterpret_cast<const float4 *>(dy + r * lddy + c);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float xh = (xs[q] - mu[q]) * inv[q];
+            const float dz = ds[q] * act_grad(xh * g[q] + b[q], act, sl[q]);
+            o[q] = scale[q] * ((dz - m1[q]) - xh * m2[q]);
+        }
+        *reinterpret_cast<float4 *>(dx + r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // BatchNorm(train) + activation backward.  dgamma = sum dz * xhat, dbeta = sum dz are returned (they double as the
 // batch sums of the dx formula).  dx may alias dy.
 extern "C" int tgp_bn_bwd(const float *dy, int lddy, const float *x, int ld, int64_t rows, int C, const float *mean,
@@ -320,6 +459,17 @@ extern "C" int tgp_bn_bwd(const float *dy, int lddy, const float *x, int ld, int
     const int chunks = tgp_cdiv(rows, BW_CHUNK);
     float *p1 = workspace, *p2 = workspace + (int64_t)chunks * C;
     const dim3 grid(tgp_cdiv(C, 64), chunks), block(256);
+    if (bw_vec_ok(dy, lddy, x, ld, C) && bw_vec_ok(dx, lddx, workspace, 0, C)) {
+        const int vchunks = tgp_cdiv(rows, BWV_CHUNK);
+        const dim3 grid4(tgp_cdiv(C, 256), vchunks);
+        p2 = workspace + (int64_t)vchunks * C;
+        hipLaunchKernelGGL(bw_partial_v4_kernel<1>, grid4, block, 0, tgp_hs(stream), dy, lddy, x, ld, rows, C, mean, var, eps, gamma, beta,
+                           act, slope, slope_vec, p1, p2);
+        hipLaunchKernelGGL(bw_finish2_kernel, dim3(tgp_cdiv(C, 64)), dim3(256), 0, tgp_hs(stream), p1, p2, vchunks, C, dbeta, dgamma, 0);
+        hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, grid4, block, 0, tgp_hs(stream), dy, lddy, x, ld, rows, C, mean, var, eps, gamma, beta,
+                           act, slope, slope_vec, dbeta, dgamma, dx, lddx);
+        return TGP_LAUNCH_RESULT();
+    }
     hipLaunchKernelGGL(bw_partial_kernel<1>, grid, block, 0, tgp_hs(stream), dy, lddy, x, ld, rows, C, mean, var, eps, gamma, beta,
                        act, slope, slope_vec, p1, p2);
     hipLaunchKernelGGL(bw_finish_kernel, dim3(tgp_cdiv(C, 256)), dim3(256), 0, tgp_hs(stream), p1, chunks, C, dbeta, 0);
@@ -381,6 +531,47 @@ __global__ __launch_bounds__(256) void bn_bwd_pooled_apply_kernel(const float *_
     }
 }
 
+__global__ __launch_bounds__(256) void bn_bwd_pooled_apply_v4_kernel(const float *__restrict__ dpool, int ldp,
+                                                                     const int *__restrict__ argrow, int lda,
+                                                                     const float *__restrict__ x, int ld, int64_t rows, int rows_per_obj,
+                                                                     int C, const float *__restrict__ mean, const float *__restrict__ var,
+                                                                     float eps, const float *__restrict__ gamma,
+                                                                     const float *__restrict__ beta, int act, float slope,
+                                                                     const float *__restrict__ slope_vec, const float *__restrict__ s1,
+                                                                     const float *__restrict__ s2, float *__restrict__ dx, int lddx)
+{
+    const int c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
+    const int slice = threadIdx.x >> 6;
+    if (c >= C) return;
+    const float inv_n = (float)(1.0 / (double)rows);
+    float mu[4], inv[4], g[4], b[4], sl[4], m1[4], m2[4], scale[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        mu[q] = mean[c + q], inv[q] = 1.0f / sqrtf(var[c + q] + eps), g[q] = gamma[c + q], b[q] = beta[c + q];
+        sl[q] = slope_vec ? slope_vec[c + q] : slope;
+        m1[q] = s1[c + q] * inv_n, m2[q] = s2[c + q] * inv_n, scale[q] = g[q] * inv[q];
+    }
+    const int64_t r0 = (int64_t)blockIdx.y * BWV_CHUNK;
+    const int64_t r1 = r0 + BWV_CHUNK < rows ? r0 + BWV_CHUNK : rows;
+#pragma unroll 4
+    for (int64_t r = r0 + slice; r < r1; r += 4) {
+        const float4 xv = *reinterpret_cast<const float4 *>(x + r * ld + c);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        const int64_t o = r / rows_per_obj;
+        const int4 ar = *reinterpret_cast<const int4 *>(argrow + o * lda + c);
+        const int as[4] = {ar.x, ar.y, ar.z, ar.w};
+        float ov[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float xh = (xs[q] - mu[q]) * inv[q];
+            float dz = 0.f;
+            if (as[q] == r) dz = dpool[o * ldp + c + q] * act_grad(xh * g[q] + b[q], act, sl[q]);
+            ov[q] = scale[q] * ((dz - m1[q]) - xh * m2[q]);
+        }
+        *reinterpret_cast<float4 *>(dx + r * lddx + c) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    }
+}
+
 extern "C" int tgp_bn_bwd_pooled(const float *dpool, int ldp, const int *argrow, int lda, const float *x, int ld, int objects,
                                  int rows_per_obj, int C, const float *mean, const float *var, float eps, const float *gamma,
                                  const float *beta, int act, float slope, const float *slope_vec, float *dx, int lddx,
@@ -391,6 +582,12 @@ extern "C" int tgp_bn_bwd_pooled(const float *dpool, int ldp, const int *argrow,
     const int64_t rows = (int64_t)objects * rows_per_obj;
     hipLaunchKernelGGL(bn_bwd_pooled_sums_kernel, dim3(tgp_cdiv(C, 64)), dim3(64), 0, tgp_hs(stream), dpool, ldp, argrow, lda, x, ld,
                        objects, C, mean, var, eps, gamma, beta, act, slope, slope_vec, dbeta, dgamma);
+    if (bw_vec_ok(x, ld, dx, lddx, C) && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(argrow) & 15) == 0) {
+        hipLaunchKernelGGL(bn_bwd_pooled_apply_v4_kernel, dim3(tgp_cdiv(C, 256), tgp_cdiv(rows, (int64_t)BWV_CHUNK)), dim3(256), 0,
+                           tgp_hs(stream), dpool, ldp, argrow, lda, x, ld, rows, rows_per_obj, C, mean, var, eps, gamma, beta, act,
+                           slope, slope_vec, dbeta, dgamma, dx, lddx);
+        return TGP_LAUNCH_RESULT();
+    }
     hipLaunchKernelGGL(bn_bwd_pooled_apply_kernel, dim3(tgp_cdiv(C, 64), tgp_cdiv(rows, (int64_t)BW_CHUNK)), dim3(256), 0,
                        tgp_hs(stream), dpool, ldp, argrow, lda, x, ld, rows, rows_per_obj, C, mean, var, eps, gamma, beta, act,
                        slope, slope_vec, dbeta, dgamma, dx, lddx);
