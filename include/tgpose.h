@@ -220,10 +220,16 @@ int tgp_add_mean(float *recon, const float *mean, int B, int n, tgp_stream_t str
 /* ---- training-mode BatchNorm / dropout ------------------------------------------------------- */
 
 /* nn.BatchNorm1d in train mode on channel-last rows x (rows, C) with row stride ld: per-channel batch mean and
- * BIASED variance (two passes, deterministic).  workspace: tgp_bn_workspace_floats(rows, C) floats. */
+ * BIASED variance (deterministic: one pass of shifted sums merged in chunk order when the rows are 16-byte addressable, two
+ * passes otherwise).  workspace: tgp_bn_workspace_floats(rows, C) floats. */
 int64_t tgp_bn_workspace_floats(int64_t rows, int C);
 int tgp_bn_stats(const float *x, int ld, int64_t rows, int C, float *mean, float *var, float *workspace,
                  tgp_stream_t stream);
+/* tgp_bn_stats that also moves nn.BatchNorm1d's buffers (ABI 4): run_mean / run_var (C) <- (1 - momentum) x running + momentum x
+ * batch value, the variance with the unbiased factor rows / (rows - 1) (torch's `running.mul_(1 - m).add_(batch, alpha = m)`);
+ * batches (one int64, may be NULL) += 1 (num_batches_tracked).  run_mean == run_var == NULL: statistics only. */
+int tgp_bn_stats_running(const float *x, int ld, int64_t rows, int C, float *mean, float *var, float *workspace, float *run_mean,
+                         float *run_var, float momentum, int64_t *batches, tgp_stream_t stream);
 
 /* y = (x - mean) / sqrt(var + eps) * gamma + beta, then leaky-relu (act = 1; per-column slope_vec overrides slope);
  * out may alias x or be NULL; colmax_keys as in tgp_gemm_args (max over each object's rows_per_obj rows for the

@@ -140,6 +140,7 @@ SIGNATURES = {
     "tgp_add_mean": (c_int, [c_vp, c_vp, c_int, c_int, c_vp]),
     "tgp_bn_workspace_floats": (c_i64, [c_i64, c_int]),
     "tgp_bn_stats": (c_int, [c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "tgp_bn_stats_running": (c_int, [c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp]),
     "tgp_bn_apply": (c_int, [c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_int, c_f32, c_vp, c_vp, c_int, c_vp,
                              c_int, c_int, c_int, c_vp]),
     "tgp_dropout_apply": (c_int, [c_vp, c_vp, c_f32, c_i64, c_vp, c_vp]),

@@ -87,8 +87,7 @@ class _BNAct(Function):
     def forward(ctx, x, gamma, beta, bn, act, slope):
         x = x.contiguous()
         y = torch.empty_like(x)
-        _, mean, var = ops.bn_train(x, gamma, beta, BN_EPS, act, slope, out=y)
-        _update_running(bn, mean, var, x.numel() // x.shape[-1])
+        _, mean, var = ops.bn_train(x, gamma, beta, BN_EPS, act, slope, out=y, running=_running(bn))
         ctx.save_for_backward(x, mean, var, gamma, beta)
         ctx.act, ctx.slope = act, slope
         return y
@@ -108,8 +107,8 @@ class _BNActPool(Function):
         x = x.contiguous()
         B, n, C = x.shape
         keys = torch.zeros(B, C, device=x.device, dtype=torch.int32)
-        _, mean, var = ops.bn_train(x, gamma, beta, BN_EPS, act, slope, want_out=False, colmax_keys=keys, rows_per_obj=n)
-        _update_running(bn, mean, var, B * n)
+        _, mean, var = ops.bn_train(x, gamma, beta, BN_EPS, act, slope, want_out=False, colmax_keys=keys, rows_per_obj=n,
+                                    running=_running(bn))
         pooled, arg = ops.colmax_arg(x, B, n, bn=(mean, var, gamma, beta), act=act, slope=slope)
         ctx.save_for_backward(x, mean, var, gamma, beta, arg)
         ctx.act, ctx.slope = act, slope
@@ -121,6 +120,13 @@ class _BNActPool(Function):
         B, n, C = x.shape
         dx, dg, db = ops.bn_bwd_pooled(dpool.contiguous(), arg, x, n, mean, var, gamma, beta, BN_EPS, ctx.act, ctx.slope)
         return dx.view(B, n, C), dg, db, None, None, None
+
+
+def _running(bn):
+    """the module's buffers for ops.bn_train(running=...): moved by the statistics kernel (was: four torch launches per module)"""
+    if bn is None or not bn.track_running_stats or bn.momentum is None:
+        return None
+    return bn.running_mean, bn.running_var, bn.momentum, bn.num_batches_tracked
 
 
 def _update_running(bn, mean, var, rows):

@@ -94,8 +94,13 @@ __global__ __launch_bounds__(256) void bn_stats_partial_v4_kernel(const float *_
 
 // 64 columns x 4 chunk groups per workgroup: group g merges the chunks [g * per, (g + 1) * per) in order, the four group results
 // are merged in group order (a fixed tree: deterministic)
+// run_mean / run_var / batches (may be NULL): nn.BatchNorm1d's buffers, moved here instead of by four tiny torch launches per
+// module and step -- running <- (1 - m) running + m batch, the variance with the unbiased factor rows / (rows - 1), in the two
+// roundings of `running.mul_(1 - m).add_(batch, alpha = m)`; num_batches_tracked += 1.
 __global__ __launch_bounds__(256) void bn_stats_finish_v4_kernel(const float *__restrict__ partial, int chunks, int C, int64_t rows,
-                                                                 float *__restrict__ mean, float *__restrict__ var)
+                                                                 float *__restrict__ mean, float *__restrict__ var,
+                                                                 float *__restrict__ run_mean, float *__restrict__ run_var, float momentum,
+                                                                 float unbias, int64_t *__restrict__ batches)
 {
     __shared__ float s_n[4][64], s_mean[4][64], s_m2[4][64];
     const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -132,9 +137,28 @@ __global__ __launch_bounds__(256) void bn_stats_finish_v4_kernel(const float *__
             }
         }
         mean[c] = mean_a;
-        const float v = m2_a / n_a;
-        var[c] = v < 0.f ? 0.f : v;                          // (a NaN stays a NaN)
+        float v = m2_a / n_a;
+        v = v < 0.f ? 0.f : v;                               // (a NaN stays a NaN)
+        var[c] = v;
+        if (run_mean) {
+            const float keep = 1.0f - momentum;
+            run_mean[c] = run_mean[c] * keep + momentum * mean_a;
+            run_var[c] = run_var[c] * keep + (momentum * unbias) * v;
+        }
+        if (batches && c == 0) batches[0] += 1;
     }
+}
+
+// the same update after the two-pass statistics (rows that are not 16-byte addressable)
+__global__ void bn_running_update_kernel(const float *__restrict__ mean, const float *__restrict__ var, int C, float *__restrict__ run_mean,
+                                         float *__restrict__ run_var, float momentum, float unbias, int64_t *__restrict__ batches)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float keep = 1.0f - momentum;
+    run_mean[c] = run_mean[c] * keep + momentum * mean[c];
+    run_var[c] = run_var[c] * keep + (momentum * unbias) * var[c];
+    if (batches && c == 0) batches[0] += 1;
 }
 
 static bool bn_vec_ok(const void *x, int ld, int C)
@@ -152,14 +176,17 @@ extern "C" int64_t tgp_bn_workspace_floats(int64_t rows, int C)
     return two_pass > one_pass ? two_pass : one_pass;
 }
 
-extern "C" int tgp_bn_stats(const float *x, int ld, int64_t rows, int C, float *mean, float *var, float *workspace,
-                            tgp_stream_t stream)
+extern "C" int tgp_bn_stats_running(const float *x, int ld, int64_t rows, int C, float *mean, float *var, float *workspace,
+                                    float *run_mean, float *run_var, float momentum, int64_t *batches, tgp_stream_t stream)
 {
     TGP_REQUIRE(x && mean && var && workspace && rows > 0 && C > 0 && ld >= C);
+    TGP_REQUIRE((run_mean == nullptr) == (run_var == nullptr) && momentum >= 0.f && momentum <= 1.f);
+    const float unbias = (float)((double)rows / (double)(rows > 1 ? rows - 1 : 1));
     if (bn_vec_ok(x, ld, C) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
         const int vchunks = tgp_cdiv(rows, BNV_CHUNK);
         hipLaunchKernelGGL(bn_stats_partial_v4_kernel, dim3(tgp_cdiv(C, 256), vchunks), dim3(256), 0, tgp_hs(stream), x, ld, rows, C, workspace);
-        hipLaunchKernelGGL(bn_stats_finish_v4_kernel, dim3(tgp_cdiv(C, 64)), dim3(256), 0, tgp_hs(stream), workspace, vchunks, C, rows, mean, var);
+        hipLaunchKernelGGL(bn_stats_finish_v4_kernel, dim3(tgp_cdiv(C, 64)), dim3(256), 0, tgp_hs(stream), workspace, vchunks, C, rows, mean, var,
+                           run_mean, run_var, momentum, unbias, batches);
         return TGP_LAUNCH_RESULT();
     }
     const int chunks = tgp_cdiv(rows, BN_CHUNK);
@@ -169,7 +196,16 @@ extern "C" int tgp_bn_stats(const float *x, int ld, int64_t rows, int C, float *
     hipLaunchKernelGGL(bn_finish_kernel, dim3(tgp_cdiv(C, 256)), dim3(256), 0, tgp_hs(stream), workspace, chunks, C, inv, mean);
     hipLaunchKernelGGL(bn_partial_kernel<true>, grid, block, 0, tgp_hs(stream), x, ld, rows, C, (const float *)mean, workspace);
     hipLaunchKernelGGL(bn_finish_kernel, dim3(tgp_cdiv(C, 256)), dim3(256), 0, tgp_hs(stream), workspace, chunks, C, inv, var);
+    if (run_mean)
+        hipLaunchKernelGGL(bn_running_update_kernel, dim3(tgp_cdiv(C, 256)), dim3(256), 0, tgp_hs(stream), mean, var, C, run_mean, run_var,
+                           momentum, unbias, batches);
     return TGP_LAUNCH_RESULT();
+}
+
+extern "C" int tgp_bn_stats(const float *x, int ld, int64_t rows, int C, float *mean, float *var, float *workspace,
+                            tgp_stream_t stream)
+{
+    return tgp_bn_stats_running(x, ld, rows, C, mean, var, workspace, nullptr, nullptr, 0.f, nullptr, stream);
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x, int ld, int64_t rows, int C,

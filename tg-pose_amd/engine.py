@@ -768,8 +768,11 @@ class TrainBN(object):
         self.sd[name + ".num_batches_tracked"].add_(1)
 
     def __call__(self, name, x, act=0, slope=0.0, **kw):
-        out, mean, var = ops.bn_train(x, self.sd[name + ".weight"], self.sd[name + ".bias"], BN_EPS, act, slope, **kw)
-        self._update(name, mean, var, math.prod(x.shape[:-1]))
+        running = None
+        if self.update:      # the statistics kernel moves the module's buffers itself (tgp_bn_stats_running)
+            running = (self.sd[name + ".running_mean"], self.sd[name + ".running_var"], self.momentum,
+                       self.sd.get(name + ".num_batches_tracked"))
+        out, mean, var = ops.bn_train(x, self.sd[name + ".weight"], self.sd[name + ".bias"], BN_EPS, act, slope, running=running, **kw)
         return out
 
     def multi(self, names, x, act, slope_vec, **kw):

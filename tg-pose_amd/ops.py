@@ -612,9 +612,11 @@ def generate_rt(p_green, p_red, f_green, f_red, T, sym=None):
 
 
 def bn_train(x, gamma, beta, eps=1e-5, act=0, slope=0.0, slope_vec=None, out=None, colmax_keys=None, cm_cols=0,
-             rows_per_obj=0, want_out=True):
+             rows_per_obj=0, want_out=True, running=None):
     """Training-mode BatchNorm over rows: x (..., C) rows (row stride may exceed C).  Normalises (in place unless `out`),
-    applies the activation, optionally feeds colmax keys.  Returns (out, batch_mean (C,), biased batch_var (C,))."""
+    applies the activation, optionally feeds colmax keys.  Returns (out, batch_mean (C,), biased batch_var (C,)).
+    running = (running_mean (C,), running_var (C,), momentum, num_batches_tracked or None): the module's buffers, updated by the
+    statistics kernel itself (tgp_bn_stats_running) instead of by four torch launches."""
     x, ld = _rows(x, "x")
     C = x.shape[-1]
     rows = math.prod(x.shape[:-1])
@@ -622,7 +624,16 @@ def bn_train(x, gamma, beta, eps=1e-5, act=0, slope=0.0, slope_vec=None, out=Non
     mean = torch.empty(C, device=dev, dtype=torch.float32)
     var = torch.empty(C, device=dev, dtype=torch.float32)
     ws = torch.empty(_lib.lib().tgp_bn_workspace_floats(rows, C), device=dev, dtype=torch.float32)
-    check(_lib.lib().tgp_bn_stats(_p(x), ld, rows, C, _p(mean), _p(var), _p(ws), _stream(x)), "tgp_bn_stats")
+    if running is None:
+        check(_lib.lib().tgp_bn_stats(_p(x), ld, rows, C, _p(mean), _p(var), _p(ws), _stream(x)), "tgp_bn_stats")
+    else:
+        rm, rv, momentum, nbt = running
+        if not (rm.is_contiguous() and rv.is_contiguous() and rm.numel() == C and rv.numel() == C and rm.dtype == torch.float32):
+            raise ValueError("bn_train: running statistics must be contiguous float32 (C,) tensors")
+        if nbt is not None and nbt.dtype != torch.int64:
+            raise ValueError("bn_train: num_batches_tracked must be int64")
+        check(_lib.lib().tgp_bn_stats_running(_p(x), ld, rows, C, _p(mean), _p(var), _p(ws), _p(rm), _p(rv), float(momentum), _p(nbt),
+                                              _stream(x)), "tgp_bn_stats_running")
     ldo = 0
     if want_out:
         out = x if out is None else out
