@@ -36,44 +36,98 @@ def _split_if_big(w, rows, grads=False):
     return ops.split_bf16(w) if grads else ops.split_w(w, check=False)     # inside the (captured) step: no read-back
 
 
+def _linear_backward(x, W, dy, need_dx, need_dw, need_db, dx_accum=None):
+    """dx = dy W (+ dx_accum, added by the GEMM's own epilogue), dW = dy^T x, db = colsum(dy) for y = x W^T + b; W contiguous (N, K).
+    Both GEMMs of a large layer run on the fp16 split kernels with dy lifted into fp16's range by one power of two chosen on the
+    device (ops.absmax_scale); small ones keep the bf16x3 / fp32 MFMA paths."""
+    N, K = W.shape
+    dy2 = dy.reshape(-1, N)
+    x2 = x.reshape(-1, K)
+    dx = dW = db = None
+    rows = dy2.shape[0]
+    dx_f16 = need_dx and ops.GEMM_MODE == "split16" and ops.TN_SPLIT and ops._routes_to_big_tile(rows, K)
+    dw_f16 = need_dw and ops.tn_split_ok(rows, N, K)
+    dyc = dy2.contiguous()
+    sc = ops.absmax_scale(dyc) if (dx_f16 or dw_f16) else None
+    if need_dx:
+        dyp = _pad4(dyc).contiguous()                       # the reduction dim of this GEMM is N
+        wt = _pad4(ops.transpose(W)).contiguous()           # (K, N)
+        out = res = None
+        if dx_accum is not None:                            # the running sum of the other consumers' gradients: read as the
+            out = res = dx_accum.view(-1, K)                # epilogue's residual and overwritten in place
+        if dx_f16:
+            dx = ops.linear_rows(dyp, wt, w_split=ops.split_f16(wt), a_scale=sc, c_scale=sc[1:], out=out, res1=res).view(x.shape)
+        else:
+            dx = ops.linear_rows(dyp, wt, w_split=_split_if_big(wt, dyp.shape[0], grads=True), out=out, res1=res).view(x.shape)
+    if need_dw:
+        dW = ops.gemm_tn(dyc, x2, scale=sc if dw_f16 else None)
+    if need_db:
+        db = ops.colsum(dyc)
+    return dx, dW, db
+
+
 class _Linear(Function):
     """y = x W^T (+ b): x (..., K) rows, W (N, K).  dW = dy^T x (TN GEMM), dx = dy W (forward kernel on W^T), db = colsum."""
 
     @staticmethod
     def forward(ctx, x, W, b):
         x = x.contiguous()
+        Wc = W.contiguous()                                 # once: a column slice of a weight (conv2's halves) is a copy
         rows = x.numel() // x.shape[-1]
-        y = ops.linear_rows(x, W.contiguous(), bias=b, w_split=_split_if_big(W.contiguous(), rows))
-        ctx.save_for_backward(x, W)
+        y = ops.linear_rows(x, Wc, bias=b, w_split=_split_if_big(Wc, rows))
+        ctx.save_for_backward(x, Wc)
         ctx.has_bias = b is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
-        N, K = W.shape
-        dy2 = dy.reshape(-1, N)
-        x2 = x.reshape(-1, K)
-        dx = dW = db = None
-        rows = dy2.shape[0]
-        # both GEMMs of a large layer run on the fp16 split kernels with dy lifted into fp16's range by one power of two chosen
-        # on the device (ops.absmax_scale); small ones keep the bf16x3 / fp32 MFMA paths
-        dx_f16 = ctx.needs_input_grad[0] and ops.GEMM_MODE == "split16" and ops.TN_SPLIT and ops._routes_to_big_tile(rows, K)
-        dw_f16 = ctx.needs_input_grad[1] and ops.tn_split_ok(rows, N, K)
-        sc = ops.absmax_scale(dy2.contiguous()) if (dx_f16 or dw_f16) else None
-        if ctx.needs_input_grad[0]:
-            dyp = _pad4(dy2).contiguous()                       # the reduction dim of this GEMM is N
-            wt = ops.transpose(W.contiguous())                  # (K, N)
-            wt = _pad4(wt).contiguous()
-            if dx_f16:
-                dx = ops.linear_rows(dyp, wt, w_split=ops.split_f16(wt), a_scale=sc, c_scale=sc[1:]).view(x.shape)
-            else:
-                dx = ops.linear_rows(dyp, wt, w_split=_split_if_big(wt, dyp.shape[0], grads=True)).view(x.shape)
-        if ctx.needs_input_grad[1]:
-            dW = ops.gemm_tn(dy2.contiguous(), x2, scale=sc if dw_f16 else None)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.colsum(dy2.contiguous())
-        return dx, dW, db
+        return _linear_backward(x, W, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+
+
+class _FeatConsumers(Function):
+    """The five layers that read the concat buffer `feat` (conv_5 of the PH predictor, the decoder's first conv, conv1 of the three
+    heads; FaceRecon.py:76,112,  PoseR.py:26, PoseTs.py:31) as ONE autograd node: y_i = feat W_i^T (+ b_i) with W_i zero-padded to
+    feat's row stride inside the node.  Forward: the same five GEMMs.  Backward: d feat is accumulated by the dx GEMMs' own
+    epilogues (each reads the running sum as its residual and overwrites it), where five separate nodes made autograd add five
+    170 MB tensors pairwise (0.38 ms per step) and pad / un-pad every weight through its own nodes."""
+
+    @staticmethod
+    def forward(ctx, feat, *wb):
+        feat = feat.contiguous()
+        rows = feat.numel() // feat.shape[-1]
+        outs, saved, cols = [], [], []
+        for i in range(0, len(wb), 2):
+            W, b = wb[i], wb[i + 1]
+            Wp = F.pad(W, (0, feat.shape[-1] - W.shape[1])).contiguous()
+            outs.append(ops.linear_rows(feat, Wp, bias=b, w_split=_split_if_big(Wp, rows)))
+            saved.append(Wp)
+            cols.append(W.shape[1])
+        ctx.save_for_backward(feat, *saved)
+        ctx.cols, ctx.has_bias = cols, [wb[i + 1] is not None for i in range(0, len(wb), 2)]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        feat, *Ws = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dfeat, grads = None, []
+        for i, (g, Wp) in enumerate(zip(gs, Ws)):
+            if g is None:
+                grads += [None, None]
+                continue
+            dx, dW, db = _linear_backward(feat, Wp, g, need[0], need[1 + 2 * i], ctx.has_bias[i] and need[2 + 2 * i], dx_accum=dfeat)
+            dfeat = dx if dx is not None else dfeat
+            grads += [dW[:, : ctx.cols[i]] if dW is not None else None, db]
+        return (dfeat,) + tuple(grads)
+
+
+def feat_consumers(feat, layers):
+    """layers: [(weight (N, K <= row stride of feat), bias or None), ...] -> one output per layer"""
+    flat = []
+    for W, b in layers:
+        flat += [W, b]
+    return _FeatConsumers.apply(feat, *flat)
 
 
 def linear(x, W, b=None):
@@ -344,9 +398,11 @@ def _w_feat(conv, cols=FEAT_C):
     return F.pad(w, (0, FEAT_LD - w.shape[1]))
 
 
-def ph_predictor(ph, feat):
-    """PH_Predictor.forward (FaceRecon.py:139-167) -> back = pi1_1 + pi2_1 (B, FEAT_LD-padded), h1, h2"""
-    x = linear(feat, _w_feat(ph.conv_5[0]))
+def ph_predictor(ph, feat, x=None):
+    """PH_Predictor.forward (FaceRecon.py:139-167) -> back = pi1_1 + pi2_1 (B, FEAT_LD-padded), h1, h2.  x: conv_5's raw output
+    when the caller computed the layers over `feat` as one node (feat_consumers)"""
+    if x is None:
+        x = linear(feat, _w_feat(ph.conv_5[0]))
     g = bn_act_pool(x, ph.conv_5[1], act=1, slope=0.2)                     # (B, 1024)
     g = torch.cat((g, g), 1)
     fa = bn_act(linear(g, ph.linear1.weight), ph.bn5, act=1, slope=0.2)
@@ -357,11 +413,12 @@ def ph_predictor(ph, feat):
     return back, torch.sigmoid(pi1), torch.sigmoid(pi2)
 
 
-def decoder(dec, feat, back):
+def decoder(dec, feat, back, x=None):
     """Face_Dec.forward on feat + back (FaceRecon.py:112-117,165): conv(feat + back) = conv(feat) + W back per object"""
     blk = dec.conv1d_block
     w0 = _w_feat(blk[0])
-    x = linear(feat, w0, blk[0].bias)
+    if x is None:
+        x = linear(feat, w0, blk[0].bias)
     if back is not None:
         x = add_row_bias(x, linear(F.pad(back, (0, FEAT_LD - back.shape[1])), w0))
     x = bn_act(x, blk[1])
@@ -371,9 +428,9 @@ def decoder(dec, feat, back):
     return linear(x, dec.recon_head[3].weight[:, :, 0], dec.recon_head[3].bias)
 
 
-def point_head(hd, feat):
+def point_head(hd, feat, x=None):
     """Rot_green / Rot_red / Pose_Ts (PoseR.py:26-39, PoseTs.py:31-45) on the concat buffer -> (B, out)"""
-    x = bn_act(linear(feat, _w_feat(hd.conv1), hd.conv1.bias), hd.bn1)
+    x = bn_act(linear(feat, _w_feat(hd.conv1), hd.conv1.bias) if x is None else x, hd.bn1)
     x = bn_act_pool(linear(x, hd.conv2.weight[:, :, 0], hd.conv2.bias), hd.bn2)
     x = bn_act(linear(x, hd.conv3.weight[:, :, 0], hd.conv3.bias), hd.bn3)
     x = hd.drop1(x)
@@ -403,11 +460,17 @@ def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=Non
     feat = encoder(face.encoder, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
     if cut is not None:
         feat = cut.split(feat)
-    back, h1, h2 = ph_predictor(face.ph_pred, feat)
-    recon = decoder(face.decoder, feat, back)
-    green = point_head(net.rot_green, feat)
-    red = point_head(net.rot_red, feat)
-    ts = point_head(net.ts, feat)
+    # the five layers over `feat` as one autograd node: d feat is accumulated inside their dx GEMMs (_FeatConsumers)
+    w1 = lambda conv: conv.weight[:, :, 0]
+    dec0 = face.decoder.conv1d_block[0]
+    x5, xd, xg, xr, xt = feat_consumers(feat, [(w1(face.ph_pred.conv_5[0]), None), (w1(dec0), dec0.bias),
+                                               (w1(net.rot_green.conv1), net.rot_green.conv1.bias),
+                                               (w1(net.rot_red.conv1), net.rot_red.conv1.bias), (w1(net.ts.conv1), net.ts.conv1.bias)])
+    back, h1, h2 = ph_predictor(face.ph_pred, feat, x5)
+    recon = decoder(face.decoder, feat, back, xd)
+    green = point_head(net.rot_green, feat, xg)
+    red = point_head(net.rot_red, feat, xr)
+    ts = point_head(net.ts, feat, xt)
     out = dict()
     if train_keys:
         out["recon"] = recon + mean
