@@ -556,6 +556,18 @@ int tgp_conv_max_fused(const tgp_conv_max_fused_args *args, tgp_stream_t stream)
 /* w2 (heads, 256, 1024) fp32 -> heads * 1024 * 256 * 2 fp16 in the kernel's operand order (hi / lo planes, K permuted). */
 int tgp_heads_pack_w2(const float *w2, int heads, void *out, tgp_stream_t stream);
 
+/* ---- the factored wide layers in TRAINING (ABI 4; this repo's engine, no reference counterpart: the reference multiplies the
+ * up-sampled copies, FaceRecon.py:70-77) -----------------------------------------------------------------------------------------
+ * The layers that read the concat buffer run as  W_fine x fine[i] + P1[near1(i)] + P2[near2(i)]  (tgp_gemm_args.gres1 / gres2); the
+ * backward of the two fetches is  d P[r] = sum of d Y[i] over the points i whose nearest coarse point is r.
+ * tgp_child_lists inverts near (B, n) (parent of every point: ids in [0, R), or b*R + that when global_ids) into CSR child lists: ptr (B*R + 1) int32,
+ * idx (B*n) int32 global rows b*n + i, children in point order.  R <= 4096, n <= 8192.
+ * tgp_segsum_rows: out[r][:C] = sum of g[idx[k]][:C] over k in [ptr[r], ptr[r+1]) in list order -- no atomics, bit-repeatable.
+ * C, ldg, ldo multiples of 4; g, out 16-byte aligned. */
+int tgp_child_lists(const int32_t *near, int B, int n, int R, int global_ids, int32_t *ptr, int32_t *idx, tgp_stream_t stream);
+int tgp_segsum_rows(const float *g, int ldg, int C, const int32_t *ptr, const int32_t *idx, int R, float *out, int ldo,
+                    tgp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

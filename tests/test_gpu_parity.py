@@ -1271,6 +1271,91 @@ def test_backward_full_network_vs_oracle_autograd(ops, B, N, seed, gemm_mode):
     assert not unused, unused
 
 
+@pytest.mark.parametrize("B,n,R", [(3, 1028, 257), (2, 1028, 64), (1, 5, 7), (4, 100, 1), (2, 8192, 4096)])
+def test_child_lists_and_segsum_vs_index_add(ops, B, n, R):
+    """tgp_child_lists / tgp_segsum_rows (the backward of the factored layers' row fetch): the CSR lists hold every point exactly
+    once, under its parent, in point order; the segment sums equal an fp64 index_add; childless parents get zeros; two runs agree
+    bit for bit (no atomics)."""
+    gen = torch.Generator().manual_seed(B * 1000 + n + R)
+    near = torch.randint(0, R, (B, n), generator=gen, dtype=torch.int32)
+    if R > 2:
+        near[near == 1] = 0                                   # a childless parent
+    for global_ids in (False, True):
+        ids = near + (torch.arange(B, dtype=torch.int32).view(B, 1) * R if global_ids else 0)
+        ptr, idx = ops.child_lists(g(ids), R, global_ids=global_ids)
+        ptr, idx = ptr.cpu().long(), idx.cpu().long()
+        assert ptr[0] == 0 and ptr[-1] == B * n and bool((ptr[1:] >= ptr[:-1]).all())
+        assert torch.equal(idx.sort().values, torch.arange(B * n))
+        parent = (near.long() + torch.arange(B).view(B, 1) * R).reshape(-1)
+        owner = torch.repeat_interleave(torch.arange(B * R), ptr[1:] - ptr[:-1])
+        assert torch.equal(parent[idx], owner)
+        same = owner[1:] == owner[:-1]
+        assert bool((idx[1:][same] > idx[:-1][same]).all())   # children in point order
+    C = 132
+    wide = torch.randn(B * n, C + 8, generator=gen)
+    ptr, idx = ops.child_lists(g(near), R)
+    out = torch.full((B * R, C + 4), 7.0, device=DEV)
+    got = ops.segsum_rows(g(wide)[:, 4:4 + C], ptr, idx, out=out[:, :C])
+    want = torch.zeros(B * R, C, dtype=torch.float64).index_add_(0, parent, wide[:, 4:4 + C].double())
+    assert torch.allclose(got.cpu().double(), want, atol=1e-5, rtol=1e-6)
+    assert bool((out[:, C:] == 7.0).all())
+    assert torch.equal(ops.segsum_rows(g(wide)[:, 4:4 + C], ptr, idx), got.contiguous())
+
+
+@pytest.mark.parametrize("gemm_mode", ["fp32", "split16"], indirect=True)
+def test_feat_consumers_factored_vs_fp64_concat(ops, gemm_mode):
+    """_FeatConsumersFactored (the layers over the concat buffer with the up-sampling factored out, training path) against the
+    reference's formulation -- multiply the concatenated, up-sampled buffer (FaceRecon.py:70-77) -- in fp64 with torch autograd:
+    outputs and the gradients of every operand.  No decision (ReLU / max) separates the two sides here, so the bars are tight:
+    1e-4 relative L2 in the exact mode, 2e-3 in the fp16-split mode (gradients spanning three decades in one launch)."""
+    from tgpose_amd import autograd as A
+    from tgpose_amd import engine
+    B, N, N1, N2 = 3, 1028, 257, 64
+    gen = torch.Generator().manual_seed(77)
+    rnd = lambda *s: torch.randn(*s, generator=gen)
+    fm0, fm1, fm2, fm3, fm4 = rnd(B, N, 128), rnd(B, N, 128), rnd(B, N1, 256), rnd(B, N1, 256), rnd(B, N2, 512)
+    tail = torch.cat([torch.eye(6)[torch.randint(0, 6, (B,), generator=gen)].view(B, 1, 6).expand(B, N, 6), rnd(B, N, 3)], 2)
+    near1 = torch.randint(0, N1, (B, N), generator=gen)
+    near2 = torch.randint(0, N2, (B, N), generator=gen)
+    layers = [(rnd(1024, 1286) * 0.03, None), (rnd(512, 1286) * 0.03, rnd(512)), (rnd(1024, 1289) * 0.03, rnd(1024))]
+    gscale = [1.0, 1e-2, 1e-3]                                   # the consumers' gradients differ in magnitude, as in the trainer
+    gouts = [rnd(B, N, W.shape[0]) * sc for (W, _), sc in zip(layers, gscale)]
+
+    # fp64, the reference's way
+    leaves64 = [t.double().requires_grad_(True) for t in (fm0, fm1, fm2, fm3, fm4)]
+    W64 = [(W.double().requires_grad_(True), None if b is None else b.double().requires_grad_(True)) for W, b in layers]
+    bidx = torch.arange(B).view(B, 1)
+    feat64 = torch.cat([leaves64[0], leaves64[1], leaves64[2][bidx, near1], leaves64[3][bidx, near1], leaves64[4][bidx, near2],
+                        tail.double()], 2)
+    loss = 0
+    want_y = []
+    for (W, b), go in zip(W64, gouts):
+        y = feat64[:, :, : W.shape[1]] @ W.t() + (0 if b is None else b)
+        want_y.append(y.detach())
+        loss = loss + (y * go.double()).sum()
+    loss.backward()
+
+    # the product's node
+    leaves = [g(t).requires_grad_(True) for t in (fm0, fm1, fm2, fm3, fm4)]
+    Wd = [(g(W).requires_grad_(True), None if b is None else g(b).requires_grad_(True)) for W, b in layers]
+    fine = torch.cat([leaves[0], leaves[1], torch.nn.functional.pad(g(tail), (0, engine.FINE_LD - 256 - 9))], 2)
+    base = torch.arange(B, dtype=torch.int32).view(B, 1)
+    parts = (fine, torch.cat([leaves[2], leaves[3]], 2), leaves[4], g(near1.int() + base * N1), g(near2.int() + base * N2))
+    ys = A.feat_consumers_factored(parts, Wd)
+    torch.autograd.backward(list(ys), [g(go) for go in gouts])
+
+    rel = lambda a, b_: ((a.detach().cpu().double() - b_).norm() / (b_.norm() + 1e-30)).item()
+    bar = 1e-4 if gemm_mode == "fp32" else 2e-3
+    errs = {"y%d" % i: rel(y, w) for i, (y, w) in enumerate(zip(ys, want_y))}
+    errs.update({"d fm_%d" % i: rel(l.grad, l64.grad) for i, (l, l64) in enumerate(zip(leaves, leaves64))})
+    for i, ((W, b), (W6, b6)) in enumerate(zip(Wd, W64)):
+        errs["dW%d" % i] = rel(W.grad, W6.grad)
+        if b is not None:
+            errs["db%d" % i] = rel(b.grad, b6.grad)
+    print("factored consumers (%s): %s" % (gemm_mode, {k: "%.1e" % v for k, v in errs.items()}))
+    assert all(v <= (1e-5 if k.startswith("y") and gemm_mode == "fp32" else bar) for k, v in errs.items()), errs
+
+
 def test_backward_encoder_only_vs_oracle_autograd(ops):
     from tgpose_amd import PoseNet9D, seeded_state_dict
     _, _, PR = _oracle()

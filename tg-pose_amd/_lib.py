@@ -156,6 +156,8 @@ SIGNATURES = {
     "tgp_sort_by_parent": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tgp_roi_cloud": (c_int, [c_vp] * 7 + [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_cloud_select": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, c_vp, c_vp]),
+    "tgp_child_lists": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "tgp_segsum_rows": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
     "tgp_roi_cloud_ex": (c_int, [c_vp] * 7 + [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp]),
     "tgp_cloud_select_ex": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_cloud_sample": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, ctypes.c_uint64, c_vp, c_vp]),

@@ -10,6 +10,8 @@ no-autograd paths of ``engine.py`` are untouched; this module trades fusion for 
 Reference graph restated here: network/fs_net_repo/gcn3d.py:78-112,142-186,210-245, FaceRecon.py:39-86,112-117,139-167,
 PoseR.py:26-39, PoseTs.py:31-45, PoseNet9D.py:33-91.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -120,6 +122,95 @@ class _FeatConsumers(Function):
             dfeat = dx if dx is not None else dfeat
             grads += [dW[:, : ctx.cols[i]] if dW is not None else None, db]
         return (dfeat,) + tuple(grads)
+
+
+class _FeatConsumersFactored(Function):
+    """The same five layers with the nearest-neighbour up-sampling factored out, as the eval forward runs them (engine.pack_factored):
+    feat = [fm_0 | fm_1 | up_1(fm_2) | up_1(fm_3) | up_2(fm_4) | tail] with up() a row fetch (FaceRecon.py:70-75), so
+        y_i = fine Wa_i^T + P1[near1][:, cols_i] + P2[near2][:, cols_i] + b_i,   P1 = [fm_2 | fm_3] Wb^T,  P2 = fm_4 Wc^T
+    with fine = [fm_0 | fm_1 | tail] and Wa_i / Wb / Wc the matching column blocks of the W_i (Wb, Wc stacked over the five layers):
+    the 1024 up-sampled columns are multiplied once per COARSE point (N/4 and N/16 of them).  131 instead of 392 GFLOP forward at
+    B = 32, N = 1028, and the same ratio in both backward GEMMs:
+        d fine += g_i Wa_i,  dWa_i = g_i^T fine,  d P1[r] = sum of g[i] over the children i of r (tgp_segsum_rows: child lists, no
+        atomics),  d[fm_2 | fm_3] = dP1 Wb,  dWb = dP1^T [fm_2 | fm_3]   (level 2 alike)
+    near1 / near2: (B, N) int32 GLOBAL coarse rows (b * N1 + nearest)."""
+
+    @staticmethod
+    def forward(ctx, fine, fm23, fm4, near1, near2, *wb):
+        fine, fm23, fm4 = fine.contiguous(), fm23.contiguous(), fm4.contiguous()
+        B, N, ldf = fine.shape
+        N1, N2 = fm23.shape[1], fm4.shape[1]
+        M = B * N
+        Ws, bs = wb[0::2], wb[1::2]
+        Wb = torch.cat([W[:, 256:768] for W in Ws], 0).contiguous()
+        Wc = torch.cat([W[:, 768:1280] for W in Ws], 0).contiguous()
+        P1 = ops.linear_rows(fm23.view(B * N1, -1), Wb, w_split=_split_if_big(Wb, B * N1))
+        P2 = ops.linear_rows(fm4.view(B * N2, -1), Wc, w_split=_split_if_big(Wc, B * N2))
+        ld = P1.shape[1]
+        outs, Was, tails = [], [], []
+        off = 0
+        for W, b in zip(Ws, bs):
+            n, kt = W.shape[0], W.shape[1] - 1280
+            Wa = F.pad(torch.cat([W[:, :256], W[:, 1280:]], 1), (0, ldf - 256 - kt)).contiguous()
+            y = torch.empty(B, N, n, device=fine.device, dtype=torch.float32)
+            ops.gemm(fine, Wa, y, M=M, N=n, K=ldf, lda=ldf, ldw=ldf, ldc=n, bias=b, rows_per_obj=N, w_split=_split_if_big(Wa, M),
+                     gather1=(P1[:, off:], ld, near1), gather2=(P2[:, off:], ld, near2), flops_ref=2.0 * M * n * W.shape[1])
+            outs.append(y)
+            Was.append(Wa)
+            tails.append(kt)
+            off += n
+        ptr1, idx1 = ops.child_lists(near1, N1, global_ids=True)
+        ptr2, idx2 = ops.child_lists(near2, N2, global_ids=True)
+        ctx.save_for_backward(fine, fm23, fm4, ptr1, idx1, ptr2, idx2, Wb, Wc, *Was)
+        ctx.tails, ctx.has_bias = tails, [b is not None for b in bs]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        fine, fm23, fm4, ptr1, idx1, ptr2, idx2, Wb, Wc, *Was = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        M = fine.shape[0] * fine.shape[1]
+        ld = Wb.shape[0]
+        dP1 = torch.empty(ptr1.numel() - 1, ld, device=fine.device, dtype=torch.float32)
+        dP2 = torch.empty(ptr2.numel() - 1, ld, device=fine.device, dtype=torch.float32)
+        dfine, part, off = None, [], 0
+        need_w = any(need[5 + 2 * i] for i in range(len(Was)))
+        for i, (g, Wa) in enumerate(zip(gs, Was)):
+            n = Wa.shape[0]
+            if g is None:
+                dP1[:, off:off + n] = 0
+                dP2[:, off:off + n] = 0
+                part.append((None, None))
+            else:
+                gc = g.reshape(M, n).contiguous()
+                ops.segsum_rows(gc, ptr1, idx1, out=dP1[:, off:off + n])
+                ops.segsum_rows(gc, ptr2, idx2, out=dP2[:, off:off + n])
+                dx, dWa, db = _linear_backward(fine, Wa, gc, need[0], need[5 + 2 * i], ctx.has_bias[i] and need[6 + 2 * i], dx_accum=dfine)
+                dfine = dx if dx is not None else dfine
+                part.append((dWa, db))
+            off += n
+        dfm23, dWb, _ = _linear_backward(fm23, Wb, dP1, need[1], need_w, False)
+        dfm4, dWc, _ = _linear_backward(fm4, Wc, dP2, need[2], need_w, False)
+        grads, off = [], 0
+        for (dWa, db), Wa, kt in zip(part, Was, ctx.tails):
+            n = Wa.shape[0]
+            dW = None
+            if dWa is not None:
+                dW = torch.cat([dWa[:, :256], dWb[off:off + n], dWc[off:off + n], dWa[:, 256:256 + kt]], 1)
+            grads += [dW, db]
+            off += n
+        return (dfine, dfm23, dfm4, None, None) + tuple(grads)
+
+
+FACTORED = os.environ.get("TGP_TRAIN_FACTORED", "1") != "0"     # the layers over the concat buffer factored over the up-sampling
+
+
+def feat_consumers_factored(parts, layers):
+    """parts: the encoder's (fine, fm23, fm4, near1, near2); layers as feat_consumers (weights UNPADDED: (N, 1286 or 1289))"""
+    flat = []
+    for W, b in layers:
+        flat += [W, b]
+    return _FeatConsumersFactored.apply(*parts, *flat)
 
 
 def feat_consumers(feat, layers):
@@ -369,7 +460,8 @@ class _GraphSource(object):
 
 
 def encoder(enc, xyz, obj_id, sample_idx, graphs, kmax=20, n_cls=6):
-    """Face_Enc.forward (FaceRecon.py:39-86) -> feat (B, N, FEAT_LD): [fm_0..fm_4 | one-hot | xyz | 0 0 0]"""
+    """Face_Enc.forward (FaceRecon.py:39-86) -> feat (B, N, FEAT_LD): [fm_0..fm_4 | one-hot | xyz | 0 0 0], and the operands of
+    the factored layers over it (None when FACTORED is off)"""
     B, N, _ = xyz.shape
     dev = xyz.device
     s1 = sample_idx[0].to(device=dev, dtype=torch.int32)
@@ -388,8 +480,16 @@ def encoder(enc, xyz, obj_id, sample_idx, graphs, kmax=20, n_cls=6):
         near2 = graphs.g.get("up_2", lambda: ops.nn1(xyz, v2)).view(B, N)
         one_hot = torch.zeros(B, n_cls, device=dev).scatter_(1, obj_id.view(-1, 1).long(), 1)
         tail = torch.cat([one_hot.unsqueeze(1).expand(B, N, n_cls), xyz, torch.zeros(B, N, FEAT_LD - FEAT_C - 3, device=dev)], 2)
-    return torch.cat([fm0, fm1, _GatherRows.apply(fm2, near1), _GatherRows.apply(fm3, near1), _GatherRows.apply(fm4, near2),
+        base = torch.arange(B, device=dev, dtype=torch.int32).view(B, 1)
+        near1g, near2g = near1 + base * v1.shape[1], near2 + base * v2.shape[1]
+    feat = torch.cat([fm0, fm1, _GatherRows.apply(fm2, near1), _GatherRows.apply(fm3, near1), _GatherRows.apply(fm4, near2),
                       tail], dim=2)
+    if not FACTORED:
+        return feat, None
+    # the operands of the factored form of the layers over feat (_FeatConsumersFactored): the columns that differ from point to
+    # point, and the two coarse levels
+    fine = torch.cat([fm0, fm1, F.pad(tail, (0, engine.FINE_LD - 256 - tail.shape[2]))], dim=2)
+    return feat, (fine, torch.cat([fm2, fm3], dim=2), fm4, near1g, near2g)
 
 
 def _w_feat(conv, cols=FEAT_C):
@@ -453,19 +553,26 @@ def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=Non
     if net.only_encoder:
         face = net.face_enc
         graphs = _GraphSource(points.device, inject, record, "face_enc.encoder.")
-        feat = encoder(face.encoder, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
-        return dict(feat_global=colmax(feat[:, :, :FEAT_C]), recon=decoder(face.decoder, feat, None))
+        feat, parts = encoder(face.encoder, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
+        dec0 = face.decoder.conv1d_block[0]
+        xd = feat_consumers_factored(parts, [(dec0.weight[:, :, 0], dec0.bias)])[0] if parts is not None else None
+        return dict(feat_global=colmax(feat[:, :, :FEAT_C]), recon=decoder(face.decoder, feat, None, xd))
     face = net.face_all
     graphs = _GraphSource(points.device, inject, record, "face_all.encoder.")
-    feat = encoder(face.encoder, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
+    feat, parts = encoder(face.encoder, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
     if cut is not None:
-        feat = cut.split(feat)
-    # the five layers over `feat` as one autograd node: d feat is accumulated inside their dx GEMMs (_FeatConsumers)
+        if parts is None:
+            feat = cut.split(feat)[0]
+        else:
+            feat, fine, fm23, fm4 = cut.split(feat, *parts[:3])
+            parts = (fine, fm23, fm4) + parts[3:]
+    # the five layers over `feat` as one autograd node: factored over the up-sampling (_FeatConsumersFactored), or over the concat
+    # buffer with d feat accumulated inside their dx GEMMs (_FeatConsumers)
     w1 = lambda conv: conv.weight[:, :, 0]
     dec0 = face.decoder.conv1d_block[0]
-    x5, xd, xg, xr, xt = feat_consumers(feat, [(w1(face.ph_pred.conv_5[0]), None), (w1(dec0), dec0.bias),
-                                               (w1(net.rot_green.conv1), net.rot_green.conv1.bias),
-                                               (w1(net.rot_red.conv1), net.rot_red.conv1.bias), (w1(net.ts.conv1), net.ts.conv1.bias)])
+    layers = [(w1(face.ph_pred.conv_5[0]), None), (w1(dec0), dec0.bias), (w1(net.rot_green.conv1), net.rot_green.conv1.bias),
+              (w1(net.rot_red.conv1), net.rot_red.conv1.bias), (w1(net.ts.conv1), net.ts.conv1.bias)]
+    x5, xd, xg, xr, xt = feat_consumers(feat, layers) if parts is None else feat_consumers_factored(parts, layers)
     back, h1, h2 = ph_predictor(face.ph_pred, feat, x5)
     recon = decoder(face.decoder, feat, back, xd)
     green = point_head(net.rot_green, feat, xg)
@@ -490,21 +597,23 @@ def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=Non
 class EncoderCut(object):
     """Splits one backward pass at the encoder's output: the layers after `feat` see a detached copy that collects d loss / d feat;
     ``backward_encoder()`` then pushes that gradient through the encoder.  Two calls instead of one ``loss.backward()``, same
-    gradients (the encoder's only consumer is `feat`)."""
+    gradients (the later layers read nothing of the encoder but what split() was given)."""
 
     def __init__(self):
-        self.feat = self.leaf = None
+        self.outs = self.leaves = None
 
-    def split(self, feat):
-        self.feat = feat
-        self.leaf = feat.detach().requires_grad_(True)
-        return self.leaf
+    def split(self, *outs):
+        """outs: the encoder's outputs that the later layers read (feat; with the factored layers also fine, [fm_2 | fm_3], fm_4)"""
+        self.outs = outs
+        self.leaves = tuple(t.detach().requires_grad_(True) for t in outs)
+        return self.leaves
 
     def backward_encoder(self):
-        self.feat.backward(self.leaf.grad)
+        pairs = [(t, l.grad) for t, l in zip(self.outs, self.leaves) if l.grad is not None]
+        torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
 
     def clear(self):
-        self.feat = self.leaf = None
+        self.outs = self.leaves = None
 
 
 # parameters whose gradients are complete when the first backward segment (everything after the encoder) ends

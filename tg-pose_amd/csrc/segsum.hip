@@ -1,0 +1,79 @@
+// Backward of "fetch the row of my nearest coarse point" (the factored wide layers' gathered residuals, csrc/gemm.hip gemm_epilogue_lds;
+// FaceRecon.py:70-75 nearest up-sampling folded into the layers that read the concat buffer): d P[r] = sum over the points i whose
+// nearest coarse point is r of d Y[i].  A scatter-add with float atomics would issue one atomic per element of d Y (M x 4608 of them
+// per step) in an order that changes from run to run; here the map point -> parent is inverted once per forward into child lists
+// (counting sort, children in point order) and each coarse row then SUMS its children's rows: coalesced 16-byte reads, every row
+// of d Y read once, fixed order, no atomics.
+#include "tgp_common.h"
+
+#define CL_MAX_PARENTS 4096
+
+// one workgroup per object: ptr[b * R + r] = first slot of parent r's children in idx (global), idx[...] = global rows (b * n + i)
+__global__ __launch_bounds__(256) void child_lists_kernel(const int32_t *__restrict__ near, int B, int n, int R, int gbase,
+                                                          int32_t *__restrict__ ptr, int32_t *__restrict__ idx)
+{
+    __shared__ int s_cnt[CL_MAX_PARENTS];
+    extern __shared__ int s_near[];                       // n parent ids of this object
+    const int b = blockIdx.x;
+    const int32_t *nb = near + (size_t)b * n;
+    for (int r = threadIdx.x; r < R; r += blockDim.x) s_cnt[r] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        int p = nb[i] - b * gbase;                        // global ids carry the object's offset b * R
+        p = p < 0 ? 0 : (p >= R ? R - 1 : p);             // (a parent id outside [0, R) would be the caller's bug: clamped, never a fault)
+        s_near[i] = p;
+        atomicAdd(&s_cnt[p], 1);                          // integer counts: order-free
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                               // exclusive scan, R <= 4096: a few microseconds
+        int run = 0;
+        for (int r = 0; r < R; ++r) {
+            const int c = s_cnt[r];
+            s_cnt[r] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        int pos = s_cnt[r];
+        ptr[(size_t)b * R + r] = b * n + pos;
+        for (int i = 0; i < n; ++i)                       // children in point order: deterministic sums downstream
+            if (s_near[i] == r) idx[(size_t)b * n + pos++] = b * n + i;
+    }
+    if (b == B - 1 && threadIdx.x == 0) ptr[(size_t)B * R] = B * n;
+}
+
+extern "C" int tgp_child_lists(const int32_t *near, int B, int n, int R, int global_ids, int32_t *ptr, int32_t *idx, tgp_stream_t stream)
+{
+    TGP_REQUIRE(near && ptr && idx && B > 0 && n > 0 && R > 0);
+    if (R > CL_MAX_PARENTS || n > 8192 || (int64_t)B * n >= 0x7fffffff) return TGP_EUNSUPPORTED;
+    hipLaunchKernelGGL(child_lists_kernel, dim3(B), dim3(256), (size_t)n * sizeof(int), tgp_hs(stream), near, B, n, R,
+                       global_ids ? R : 0, ptr, idx);
+    return TGP_LAUNCH_RESULT();
+}
+
+// out[r][c] = sum over k in [ptr[r], ptr[r + 1]) of g[idx[k]][c], children in list order; a workgroup per (parent, 1024 columns)
+__global__ __launch_bounds__(256) void segsum_rows_kernel(const float *__restrict__ g, int ldg, int C, const int32_t *__restrict__ ptr,
+                                                          const int32_t *__restrict__ idx, float *__restrict__ out, int ldo)
+{
+    const int r = blockIdx.x;
+    const int c = blockIdx.y * 1024 + threadIdx.x * 4;
+    if (c >= C) return;
+    const int k0 = ptr[r], k1 = ptr[r + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = k0; k < k1; ++k) {
+        const float4 v = *reinterpret_cast<const float4 *>(g + (int64_t)idx[k] * ldg + c);
+        acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(out + (int64_t)r * ldo + c) = acc;
+}
+
+extern "C" int tgp_segsum_rows(const float *g, int ldg, int C, const int32_t *ptr, const int32_t *idx, int R, float *out, int ldo,
+                               tgp_stream_t stream)
+{
+    TGP_REQUIRE(g && ptr && idx && out && C > 0 && R > 0 && ldg >= C && ldo >= C);
+    TGP_REQUIRE((C & 3) == 0 && (ldg & 3) == 0 && (ldo & 3) == 0 &&
+                ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(out)) & 15) == 0);
+    hipLaunchKernelGGL(segsum_rows_kernel, dim3(R, tgp_cdiv(C, 1024)), dim3(256), 0, tgp_hs(stream), g, ldg, C, ptr, idx, out, ldo);
+    return TGP_LAUNCH_RESULT();
+}

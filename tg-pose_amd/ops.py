@@ -878,6 +878,34 @@ def gather_rows_bwd(dy, idx, n_src):
     return dsrc
 
 
+def child_lists(near, R, global_ids=False):
+    """near (B, n) int32 parent of every point, in [0, R) (global_ids: b * R + that) -> (ptr (B*R + 1,), idx (B*n,)) int32: CSR
+    child lists over the B*R global parent rows, idx = global point rows b*n + i, children in point order"""
+    _i32(near, "near")
+    near = near.contiguous()
+    B, n = near.shape
+    ptr = torch.empty(B * R + 1, device=near.device, dtype=torch.int32)
+    idx = torch.empty(B * n, device=near.device, dtype=torch.int32)
+    check(_lib.lib().tgp_child_lists(_p(near), B, n, R, 1 if global_ids else 0, _p(ptr), _p(idx), _stream(near)), "tgp_child_lists")
+    return ptr, idx
+
+
+@_timed("graph")
+def segsum_rows(g, ptr, idx, out=None):
+    """g (M, C) rows -> out (R, C), R = ptr.numel() - 1: out[r] = sum of g[idx[k]] over k in [ptr[r], ptr[r+1]); out may be a
+    column slice of a wider buffer"""
+    g, ldg = _rows(g, "g")
+    C = g.shape[-1]
+    R = ptr.numel() - 1
+    if out is None:
+        out = torch.empty(R, C, device=g.device, dtype=torch.float32)
+    out, ldo = _rows(out, "out")
+    if tuple(out.shape) != (R, C):
+        raise ValueError("segsum_rows: out must be (%d, %d)" % (R, C))
+    check(_lib.lib().tgp_segsum_rows(_p(g), ldg, C, _p(ptr), _p(idx), R, _p(out), ldo, _stream(g)), "tgp_segsum_rows")
+    return out
+
+
 def pose_transform(points, R, t, s):
     """out = (R^T (points - t)) * s per object: points (B,n,3), R (B,3,3), t, s (B,3)"""
     points, R, t, s = points.contiguous(), R.contiguous(), t.contiguous(), s.contiguous()
