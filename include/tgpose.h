@@ -568,6 +568,24 @@ int tgp_child_lists(const int32_t *near, int B, int n, int R, int global_ids, in
 int tgp_segsum_rows(const float *g, int ldg, int C, const int32_t *ptr, const int32_t *idx, int R, float *out, int ldo,
                     tgp_stream_t stream);
 
+/* ---- scatter-free backward of the graph layers (ABI 4; csrc/graph_bwd.hip) ---------------------------------------------------------
+ * Same gradients as tgp_nbrmax_bwd / tgp_gconv_hs_bwd (the reference's autograd: max backward + index_add, gcn3d.py:157-180,210-245)
+ * without float atomics: the neighbour lists are inverted once (tgp_reverse_graph), pass 1 stores every (row, channel)'s winning slot,
+ * pass 2 sums per SOURCE row over its reverse list.  Outputs are written densely (no zero fill by the caller) and are bit-repeatable.
+ * tgp_reverse_graph: idx (B, n_rows, k) int32 ids in [0, n_src) -> rptr (B*n_src + 1) int32, rent (B*n_rows*k) int32 = (row << 6) | slot,
+ * each list ascending.  k <= 64, n_src <= 8192, (n_rows*k + 2*n_src) * 4 <= 150 KB (one workgroup sorts an object in LDS), else
+ * TGP_EUNSUPPORTED.
+ * tgp_nbrmax_bwd_gather: arg_ws B*n_rows*C bytes; C % 4 == 0, C / 4 a divisor of 256, strides % 4 == 0, 16-byte aligned, else
+ * TGP_EUNSUPPORTED.  tgp_gconv_hs_bwd_gather: workspace as tgp_gconv_bwd_workspace_floats; arg_ws B*n*7C bytes, contrib_ws B*n*7C
+ * floats; C in {128, 256, 512}, k <= 63, 16-byte aligned operands, else TGP_EUNSUPPORTED. */
+int tgp_reverse_graph(const int32_t *idx, int B, int n_rows, int k, int n_src, int32_t *rptr, int32_t *rent, tgp_stream_t stream);
+int tgp_nbrmax_bwd_gather(const float *src, int ld_src, const int32_t *idx, const int32_t *rptr, const int32_t *rent, int B, int n_src,
+                          int n_rows, int k, int C, const float *dy, int lddy, int per_object, float scale, uint8_t *arg_ws,
+                          float *dsrc, int ld_dsrc, tgp_stream_t stream);
+int tgp_gconv_hs_bwd_gather(const float *xyz, const int32_t *idx, const int32_t *rptr, const int32_t *rent, const float *proj, int ldp,
+                            const float *sdn, const float *dg, int ldg, int B, int n, int k, int S, int C, float *dproj, int lddp,
+                            float *dsdn, float *workspace, uint8_t *arg_ws, float *contrib_ws, tgp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1302,6 +1302,76 @@ def test_child_lists_and_segsum_vs_index_add(ops, B, n, R):
     assert torch.equal(ops.segsum_rows(g(wide)[:, 4:4 + C], ptr, idx), got.contiguous())
 
 
+@pytest.mark.parametrize("B,n_rows,k,n_src", [(3, 257, 20, 257), (2, 1028, 20, 1028), (2, 64, 4, 257), (1, 5, 3, 9), (2, 300, 64, 300)])
+def test_reverse_graph_lists(ops, B, n_rows, k, n_src):
+    """tgp_reverse_graph: every (row, slot) appears exactly once, in the list of the source it names, lists ascending; hubs (one
+    source named by every row) and sources nobody names included."""
+    gen = torch.Generator().manual_seed(B + n_rows + k)
+    idx = torch.randint(0, n_src, (B, n_rows, k), generator=gen, dtype=torch.int32)
+    idx[:, :, 0] = 2                                           # a hub
+    idx[idx == 1] = 0                                          # a source without entries
+    rptr, rent = ops.reverse_graph(g(idx), n_src)
+    rptr, rent = rptr.cpu().long(), rent.cpu().long()
+    E = n_rows * k
+    assert rptr[0] == 0 and rptr[-1] == B * E and bool((rptr[1:] >= rptr[:-1]).all())
+    owner = torch.repeat_interleave(torch.arange(B * n_src), rptr[1:] - rptr[:-1])      # global source of every entry
+    b = owner // n_src
+    row, slot = rent >> 6, rent & 63
+    assert bool((slot < k).all()) and bool((row < n_rows).all())
+    assert torch.equal(idx.long()[b, row, slot], owner % n_src)
+    flat = (b * E + row * k + slot).sort().values
+    assert torch.equal(flat, torch.arange(B * E))
+    same = owner[1:] == owner[:-1]
+    assert bool((rent[1:][same] > rent[:-1][same]).all())
+    assert ops.reverse_graph(g(idx[:, :, :1].expand(B, n_rows, 65).contiguous()), n_src) is None      # k > 64: the caller falls back
+
+
+@pytest.mark.parametrize("B,n_src,n_rows,k,C,per_object", [(3, 257, 257, 20, 256, True), (2, 1028, 1028, 20, 128, True),
+                                                            (2, 1028, 257, 4, 128, False), (2, 257, 64, 4, 256, False),
+                                                            (2, 64, 64, 8, 512, True)])
+def test_nbrmax_bwd_gather_vs_scatter(ops, B, n_src, n_rows, k, C, per_object):
+    """the scatter-free backward of the neighbourhood max (ORL pooling, Pool_layer) against the atomic scatter and an fp64 index_add
+    of the same arg-max; ties (duplicated source rows) go to the first slot on both sides; two runs agree bit for bit."""
+    gen = torch.Generator().manual_seed(C + k)
+    src = torch.randn(B, n_src, C, generator=gen)
+    src[:, 3] = src[:, 1]                                      # ties
+    idx = torch.randint(0, n_src, (B, n_rows, k), generator=gen, dtype=torch.int32)
+    dy = torch.randn(B, C, generator=gen) if per_object else torch.randn(B, n_rows, C, generator=gen)
+    scale = 1.0 / n_rows if per_object else 1.0
+    rev = ops.reverse_graph(g(idx), n_src)
+    got = ops.nbrmax_bwd_gather(g(src), g(idx), rev, g(dy), per_object=per_object, scale=scale)
+    old = ops.nbrmax_bwd(g(src), g(idx), g(dy), per_object=per_object, scale=scale)
+    bidx = torch.arange(B).view(B, 1, 1)
+    vals = src.double()[bidx, idx.long()]                      # (B, n_rows, k, C)
+    win = torch.gather(idx.long().unsqueeze(-1).expand(B, n_rows, k, C), 2, vals.argmax(2, keepdim=True)).squeeze(2)   # first max
+    want = torch.zeros(B, n_src, C, dtype=torch.float64)
+    contrib = (dy.double().unsqueeze(1).expand(B, n_rows, C) * scale) if per_object else dy.double()
+    want.scatter_add_(1, win, contrib)
+    assert torch.allclose(got.cpu().double(), want, atol=1e-5, rtol=1e-5)
+    assert torch.allclose(old.cpu().double(), want, atol=1e-5, rtol=1e-5)
+    assert torch.equal(ops.nbrmax_bwd_gather(g(src), g(idx), rev, g(dy), per_object=per_object, scale=scale), got)
+
+
+@pytest.mark.parametrize("B,n,k,C", [(2, 300, 20, 128), (2, 257, 20, 256), (3, 64, 8, 512), (1, 40, 5, 128)])
+def test_gconv_hs_bwd_gather_vs_scatter(ops, B, n, k, C):
+    """the scatter-free backward of HS_layer.graph_conv (gcn3d.py:157-180) against the first version's atomic scatter on the same
+    inputs: d proj (centre and support halves) and d directions to summation-order accuracy; two runs agree bit for bit."""
+    gen = torch.Generator().manual_seed(n + C)
+    xyz = torch.randn(B, n, 3, generator=gen)
+    idx = torch.randint(0, n, (B, n, k), generator=gen, dtype=torch.int32)
+    idx[:, :, 0] = torch.arange(n, dtype=torch.int32)          # the point itself first, as kNN gives it (zero direction)
+    proj = torch.randn(B, n, 8 * C, generator=gen)
+    sdn = torch.nn.functional.normalize(torch.randn(3, 7 * C, generator=gen), dim=0)
+    dg = torch.randn(B, n, C, generator=gen)
+    rev = ops.reverse_graph(g(idx), n)
+    dproj, dsdn = ops.gconv_hs_bwd_gather(g(xyz), g(idx), rev, g(proj), g(sdn), g(dg), 7, C)
+    dproj0, dsdn0 = ops.gconv_hs_bwd(g(xyz), g(idx), g(proj), g(sdn), g(dg), 7, C)
+    assert torch.allclose(dproj, dproj0, atol=2e-5, rtol=1e-5), (dproj - dproj0).abs().max()
+    assert torch.allclose(dsdn, dsdn0, atol=1e-4 * float(dsdn0.abs().max()), rtol=0), (dsdn - dsdn0).abs().max()
+    again = ops.gconv_hs_bwd_gather(g(xyz), g(idx), rev, g(proj), g(sdn), g(dg), 7, C)
+    assert torch.equal(again[0], dproj) and torch.equal(again[1], dsdn)
+
+
 @pytest.mark.parametrize("gemm_mode", ["fp32", "split16"], indirect=True)
 def test_feat_consumers_factored_vs_fp64_concat(ops, gemm_mode):
     """_FeatConsumersFactored (the layers over the concat buffer with the up-sampling factored out, training path) against the
@@ -1340,7 +1410,9 @@ def test_feat_consumers_factored_vs_fp64_concat(ops, gemm_mode):
     Wd = [(g(W).requires_grad_(True), None if b is None else g(b).requires_grad_(True)) for W, b in layers]
     fine = torch.cat([leaves[0], leaves[1], torch.nn.functional.pad(g(tail), (0, engine.FINE_LD - 256 - 9))], 2)
     base = torch.arange(B, dtype=torch.int32).view(B, 1)
-    parts = (fine, torch.cat([leaves[2], leaves[3]], 2), leaves[4], g(near1.int() + base * N1), g(near2.int() + base * N2))
+    n1g, n2g = g(near1.int() + base * N1), g(near2.int() + base * N2)
+    parts = (fine, torch.cat([leaves[2], leaves[3]], 2), leaves[4], n1g, n2g, ops.child_lists(n1g, N1, global_ids=True),
+             ops.child_lists(n2g, N2, global_ids=True))
     ys = A.feat_consumers_factored(parts, Wd)
     torch.autograd.backward(list(ys), [g(go) for go in gouts])
 
@@ -1354,6 +1426,33 @@ def test_feat_consumers_factored_vs_fp64_concat(ops, gemm_mode):
             errs["db%d" % i] = rel(b.grad, b6.grad)
     print("factored consumers (%s): %s" % (gemm_mode, {k: "%.1e" % v for k, v in errs.items()}))
     assert all(v <= (1e-5 if k.startswith("y") and gemm_mode == "fp32" else bar) for k, v in errs.items()), errs
+
+
+def test_backward_full_network_is_bit_repeatable(ops):
+    """Round 3: with the scatter-free backward of the graph layers (reverse neighbour lists, child lists of the up-sampling) no
+    float atomic is left in loss.backward() through PoseNet9D: two runs on the same inputs give bit-identical gradients for every
+    parameter.  (The first version scattered with hardware atomics, as the reference's CUDA autograd does: equal to rounding only.)"""
+    from tgpose_amd import FLAGS
+    B, N, seed = 3, 1028, 42
+    pts, obj = synth_points(B, N, seed)
+    torch.manual_seed(seed)
+    i1 = torch.randperm(N)[: N // 4]
+    sample = (i1, torch.randperm(i1.numel())[: i1.numel() // 4])
+    runs = []
+    FLAGS.train = 1
+    try:
+        for _ in range(2):
+            net = _train_net(seed)
+            out = net(g(pts), g(obj), sample_idx=sample)
+            gen = torch.Generator().manual_seed(5)
+            loss = sum((v * g(torch.randn(v.shape, generator=gen))).sum() for k, v in sorted(out.items()))
+            loss.backward()
+            runs.append({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    finally:
+        FLAGS.train = 0
+    assert set(runs[0]) == set(runs[1]) and len(runs[0]) > 100
+    differ = [k for k in runs[0] if not torch.equal(runs[0][k], runs[1][k])]
+    assert not differ, differ
 
 
 def test_backward_encoder_only_vs_oracle_autograd(ops):
@@ -1442,6 +1541,9 @@ class _Renamer(object):
 
     def __call__(self, name, level, x, k):
         return self.graphs("rf" if name.endswith(".rf") else "orl_xyz", level, x, k)
+
+    def rev(self, idx, n_src):
+        return self.graphs.rev(idx, n_src)
 
 
 def test_surface_layer_backward_vs_oracle_autograd(ops):

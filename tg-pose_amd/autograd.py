@@ -47,7 +47,7 @@ def _linear_backward(x, W, dy, need_dx, need_dw, need_db, dx_accum=None):
     x2 = x.reshape(-1, K)
     dx = dW = db = None
     rows = dy2.shape[0]
-    dx_f16 = need_dx and ops.GEMM_MODE == "split16" and ops.TN_SPLIT and ops._routes_to_big_tile(rows, K)
+    dx_f16 = need_dx and ops.GEMM_MODE == "split16" and ops.TN_SPLIT and ops._routes_to_big_tile(rows, K, 1, True)
     dw_f16 = need_dw and ops.tn_split_ok(rows, N, K)
     dyc = dy2.contiguous()
     sc = ops.absmax_scale(dyc) if (dx_f16 or dw_f16) else None
@@ -133,10 +133,10 @@ class _FeatConsumersFactored(Function):
     B = 32, N = 1028, and the same ratio in both backward GEMMs:
         d fine += g_i Wa_i,  dWa_i = g_i^T fine,  d P1[r] = sum of g[i] over the children i of r (tgp_segsum_rows: child lists, no
         atomics),  d[fm_2 | fm_3] = dP1 Wb,  dWb = dP1^T [fm_2 | fm_3]   (level 2 alike)
-    near1 / near2: (B, N) int32 GLOBAL coarse rows (b * N1 + nearest)."""
+    near1 / near2: (B, N) int32 GLOBAL coarse rows (b * N1 + nearest); lists1 / lists2: ops.child_lists of the two levels."""
 
     @staticmethod
-    def forward(ctx, fine, fm23, fm4, near1, near2, *wb):
+    def forward(ctx, fine, fm23, fm4, near1, near2, lists1, lists2, *wb):
         fine, fm23, fm4 = fine.contiguous(), fm23.contiguous(), fm4.contiguous()
         B, N, ldf = fine.shape
         N1, N2 = fm23.shape[1], fm4.shape[1]
@@ -159,8 +159,7 @@ class _FeatConsumersFactored(Function):
             Was.append(Wa)
             tails.append(kt)
             off += n
-        ptr1, idx1 = ops.child_lists(near1, N1, global_ids=True)
-        ptr2, idx2 = ops.child_lists(near2, N2, global_ids=True)
+        (ptr1, idx1), (ptr2, idx2) = lists1, lists2
         ctx.save_for_backward(fine, fm23, fm4, ptr1, idx1, ptr2, idx2, Wb, Wc, *Was)
         ctx.tails, ctx.has_bias = tails, [b is not None for b in bs]
         return tuple(outs)
@@ -174,7 +173,7 @@ class _FeatConsumersFactored(Function):
         dP1 = torch.empty(ptr1.numel() - 1, ld, device=fine.device, dtype=torch.float32)
         dP2 = torch.empty(ptr2.numel() - 1, ld, device=fine.device, dtype=torch.float32)
         dfine, part, off = None, [], 0
-        need_w = any(need[5 + 2 * i] for i in range(len(Was)))
+        need_w = any(need[7 + 2 * i] for i in range(len(Was)))
         for i, (g, Wa) in enumerate(zip(gs, Was)):
             n = Wa.shape[0]
             if g is None:
@@ -185,7 +184,7 @@ class _FeatConsumersFactored(Function):
                 gc = g.reshape(M, n).contiguous()
                 ops.segsum_rows(gc, ptr1, idx1, out=dP1[:, off:off + n])
                 ops.segsum_rows(gc, ptr2, idx2, out=dP2[:, off:off + n])
-                dx, dWa, db = _linear_backward(fine, Wa, gc, need[0], need[5 + 2 * i], ctx.has_bias[i] and need[6 + 2 * i], dx_accum=dfine)
+                dx, dWa, db = _linear_backward(fine, Wa, gc, need[0], need[7 + 2 * i], ctx.has_bias[i] and need[8 + 2 * i], dx_accum=dfine)
                 dfine = dx if dx is not None else dfine
                 part.append((dWa, db))
             off += n
@@ -199,14 +198,14 @@ class _FeatConsumersFactored(Function):
                 dW = torch.cat([dWa[:, :256], dWb[off:off + n], dWc[off:off + n], dWa[:, 256:256 + kt]], 1)
             grads += [dW, db]
             off += n
-        return (dfine, dfm23, dfm4, None, None) + tuple(grads)
+        return (dfine, dfm23, dfm4, None, None, None, None) + tuple(grads)
 
 
 FACTORED = os.environ.get("TGP_TRAIN_FACTORED", "1") != "0"     # the layers over the concat buffer factored over the up-sampling
 
 
 def feat_consumers_factored(parts, layers):
-    """parts: the encoder's (fine, fm23, fm4, near1, near2); layers as feat_consumers (weights UNPADDED: (N, 1286 or 1289))"""
+    """parts: the encoder's (fine, fm23, fm4, near1, near2, lists1, lists2); layers as feat_consumers (weights UNPADDED: (N, 1286 or 1289))"""
     flat = []
     for W, b in layers:
         flat += [W, b]
@@ -306,35 +305,49 @@ class _GConvSurface(Function):
         return None, None, ops.gconv_surface_bwd(xyz, idx, sdn.contiguous(), dg.contiguous(), S, ctx.C), None
 
 
+# The backward of the graph layers without float atomics (csrc/graph_bwd.hip): reverse neighbour lists + two dense passes.  0: the
+# first version's scatter with hardware atomics (csrc/gconv_bwd.hip), also the fallback for shapes the gather kernels do not take.
+SCATTER_FREE = os.environ.get("TGP_SCATTER_FREE", "1") != "0"
+
+
 class _GConvHS(Function):
+    """rev: ops.reverse_graph(idx, n) or None (-> the atomic scatter)"""
+
     @staticmethod
-    def forward(ctx, xyz, idx, proj, sdn, C):
+    def forward(ctx, xyz, idx, proj, sdn, C, rev=None):
         proj = proj.contiguous()
         g = ops.gconv_hs(xyz, idx, proj, sdn.contiguous(), S, C)
         ctx.save_for_backward(xyz, idx, proj, sdn)
-        ctx.C = C
+        ctx.C, ctx.rev = C, rev
         return g
 
     @staticmethod
     def backward(ctx, dg):
         xyz, idx, proj, sdn = ctx.saved_tensors
-        dproj, dsdn = ops.gconv_hs_bwd(xyz, idx, proj, sdn.contiguous(), dg.contiguous(), S, ctx.C)
-        return None, None, dproj, dsdn, None
+        if ctx.rev is not None and ctx.C in (128, 256, 512) and idx.shape[2] <= 63:
+            dproj, dsdn = ops.gconv_hs_bwd_gather(xyz, idx, ctx.rev, proj, sdn.contiguous(), dg.contiguous(), S, ctx.C)
+        else:
+            dproj, dsdn = ops.gconv_hs_bwd(xyz, idx, proj, sdn.contiguous(), dg.contiguous(), S, ctx.C)
+        return None, None, dproj, dsdn, None, None
 
 
 class _NbrMaxMean(Function):
     """get_ORL_global without the repeat: mean over points of the max over each point's neighbours -> (B, C)"""
 
     @staticmethod
-    def forward(ctx, g, idx):
+    def forward(ctx, g, idx, rev=None):
         g = g.contiguous()
         ctx.save_for_backward(g, idx)
+        ctx.rev = rev
         return ops.orl_global(g, idx)
 
     @staticmethod
     def backward(ctx, dglob):
         g, idx = ctx.saved_tensors
-        return ops.nbrmax_bwd(g, idx, dglob.contiguous(), per_object=True, scale=1.0 / g.shape[1]), None
+        dglob = dglob.contiguous()
+        if ctx.rev is not None and ops.nbrmax_gather_ok(g.shape[2], g, dglob):
+            return ops.nbrmax_bwd_gather(g, idx, ctx.rev, dglob, per_object=True, scale=1.0 / g.shape[1]), None, None
+        return ops.nbrmax_bwd(g, idx, dglob, per_object=True, scale=1.0 / g.shape[1]), None, None
 
 
 class _PoolMax(Function):
@@ -344,31 +357,44 @@ class _PoolMax(Function):
     def forward(ctx, xyz, fm, idx, sample, kpool=4):
         fm = fm.contiguous()
         v, f = ops.pool(xyz, fm, idx, sample, kpool=kpool)
-        ctx.save_for_backward(fm, idx[:, sample.long(), :kpool].contiguous())
+        idx_s = idx[:, sample.long(), :kpool].contiguous()
+        ctx.save_for_backward(fm, idx_s)
+        ctx.rev = ops.reverse_graph(idx_s, fm.shape[1]) if SCATTER_FREE and fm.requires_grad else None
         ctx.mark_non_differentiable(v)
         return v, f
 
     @staticmethod
     def backward(ctx, _dv, df):
         fm, idx_s = ctx.saved_tensors
-        return None, ops.nbrmax_bwd(fm, idx_s, df.contiguous()), None, None, None
+        df = df.contiguous()
+        if ctx.rev is not None and ops.nbrmax_gather_ok(fm.shape[2], fm, df):
+            return None, ops.nbrmax_bwd_gather(fm, idx_s, ctx.rev, df), None, None, None
+        return None, ops.nbrmax_bwd(fm, idx_s, df), None, None, None
 
 
 class _GatherRows(Function):
+    """nearest up-sampling out[b, i] = fm[b, near[b, i]] (FaceRecon.py:70-75).  lists: ops.child_lists(near, n_src) -- the backward
+    is then a segment sum per source row (no atomics); None: the atomic scatter."""
+
     @staticmethod
-    def forward(ctx, fm, near):
+    def forward(ctx, fm, near, lists=None):
         fm = fm.contiguous()
         B, n_src, C = fm.shape
         out = torch.empty(B, near.shape[1], C, device=fm.device, dtype=torch.float32)
         ops.gather_rows(fm, near, out)
         ctx.save_for_backward(near)
-        ctx.n_src = n_src
+        ctx.n_src, ctx.lists = n_src, lists
         return out
 
     @staticmethod
     def backward(ctx, dy):
         (near,) = ctx.saved_tensors
-        return ops.gather_rows_bwd(dy.contiguous(), near, ctx.n_src), None
+        B, n, C = dy.shape
+        if ctx.lists is not None and C % 4 == 0 and dy.stride(2) == 1 and dy.stride(0) == n * dy.stride(1) and dy.stride(1) % 4 == 0 \
+                and dy.data_ptr() % 16 == 0:
+            return ops.segsum_rows(dy.view(B * n, C) if dy.is_contiguous() else dy.as_strided((B * n, C), (dy.stride(1), 1)),
+                                   ctx.lists[0], ctx.lists[1]).view(B, ctx.n_src, C), None, None
+        return ops.gather_rows_bwd(dy.contiguous(), near, ctx.n_src), None, None
 
 
 class _AddRowBias(Function):
@@ -412,12 +438,12 @@ def colmax(x):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def _orl(layer, g, idx_orl):
+def _orl(layer, g, idx_orl, rev=None):
     """ORL_forward (gcn3d.py:108-112,182-186): conv2(cat[g, global]) + g, with the concatenation split into the two
     halves of conv2's weight (the global half is one row per object)."""
     C = g.shape[-1]
     w = layer.conv2.weight[:, :, 0]
-    glob = _NbrMaxMean.apply(g, idx_orl)                                  # (B, C)
+    glob = _NbrMaxMean.apply(g, idx_orl, rev)                             # (B, C)
     return add_row_bias(linear(g, w[:, :C]), linear(glob, w[:, C:])) + g
 
 
@@ -425,7 +451,8 @@ def _surface(layer, xyz, graphs, kmax):
     C = layer.kernel_num
     sdn = F.normalize(layer.directions, dim=0)
     g = _GConvSurface.apply(xyz, graphs("conv_0.rf", 0, xyz, kmax), sdn, C)
-    out = _orl(layer, g, graphs("conv_0.orl_xyz", 0, xyz, kmax))
+    idx_orl = graphs("conv_0.orl_xyz", 0, xyz, kmax)
+    out = _orl(layer, g, idx_orl, graphs.rev(idx_orl, xyz.shape[1]))
     ste = linear(_pad4(xyz), _pad4(layer.STE_layer.weight[:, :, 0]))
     return out + ste
 
@@ -435,8 +462,9 @@ def _hs(layer, name, xyz, fm, graphs, level, k):
     sdn = F.normalize(layer.directions, dim=0)
     idx_rf = graphs(name + ".rf", None, fm, k)
     proj = linear(fm, layer.weights.t(), layer.bias)                      # (B, n, 8C) = [centre | support]
-    g = _GConvHS.apply(xyz, idx_rf, proj, sdn, C)
-    out = _orl(layer, g, graphs(name + ".orl_xyz", level, xyz, k))
+    g = _GConvHS.apply(xyz, idx_rf, proj, sdn, C, graphs.rev(idx_rf, xyz.shape[1]))
+    idx_orl = graphs(name + ".orl_xyz", level, xyz, k)
+    out = _orl(layer, g, idx_orl, graphs.rev(idx_orl, xyz.shape[1]))
     return out + linear(fm, layer.STE_layer.weight[:, :, 0])
 
 
@@ -447,6 +475,18 @@ class _GraphSource(object):
     def __init__(self, device, inject, record, prefix):
         self.g = engine.Graphs(device, inject, record, prefix)
         self.xyz = {}
+        self._rev = {}
+
+    def rev(self, idx, n_src):
+        """reverse lists of a graph of this forward for the scatter-free backward (one per distinct graph: the xyz graphs are shared
+        by the layers of a level); None when gradients are off, the switch is off or the shape is unsupported"""
+        if not (SCATTER_FREE and torch.is_grad_enabled()):
+            return None
+        key = (idx.data_ptr(), tuple(idx.shape), n_src)       # every graph of the forward is alive in self.g: pointers are unique
+        if key not in self._rev:
+            with torch.no_grad():
+                self._rev[key] = (idx, ops.reverse_graph(idx, n_src))     # (idx held: its pointer cannot be handed out again)
+        return self._rev[key][1]
 
     def __call__(self, name, level, x, k):
         def compute():
@@ -482,14 +522,18 @@ def encoder(enc, xyz, obj_id, sample_idx, graphs, kmax=20, n_cls=6):
         tail = torch.cat([one_hot.unsqueeze(1).expand(B, N, n_cls), xyz, torch.zeros(B, N, FEAT_LD - FEAT_C - 3, device=dev)], 2)
         base = torch.arange(B, device=dev, dtype=torch.int32).view(B, 1)
         near1g, near2g = near1 + base * v1.shape[1], near2 + base * v2.shape[1]
-    feat = torch.cat([fm0, fm1, _GatherRows.apply(fm2, near1), _GatherRows.apply(fm3, near1), _GatherRows.apply(fm4, near2),
-                      tail], dim=2)
+        # children of every coarse point: the backward of the up-sampling (here and in the factored layers) is a segment sum
+        lists1 = ops.child_lists(near1, v1.shape[1]) if SCATTER_FREE or FACTORED else None
+        lists2 = ops.child_lists(near2, v2.shape[1]) if SCATTER_FREE or FACTORED else None
+    up1, up2 = (lists1, lists2) if SCATTER_FREE else (None, None)
+    feat = torch.cat([fm0, fm1, _GatherRows.apply(fm2, near1, up1), _GatherRows.apply(fm3, near1, up1),
+                      _GatherRows.apply(fm4, near2, up2), tail], dim=2)
     if not FACTORED:
         return feat, None
     # the operands of the factored form of the layers over feat (_FeatConsumersFactored): the columns that differ from point to
     # point, and the two coarse levels
     fine = torch.cat([fm0, fm1, F.pad(tail, (0, engine.FINE_LD - 256 - tail.shape[2]))], dim=2)
-    return feat, (fine, torch.cat([fm2, fm3], dim=2), fm4, near1g, near2g)
+    return feat, (fine, torch.cat([fm2, fm3], dim=2), fm4, near1g, near2g, lists1, lists2)
 
 
 def _w_feat(conv, cols=FEAT_C):

@@ -596,24 +596,27 @@ extern "C" int tgp_bn_bwd_pooled(const float *dpool, int ldp, const int *argrow,
 
 // ---------------------------------------------------------------------------------------------------
 // max over each object's points with the winning row (first row on ties, as torch.max) of y = act(BN(x)) computed on the
-// fly from the raw layer output (mean == NULL: y = x).  One thread per (object, channel) walks the object's rows:
-// coalesced across channels.
-__global__ __launch_bounds__(256) void colmax_arg_kernel(const float *__restrict__ x, int ld, int n, int C, const float *__restrict__ mean,
+// fly from the raw layer output (mean == NULL: y = x).  CW channels x 1024 / CW row slices per workgroup: slice s scans the
+// contiguous rows [s n / S, (s + 1) n / S) of the object, the (value, row) candidates are merged in slice order with a strict
+// '>' so the first row wins ties.  (Round 3: was 64 channels x 4 slices in 256 threads -- 128 workgroups for a 256-channel
+// layer at B = 32, half a wave per SIMD walking 257 rows each: 87 us for 34 MB.)
+template <int CW>
+__global__ __launch_bounds__(1024) void colmax_arg_kernel(const float *__restrict__ x, int ld, int n, int C, const float *__restrict__ mean,
                                   const float *__restrict__ var, float eps, const float *__restrict__ gamma,
                                   const float *__restrict__ beta, int act, float slope, const float *__restrict__ slope_vec,
                                   float *__restrict__ out, int ldo, int *__restrict__ argrow, int lda)
 {
-    // 64 channels x 4 row slices per workgroup; slice s scans the contiguous rows [s * n / 4, (s + 1) * n / 4) of the
-    // object, the four (value, row) candidates are merged in slice order with a strict '>' so the first row wins ties
-    __shared__ float s_best[4][64];
-    __shared__ int s_arg[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int slice = threadIdx.x >> 6;
+    constexpr int S = 1024 / CW;
+    __shared__ float s_best[S][CW];
+    __shared__ int s_arg[S][CW];
+    const int lane = threadIdx.x % CW;
+    const int c = blockIdx.x * CW + lane;
+    const int slice = threadIdx.x / CW;
     const int o = blockIdx.y;
     float mu = 0.f, a = 1.f, b = 0.f, sl = 0.f;
     if (c < C && mean) mu = mean[c], a = gamma[c] / sqrtf(var[c] + eps), b = beta[c], sl = slope_vec ? slope_vec[c] : slope;
     const int64_t r0 = (int64_t)o * n;
-    const int64_t ra = r0 + (int64_t)n * slice / 4, rb = r0 + (int64_t)n * (slice + 1) / 4;
+    const int64_t ra = r0 + (int64_t)n * slice / S, rb = r0 + (int64_t)n * (slice + 1) / S;
     float best = 0.f;
     int64_t arg = -1;
     if (c < C) {
@@ -627,20 +630,22 @@ __global__ __launch_bounds__(256) void colmax_arg_kernel(const float *__restrict
             if (arg < 0 || v > best || (v != v && best == best)) best = v, arg = r;   // NaN propagates like torch.max
         }
     }
-    s_best[slice][threadIdx.x & 63] = best;
-    s_arg[slice][threadIdx.x & 63] = (int)arg;
+    s_best[slice][lane] = best;
+    s_arg[slice][lane] = (int)arg;
     __syncthreads();
     if (slice == 0 && c < C) {
-        const int l = threadIdx.x;
-        for (int s = 1; s < 4; ++s) {
-            const float v = s_best[s][l];
-            const int r = s_arg[s][l];
+        for (int s = 1; s < S; ++s) {
+            const float v = s_best[s][lane];
+            const int r = s_arg[s][lane];
             if (r >= 0 && (arg < 0 || v > best || (v != v && best == best))) best = v, arg = r;
         }
         out[(int64_t)o * ldo + c] = best;
         argrow[(int64_t)o * lda + c] = (int)arg;
     }
 }
+
+// narrow layers get 32-channel workgroups (twice the workgroups, 32 row slices each)
+static inline bool per_object_narrow(int C, int objects) { return (int64_t)tgp_cdiv(C, 64) * objects < 512; }
 
 extern "C" int tgp_colmax_arg(const float *x, int ld, int objects, int n, int C, const float *mean, const float *var, float eps,
                               const float *gamma, const float *beta, int act, float slope, const float *slope_vec, float *out,
@@ -649,36 +654,51 @@ extern "C" int tgp_colmax_arg(const float *x, int ld, int objects, int n, int C,
     TGP_REQUIRE(x && out && argrow && objects > 0 && n > 0 && C > 0 && ld >= C && ldo >= C && lda >= C);
     TGP_REQUIRE(!mean || (var && gamma && beta));
     TGP_REQUIRE((int64_t)objects * n < 0x7fffffff);
-    hipLaunchKernelGGL(colmax_arg_kernel, dim3(tgp_cdiv(C, 64), objects), dim3(256), 0, tgp_hs(stream), x, ld, n, C, mean, var, eps,
-                       gamma, beta, act, slope, slope_vec, out, ldo, argrow, lda);
+    if (per_object_narrow(C, objects))
+        hipLaunchKernelGGL(colmax_arg_kernel<32>, dim3(tgp_cdiv(C, 32), objects), dim3(1024), 0, tgp_hs(stream), x, ld, n, C, mean, var,
+                           eps, gamma, beta, act, slope, slope_vec, out, ldo, argrow, lda);
+    else
+        hipLaunchKernelGGL(colmax_arg_kernel<64>, dim3(tgp_cdiv(C, 64), objects), dim3(1024), 0, tgp_hs(stream), x, ld, n, C, mean, var,
+                           eps, gamma, beta, act, slope, slope_vec, out, ldo, argrow, lda);
     return TGP_LAUNCH_RESULT();
 }
 
 // out[o][c] = sum over the object's n rows of dy: the gradient of a per-object bias that was broadcast over the object's points
-// (ORL_forward's global half, gcn3d.py:108-112; the PH back-projection in front of the decoder, FaceRecon.py:165).  64 channels x 4
-// contiguous row slices per workgroup, the four partial sums combined in slice order: deterministic.  (torch's own sum over the
+// (ORL_forward's global half, gcn3d.py:108-112; the PH back-projection in front of the decoder, FaceRecon.py:165).  CW channels x
+// 1024 / CW contiguous row slices per workgroup, the partial sums combined in slice order: deterministic.  (torch's own sum over the
 // point dimension is a multi-block reduction with semaphores, which did not survive hipGraph replay reliably: the backward of the
 // captured step keeps to this library's kernels.)
-__global__ __launch_bounds__(256) void colsum_objects_kernel(const float *__restrict__ dy, int ld, int n, int C, float *__restrict__ out, int ldo)
+template <int CW>
+__global__ __launch_bounds__(1024) void colsum_objects_kernel(const float *__restrict__ dy, int ld, int n, int C, float *__restrict__ out, int ldo)
 {
-    __shared__ float part[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int slice = threadIdx.x >> 6;
+    constexpr int S = 1024 / CW;
+    __shared__ float part[S][CW];
+    const int lane = threadIdx.x % CW;
+    const int c = blockIdx.x * CW + lane;
+    const int slice = threadIdx.x / CW;
     const int o = blockIdx.y;
     const int64_t r0 = (int64_t)o * n;
-    const int64_t ra = r0 + (int64_t)n * slice / 4, rb = r0 + (int64_t)n * (slice + 1) / 4;
+    const int64_t ra = r0 + (int64_t)n * slice / S, rb = r0 + (int64_t)n * (slice + 1) / S;
     float acc = 0.f;
-    if (c < C)
+    if (c < C) {
+#pragma unroll 8
         for (int64_t r = ra; r < rb; ++r) acc += dy[r * ld + c];
-    part[slice][threadIdx.x & 63] = acc;
+    }
+    part[slice][lane] = acc;
     __syncthreads();
-    if (slice == 0 && c < C) out[(int64_t)o * ldo + c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+    if (slice == 0 && c < C) {
+        for (int s = 1; s < S; ++s) acc += part[s][lane];
+        out[(int64_t)o * ldo + c] = acc;
+    }
 }
 
 extern "C" int tgp_colsum_objects(const float *dy, int ld, int objects, int n, int C, float *out, int ldo, tgp_stream_t stream)
 {
     TGP_REQUIRE(dy && out && objects > 0 && n > 0 && C > 0 && ld >= C && ldo >= C);
-    hipLaunchKernelGGL(colsum_objects_kernel, dim3(tgp_cdiv(C, 64), objects), dim3(256), 0, tgp_hs(stream), dy, ld, n, C, out, ldo);
+    if (per_object_narrow(C, objects))
+        hipLaunchKernelGGL(colsum_objects_kernel<32>, dim3(tgp_cdiv(C, 32), objects), dim3(1024), 0, tgp_hs(stream), dy, ld, n, C, out, ldo);
+    else
+        hipLaunchKernelGGL(colsum_objects_kernel<64>, dim3(tgp_cdiv(C, 64), objects), dim3(1024), 0, tgp_hs(stream), dy, ld, n, C, out, ldo);
     return TGP_LAUNCH_RESULT();
 }
 

@@ -15,13 +15,13 @@
 struct GbMap {
     int c, stream, streams, chunk;
 };
-__device__ __forceinline__ GbMap gb_map(int C)
+__device__ __forceinline__ GbMap gb_map(int C, int ychunk)
 {
     GbMap m;
     const int cw = C < 256 ? C : 256;           // channels per workgroup
     m.streams = 256 / cw;
     m.stream = threadIdx.x / cw;
-    m.c = blockIdx.y * cw + threadIdx.x % cw;   // blockIdx.y: channel chunk
+    m.c = ychunk * cw + threadIdx.x % cw;       // ychunk: channel chunk
     m.chunk = cw;
     return m;
 }
@@ -36,10 +36,17 @@ __global__ __launch_bounds__(256) void gconv_bwd_kernel(const float *__restrict_
                                                         const float *__restrict__ dg, int ldg, int B, int n, int k, int C,
                                                         float *__restrict__ dproj, int lddp, float *__restrict__ dsdn_partial)
 {
-    const GbMap mp = gb_map(C);
+    // (round 3) an object's workgroups share an XCD, as in the forward kernel: its projection table (n x 8C floats) is then served
+    // from ONE L2 instead of being pulled through all eight
+    const int ychunks = C < 256 ? 1 : C / 256;
     const int SC = GB_S * C;
-    const int tiles_per_obj = (n + GB_PTS * mp.streams - 1) / (GB_PTS * mp.streams);
-    const int b = blockIdx.x / tiles_per_obj, tile = blockIdx.x % tiles_per_obj;
+    const int streams_ = 256 / (C < 256 ? C : 256);
+    const int tiles_per_obj = (n + GB_PTS * streams_ - 1) / (GB_PTS * streams_);
+    int b, t_;
+    if (!tgp_xcd_object_tile(blockIdx.x, B, tiles_per_obj * ychunks, b, t_)) return;
+    const int tile = t_ / ychunks;
+    const GbMap mp = gb_map(C, t_ % ychunks);
+    const int bx = b * tiles_per_obj + tile;      // the workgroup's slot in the partial buffer
     const int c = mp.c;
     float D[GB_S][3], dD[GB_S][3];
 #pragma unroll
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256) void gconv_bwd_kernel(const float *__restrict_
         }
     }
     if (c < C) {
-        float *o = dsdn_partial + ((int64_t)blockIdx.x * mp.streams + mp.stream) * 3 * SC;
+        float *o = dsdn_partial + ((int64_t)bx * mp.streams + mp.stream) * 3 * SC;
 #pragma unroll
         for (int s = 0; s < GB_S; ++s)
 #pragma unroll
@@ -155,7 +162,7 @@ static int gconv_bwd_launch(bool surface, const float *xyz, const int32_t *idx, 
         return TGP_EINVAL;
     const int cw = C < 256 ? C : 256;
     const int streams = 256 / cw;
-    const dim3 grid(B * tgp_cdiv(n, GB_PTS * streams), tgp_cdiv(C, cw));
+    const dim3 grid(tgp_xcd_grid(B, tgp_cdiv(n, GB_PTS * streams) * tgp_cdiv(C, cw)));
     // every (workgroup, stream) writes its full 3 x S x C-chunk slice, so the partial buffer needs no clearing -- but the
     // chunks of different blockIdx.y share a slice: they write disjoint channels of it
     if (surface)

@@ -8,46 +8,78 @@
 
 #define CL_MAX_PARENTS 4096
 
-// one workgroup per object: ptr[b * R + r] = first slot of parent r's children in idx (global), idx[...] = global rows (b * n + i)
+#define CL_SPLIT 4   // workgroups per object (each repeats the counting sort's histogram and ranks a quarter of the points)
+
+// ptr[b * R + r] = first slot of parent r's children in idx (global), idx[...] = global rows (b * n + i): a counting sort of the
+// object's points by parent.  Slot of point i = (points with a smaller parent) + (earlier points with the same parent); the second
+// term is counted by scanning the object's parent ids in LDS (every lane of a wave reads the same 16 bytes: a broadcast).
 __global__ __launch_bounds__(256) void child_lists_kernel(const int32_t *__restrict__ near, int B, int n, int R, int gbase,
                                                           int32_t *__restrict__ ptr, int32_t *__restrict__ idx)
 {
     __shared__ int s_cnt[CL_MAX_PARENTS];
-    extern __shared__ int s_near[];                       // n parent ids of this object
+    __shared__ int s_part[256];
+    extern __shared__ int4 s_near4[];                     // the object's parent ids, padded to a multiple of 4 with -1
+    int *s_near = reinterpret_cast<int *>(s_near4);
     const int b = blockIdx.x;
     const int32_t *nb = near + (size_t)b * n;
-    for (int r = threadIdx.x; r < R; r += blockDim.x) s_cnt[r] = 0;
+    for (int r = threadIdx.x; r < R; r += 256) s_cnt[r] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        int p = nb[i] - b * gbase;                        // global ids carry the object's offset b * R
-        p = p < 0 ? 0 : (p >= R ? R - 1 : p);             // (a parent id outside [0, R) would be the caller's bug: clamped, never a fault)
-        s_near[i] = p;
-        atomicAdd(&s_cnt[p], 1);                          // integer counts: order-free
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {                               // exclusive scan, R <= 4096: a few microseconds
-        int run = 0;
-        for (int r = 0; r < R; ++r) {
-            const int c = s_cnt[r];
-            s_cnt[r] = run;
-            run += c;
+    const int n4 = (n + 3) & ~3;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        int p = -1;
+        if (i < n) {
+            p = nb[i] - b * gbase;                        // global ids carry the object's offset b * R
+            p = p < 0 ? 0 : (p >= R ? R - 1 : p);         // (a parent id outside [0, R) would be the caller's bug: clamped, never a fault)
+            atomicAdd(&s_cnt[p], 1);                      // integer counts: order-free
         }
+        s_near[i] = p;
     }
     __syncthreads();
-    for (int r = threadIdx.x; r < R; r += blockDim.x) {
-        int pos = s_cnt[r];
-        ptr[(size_t)b * R + r] = b * n + pos;
-        for (int i = 0; i < n; ++i)                       // children in point order: deterministic sums downstream
-            if (s_near[i] == r) idx[(size_t)b * n + pos++] = b * n + i;
+    // exclusive scan of the counts: each thread owns `per` consecutive parents
+    const int per = (R + 255) / 256;
+    const int r0 = threadIdx.x * per;
+    int local = 0;
+    for (int r = r0; r < r0 + per && r < R; ++r) local += s_cnt[r];
+    s_part[threadIdx.x] = local;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int v = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
     }
-    if (b == B - 1 && threadIdx.x == 0) ptr[(size_t)B * R] = B * n;
+    int run = s_part[threadIdx.x] - local;
+    for (int r = r0; r < r0 + per && r < R; ++r) {
+        const int c = s_cnt[r];
+        s_cnt[r] = run;
+        run += c;
+    }
+    __syncthreads();
+    if (blockIdx.y == 0) {
+        for (int r = threadIdx.x; r < R; r += 256) ptr[(size_t)b * R + r] = b * n + s_cnt[r];
+        if (b == B - 1 && threadIdx.x == 0) ptr[(size_t)B * R] = B * n;
+    }
+    const int chunk = (n + CL_SPLIT - 1) / CL_SPLIT;
+    const int q0 = blockIdx.y * chunk, q1 = q0 + chunk < n ? q0 + chunk : n;
+    for (int base = q0; base < q1; base += 256) {
+        const int i = base + threadIdx.x;
+        const int p = i < q1 ? s_near[i] : -2;
+        const int top = base + 256 < q1 ? base + 256 : q1;      // uniform bound: the last point this pass ranks
+        int rank = 0;
+        for (int j4 = 0; j4 * 4 < top; ++j4) {
+            const int4 v = s_near4[j4];
+            const int j = j4 * 4;
+            rank += (v.x == p && j < i) + (v.y == p && j + 1 < i) + (v.z == p && j + 2 < i) + (v.w == p && j + 3 < i);
+        }
+        if (i < q1) idx[(size_t)b * n + s_cnt[p] + rank] = b * n + i;    // children in point order: deterministic sums downstream
+    }
 }
 
 extern "C" int tgp_child_lists(const int32_t *near, int B, int n, int R, int global_ids, int32_t *ptr, int32_t *idx, tgp_stream_t stream)
 {
     TGP_REQUIRE(near && ptr && idx && B > 0 && n > 0 && R > 0);
     if (R > CL_MAX_PARENTS || n > 8192 || (int64_t)B * n >= 0x7fffffff) return TGP_EUNSUPPORTED;
-    hipLaunchKernelGGL(child_lists_kernel, dim3(B), dim3(256), (size_t)n * sizeof(int), tgp_hs(stream), near, B, n, R,
+    hipLaunchKernelGGL(child_lists_kernel, dim3(B, CL_SPLIT), dim3(256), (size_t)((n + 3) & ~3) * sizeof(int), tgp_hs(stream), near, B, n, R,
                        global_ids ? R : 0, ptr, idx);
     return TGP_LAUNCH_RESULT();
 }

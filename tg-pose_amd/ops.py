@@ -878,6 +878,57 @@ def gather_rows_bwd(dy, idx, n_src):
     return dsrc
 
 
+def reverse_graph(idx, n_src):
+    """idx (B, n_rows, k) int32 ids in [0, n_src) -> (rptr (B*n_src + 1,), rent (B*n_rows*k,)) int32: for every source row the
+    ascending (row << 6 | slot) pairs that list it; None when the shape is outside what tgp_reverse_graph sorts in LDS"""
+    _i32(idx, "idx")
+    idx = idx.contiguous()
+    B, n_rows, k = idx.shape
+    if k > 64 or n_src > 8192 or (n_rows * k + 2 * n_src) * 4 > 150 * 1024:
+        return None
+    rptr = torch.empty(B * n_src + 1, device=idx.device, dtype=torch.int32)
+    rent = torch.empty(B * n_rows * k, device=idx.device, dtype=torch.int32)
+    check(_lib.lib().tgp_reverse_graph(_p(idx), B, n_rows, k, n_src, _p(rptr), _p(rent), _stream(idx)), "tgp_reverse_graph")
+    return rptr, rent
+
+
+def nbrmax_gather_ok(C, *tensors):
+    lanes = C // 4
+    return C % 4 == 0 and 0 < lanes <= 256 and 256 % lanes == 0 and all(t.data_ptr() % 16 == 0 for t in tensors)
+
+
+@_timed("graph")
+def nbrmax_bwd_gather(src, idx, rev, dy, per_object=False, scale=1.0):
+    """nbrmax_bwd without atomics (rev = reverse_graph(idx, n_src)); dsrc is written densely"""
+    src, lds = _rows(src, "src")
+    _i32(idx, "idx")
+    B, n_src, C = src.shape
+    n_rows, k = idx.shape[1], idx.shape[2]
+    dy, lddy = _rows(dy, "dy")
+    dsrc = torch.empty(B, n_src, C, device=src.device, dtype=torch.float32)
+    arg = torch.empty(B * n_rows * C, device=src.device, dtype=torch.uint8)
+    check(_lib.lib().tgp_nbrmax_bwd_gather(_p(src), lds, _p(idx), _p(rev[0]), _p(rev[1]), B, n_src, n_rows, k, C, _p(dy), lddy,
+                                           int(per_object), float(scale), _p(arg), _p(dsrc), C, _stream(src)), "tgp_nbrmax_bwd_gather")
+    return dsrc
+
+
+@_timed("graph")
+def gconv_hs_bwd_gather(xyz, idx, rev, proj, sdn, dg, S, C):
+    """gconv_hs_bwd without atomics (rev = reverse_graph(idx, n)) -> (dproj (B,n,8C), dsdn (3, S*C))"""
+    proj, ldp = _rows(proj, "proj")
+    dg, ldg = _rows(dg, "dg")
+    B, n, k = idx.shape
+    dproj = torch.empty(B, n, 8 * C, device=xyz.device, dtype=torch.float32)
+    dsdn = torch.empty(3, S * C, device=xyz.device, dtype=torch.float32)
+    ws = _ws(_lib.lib().tgp_gconv_bwd_workspace_floats(B, n, C), xyz.device)
+    arg = torch.empty(B * n * S * C, device=xyz.device, dtype=torch.uint8)
+    contrib = torch.empty(B * n * S * C, device=xyz.device, dtype=torch.float32)
+    check(_lib.lib().tgp_gconv_hs_bwd_gather(_p(xyz), _p(idx), _p(rev[0]), _p(rev[1]), _p(proj), ldp, _p(sdn), _p(dg), ldg, B, n, k, S, C,
+                                             _p(dproj), 8 * C, _p(dsdn), _p(ws), _p(arg), _p(contrib), _stream(xyz)),
+          "tgp_gconv_hs_bwd_gather")
+    return dproj, dsdn
+
+
 def child_lists(near, R, global_ids=False):
     """near (B, n) int32 parent of every point, in [0, R) (global_ids: b * R + that) -> (ptr (B*R + 1,), idx (B*n,)) int32: CSR
     child lists over the B*R global parent rows, idx = global point rows b*n + i, children in point order"""
