@@ -577,14 +577,19 @@ int tgp_segsum_rows(const float *g, int ldg, int C, const int32_t *ptr, const in
  * TGP_EUNSUPPORTED.
  * tgp_nbrmax_bwd_gather: arg_ws B*n_rows*C bytes; C % 4 == 0, C / 4 a divisor of 256, strides % 4 == 0, 16-byte aligned, else
  * TGP_EUNSUPPORTED.  tgp_gconv_hs_bwd_gather: workspace as tgp_gconv_bwd_workspace_floats; arg_ws B*n*7C bytes, contrib_ws B*n*7C
- * floats; C in {128, 256, 512}, k <= 63, 16-byte aligned operands, else TGP_EUNSUPPORTED. */
+ * floats; C in {128, 256, 512}, k <= 63, 16-byte aligned operands, else TGP_EUNSUPPORTED; have_slots: arg_ws was filled by
+ * tgp_gconv_hs_fwd_slots (below) and the slot pass is skipped. */
 int tgp_reverse_graph(const int32_t *idx, int B, int n_rows, int k, int n_src, int32_t *rptr, int32_t *rent, tgp_stream_t stream);
 int tgp_nbrmax_bwd_gather(const float *src, int ld_src, const int32_t *idx, const int32_t *rptr, const int32_t *rent, int B, int n_src,
                           int n_rows, int k, int C, const float *dy, int lddy, int per_object, float scale, uint8_t *arg_ws,
                           float *dsrc, int ld_dsrc, tgp_stream_t stream);
 int tgp_gconv_hs_bwd_gather(const float *xyz, const int32_t *idx, const int32_t *rptr, const int32_t *rent, const float *proj, int ldp,
                             const float *sdn, const float *dg, int ldg, int B, int n, int k, int S, int C, float *dproj, int lddp,
-                            float *dsdn, float *workspace, uint8_t *arg_ws, float *contrib_ws, tgp_stream_t stream);
+                            float *dsdn, float *workspace, uint8_t *arg_ws, float *contrib_ws, int have_slots, tgp_stream_t stream);
+/* tgp_gconv_hs_fwd (same output, bit for bit) that also records the slots (B*n*7C bytes) for tgp_gconv_hs_bwd_gather(have_slots = 1):
+ * the training forward then needs no slot pass in the backward.  Same shape limits as tgp_gconv_hs_bwd_gather. */
+int tgp_gconv_hs_fwd_slots(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B, int n, int k, int S,
+                           int C, float *out, int ldo, uint8_t *slots, tgp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1370,6 +1370,11 @@ def test_gconv_hs_bwd_gather_vs_scatter(ops, B, n, k, C):
     assert torch.allclose(dsdn, dsdn0, atol=1e-4 * float(dsdn0.abs().max()), rtol=0), (dsdn - dsdn0).abs().max()
     again = ops.gconv_hs_bwd_gather(g(xyz), g(idx), rev, g(proj), g(sdn), g(dg), 7, C)
     assert torch.equal(again[0], dproj) and torch.equal(again[1], dsdn)
+    # the training forward's kernel: the forward kernel's output bit for bit, and slots that give the same backward
+    out, slots = ops.gconv_hs_slots(g(xyz), g(idx), g(proj), g(sdn), 7, C)
+    assert torch.equal(out, ops.gconv_hs(g(xyz), g(idx), g(proj), g(sdn), 7, C))
+    fused = ops.gconv_hs_bwd_gather(g(xyz), g(idx), rev, g(proj), g(sdn), g(dg), 7, C, slots=slots)
+    assert torch.equal(fused[0], dproj) and torch.equal(fused[1], dsdn)
 
 
 @pytest.mark.parametrize("gemm_mode", ["fp32", "split16"], indirect=True)

@@ -160,7 +160,8 @@ SIGNATURES = {
     "tgp_nbrmax_bwd_gather": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_f32,
                                       c_vp, c_vp, c_int, c_vp]),
     "tgp_gconv_hs_bwd_gather": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int,
-                                        c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+                                        c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "tgp_gconv_hs_fwd_slots": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "tgp_child_lists": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_segsum_rows": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
     "tgp_roi_cloud_ex": (c_int, [c_vp] * 7 + [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp]),

@@ -316,7 +316,14 @@ class _GConvHS(Function):
     @staticmethod
     def forward(ctx, xyz, idx, proj, sdn, C, rev=None):
         proj = proj.contiguous()
-        g = ops.gconv_hs(xyz, idx, proj, sdn.contiguous(), S, C)
+        sdn_c = sdn.contiguous()
+        ctx.slots = None
+        if rev is not None and ops.gconv_gather_ok(C, idx.shape[2], proj, sdn_c):
+            # the forward kernel that also records every maximum's slot: the backward then starts from them (no second walk over
+            # the k neighbour rows); the slots are consumed by the one backward pass a training step runs
+            g, ctx.slots = ops.gconv_hs_slots(xyz, idx, proj, sdn_c, S, C)
+        else:
+            g = ops.gconv_hs(xyz, idx, proj, sdn_c, S, C)
         ctx.save_for_backward(xyz, idx, proj, sdn)
         ctx.C, ctx.rev = C, rev
         return g
@@ -324,8 +331,10 @@ class _GConvHS(Function):
     @staticmethod
     def backward(ctx, dg):
         xyz, idx, proj, sdn = ctx.saved_tensors
-        if ctx.rev is not None and ctx.C in (128, 256, 512) and idx.shape[2] <= 63:
-            dproj, dsdn = ops.gconv_hs_bwd_gather(xyz, idx, ctx.rev, proj, sdn.contiguous(), dg.contiguous(), S, ctx.C)
+        dg = dg.contiguous()
+        if ctx.rev is not None and ops.gconv_gather_ok(ctx.C, idx.shape[2], proj, dg):
+            slots, ctx.slots = ctx.slots, None            # (a second backward over the same graph recomputes them)
+            dproj, dsdn = ops.gconv_hs_bwd_gather(xyz, idx, ctx.rev, proj, sdn.contiguous(), dg, S, ctx.C, slots=slots)
         else:
             dproj, dsdn = ops.gconv_hs_bwd(xyz, idx, proj, sdn.contiguous(), dg.contiguous(), S, ctx.C)
         return None, None, dproj, dsdn, None, None

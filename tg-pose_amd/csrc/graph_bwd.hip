@@ -206,7 +206,8 @@ struct GgLanes {
 template <int C>
 __global__ __launch_bounds__(256) void gconv_bwd_slot_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ idx,
                                                              const float *__restrict__ proj, int ldp, const float *__restrict__ sdn,
-                                                             int B, int n, int k, uint8_t *__restrict__ arg, int tiles_per_obj)
+                                                             int B, int n, int k, uint8_t *__restrict__ arg, int tiles_per_obj,
+                                                             float *__restrict__ out, int ldo)
 {
     using RL = GgLanes<C>;
     int b, tile;
@@ -278,6 +279,15 @@ __global__ __launch_bounds__(256) void gconv_bwd_slot_kernel(const float *__rest
 #pragma unroll
             for (int s = 0; s < GG_S; ++s)
                 *reinterpret_cast<uchar4 *>(arg + rowi * SC + s * C + cb) = make_uchar4((uint8_t)ax[s], (uint8_t)ay[s], (uint8_t)az[s], (uint8_t)aw[s]);
+            if (out) {             // the layer's output as well (training forward: this kernel then replaces gconv_kernel) -- the same
+                float4 acc = m[0]; // maxima, the same sequential mean over the 7 supports and the same centre add, bit for bit
+#pragma unroll
+                for (int s = 1; s < GG_S; ++s) acc.x += m[s].x, acc.y += m[s].y, acc.z += m[s].z, acc.w += m[s].w;
+                acc.x = acc.x / 7.0f, acc.y = acc.y / 7.0f, acc.z = acc.z / 7.0f, acc.w = acc.w / 7.0f;
+                const float4 ctr = *reinterpret_cast<const float4 *>(proj + rowi * ldp + cb);
+                acc.x = ctr.x + acc.x, acc.y = ctr.y + acc.y, acc.z = ctr.z + acc.z, acc.w = ctr.w + acc.w;
+                *reinterpret_cast<float4 *>(out + rowi * ldo + cb) = acc;
+            }
         }
     }
 }
@@ -408,30 +418,55 @@ __global__ void gg_partial_sum_kernel(const float *__restrict__ partial, int64_t
     out[(int64_t)blockIdx.y * width + t] = s;
 }
 
-// workspace (floats): partials of d D, as tgp_gconv_bwd_workspace_floats; arg_ws: B*n*7C bytes; contrib_ws: B*n*7C floats
+static int gg_supported(const void *proj, const void *sdn, int ldp, int k, int C)
+{
+    return (C == 128 || C == 256 || C == 512) && k <= GG_MAXK - 1 && (ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(proj) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(sdn) & 15) == 0;
+}
+
+static void gg_launch_slots(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B, int n, int k, int C,
+                            uint8_t *arg, float *out, int ldo, hipStream_t stream)
+{
+    const int ptiles = tgp_cdiv(n, GG_PTS);
+#define GG_GO(CC)                                                                                                                       \
+    {                                                                                                                                   \
+        const int tiles = ptiles * GgLanes<CC>::CHUNKS;                                                                                 \
+        hipLaunchKernelGGL((gconv_bwd_slot_kernel<CC>), dim3(tgp_xcd_grid(B, tiles)), dim3(256), 0, stream, xyz, idx, proj, ldp, sdn, B, \
+                           n, k, arg, tiles, out, ldo);                                                                                 \
+    }
+    if (C == 128) GG_GO(128) else if (C == 256) GG_GO(256) else GG_GO(512)
+#undef GG_GO
+}
+
+// HS_layer.graph_conv forward that also records the winning slot of every (point, direction, channel) for the scatter-free
+// backward (slots: B*n*7C bytes): same output as tgp_gconv_hs_fwd, bit for bit.
+extern "C" int tgp_gconv_hs_fwd_slots(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B, int n,
+                                      int k, int S, int C, float *out, int ldo, uint8_t *slots, tgp_stream_t stream)
+{
+    TGP_REQUIRE(xyz && idx && proj && sdn && out && slots && B > 0 && n > 0 && k > 0 && S == GG_S && ldp >= 8 * C && ldo >= C);
+    if (!gg_supported(proj, sdn, ldp, k, C) || (ldo & 3) || ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(slots)) & 15))
+        return TGP_EUNSUPPORTED;
+    gg_launch_slots(xyz, idx, proj, ldp, sdn, B, n, k, C, slots, out, ldo, tgp_hs(stream));
+    return TGP_LAUNCH_RESULT();
+}
+
+// workspace (floats): partials of d D, as tgp_gconv_bwd_workspace_floats; arg_ws: B*n*7C bytes; contrib_ws: B*n*7C floats.
+// have_slots != 0: arg_ws already holds the slots recorded by tgp_gconv_hs_fwd_slots (the slot pass is skipped).
 extern "C" int tgp_gconv_hs_bwd_gather(const float *xyz, const int32_t *idx, const int32_t *rptr, const int32_t *rent, const float *proj,
                                        int ldp, const float *sdn, const float *dg, int ldg, int B, int n, int k, int S, int C,
                                        float *dproj, int lddp, float *dsdn, float *workspace, uint8_t *arg_ws, float *contrib_ws,
-                                       tgp_stream_t stream)
+                                       int have_slots, tgp_stream_t stream)
 {
     TGP_REQUIRE(xyz && idx && rptr && rent && proj && sdn && dg && dproj && dsdn && workspace && arg_ws && contrib_ws);
     TGP_REQUIRE(B > 0 && n > 0 && k > 0 && S == GG_S && C > 0 && ldg >= C && ldp >= 8 * C && lddp >= 8 * C);
-    if (!(C == 128 || C == 256 || C == 512) || k > GG_MAXK - 1 || ((ldg | lddp | ldp) & 3) || (reinterpret_cast<uintptr_t>(proj) & 15) ||
-        (reinterpret_cast<uintptr_t>(sdn) & 15) ||
+    if (!gg_supported(proj, sdn, ldp, k, C) || ((ldg | lddp) & 3) ||
         ((reinterpret_cast<uintptr_t>(dg) | reinterpret_cast<uintptr_t>(dproj) | reinterpret_cast<uintptr_t>(arg_ws) |
           reinterpret_cast<uintptr_t>(contrib_ws)) & 15))
         return TGP_EUNSUPPORTED;
     const int64_t parts = (int64_t)B * tgp_cdiv(n, GG_PTS);
     const int chunks = GG_S * C / GG_THREADS;
     const int ptiles = tgp_cdiv(n, GG_PTS);
-#define GG_GO(CC)                                                                                                                  \
-    {                                                                                                                              \
-        const int tiles = ptiles * GgLanes<CC>::CHUNKS;                                                                            \
-        hipLaunchKernelGGL((gconv_bwd_slot_kernel<CC>), dim3(tgp_xcd_grid(B, tiles)), dim3(256), 0, tgp_hs(stream), xyz, idx, proj, \
-                           ldp, sdn, B, n, k, arg_ws, tiles);                                                                      \
-    }
-    if (C == 128) GG_GO(128) else if (C == 256) GG_GO(256) else GG_GO(512)
-#undef GG_GO
+    if (!have_slots) gg_launch_slots(xyz, idx, proj, ldp, sdn, B, n, k, C, arg_ws, nullptr, 0, tgp_hs(stream));
     const dim3 grid(tgp_xcd_grid(B, ptiles * chunks));
     hipLaunchKernelGGL(gconv_bwd_value_kernel, grid, dim3(GG_THREADS), 0, tgp_hs(stream), xyz, idx, proj, ldp, sdn, dg, ldg, B, n, k, C,
                        arg_ws, contrib_ws, workspace);

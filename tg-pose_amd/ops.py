@@ -912,20 +912,38 @@ def nbrmax_bwd_gather(src, idx, rev, dy, per_object=False, scale=1.0):
     return dsrc
 
 
+def gconv_gather_ok(C, k, *tensors):
+    return C in (128, 256, 512) and k <= 63 and all(t.data_ptr() % 16 == 0 for t in tensors)
+
+
 @_timed("graph")
-def gconv_hs_bwd_gather(xyz, idx, rev, proj, sdn, dg, S, C):
-    """gconv_hs_bwd without atomics (rev = reverse_graph(idx, n)) -> (dproj (B,n,8C), dsdn (3, S*C))"""
+def gconv_hs_slots(xyz, idx, proj, sdn, S, C):
+    """gconv_hs that also records the winning slots for gconv_hs_bwd_gather(slots=...): -> (out (B,n,C), slots uint8 (B*n*S*C,))"""
+    _f32(xyz, "xyz", 3), _i32(idx, "idx")
+    proj, ldp = _rows(proj, "proj")
+    B, n, k = idx.shape
+    out = torch.empty(B, n, C, device=xyz.device, dtype=torch.float32)
+    slots = torch.empty(B * n * S * C, device=xyz.device, dtype=torch.uint8)
+    check(_lib.lib().tgp_gconv_hs_fwd_slots(_p(xyz), _p(idx), _p(proj), ldp, _p(sdn), B, n, k, S, C, _p(out), C, _p(slots),
+                                            _stream(xyz)), "tgp_gconv_hs_fwd_slots")
+    return out, slots
+
+
+@_timed("graph")
+def gconv_hs_bwd_gather(xyz, idx, rev, proj, sdn, dg, S, C, slots=None):
+    """gconv_hs_bwd without atomics (rev = reverse_graph(idx, n)) -> (dproj (B,n,8C), dsdn (3, S*C)).  slots: as recorded by
+    gconv_hs_slots in the forward (CONSUMED: entries that carry no gradient are rewritten); None: recomputed here."""
     proj, ldp = _rows(proj, "proj")
     dg, ldg = _rows(dg, "dg")
     B, n, k = idx.shape
     dproj = torch.empty(B, n, 8 * C, device=xyz.device, dtype=torch.float32)
     dsdn = torch.empty(3, S * C, device=xyz.device, dtype=torch.float32)
     ws = _ws(_lib.lib().tgp_gconv_bwd_workspace_floats(B, n, C), xyz.device)
-    arg = torch.empty(B * n * S * C, device=xyz.device, dtype=torch.uint8)
+    arg = slots if slots is not None else torch.empty(B * n * S * C, device=xyz.device, dtype=torch.uint8)
     contrib = torch.empty(B * n * S * C, device=xyz.device, dtype=torch.float32)
     check(_lib.lib().tgp_gconv_hs_bwd_gather(_p(xyz), _p(idx), _p(rev[0]), _p(rev[1]), _p(proj), ldp, _p(sdn), _p(dg), ldg, B, n, k, S, C,
-                                             _p(dproj), 8 * C, _p(dsdn), _p(ws), _p(arg), _p(contrib), _stream(xyz)),
-          "tgp_gconv_hs_bwd_gather")
+                                             _p(dproj), 8 * C, _p(dsdn), _p(ws), _p(arg), _p(contrib), int(slots is not None),
+                                             _stream(xyz)), "tgp_gconv_hs_bwd_gather")
     return dproj, dsdn
 
 
