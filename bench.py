@@ -261,6 +261,9 @@ def main():
                     help="replay the forward as a captured hipGraph (default 1 = whole batch; 0 = eager launches; "
                          "2 = two half batches on forked streams, measured slower)")
     ap.add_argument("--frames", type=int, default=32, help="input_side: frames per step (6 detections each)")
+    ap.add_argument("--eval-outputs-only", action="store_true",
+                    help="forward: skip the PH predictor and the decoder, whose results the six-key eval dict does not return "
+                         "(engine.EVAL_OUTPUTS_ONLY; a secondary, deployment figure -- the headline is the full forward)")
     ap.add_argument("--workload", choices=("forward", "train_step", "input_side"), default="forward",
                     help="forward: the headline metric (eval-mode forward).  train_step: BASELINE config 4's step on one rank's "
                          "share -- the reference's RL_TDA_train_step (net1 with gradients, net2 under no_grad on the augmented cloud, "
@@ -307,6 +310,7 @@ def main():
         args.branch_streams = "off"
     _engine.BRANCH_STREAMS = args.branch_streams == "on" or (args.branch_streams == "auto" and (args.streams <= 2 or args.workload != "forward"
                                                                                                   or args.graph != 1))
+    _engine.EVAL_OUTPUTS_ONLY = bool(args.eval_outputs_only)      # (never from the environment: the default line is the full forward)
     B = args.batch
     torch.manual_seed(rank)
     step_no = [0]
@@ -493,9 +497,13 @@ def main():
             "gemm_mode": {"split": "fp32-accurate 3xbf16 operand split on the bf16 matrix cores, fp32 accumulate",
                           "split16": "fp32-accurate 2xfp16 operand split on the fp16 matrix cores, fp32 accumulate",
                           "fp32": "fp32 MFMA"}[args.gemm],
-            "config": {"workload": ("PoseNet9D.forward eval mode, full forward (kNN graphs + 3D-GCN encoder + PH predictor "
-                                    "+ decoder + R/t/s heads), B=%d objects per GPU, N=%d points, seeded random weights "
-                                    "of the reference architecture (27.43 M params)" % (B, N_POINTS)) if fwd
+            "config": {"workload": (("PoseNet9D.forward eval mode, full forward (kNN graphs + 3D-GCN encoder + PH predictor "
+                                     "+ decoder + R/t/s heads), B=%d objects per GPU, N=%d points, seeded random weights "
+                                     "of the reference architecture (27.43 M params)" % (B, N_POINTS)) if not args.eval_outputs_only else
+                                    ("PoseNet9D.forward eval mode WITHOUT the PH predictor and the decoder, whose results the six-key "
+                                     "eval dict does not return (reduced set: -4,968 MFLOP, -41.5 MB per object against SURVEY 8d's "
+                                     "full-forward figures; NOT the headline configuration), B=%d objects per GPU, N=%d points, seeded "
+                                     "random weights" % (B, N_POINTS))) if fwd
                        else ("the reference's RL_TDA_train_step (trainer/RL_TDA.py:110-226): net1 = PoseNet9D training-mode forward "
                              "with autograd, net2 = PoseNet9D(only_encoder) under no_grad on the augmented cloud, feat_consistency + 2x "
                              "prop_sym_matching, the 14 control_loss('TDA') terms, total = 0.1 (con + recon_1 + recon_cons) + 0.9 sum(TDA), "
@@ -503,6 +511,7 @@ def main():
                              "clip_grad_norm_(5), SGD step; B=%d objects per GPU, N=%d points sampled "
                              "from the six obj_model category clouds with their pdh1/pdh2 priors" % (B, N_POINTS)),
                        "objects_per_gpu": B, "points": N_POINTS, "replicas": world, "batches_in_flight": len(streams),
+                       "full_forward": not (fwd and args.eval_outputs_only),
                        "side_branches_in_a_forward": bool(_engine.BRANCH_STREAMS),
                        "hipgraph": {0: "off", 1: "whole batch" if replayers is None else "whole batch, one captured forward per stream",
                                     2: "two half batches on forked streams"}[args.graph]},

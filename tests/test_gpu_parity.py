@@ -1433,6 +1433,26 @@ def test_feat_consumers_factored_vs_fp64_concat(ops, gemm_mode):
     assert all(v <= (1e-5 if k.startswith("y") and gemm_mode == "fp32" else bar) for k, v in errs.items()), errs
 
 
+def test_eval_outputs_only_returns_the_same_six_outputs(ops):
+    """engine.EVAL_OUTPUTS_ONLY (deployment switch: the PH predictor and the decoder, which the eval dict of PoseNet9D.py:85-90 does
+    not return, are not computed) gives the six outputs of the full eval forward bit for bit."""
+    from tgpose_amd import engine
+    net = _net(3).eval()
+    pts, obj = synth_points(4, 1028, 9)
+    torch.manual_seed(1)
+    sample = engine.draw_sample_idx(1028)
+    with torch.no_grad():
+        full = net(g(pts), g(obj), sample_idx=sample)
+        engine.EVAL_OUTPUTS_ONLY = True
+        try:
+            lean = net(g(pts), g(obj), sample_idx=sample)
+        finally:
+            engine.EVAL_OUTPUTS_ONLY = False
+    assert set(full) == set(lean) == {"p_green_R", "p_red_R", "f_green_R", "f_red_R", "Pred_T", "Pred_s"}
+    for k in full:
+        assert torch.equal(full[k], lean[k]), k
+
+
 def test_backward_full_network_is_bit_repeatable(ops):
     """Round 3: with the scatter-free backward of the graph layers (reverse neighbour lists, child lists of the up-sampling) no
     float atomic is left in loss.backward() through PoseNet9D: two runs on the same inputs give bit-identical gradients for every
