@@ -447,6 +447,18 @@ def colmax(x):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def _reverse(graphs, idx, n_src):
+    """reverse lists of a graph for the scatter-free backward: from the forward's graph source when it keeps them (one per distinct
+    graph), else computed here (the stand-alone layer modules of the seam)"""
+    rev = getattr(graphs, "rev", None)
+    if rev is not None:
+        return rev(idx, n_src)
+    if not (SCATTER_FREE and torch.is_grad_enabled()):
+        return None
+    with torch.no_grad():
+        return ops.reverse_graph(idx, n_src)
+
+
 def _orl(layer, g, idx_orl, rev=None):
     """ORL_forward (gcn3d.py:108-112,182-186): conv2(cat[g, global]) + g, with the concatenation split into the two
     halves of conv2's weight (the global half is one row per object)."""
@@ -461,7 +473,7 @@ def _surface(layer, xyz, graphs, kmax):
     sdn = F.normalize(layer.directions, dim=0)
     g = _GConvSurface.apply(xyz, graphs("conv_0.rf", 0, xyz, kmax), sdn, C)
     idx_orl = graphs("conv_0.orl_xyz", 0, xyz, kmax)
-    out = _orl(layer, g, idx_orl, graphs.rev(idx_orl, xyz.shape[1]))
+    out = _orl(layer, g, idx_orl, _reverse(graphs, idx_orl, xyz.shape[1]))
     ste = linear(_pad4(xyz), _pad4(layer.STE_layer.weight[:, :, 0]))
     return out + ste
 
@@ -471,9 +483,9 @@ def _hs(layer, name, xyz, fm, graphs, level, k):
     sdn = F.normalize(layer.directions, dim=0)
     idx_rf = graphs(name + ".rf", None, fm, k)
     proj = linear(fm, layer.weights.t(), layer.bias)                      # (B, n, 8C) = [centre | support]
-    g = _GConvHS.apply(xyz, idx_rf, proj, sdn, C, graphs.rev(idx_rf, xyz.shape[1]))
+    g = _GConvHS.apply(xyz, idx_rf, proj, sdn, C, _reverse(graphs, idx_rf, xyz.shape[1]))
     idx_orl = graphs(name + ".orl_xyz", level, xyz, k)
-    out = _orl(layer, g, idx_orl, graphs.rev(idx_orl, xyz.shape[1]))
+    out = _orl(layer, g, idx_orl, _reverse(graphs, idx_orl, xyz.shape[1]))
     return out + linear(fm, layer.STE_layer.weight[:, :, 0])
 
 
