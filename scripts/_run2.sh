@@ -1,3 +1,3 @@
-O=$GRAFT_REPO_ROOT/gpurun_out/r03u
+O=$GRAFT_REPO_ROOT/gpurun_out/r03z
 mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "bit_repeatable" > $O/t.log 2>&1; tail -15 $O/t.log
+timeout -k 10 500 python scripts/train_glue.py > $O/glue.txt 2> $O/glue.err; tail -3 $O/glue.err; head -80 $O/glue.txt

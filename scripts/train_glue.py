@@ -29,5 +29,5 @@ for e in prof.key_averages(group_by_input_shape=True):
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print("ATen ops with device time: %.2f ms in one eager step" % (tot / 1e3))
-for t, c, k, s in rows[:40]:
+for t, c, k, s in rows[:70]:
     print("%8.1f us  x%-4d %-28s %s" % (t, c, k, s))

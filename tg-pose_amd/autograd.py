@@ -23,6 +23,13 @@ FEAT_C, FEAT_LD = engine.FEAT_C, engine.FEAT_LD
 S = 7
 
 
+def _w2(conv):
+    """(N, K) view of a kernel-size-1 Conv1d weight (N, K, 1).  A view, not `weight[:, :, 0]`: the select's backward is a zero fill
+    plus a copy of every weight gradient (two launches and 2 x the weight's bytes per layer and step), a view's is free."""
+    w = conv.weight
+    return w.view(w.shape[0], w.shape[1])
+
+
 def _pad4(t):
     """pad the last dim with zeros to a multiple of 4 (the GEMM kernels read 16-byte quads)"""
     r = (-t.shape[-1]) % 4
@@ -399,10 +406,11 @@ class _GatherRows(Function):
     def backward(ctx, dy):
         (near,) = ctx.saved_tensors
         B, n, C = dy.shape
-        if ctx.lists is not None and C % 4 == 0 and dy.stride(2) == 1 and dy.stride(0) == n * dy.stride(1) and dy.stride(1) % 4 == 0 \
-                and dy.data_ptr() % 16 == 0:
-            return ops.segsum_rows(dy.view(B * n, C) if dy.is_contiguous() else dy.as_strided((B * n, C), (dy.stride(1), 1)),
-                                   ctx.lists[0], ctx.lists[1]).view(B, ctx.n_src, C), None, None
+        if ctx.lists is not None and C % 4 == 0:
+            if not (dy.stride(2) == 1 and dy.stride(0) == n * dy.stride(1) and dy.stride(1) % 4 == 0 and dy.data_ptr() % 16 == 0):
+                dy = dy.contiguous()          # (a column slice of a 1286-wide gradient: rows not 16-byte aligned)
+            rows = dy.view(B * n, C) if dy.is_contiguous() else dy.as_strided((B * n, C), (dy.stride(1), 1))
+            return ops.segsum_rows(rows, ctx.lists[0], ctx.lists[1]).view(B, ctx.n_src, C), None, None
         return ops.gather_rows_bwd(dy.contiguous(), near, ctx.n_src), None, None
 
 
@@ -421,6 +429,19 @@ class _AddRowBias(Function):
 
 def add_row_bias(x, rb):
     return _AddRowBias.apply(x, rb)
+
+
+class _SplitCols(Function):
+    """w (N, K) -> (w[:, :c], w[:, c:]) as contiguous tensors; the backward is one concatenation (two column slices under autograd
+    cost two zero fills, two copies and an add per layer and step)"""
+
+    @staticmethod
+    def forward(ctx, w, c):
+        return w[:, :c].contiguous(), w[:, c:].contiguous()
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        return torch.cat([ga, gb], 1), None
 
 
 class _ColMax(Function):
@@ -463,9 +484,9 @@ def _orl(layer, g, idx_orl, rev=None):
     """ORL_forward (gcn3d.py:108-112,182-186): conv2(cat[g, global]) + g, with the concatenation split into the two
     halves of conv2's weight (the global half is one row per object)."""
     C = g.shape[-1]
-    w = layer.conv2.weight[:, :, 0]
+    w_pt, w_glob = _SplitCols.apply(_w2(layer.conv2), C)
     glob = _NbrMaxMean.apply(g, idx_orl, rev)                             # (B, C)
-    return add_row_bias(linear(g, w[:, :C]), linear(glob, w[:, C:])) + g
+    return add_row_bias(linear(g, w_pt), linear(glob, w_glob)) + g
 
 
 def _surface(layer, xyz, graphs, kmax):
@@ -474,7 +495,7 @@ def _surface(layer, xyz, graphs, kmax):
     g = _GConvSurface.apply(xyz, graphs("conv_0.rf", 0, xyz, kmax), sdn, C)
     idx_orl = graphs("conv_0.orl_xyz", 0, xyz, kmax)
     out = _orl(layer, g, idx_orl, _reverse(graphs, idx_orl, xyz.shape[1]))
-    ste = linear(_pad4(xyz), _pad4(layer.STE_layer.weight[:, :, 0]))
+    ste = linear(_pad4(xyz), _pad4(_w2(layer.STE_layer)))
     return out + ste
 
 
@@ -486,7 +507,7 @@ def _hs(layer, name, xyz, fm, graphs, level, k):
     g = _GConvHS.apply(xyz, idx_rf, proj, sdn, C, _reverse(graphs, idx_rf, xyz.shape[1]))
     idx_orl = graphs(name + ".orl_xyz", level, xyz, k)
     out = _orl(layer, g, idx_orl, _reverse(graphs, idx_orl, xyz.shape[1]))
-    return out + linear(fm, layer.STE_layer.weight[:, :, 0])
+    return out + linear(fm, _w2(layer.STE_layer))
 
 
 class _GraphSource(object):
@@ -521,8 +542,9 @@ class _GraphSource(object):
 
 
 def encoder(enc, xyz, obj_id, sample_idx, graphs, kmax=20, n_cls=6):
-    """Face_Enc.forward (FaceRecon.py:39-86) -> feat (B, N, FEAT_LD): [fm_0..fm_4 | one-hot | xyz | 0 0 0], and the operands of
-    the factored layers over it (None when FACTORED is off)"""
+    """Face_Enc.forward (FaceRecon.py:39-86) -> feat, and the operands of the factored layers over it.  FACTORED off: feat is
+    (B, N, FEAT_LD) = [fm_0..fm_4 | one-hot | xyz | 0 0 0] (the layers' GEMM operand) and the operands are None; on: feat is
+    (B, N, FEAT_C) = [fm_0..fm_4 | one-hot]."""
     B, N, _ = xyz.shape
     dev = xyz.device
     s1 = sample_idx[0].to(device=dev, dtype=torch.int32)
@@ -547,10 +569,12 @@ def encoder(enc, xyz, obj_id, sample_idx, graphs, kmax=20, n_cls=6):
         lists1 = ops.child_lists(near1, v1.shape[1]) if SCATTER_FREE or FACTORED else None
         lists2 = ops.child_lists(near2, v2.shape[1]) if SCATTER_FREE or FACTORED else None
     up1, up2 = (lists1, lists2) if SCATTER_FREE else (None, None)
-    feat = torch.cat([fm0, fm1, _GatherRows.apply(fm2, near1, up1), _GatherRows.apply(fm3, near1, up1),
-                      _GatherRows.apply(fm4, near2, up2), tail], dim=2)
+    ups = [_GatherRows.apply(fm2, near1, up1), _GatherRows.apply(fm3, near1, up1), _GatherRows.apply(fm4, near2, up2)]
     if not FACTORED:
-        return feat, None
+        return torch.cat([fm0, fm1] + ups + [tail], dim=2), None
+    # factored: no GEMM reads the concat buffer, so it carries exactly the FEAT_C columns the outputs `feat` / `feat_global` have (no
+    # xyz / padding columns: a column slice under autograd costs a zero fill and a copy of the whole (B, N, 1292) gradient)
+    feat = torch.cat([fm0, fm1] + ups + [tail[:, :, :n_cls]], dim=2)
     # the operands of the factored form of the layers over feat (_FeatConsumersFactored): the columns that differ from point to
     # point, and the two coarse levels
     fine = torch.cat([fm0, fm1, F.pad(tail, (0, engine.FINE_LD - 256 - tail.shape[2]))], dim=2)
@@ -559,7 +583,7 @@ def encoder(enc, xyz, obj_id, sample_idx, graphs, kmax=20, n_cls=6):
 
 def _w_feat(conv, cols=FEAT_C):
     """weight of a Conv1d that reads the concat buffer, zero-padded to its row stride (the xyz columns included for Pose_Ts)"""
-    w = conv.weight[:, :, 0]
+    w = _w2(conv)
     return F.pad(w, (0, FEAT_LD - w.shape[1]))
 
 
@@ -587,19 +611,19 @@ def decoder(dec, feat, back, x=None):
     if back is not None:
         x = add_row_bias(x, linear(F.pad(back, (0, FEAT_LD - back.shape[1])), w0))
     x = bn_act(x, blk[1])
-    x = bn_act(linear(x, blk[3].weight[:, :, 0], blk[3].bias), blk[4])
-    x = bn_act(linear(x, blk[6].weight[:, :, 0], blk[6].bias), blk[7])
-    x = bn_act(linear(x, dec.recon_head[0].weight[:, :, 0], dec.recon_head[0].bias), dec.recon_head[1])
-    return linear(x, dec.recon_head[3].weight[:, :, 0], dec.recon_head[3].bias)
+    x = bn_act(linear(x, _w2(blk[3]), blk[3].bias), blk[4])
+    x = bn_act(linear(x, _w2(blk[6]), blk[6].bias), blk[7])
+    x = bn_act(linear(x, _w2(dec.recon_head[0]), dec.recon_head[0].bias), dec.recon_head[1])
+    return linear(x, _w2(dec.recon_head[3]), dec.recon_head[3].bias)
 
 
 def point_head(hd, feat, x=None):
     """Rot_green / Rot_red / Pose_Ts (PoseR.py:26-39, PoseTs.py:31-45) on the concat buffer -> (B, out)"""
     x = bn_act(linear(feat, _w_feat(hd.conv1), hd.conv1.bias) if x is None else x, hd.bn1)
-    x = bn_act_pool(linear(x, hd.conv2.weight[:, :, 0], hd.conv2.bias), hd.bn2)
-    x = bn_act(linear(x, hd.conv3.weight[:, :, 0], hd.conv3.bias), hd.bn3)
+    x = bn_act_pool(linear(x, _w2(hd.conv2), hd.conv2.bias), hd.bn2)
+    x = bn_act(linear(x, _w2(hd.conv3), hd.conv3.bias), hd.bn3)
     x = hd.drop1(x)
-    return linear(x, hd.conv4.weight[:, :, 0], hd.conv4.bias)
+    return linear(x, _w2(hd.conv4), hd.conv4.bias)
 
 
 def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6, cut=None):
@@ -620,8 +644,8 @@ def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=Non
         graphs = _GraphSource(points.device, inject, record, "face_enc.encoder.")
         feat, parts = encoder(face.encoder, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
         dec0 = face.decoder.conv1d_block[0]
-        xd = feat_consumers_factored(parts, [(dec0.weight[:, :, 0], dec0.bias)])[0] if parts is not None else None
-        return dict(feat_global=colmax(feat[:, :, :FEAT_C]), recon=decoder(face.decoder, feat, None, xd))
+        xd = feat_consumers_factored(parts, [(_w2(dec0), dec0.bias)])[0] if parts is not None else None
+        return dict(feat_global=colmax(feat[:, :, :FEAT_C] if parts is None else feat), recon=decoder(face.decoder, feat, None, xd))
     face = net.face_all
     graphs = _GraphSource(points.device, inject, record, "face_all.encoder.")
     feat, parts = encoder(face.encoder, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
@@ -633,7 +657,7 @@ def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=Non
             parts = (fine, fm23, fm4) + parts[3:]
     # the five layers over `feat` as one autograd node: factored over the up-sampling (_FeatConsumersFactored), or over the concat
     # buffer with d feat accumulated inside their dx GEMMs (_FeatConsumers)
-    w1 = lambda conv: conv.weight[:, :, 0]
+    w1 = _w2
     dec0 = face.decoder.conv1d_block[0]
     layers = [(w1(face.ph_pred.conv_5[0]), None), (w1(dec0), dec0.bias), (w1(net.rot_green.conv1), net.rot_green.conv1.bias),
               (w1(net.rot_red.conv1), net.rot_red.conv1.bias), (w1(net.ts.conv1), net.ts.conv1.bias)]
@@ -654,8 +678,8 @@ def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=Non
     out["Pred_s"] = ts[:, 3:6]
     if train_keys:
         out["h1"], out["h2"] = h1, h2
-        out["feat"] = feat[:, :, :FEAT_C]
-        out["feat_global"] = colmax(feat[:, :, :FEAT_C])
+        out["feat"] = feat[:, :, :FEAT_C] if parts is None else feat
+        out["feat_global"] = colmax(out["feat"])
     return out
 
 
