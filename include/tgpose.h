@@ -591,6 +591,15 @@ int tgp_gconv_hs_bwd_gather(const float *xyz, const int32_t *idx, const int32_t 
 int tgp_gconv_hs_fwd_slots(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B, int n, int k, int S,
                            int C, float *out, int ldo, uint8_t *slots, tgp_stream_t stream);
 
+/* ---- the rotation R_DCD canonicalises with, and its gradient (ABI 4; csrc/poserot.hip) --------------------------------------------
+ * losses/TDA_loss_sym_recon.py:327-333 (get_vertical_rot_vec_in_batch :370-395 for the symmetric and the general case,
+ * get_rot_mat_y_first :351-360) in one launch.  gR0 (B, 3) = g_R[:, :, 0]; p_g, p_r (B, 3) predicted axes; f_g, f_r (B) their
+ * confidences; sym0 (B) = sym[:, 0] as float.  R (B, 3, 3) row-major; J (B, 9, 8) = d R / d (p_g, f_g, p_r, f_r), evaluated by
+ * forward-mode differentiation of the same formulas.  tgp_pose_rotation_bwd: din (B, 8) = J^T dR per object. */
+int tgp_pose_rotation_fwd(const float *gR0, const float *p_g, const float *f_g, const float *p_r, const float *f_r, const float *sym0,
+                          int B, float *R, float *J, tgp_stream_t stream);
+int tgp_pose_rotation_bwd(const float *dR, const float *J, int B, float *din, tgp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

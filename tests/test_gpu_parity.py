@@ -1433,6 +1433,45 @@ def test_feat_consumers_factored_vs_fp64_concat(ops, gemm_mode):
     assert all(v <= (1e-5 if k.startswith("y") and gemm_mode == "fp32" else bar) for k, v in errs.items()), errs
 
 
+def test_pose_rotation_fused_vs_torch_autograd(ops):
+    """losses.dcd.pose_rotation (one launch forward with the Jacobian by forward-mode differentiation, one backward) against the
+    same formulas as (B, 3)-sized torch arithmetic under autograd (TDA_loss_sym_recon.py:327-333, :351-360, :370-395): the
+    rotation and the gradients of the predicted axes and confidences, symmetric and non-symmetric objects mixed, axes that are
+    far from perpendicular and nearly parallel (the clamp in front of acos) included."""
+    from tgpose_amd.losses import dcd
+    B = 64
+    gen = torch.Generator().manual_seed(3)
+    unit = lambda t: t / t.norm(dim=1, keepdim=True)
+    p_g, p_r = unit(torch.randn(B, 3, generator=gen)), unit(torch.randn(B, 3, generator=gen))
+    p_r[:4] = unit(p_g[:4] + 1e-4 * torch.randn(4, 3, generator=gen))          # nearly parallel: clamp active or close to it
+    g_R = torch.linalg.qr(torch.randn(B, 3, 3, generator=gen))[0]
+    f_g, f_r = torch.rand(B, generator=gen) * 0.9 + 0.05, torch.rand(B, generator=gen) * 0.9 + 0.05
+    sym = torch.zeros(B, 4)
+    sym[::3, 0] = 1
+    w = torch.randn(B, 3, 3, generator=gen)
+    res = []
+    for fn in (dcd.pose_rotation, dcd.pose_rotation_torch):
+        leaves = [g(t).clone().requires_grad_(True) for t in (p_g, f_g, p_r, f_r)]
+        R = fn(g(g_R), leaves[0], leaves[1], leaves[2], leaves[3], g(sym))
+        (R * g(w)).sum().backward()
+        res.append((R.detach(), [l.grad for l in leaves]))
+    # rows 4.. are well conditioned: rounding-level agreement.  Rows 0..3 (axes 1e-4 apart: the common normal is a difference of
+    # nearly equal products, its normalisation amplifies every rounding by 1e4) are held to that conditioning.
+    err = (res[0][0] - res[1][0]).abs().amax(dim=(1, 2))
+    print("pose_rotation: max |dR| well conditioned %.1e, nearly parallel axes %.1e" % (float(err[4:].max()), float(err[:4].max())))
+    assert float(err[4:].max()) <= 2e-6 and float(err[:4].max()) <= 5e-3
+    eye = torch.eye(3, device=DEV).expand(B, 3, 3)
+    assert torch.allclose(res[0][0].transpose(1, 2) @ res[0][0], eye, atol=1e-5)
+    for name, a, b_ in zip(("p_g", "f_g", "p_r", "f_r"), res[0][1], res[1][1]):
+        assert bool(torch.isfinite(b_).all()) and bool(torch.isfinite(a).all()), name
+        scale = float(b_[4:].abs().max())
+        assert torch.allclose(a[4:], b_[4:], atol=2e-5 * scale, rtol=1e-4), (name, float((a[4:] - b_[4:]).abs().max()), scale)
+        rel = float((a[:4] - b_[:4]).norm() / (b_[:4].norm() + 1e-30))
+        assert rel <= 2e-2, (name, rel)
+    # the symmetric objects take no gradient from the red axis or its confidence
+    assert float(res[0][1][2][::3].abs().max()) == 0.0 and float(res[0][1][3][::3].abs().max()) == 0.0
+
+
 def test_eval_outputs_only_returns_the_same_six_outputs(ops):
     """engine.EVAL_OUTPUTS_ONLY (deployment switch: the PH predictor and the decoder, which the eval dict of PoseNet9D.py:85-90 does
     not return, are not computed) gives the six outputs of the full eval forward bit for bit."""

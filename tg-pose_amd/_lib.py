@@ -156,6 +156,8 @@ SIGNATURES = {
     "tgp_sort_by_parent": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tgp_roi_cloud": (c_int, [c_vp] * 7 + [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_cloud_select": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, c_vp, c_vp]),
+    "tgp_pose_rotation_fwd": (c_int, [c_vp] * 6 + [c_int, c_vp, c_vp, c_vp]),
+    "tgp_pose_rotation_bwd": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp]),
     "tgp_reverse_graph": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_nbrmax_bwd_gather": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_f32,
                                       c_vp, c_vp, c_int, c_vp]),

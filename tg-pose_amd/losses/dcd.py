@@ -115,9 +115,34 @@ def _vertical_axes(c1, c2, y, z):
     return _rodrigues(k, c2 / (c1 + c2) * theta, y), _rodrigues(k, -(c1 / (c1 + c2)) * theta, z)
 
 
+class _PoseRotation(Function):
+    """pose_rotation_torch as one launch forward (R and its Jacobian by forward-mode differentiation in the kernel) and one backward
+    (csrc/poserot.hip): ~300 element-wise launches less per training step"""
+
+    @staticmethod
+    def forward(ctx, gR0, p_g, f_g, p_r, f_r, sym0):
+        R, J = ops.pose_rotation_fwd(gR0, p_g, f_g, p_r, f_r, sym0)
+        ctx.save_for_backward(J)
+        return R
+
+    @staticmethod
+    def backward(ctx, dR):
+        (J,) = ctx.saved_tensors
+        din = ops.pose_rotation_bwd(dR.contiguous(), J)
+        return None, din[:, 0:3], din[:, 3], din[:, 4:7], din[:, 7], None
+
+
 def pose_rotation(g_R, p_g_vec, f_g_vec, p_r_vec, f_r_vec, sym):
     """The rotation R_DCD canonicalises with (TDA_loss_sym_recon.py:327-333, get_rot_mat_y_first :351-360): (B,3,3),
-    differentiable w.r.t. the predicted axes and confidences ((B,3)-sized torch arithmetic)."""
+    differentiable w.r.t. the predicted axes and confidences."""
+    c = lambda t: t.float().contiguous()
+    return _PoseRotation.apply(c(g_R[..., 0]), c(p_g_vec), c(f_g_vec).reshape(-1), c(p_r_vec), c(f_r_vec).reshape(-1),
+                               c(sym[:, 0]))
+
+
+def pose_rotation_torch(g_R, p_g_vec, f_g_vec, p_r_vec, f_r_vec, sym):
+    """pose_rotation as (B,3)-sized torch arithmetic under autograd: the formulation the fused kernel is tested against
+    (tests/test_gpu_parity.py::test_pose_rotation_fused_vs_torch_autograd)"""
     ys, xs = _vertical_axes(f_g_vec, torch.full_like(f_g_vec, 1e-5), p_g_vec, g_R[..., 0])
     y, x = _vertical_axes(f_g_vec, f_r_vec, p_g_vec, p_r_vec)
     flag = sym[:, 0].unsqueeze(-1) == 1

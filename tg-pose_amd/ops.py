@@ -878,6 +878,23 @@ def gather_rows_bwd(dy, idx, n_src):
     return dsrc
 
 
+def pose_rotation_fwd(gR0, p_g, f_g, p_r, f_r, sym0):
+    """-> R (B,3,3), J (B,9,8): tgp_pose_rotation_fwd (all inputs float32, contiguous, on the device)"""
+    B = p_g.shape[0]
+    R = torch.empty(B, 3, 3, device=p_g.device, dtype=torch.float32)
+    J = torch.empty(B, 9, 8, device=p_g.device, dtype=torch.float32)
+    check(_lib.lib().tgp_pose_rotation_fwd(_p(gR0), _p(p_g), _p(f_g), _p(p_r), _p(f_r), _p(sym0), B, _p(R), _p(J), _stream(p_g)),
+          "tgp_pose_rotation_fwd")
+    return R, J
+
+
+def pose_rotation_bwd(dR, J):
+    B = J.shape[0]
+    din = torch.empty(B, 8, device=J.device, dtype=torch.float32)
+    check(_lib.lib().tgp_pose_rotation_bwd(_p(dR), _p(J), B, _p(din), _stream(J)), "tgp_pose_rotation_bwd")
+    return din
+
+
 def reverse_graph(idx, n_src):
     """idx (B, n_rows, k) int32 ids in [0, n_src) -> (rptr (B*n_src + 1,), rent (B*n_rows*k,)) int32: for every source row the
     ascending (row << 6 | slot) pairs that list it; None when the shape is outside what tgp_reverse_graph sorts in LDS"""
