@@ -599,6 +599,11 @@ int tgp_gconv_hs_fwd_slots(const float *xyz, const int32_t *idx, const float *pr
 int tgp_pose_rotation_fwd(const float *gR0, const float *p_g, const float *f_g, const float *p_r, const float *f_r, const float *sym0,
                           int B, float *R, float *J, tgp_stream_t stream);
 int tgp_pose_rotation_bwd(const float *dR, const float *J, int B, float *din, tgp_stream_t stream);
+/* backward of tgp_head_post (PoseNet9D.py:57-66): dgreen (B, 4), dred (B, 4), dts (B, 6) contiguous, from the gradients of the six
+ * outputs (contiguous; NULL = zero). */
+int tgp_head_post_bwd(const float *green, const float *red, int ldg, int ldr, int B, const float *g_pg, const float *g_pr,
+                      const float *g_fg, const float *g_fr, const float *g_T, const float *g_s, float *dgreen, float *dred, float *dts,
+                      tgp_stream_t stream);
 
 #ifdef __cplusplus
 }

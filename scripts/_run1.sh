@@ -1,6 +1,6 @@
 O=$GRAFT_REPO_ROOT/gpurun_out/r03v
 mkdir -p $O
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "pose_rotation or dcd or tda_loss or train_step or captured or graphed" > $O/t.log 2>&1 || { tail -40 $O/t.log; exit 1; }
+timeout -k 10 1100 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "pose_rotation or dcd or tda_loss or train or captured or graphed or backward or loss or consistency" > $O/t.log 2>&1 || { tail -40 $O/t.log; exit 1; }
 tail -2 $O/t.log
 cd /tmp && export TMPDIR=/tmp
 python3 $GRAFT_REPO_ROOT/bench.py --workload train_step --steps 30 --warmup 5 --no-cpu-baseline > $O/train_step.jsonl 2> $O/err0.log || exit 1

@@ -431,6 +431,23 @@ def add_row_bias(x, rb):
     return _AddRowBias.apply(x, rb)
 
 
+class _HeadPost(Function):
+    """PoseNet9D.py:57-66 on the heads' raw outputs -- axis / (|axis| + 1e-6), sigmoid of the confidences, T = ts[:3] + mean,
+    s = ts[3:] -- as one launch each way (tgp_head_post, the eval forward's kernel, and tgp_head_post_bwd)"""
+
+    @staticmethod
+    def forward(ctx, green, red, ts, mean):
+        green, red, ts = green.contiguous(), red.contiguous(), ts.contiguous()
+        ctx.save_for_backward(green, red)
+        return ops.head_post(green, red, ts, mean)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        green, red = ctx.saved_tensors
+        dg, dr, dt = ops.head_post_bwd(green, red, grads)
+        return dg, dr, dt, None
+
+
 class _SplitCols(Function):
     """w (N, K) -> (w[:, :c], w[:, c:]) as contiguous tensors; the backward is one concatenation (two column slices under autograd
     cost two zero fills, two copies and an add per layer and step)"""
@@ -670,12 +687,8 @@ def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=Non
     out = dict()
     if train_keys:
         out["recon"] = recon + mean
-    out["p_green_R"] = green[:, 1:] / (torch.norm(green[:, 1:], dim=1, keepdim=True) + 1e-6)
-    out["p_red_R"] = red[:, 1:] / (torch.norm(red[:, 1:], dim=1, keepdim=True) + 1e-6)
-    out["f_green_R"] = torch.sigmoid(green[:, 0])
-    out["f_red_R"] = torch.sigmoid(red[:, 0])
-    out["Pred_T"] = ts[:, 0:3] + mean[:, 0]
-    out["Pred_s"] = ts[:, 3:6]
+    (out["p_green_R"], out["p_red_R"], out["f_green_R"], out["f_red_R"], out["Pred_T"], out["Pred_s"]) = _HeadPost.apply(
+        green, red, ts, mean[:, 0].contiguous())
     if train_keys:
         out["h1"], out["h2"] = h1, h2
         out["feat"] = feat[:, :, :FEAT_C] if parts is None else feat

@@ -212,3 +212,47 @@ extern "C" int tgp_pose_rotation_bwd(const float *dR, const float *J, int B, flo
     hipLaunchKernelGGL(pose_rotation_bwd_kernel, dim3(tgp_cdiv(B * PR_NIN, 64)), dim3(64), 0, tgp_hs(stream), dR, J, B, din);
     return TGP_LAUNCH_RESULT();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward of tgp_head_post (PoseNet9D.py:57-66: axis / (|axis| + 1e-6), sigmoid of the confidences, T = ts[:3] + mean, s = ts[3:]):
+// d green (B, 4), d red (B, 4), d ts (B, 6) from the gradients of the six outputs (a NULL gradient counts as zero).  Under autograd
+// the same lines are ~10 launches forward and ~25 backward.
+__device__ __forceinline__ void hp_axis_bwd(const float *v4, const float *gp, float gf, float *dv4)
+{
+    // v4 = (confidence logit, x, y, z);  p = v / (n + eps), n = |v|:  dv = g / (n + eps) - v (v . g) / (n (n + eps)^2)
+    const float x = v4[1], y = v4[2], z = v4[3];
+    const float n = sqrtf((x * x + y * y) + z * z), ne = n + 1e-6f;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    if (gp) gx = gp[0], gy = gp[1], gz = gp[2];
+    const float vg = (x * gx + y * gy) + z * gz;
+    const float k = n > 0.f ? vg / (n * ne * ne) : 0.f;      // (torch.norm's backward at the origin: 0)
+    dv4[1] = gx / ne - x * k, dv4[2] = gy / ne - y * k, dv4[3] = gz / ne - z * k;
+    const float f = 1.0f / (1.0f + expf(-v4[0]));
+    dv4[0] = gf * f * (1.f - f);
+}
+
+__global__ void head_post_bwd_kernel(const float *__restrict__ green, const float *__restrict__ red, int ldg, int ldr, int B,
+                                     const float *__restrict__ g_pg, const float *__restrict__ g_pr, const float *__restrict__ g_fg,
+                                     const float *__restrict__ g_fr, const float *__restrict__ g_T, const float *__restrict__ g_s,
+                                     float *__restrict__ dgreen, float *__restrict__ dred, float *__restrict__ dts)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    hp_axis_bwd(green + b * ldg, g_pg ? g_pg + 3 * b : nullptr, g_fg ? g_fg[b] : 0.f, dgreen + 4 * b);
+    hp_axis_bwd(red + b * ldr, g_pr ? g_pr + 3 * b : nullptr, g_fr ? g_fr[b] : 0.f, dred + 4 * b);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        dts[6 * b + c] = g_T ? g_T[3 * b + c] : 0.f;
+        dts[6 * b + 3 + c] = g_s ? g_s[3 * b + c] : 0.f;
+    }
+}
+
+extern "C" int tgp_head_post_bwd(const float *green, const float *red, int ldg, int ldr, int B, const float *g_pg, const float *g_pr,
+                                 const float *g_fg, const float *g_fr, const float *g_T, const float *g_s, float *dgreen, float *dred,
+                                 float *dts, tgp_stream_t stream)
+{
+    TGP_REQUIRE(green && red && dgreen && dred && dts && B > 0 && ldg >= 4 && ldr >= 4);
+    hipLaunchKernelGGL(head_post_bwd_kernel, dim3(tgp_cdiv(B, 64)), dim3(64), 0, tgp_hs(stream), green, red, ldg, ldr, B, g_pg, g_pr, g_fg,
+                       g_fr, g_T, g_s, dgreen, dred, dts);
+    return TGP_LAUNCH_RESULT();
+}

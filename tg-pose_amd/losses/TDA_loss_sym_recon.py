@@ -71,17 +71,18 @@ class TDA_loss(nn.Module):
             self.kind, self.beta = 1, 0.5
         else:
             raise NotImplementedError
+        self._wcache = {}                              # FLAGS weights of the eight regression terms as device vectors
 
     # ---- the bundle --------------------------------------------------------------------------------------------------------
-    def pose_terms(self, pred_list, gt_list, sym):
-        """dict of the eight UNWEIGHTED regression terms, one launch"""
+    def pose_terms(self, pred_list, gt_list, sym, stacked=False):
+        """dict of the eight UNWEIGHTED regression terms, one launch (stacked: the (8,) tensor itself)"""
         out = _PoseTerms.apply(_f(pred_list["Rot1"]), _f(pred_list["Rot2"]), _f(pred_list["Rot1_f"]).reshape(-1),
                                _f(pred_list["Rot2_f"]).reshape(-1), _f(pred_list["Tran"]), _f(pred_list["Size"]),
                                _f(gt_list["Rot1"]), _f(gt_list["Rot2"]), _f(gt_list["Tran"]), _f(gt_list["Size"]),
                                ops.sym_i32(sym), self.kind, self.beta)
-        return dict(zip(POSE_TERMS, out.unbind(0)))
+        return out if stacked else dict(zip(POSE_TERMS, out.unbind(0)))
 
-    def _bundle(self, pred_list, gt_list, sym):
+    def _bundle(self, pred_list, gt_list, sym, stacked=False):
         """pose_terms with zeros standing in for operands the caller's dicts lack (their terms are then not asked for)"""
         have = [v for v in (pred_list.get("Rot1"), pred_list.get("Rot2"), pred_list.get("Tran"), pred_list.get("Size")) if v is not None]
         B = have[0].shape[0]
@@ -89,21 +90,31 @@ class TDA_loss(nn.Module):
         pick = lambda d, k, z: d[k] if d.get(k) is not None else z
         pred = {k: pick(pred_list, k, z1 if k.endswith("_f") else z3) for k in ("Rot1", "Rot2", "Rot1_f", "Rot2_f", "Tran", "Size")}
         gt = {k: pick(gt_list, k, z3) for k in ("Rot1", "Rot2", "Tran", "Size")}
-        return self.pose_terms(pred, gt, sym)
+        return self.pose_terms(pred, gt, sym, stacked)
+
+    def _weighted(self, pred_list, gt_list, sym):
+        """the eight regression terms times their FLAGS weights: one multiply for all of them (a product per term is a launch
+        forward and one backward each)"""
+        wts = (FLAGS.rot_1_w, FLAGS.rot_1_w, FLAGS.rot_2_w, FLAGS.rot_2_w, FLAGS.rot_regular, FLAGS.tran_w, FLAGS.size_w, FLAGS.r_con_w)
+        t = self._bundle(pred_list, gt_list, sym, stacked=True)
+        key = (t.device, tuple(float(w) for w in wts))
+        if key not in self._wcache:
+            self._wcache[key] = torch.tensor(key[1], dtype=torch.float32).to(t.device)
+        return dict(zip(POSE_TERMS, (t * self._wcache[key]).unbind(0)))
 
     def forward(self, name_list, pred_list, gt_list, sym, gt_pred_flag=False):
         loss_list = dict()
-        t = self._bundle(pred_list, gt_list, sym) if any(n in name_list for n in POSE_TERMS) else None
+        t = self._weighted(pred_list, gt_list, sym) if any(n in name_list for n in POSE_TERMS) else None
         if "Rot1" in name_list:
-            loss_list["Rot1"] = FLAGS.rot_1_w * t["Rot1"]
+            loss_list["Rot1"] = t["Rot1"]
         if "Rot1_cos" in name_list:
-            loss_list["Rot1_cos"] = FLAGS.rot_1_w * t["Rot1_cos"]
+            loss_list["Rot1_cos"] = t["Rot1_cos"]
         if "Rot2" in name_list:
-            loss_list["Rot2"] = FLAGS.rot_2_w * t["Rot2"].reshape(1)
+            loss_list["Rot2"] = t["Rot2"].reshape(1)
         if "Rot2_cos" in name_list:
-            loss_list["Rot2_cos"] = FLAGS.rot_2_w * t["Rot2_cos"].reshape(1)
+            loss_list["Rot2_cos"] = t["Rot2_cos"].reshape(1)
         if "Rot_regular" in name_list:
-            loss_list["Rot_r_a"] = FLAGS.rot_regular * t["Rot_regular"].reshape(1)
+            loss_list["Rot_r_a"] = t["Rot_regular"].reshape(1)
         if "Prop_sym" in name_list and (FLAGS.prop_sym_w > 0):
             loss_list["Prop_sym"] = FLAGS.prop_sym_w * self.prop_sym_matching_loss(
                 gt_list['Recon'], pred_list['Recon'], pred_list['Rot1'], pred_list['Rot2'], pred_list['Tran'], gt_list['R'],
@@ -111,11 +122,11 @@ class TDA_loss(nn.Module):
         if "recon_completion" in name_list and (FLAGS.recon_w > 0):      # (:70-72; in none of organize_loss's lists)
             loss_list["recon_completion"] = FLAGS.recon_w * self.recon_completion_loss(gt_list['Recon'], pred_list['Recon'])
         if "Tran" in name_list:
-            loss_list["Tran"] = FLAGS.tran_w * t["Tran"]
+            loss_list["Tran"] = t["Tran"]
         if "Size" in name_list:
-            loss_list["Size"] = FLAGS.size_w * t["Size"]
+            loss_list["Size"] = t["Size"]
         if "R_con" in name_list:
-            loss_list["R_con"] = FLAGS.r_con_w * t["R_con"]
+            loss_list["R_con"] = t["R_con"]
         if "TDA_h1_cate" in name_list:
             loss_list["TDA_h1_cate"] = self.ph_loss_fn_cate(pred_list["TDA_h1"], gt_list["pdh1_category"], gt_list["h1"])
         if "TDA_h1" in name_list:

@@ -533,6 +533,16 @@ def head_post(green, red, ts, mean):
     return pg, pr, fg, fr, pT, ps
 
 
+def head_post_bwd(green, red, grads):
+    """grads: gradients of head_post's six outputs (None = zero) -> d green (B,4), d red (B,4), d ts (B,6)"""
+    B, dev = green.shape[0], green.device
+    gs = [None if t is None else t.float().contiguous() for t in grads]
+    dg, dr, dt = torch.empty(B, 4, device=dev), torch.empty(B, 4, device=dev), torch.empty(B, 6, device=dev)
+    check(_lib.lib().tgp_head_post_bwd(_p(green), _p(red), green.stride(0), red.stride(0), B, *[_p(t) for t in gs], _p(dg), _p(dr),
+                                       _p(dt), _stream(green)), "tgp_head_post_bwd")
+    return dg, dr, dt
+
+
 @_timed("graph")
 def add_mean_(recon, mean):
     B, n, _ = recon.shape
