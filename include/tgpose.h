@@ -605,6 +605,14 @@ int tgp_head_post_bwd(const float *green, const float *red, int ldg, int ldr, in
                       const float *g_fg, const float *g_fr, const float *g_T, const float *g_s, float *dgreen, float *dred, float *dts,
                       tgp_stream_t stream);
 
+/* ---- dW = dy^T x on the fp16 split without transposed copies (ABI 4; csrc/gemm_tn_split.hip) --------------------------------------
+ * a = dy (rows, N), b = x (rows, K), both row-major; scale = tgp_absmax_scale(a) ({s, 1/s, ...} on the device).  The reduction over
+ * the rows is cut into Z chunks of `chunk` rows (Z * chunk >= rows); parts (Z, N, K) receives their partial products, which
+ * tgp_sum_slabs adds in order and unscales.  N, K, lda, ldb multiples of 4 and 16-byte aligned operands, else TGP_EUNSUPPORTED
+ * (the caller then takes the transposed-copy form: tgp_transpose_scaled + tgp_transpose_split_f16 + tgp_gemm_f32). */
+int tgp_gemm_tn_split(const float *a, int lda, const float *b, int ldb, int rows, int N, int K, const float *scale, int Z, int chunk,
+                      float *parts, tgp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1092,7 +1092,8 @@ def test_gemm_tn_vs_fp64(ops, rows, N, K, lda, ldb):
     assert torch.allclose(acc, 2 * got, rtol=1e-6, atol=0)
 
 
-@pytest.mark.parametrize("rows,N,K", [(32896, 256, 1024), (32896, 1024, 1292), (8224, 2304, 128), (4112, 512, 512), (32896, 131, 260)])
+@pytest.mark.parametrize("rows,N,K", [(32896, 256, 1024), (32896, 1024, 1292), (8224, 2304, 128), (4112, 512, 512), (32896, 131, 260),
+                                      (32893, 260, 516), (2056, 4608, 512)])
 @pytest.mark.parametrize("mag", [1.0, 3e-7])
 def test_gemm_tn_fp16_split_vs_fp64(ops, rows, N, K, mag):
     """The weight-gradient GEMM on the fp16 split kernels (scale chosen on the device, K-split partial sums): gradient-sized
@@ -1119,6 +1120,15 @@ def test_gemm_tn_fp16_split_vs_fp64(ops, rows, N, K, mag):
         ops.TN_SPLIT = old
     assert (base.cpu().double() - want).abs().max().item() * 3 + 1e-7 * ref >= err      # no worse than ~3x the fp32 MFMA path
     assert torch.equal(got, ops.gemm_tn(g(dy), g(x)))
+    # round 3: the operands as they lie (transposed LDS reads, csrc/gemm_tn_split.hip) against the transposed-copy form of the same
+    # products: same split, same chunks -- equal to the rounding of the slab sums
+    oldn, ops.TN_NATIVE = ops.TN_NATIVE, False
+    try:
+        copied = ops.gemm_tn(g(dy), g(x))
+    finally:
+        ops.TN_NATIVE = oldn
+    assert (copied.cpu().double() - want).abs().max().item() <= 2e-6 * ref * max(1.0, (rows / 1000) ** 0.5)
+    assert (copied - got).abs().max().item() <= 1e-6 * ref
     acc = ops.gemm_tn(g(dy), g(x), out=got.clone(), accumulate=True)
     assert torch.allclose(acc, 2 * got, rtol=1e-6, atol=0)
     zero = ops.gemm_tn(g(torch.zeros(rows, N)), g(x))

@@ -676,6 +676,7 @@ def _ws(floats, dev):
 FP16_TOP = 32768.0           # scaled gradients peak in [2^14, 2^15): a factor of two under fp16's largest finite value
 TN_SPLIT = os.environ.get("TGP_TN_SPLIT", "1") != "0"    # backward GEMMs of large layers on the scaled fp16 split (0: bf16x3 / fp32 MFMA)
 TN_SPLIT_MIN = 128 * 256     # smallest N * K routed to the split path
+TN_NATIVE = os.environ.get("TGP_TN_NATIVE", "1") != "0"  # dW of the split path without transposed copies (0: transpose + NT kernel)
 
 
 def absmax_scale(x, target=FP16_TOP):
@@ -713,6 +714,17 @@ def gemm_tn_split(a, b, scale, out=None, accumulate=False):
     rows, N, K = math.prod(a.shape[:-1]), a.shape[-1], b.shape[-1]
     dev = a.device
     Z, chunk = _ksplit_plan(rows, ((N + 255) // 256) * ((K + 255) // 256))
+    if TN_NATIVE and N % 4 == 0 and K % 4 == 0 and lda % 4 == 0 and ldb % 4 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0:
+        # (round 3) the operands as they lie: transposed LDS reads instead of transposed copies (csrc/gemm_tn_split.hip)
+        parts = torch.empty(Z, N, K, device=dev, dtype=torch.float32)
+        check(_lib.lib().tgp_gemm_tn_split(_p(a), lda, _p(b), ldb, rows, N, K, _p(scale), Z, chunk, _p(parts), _stream(a)),
+              "tgp_gemm_tn_split")
+        if out is None:
+            out = torch.empty(N, K, device=dev, dtype=torch.float32)
+        if not out.is_contiguous():
+            raise ValueError("gemm_tn_split: out must be contiguous")
+        check(_lib.lib().tgp_sum_slabs(_p(parts), Z, N * K, _p(scale[1:]), _p(out), int(accumulate), _stream(a)), "tgp_sum_slabs")
+        return out
     pad = Z * chunk
     at = torch.empty(N, pad, device=dev, dtype=torch.float32)
     check(_lib.lib().tgp_transpose_scaled(_p(a), lda, rows, N, _p(scale), _p(at), pad, _stream(a)), "tgp_transpose_scaled")
