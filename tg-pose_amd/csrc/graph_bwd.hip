@@ -332,29 +332,44 @@ __global__ __launch_bounds__(GG_THREADS) void gconv_bwd_value_kernel(const float
     }
     __syncthreads();
     const float *pb = proj + (int64_t)b * n * ldp + C + e;
-#pragma unroll 4
-    for (int lp = 0; lp < GG_PTS; ++lp) {
-        const int i = base + lp;
-        if (i >= n) break;
-        const int64_t rowi = (int64_t)b * n + i;
-        const int bj = arg[rowi * SC + e];
-        float send = 0.f;
-        bool travels = false;
-        if (bj != 255) {
-            const float g = dg[rowi * ldg + c] / 7.0f;
-            const float4 nd = s_nd[lp][bj];
-            const float sup = pb[(int64_t)__float_as_int(nd.w) * ldp];
-            float th = fmaf(nd.z, D2, fmaf(nd.y, D1, nd.x * D0));   // same expression as the forward kernel
-            th = fmaxf(th, 0.f);
-            send = g * th;
-            travels = th != 0.f;
-            if (th > 0.f) {
-                const float dth = g * sup;
-                dD0 += dth * nd.x, dD1 += dth * nd.y, dD2 += dth * nd.z;
-            }
+    // in rounds of eight points, each round three batches of independent loads (slots | gradient, then the winners' support values):
+    // point by point the chain slot -> LDS -> gathered support value -> store ran sixteen times in a row per thread
+    for (int lp0 = 0; lp0 < GG_PTS; lp0 += 8) {
+        int bj[8];
+        float g[8], sup[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + lp0 + u;
+            const int64_t rowi = (int64_t)b * n + (i < n ? i : n - 1);
+            bj[u] = i < n ? arg[rowi * SC + e] : 255;
+            g[u] = dg[rowi * ldg + c] / 7.0f;
         }
-        if (!travels && bj != 255) arg[rowi * SC + e] = 255;
-        contrib[rowi * SC + e] = send;
+        float4 nd[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            nd[u] = s_nd[lp0 + u][bj[u] != 255 ? bj[u] : 0];
+            sup[u] = pb[(int64_t)__float_as_int(nd[u].w) * ldp];     // (slot 0 of an inactive point: a valid row, value unused)
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + lp0 + u;
+            if (i >= n) continue;
+            const int64_t rowi = (int64_t)b * n + i;
+            float send = 0.f;
+            bool travels = false;
+            if (bj[u] != 255) {
+                float th = fmaf(nd[u].z, D2, fmaf(nd[u].y, D1, nd[u].x * D0));   // same expression as the forward kernel
+                th = fmaxf(th, 0.f);
+                send = g[u] * th;
+                travels = th != 0.f;
+                if (th > 0.f) {
+                    const float dth = g[u] * sup[u];
+                    dD0 += dth * nd[u].x, dD1 += dth * nd[u].y, dD2 += dth * nd[u].z;
+                }
+            }
+            if (!travels && bj[u] != 255) arg[rowi * SC + e] = 255;
+            contrib[rowi * SC + e] = send;
+        }
     }
     float *o = dsdn_partial + (int64_t)part * 3 * SC;
     o[e] = dD0, o[SC + e] = dD1, o[2 * SC + e] = dD2;
@@ -362,7 +377,9 @@ __global__ __launch_bounds__(GG_THREADS) void gconv_bwd_value_kernel(const float
 
 // pass 2: dproj[q][C + e] = sum over (p, j) in q's reverse list with arg[p][e] == j of contrib[p][e];  dproj[q][c] = dg[q][c].
 // Four consecutive elements per thread (one 4-byte load of slots per entry, a 16-byte load of values on a match): 224 threads
-// cover a 896-element chunk.
+// cover a 896-element chunk.  (Measured and dropped: a workgroup per EIGHT consecutive source rows, their lists walked as one loop with
+// eight slot loads in flight across row boundaries -- 200 us per launch against 150: an eighth of the workgroups, each a long
+// serial walk; the one-row form's short chains overlap across the 8 workgroups a CU holds.)
 #define GG_GTHREADS (GG_THREADS / 4)
 __global__ __launch_bounds__(GG_GTHREADS) void gconv_bwd_gather_kernel(const uint8_t *__restrict__ arg, const float *__restrict__ contrib,
                                                                        const int32_t *__restrict__ rptr, const int32_t *__restrict__ rent,
