@@ -13,6 +13,8 @@ with the ground-truth record.
 The per-category tables are the reference's data (``evaluation/load_data_eval.py:477-545`` mean shapes in millimetres,
 ``:547-566`` symmetry flags); file reading stays with the caller.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -32,6 +34,9 @@ class myEvaluater:
 
     def __init__(self, net, frames_per_batch=32, max_batch=256, sampler="numpy", seed=0, overlap=True, graph=False):
         self.net1 = net.eval()
+        if getattr(net, "eval_outputs_only", None) is None and not os.environ.get("TGP_EVAL_FULL_FORWARD")   # (A/B switch: keep the full forward):
+            net.eval_outputs_only = True                     # the driver reads the six pose outputs only (:143-150): PH predictor and
+                                                             # decoder are dead code here, as in the reference's eval dict
         self.device = next(net.parameters()).device
         self.frames_per_batch, self.max_batch, self.sampler, self.seed, self.overlap = frames_per_batch, max_batch, sampler, seed, overlap
         self.graph = graph                                   # replay the forward as a captured hipGraph (PoseNet9D.graph_replay)

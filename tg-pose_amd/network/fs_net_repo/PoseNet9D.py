@@ -69,10 +69,19 @@ class PoseNet9D(_WithBuffers):
             if self.only_encoder:
                 return engine.encoder_only_forward(pk, points, obj_id, sample_idx, inject, record,
                                                    FLAGS.gcn_n_num, FLAGS.obj_c)
+            # net.eval_outputs_only = True (a deployment switch, e.g. the evaluation driver's): the layers whose results the six-key
+            # eval dict does not return -- PH predictor, decoder -- are not computed (engine.EVAL_OUTPUTS_ONLY for this call)
+            lean = getattr(self, "eval_outputs_only", None)
+            if lean is not None and bool(lean) != engine.EVAL_OUTPUTS_ONLY:
+                prev, engine.EVAL_OUTPUTS_ONLY = engine.EVAL_OUTPUTS_ONLY, bool(lean)
+                try:
+                    return self.forward(points, obj_id, enable_proj, sample_idx=sample_idx, inject=inject, record=record, cut=cut)
+                finally:
+                    engine.EVAL_OUTPUTS_ONLY = prev
             if getattr(self, "graph_replay", False) and inject is None and record is None:
                 # opt-in (net.graph_replay = True): the forward of this (batch, cloud size, output set) is captured once as
                 # a hipGraph and replayed; the returned tensors are the graph's static outputs, valid until the next call
-                key = (id(pk), tuple(points.shape), bool(FLAGS.train), ops.GEMM_MODE, engine.BRANCH_STREAMS)
+                key = (id(pk), tuple(points.shape), bool(FLAGS.train), ops.GEMM_MODE, engine.BRANCH_STREAMS, engine.EVAL_OUTPUTS_ONLY)
                 graphs = self.__dict__.setdefault("_graphs", {})
                 if key not in graphs:
                     graphs.clear()                      # one resident graph: its private pool holds every activation
