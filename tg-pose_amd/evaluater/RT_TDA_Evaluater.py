@@ -34,7 +34,7 @@ class myEvaluater:
 
     def __init__(self, net, frames_per_batch=32, max_batch=256, sampler="numpy", seed=0, overlap=True, graph=False):
         self.net1 = net.eval()
-        if getattr(net, "eval_outputs_only", None) is None and not os.environ.get("TGP_EVAL_FULL_FORWARD")   # (A/B switch: keep the full forward):
+        if getattr(net, "eval_outputs_only", None) is None and not os.environ.get("TGP_EVAL_FULL_FORWARD"):   # (A/B switch)
             net.eval_outputs_only = True                     # the driver reads the six pose outputs only (:143-150): PH predictor and
                                                              # decoder are dead code here, as in the reference's eval dict
         self.device = next(net.parameters()).device
