@@ -1,17 +1,10 @@
-O=$GRAFT_REPO_ROOT/gpurun_out/r03c
+O=$GRAFT_REPO_ROOT/gpurun_out/r03v
 mkdir -p $O
-cd $GRAFT_REPO_ROOT
-for i in 1 2; do
-timeout -k 10 600 python3 scripts/eval_pipeline.py > $O/eval_pipeline.txt 2>> $O/err.log || exit 1
+timeout -k 10 1100 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "bn_ or backward or train or captured or graphed or feat_consumers" > $O/t.log 2>&1 || { tail -40 $O/t.log; exit 1; }
+tail -2 $O/t.log
+cd /tmp && export TMPDIR=/tmp
+python3 $GRAFT_REPO_ROOT/bench.py --workload train_step --steps 30 --warmup 5 --no-cpu-baseline > $O/train_step.jsonl 2> $O/err0.log || exit 1
 python3 -c "
 import json
-for l in open('$O/eval_pipeline.txt'):
-    if l.startswith('{'):
-        d=json.loads(l); print('lean', d['sampler'], d['hipgraph'], d['frames_per_s'], d['objects_per_s'])"
-TGP_EVAL_LEAN_OFF=1 timeout -k 10 600 python3 scripts/eval_pipeline.py > $O/eval_pipeline_full.txt 2>> $O/err.log || exit 1
-python3 -c "
-import json
-for l in open('$O/eval_pipeline_full.txt'):
-    if l.startswith('{'):
-        d=json.loads(l); print('full', d['sampler'], d['hipgraph'], d['frames_per_s'], d['objects_per_s'])"
-done
+for f in ('train_step',):
+    d=json.loads(open('$O/'+f+'.jsonl').read().strip().splitlines()[-1]);print(f, d['ms_per_step'],d['value'])"

@@ -1443,6 +1443,27 @@ def test_feat_consumers_factored_vs_fp64_concat(ops, gemm_mode):
     assert all(v <= (1e-5 if k.startswith("y") and gemm_mode == "fp32" else bar) for k, v in errs.items()), errs
 
 
+@pytest.mark.parametrize("rows,C", [(32896, 512), (8224, 260), (2056, 128)])
+def test_bn_backward_collects_the_next_layers_scale(ops, rows, C):
+    """tgp_bn_bwd(absmax_bits): the apply pass leaves max |dx| behind, and the scale built from it equals tgp_absmax_scale's pass
+    over dx bit for bit (partial last column block, NaN in dx -> scale 1 on both sides)."""
+    gen = torch.Generator().manual_seed(rows + C)
+    x = g(torch.randn(rows, C, generator=gen) * 2 + 0.5)
+    dy = g(torch.randn(rows, C, generator=gen) * torch.exp(2.0 * torch.randn(rows, 1, generator=gen)) * 1e-5)
+    gamma, beta = g(torch.rand(C, generator=gen) + 0.5), g(torch.randn(C, generator=gen))
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    for poison in (False, True):
+        d = dy.clone()
+        if poison:
+            d[7, 3] = float("nan")
+        dx, _, _ = ops.bn_bwd(d, x, mean, var, gamma, beta, 1e-5, 1, 0.0, dx=torch.empty_like(x), want_scale=True)
+        assert torch.equal(dx._tgp_scale[:2], ops.absmax_scale(dx)[:2])
+        if not poison:
+            assert float(dx._tgp_scale[2]) == float(dx.abs().max())
+        else:
+            assert float(dx._tgp_scale[0]) == 1.0
+
+
 def test_pose_rotation_fused_vs_torch_autograd(ops):
     """losses.dcd.pose_rotation (one launch forward with the Jacobian by forward-mode differentiation, one backward) against the
     same formulas as (B, 3)-sized torch arithmetic under autograd (TDA_loss_sym_recon.py:327-333, :351-360, :370-395): the

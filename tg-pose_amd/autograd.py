@@ -45,7 +45,7 @@ def _split_if_big(w, rows, grads=False):
     return ops.split_bf16(w) if grads else ops.split_w(w, check=False)     # inside the (captured) step: no read-back
 
 
-def _linear_backward(x, W, dy, need_dx, need_dw, need_db, dx_accum=None):
+def _linear_backward(x, W, dy, need_dx, need_dw, need_db, dx_accum=None, scale=None):
     """dx = dy W (+ dx_accum, added by the GEMM's own epilogue), dW = dy^T x, db = colsum(dy) for y = x W^T + b; W contiguous (N, K).
     Both GEMMs of a large layer run on the fp16 split kernels with dy lifted into fp16's range by one power of two chosen on the
     device (ops.absmax_scale); small ones keep the bf16x3 / fp32 MFMA paths."""
@@ -57,7 +57,8 @@ def _linear_backward(x, W, dy, need_dx, need_dw, need_db, dx_accum=None):
     dx_f16 = need_dx and ops.GEMM_MODE == "split16" and ops.TN_SPLIT and ops._routes_to_big_tile(rows, K, 1, True)
     dw_f16 = need_dw and ops.tn_split_ok(rows, N, K)
     dyc = dy2.contiguous()
-    sc = ops.absmax_scale(dyc) if (dx_f16 or dw_f16) else None
+    # (scale: absmax_scale(dy) when the producer of dy collected it on the way -- the BatchNorm backward's apply pass)
+    sc = (scale if scale is not None else ops.absmax_scale(dyc)) if (dx_f16 or dw_f16) else None
     if need_dx:
         dyp = _pad4(dyc).contiguous()                       # the reduction dim of this GEMM is N
         wt = _pad4(ops.transpose(W)).contiguous()           # (K, N)
@@ -91,7 +92,8 @@ class _Linear(Function):
     @staticmethod
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
-        return _linear_backward(x, W, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        return _linear_backward(x, W, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2],
+                                scale=getattr(dy, "_tgp_scale", None))
 
 
 class _FeatConsumers(Function):
@@ -191,7 +193,8 @@ class _FeatConsumersFactored(Function):
                 gc = g.reshape(M, n).contiguous()
                 ops.segsum_rows(gc, ptr1, idx1, out=dP1[:, off:off + n])
                 ops.segsum_rows(gc, ptr2, idx2, out=dP2[:, off:off + n])
-                dx, dWa, db = _linear_backward(fine, Wa, gc, need[0], need[7 + 2 * i], ctx.has_bias[i] and need[8 + 2 * i], dx_accum=dfine)
+                dx, dWa, db = _linear_backward(fine, Wa, gc, need[0], need[7 + 2 * i], ctx.has_bias[i] and need[8 + 2 * i], dx_accum=dfine,
+                                               scale=getattr(g, "_tgp_scale", None))
                 dfine = dx if dx is not None else dfine
                 part.append((dWa, db))
             off += n
@@ -246,7 +249,10 @@ class _BNAct(Function):
     @staticmethod
     def backward(ctx, dy):
         x, mean, var, gamma, beta = ctx.saved_tensors
-        dx, dg, db = ops.bn_bwd(dy.contiguous(), x, mean, var, gamma, beta, BN_EPS, ctx.act, ctx.slope, dx=torch.empty_like(x))
+        # (large layers: the apply pass also collects max |dx|, which the backward of the linear layer in front needs for its scale)
+        big = x.shape[-1] >= 128 and x.numel() // x.shape[-1] >= 2048
+        dx, dg, db = ops.bn_bwd(dy.contiguous(), x, mean, var, gamma, beta, BN_EPS, ctx.act, ctx.slope, dx=torch.empty_like(x),
+                                want_scale=big)
         return dx, dg, db, None, None, None
 
 

@@ -323,9 +323,11 @@ __global__ __launch_bounds__(256) void bw_partial_v4_kernel(const float *__restr
 
 // both BatchNorm sums finished by one launch (was two): 64 columns x 4 chunk groups per workgroup, groups added in order
 __global__ __launch_bounds__(256) void bw_finish2_kernel(const float *__restrict__ p1, const float *__restrict__ p2, int chunks, int C,
-                                                         float *__restrict__ o1, float *__restrict__ o2, int accumulate)
+                                                         float *__restrict__ o1, float *__restrict__ o2, int accumulate,
+                                                         uint32_t *__restrict__ zero = nullptr)
 {
     __shared__ float sa[4][64], sb[4][64];
+    if (zero && blockIdx.x == 0 && threadIdx.x == 0) *zero = 0u;      // the apply pass that follows collects max |dx| here
     const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + l;
     const int per = (chunks + 3) / 4;
@@ -416,11 +418,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float *__res
                                                               const float *__restrict__ var, float eps, const float *__restrict__ gamma,
                                                               const float *__restrict__ beta, int act, float slope,
                                                               const float *__restrict__ slope_vec, const float *__restrict__ s1,
-                                                              const float *__restrict__ s2, float *__restrict__ dx, int lddx)
+                                                              const float *__restrict__ s2, float *__restrict__ dx, int lddx,
+                                                              uint32_t *__restrict__ amax_bits)
 {
-    const int c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
+    const int c0 = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
     const int slice = threadIdx.x >> 6;
-    if (c >= C) return;
+    const bool live = c0 < C;                                  // (no early return: the wave reduces max |dx| together at the end)
+    const int c = live ? c0 : 0;
+    float amax = 0.f;          // max |dx| of this thread (as bits a NaN sorts above every number: the scale kernel then answers 1)
+    uint32_t nanbits = 0u;
     const float inv_n = (float)(1.0 / (double)rows);
     float mu[4], inv[4], g[4], b[4], sl[4], m1[4], m2[4], scale[4];
 #pragma unroll
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float *__res
         m1[q] = s1[c + q] * inv_n, m2[q] = s2[c + q] * inv_n, scale[q] = g[q] * inv[q];
     }
     const int64_t r0 = (int64_t)blockIdx.y * BWV_CHUNK;
-    const int64_t r1 = r0 + BWV_CHUNK < rows ? r0 + BWV_CHUNK : rows;
+    const int64_t r1 = live ? (r0 + BWV_CHUNK < rows ? r0 + BWV_CHUNK : rows) : r0;
 #pragma unroll 4
     for (int64_t r = r0 + slice; r < r1; r += 4) {
         const float4 xv = *reinterpret_cast<const float4 *>(x + r * ld + c);
@@ -442,8 +448,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float *__res
             const float xh = (xs[q] - mu[q]) * inv[q];
             const float dz = ds[q] * act_grad(xh * g[q] + b[q], act, sl[q]);
             o[q] = scale[q] * ((dz - m1[q]) - xh * m2[q]);
+            amax = fmaxf(amax, fabsf(o[q]));
+            if (o[q] != o[q]) nanbits = 0x7fc00000u;
         }
         *reinterpret_cast<float4 *>(dx + r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (amax_bits) {
+        // max |dx| for the next layer's fp16 scale (tgp_absmax_scale_from_bits): the consumer of dx is a linear layer's backward,
+        // which otherwise reads all of dx once more just for this number.  A maximum is order-free: bit-repeatable.
+        uint32_t m = __float_as_uint(amax) | nanbits;
+        m = nanbits ? nanbits : m;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o2 = (uint32_t)__shfl_xor((int)m, off, 64);
+            m = o2 > m ? o2 : m;
+        }
+        if ((threadIdx.x & 63) == 0 && m) atomicMax(amax_bits, m);
     }
 }
 
@@ -452,7 +472,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float *__res
 extern "C" int tgp_bn_bwd(const float *dy, int lddy, const float *x, int ld, int64_t rows, int C, const float *mean,
                           const float *var, float eps, const float *gamma, const float *beta, int act, float slope,
                           const float *slope_vec, float *dx, int lddx, float *dgamma, float *dbeta, float *workspace,
-                          tgp_stream_t stream)
+                          uint32_t *absmax_bits, tgp_stream_t stream)
 {
     TGP_REQUIRE(dy && x && mean && var && gamma && beta && dx && dgamma && dbeta && workspace && rows > 0 && C > 0);
     TGP_REQUIRE(lddy >= C && ld >= C && lddx >= C && (act == 0 || act == 1));
@@ -465,11 +485,13 @@ extern "C" int tgp_bn_bwd(const float *dy, int lddy, const float *x, int ld, int
         p2 = workspace + (int64_t)vchunks * C;
         hipLaunchKernelGGL(bw_partial_v4_kernel<1>, grid4, block, 0, tgp_hs(stream), dy, lddy, x, ld, rows, C, mean, var, eps, gamma, beta,
                            act, slope, slope_vec, p1, p2);
-        hipLaunchKernelGGL(bw_finish2_kernel, dim3(tgp_cdiv(C, 64)), dim3(256), 0, tgp_hs(stream), p1, p2, vchunks, C, dbeta, dgamma, 0);
+        hipLaunchKernelGGL(bw_finish2_kernel, dim3(tgp_cdiv(C, 64)), dim3(256), 0, tgp_hs(stream), p1, p2, vchunks, C, dbeta, dgamma, 0,
+                           absmax_bits);
         hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, grid4, block, 0, tgp_hs(stream), dy, lddy, x, ld, rows, C, mean, var, eps, gamma, beta,
-                           act, slope, slope_vec, dbeta, dgamma, dx, lddx);
+                           act, slope, slope_vec, dbeta, dgamma, dx, lddx, absmax_bits);
         return TGP_LAUNCH_RESULT();
     }
+    if (absmax_bits) return TGP_EUNSUPPORTED;                  // (collected by the 16-byte form only; the caller asks for it there only)
     hipLaunchKernelGGL(bw_partial_kernel<1>, grid, block, 0, tgp_hs(stream), dy, lddy, x, ld, rows, C, mean, var, eps, gamma, beta,
                        act, slope, slope_vec, p1, p2);
     hipLaunchKernelGGL(bw_finish_kernel, dim3(tgp_cdiv(C, 256)), dim3(256), 0, tgp_hs(stream), p1, chunks, C, dbeta, 0);
@@ -819,6 +841,14 @@ __global__ __launch_bounds__(AM_THREADS) void absmax_final_kernel(const uint32_t
         }
         out[0] = s, out[1] = 1.f / s, out[2] = mx;
     }
+}
+
+// the scale from maxima already collected as bit patterns of |x| (tgp_bn_bwd's absmax_bits): {s, 1 / s, max}
+extern "C" int tgp_absmax_scale_from_bits(const uint32_t *bits, int n, float target, float *out, tgp_stream_t stream)
+{
+    TGP_REQUIRE(bits && out && n > 0 && target > 0.f);
+    hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(AM_THREADS), 0, tgp_hs(stream), bits, n, target, out);
+    return TGP_LAUNCH_RESULT();
 }
 
 extern "C" int tgp_absmax_scale(const float *x, int ld, int64_t rows, int cols, float target, uint32_t *workspace, float *out,

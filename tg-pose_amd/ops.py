@@ -778,8 +778,10 @@ def colsum(dy, out=None, accumulate=False):
     return out
 
 
-def bn_bwd(dy, x, mean, var, gamma, beta, eps=1e-5, act=0, slope=0.0, slope_vec=None, dx=None):
-    """Backward of y = act(BatchNorm_train(x)) over rows.  Returns (dx, dgamma, dbeta); dx defaults to in place on dy."""
+def bn_bwd(dy, x, mean, var, gamma, beta, eps=1e-5, act=0, slope=0.0, slope_vec=None, dx=None, want_scale=False):
+    """Backward of y = act(BatchNorm_train(x)) over rows.  Returns (dx, dgamma, dbeta); dx defaults to in place on dy.
+    want_scale: also absmax_scale(dx), collected by the apply pass itself (attached to dx as ``_tgp_scale`` for the linear layer
+    whose backward consumes dx next; skipped when the operands do not take the 16-byte form)."""
     dy, lddy = _rows(dy, "dy")
     x, ld = _rows(x, "x")
     rows, C = math.prod(x.shape[:-1]), x.shape[-1]
@@ -788,8 +790,16 @@ def bn_bwd(dy, x, mean, var, gamma, beta, eps=1e-5, act=0, slope=0.0, slope_vec=
     dg = torch.empty(C, device=x.device, dtype=torch.float32)
     db = torch.empty(C, device=x.device, dtype=torch.float32)
     ws = _ws(_lib.lib().tgp_bw_workspace_floats(rows, C), x.device)
+    bits = None
+    if want_scale and C % 4 == 0 and lddy % 4 == 0 and ld % 4 == 0 and lddx % 4 == 0 and \
+            all(t.data_ptr() % 16 == 0 for t in (dy, x, dx, ws)):
+        bits = torch.empty(1, device=x.device, dtype=torch.int32)
     check(_lib.lib().tgp_bn_bwd(_p(dy), lddy, _p(x), ld, rows, C, _p(mean), _p(var), float(eps), _p(gamma), _p(beta), act,
-                                float(slope), _p(slope_vec), _p(dx), lddx, _p(dg), _p(db), _p(ws), _stream(x)), "tgp_bn_bwd")
+                                float(slope), _p(slope_vec), _p(dx), lddx, _p(dg), _p(db), _p(ws), _p(bits), _stream(x)), "tgp_bn_bwd")
+    if bits is not None:
+        sc = torch.empty(3, device=x.device, dtype=torch.float32)
+        check(_lib.lib().tgp_absmax_scale_from_bits(_p(bits), 1, float(FP16_TOP), _p(sc), _stream(x)), "tgp_absmax_scale_from_bits")
+        dx._tgp_scale = sc
     return dx, dg, db
 
 
