@@ -306,9 +306,11 @@ int tgp_colsum(const float *dy, int lddy, int64_t rows, int C, float *out, int a
 int tgp_bn_bwd(const float *dy, int lddy, const float *x, int ld, int64_t rows, int C, const float *mean, const float *var,
                float eps, const float *gamma, const float *beta, int act, float slope, const float *slope_vec, float *dx,
                int lddx, float *dgamma, float *dbeta, float *workspace, uint32_t *absmax_bits, tgp_stream_t stream);
-/* absmax_bits (round 3; NULL = not wanted): one word that receives the bit pattern of max |dx| -- the number the next layer's
- * backward needs for its fp16 scale (tgp_absmax_scale_from_bits instead of tgp_absmax_scale's pass over dx).  Collected by the
+/* absmax_bits (round 3; NULL = not wanted): tgp_bn_bwd_absmax_words(rows, C) words, one per workgroup of the apply pass, that
+ * receive the bit patterns of max |dx| -- the number the next layer's backward needs for its fp16 scale
+ * (tgp_absmax_scale_from_bits over these words instead of tgp_absmax_scale's pass over dx).  Collected by the
  * 16-byte form only (C % 4 == 0, strides % 4 == 0, 16-byte aligned operands): TGP_EUNSUPPORTED otherwise. */
+int64_t tgp_bn_bwd_absmax_words(int64_t rows, int C);
 int tgp_absmax_scale_from_bits(const uint32_t *bits, int n, float target, float *out, tgp_stream_t stream);
 
 /* The same for a layer followed by a max over each object's points: dpool (objects, C) is the gradient of the pooled

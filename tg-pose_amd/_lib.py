@@ -103,6 +103,7 @@ SIGNATURES = {
     "tgp_bn_bwd": (c_int, [c_vp, c_int, c_vp, c_int, c_i64, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_int, c_f32, c_vp,
                            c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tgp_absmax_scale_from_bits": (c_int, [c_vp, c_int, c_f32, c_vp, c_vp]),
+    "tgp_bn_bwd_absmax_words": (c_i64, [c_i64, c_int]),
     "tgp_bn_bwd_pooled": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_f32, c_vp, c_vp,
                                   c_int, c_f32, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "tgp_colmax_arg": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_int, c_f32, c_vp, c_vp,

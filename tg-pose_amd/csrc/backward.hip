@@ -323,11 +323,9 @@ __global__ __launch_bounds__(256) void bw_partial_v4_kernel(const float *__restr
 
 // both BatchNorm sums finished by one launch (was two): 64 columns x 4 chunk groups per workgroup, groups added in order
 __global__ __launch_bounds__(256) void bw_finish2_kernel(const float *__restrict__ p1, const float *__restrict__ p2, int chunks, int C,
-                                                         float *__restrict__ o1, float *__restrict__ o2, int accumulate,
-                                                         uint32_t *__restrict__ zero = nullptr)
+                                                         float *__restrict__ o1, float *__restrict__ o2, int accumulate)
 {
     __shared__ float sa[4][64], sb[4][64];
-    if (zero && blockIdx.x == 0 && threadIdx.x == 0) *zero = 0u;      // the apply pass that follows collects max |dx| here
     const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + l;
     const int per = (chunks + 3) / 4;
@@ -426,7 +424,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float *__res
     const bool live = c0 < C;                                  // (no early return: the wave reduces max |dx| together at the end)
     const int c = live ? c0 : 0;
     float amax = 0.f;          // max |dx| of this thread (as bits a NaN sorts above every number: the scale kernel then answers 1)
-    uint32_t nanbits = 0u;
+    float poison = 0.f;
     const float inv_n = (float)(1.0 / (double)rows);
     float mu[4], inv[4], g[4], b[4], sl[4], m1[4], m2[4], scale[4];
 #pragma unroll
@@ -449,21 +447,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float *__res
             const float dz = ds[q] * act_grad(xh * g[q] + b[q], act, sl[q]);
             o[q] = scale[q] * ((dz - m1[q]) - xh * m2[q]);
             amax = fmaxf(amax, fabsf(o[q]));
-            if (o[q] != o[q]) nanbits = 0x7fc00000u;
+            poison = fmaf(0.f, o[q], poison);                  // NaN once a NaN or an infinity went by (fmaxf drops NaNs); no branch
         }
         *reinterpret_cast<float4 *>(dx + r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
     if (amax_bits) {
         // max |dx| for the next layer's fp16 scale (tgp_absmax_scale_from_bits): the consumer of dx is a linear layer's backward,
         // which otherwise reads all of dx once more just for this number.  A maximum is order-free: bit-repeatable.
-        uint32_t m = __float_as_uint(amax) | nanbits;
-        m = nanbits ? nanbits : m;
+        uint32_t m = poison != poison ? 0x7fc00000u : __float_as_uint(amax);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const uint32_t o2 = (uint32_t)__shfl_xor((int)m, off, 64);
             m = o2 > m ? o2 : m;
         }
-        if ((threadIdx.x & 63) == 0 && m) atomicMax(amax_bits, m);
+        __shared__ uint32_t s_m[4];
+        if ((threadIdx.x & 63) == 0) s_m[slice] = m;
+        __syncthreads();
+        // one word per workgroup, no atomics (a thousand device-scope atomicMax on one address cost this pass 60 % more time)
+        if (threadIdx.x == 0) {
+            const uint32_t a = s_m[0] > s_m[1] ? s_m[0] : s_m[1], b2 = s_m[2] > s_m[3] ? s_m[2] : s_m[3];
+            amax_bits[blockIdx.y * gridDim.x + blockIdx.x] = a > b2 ? a : b2;
+        }
     }
 }
 
@@ -485,8 +489,7 @@ extern "C" int tgp_bn_bwd(const float *dy, int lddy, const float *x, int ld, int
         p2 = workspace + (int64_t)vchunks * C;
         hipLaunchKernelGGL(bw_partial_v4_kernel<1>, grid4, block, 0, tgp_hs(stream), dy, lddy, x, ld, rows, C, mean, var, eps, gamma, beta,
                            act, slope, slope_vec, p1, p2);
-        hipLaunchKernelGGL(bw_finish2_kernel, dim3(tgp_cdiv(C, 64)), dim3(256), 0, tgp_hs(stream), p1, p2, vchunks, C, dbeta, dgamma, 0,
-                           absmax_bits);
+        hipLaunchKernelGGL(bw_finish2_kernel, dim3(tgp_cdiv(C, 64)), dim3(256), 0, tgp_hs(stream), p1, p2, vchunks, C, dbeta, dgamma, 0);
         hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, grid4, block, 0, tgp_hs(stream), dy, lddy, x, ld, rows, C, mean, var, eps, gamma, beta,
                            act, slope, slope_vec, dbeta, dgamma, dx, lddx, absmax_bits);
         return TGP_LAUNCH_RESULT();
@@ -842,6 +845,9 @@ __global__ __launch_bounds__(AM_THREADS) void absmax_final_kernel(const uint32_t
         out[0] = s, out[1] = 1.f / s, out[2] = mx;
     }
 }
+
+// words tgp_bn_bwd(absmax_bits) writes: one per workgroup of its apply pass
+extern "C" int64_t tgp_bn_bwd_absmax_words(int64_t rows, int C) { return (int64_t)tgp_cdiv(C, 256) * tgp_cdiv(rows, (int64_t)BWV_CHUNK); }
 
 // the scale from maxima already collected as bit patterns of |x| (tgp_bn_bwd's absmax_bits): {s, 1 / s, max}
 extern "C" int tgp_absmax_scale_from_bits(const uint32_t *bits, int n, float target, float *out, tgp_stream_t stream)

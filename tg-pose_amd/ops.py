@@ -793,12 +793,13 @@ def bn_bwd(dy, x, mean, var, gamma, beta, eps=1e-5, act=0, slope=0.0, slope_vec=
     bits = None
     if want_scale and C % 4 == 0 and lddy % 4 == 0 and ld % 4 == 0 and lddx % 4 == 0 and \
             all(t.data_ptr() % 16 == 0 for t in (dy, x, dx, ws)):
-        bits = torch.empty(1, device=x.device, dtype=torch.int32)
+        bits = torch.empty(int(_lib.lib().tgp_bn_bwd_absmax_words(rows, C)), device=x.device, dtype=torch.int32)
     check(_lib.lib().tgp_bn_bwd(_p(dy), lddy, _p(x), ld, rows, C, _p(mean), _p(var), float(eps), _p(gamma), _p(beta), act,
                                 float(slope), _p(slope_vec), _p(dx), lddx, _p(dg), _p(db), _p(ws), _p(bits), _stream(x)), "tgp_bn_bwd")
     if bits is not None:
         sc = torch.empty(3, device=x.device, dtype=torch.float32)
-        check(_lib.lib().tgp_absmax_scale_from_bits(_p(bits), 1, float(FP16_TOP), _p(sc), _stream(x)), "tgp_absmax_scale_from_bits")
+        check(_lib.lib().tgp_absmax_scale_from_bits(_p(bits), bits.numel(), float(FP16_TOP), _p(sc), _stream(x)),
+              "tgp_absmax_scale_from_bits")
         dx._tgp_scale = sc
     return dx, dg, db
 
