@@ -1523,6 +1523,47 @@ def test_eval_outputs_only_returns_the_same_six_outputs(ops):
         assert torch.equal(full[k], lean[k]), k
 
 
+@pytest.mark.parametrize("gemm_mode", ["fp32"], indirect=True)
+@pytest.mark.parametrize("seed", [7, 13])
+def test_backward_full_network_tight_on_flip_free_inputs(ops, seed, gemm_mode):
+    """The whole network's gradients at a bar that sees a 1 % error in any layer: 2e-3 relative L2 per parameter (median 5e-4).
+    The 3 % of test_backward_full_network_vs_oracle_autograd is the price of ReLU / max decisions that flip between two fp32
+    evaluations; for these inputs (B = 4, N = 128, seeds picked by scripts/grad_seed_scan.py out of 16: the ones whose worst
+    parameter is under 1e-3) no decision that matters flips in the exact-fp32 GEMM mode, so the two sides differ by rounding
+    only.  The backward is bit-repeatable (no atomics), so the selection holds from run to run.  Parameters whose true gradient
+    is zero (a bias in front of a BatchNorm) are left out: both sides return rounding noise there."""
+    from tgpose_amd import FLAGS, seeded_state_dict
+    _, _, PR = _oracle()
+    B, N = 4, 128
+    sd = seeded_state_dict(seed)
+    pts, obj = synth_points(B, N, seed)
+    torch.manual_seed(seed)
+    i1 = torch.randperm(N)[: N // 4]
+    sample = (i1, torch.randperm(i1.numel())[: i1.numel() // 4])
+    with torch.no_grad():
+        probe = PR.posenet_forward(sd, pts, obj, sample_idx=sample, train_keys=True, mode="exact", bn_train=True)
+    probe.pop("_bn_new")
+    weights = _loss_weights(probe, seed)
+    want_out, inter, want = _oracle_grads(PR, sd, pts, obj, sample, weights)
+    net = _train_net(seed)
+    FLAGS.train = 1
+    try:
+        out = net(g(pts), g(obj), sample_idx=sample, inject=inter["indices"])
+    finally:
+        FLAGS.train = 0
+    sum((out[k] * g(weights[k])).sum() for k in weights).backward()
+    got = {k: p.grad for k, p in net.named_parameters()}
+    rel = {k: (got[k].cpu() - w).norm().item() / w.norm().item() for k, w in want.items() if w.norm().item() > 1e-2}
+    assert len(rel) >= 80
+    worst = sorted(rel, key=rel.get, reverse=True)[:3]
+    print("tight full-network backward, seed %d: worst %s" % (seed, [(k, "%.1e" % rel[k]) for k in worst]))
+    assert rel[worst[0]] <= 2e-3, {k: rel[k] for k in worst}
+    assert sorted(rel.values())[len(rel) // 2] <= 5e-4
+    # and the bar does see a 1 % error: scale one layer's weight gradient by 1.01 and the same metric fails
+    k = "face_all.decoder.conv1d_block.3.weight"
+    assert ((got[k] * 1.01).cpu() - want[k]).norm().item() / want[k].norm().item() > 2e-3
+
+
 def test_backward_full_network_is_bit_repeatable(ops):
     """Round 3: with the scatter-free backward of the graph layers (reverse neighbour lists, child lists of the up-sampling) no
     float atomic is left in loss.backward() through PoseNet9D: two runs on the same inputs give bit-identical gradients for every
