@@ -1135,7 +1135,8 @@ def test_gemm_tn_fp16_split_vs_fp64(ops, rows, N, K, mag):
     assert zero.abs().max().item() == 0.0
 
 
-@pytest.mark.parametrize("rows,N,K", [(32896, 1024, 1292), (8224, 256, 2304), (32896, 512, 512)])
+@pytest.mark.parametrize("rows,N,K", [(32896, 1024, 1292), (8224, 256, 2304), (32896, 512, 512), (2048, 4608, 512), (8224, 2048, 128),
+                                      (2048, 4096, 256)])
 def test_linear_backward_fp16_split_vs_fp64(ops, rows, N, K):
     """_Linear.backward with both GEMMs on the scaled fp16 split (dx = dy W through a_scale / c_scale, dW through the K-split
     path) against fp64, with gradient-sized dy."""
@@ -1423,11 +1424,11 @@ def test_feat_consumers_factored_vs_fp64_concat(ops, gemm_mode):
     # the product's node
     leaves = [g(t).requires_grad_(True) for t in (fm0, fm1, fm2, fm3, fm4)]
     Wd = [(g(W).requires_grad_(True), None if b is None else g(b).requires_grad_(True)) for W, b in layers]
-    fine = torch.cat([leaves[0], leaves[1], torch.nn.functional.pad(g(tail), (0, engine.FINE_LD - 256 - 9))], 2)
+    tail16 = torch.nn.functional.pad(g(tail), (0, engine.FINE_LD - 256 - 9))
     base = torch.arange(B, dtype=torch.int32).view(B, 1)
     n1g, n2g = g(near1.int() + base * N1), g(near2.int() + base * N2)
-    parts = (fine, torch.cat([leaves[2], leaves[3]], 2), leaves[4], n1g, n2g, ops.child_lists(n1g, N1, global_ids=True),
-             ops.child_lists(n2g, N2, global_ids=True))
+    parts = (torch.cat([leaves[0], leaves[1]], 2), torch.cat([leaves[2], leaves[3]], 2), leaves[4], tail16, n1g, n2g,
+             ops.child_lists(n1g, N1, global_ids=True), ops.child_lists(n2g, N2, global_ids=True))
     ys = A.feat_consumers_factored(parts, Wd)
     torch.autograd.backward(list(ys), [g(go) for go in gouts])
 

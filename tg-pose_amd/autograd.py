@@ -45,7 +45,19 @@ def _split_if_big(w, rows, grads=False):
     return ops.split_bf16(w) if grads else ops.split_w(w, check=False)     # inside the (captured) step: no read-back
 
 
-def _linear_backward(x, W, dy, need_dx, need_dw, need_db, dx_accum=None, scale=None):
+def _dx_ksplit(rows, Kx, N):
+    """chunks of the reduction (over the layer's N outputs) for dx = dy W when its output has few tiles: a power of two that brings
+    tiles x chunks to about half a round of the 256 workgroup slots and divides N into multiples of 16; 1 = no split"""
+    tiles = ((rows + 255) // 256) * ((Kx + 255) // 256)
+    if N < 2048 or tiles > 80:
+        return 1
+    Z = 1
+    while Z * 2 * tiles <= 160 and N % (Z * 2 * 16) == 0 and N // (Z * 2) >= 256:
+        Z *= 2
+    return Z
+
+
+def _linear_backward(x, W, dy, need_dx, need_dw, need_db, dx_accum=None, scale=None, dx_cols=None):
     """dx = dy W (+ dx_accum, added by the GEMM's own epilogue), dW = dy^T x, db = colsum(dy) for y = x W^T + b; W contiguous (N, K).
     Both GEMMs of a large layer run on the fp16 split kernels with dy lifted into fp16's range by one power of two chosen on the
     device (ops.absmax_scale); small ones keep the bf16x3 / fp32 MFMA paths."""
@@ -54,21 +66,33 @@ def _linear_backward(x, W, dy, need_dx, need_dw, need_db, dx_accum=None, scale=N
     x2 = x.reshape(-1, K)
     dx = dW = db = None
     rows = dy2.shape[0]
-    dx_f16 = need_dx and ops.GEMM_MODE == "split16" and ops.TN_SPLIT and ops._routes_to_big_tile(rows, K, 1, True)
+    Kx = K if dx_cols is None else dx_cols        # dx_cols: only the first dx_cols input columns need a gradient (the rest are data)
+    dx_f16 = need_dx and ops.GEMM_MODE == "split16" and ops.TN_SPLIT and ops._routes_to_big_tile(rows, Kx, 1, True)
     dw_f16 = need_dw and ops.tn_split_ok(rows, N, K)
     dyc = dy2.contiguous()
     # (scale: absmax_scale(dy) when the producer of dy collected it on the way -- the BatchNorm backward's apply pass)
     sc = (scale if scale is not None else ops.absmax_scale(dyc)) if (dx_f16 or dw_f16) else None
     if need_dx:
         dyp = _pad4(dyc).contiguous()                       # the reduction dim of this GEMM is N
-        wt = _pad4(ops.transpose(W)).contiguous()           # (K, N)
+        Wd = W if dx_cols is None else W[:, :dx_cols].contiguous()
+        wt = _pad4(ops.transpose(Wd)).contiguous()          # (Kx, N)
         out = res = None
         if dx_accum is not None:                            # the running sum of the other consumers' gradients: read as the
-            out = res = dx_accum.view(-1, K)                # epilogue's residual and overwritten in place
-        if dx_f16:
-            dx = ops.linear_rows(dyp, wt, w_split=ops.split_f16(wt), a_scale=sc, c_scale=sc[1:], out=out, res1=res).view(x.shape)
+            out = res = dx_accum.view(-1, Kx)               # epilogue's residual and overwritten in place
+        shape = tuple(x.shape[:-1]) + (Kx,)
+        Z = _dx_ksplit(rows, Kx, dyp.shape[1]) if dx_f16 else 1
+        if Z > 1:
+            # few output tiles under a long reduction (the coarse levels' layers: 2048 or 8224 rows, N up to 4608): the reduction
+            # is cut into Z chunks that run as the batch dimension of one launch; the partial products are added in order
+            chunk = dyp.shape[1] // Z
+            parts = torch.empty(Z, rows, Kx, device=dyp.device, dtype=torch.float32)
+            ops.gemm(dyp, wt, parts, M=rows, N=Kx, K=chunk, lda=dyp.shape[1], ldw=wt.shape[1], ldc=Kx, batch=Z,
+                     batch_strides=(chunk, 0, rows * Kx, 0, 0), w_split=ops.split_f16(wt), a_scale=sc, ksplit_chunk=chunk)
+            dx = ops.sum_slabs(parts, sc[1:], out=out, accumulate=out is not None).view(shape)
+        elif dx_f16:
+            dx = ops.linear_rows(dyp, wt, w_split=ops.split_f16(wt), a_scale=sc, c_scale=sc[1:], out=out, res1=res).view(shape)
         else:
-            dx = ops.linear_rows(dyp, wt, w_split=_split_if_big(wt, dyp.shape[0], grads=True), out=out, res1=res).view(x.shape)
+            dx = ops.linear_rows(dyp, wt, w_split=_split_if_big(wt, dyp.shape[0], grads=True), out=out, res1=res).view(shape)
     if need_dw:
         dW = ops.gemm_tn(dyc, x2, scale=sc if dw_f16 else None)
     if need_db:
@@ -142,11 +166,15 @@ class _FeatConsumersFactored(Function):
     B = 32, N = 1028, and the same ratio in both backward GEMMs:
         d fine += g_i Wa_i,  dWa_i = g_i^T fine,  d P1[r] = sum of g[i] over the children i of r (tgp_segsum_rows: child lists, no
         atomics),  d[fm_2 | fm_3] = dP1 Wb,  dWb = dP1^T [fm_2 | fm_3]   (level 2 alike)
-    near1 / near2: (B, N) int32 GLOBAL coarse rows (b * N1 + nearest); lists1 / lists2: ops.child_lists of the two levels."""
+    Inputs: fm01 = [fm_0 | fm_1] (B, N, 256), [fm_2 | fm_3], fm_4, tail (B, N, 16: one-hot | xyz | 0, no gradient); near1 / near2:
+    (B, N) int32 GLOBAL coarse rows (b * N1 + nearest); lists1 / lists2: ops.child_lists of the two levels."""
 
     @staticmethod
-    def forward(ctx, fine, fm23, fm4, near1, near2, lists1, lists2, *wb):
-        fine, fm23, fm4 = fine.contiguous(), fm23.contiguous(), fm4.contiguous()
+    def forward(ctx, fm01, fm23, fm4, tail, near1, near2, lists1, lists2, *wb):
+        # fine = [fm_0 | fm_1 | tail]: built here, so that the node's differentiable input is the 256 feature columns only -- the
+        # tail (one-hot, xyz, padding) is data, and d fine over 272 columns made every dx GEMM 2.1 column tiles wide (190 us each)
+        fine = torch.cat([fm01, tail], 2)
+        fm23, fm4 = fm23.contiguous(), fm4.contiguous()
         B, N, ldf = fine.shape
         N1, N2 = fm23.shape[1], fm4.shape[1]
         M = B * N
@@ -170,7 +198,7 @@ class _FeatConsumersFactored(Function):
             off += n
         (ptr1, idx1), (ptr2, idx2) = lists1, lists2
         ctx.save_for_backward(fine, fm23, fm4, ptr1, idx1, ptr2, idx2, Wb, Wc, *Was)
-        ctx.tails, ctx.has_bias = tails, [b is not None for b in bs]
+        ctx.tails, ctx.has_bias, ctx.nfeat = tails, [b is not None for b in bs], fm01.shape[2]
         return tuple(outs)
 
     @staticmethod
@@ -182,7 +210,7 @@ class _FeatConsumersFactored(Function):
         dP1 = torch.empty(ptr1.numel() - 1, ld, device=fine.device, dtype=torch.float32)
         dP2 = torch.empty(ptr2.numel() - 1, ld, device=fine.device, dtype=torch.float32)
         dfine, part, off = None, [], 0
-        need_w = any(need[7 + 2 * i] for i in range(len(Was)))
+        need_w = any(need[8 + 2 * i] for i in range(len(Was)))
         for i, (g, Wa) in enumerate(zip(gs, Was)):
             n = Wa.shape[0]
             if g is None:
@@ -193,8 +221,8 @@ class _FeatConsumersFactored(Function):
                 gc = g.reshape(M, n).contiguous()
                 ops.segsum_rows(gc, ptr1, idx1, out=dP1[:, off:off + n])
                 ops.segsum_rows(gc, ptr2, idx2, out=dP2[:, off:off + n])
-                dx, dWa, db = _linear_backward(fine, Wa, gc, need[0], need[7 + 2 * i], ctx.has_bias[i] and need[8 + 2 * i], dx_accum=dfine,
-                                               scale=getattr(g, "_tgp_scale", None))
+                dx, dWa, db = _linear_backward(fine, Wa, gc, need[0], need[8 + 2 * i], ctx.has_bias[i] and need[9 + 2 * i], dx_accum=dfine,
+                                               scale=getattr(g, "_tgp_scale", None), dx_cols=ctx.nfeat)
                 dfine = dx if dx is not None else dfine
                 part.append((dWa, db))
             off += n
@@ -208,14 +236,14 @@ class _FeatConsumersFactored(Function):
                 dW = torch.cat([dWa[:, :256], dWb[off:off + n], dWc[off:off + n], dWa[:, 256:256 + kt]], 1)
             grads += [dW, db]
             off += n
-        return (dfine, dfm23, dfm4, None, None, None, None) + tuple(grads)
+        return (dfine, dfm23, dfm4, None, None, None, None, None) + tuple(grads)
 
 
 FACTORED = os.environ.get("TGP_TRAIN_FACTORED", "1") != "0"     # the layers over the concat buffer factored over the up-sampling
 
 
 def feat_consumers_factored(parts, layers):
-    """parts: the encoder's (fine, fm23, fm4, near1, near2, lists1, lists2); layers as feat_consumers (weights UNPADDED: (N, 1286 or 1289))"""
+    """parts: the encoder's (fm01, fm23, fm4, tail16, near1, near2, lists1, lists2); layers as feat_consumers (weights UNPADDED: (N, 1286 or 1289))"""
     flat = []
     for W, b in layers:
         flat += [W, b]
@@ -600,8 +628,8 @@ def encoder(enc, xyz, obj_id, sample_idx, graphs, kmax=20, n_cls=6):
     feat = torch.cat([fm0, fm1] + ups + [tail[:, :, :n_cls]], dim=2)
     # the operands of the factored form of the layers over feat (_FeatConsumersFactored): the columns that differ from point to
     # point, and the two coarse levels
-    fine = torch.cat([fm0, fm1, F.pad(tail, (0, engine.FINE_LD - 256 - tail.shape[2]))], dim=2)
-    return feat, (fine, torch.cat([fm2, fm3], dim=2), fm4, near1g, near2g, lists1, lists2)
+    tail16 = F.pad(tail, (0, engine.FINE_LD - 256 - tail.shape[2]))
+    return feat, (torch.cat([fm0, fm1], dim=2), torch.cat([fm2, fm3], dim=2), fm4, tail16, near1g, near2g, lists1, lists2)
 
 
 def _w_feat(conv, cols=FEAT_C):
@@ -676,8 +704,8 @@ def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=Non
         if parts is None:
             feat = cut.split(feat)[0]
         else:
-            feat, fine, fm23, fm4 = cut.split(feat, *parts[:3])
-            parts = (fine, fm23, fm4) + parts[3:]
+            feat, fm01, fm23, fm4 = cut.split(feat, *parts[:3])
+            parts = (fm01, fm23, fm4) + parts[3:]
     # the five layers over `feat` as one autograd node: factored over the up-sampling (_FeatConsumersFactored), or over the concat
     # buffer with d feat accumulated inside their dx GEMMs (_FeatConsumers)
     w1 = _w2

@@ -741,6 +741,18 @@ def gemm_tn_split(a, b, scale, out=None, accumulate=False):
     return out
 
 
+def sum_slabs(parts, scale, out=None, accumulate=False):
+    """out (+)= scale[0] * sum over the leading dim of parts (Z, ...), slabs added in order (tgp_sum_slabs)"""
+    Z = parts.shape[0]
+    n = parts.numel() // Z
+    if out is None:
+        out = torch.empty(parts.shape[1:], device=parts.device, dtype=torch.float32)
+    if not out.is_contiguous():
+        raise ValueError("sum_slabs: out must be contiguous")
+    check(_lib.lib().tgp_sum_slabs(_p(parts), Z, n, _p(scale), _p(out), int(accumulate), _stream(parts)), "tgp_sum_slabs")
+    return out
+
+
 def tn_split_ok(rows, N, K):
     """does gemm_tn route (rows, N)^T (rows, K) to the fp16 split path?  Large enough for the tile kernels in both output dims."""
     if not (TN_SPLIT and GEMM_MODE == "split16" and rows >= 2048 and N * K >= TN_SPLIT_MIN and N > 32 and K > 64):
