@@ -379,7 +379,9 @@ __global__ __launch_bounds__(GG_THREADS) void gconv_bwd_value_kernel(const float
 // Four consecutive elements per thread (one 4-byte load of slots per entry, a 16-byte load of values on a match): 224 threads
 // cover a 896-element chunk.  (Measured and dropped: a workgroup per EIGHT consecutive source rows, their lists walked as one loop with
 // eight slot loads in flight across row boundaries -- 200 us per launch against 150: an eighth of the workgroups, each a long
-// serial walk; the one-row form's short chains overlap across the 8 workgroups a CU holds.)
+// serial walk; the one-row form's short chains overlap across the 8 workgroups a CU holds.  Also measured: one WAVE per row with 16
+// elements per lane (32 rows per CU in flight: 150 us, no change) and four independent waves per workgroup walking four rows each
+// (250 us).  Neither the walks in flight nor the workgroup count is what bounds this pass.)
 #define GG_GTHREADS (GG_THREADS / 4)
 __global__ __launch_bounds__(GG_GTHREADS) void gconv_bwd_gather_kernel(const uint8_t *__restrict__ arg, const float *__restrict__ contrib,
                                                                        const int32_t *__restrict__ rptr, const int32_t *__restrict__ rent,
