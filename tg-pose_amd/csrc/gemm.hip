@@ -1158,6 +1158,10 @@ __global__ __launch_bounds__(1024) void gemm_split32_kernel(GemmParams p)
     }
 }
 
+// (Round 3, measured and dropped: the 256 x 256 tile on 512 threads with 128 x 64 wave tiles -- a third less LDS read traffic per
+// MFMA, which is the K loop's co-bottleneck: this kernel and the transposed-read TN kernel both level off near 300 TF, where LDS
+// reads + writes take about as long as the MFMAs.  At two waves per SIMD a wave has 256 registers; 128 accumulators + fragments +
+// the prefetch ring + the epilogue's state spill 221 of them: 30 TF.)
 // The same tiles as two independent 512-thread workgroups per CU (256 x 128 outputs each, 4 x 2 waves of 64 x 64; tail:
 // 128 x 128).  Two barrier domains per CU de-phase on their own: while one workgroup waits at its barrier or runs its
 // epilogue the other keeps the matrix cores busy.  The price is 1.5x the operand traffic per output (A rows are shared
