@@ -1077,7 +1077,8 @@ def test_batched_inference_matches_per_image_runs(ops):
 
 # ----------------------------------------------------------------------------------------- backward kernels
 @pytest.mark.parametrize("rows,N,K,lda,ldb", [(32896, 256, 1024, 256, 1024), (8224, 300, 77, 304, 1292), (1000, 1024, 1292, 1024, 1292),
-                                              (32, 256, 256, 256, 256), (33, 5, 3, 8, 4), (4112, 2304, 128, 2304, 128)])
+                                              (32, 256, 256, 256, 256), (33, 5, 3, 8, 4), (4112, 2304, 128, 2304, 128),
+                                              (32896, 3, 128, 3, 128), (32896, 128, 4, 128, 4), (8224, 8, 300, 12, 304), (2056, 260, 1, 260, 3)])
 def test_gemm_tn_vs_fp64(ops, rows, N, K, lda, ldb):
     """dW = dx^T a (reduction over the rows) against an fp64 product; fp32 MFMA accumulation, slices summed in order."""
     gen = torch.Generator().manual_seed(rows + N)

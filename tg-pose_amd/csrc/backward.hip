@@ -168,14 +168,52 @@ __global__ __launch_bounds__(256) void gemm_tn_lds_kernel(const float *__restric
         }
 }
 
-// out[n][k] (+)= sum over slices, in slice order
+// One operand a few columns wide (the decoder's 128 -> 3 head: dW is 3 x 128; the surface layer's STE on xyz: 128 x 4): the MFMA tile
+// kernels spend a 128 x 128 tile on it (159 / 66 us per launch at 32896 rows).  Here a thread owns one column of the WIDE operand and
+// keeps the <= 8 products with the narrow one in registers; the narrow operand's row is the same address for the whole workgroup.
+// part[slice][w][c] = sum over the slice's rows of narrow[r][w] * wide[r][c]
+#define TNS_MAXW 8
+// 64 columns of the wide operand x 4 row lanes per workgroup; a row lane takes every fourth row of the slice, the four partial sums
+// are combined through LDS in lane order (deterministic)
+__global__ __launch_bounds__(256) void gemm_tn_skinny_kernel(const float *__restrict__ nar, int ldn, int Wn, const float *__restrict__ wide,
+                                                             int ldw, int Wd, int64_t rows, int64_t rows_per_slice, float *__restrict__ part)
+{
+    __shared__ float red[4][TNS_MAXW][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int64_t m0 = (int64_t)blockIdx.y * rows_per_slice;
+    const int64_t m1 = m0 + rows_per_slice < rows ? m0 + rows_per_slice : rows;
+    float acc[TNS_MAXW];
+#pragma unroll
+    for (int w = 0; w < TNS_MAXW; ++w) acc[w] = 0.f;
+    const int cc = c < Wd ? c : 0;
+#pragma unroll 8
+    for (int64_t m = m0 + rl; m < m1; m += 4) {
+        const float x = wide[m * ldw + cc];
+#pragma unroll
+        for (int w = 0; w < TNS_MAXW; ++w)
+            if (w < Wn) acc[w] = fmaf(nar[m * ldn + w], x, acc[w]);
+    }
+#pragma unroll
+    for (int w = 0; w < TNS_MAXW; ++w) red[rl][w][cl] = acc[w];
+    __syncthreads();
+    if (rl == 0 && c < Wd)
+#pragma unroll
+        for (int w = 0; w < TNS_MAXW; ++w)
+            if (w < Wn) part[((int64_t)blockIdx.y * Wn + w) * Wd + c] = ((red[0][w][cl] + red[1][w][cl]) + red[2][w][cl]) + red[3][w][cl];
+}
+
+// out[n][k] (+)= sum over slices, in slice order (transposed: the slices hold [k][n], the skinny kernel's layout when B is the narrow one)
 __global__ void gemm_tn_reduce_kernel(const float *__restrict__ part, int slices, int64_t slice_stride, int N, int K,
-                                      float *__restrict__ out, int ldo, int accumulate)
+                                      float *__restrict__ out, int ldo, int accumulate, int transposed = 0)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)N * K) return;
     const int n = (int)(t / K), k = (int)(t - (int64_t)n * K);
     float s = 0.f;
+    if (transposed) {
+        for (int z = 0; z < slices; ++z) s += part[(int64_t)z * slice_stride + (int64_t)k * N + n];
+    } else
     for (int z = 0; z < slices; ++z) s += part[(int64_t)z * slice_stride + t];
     float *o = out + (int64_t)n * ldo + k;
     *o = accumulate ? *o + s : s;
@@ -205,6 +243,15 @@ extern "C" int tgp_gemm_tn_f32(const float *A, int lda, const float *B, int ldb,
     per = (per + 2 * TN_UNROLL - 1) / (2 * TN_UNROLL) * (2 * TN_UNROLL);
     const int used = (int)tgp_cdiv(rows, per);
     const int64_t stride = (int64_t)N * K;
+    if ((N <= TNS_MAXW || K <= TNS_MAXW) && rows >= 1024) {
+        const bool a_narrow = N <= K;                          // the narrow operand: A (N columns) or B (K columns)
+        const int Wn = a_narrow ? N : K, Wd = a_narrow ? K : N;
+        hipLaunchKernelGGL(gemm_tn_skinny_kernel, dim3(tgp_cdiv(Wd, 64), used), dim3(256), 0, tgp_hs(stream), a_narrow ? A : B,
+                           a_narrow ? lda : ldb, Wn, a_narrow ? B : A, a_narrow ? ldb : lda, Wd, rows, per, workspace);
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(tgp_cdiv(stride, (int64_t)256)), dim3(256), 0, tgp_hs(stream), workspace, used,
+                           stride, N, K, C, ldc, accumulate, a_narrow ? 0 : 1);
+        return TGP_LAUNCH_RESULT();
+    }
     const bool aligned = !((lda | ldb | N | K) & 3) && !((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15);
     const dim3 grid(tgp_cdiv(K, TN_TILE), tgp_cdiv(N, TN_TILE), used);
     if (aligned)
