@@ -569,7 +569,7 @@ int tgp_heads_pack_w2(const float *w2, int heads, void *out, tgp_stream_t stream
  * tgp_child_lists inverts near (B, n) (parent of every point: ids in [0, R), or b*R + that when global_ids) into CSR child lists: ptr (B*R + 1) int32,
  * idx (B*n) int32 global rows b*n + i, children in point order.  R <= 4096, n <= 8192.
  * tgp_segsum_rows: out[r][:C] = sum of g[idx[k]][:C] over k in [ptr[r], ptr[r+1]) in list order -- no atomics, bit-repeatable.
- * C, ldg, ldo multiples of 4; g, out 16-byte aligned. */
+ * C, ldg, ldo multiples of 4 and g, out 16-byte aligned (16-byte accesses), or multiples of 2 and 8-byte aligned (8-byte accesses). */
 int tgp_child_lists(const int32_t *near, int B, int n, int R, int global_ids, int32_t *ptr, int32_t *idx, tgp_stream_t stream);
 int tgp_segsum_rows(const float *g, int ldg, int C, const int32_t *ptr, const int32_t *idx, int R, float *out, int ldo,
                     tgp_stream_t stream);

@@ -1312,6 +1312,11 @@ def test_child_lists_and_segsum_vs_index_add(ops, B, n, R):
     assert torch.allclose(got.cpu().double(), want, atol=1e-5, rtol=1e-6)
     assert bool((out[:, C:] == 7.0).all())
     assert torch.equal(ops.segsum_rows(g(wide)[:, 4:4 + C], ptr, idx), got.contiguous())
+    # rows that are only 8-byte aligned (a column slice at an even offset of a buffer with an even, not fourfold, row stride)
+    odd = torch.randn(B * n, C + 10, generator=gen)
+    got2 = ops.segsum_rows(g(odd)[:, 2:2 + C], ptr, idx)
+    want2 = torch.zeros(B * R, C, dtype=torch.float64).index_add_(0, parent, odd[:, 2:2 + C].double())
+    assert torch.allclose(got2.cpu().double(), want2, atol=1e-5, rtol=1e-6)
 
 
 @pytest.mark.parametrize("B,n_rows,k,n_src", [(3, 257, 20, 257), (2, 1028, 20, 1028), (2, 64, 4, 257), (1, 5, 3, 9), (2, 300, 64, 300)])

@@ -441,8 +441,9 @@ class _GatherRows(Function):
         (near,) = ctx.saved_tensors
         B, n, C = dy.shape
         if ctx.lists is not None and C % 4 == 0:
-            if not (dy.stride(2) == 1 and dy.stride(0) == n * dy.stride(1) and dy.stride(1) % 4 == 0 and dy.data_ptr() % 16 == 0):
-                dy = dy.contiguous()          # (a column slice of a 1286-wide gradient: rows not 16-byte aligned)
+            # (a column slice of the 1286-wide gradient of the concat buffer has 8-byte-aligned rows: tgp_segsum_rows' 8-byte form)
+            if not (dy.stride(2) == 1 and dy.stride(0) == n * dy.stride(1) and dy.stride(1) % 2 == 0 and dy.data_ptr() % 8 == 0):
+                dy = dy.contiguous()
             rows = dy.view(B * n, C) if dy.is_contiguous() else dy.as_strided((B * n, C), (dy.stride(1), 1))
             return ops.segsum_rows(rows, ctx.lists[0], ctx.lists[1]).view(B, ctx.n_src, C), None, None
         return ops.gather_rows_bwd(dy.contiguous(), near, ctx.n_src), None, None

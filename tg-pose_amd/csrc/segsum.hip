@@ -84,28 +84,45 @@ extern "C" int tgp_child_lists(const int32_t *near, int B, int n, int R, int glo
     return TGP_LAUNCH_RESULT();
 }
 
-// out[r][c] = sum over k in [ptr[r], ptr[r + 1]) of g[idx[k]][c], children in list order; a workgroup per (parent, 1024 columns)
+// out[r][c] = sum over k in [ptr[r], ptr[r + 1]) of g[idx[k]][c], children in list order; a workgroup per (parent, 256 x V columns).
+// V = 4: 16-byte accesses; V = 2: 8-byte accesses, for rows that are only 8-byte aligned (a column slice of the 1286-wide gradient of
+// the concat buffer: row stride 5144 bytes)
+template <int V>
 __global__ __launch_bounds__(256) void segsum_rows_kernel(const float *__restrict__ g, int ldg, int C, const int32_t *__restrict__ ptr,
                                                           const int32_t *__restrict__ idx, float *__restrict__ out, int ldo)
 {
     const int r = blockIdx.x;
-    const int c = blockIdx.y * 1024 + threadIdx.x * 4;
+    const int c = blockIdx.y * 256 * V + threadIdx.x * V;
     if (c >= C) return;
     const int k0 = ptr[r], k1 = ptr[r + 1];
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc[V];
+#pragma unroll
+    for (int u = 0; u < V; ++u) acc[u] = 0.f;
     for (int k = k0; k < k1; ++k) {
-        const float4 v = *reinterpret_cast<const float4 *>(g + (int64_t)idx[k] * ldg + c);
-        acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+        const float *src = g + (int64_t)idx[k] * ldg + c;
+        if (V == 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(src);
+            acc[0] += v.x, acc[1] += v.y, acc[2] += v.z, acc[3] += v.w;
+        } else {
+            const float2 v = *reinterpret_cast<const float2 *>(src);
+            acc[0] += v.x, acc[1] += v.y;
+        }
     }
-    *reinterpret_cast<float4 *>(out + (int64_t)r * ldo + c) = acc;
+    float *dst = out + (int64_t)r * ldo + c;
+    if (V == 4) *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    else *reinterpret_cast<float2 *>(dst) = make_float2(acc[0], acc[1]);
 }
 
 extern "C" int tgp_segsum_rows(const float *g, int ldg, int C, const int32_t *ptr, const int32_t *idx, int R, float *out, int ldo,
                                tgp_stream_t stream)
 {
     TGP_REQUIRE(g && ptr && idx && out && C > 0 && R > 0 && ldg >= C && ldo >= C);
-    TGP_REQUIRE((C & 3) == 0 && (ldg & 3) == 0 && (ldo & 3) == 0 &&
-                ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(out)) & 15) == 0);
-    hipLaunchKernelGGL(segsum_rows_kernel, dim3(R, tgp_cdiv(C, 1024)), dim3(256), 0, tgp_hs(stream), g, ldg, C, ptr, idx, out, ldo);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(out);
+    if ((C & 3) == 0 && (ldg & 3) == 0 && (ldo & 3) == 0 && (al & 15) == 0)
+        hipLaunchKernelGGL(segsum_rows_kernel<4>, dim3(R, tgp_cdiv(C, 1024)), dim3(256), 0, tgp_hs(stream), g, ldg, C, ptr, idx, out, ldo);
+    else {
+        TGP_REQUIRE((C & 1) == 0 && (ldg & 1) == 0 && (ldo & 1) == 0 && (al & 7) == 0);
+        hipLaunchKernelGGL(segsum_rows_kernel<2>, dim3(R, tgp_cdiv(C, 512)), dim3(256), 0, tgp_hs(stream), g, ldg, C, ptr, idx, out, ldo);
+    }
     return TGP_LAUNCH_RESULT();
 }
