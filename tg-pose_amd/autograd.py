@@ -57,7 +57,7 @@ def _dx_ksplit(rows, Kx, N):
     return Z
 
 
-def _linear_backward(x, W, dy, need_dx, need_dw, need_db, dx_accum=None, scale=None, dx_cols=None):
+def _linear_backward(x, W, dy, need_dx, need_dw, need_db, dx_accum=None, scale=None, dx_cols=None, dx_res=None):
     """dx = dy W (+ dx_accum, added by the GEMM's own epilogue), dW = dy^T x, db = colsum(dy) for y = x W^T + b; W contiguous (N, K).
     Both GEMMs of a large layer run on the fp16 split kernels with dy lifted into fp16's range by one power of two chosen on the
     device (ops.absmax_scale); small ones keep the bf16x3 / fp32 MFMA paths."""
@@ -79,8 +79,10 @@ def _linear_backward(x, W, dy, need_dx, need_dw, need_db, dx_accum=None, scale=N
         out = res = None
         if dx_accum is not None:                            # the running sum of the other consumers' gradients: read as the
             out = res = dx_accum.view(-1, Kx)               # epilogue's residual and overwritten in place
+        if dx_res is not None:                              # dx = dy W + dx_res (a residual path's gradient), added by the epilogue
+            res = dx_res.reshape(-1, Kx)
         shape = tuple(x.shape[:-1]) + (Kx,)
-        Z = _dx_ksplit(rows, Kx, dyp.shape[1]) if dx_f16 else 1
+        Z = _dx_ksplit(rows, Kx, dyp.shape[1]) if (dx_f16 and dx_res is None) else 1
         if Z > 1:
             # few output tiles under a long reduction (the coarse levels' layers: 2048 or 8224 rows, N up to 4608): the reduction
             # is cut into Z chunks that run as the batch dimension of one launch; the partial products are added in order
@@ -118,6 +120,36 @@ class _Linear(Function):
         x, W = ctx.saved_tensors
         return _linear_backward(x, W, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2],
                                 scale=getattr(dy, "_tgp_scale", None))
+
+
+class _LinearEpi(Function):
+    """y = x W^T (+ b) (+ rb broadcast over each object's points) (+ res) in ONE launch: the GEMM's epilogue adds the per-object row
+    bias and the residual (the ORL block's `conv2(cat[g, global]) + g`, gcn3d.py:108-112, and `... + STE(...)`, :87-89 / :147-152,
+    were a GEMM plus two element-wise passes forward and a gradient add backward).  res_is_x: the residual is x itself (then
+    dx = dy W + dy, the second term through the dx GEMM's epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, rb, res, res_is_x):
+        x = x.contiguous()
+        Wc = W.contiguous()
+        rows = x.numel() // x.shape[-1]
+        r = x if res_is_x else res
+        y = ops.linear_rows(x, Wc, bias=b, rowbias=None if rb is None else rb.contiguous(), rows_per_obj=x.shape[-2] if rb is not None else 0,
+                            res1=None if r is None else r.contiguous(), w_split=_split_if_big(Wc, rows))
+        ctx.save_for_backward(x, Wc)
+        ctx.flags = (b is not None, rb is not None, res is not None, bool(res_is_x))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        has_b, has_rb, has_res, same = ctx.flags
+        need = ctx.needs_input_grad
+        dyc = dy.contiguous()
+        dx, dW, db = _linear_backward(x, W, dyc, need[0], need[1], has_b and need[2], scale=getattr(dy, "_tgp_scale", None),
+                                      dx_res=dyc if (same and need[0]) else None)
+        drb = ops.colsum_objects(dyc) if (has_rb and need[3]) else None
+        return dx, dW, db, drb, (dy if (has_res and need[4]) else None), None
 
 
 class _FeatConsumers(Function):
@@ -538,7 +570,7 @@ def _orl(layer, g, idx_orl, rev=None):
     C = g.shape[-1]
     w_pt, w_glob = _SplitCols.apply(_w2(layer.conv2), C)
     glob = _NbrMaxMean.apply(g, idx_orl, rev)                             # (B, C)
-    return add_row_bias(linear(g, w_pt), linear(glob, w_glob)) + g
+    return _LinearEpi.apply(g, w_pt, None, linear(glob, w_glob), None, True)
 
 
 def _surface(layer, xyz, graphs, kmax):
@@ -547,8 +579,7 @@ def _surface(layer, xyz, graphs, kmax):
     g = _GConvSurface.apply(xyz, graphs("conv_0.rf", 0, xyz, kmax), sdn, C)
     idx_orl = graphs("conv_0.orl_xyz", 0, xyz, kmax)
     out = _orl(layer, g, idx_orl, _reverse(graphs, idx_orl, xyz.shape[1]))
-    ste = linear(_pad4(xyz), _pad4(_w2(layer.STE_layer)))
-    return out + ste
+    return _LinearEpi.apply(_pad4(xyz), _pad4(_w2(layer.STE_layer)), None, None, out, False)      # STE(xyz) + out
 
 
 def _hs(layer, name, xyz, fm, graphs, level, k):
@@ -559,7 +590,7 @@ def _hs(layer, name, xyz, fm, graphs, level, k):
     g = _GConvHS.apply(xyz, idx_rf, proj, sdn, C, _reverse(graphs, idx_rf, xyz.shape[1]))
     idx_orl = graphs(name + ".orl_xyz", level, xyz, k)
     out = _orl(layer, g, idx_orl, _reverse(graphs, idx_orl, xyz.shape[1]))
-    return out + linear(fm, _w2(layer.STE_layer))
+    return _LinearEpi.apply(fm, _w2(layer.STE_layer), None, None, out, False)                          # STE(fm) + out
 
 
 class _GraphSource(object):
