@@ -70,6 +70,8 @@ int tgp_nn1(const float *target, const float *source, int B, int n, int m, int32
 
 /* F.normalize(directions, dim=0) (gcn3d.py:100,165).  directions (3,SC) -> out (3,SC). */
 int tgp_normalize_dirs(const float *directions, int SC, float *out, tgp_stream_t stream);
+/* its backward (round 3): out (3, SC) = d loss / d directions from grad (3, SC) = d loss / d normalised directions */
+int tgp_normalize_dirs_bwd(const float *directions, const float *grad, int SC, float *out, tgp_stream_t stream);
 
 /* gcn3d.py:91-106 HSlayer_surface.graph_conv.  xyz (B,n,3), idx (B,n,k), sdn (3,S*C) unit support
  * directions -> out (B,n,C) row stride ldo:  mean_s max_j relu(<dir_j, sdn[:, s*C+c]>).

@@ -86,6 +86,7 @@ SIGNATURES = {
     "tgp_knn_feat": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp]),
     "tgp_nn1": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "tgp_normalize_dirs": (c_int, [c_vp, c_int, c_vp, c_vp]),
+    "tgp_normalize_dirs_bwd": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp]),
     "tgp_gconv_surface_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
     "tgp_gconv_hs_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "tgp_orl_partial_floats": (c_i64, [c_int, c_int, c_int]),

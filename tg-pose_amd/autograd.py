@@ -515,6 +515,21 @@ class _HeadPost(Function):
         return dg, dr, dt, None
 
 
+class _NormalizeDirs(Function):
+    """F.normalize(directions, dim=0) (gcn3d.py:93, :160) as one launch each way (tgp_normalize_dirs / _bwd)"""
+
+    @staticmethod
+    def forward(ctx, d):
+        d = d.contiguous()
+        ctx.save_for_backward(d)
+        return ops.normalize_dirs(d)
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return ops.normalize_dirs_bwd(d, g)
+
+
 class _SplitCols(Function):
     """w (N, K) -> (w[:, :c], w[:, c:]) as contiguous tensors; the backward is one concatenation (two column slices under autograd
     cost two zero fills, two copies and an add per layer and step)"""
@@ -575,7 +590,7 @@ def _orl(layer, g, idx_orl, rev=None):
 
 def _surface(layer, xyz, graphs, kmax):
     C = layer.kernel_num
-    sdn = F.normalize(layer.directions, dim=0)
+    sdn = _NormalizeDirs.apply(layer.directions)
     g = _GConvSurface.apply(xyz, graphs("conv_0.rf", 0, xyz, kmax), sdn, C)
     idx_orl = graphs("conv_0.orl_xyz", 0, xyz, kmax)
     out = _orl(layer, g, idx_orl, _reverse(graphs, idx_orl, xyz.shape[1]))
@@ -584,7 +599,7 @@ def _surface(layer, xyz, graphs, kmax):
 
 def _hs(layer, name, xyz, fm, graphs, level, k):
     C = layer.out_channel
-    sdn = F.normalize(layer.directions, dim=0)
+    sdn = _NormalizeDirs.apply(layer.directions)
     idx_rf = graphs(name + ".rf", None, fm, k)
     proj = linear(fm, layer.weights.t(), layer.bias)                      # (B, n, 8C) = [centre | support]
     g = _GConvHS.apply(xyz, idx_rf, proj, sdn, C, _reverse(graphs, idx_rf, xyz.shape[1]))

@@ -31,6 +31,30 @@ extern "C" int tgp_normalize_dirs(const float *directions, int SC, float *out, t
     return TGP_LAUNCH_RESULT();
 }
 
+// backward of normalize_dirs: n = d / max(|d|, eps) per column -> dd = (g - n (n . g)) / |d|   (|d| > eps; below it n = d / eps, dd = g / eps)
+__global__ void normalize_dirs_bwd_kernel(const float *__restrict__ d, const float *__restrict__ g, int SC, float *__restrict__ dd)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= SC) return;
+    const float x = d[c], y = d[SC + c], z = d[2 * SC + c];
+    const float gx = g[c], gy = g[SC + c], gz = g[2 * SC + c];
+    const float nrm = sqrtf((x * x + y * y) + z * z);
+    if (nrm > 1e-12f) {
+        const float nx = x / nrm, ny = y / nrm, nz = z / nrm;
+        const float dot = (nx * gx + ny * gy) + nz * gz;
+        dd[c] = (gx - nx * dot) / nrm, dd[SC + c] = (gy - ny * dot) / nrm, dd[2 * SC + c] = (gz - nz * dot) / nrm;
+    } else {
+        dd[c] = gx / 1e-12f, dd[SC + c] = gy / 1e-12f, dd[2 * SC + c] = gz / 1e-12f;
+    }
+}
+
+extern "C" int tgp_normalize_dirs_bwd(const float *directions, const float *grad, int SC, float *out, tgp_stream_t stream)
+{
+    TGP_REQUIRE(directions && grad && out && SC > 0);
+    hipLaunchKernelGGL(normalize_dirs_bwd_kernel, dim3(tgp_cdiv(SC, 256)), dim3(256), 0, tgp_hs(stream), directions, grad, SC, out);
+    return TGP_LAUNCH_RESULT();
+}
+
 // Two fp32 lanes per instruction (v_pk_mul_f32 / v_pk_fma_f32 run at the full VALU rate on gfx950, so the <direction, support
 // direction> products cost half the issue slots); each component is the same IEEE operation as the scalar fmaf / multiply.
 typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -138,6 +138,14 @@ def normalize_dirs(directions):
     return out
 
 
+def normalize_dirs_bwd(directions, grad):
+    directions, grad = directions.contiguous(), grad.contiguous()
+    out = torch.empty_like(directions)
+    check(_lib.lib().tgp_normalize_dirs_bwd(_p(directions), _p(grad), directions.shape[1], _p(out), _stream(directions)),
+          "tgp_normalize_dirs_bwd")
+    return out
+
+
 @_timed("graph")
 def gconv_surface(xyz, idx, sdn, S, C, out=None, xyz_pad=False):
     """xyz_pad: `out` is a (B, n, C) view of a buffer whose rows are at least C + 4 floats long; columns C..C+3 of every row
