@@ -389,6 +389,10 @@ int tgp_transpose_scaled(const float *src, int ld_src, int rows, int cols, const
 int tgp_transpose_split_f16(const float *src, int ld_src, int rows, int cols, const float *scale, uint16_t *dst, int rows_pad,
                             tgp_stream_t stream);
 /* out[i] (+)= *scale * sum_z parts[z * n + i], z ascending (scale may be NULL) */
+/* (round 3) W (rows, cols) -> dst_f32 (cols, rows_pad) = W^T zero padded and dst_split = its fp16 hi / lo planes
+ * [cols][rows_pad / 16][2][16], rows_pad % 16 == 0: the weight operands of the backward's dx GEMM in one pass */
+int tgp_transpose_both(const float *src, int ld_src, int rows, int cols, float *dst_f32, uint16_t *dst_split, int rows_pad,
+                       tgp_stream_t stream);
 int tgp_sum_slabs(const float *parts, int Z, int64_t n, const float *scale, float *out, int accumulate, tgp_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -162,6 +162,7 @@ SIGNATURES = {
     "tgp_pose_rotation_fwd": (c_int, [c_vp] * 6 + [c_int, c_vp, c_vp, c_vp]),
     "tgp_pose_rotation_bwd": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp]),
     "tgp_head_post_bwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int] + [c_vp] * 10),
+    "tgp_transpose_both": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
     "tgp_gemm_tn_split": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
     "tgp_reverse_graph": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_nbrmax_bwd_gather": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_f32,

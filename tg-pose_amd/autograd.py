@@ -74,8 +74,11 @@ def _linear_backward(x, W, dy, need_dx, need_dw, need_db, dx_accum=None, scale=N
     sc = (scale if scale is not None else ops.absmax_scale(dyc)) if (dx_f16 or dw_f16) else None
     if need_dx:
         dyp = _pad4(dyc).contiguous()                       # the reduction dim of this GEMM is N
-        Wd = W if dx_cols is None else W[:, :dx_cols].contiguous()
-        wt = _pad4(ops.transpose(Wd)).contiguous()          # (Kx, N)
+        Wd = W if dx_cols is None else W[:, :dx_cols]       # (a column slice: read through its row stride)
+        if dx_f16:
+            wt, wt_s = ops.transpose_both(Wd)               # (Kx, N16) fp32 and its fp16 planes, one pass over the weight
+        else:
+            wt, wt_s = _pad4(ops.transpose(Wd.contiguous())).contiguous(), None     # (Kx, N4)
         out = res = None
         if dx_accum is not None:                            # the running sum of the other consumers' gradients: read as the
             out = res = dx_accum.view(-1, Kx)               # epilogue's residual and overwritten in place
@@ -89,10 +92,10 @@ def _linear_backward(x, W, dy, need_dx, need_dw, need_db, dx_accum=None, scale=N
             chunk = dyp.shape[1] // Z
             parts = torch.empty(Z, rows, Kx, device=dyp.device, dtype=torch.float32)
             ops.gemm(dyp, wt, parts, M=rows, N=Kx, K=chunk, lda=dyp.shape[1], ldw=wt.shape[1], ldc=Kx, batch=Z,
-                     batch_strides=(chunk, 0, rows * Kx, 0, 0), w_split=ops.split_f16(wt), a_scale=sc, ksplit_chunk=chunk)
+                     batch_strides=(chunk, 0, rows * Kx, 0, 0), w_split=wt_s, a_scale=sc, ksplit_chunk=chunk)
             dx = ops.sum_slabs(parts, sc[1:], out=out, accumulate=out is not None).view(shape)
         elif dx_f16:
-            dx = ops.linear_rows(dyp, wt, w_split=ops.split_f16(wt), a_scale=sc, c_scale=sc[1:], out=out, res1=res).view(shape)
+            dx = ops.linear_rows(dyp, wt, w_split=wt_s, a_scale=sc, c_scale=sc[1:], out=out, res1=res).view(shape)
         else:
             dx = ops.linear_rows(dyp, wt, w_split=_split_if_big(wt, dyp.shape[0], grads=True), out=out, res1=res).view(shape)
     if need_dw:

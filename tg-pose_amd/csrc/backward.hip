@@ -923,7 +923,8 @@ extern "C" int tgp_absmax_scale(const float *x, int ld, int64_t rows, int cols, 
 #define TS_TILE 64
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void transpose_scaled_kernel(const float *__restrict__ src, int lds_, int rows, int cols,
-                                                               const float *__restrict__ scale, void *__restrict__ dst_, int rows_pad)
+                                                               const float *__restrict__ scale, void *__restrict__ dst_, int rows_pad,
+                                                               float *__restrict__ dst_f32 = nullptr)
 {
     __shared__ float tile[TS_TILE][TS_TILE + 1];
     const int c0 = blockIdx.x * TS_TILE, r0 = blockIdx.y * TS_TILE;
@@ -964,6 +965,11 @@ __global__ __launch_bounds__(256) void transpose_scaled_kernel(const float *__re
             uint16_t *o = static_cast<uint16_t *>(dst_) + ((int64_t)c * (rows_pad / 16) + r / 16) * 32 + (r & 15);
             *reinterpret_cast<uint4 *>(o) = *reinterpret_cast<const uint4 *>(hi);
             *reinterpret_cast<uint4 *>(o + 16) = *reinterpret_cast<const uint4 *>(lo);
+            if (dst_f32) {       // the fp32 transpose beside the planes (tgp_transpose_both: one pass over a weight for the dx GEMM)
+                float *f = dst_f32 + (int64_t)c * rows_pad + r;
+                *reinterpret_cast<float4 *>(f) = make_float4(tile[8 * hf][cc], tile[8 * hf + 1][cc], tile[8 * hf + 2][cc], tile[8 * hf + 3][cc]);
+                *reinterpret_cast<float4 *>(f + 4) = make_float4(tile[8 * hf + 4][cc], tile[8 * hf + 5][cc], tile[8 * hf + 6][cc], tile[8 * hf + 7][cc]);
+            }
         }
     } else {
         for (int t = threadIdx.x; t < TS_TILE * (TS_TILE / 4); t += 256) {
@@ -993,6 +999,18 @@ extern "C" int tgp_transpose_split_f16(const float *src, int ld_src, int rows, i
                 (reinterpret_cast<uintptr_t>(dst) & 15) == 0);
     hipLaunchKernelGGL((transpose_scaled_kernel<true>), dim3(tgp_cdiv(cols, TS_TILE), tgp_cdiv(rows_pad, TS_TILE)), dim3(256), 0,
                        tgp_hs(stream), src, ld_src, rows, cols, scale, dst, rows_pad);
+    return TGP_LAUNCH_RESULT();
+}
+
+// dst_f32 (cols, rows_pad) = src^T zero padded, dst_split = its fp16 hi / lo planes [cols][rows_pad / 16][2][16]: what the backward's
+// dx GEMM takes as its weight (W^T and split_f16(W^T)), in one pass over W instead of a transpose, a padding copy and a split
+extern "C" int tgp_transpose_both(const float *src, int ld_src, int rows, int cols, float *dst_f32, uint16_t *dst_split, int rows_pad,
+                                  tgp_stream_t stream)
+{
+    TGP_REQUIRE(src && dst_f32 && dst_split && rows > 0 && cols > 0 && ld_src >= cols && rows_pad >= rows && (rows_pad & 15) == 0 &&
+                ((reinterpret_cast<uintptr_t>(dst_f32) | reinterpret_cast<uintptr_t>(dst_split)) & 15) == 0);
+    hipLaunchKernelGGL((transpose_scaled_kernel<true>), dim3(tgp_cdiv(cols, TS_TILE), tgp_cdiv(rows_pad, TS_TILE)), dim3(256), 0,
+                       tgp_hs(stream), src, ld_src, rows, cols, (const float *)nullptr, dst_split, rows_pad, dst_f32);
     return TGP_LAUNCH_RESULT();
 }
 

@@ -881,6 +881,17 @@ def transpose(w):
     return out
 
 
+def transpose_both(w):
+    """w (rows, cols) -> (wt (cols, rows16) fp32 = w^T zero padded to a multiple of 16 columns, split_f16(wt)) in one launch"""
+    w, ld = _rows(w, "w")
+    rows, cols = w.shape
+    pad = (rows + 15) // 16 * 16
+    wt = torch.empty(cols, pad, device=w.device, dtype=torch.float32)
+    planes = torch.empty(cols, pad // 16, 2, 16, device=w.device, dtype=torch.int16)
+    check(_lib.lib().tgp_transpose_both(_p(w), ld, rows, cols, _p(wt), _p(planes), pad, _stream(w)), "tgp_transpose_both")
+    return wt, planes
+
+
 def gconv_surface_bwd(xyz, idx, sdn, dg, S, C):
     """-> dsdn (3, S*C)"""
     dg, ldg = _rows(dg, "dg")
