@@ -8,7 +8,7 @@
 
 #define CL_MAX_PARENTS 4096
 
-#define CL_SPLIT 4   // workgroups per object (each repeats the counting sort's histogram and ranks a quarter of the points)
+#define CL_SPLIT 16  // workgroups per object (each repeats the counting sort's histogram and ranks a sixteenth of the points)
 
 // ptr[b * R + r] = first slot of parent r's children in idx (global), idx[...] = global rows (b * n + i): a counting sort of the
 // object's points by parent.  Slot of point i = (points with a smaller parent) + (earlier points with the same parent); the second
