@@ -1471,6 +1471,52 @@ def test_bn_backward_collects_the_next_layers_scale(ops, rows, C):
             assert float(dx._tgp_scale[0]) == 1.0
 
 
+def test_pose_glue_nodes_vs_torch_autograd(ops):
+    """The small single-launch nodes of the training path against the torch formulations they replace, values and gradients:
+    F.normalize(directions, dim=0) (gcn3d.py:93), the heads' post-processing (PoseNet9D.py:57-66), conv2(cat[g, global]) + g with
+    the row bias and the residual in the GEMM epilogue (gcn3d.py:108-112)."""
+    from tgpose_amd import autograd as A
+    gen = torch.Generator().manual_seed(11)
+    # direction normalisation
+    d0 = torch.randn(3, 896, generator=gen)
+    w = torch.randn(3, 896, generator=gen)
+    a = g(d0).requires_grad_(True)
+    b = g(d0).requires_grad_(True)
+    (A._NormalizeDirs.apply(a) * g(w)).sum().backward()
+    (torch.nn.functional.normalize(b, dim=0) * g(w)).sum().backward()
+    assert torch.allclose(a.grad, b.grad, atol=1e-6, rtol=1e-5)
+    # head post-processing
+    B = 32
+    green, red, ts, mean = (torch.randn(B, 4, generator=gen), torch.randn(B, 4, generator=gen), torch.randn(B, 6, generator=gen),
+                            torch.randn(B, 3, generator=gen))
+    ws = [torch.randn(B, 3, generator=gen), torch.randn(B, 3, generator=gen), torch.randn(B, generator=gen), torch.randn(B, generator=gen),
+          torch.randn(B, 3, generator=gen), torch.randn(B, 3, generator=gen)]
+    res = []
+    for fused in (True, False):
+        gr, rd, t = (g(x).requires_grad_(True) for x in (green, red, ts))
+        if fused:
+            outs = A._HeadPost.apply(gr, rd, t, g(mean))
+        else:
+            outs = (gr[:, 1:] / (torch.norm(gr[:, 1:], dim=1, keepdim=True) + 1e-6), rd[:, 1:] / (torch.norm(rd[:, 1:], dim=1, keepdim=True) + 1e-6),
+                    torch.sigmoid(gr[:, 0]), torch.sigmoid(rd[:, 0]), t[:, 0:3] + g(mean), t[:, 3:6])
+        sum((o * g(wt)).sum() for o, wt in zip(outs, ws)).backward()
+        res.append(([o.detach() for o in outs], [gr.grad, rd.grad, t.grad]))
+    for x, y in zip(res[0][0] + res[0][1], res[1][0] + res[1][1]):
+        assert torch.allclose(x, y, atol=2e-6, rtol=1e-5)
+    # ORL block: x W^T + rb[object] + x
+    Bn, n, C = 3, 257, 128
+    x0, W0, rb0, wy = (torch.randn(Bn, n, C, generator=gen), torch.randn(C, C, generator=gen) / C ** 0.5, torch.randn(Bn, C, generator=gen),
+                       torch.randn(Bn, n, C, generator=gen))
+    res = []
+    for fused in (True, False):
+        x, W, rb = (g(v).requires_grad_(True) for v in (x0, W0, rb0))
+        y = A._LinearEpi.apply(x, W, None, rb, None, True) if fused else (x @ W.t() + rb.unsqueeze(1) + x)
+        (y * g(wy)).sum().backward()
+        res.append((y.detach(), x.grad, W.grad, rb.grad))
+    for x, y in zip(res[0], res[1]):
+        assert torch.allclose(x, y, atol=2e-4 * float(y.abs().max()), rtol=0), float((x - y).abs().max())
+
+
 def test_pose_rotation_fused_vs_torch_autograd(ops):
     """losses.dcd.pose_rotation (one launch forward with the Jacobian by forward-mode differentiation, one backward) against the
     same formulas as (B, 3)-sized torch arithmetic under autograd (TDA_loss_sym_recon.py:327-333, :351-360, :370-395): the
