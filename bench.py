@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- objects/s of PoseNet9D.forward (eval, B=32 per GPU, N=1028) on the HIP path.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts its N ranks as child processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -234,6 +234,63 @@ def train_batch(B, N, seed):
                           torch.from_numpy(gc["pdh2_category"]), gc["sym"].astype(int).tolist(), [i % 6 for i in range(B)], N, seed)
 
 
+def rank_env(rank, world, port, base=None):
+    """environment of rank `rank` of a one-node job of `world` ranks (what torch.distributed.run would set)"""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on this driver
+    return env
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(world, argv=None, cmd=None, poll=0.2):
+    """`python bench.py --gpus N` typed as it stands: start the N ranks as CHILD processes (never an exec: the parent has not touched
+    the GPU and never will), one per GPU, wait for them, relay rank 0's standard output (the JSON line) and return 0, or the first
+    non-zero exit code -- the other ranks are then terminated, so a rank that died cannot leave the rest waiting in a collective."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv) if cmd is None else list(cmd)
+    port = free_port()
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen(cmd, env=rank_env(r, world, port), stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc, out0 = 0, []
+    import threading
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()))     # (drained while waiting: a full pipe would block rank 0)
+    reader.start()
+    live = set(range(world))
+    while live and rc == 0:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is not None:
+                live.discard(r)
+                if code != 0:
+                    rc = code
+                    sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, code))
+                    break
+        if live and rc == 0:
+            time.sleep(poll)
+    for r in live:                       # only after a failure: exactly the children started above
+        procs[r].terminate()
+    for r in live:
+        try:
+            procs[r].wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+            procs[r].wait()
+    reader.join()
+    if rc == 0:
+        sys.stdout.write(b"".join(out0).decode())
+        sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -276,8 +333,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (see the module docstring)" % args.gpus)
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # typed without a launcher: this process becomes the launcher (nothing above has touched the GPU)
+            raise SystemExit(self_launch(args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 4
+#define TGP_ABI_VERSION 5
 #define TGP_EINVAL (-1)       /* null pointer / non-positive size / misaligned stride */
 #define TGP_EUNSUPPORTED (-2) /* shape outside what the kernels are built for */
 
@@ -187,6 +187,25 @@ typedef struct tgp_gemm_args {
      * gather-index pointers are those of the launch's first row, as always.  0 for whole-batch launches.  (The eval forward
      * hands the last rows of the heads' layers to the tile kernels beside the fused kernel: engine.wide_gemm_factored.) */
     int row_base;
+    /* (ABI 5) Operands and results as BLOCKED fp16 planes.  A row-major fp32 matrix X (rows, K) in this form is
+     * tgp_planes_bytes(rows, K) bytes: for each block of 32 rows and each 16-wide K-tile a 2 KB chunk
+     *     [plane: hi | lo][h = (k % 16) / 8][r = row % 32][8 fp16],      x = hi + lo to ~2^-23 (the split of tgp_split_f16),
+     * chunks ordered [row block][K-tile], `kt` K-tiles per row block (>= ceil(K / 16); rows and columns past the end are zero).
+     * One plane of a chunk is 1 KB in the lane order of v_mfma_f32_32x32x16_f16's operand, so the kernels stage it by LDS-DMA and
+     * never convert in their K loop.
+     *   A_planes + W_planes (both or neither): the launch runs on the pre-split kernel (csrc/gemm_pp.hip); batch == 1, no
+     *     a_scale / ksplit_chunk; every epilogue operand 16-byte addressable.  Results are bit-identical to the launch without
+     *     them (same products, same order).  a_amax (may be NULL = unguarded): per 32-row block of A the bits of its largest
+     *     magnitude, as tgp_planes_split / a producing launch's c_amax wrote them: a tile whose blocks hold a magnitude
+     *     >= 65504 (or a NaN), or nothing >= 2^-4, is computed in exact fp32 from A / W, which are still required then.
+     *   C_planes: the result (the columns >= c_col0) is ALSO written as planes, column c_col0 landing at plane column cp_col0
+     *     (% 16 == 0), N - c_col0 a multiple of 16; c_amax (zero-filled by the caller once per tensor) receives the per-block
+     *     magnitudes.  Tile kernels with the 16-byte epilogue only (the launch is refused otherwise).  C may be NULL.
+     * pp_config: 0 = the library picks the tile shape; 1 .. 7 force one (tests, tuning scripts). */
+    const void *A_planes; int a_kt; const uint32_t *a_amax;
+    const void *W_planes; int w_kt;
+    void *C_planes; int c_kt; int cp_col0; uint32_t *c_amax;
+    int pp_config;
 } tgp_gemm_args;
 
 /* W (rows, K) fp32, row stride ld -> out[rows][ldo/16][3][16] bf16: per 16-wide K-tile the hi, mid and lo terms
@@ -195,6 +214,17 @@ typedef struct tgp_gemm_args {
 int tgp_split_bf16(const float *W, int rows, int K, int ld, uint16_t *out, int ldo, tgp_stream_t stream);
 /* Same for the two-term fp16 split: out[rows][ldo/16][2][16] (hi, lo), 2*rows*ldo elements. */
 int tgp_split_f16(const float *W, int rows, int K, int ld, uint16_t *out, int ldo, tgp_stream_t stream);
+
+/* (ABI 5) bytes of the blocked fp16 planes of a (rows, K) matrix (tgp_gemm_args.A_planes), and the split itself: X (rows, K) fp32
+ * with row stride ld -> out (kts >= ceil(K / 16) K-tiles per row block; padding rows / columns zero); amax (may be NULL; ceil(rows /
+ * 32) words, zero-filled by the caller) receives atomicMax of the bits of |x| per row block.  Weights at pack time; activations
+ * whose producer does not write planes itself. */
+int64_t tgp_planes_bytes(int64_t rows, int K);
+int tgp_planes_split(const float *X, int rows, int K, int ld, void *out, int kts, uint32_t *amax, tgp_stream_t stream);
+/* tgp_gather_rows and tgp_planes_split in one pass: dst[b][p][0..C) = src[b][idx[b][p]][0..C) (dst may be NULL) and the planes of
+ * the gathered rows' first K columns (columns K.. of the planes zero); kts * 16 >= C when dst is given. */
+int tgp_planes_gather(const float *src, int lds, const int32_t *idx, int B, int n_src, int n_out, int K, int C, float *dst, int ldd,
+                      void *out, int kts, uint32_t *amax, tgp_stream_t stream);
 
 /* nn.Conv1d(kernel 1) / nn.Linear on channel-last rows with the fused epilogue above. */
 int tgp_gemm_f32(const tgp_gemm_args *args, tgp_stream_t stream);

@@ -3282,3 +3282,164 @@ def test_train_loader_vs_reference_getitem(ops):
         train_clouds([dict(items[0], inst_id=0)], device=DEV)
     with pytest.raises(ValueError):
         train_clouds([dict(items[0], mask=items[0]["mask"].astype(np.int32))], device=DEV)
+
+
+# ----------------------------------------------------------------------------------------- round 4: fp16 planes, pre-split GEMM
+def _ref_planes(x, K=None, kt=None):
+    """torch restatement of the blocked-planes layout: x (rows, ld) -> uint8 (nblk, kt, 2048) and the per-block magnitude bits"""
+    rows = x.shape[0]
+    K = x.shape[1] if K is None else K
+    kt = (K + 15) // 16 if kt is None else kt
+    nblk = (rows + 31) // 32
+    xp = torch.zeros(nblk * 32, kt * 16, device=x.device)
+    xp[:rows, :K] = x[:, :K]
+    hi = xp.half()
+    lo = (xp - hi.float()).half()
+    pl = torch.stack([hi, lo], 0).view(2, nblk, 32, kt, 2, 8).permute(1, 3, 0, 4, 2, 5).contiguous()      # [rb][kt][plane][h][r][8]
+    amax = xp.abs().view(nblk, -1).max(dim=1)[0].view(torch.int32)
+    return pl.view(torch.uint8).view(nblk, kt, 2048), amax
+
+
+@pytest.mark.parametrize("rows,K,ld", [(1028, 268, 272), (4112, 128, 128), (33, 20, 24), (257 * 3, 512, 512)])
+def test_planes_split_layout_and_magnitudes(ops, rows, K, ld):
+    """tgp_planes_split: hi = fp16(x), lo = fp16(x - hi) in the blocked layout of include/tgpose.h (chunk = 32 rows x 16 columns,
+    [plane][half][row][8]), zero padding, per-block magnitude bits; Planes.to_float gives hi + lo back."""
+    gen = torch.Generator().manual_seed(rows + K)
+    x = g(torch.randn(rows, ld, generator=gen) * torch.logspace(-3, 2, rows, base=10.0).unsqueeze(1))
+    P = ops.planes_split(x, K=K)
+    want, amax = _ref_planes(x, K)
+    assert torch.equal(P.buf, want) and torch.equal(P.amax, amax)
+    assert (P.to_float() - x[:, :K]).abs().max().item() <= 2e-7 * x.abs().max().item() + 6e-8
+
+
+def test_planes_gather_equals_gather_then_split(ops):
+    """tgp_planes_gather = tgp_gather_rows + tgp_planes_split in one pass (the factored layers' sorted fine buffer)"""
+    gen = torch.Generator().manual_seed(5)
+    B, n, C, K = 3, 1028, 272, 268
+    src = g(torch.randn(B, n, C, generator=gen))
+    idx = g(torch.stack([torch.randperm(n, generator=gen) for _ in range(B)]).int())
+    d0 = torch.empty_like(src)
+    ops.gather_rows(src, idx, d0)
+    P0 = ops.planes_split(d0.view(B * n, C), K=K)
+    d1 = torch.full_like(src, 7.0)
+    P1 = ops.Planes(B * n, K, DEV)
+    ops.planes_gather(src, idx, d1, K, P1)
+    assert torch.equal(d0, d1) and torch.equal(P0.buf, P1.buf) and torch.equal(P0.amax, P1.amax)
+
+
+@pytest.mark.parametrize("M,N,K,rpo", [(4112, 1152, 128, 1028), (1300, 640, 268, 100), (522, 384, 64, 64), (8224 // 4, 512, 512, 257),
+                                       (2056, 128, 132, 1028)])
+def test_gemm_pp_bit_identical_to_split_kernel(ops, M, N, K, rpo):
+    """The pre-split kernel (both operands as fp16 planes, staged by LDS-DMA; csrc/gemm_pp.hip) against the in-loop-split kernels of
+    csrc/gemm.hip on the same operands, every tile shape, with every epilogue feature on (bias, per-object bias, two residuals, BN
+    fold, per-column slope, column ranges, max over points): the planes are a deterministic function of the fp32 values and the
+    MFMA sequence per output block is the same, so C and the colmax keys carry the same bits.  Also: the result planes the epilogue
+    writes equal the stand-alone split of C, from both kernel families."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    nobj = (M + rpo - 1) // rpo
+    ld = (K + 3) // 4 * 4
+    A, W = g(torch.randn(M, ld, generator=gen)), g(torch.randn(N, ld, generator=gen) / K ** 0.5)
+    vec = lambda: g(torch.randn(N, generator=gen))
+    bias, scale, shift, slope = vec(), g(torch.rand(N, generator=gen) + 0.5), vec(), g(torch.rand(N, generator=gen) * 0.3)
+    rowbias, res1, res2 = g(torch.randn(nobj, N, generator=gen)), g(torch.randn(M, N, generator=gen)), g(torch.randn(M, N + 8, generator=gen))
+    c0, cmc = 128 if N > 128 else 0, N // 2
+    kw = dict(M=M, N=N, K=K, lda=ld, ldw=ld, ldc=N - c0, bias=bias, rowbias=rowbias, rows_per_obj=rpo, res1=res1, ldr1=N,
+              res2=res2[:, 4:], ldr2=N + 8, scale=scale, shift=shift, act=1, slope_vec=slope, cm_cols=cmc, c_col0=c0, w_split=ops.split_w(W))
+    keys0 = torch.zeros(nobj, cmc, dtype=torch.int32, device=DEV)
+    C0 = torch.full((M, N - c0), 7.0, device=DEV)
+    ops.gemm(A, W, C0, colmax_keys=keys0, **kw)
+    Ap, Wp = ops.planes_split(A, K=K), ops.planes_w(W[:, :K].contiguous())
+    ref_pl, ref_amax = _ref_planes(C0)
+    rows_ok = (torch.arange(ref_pl.shape[0] * 32, device=DEV) < M).view(-1, 1, 1, 1, 32, 1)
+    for cfg in (0, 1, 2, 3, 4, 5, 6, 7):
+        keys = torch.zeros_like(keys0)
+        C = torch.full((M, N - c0), 7.0, device=DEV)
+        Cp = ops.Planes(M, N - c0, DEV)
+        ops.gemm(A, W, C, colmax_keys=keys, a_planes=Ap, w_planes=Wp, c_planes=Cp, pp_config=cfg, **kw)
+        assert torch.equal(C, C0) and torch.equal(keys, keys0), cfg
+        same = (Cp.buf.view(-1, Cp.kt, 2, 2, 32, 16) == ref_pl.view(-1, Cp.kt, 2, 2, 32, 16)) | ~rows_ok
+        assert bool(same.all()) and torch.equal(Cp.amax, ref_amax), cfg
+    # the small-tile split kernel's planes-writing instance (fp32 operand, result planes)
+    Cp = ops.Planes(M, N - c0, DEV)
+    C = torch.full((M, N - c0), 7.0, device=DEV)
+    keys = torch.zeros_like(keys0)
+    ops.gemm(A, W, C, colmax_keys=keys, c_planes=Cp, **kw)
+    assert torch.equal(C, C0) and torch.equal(keys, keys0)
+    assert bool(((Cp.buf.view(-1, Cp.kt, 2, 2, 32, 16) == ref_pl.view(-1, Cp.kt, 2, 2, 32, 16)) | ~rows_ok).all()) and torch.equal(Cp.amax, ref_amax)
+
+
+def test_gemm_pp_gathered_residuals_bit_identical(ops):
+    """the factored layers' epilogue (gathered coarse products + per-object bias + max over points) on the pre-split kernel"""
+    gen = torch.Generator().manual_seed(78)
+    B, n, n1, n2, N, K = 5, 300, 75, 19, 512, 268
+    M = B * n
+    A, W = g(torch.randn(M, 272, generator=gen)), g(torch.randn(N, 272, generator=gen) / K ** 0.5)
+    P1, P2 = g(torch.randn(B * n1, N + 64, generator=gen)), g(torch.randn(B * n2, N + 64, generator=gen))
+    i1 = g((torch.randint(0, n1, (B, n), generator=gen) + torch.arange(B).unsqueeze(1) * n1).int()).contiguous()
+    i2 = g((torch.randint(0, n2, (B, n), generator=gen) + torch.arange(B).unsqueeze(1) * n2).int()).contiguous()
+    kw = dict(M=M, N=N, K=K, lda=272, ldw=272, ldc=N, bias=g(torch.randn(N, generator=gen)), rowbias=g(torch.randn(B, N, generator=gen)),
+              rows_per_obj=n, scale=g(torch.rand(N, generator=gen) + 0.5), shift=g(torch.randn(N, generator=gen)), act=1, slope=0.1,
+              w_split=ops.split_w(W), gather1=(P1[:, 32:], N + 64, i1), gather2=(P2[:, 32:], N + 64, i2))
+    keys0, C0 = torch.zeros(B, N, dtype=torch.int32, device=DEV), torch.empty(M, N, device=DEV)
+    ops.gemm(A, W, C0, colmax_keys=keys0, **kw)
+    Ap, Wp = ops.planes_split(A, K=K), ops.planes_w(W[:, :K].contiguous())
+    for cfg in (0, 1, 3, 4, 5):
+        keys, C = torch.zeros_like(keys0), torch.empty_like(C0)
+        ops.gemm(A, W, C, colmax_keys=keys, a_planes=Ap, w_planes=Wp, pp_config=cfg, **kw)
+        assert torch.equal(C, C0) and torch.equal(keys, keys0), cfg
+
+
+def test_gemm_pp_range_guard(ops):
+    """The consumer's fp16 range guard works from what the producer of the planes recorded: a 32-row block holding 3e5 (beyond
+    fp16) or a NaN, and blocks whose entries all lie under 2^-4, make their tiles recompute in exact fp32 from the fp32 operand --
+    every row within 3e-6 of ITS output scale against fp64 (the tile kernels' own guard tests use the same bar); an unguarded launch
+    (no magnitudes passed) is the proof that the inputs do need the guard."""
+    gen = torch.Generator().manual_seed(9)
+    M, N, K = 1024, 256, 256
+    A = torch.randn(M, K, generator=gen)
+    A[100:132] *= 3e5 / 4                       # one block far beyond fp16's range
+    A[512:768] *= 1e-4                          # two whole 128-row tiles of tiny entries
+    W = torch.randn(N, K, generator=gen) / K ** 0.5
+    want = A.double() @ W.double().t()
+    dA, dW = g(A), g(W)
+    Ap, Wp = ops.planes_split(dA), ops.planes_w(dW)
+    for cfg in (1, 3, 4, 5):
+        C = torch.empty(M, N, device=DEV)
+        ops.gemm(dA, dW, C, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, w_split=ops.split_w(dW), a_planes=Ap, w_planes=Wp, pp_config=cfg)
+        err = (C.cpu().double() - want).abs().amax(dim=1) / want.abs().amax(dim=1)
+        assert torch.isfinite(C).all() and err.max().item() < 3e-6, (cfg, err.max().item(), int(err.argmax()))
+    Au = ops.Planes(M, K, DEV, amax=False, buf=Ap.buf)           # the same planes without their magnitudes: no guard
+    C = torch.empty(M, N, device=DEV)
+    ops.gemm(dA, dW, C, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, w_split=ops.split_w(dW), a_planes=Au, w_planes=Wp, pp_config=4)
+    err = (C.cpu().double() - want).abs().amax(dim=1) / want.abs().amax(dim=1)
+    assert not torch.isfinite(C[100:132]).all() or err[100:132].max().item() > 1e-3
+    assert err[512:768].max().item() > 3e-6
+
+
+@pytest.mark.parametrize("B,N", [(3, 1028), (2, 256)])
+def test_forward_on_planes_bit_identical_to_forward_without(ops, B, N):
+    """ops.PLANES: the eval forward whose GEMM operands travel as fp16 planes (projection GEMMs, coarse products, the decoder chain
+    on the pre-split kernel; planes written by the producing epilogues, the pooling outputs' split and the fused row gather)
+    against the same forward on the in-loop-split kernels: every output, the reconstruction and the PH codes bit for bit."""
+    from tgpose_amd import FLAGS, engine
+    net = _net(11)
+    FLAGS.train = 0
+    pts, obj = synth_points(B, N, 37)
+    torch.manual_seed(6)
+    i1 = torch.randperm(N)[: N // 4]
+    smp = (i1, torch.randperm(N // 4)[: N // 16])
+    assert ops.planes_on()
+    pk = net.packed(DEV)
+    assert pk.fact.get("Wb_p") is not None                      # packed with planes
+    got = []
+    for on in (True, False):
+        old, ops.PLANES = ops.PLANES, on
+        try:
+            probe = {}
+            with torch.no_grad():
+                out = engine.posenet_forward(pk, g(pts), g(obj), False, sample_idx=smp, probe=probe)
+            got.append({k: v.clone() for k, v in list(out.items()) + [(k, probe[k]) for k in ("recon", "h1", "h2")]})
+        finally:
+            ops.PLANES = old
+    for k in got[0]:
+        assert torch.equal(got[0][k], got[1][k]), k

@@ -42,6 +42,9 @@ def test_c_abi_argument_errors_do_not_launch():
     assert h.tgp_gemm_f32(a, None) == -1
     assert h.tgp_heads_fused(_lib.HeadsFusedArgs(), None) == -1 and h.tgp_conv_max_fused(_lib.ConvMaxFusedArgs(), None) == -1
     assert h.tgp_heads_pack_w2(None, 3, None, None) == -1
+    # (ABI 5) blocked fp16 planes: 2 KB per (32 rows, 16 columns) chunk; a split without buffers is refused
+    assert h.tgp_planes_bytes(32896, 268) == 1028 * 17 * 2048 and h.tgp_planes_bytes(1, 1) == 2048 and h.tgp_planes_bytes(0, 16) == 0
+    assert h.tgp_planes_split(None, 4, 16, 16, None, 1, None, None) == -1
 
 
 def test_gemm_args_struct_matches_header_layout():
@@ -50,17 +53,19 @@ def test_gemm_args_struct_matches_header_layout():
     import subprocess
     import tempfile
     from tgpose_amd import _lib
-    src = '#include <stdio.h>\n#include <stddef.h>\n#include "tgpose.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",' \
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "tgpose.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",' \
           'sizeof(tgp_gemm_args),offsetof(tgp_gemm_args,M),offsetof(tgp_gemm_args,rowbias),' \
           'offsetof(tgp_gemm_args,slope),offsetof(tgp_gemm_args,ldcm),offsetof(tgp_gemm_args,c_col0),' \
-          'offsetof(tgp_gemm_args,batch_stride_colmax));return 0;}\n'
+          'offsetof(tgp_gemm_args,batch_stride_colmax),offsetof(tgp_gemm_args,A_planes),offsetof(tgp_gemm_args,a_amax),' \
+          'offsetof(tgp_gemm_args,cp_col0),offsetof(tgp_gemm_args,pp_config));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
     G = _lib.GemmArgs
     assert [int(x) for x in out] == [ctypes.sizeof(G), G.M.offset, G.rowbias.offset, G.slope.offset, G.ldcm.offset,
-                                     G.c_col0.offset, G.batch_stride_colmax.offset]
+                                     G.c_col0.offset, G.batch_stride_colmax.offset, G.A_planes.offset, G.a_amax.offset,
+                                     G.cp_col0.offset, G.pp_config.offset]
 
 
 def test_fused_kernel_arg_structs_match_header_layout():
@@ -258,6 +263,32 @@ def test_bucketed_overlapped_gradient_exchange_two_ranks_gloo():
             assert torch.allclose(a, base + 2.0) and torch.allclose(b, base + 4.0)
             continue
         assert torch.allclose(a, base + 1.5 * (i + 1)) and torch.equal(a, b), i
+
+
+def test_bench_self_launch_builds_rank_environments_and_propagates_failure(capfd):
+    """`python bench.py --gpus N` without a launcher starts its ranks as child processes (bench.self_launch): each child gets the
+    environment torch.distributed.run would give it, rank 0's output is relayed, and one failing rank fails the call (and stops the
+    others).  CPU-only: the children here are one-line Python programs, not the bench."""
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    env = bench.rank_env(3, 8, 29511, base={"PATH": "/bin"})
+    assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], env["MASTER_ADDR"], env["MASTER_PORT"]) == ("3", "3", "8", "127.0.0.1", "29511")
+    assert env["PATH"] == "/bin" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    ok = [sys.executable, "-c", "import os, json; r = int(os.environ['RANK']); w = int(os.environ['WORLD_SIZE']);"
+          "assert os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0;"
+          "print(json.dumps({'rank': r, 'world': w}))"]
+    assert bench.self_launch(3, cmd=ok) == 0
+    out = capfd.readouterr().out.strip().splitlines()
+    assert out == ['{"rank": 0, "world": 3}']                    # only rank 0's line is relayed
+    # rank 1 fails at once; ranks 0 and 2 would run for a minute: the call returns rank 1's code quickly, the others are stopped
+    bad = [sys.executable, "-c", "import os, sys, time; r = int(os.environ['RANK']);\n"
+           "if r == 1: sys.exit(7)\ntime.sleep(60)"]
+    t0 = time.time()
+    assert bench.self_launch(3, cmd=bad) == 7
+    assert time.time() - t0 < 30
+    assert capfd.readouterr().out == ""                          # no JSON line from a failed job
 
 
 def test_input_side_host_packing_and_category_tables():

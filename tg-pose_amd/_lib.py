@@ -40,6 +40,10 @@ class GemmArgs(ctypes.Structure):
         ("gres2", c_vp), ("ldg2", c_int), ("gidx2", c_vp),
         ("epilogue", c_int), ("pred", c_vp),
         ("row_base", c_int),
+        ("A_planes", c_vp), ("a_kt", c_int), ("a_amax", c_vp),
+        ("W_planes", c_vp), ("w_kt", c_int),
+        ("C_planes", c_vp), ("c_kt", c_int), ("cp_col0", c_int), ("c_amax", c_vp),
+        ("pp_config", c_int),
     ]
 
 
@@ -97,6 +101,9 @@ SIGNATURES = {
     "tgp_fill_tail": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
     "tgp_split_bf16": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     "tgp_split_f16": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),
+    "tgp_planes_bytes": (c_i64, [c_i64, c_int]),
+    "tgp_planes_split": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
+    "tgp_planes_gather": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
     "tgp_gemm_tn_workspace_floats": (c_i64, [c_i64, c_int, c_int]),
     "tgp_gemm_tn_f32": (c_int, [c_vp, c_int, c_vp, c_int, c_i64, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
     "tgp_bw_workspace_floats": (c_i64, [c_i64, c_int]),
@@ -177,7 +184,7 @@ SIGNATURES = {
     "tgp_cloud_sample": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, ctypes.c_uint64, c_vp, c_vp]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

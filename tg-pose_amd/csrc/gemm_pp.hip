@@ -1,0 +1,347 @@
+// fp32-accurate GEMM on the fp16 matrix cores with BOTH operands pre-split (round 4).
+//
+// gemm.hip's split kernels take the activations as fp32 and split them into fp16 hi / lo planes while they are staged into LDS:
+// ~45 vector instructions per wave and K-step beside 12 MFMAs, through a ring of prefetch registers that pins the kernel at its
+// 128-VGPR cap.  Here the producer of an activation (a GEMM epilogue, the row gather, tgp_planes_split) has already written the
+// two planes -- a deterministic function of the fp32 value, so every product below equals the one the in-loop split feeds the
+// matrix cores -- in a BLOCKED layout made for LDS-DMA:
+//
+//     chunk (rb = row / 32, kt = k / 16), 2 KB:  [plane: hi | lo][h = (k % 16) / 8][r = row % 32][8 fp16]
+//
+// One plane of a chunk is 1 KB, contiguous in memory, and in exactly the order in which the 64 lanes of a
+// v_mfma_f32_32x32x16_f16 hold it (lane = 32 h + r supplies row r, k = 8 h .. 8 h + 7): one global_load_lds_dwordx4 per wave moves
+// it into LDS as it lies, and the fragment read is ds_read_b128 at base + 16 * lane -- linear, conflict-free, no padding, no
+// swizzle.  No VGPR staging, no conversion in the loop: the K loop is DMA issue, fragment reads and MFMAs.
+//
+// Arithmetic: per 32 x 32 output block, K-tiles ascending, per K-tile the three terms A_hi W_lo, A_lo W_hi, A_hi W_hi -- the
+// sequence of gemm_split_tile<..., F16> -- so results are bit-identical to that kernel whatever the tile shape
+// (tests/test_gpu_parity.py::test_gemm_pp_bit_identical_to_split_kernel).
+#include "gemm_epi.h"
+
+#define PP_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(0x0f70 | ((N) & 15) | (((N) >> 4) << 14))
+
+template <int BM, int BN, int NWM, int NWN, int KTS, int STAGES>
+__device__ __forceinline__ void gemm_pp_tile(const GemmParams &p, const int m0, const int n0, char *smem)
+{
+    constexpr int NW = NWM * NWN;
+    constexpr int WTM = BM / NWM, WTN = BN / NWN, TM = WTM / 32, TN = WTN / 32;
+    constexpr int ABLK = BM / 32, WBLK = BN / 32;
+    constexpr int NCH = (ABLK + WBLK) * KTS * 2;           // 1 KB pieces per stage: [A blocks | W blocks][K-tile of the step][plane]
+    constexpr int NI = NCH / NW;                           // LDS-DMA instructions per wave and step
+    constexpr int STAGE_BYTES = NCH * 1024;
+    constexpr int D = STAGES - 1;                          // steps of prefetch
+    static_assert(NCH % NW == 0 && STAGES >= 2 && STAGES <= 3, "piece / wave mapping");
+    static_assert(STAGES * STAGE_BYTES >= NW * 4096, "the epilogue turns blocks through 4 KB per wave");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int r = lane & 31, h = lane >> 5;
+    const int KT = (p.K + 15) >> 4;
+    const int numS = (KT + KTS - 1) / KTS;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fp16 range guard, decided per tile from what the PRODUCER of the planes recorded (bits of max |a| per 32-row block): a
+    // tile holding a magnitude >= 65504 (or a NaN), or nothing at or above 2^-4, is computed in exact fp32 from the fp32 copy
+    // of the operand -- the same rule, tile by tile, as gemm_split_tile's in-loop guard.
+    bool exact = false;
+    if (p.a_amax) {
+        uint32_t am = 0u;
+        const int nblk = (p.M + 31) >> 5;
+#pragma unroll
+        for (int i = 0; i < ABLK; ++i) {
+            const int rb = (m0 >> 5) + i;
+            const uint32_t v = rb < nblk ? p.a_amax[rb] : 0u;
+            am = v > am ? v : am;
+        }
+        exact = am >= 0x477fe000u || (am != 0u && am < 0x3d800000u);       // >= 65504 | all below 2^-4 (and not all zero)
+    }
+    if (!exact) {
+        // ---- staging: piece c = j * NW + wave of a stage is this wave's j-th instruction
+        const int a_blocks = (p.M + 31) >> 5, w_blocks = (p.N + 31) >> 5;
+        const char *cbase[NI];
+        int ct[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int c = j * NW + wave, plane = c & 1, t = (c >> 1) % KTS, ob = (c >> 1) / KTS;
+            const char *base;
+            if (ob < ABLK) {
+                const int rb = min((m0 >> 5) + ob, a_blocks - 1);          // blocks past the end re-read the last one (never stored)
+                base = p.Ap + (int64_t)rb * p.a_kt * 2048;
+            } else {
+                const int nb = min((n0 >> 5) + ob - ABLK, w_blocks - 1);
+                base = p.Wp + (int64_t)nb * p.w_kt * 2048;
+            }
+            cbase[j] = base + plane * 1024 + lane * 16;
+            ct[j] = t;
+        }
+        const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem + wave * 1024);
+        auto dma = [&](const int s, const int stage) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int kt = min(s * KTS + ct[j], KT - 1);               // a K-tile past the end: any valid piece (its MFMAs are skipped)
+                const char *src = cbase[j] + (int64_t)kt * 2048;
+                const uint32_t lds = lds0 + stage * STAGE_BYTES + j * NW * 1024;
+                // inline assembly: opaque to the compiler's counters, so no vmcnt(0) appears before the fragment reads that
+                // follow; the waits are written by hand below (as in heads_fused.hip)
+                asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "{m0}"(lds) : "memory");
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d < numS) dma(d, d);
+        for (int s = 0; s < numS; ++s) {
+            // step s's pieces have landed (this wave's; after the barrier everybody's), and everybody has finished reading the
+            // stage that step s + D is about to overwrite (it held step s - 1)
+            if (D == 1 || s + 1 >= numS) PP_WAIT_VM(0);
+            else PP_WAIT_VM(NI);
+            __builtin_amdgcn_s_barrier();
+            if (s + D < numS) dma(s + D, (s + D) % STAGES);
+            const char *st = smem + (s % STAGES) * STAGE_BYTES + lane * 16;
+#pragma unroll
+            for (int t = 0; t < KTS; ++t) {
+                if (KTS > 1 && s * KTS + t >= KT) break;                   // workgroup-uniform
+                uint4 a[TM][2];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        a[i][q] = *reinterpret_cast<const uint4 *>(st + (((wm * TM + i) * KTS + t) * 2 + q) * 1024);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    uint4 b[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        b[q] = *reinterpret_cast<const uint4 *>(st + (((ABLK + wn * TN + j) * KTS + t) * 2 + q) * 1024);
+                    // smallest terms first, as in gemm_split_tile: hi x lo, lo x hi, hi x hi; consecutive MFMAs walk the column's accumulators
+#define PP_TERM(QA, QB)                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                     \
+        __builtin_bit_cast(f16x8, a[i][QA]), __builtin_bit_cast(f16x8, b[QB]), acc[i][j], 0, 0, 0);
+                    PP_TERM(0, 1)
+                    PP_TERM(1, 0)
+                    PP_TERM(0, 0)
+#undef PP_TERM
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();                                      // every fragment read is done: the stages become epilogue scratch
+    } else {
+        // exact fp32 recomputation straight from global memory (v_mfma_f32_32x32x2_f32; lane (r, h) supplies k = 8 t + 4 h + s to
+        // sub-step s of the 8-wide group t), same accumulator layout: gemm_split_tile's fallback
+        const float *ag[TM], *wg[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = m0 + wm * WTM + i * 32 + r;
+            ag[i] = p.A + (int64_t)(row < p.M ? row : p.M - 1) * p.lda + 4 * h;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WTN + j * 32 + r;
+            wg[j] = p.W + (int64_t)(col < p.N ? col : p.N - 1) * p.ldw + 4 * h;
+        }
+#pragma unroll 1
+        for (int k0 = 0; k0 < p.K; k0 += 8) {
+            const bool ok = k0 + 4 * h < p.K;
+            float4 av[TM], wv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = ok ? *reinterpret_cast<const float4 *>(ag[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wv[j] = ok ? *reinterpret_cast<const float4 *>(wg[j] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, wv[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, wv[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, wv[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, wv[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    if (p.c_scale && !exact) {                     // a pre-scaled weight (ops.split_w); the exact path used the unscaled operands
+        const float cs = p.c_scale[0];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] *= cs;
+    }
+    // (one instance whose planes output is a run-time branch: two inlined instances spilled 73 registers at the 128-register shapes)
+    gemm_epilogue_lds<TM, TN, WTM, WTN, true>(p, acc, m0, n0, 0, wm, wn, r, h, reinterpret_cast<float *>(smem) + wave * 1024);
+}
+
+// Workgroups are dealt round-robin to the 8 XCDs; the remap gives each XCD a contiguous range of tiles (N fastest), so the tiles
+// that share A rows meet in one L2 (bijective for any tile count).
+__device__ __forceinline__ int pp_xcd_remap(const int b, const int n)
+{
+    const int q = n >> 3, rr = n & 7, x = b & 7;
+    return (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + (b >> 3);
+}
+
+template <int BM, int BN, int NWM, int NWN, int KTS, int STAGES, int WPE>
+__global__ __launch_bounds__(64 * NWM * NWN, WPE) void gemm_pp_kernel(GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(1024))) char pp_smem[];
+    if (p.pred && *p.pred == 0) return;
+    const int L = pp_xcd_remap((int)blockIdx.x, p.pp_tiles_m * p.pp_tiles_n);
+    gemm_pp_tile<BM, BN, NWM, NWN, KTS, STAGES>(p, (L / p.pp_tiles_n) * BM, (L % p.pp_tiles_n) * BN, pp_smem);
+}
+
+// ---- fp32 rows -> blocked planes (weights at pack time; activations whose producer does not write planes itself), optionally
+// through a row gather (dst[b][p] = src[b][idx[b][p]], the factored layers' row order: engine.encoder_forward) that also leaves
+// the fp32 copy -- one pass over the rows instead of a gather and a split
+__global__ __launch_bounds__(256) void planes_split_kernel(const float *__restrict__ X, int rows, int K, int ld, char *__restrict__ out,
+                                                           int kts, uint32_t *__restrict__ amax, const int32_t *__restrict__ idx,
+                                                           int n_src, int n_out, float *__restrict__ dst, int ldd, int ccopy)
+{
+    // thread = (row block rb, K-tile kt, half h, row r): one 16-byte piece of each plane; a wave covers both halves of one (rb, kt)
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nblk = (rows + 31) >> 5;
+    if (t >= (int64_t)nblk * kts * 64) return;              // (whole waves: the grid is a multiple of 64 threads)
+    const int r = (int)(t & 31), h = (int)((t >> 5) & 1);
+    const int kt = (int)((t >> 6) % kts), rb = (int)((t >> 6) / kts);
+    const int row = rb * 32 + r, k0 = kt * 16 + h * 8;
+    int64_t srow = row;
+    if (idx && row < rows) srow = (int64_t)(row / n_out) * n_src + idx[row];
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (row < rows && k0 + e < ld) ? X[srow * ld + k0 + e] : 0.f;
+    if (dst && row < rows) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (k0 + e < ccopy) dst[(int64_t)row * ldd + k0 + e] = v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = k0 + e < K ? v[e] : 0.f;          // columns K .. ld - 1 are not the caller's to define
+    uint2 h0, l0, h1, l1;
+    split2(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
+    split2(make_float4(v[4], v[5], v[6], v[7]), h1, l1);
+    char *o = out + ((int64_t)rb * kts + kt) * 2048 + h * 512 + r * 16;
+    *reinterpret_cast<uint4 *>(o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    *reinterpret_cast<uint4 *>(o + 1024) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    if (amax) {
+        uint32_t m = 0u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t b = __float_as_uint(v[e]) & 0x7fffffffu;
+            m = b > m ? b : m;
+        }
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const uint32_t o2 = (uint32_t)__shfl_xor((int)m, s);
+            m = o2 > m ? o2 : m;
+        }
+        if ((threadIdx.x & 63) == 0 && m) atomicMax(amax + rb, m);
+    }
+}
+
+extern "C" int64_t tgp_planes_bytes(int64_t rows, int K)
+{
+    if (rows <= 0 || K <= 0) return 0;
+    return ((rows + 31) / 32) * ((K + 15) / 16) * 2048;
+}
+
+extern "C" int tgp_planes_split(const float *X, int rows, int K, int ld, void *out, int kts, uint32_t *amax, tgp_stream_t stream)
+{
+    TGP_REQUIRE(X && out && rows > 0 && K > 0 && ld >= K && kts >= (K + 15) / 16);
+    TGP_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    const int64_t threads = (int64_t)((rows + 31) / 32) * kts * 64;
+    hipLaunchKernelGGL(planes_split_kernel, dim3(tgp_cdiv(threads, 256)), dim3(256), 0, tgp_hs(stream), X, rows, K, ld,
+                       reinterpret_cast<char *>(out), kts, amax, nullptr, 0, 0, nullptr, 0, 0);
+    return TGP_LAUNCH_RESULT();
+}
+
+extern "C" int tgp_planes_gather(const float *src, int lds, const int32_t *idx, int B, int n_src, int n_out, int K, int C, float *dst,
+                                 int ldd, void *out, int kts, uint32_t *amax, tgp_stream_t stream)
+{
+    TGP_REQUIRE(src && idx && out && B > 0 && n_src > 0 && n_out > 0 && K > 0 && C >= K && lds >= C && kts >= (K + 15) / 16);
+    TGP_REQUIRE(!dst || ldd >= C);
+    TGP_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0 && (int64_t)B * n_out < (1ll << 31));
+    const int rows = B * n_out;
+    // (columns [K, C) travel in the fp32 copy only; the K-tiles must cover them so that every column of the copy is visited)
+    TGP_REQUIRE(!dst || kts * 16 >= C);
+    const int64_t threads = (int64_t)((rows + 31) / 32) * kts * 64;
+    hipLaunchKernelGGL(planes_split_kernel, dim3(tgp_cdiv(threads, 256)), dim3(256), 0, tgp_hs(stream), src, rows, K, lds,
+                       reinterpret_cast<char *>(out), kts, amax, idx, n_src, n_out, dst, ldd, C);
+    return TGP_LAUNCH_RESULT();
+}
+
+// ---- launch
+// config: 1 = 256 x 256 on 8 waves (128 x 64 wave tiles), 32-wide steps, 2 stages (128 KB): one workgroup per CU
+//         2 = 256 x 256 on 16 waves (64 x 64), 32-wide steps, 2 stages
+//         3 = 256 x 128 on 8 waves (64 x 64), 16-wide steps, 3 stages (72 KB): two workgroups per CU
+//         4 = 128 x 128 on 4 waves (64 x 64), 16-wide steps, 2 stages (32 KB): four workgroups per CU
+//         5 = 64 x 128 on 4 waves (32 x 64), 16-wide steps, 2 stages (24 KB): the few-tile launches
+//         6 = 128 x 128 on 4 waves, 32-wide steps, 2 stages (64 KB): two workgroups per CU
+//         7 = 128 x 256 on 8 waves (64 x 64), 16-wide steps, 3 stages (72 KB): two workgroups per CU
+template <int BM, int BN, int NWM, int NWN, int KTS, int STAGES, int WPE>
+static int pp_launch(GemmParams &p, hipStream_t stream)
+{
+    constexpr int lds = STAGES * ((BM + BN) / 32) * KTS * 2 * 1024;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp_kernel<BM, BN, NWM, NWN, KTS, STAGES, WPE>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    p.pp_tiles_m = tgp_cdiv(p.M, BM), p.pp_tiles_n = tgp_cdiv(p.N, BN);
+    hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, NWM, NWN, KTS, STAGES, WPE>), dim3(p.pp_tiles_m * p.pp_tiles_n), dim3(64 * NWM * NWN),
+                       lds, stream, p);
+    return TGP_LAUNCH_RESULT();
+}
+
+static int pp_cus(void)
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus <= 0)
+            cus = 256;
+    }
+    return cus;
+}
+
+// the library's choice of tile shape for a launch (0 in tgp_gemm_args.pp_config)
+static int pp_auto_config(const GemmParams &p)
+{
+    const int64_t cus = pp_cus();
+    const int64_t t256 = (int64_t)tgp_cdiv(p.M, 256) * tgp_cdiv(p.N, 256);
+    const int64_t t128 = (int64_t)tgp_cdiv(p.M, 128) * tgp_cdiv(p.N, 128);
+    if (t128 * 10 < 3 * 4 * cus) return 5;                 // fewer than ~0.3 rounds of the 128 x 128 tiles at four per CU
+    if (t256 < 2 * cus) return 4;
+    return 1;
+}
+
+int tgp_launch_gemm_pp(GemmParams &p, int config, hipStream_t stream)
+{
+    TGP_REQUIRE(p.Ap && p.Wp && p.batch == 1 && !p.ksplit && !p.a_scale);
+    TGP_REQUIRE(p.a_kt >= (p.K + 15) / 16 && p.w_kt >= (p.K + 15) / 16);
+    TGP_REQUIRE(!p.a_amax || (p.A && p.W));                 // the guard's exact path reads the fp32 operands
+    if (!config) config = pp_auto_config(p);
+    // the epilogue keeps two objects per wave tile: its per-object bias / max over points need rows_per_obj >= the wave tile's rows
+    if (p.rowbias || p.cm) {
+        TGP_REQUIRE(p.rows_per_obj >= 32);
+        if (p.rows_per_obj < 64) config = 5;
+        else if (p.rows_per_obj < 128 && config == 1) config = 4;
+    }
+    switch (config) {
+    case 1: return pp_launch<256, 256, 2, 4, 2, 2, 2>(p, stream);
+    case 2: return pp_launch<256, 256, 4, 4, 2, 2, 4>(p, stream);
+    case 3: return pp_launch<256, 128, 4, 2, 1, 3, 4>(p, stream);
+    case 4: return pp_launch<128, 128, 2, 2, 1, 2, 4>(p, stream);
+    case 5: return pp_launch<64, 128, 2, 2, 1, 2, 4>(p, stream);
+    case 6: return pp_launch<128, 128, 2, 2, 2, 2, 2>(p, stream);
+    case 7: return pp_launch<128, 256, 2, 4, 1, 3, 4>(p, stream);
+    default: return TGP_EINVAL;
+    }
+}

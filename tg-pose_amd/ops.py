@@ -263,6 +263,7 @@ def fill_tail(obj_id, xyz_c, feat, col0, n_cls):
 #   "fp32"     always the fp32 MFMA kernels
 # split_w() packs weights for the mode current at pack time; gemm() reads the kind off the packed tensor's shape.
 GEMM_MODE = "split16"
+PLANES = os.environ.get("TGP_PLANES", "1") != "0"     # activations also as fp16 planes, consumers on the pre-split kernel (split16 mode)
 
 
 FP16_SAFE = 32768.0          # |w| at or above this is pre-scaled before the fp16 split (fp16's largest finite value is 65504)
@@ -312,6 +313,70 @@ def split_bf16(W):
     return out
 
 
+class Planes(object):
+    """A (rows, K) fp32 matrix as BLOCKED fp16 hi / lo planes (include/tgpose.h, tgp_gemm_args.A_planes): what the pre-split GEMM
+    kernel (csrc/gemm_pp.hip) stages by LDS-DMA.  buf: uint8 (ceil(rows / 32), kt, 2048); amax: int32 (ceil(rows / 32),) bits of the
+    largest magnitude per row block (the fp16 range guard of the consumer), or None for weights (checked once at pack time)."""
+
+    __slots__ = ("buf", "amax", "rows", "K", "kt", "tgp_unscale")
+
+    def __init__(self, rows, K, device, kt=None, amax=True, buf=None, amax_buf=None):
+        self.rows, self.K = int(rows), int(K)
+        self.kt = int(kt) if kt is not None else (self.K + 15) // 16
+        nblk = (self.rows + 31) // 32
+        self.buf = buf if buf is not None else torch.empty(nblk, self.kt, 2048, device=device, dtype=torch.uint8)
+        self.amax = (amax_buf if amax_buf is not None else torch.zeros(nblk, device=device, dtype=torch.int32)) if amax else None
+        self.tgp_unscale = None
+
+    def to_float(self):
+        """(tests) the fp32 matrix hi + lo the planes stand for, (rows, K)"""
+        nblk = self.buf.shape[0]
+        h = self.buf.view(torch.float16).view(nblk, self.kt, 2, 2, 32, 8).float()      # [rb][kt][plane][h][r][8]
+        x = (h[:, :, 0] + h[:, :, 1]).permute(0, 3, 1, 2, 4).reshape(nblk * 32, self.kt * 16)
+        return x[: self.rows, : self.K]
+
+
+def planes_on():
+    """activations also travel as fp16 planes and their consumers run on the pre-split kernel (the default arithmetic only)"""
+    return PLANES and GEMM_MODE == "split16"
+
+
+@_timed("graph")
+def planes_split(X, K=None, kt=None, amax=True, out=None):
+    """X (..., K) fp32 rows (row stride >= K) -> Planes (tgp_planes_split).  Weights at pack time (amax=False), activations whose
+    producer does not write planes itself."""
+    X, ld = _rows(X, "X")
+    K = X.shape[-1] if K is None else K
+    rows = math.prod(X.shape[:-1])
+    P = out if out is not None else Planes(rows, K, X.device, kt=kt, amax=amax)
+    check(_lib.lib().tgp_planes_split(_p(X), rows, K, ld, _p(P.buf), P.kt, _p(P.amax), _stream(X)), "tgp_planes_split")
+    return P
+
+
+@_timed("graph")
+def planes_gather(src, idx, dst, K, planes):
+    """gather_rows(src, idx, dst) that also writes the planes of the gathered rows' first K columns (tgp_planes_gather)"""
+    src, lds = _rows(_f32(src, "src", 3), "src")
+    dst, ldd = _rows(_f32(dst, "dst", 3), "dst")
+    B, n_src, C = src.shape
+    n_out = dst.shape[1]
+    check(_lib.lib().tgp_planes_gather(_p(src), lds, _p(_i32(idx, "idx")), B, n_src, n_out, K, C, _p(dst), ldd, _p(planes.buf),
+                                       planes.kt, _p(planes.amax), _stream(src)), "tgp_planes_gather")
+    return dst
+
+
+def planes_w(W):
+    """pack-time planes of a weight (N, K) for the pre-split kernel, with split_w's range rule: a weight that reaches 2^15 is split
+    as W * 2^-k and the power of two rides along as .tgp_unscale (c_scale of the launch)."""
+    amax = float(W.detach().abs().max()) if W.numel() else 0.0
+    if not (amax >= FP16_SAFE) or not math.isfinite(amax):
+        return planes_split(W.contiguous(), amax=False)
+    k = math.frexp(amax)[1] - 15
+    P = planes_split((W * (2.0 ** -k)).contiguous(), amax=False)
+    P.tgp_unscale = torch.full((1,), 2.0 ** k, device=W.device, dtype=torch.float32)
+    return P
+
+
 # bench.py sets this to a list to time, with HIP events on the launch stream, every launch that the
 # library routes to its 128x128-tile MFMA kernel (same rule as tgp_gemm_f32 in csrc/gemm.hip).
 GEMM_TIMER = None
@@ -344,12 +409,13 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
          rows_per_obj=0, res1=None, ldr1=0, res2=None, ldr2=0, scale=None, shift=None, act=0, slope=0.0,
          colmax_keys=None, k_alg=None, slope_vec=None, cm_cols=0, c_col0=0, batch=1, batch_strides=None, w_split=None,
          a_scale=None, c_scale=None, ksplit_chunk=0, gather1=None, gather2=None, flops_ref=None, epilogue=0, pred=None,
-         row_base=0):
+         row_base=0, a_planes=None, w_planes=None, c_planes=None, cp_col0=0, pp_config=0):
     """Raw call into tgp_gemm_f32.  A/W/C/res* are tensors whose data_ptr is the first element of the
     operand (views into wider buffers are fine); all sizes/strides are explicit.  k_alg: the layer's
     true input width when K includes zero padding (only used for FLOP accounting in bench.py)."""
     split16 = w_split is not None and GEMM_MODE != "fp32" and w_split.shape[-2] == 2 and not ksplit_chunk
-    timed = GEMM_TIMER is not None and pred is None and (GEMM_TIMER_ALL or _routes_to_big_tile(M, N, batch, split16))   # (a predicated
+    pp = a_planes is not None and w_planes is not None and GEMM_MODE == "split16" and PLANES
+    timed = GEMM_TIMER is not None and pred is None and (GEMM_TIMER_ALL or pp or _routes_to_big_tile(M, N, batch, split16))   # (a predicated
     # launch is a repair path that normally does nothing: it has no place in a FLOP rate)
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -373,8 +439,10 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
         a.W_split, a.ldws = _p(w_split), w_split.shape[-3] * 16
         a.w_split_kind = 1 if w_split.shape[-2] == 2 else 0
         unscale = getattr(w_split, "tgp_unscale", None)       # a weight that was pre-scaled into fp16's range (split_w)
-        if unscale is not None and _routes_to_big_tile(M, N, batch, split16):
+        if unscale is not None and not pp and _routes_to_big_tile(M, N, batch, split16):
             c_scale = unscale if c_scale is None else c_scale * unscale
+    if pp and w_planes.tgp_unscale is not None:
+        c_scale = w_planes.tgp_unscale if c_scale is None else c_scale * w_planes.tgp_unscale
     a.a_scale, a.c_scale, a.ksplit_chunk = _p(a_scale), _p(c_scale), int(ksplit_chunk)
     if gather1 is not None:                      # (rows tensor whose data_ptr is the first column wanted, row stride, int32 row ids)
         a.gres1, a.ldg1, a.gidx1 = _p(gather1[0]), int(gather1[1]), _p(gather1[2])
@@ -383,6 +451,12 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
     a.epilogue = int(epilogue)
     a.pred = _p(pred)
     a.row_base = int(row_base)
+    if pp:                                       # both operands as blocked fp16 planes: the pre-split kernel (bit-identical results)
+        a.A_planes, a.a_kt, a.a_amax = _p(a_planes.buf), a_planes.kt, _p(a_planes.amax)
+        a.W_planes, a.w_kt = _p(w_planes.buf), w_planes.kt
+        a.pp_config = int(pp_config)
+    if c_planes is not None and GEMM_MODE == "split16" and PLANES:
+        a.C_planes, a.c_kt, a.cp_col0, a.c_amax = _p(c_planes.buf), c_planes.kt, int(cp_col0), _p(c_planes.amax)
     check(_lib.lib().tgp_gemm_f32(ctypes.byref(a), _stream(A)), "tgp_gemm_f32")
     if timed:
         e1.record(torch.cuda.current_stream(A.device))
@@ -394,7 +468,7 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
 
 def linear_rows(x, weight, bias=None, scale=None, shift=None, act=0, slope=0.0, out=None, rowbias=None,
                 rows_per_obj=0, res1=None, res2=None, colmax_keys=None, want_out=True, k_alg=None, w_split=None,
-                a_scale=None, c_scale=None, flops_ref=None):
+                a_scale=None, c_scale=None, flops_ref=None, a_planes=None, w_planes=None, c_planes=None, cp_col0=0):
     """x (..., K) rows (row stride >= K), weight (N, Kw>=K) -> (..., N).  Convenience over gemm()."""
     x, lda = _rows(x, "x")
     weight, ldw = _rows(weight, "weight")
@@ -414,7 +488,8 @@ def linear_rows(x, weight, bias=None, scale=None, shift=None, act=0, slope=0.0, 
         r2, l2 = _rows(res2, "res2")
     gemm(x, weight, out if want_out else None, M=M, N=N, K=K, lda=lda, ldw=ldw, ldc=ldc, bias=bias, rowbias=rowbias,
          rows_per_obj=rows_per_obj, res1=r1, ldr1=l1, res2=r2, ldr2=l2, scale=scale, shift=shift, act=act, slope=slope,
-         colmax_keys=colmax_keys, k_alg=k_alg, w_split=w_split, a_scale=a_scale, c_scale=c_scale, flops_ref=flops_ref)
+         colmax_keys=colmax_keys, k_alg=k_alg, w_split=w_split, a_scale=a_scale, c_scale=c_scale, flops_ref=flops_ref,
+         a_planes=a_planes, w_planes=w_planes, c_planes=c_planes, cp_col0=cp_col0)
     return out
 
 
