@@ -221,6 +221,9 @@ int tgp_split_f16(const float *W, int rows, int K, int ld, uint16_t *out, int ld
  * whose producer does not write planes itself. */
 int64_t tgp_planes_bytes(int64_t rows, int K);
 int tgp_planes_split(const float *X, int rows, int K, int ld, void *out, int kts, uint32_t *amax, tgp_stream_t stream);
+/* the same into a column range of a wider planes buffer: X's K columns land at plane columns col0 .. col0 + K - 1 (col0 % 16 == 0;
+ * only those ceil(K / 16) K-tiles of each row block are written, the last one zero padded) */
+int tgp_planes_split_cols(const float *X, int rows, int K, int ld, void *out, int kts, int col0, uint32_t *amax, tgp_stream_t stream);
 /* tgp_gather_rows and tgp_planes_split in one pass: dst[b][p][0..C) = src[b][idx[b][p]][0..C) (dst may be NULL) and the planes of
  * the gathered rows' first K columns (columns K.. of the planes zero); kts * 16 >= C when dst is given. */
 int tgp_planes_gather(const float *src, int lds, const int32_t *idx, int B, int n_src, int n_out, int K, int C, float *dst, int ldd,

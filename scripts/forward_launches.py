@@ -1,0 +1,25 @@
+"""One eval forward's kernel launches, in order, from a rocprofv3 kernel trace of serial eager forwards
+(`rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --graph 0 --streams 1
+--no-branch-streams --min-seconds 0`): the last forward of the trace, from its center_mean_kernel to its head_post_kernel.
+usage: python scripts/forward_launches.py <kernel_trace.csv> [out.txt]"""
+import csv
+import sys
+
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("center_mean_kernel")]
+ends = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("head_post_kernel")]
+i1 = ends[-1]
+i0 = max(i for i in starts if i < i1)
+fwd = rows[i0:i1 + 1]
+t0 = int(fwd[0]["Start_Timestamp"])
+out = open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout
+print(" start us   dur us  kernel  [grid x workgroup]", file=out)
+tot = 0.0
+for r in fwd:
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    tot += d
+    name = r["Kernel_Name"]
+    name = name[:name.index("(")] if "(" in name else name
+    print("%9.1f %8.1f  %s  [%s x %s]" % ((int(r["Start_Timestamp"]) - t0) / 1e3, d, name[:90], r.get("Grid_Size", r.get("Grid_Size_X", "?")),
+                                           r.get("Workgroup_Size", r.get("Workgroup_Size_X", "?"))), file=out)
+print("\nlaunches: %d   kernel time: %.1f us" % (len(fwd), tot), file=out)

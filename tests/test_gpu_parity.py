@@ -1233,8 +1233,8 @@ def test_backward_full_network_vs_oracle_autograd(ops, B, N, seed, gemm_mode):
     Metric: relative L2 error per parameter <= 3 %.  The network's gradient is discontinuous wherever a ReLU input or a
     max over neighbours / points changes sign or winner, and two fp32 evaluations whose forward activations differ by 1e-6
     disagree on a handful of those ~1e5 decisions per layer; each flip moves one activation's gradient by O(1).  torch's
-    own fp32 GPU ops against its fp64 ops show the same size of deviation on this network (scripts/debug_grad3.py: up to
-    17 % in the max norm at one BatchNorm input, 1-5 % in the weights downstream), so a max-norm bound would test the coin
+    own fp32 GPU ops against its fp64 ops show the same size of deviation on this network (measured in round 1 with a script
+    since deleted: up to 17 % in the max norm at one BatchNorm input, 1-5 % in the weights downstream), so a max-norm bound would test the coin
     flips, not the kernels.  The kernels themselves are checked tightly (1e-4 .. 1e-6) where no such decision separates
     the two sides: test_gemm_tn_vs_fp64, test_bn_backward_vs_autograd, test_pooled_bn_backward_vs_autograd,
     test_hs_layer_backward_vs_oracle_autograd, test_surface_layer_backward_vs_oracle_autograd,
@@ -1571,9 +1571,39 @@ def test_eval_outputs_only_returns_the_same_six_outputs(ops):
             lean = net(g(pts), g(obj), sample_idx=sample)
         finally:
             engine.EVAL_OUTPUTS_ONLY = False
-    assert set(full) == set(lean) == {"p_green_R", "p_red_R", "f_green_R", "f_red_R", "Pred_T", "Pred_s"}
+        per_call = net(g(pts), g(obj), sample_idx=sample, eval_outputs_only=True)     # the evaluation driver's form: nothing global moves
+        assert engine.EVAL_OUTPUTS_ONLY is False and getattr(net, "eval_outputs_only", None) is None
+    assert set(full) == set(lean) == set(per_call) == {"p_green_R", "p_red_R", "f_green_R", "f_red_R", "Pred_T", "Pred_s"}
     for k in full:
-        assert torch.equal(full[k], lean[k]), k
+        assert torch.equal(full[k], lean[k]) and torch.equal(full[k], per_call[k]), k
+
+
+def test_eval_outputs_only_with_a_prescaled_weight(ops):
+    """A weight that reaches 2^15 is packed pre-scaled and carries its power of two as a Python attribute (ops.split_w): the lean
+    forward slices the packed coarse operands to the heads' rows and must keep that attribute (round-3 advisor: plain slicing
+    dropped it and the coarse products came out 2^k too small).  The heads' conv1 rows of the level-1 coarse weight are scaled
+    to 1e5 here (and conv1's BatchNorm scale down by the same factor, so activations stay sane): lean == full, bit for bit."""
+    from tgpose_amd import PoseNet9D, seeded_state_dict, engine
+    sd = seeded_state_dict(4)
+    w = sd["rot_green.conv1.weight"].clone()
+    factor = float(4e5 / w[:8, 300:310].abs().max())
+    w[:8, 300:310] *= factor
+    sd["rot_green.conv1.weight"] = w
+    sd["rot_green.bn1.weight"] = sd["rot_green.bn1.weight"].clone()
+    sd["rot_green.bn1.weight"][:8] /= factor
+    net = PoseNet9D()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    pk = net.packed(DEV)
+    assert getattr(pk.fact["Wb_s"], "tgp_unscale", None) is not None and pk.fact["w2p"] is not None
+    pts, obj = synth_points(2, 1028, 10)
+    torch.manual_seed(2)
+    sample = engine.draw_sample_idx(1028)
+    with torch.no_grad():
+        full = net(g(pts), g(obj), sample_idx=sample)
+        lean = net(g(pts), g(obj), sample_idx=sample, eval_outputs_only=True)
+    for k in full:
+        assert torch.isfinite(full[k]).all() and torch.equal(full[k], lean[k]), k
 
 
 @pytest.mark.parametrize("gemm_mode", ["fp32"], indirect=True)
@@ -2037,8 +2067,8 @@ def test_graphed_backward_refuses_a_live_eager_graph(ops):
             loss = gb(sample_idx=sample).item()
             runs.append((loss, {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
         assert runs[0][0] == runs[1][0] and not gb.loss.requires_grad
-        for k, v in runs[0][1].items():                       # the float-atomic scatters may reorder sums between replays
-            assert (v - runs[1][1][k]).abs().max().item() <= 1e-5 * v.abs().max().item() + 1e-7, k
+        for k, v in runs[0][1].items():                       # no float atomics are left in the backward: replays repeat bit for bit
+            assert torch.equal(v, runs[1][1][k]), k
     finally:
         FLAGS.train = 0
 
@@ -2884,7 +2914,7 @@ def test_train_step_one_rank_of_config_4(ops):
     """BASELINE config 4, one rank: B = 128 objects of N = 1028 points through the whole trainer step.  The CPU oracle needs
     ~80 GB and minutes at this size, so the check is by properties that do not depend on size:
       * the captured step (trainer.graphed_step: both forwards + losses + backward as one hipGraph) reproduces the eager step
-        -- same total to 1e-6, same gradients up to the float-atomic scatters;
+        -- same total, same gradients, bit for bit (the backward has no float atomics left: round 3's gather kernels);
       * the step is invariant under a permutation of the objects of the batch (BatchNorm statistics, the means over objects in
         every loss term and the gradient sums are symmetric in the objects): total to 1e-3 relative, gradient norms to 3 %
         (a permutation reorders fp32 sums, and a last-bit change of a BatchNorm statistic can swap near-tied feature-space
@@ -2933,10 +2963,10 @@ def test_train_step_one_rank_of_config_4(ops):
         step = tr.graphed_step(db)
         reset()
         t2 = step(sample_idx=samples).item()
-        assert abs(t2 - t0) <= 1e-6 * abs(t0), (t0, t2)
+        assert t2 == t0, (t0, t2)
         for k, p in tr.net1.named_parameters():
             if p.grad is not None and k in g0:
-                assert (p.grad - g0[k]).abs().max().item() <= 1e-4 * g0[k].abs().max().item() + 1e-7, k   # float-atomic scatters reorder sums
+                assert torch.equal(p.grad, g0[k]), k          # a stale buffer in the captured step would show here
     finally:
         FLAGS.train = 0
 
@@ -3057,8 +3087,8 @@ def test_graphed_training_follows_eager_training(ops):
     finally:
         FLAGS.train = 0
     # step 0 starts from identical state: same total, and the same weights after the optimizer step; from then on the two runs
-    # are two fp32 trajectories (float-atomic scatters order their sums differently) whose feature-space neighbour lists may
-    # swap near-tied entries: their totals stay within 1e-2 of each other while the loss moves by 25 %
+    # are two fp32 trajectories (the optimizer's eager and captured updates round differently) whose feature-space neighbour
+    # lists may swap near-tied entries: their totals stay within 1e-2 of each other while the loss moves by 25 %
     assert abs(totals["eager"][0] - totals["graph"][0]) <= 1e-6 * abs(totals["eager"][0]), (totals["eager"], totals["graph"])
     for a, b in zip(totals["eager"][1:], totals["graph"][1:]):
         assert abs(a - b) <= 1e-2 * abs(a), (totals["eager"], totals["graph"])
@@ -3071,7 +3101,7 @@ def test_graphed_training_follows_eager_training(ops):
 def test_overlapped_two_segment_step_equals_single_graph(ops):
     """The data-parallel form of the captured step -- backward split at the encoder's output into two hipGraphs that share a pool,
     gradients in two flat buckets whose exchange hooks run between / after the segments (no-ops in one process) -- computes
-    what the single-graph step computes: same total, same gradients (float-atomic scatters aside), on two different draws; the
+    what the single-graph step computes: same total, same gradients, bit for bit, on two different draws; the
     gradients are views of the buckets and the late bucket is complete when the first segment ends."""
     from tgpose_amd import FLAGS
     B, N = 6, 512
@@ -3106,11 +3136,11 @@ def test_overlapped_two_segment_step_equals_single_graph(ops):
     finally:
         FLAGS.train = 0
     for (t0, g0), (t1, g1) in zip(out[False], out[True]):
-        assert abs(t0 - t1) <= 1e-6 * abs(t0), (t0, t1)
+        assert t0 == t1, (t0, t1)
         for k, v in g0.items():
             if "proj_layer" in k:
                 continue
-            assert (g1[k] - v).abs().max().item() <= 1e-4 * v.abs().max().item() + 1e-7, k
+            assert torch.equal(g1[k], v), k
     assert out[True][0][0] != out[True][1][0]
 
 
@@ -3120,7 +3150,7 @@ def test_rccl_exchange_branch_world_size_one(ops):
     data.  What runs is exactly the multi-rank code path: in-place reduce_scatter_tensor on a view of the flat bucket, the
     slice's division, all_gather_into_tensor, all on the exchange stream between the two captured segments, the compute stream
     joining through the recorded event.  Against the same step without collectives: the late bucket (heads, PH predictor,
-    decoder: fixed-order sums) bit for bit, the encoder's bucket up to its float-atomic scatters; the NaN-aware finish_step steps."""
+    decoder) and the encoder's bucket bit for bit (every sum of the backward runs in a fixed order); the NaN-aware finish_step steps."""
     import socket
     import torch.distributed as dist
     from tgpose_amd import FLAGS, shard
@@ -3167,10 +3197,7 @@ def test_rccl_exchange_branch_world_size_one(ops):
         for k, v in g0.items():
             if "proj_layer" in k:
                 continue
-            if k.startswith(tuple(LATE_PREFIXES)):
-                assert torch.equal(g1[k], v), k
-            else:
-                assert (g1[k] - v).abs().max().item() <= 1e-4 * v.abs().max().item() + 1e-7, k
+            assert torch.equal(g1[k], v), k
 
 
 def test_nan_step_is_skipped_like_the_reference_loop(ops):
@@ -3312,6 +3339,29 @@ def test_planes_split_layout_and_magnitudes(ops, rows, K, ld):
     assert (P.to_float() - x[:, :K]).abs().max().item() <= 2e-7 * x.abs().max().item() + 6e-8
 
 
+def test_planes_split_cols_writes_its_column_range_only(ops):
+    """tgp_planes_split_cols (the result planes of a launch too small for the tile kernels, ops.gemm's late split): the K columns land
+    at plane columns col0 .. col0 + K - 1 of a wider buffer; every other chunk of the buffer -- the other columns of the same row
+    blocks, the neighbouring row blocks -- keeps its bytes (round 4: the first version walked all kts K-tiles from the offset and
+    wrote past the row block, past the buffer for the last one)."""
+    import ctypes
+    from tgpose_amd import _lib
+    gen = torch.Generator().manual_seed(3)
+    rows, K, ld, kts, col0 = 257, 256, 512, 32, 256
+    x = g(torch.randn(rows, ld, generator=gen))
+    nblk = (rows + 31) // 32
+    guard = 4
+    buf = torch.full((nblk + guard, kts, 2048), 0xAB, dtype=torch.uint8, device=DEV)       # `guard` row blocks of canary behind the buffer
+    amax = torch.zeros(nblk, dtype=torch.int32, device=DEV)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = _lib.lib().tgp_planes_split_cols(ctypes.c_void_p(x[:, 256:].data_ptr()), rows, K, ld, ctypes.c_void_p(buf.data_ptr()), kts, col0,
+                                          ctypes.c_void_p(amax.data_ptr()), st)
+    assert rc == 0
+    want, want_amax = _ref_planes(x[:, 256:].contiguous(), K)
+    assert torch.equal(buf[:nblk, 16:], want) and torch.equal(amax, want_amax)
+    assert bool((buf[:nblk, :16] == 0xAB).all()) and bool((buf[nblk:] == 0xAB).all())
+
+
 def test_planes_gather_equals_gather_then_split(ops):
     """tgp_planes_gather = tgp_gather_rows + tgp_planes_split in one pass (the factored layers' sorted fine buffer)"""
     gen = torch.Generator().manual_seed(5)
@@ -3327,8 +3377,8 @@ def test_planes_gather_equals_gather_then_split(ops):
     assert torch.equal(d0, d1) and torch.equal(P0.buf, P1.buf) and torch.equal(P0.amax, P1.amax)
 
 
-@pytest.mark.parametrize("M,N,K,rpo", [(4112, 1152, 128, 1028), (1300, 640, 268, 100), (522, 384, 64, 64), (8224 // 4, 512, 512, 257),
-                                       (2056, 128, 132, 1028)])
+@pytest.mark.parametrize("M,N,K,rpo", [(4112, 1152, 128, 1028), (1300, 640, 268, 100), (1310, 384, 64, 64), (8224 // 4, 512, 512, 257),
+                                       (2056, 128, 132, 1028), (300, 128, 64, 100)])
 def test_gemm_pp_bit_identical_to_split_kernel(ops, M, N, K, rpo):
     """The pre-split kernel (both operands as fp16 planes, staged by LDS-DMA; csrc/gemm_pp.hip) against the in-loop-split kernels of
     csrc/gemm.hip on the same operands, every tile shape, with every epilogue feature on (bias, per-object bias, two residuals, BN

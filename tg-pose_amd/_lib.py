@@ -103,6 +103,7 @@ SIGNATURES = {
     "tgp_split_f16": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     "tgp_planes_bytes": (c_i64, [c_i64, c_int]),
     "tgp_planes_split": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
+    "tgp_planes_split_cols": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
     "tgp_planes_gather": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
     "tgp_gemm_tn_workspace_floats": (c_i64, [c_i64, c_int, c_int]),
     "tgp_gemm_tn_f32": (c_int, [c_vp, c_int, c_vp, c_int, c_i64, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp]),

@@ -200,14 +200,16 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPE) void gemm_pp_kernel(GemmParams
 // the fp32 copy -- one pass over the rows instead of a gather and a split
 __global__ __launch_bounds__(256) void planes_split_kernel(const float *__restrict__ X, int rows, int K, int ld, char *__restrict__ out,
                                                            int kts, uint32_t *__restrict__ amax, const int32_t *__restrict__ idx,
-                                                           int n_src, int n_out, float *__restrict__ dst, int ldd, int ccopy)
+                                                           int n_src, int n_out, float *__restrict__ dst, int ldd, int ccopy, int kt0,
+                                                           int nkt)
 {
-    // thread = (row block rb, K-tile kt, half h, row r): one 16-byte piece of each plane; a wave covers both halves of one (rb, kt)
+    // thread = (row block rb, K-tile kt, half h, row r): one 16-byte piece of each plane; a wave covers both halves of one (rb, kt).
+    // nkt K-tiles are written per row block, at tiles kt0 .. kt0 + nkt - 1 of its kts (a column range of a wider planes buffer).
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int nblk = (rows + 31) >> 5;
-    if (t >= (int64_t)nblk * kts * 64) return;              // (whole waves: the grid is a multiple of 64 threads)
+    if (t >= (int64_t)nblk * nkt * 64) return;              // (whole waves: the grid is a multiple of 64 threads)
     const int r = (int)(t & 31), h = (int)((t >> 5) & 1);
-    const int kt = (int)((t >> 6) % kts), rb = (int)((t >> 6) / kts);
+    const int kt = (int)((t >> 6) % nkt), rb = (int)((t >> 6) / nkt);
     const int row = rb * 32 + r, k0 = kt * 16 + h * 8;
     int64_t srow = row;
     if (idx && row < rows) srow = (int64_t)(row / n_out) * n_src + idx[row];
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256) void planes_split_kernel(const float *__restri
     uint2 h0, l0, h1, l1;
     split2(make_float4(v[0], v[1], v[2], v[3]), h0, l0);
     split2(make_float4(v[4], v[5], v[6], v[7]), h1, l1);
-    char *o = out + ((int64_t)rb * kts + kt) * 2048 + h * 512 + r * 16;
+    char *o = out + ((int64_t)rb * kts + kt0 + kt) * 2048 + h * 512 + r * 16;
     *reinterpret_cast<uint4 *>(o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
     *reinterpret_cast<uint4 *>(o + 1024) = make_uint4(l0.x, l0.y, l1.x, l1.y);
     if (amax) {
@@ -243,6 +245,93 @@ __global__ __launch_bounds__(256) void planes_split_kernel(const float *__restri
     }
 }
 
+// The same through LDS, one 256-thread workgroup per block of 32 rows: the rows are read along their length (float4 per lane,
+// coalesced; the fp32 copy of a gather is written the same way), transposed through a 32 x (16 nkt + 4)-float tile -- the 4-float pad
+// makes the row stride 16 x odd bytes mod 256, so the 16-lane groups of the ds_read_b128 below meet 16 distinct bank quads -- and
+// leave as 512-byte runs of 16-byte plane pieces.  The direct kernel above reads 32 B per lane from 32 different rows per wave
+// instruction: 53 us for the sorted fine buffer (36 MB in, 72 MB out) against 20 here.
+#define PLANES_ROWS_MAX_KT 64
+__global__ __launch_bounds__(256) void planes_rows_kernel(const float *__restrict__ X, int rows, int K, int ld, int C,
+                                                          char *__restrict__ out, int kts, uint32_t *__restrict__ amax,
+                                                          const int32_t *__restrict__ idx, int n_src, int n_out,
+                                                          float *__restrict__ dst, int ldd, int kt0, int nkt)
+{
+    extern __shared__ __attribute__((aligned(16))) float pr_tile[];
+    __shared__ uint32_t pr_amax[4];
+    const int rb = blockIdx.x, tid = threadIdx.x;
+    const int LDP = nkt * 16 + 4, W4 = nkt * 4;                 // tile row stride in floats; float4 per tile row
+    const int C4 = C >> 2;                                      // float4 per source row (C % 4 == 0)
+    for (int i = tid; i < 32 * W4; i += 256) {
+        const int r = i / W4, c4 = i - r * W4;
+        const int row = rb * 32 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < rows && c4 < C4) {
+            const int64_t srow = idx ? (int64_t)(row / n_out) * n_src + idx[row] : row;
+            v = *reinterpret_cast<const float4 *>(X + srow * ld + 4 * c4);
+            if (dst) *reinterpret_cast<float4 *>(dst + (int64_t)row * ldd + 4 * c4) = v;
+            const int k = 4 * c4;                                // columns K .. C - 1 travel in the fp32 copy only
+            v.x = k + 0 < K ? v.x : 0.f, v.y = k + 1 < K ? v.y : 0.f, v.z = k + 2 < K ? v.z : 0.f, v.w = k + 3 < K ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4 *>(pr_tile + r * LDP + 4 * c4) = v;
+    }
+    __syncthreads();
+    uint32_t m = 0u;
+    for (int q = tid; q < nkt * 64; q += 256) {
+        const int r = q & 31, h = (q >> 5) & 1, kt = q >> 6;
+        const float4 v0 = *reinterpret_cast<const float4 *>(pr_tile + r * LDP + kt * 16 + h * 8);
+        const float4 v1 = *reinterpret_cast<const float4 *>(pr_tile + r * LDP + kt * 16 + h * 8 + 4);
+        uint2 h0, l0, h1, l1;
+        split2(v0, h0, l0);
+        split2(v1, h1, l1);
+        char *o = out + ((int64_t)rb * kts + kt0 + kt) * 2048 + h * 512 + r * 16;
+        *reinterpret_cast<uint4 *>(o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        *reinterpret_cast<uint4 *>(o + 1024) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        const uint32_t b[8] = {__float_as_uint(v0.x), __float_as_uint(v0.y), __float_as_uint(v0.z), __float_as_uint(v0.w),
+                               __float_as_uint(v1.x), __float_as_uint(v1.y), __float_as_uint(v1.z), __float_as_uint(v1.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m = (b[e] & 0x7fffffffu) > m ? (b[e] & 0x7fffffffu) : m;
+    }
+    if (amax) {
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const uint32_t o2 = (uint32_t)__shfl_xor((int)m, s);
+            m = o2 > m ? o2 : m;
+        }
+        if ((tid & 63) == 0) pr_amax[tid >> 6] = m;
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t a = max(max(pr_amax[0], pr_amax[1]), max(pr_amax[2], pr_amax[3]));
+            if (a) atomicMax(amax + rb, a);
+        }
+    }
+}
+
+// rows -> planes: the LDS form when the rows are float4-addressable and at most 1024 columns wide, else the direct form
+static int planes_launch(const float *X, int rows, int K, int ld, int C, char *out, int kts, uint32_t *amax, const int32_t *idx, int n_src,
+                         int n_out, float *dst, int ldd, int kt0, int nkt, hipStream_t stream)
+{
+    const int nblk = (rows + 31) / 32;
+    const bool vec = nkt <= PLANES_ROWS_MAX_KT && (ld & 3) == 0 && (C & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
+                     (!dst || ((ldd & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0)) && C <= nkt * 16;
+    if (vec) {
+        const size_t lds = (size_t)32 * (nkt * 16 + 4) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(planes_rows_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 32 * (PLANES_ROWS_MAX_KT * 16 + 4) * 4);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(planes_rows_kernel, dim3(nblk), dim3(256), lds, stream, X, rows, K, ld, C, out, kts, amax, idx, n_src, n_out, dst,
+                           ldd, kt0, nkt);
+        return TGP_LAUNCH_RESULT();
+    }
+    const int64_t threads = (int64_t)nblk * nkt * 64;
+    hipLaunchKernelGGL(planes_split_kernel, dim3(tgp_cdiv(threads, 256)), dim3(256), 0, stream, X, rows, K, ld, out, kts, amax, idx, n_src,
+                       n_out, dst, ldd, C, kt0, nkt);
+    return TGP_LAUNCH_RESULT();
+}
+
 extern "C" int64_t tgp_planes_bytes(int64_t rows, int K)
 {
     if (rows <= 0 || K <= 0) return 0;
@@ -253,10 +342,19 @@ extern "C" int tgp_planes_split(const float *X, int rows, int K, int ld, void *o
 {
     TGP_REQUIRE(X && out && rows > 0 && K > 0 && ld >= K && kts >= (K + 15) / 16);
     TGP_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-    const int64_t threads = (int64_t)((rows + 31) / 32) * kts * 64;
-    hipLaunchKernelGGL(planes_split_kernel, dim3(tgp_cdiv(threads, 256)), dim3(256), 0, tgp_hs(stream), X, rows, K, ld,
-                       reinterpret_cast<char *>(out), kts, amax, nullptr, 0, 0, nullptr, 0, 0);
-    return TGP_LAUNCH_RESULT();
+    // (the direct form reads columns < ld; the LDS form takes the K columns, rounded up to whole float4 when the row stride allows)
+    const int C = (ld & 3) == 0 ? min((K + 3) & ~3, ld) : K;
+    return planes_launch(X, rows, K, ld, C, reinterpret_cast<char *>(out), kts, amax, nullptr, 0, 0, nullptr, 0, 0, kts, tgp_hs(stream));
+}
+
+extern "C" int tgp_planes_split_cols(const float *X, int rows, int K, int ld, void *out, int kts, int col0, uint32_t *amax,
+                                     tgp_stream_t stream)
+{
+    TGP_REQUIRE(X && out && rows > 0 && K > 0 && ld >= K && col0 >= 0 && (col0 & 15) == 0 && kts >= col0 / 16 + (K + 15) / 16);
+    TGP_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    const int nkt = (K + 15) / 16;
+    const int C = (ld & 3) == 0 ? min((K + 3) & ~3, ld) : K;
+    return planes_launch(X, rows, K, ld, C, reinterpret_cast<char *>(out), kts, amax, nullptr, 0, 0, nullptr, 0, col0 / 16, nkt, tgp_hs(stream));
 }
 
 extern "C" int tgp_planes_gather(const float *src, int lds, const int32_t *idx, int B, int n_src, int n_out, int K, int C, float *dst,
@@ -268,10 +366,7 @@ extern "C" int tgp_planes_gather(const float *src, int lds, const int32_t *idx, 
     const int rows = B * n_out;
     // (columns [K, C) travel in the fp32 copy only; the K-tiles must cover them so that every column of the copy is visited)
     TGP_REQUIRE(!dst || kts * 16 >= C);
-    const int64_t threads = (int64_t)((rows + 31) / 32) * kts * 64;
-    hipLaunchKernelGGL(planes_split_kernel, dim3(tgp_cdiv(threads, 256)), dim3(256), 0, tgp_hs(stream), src, rows, K, lds,
-                       reinterpret_cast<char *>(out), kts, amax, idx, n_src, n_out, dst, ldd, C);
-    return TGP_LAUNCH_RESULT();
+    return planes_launch(src, rows, K, lds, C, reinterpret_cast<char *>(out), kts, amax, idx, n_src, n_out, dst, ldd, 0, kts, tgp_hs(stream));
 }
 
 // ---- launch
@@ -299,27 +394,17 @@ static int pp_launch(GemmParams &p, hipStream_t stream)
     return TGP_LAUNCH_RESULT();
 }
 
-static int pp_cus(void)
-{
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            cus <= 0)
-            cus = 256;
-    }
-    return cus;
-}
-
-// the library's choice of tile shape for a launch (0 in tgp_gemm_args.pp_config)
+// the library's choice of tile shape for a launch (0 in tgp_gemm_args.pp_config).  Measured on the eval forward's launches, every
+// shape against every launch (scripts/gemm_pp_ab.py, profiles/r04_a_gemm_pp_ab.txt): the 256 x 256 tiles -- one workgroup per CU --
+// lose everywhere on this network's short-K, epilogue-heavy layers (K = 128 .. 512: a tile is prologue + 4-16 steps + a 256 KB
+// store burst, nothing overlaps it); four 128 x 128 workgroups per CU overlap one another's phases and quantise the 128.5 row tiles
+// of 32896 rows finely; narrow outputs (N <= 512) do best on 64 x 128; only the long, wide level-1 coarse product (K = 512, 38 M
+// outputs) is better on 256 x 128 with three stages.
 static int pp_auto_config(const GemmParams &p)
 {
-    const int64_t cus = pp_cus();
-    const int64_t t256 = (int64_t)tgp_cdiv(p.M, 256) * tgp_cdiv(p.N, 256);
-    const int64_t t128 = (int64_t)tgp_cdiv(p.M, 128) * tgp_cdiv(p.N, 128);
-    if (t128 * 10 < 3 * 4 * cus) return 5;                 // fewer than ~0.3 rounds of the 128 x 128 tiles at four per CU
-    if (t256 < 2 * cus) return 4;
-    return 1;
+    if (p.N <= 512) return 5;
+    if (p.K >= 512 && (int64_t)p.M * p.N >= (1ll << 25)) return 3;
+    return 4;
 }
 
 int tgp_launch_gemm_pp(GemmParams &p, int config, hipStream_t stream)

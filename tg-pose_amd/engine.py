@@ -250,6 +250,7 @@ COARSE_SIDE = os.environ.get("TGP_COARSE_SIDE", "0") != "0"
 # reference's FLOPs).  A deployment switch; the bench's headline and every parity test run the full forward.
 EVAL_OUTPUTS_ONLY = os.environ.get("TGP_EVAL_OUTPUTS_ONLY", "0") != "0"
 HEADS_TAIL = os.environ.get("TGP_HEADS_TAIL", "0") != "0"
+REPAIR_OBJS = 16        # objects per chunk of the fused heads kernel's fp16-range repair (wide_gemm_factored)
 
 
 SIDE_TAG = 0            # GraphedForward gives each half batch its own side stream
@@ -542,7 +543,7 @@ def coarse_products(pk, inter, heads_only=False):
         for src, W, Ws in ((inter["fm23"], f["Wb"], f["Wb_s"]), (inter["fm_4"], f["Wc"], f["Wc_s"])):
             src = src.reshape(-1, 512)
             P = torch.empty(src.shape[0], W.shape[0], device=src.device, dtype=torch.float32)
-            ops.linear_rows(src, W[1024:4096], w_split=Ws[1024:4096], out=P[:, 1024:4096], flops_ref=0)
+            ops.linear_rows(src, W[1024:4096], w_split=ops.split_rows(Ws, 1024, 4096), out=P[:, 1024:4096], flops_ref=0)
             out.append(P)
         return out[0], out[1]
     P1 = inter.get("P1")
@@ -600,7 +601,7 @@ def wide_gemm_factored(pk, fine, inter, P1, P2, N, arena=None, heads_only=False)
                     Ht = torch.empty(Mt, 3072, device=dev, dtype=torch.float32)
                     ft = fine.view(M, -1)[rows:]
                     ops.gemm(ft, f["Wa"][1024:], Ht, M=Mt, N=3072, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=3072, bias=w["bias"][1024:],
-                             scale=w["scale"][1024:], shift=w["shift"][1024:], act=1, slope=0.0, rows_per_obj=N, w_split=f["Wa_s"][1024:],
+                             scale=w["scale"][1024:], shift=w["shift"][1024:], act=1, slope=0.0, rows_per_obj=N, w_split=ops.split_rows(f["Wa_s"], 1024),
                              gather1=(P1[:, 1024:], P1.shape[1], inter["near1"].view(-1)[rows:]),
                              gather2=(P2[:, 1024:], P2.shape[1], inter["near2"].view(-1)[rows:]), flops_ref=0, row_base=rows)
                     ops.gemm(Ht, w["W2"], None, M=Mt, N=256, K=1024, lda=3072, ldw=1024, ldc=0, bias=w["b2"], scale=w["scale2"],
@@ -623,14 +624,22 @@ def wide_gemm_factored(pk, fine, inter, P1, P2, N, arena=None, heads_only=False)
             # fp16 range repair, decided on the device: a wave of the fused kernel that met a magnitude beyond fp16's range wrote no
             # keys and raised `overflow`; the two-launch form (whose tiles guard themselves) then supplies every key.  While the
             # flag is 0 -- always, for sane weights -- both launches return at once (tgp_gemm_args.pred).
-            H = torch.empty(M, 3072, device=dev, dtype=torch.float32)
-            ops.gemm(fine, f["Wa"][1024:], H, M=M, N=3072, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=3072, bias=w["bias"][1024:],
-                     scale=w["scale"][1024:], shift=w["shift"][1024:], act=1, slope=0.0, rows_per_obj=N, w_split=f["Wa_s"][1024:],
-                     gather1=(P1[:, 1024:], P1.shape[1], inter["near1"]), gather2=(P2[:, 1024:], P2.shape[1], inter["near2"]),
-                     flops_ref=0, pred=overflow)
-            ops.gemm(H, w["W2"], None, M=M, N=256, K=1024, lda=3072, ldw=1024, ldc=0, bias=w["b2"], scale=w["scale2"],
-                     shift=w["shift2"], act=1, slope=0.0, colmax_keys=keys2, rows_per_obj=N, batch=3,
-                     batch_strides=(1024, 256 * 1024, 0, 256, B * 256), w_split=w["W2s"], flops_ref=0, pred=overflow)
+            # The repair's conv1 activation is (rows, 3072) fp32 -- 404 MB for B = 32 objects of 1028 points, 3.2 GB for 256 -- and
+            # sits in every captured forward's pool although the launches normally return at once: the repair therefore walks
+            # the batch in chunks of REPAIR_OBJS objects through ONE chunk-sized buffer (tgp_gemm_args.row_base addresses the
+            # chunk's objects in the max over points): two predicated launches per chunk.
+            Rr = min(M, REPAIR_OBJS * N)
+            H = torch.empty(Rr, 3072, device=dev, dtype=torch.float32)
+            f2, n1v, n2v = fine.view(M, -1), inter["near1"].view(-1), inter["near2"].view(-1)
+            for r0 in range(0, M, Rr):
+                Mt = min(Rr, M - r0)
+                ops.gemm(f2[r0:], f["Wa"][1024:], H, M=Mt, N=3072, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=3072, bias=w["bias"][1024:],
+                         scale=w["scale"][1024:], shift=w["shift"][1024:], act=1, slope=0.0, rows_per_obj=N,
+                         w_split=ops.split_rows(f["Wa_s"], 1024), gather1=(P1[:, 1024:], P1.shape[1], n1v[r0:]),
+                         gather2=(P2[:, 1024:], P2.shape[1], n2v[r0:]), flops_ref=0, pred=overflow, row_base=r0)
+                ops.gemm(H, w["W2"], None, M=Mt, N=256, K=1024, lda=3072, ldw=1024, ldc=0, bias=w["b2"], scale=w["scale2"],
+                         shift=w["shift2"], act=1, slope=0.0, colmax_keys=keys2, rows_per_obj=N, batch=3,
+                         batch_strides=(1024, 256 * 1024, 0, 256, B * 256), w_split=w["W2s"], flops_ref=0, pred=overflow, row_base=r0)
             return keys2
         return keys5, heads
     keys5 = arena.keys5
@@ -742,7 +751,8 @@ def draw_sample_idx(N):
     return i1, i2
 
 
-def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6, probe=None):
+def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6, probe=None,
+                    outputs_only=None):
     """PoseNet9D(only_encoder=False).forward in eval mode (PoseNet9D.py:46-91).
     probe (tests): a dict that receives what the six-key eval result does not return -- recon (with the cloud's mean added), h1,
     h2, feat_global -- so that the factored / fused eval paths' decoder and PH branch can be compared with the concat path's."""
@@ -761,7 +771,9 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
     feat, inter = encoder_forward(pk, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls, factored=factored, arena=arena)
     # EVAL_OUTPUTS_ONLY: the six-key eval dict (PoseNet9D.py:85-90) needs neither the PH predictor nor the decoder -- the reference
     # computes both and drops them.  Off by default: the bench's headline is the full forward (SURVEY 8d's algorithmic figures).
-    heads_only = (EVAL_OUTPUTS_ONLY and factored and probe is None and HEADS_FUSED and getattr(pk, "fact", None) is not None
+    # outputs_only: this call's setting (PoseNet9D.forward hands its caller's down); None = the process-wide default
+    heads_only = ((EVAL_OUTPUTS_ONLY if outputs_only is None else bool(outputs_only)) and factored and probe is None and HEADS_FUSED
+                  and getattr(pk, "fact", None) is not None
                   and pk.fact["w2p"] is not None)
     if heads_only:
         P1, P2 = coarse_products(pk, inter, heads_only=True)
@@ -1069,7 +1081,7 @@ class PinnedRing(object):
 
 
 class GraphedForward(object):
-    def __init__(self, pk, B, N, device, train_keys=False, parts=1, kmax=20, n_cls=6):
+    def __init__(self, pk, B, N, device, train_keys=False, parts=1, kmax=20, n_cls=6, outputs_only=None):
         global SIDE_TAG
         if parts not in (1, 2) or (parts == 2 and B % 2):
             raise ValueError("parts must be 1, or 2 with an even batch")
@@ -1088,7 +1100,8 @@ class GraphedForward(object):
             self.s1.copy_(self._s12[:n1])
             self.s2.copy_(self._s12[n1:])
             if parts == 1:
-                return posenet_forward(pk, self.points, self.obj, train_keys, (self.s1, self.s2), None, None, kmax, n_cls)
+                return posenet_forward(pk, self.points, self.obj, train_keys, (self.s1, self.s2), None, None, kmax, n_cls,
+                                       outputs_only=outputs_only)
             global SIDE_TAG, BRANCH_STREAMS
             branch, BRANCH_STREAMS = BRANCH_STREAMS, False     # two streams in all: the halves overlap each other
             cur = torch.cuda.current_stream(device)
@@ -1103,7 +1116,7 @@ class GraphedForward(object):
                         stream.wait_event(fork)
                     sl = slice(part * half, (part + 1) * half)
                     outs.append(posenet_forward(pk, self.points[sl], self.obj[sl], train_keys, (self.s1, self.s2), None, None,
-                                                kmax, n_cls))
+                                                kmax, n_cls, outputs_only=outputs_only))
                     if part:
                         join = torch.cuda.Event()
                         join.record(stream)

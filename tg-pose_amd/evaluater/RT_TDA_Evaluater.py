@@ -34,9 +34,10 @@ class myEvaluater:
 
     def __init__(self, net, frames_per_batch=32, max_batch=256, sampler="numpy", seed=0, overlap=True, graph=False):
         self.net1 = net.eval()
-        if getattr(net, "eval_outputs_only", None) is None and not os.environ.get("TGP_EVAL_FULL_FORWARD"):   # (A/B switch)
-            net.eval_outputs_only = True                     # the driver reads the six pose outputs only (:143-150): PH predictor and
-                                                             # decoder are dead code here, as in the reference's eval dict
+        # The driver reads the six pose outputs only (:143-150): PH predictor and decoder are dead code here, as in the reference's
+        # eval dict, so its forwards run lean BY DEFAULT (TGP_EVAL_FULL_FORWARD=1 or eval_outputs_only=False: the full forward).
+        # The setting is this evaluater's and travels with each call; the caller's module is not touched.
+        self.eval_outputs_only = not os.environ.get("TGP_EVAL_FULL_FORWARD")
         self.device = next(net.parameters()).device
         self.frames_per_batch, self.max_batch, self.sampler, self.seed, self.overlap = frames_per_batch, max_batch, sampler, seed, overlap
         self.graph = graph                                   # replay the forward as a captured hipGraph (PoseNet9D.graph_replay)
@@ -67,7 +68,7 @@ class myEvaluater:
         if ok is not None:
             pts = torch.nan_to_num(pts, nan=0.0)
         with torch.no_grad():
-            rts, scales = infer_device(self.net1, pts, cat, mean, sym, self.max_batch)
+            rts, scales = infer_device(self.net1, pts, cat, mean, sym, self.max_batch, eval_outputs_only=self.eval_outputs_only)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(self.device))
         return records, alive, ok, kept, rts, scales, done

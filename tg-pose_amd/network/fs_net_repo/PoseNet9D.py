@@ -45,7 +45,8 @@ class PoseNet9D(_WithBuffers):
             self._pk_bsig = tuple((b.data_ptr(), b._version) for b in self.buffers())
         return self._pk
 
-    def forward(self, points, obj_id, enable_proj=False, *, sample_idx=None, inject=None, record=None, cut=None):
+    def forward(self, points, obj_id, enable_proj=False, *, sample_idx=None, inject=None, record=None, cut=None,
+                eval_outputs_only=None):
         if enable_proj:
             raise NotImplementedError("enable_proj=True is never used by the reference's train/eval path")
         if not points.is_cuda:
@@ -69,24 +70,21 @@ class PoseNet9D(_WithBuffers):
             if self.only_encoder:
                 return engine.encoder_only_forward(pk, points, obj_id, sample_idx, inject, record,
                                                    FLAGS.gcn_n_num, FLAGS.obj_c)
-            # net.eval_outputs_only = True (a deployment switch, e.g. the evaluation driver's): the layers whose results the six-key
-            # eval dict does not return -- PH predictor, decoder -- are not computed (engine.EVAL_OUTPUTS_ONLY for this call)
-            lean = getattr(self, "eval_outputs_only", None)
-            if lean is not None and bool(lean) != engine.EVAL_OUTPUTS_ONLY:
-                prev, engine.EVAL_OUTPUTS_ONLY = engine.EVAL_OUTPUTS_ONLY, bool(lean)
-                try:
-                    return self.forward(points, obj_id, enable_proj, sample_idx=sample_idx, inject=inject, record=record, cut=cut)
-                finally:
-                    engine.EVAL_OUTPUTS_ONLY = prev
+            # eval outputs only (a deployment switch): the layers whose results the six-key eval dict does not return -- PH
+            # predictor, decoder -- are not computed.
+            # Per call (eval_outputs_only=..., what the evaluation driver passes), else the module's attribute, else the process
+            # default; handed down as an argument -- nothing global is rewritten, so nets with different settings do not interfere.
+            lean = eval_outputs_only if eval_outputs_only is not None else getattr(self, "eval_outputs_only", None)
+            lean = engine.EVAL_OUTPUTS_ONLY if lean is None else bool(lean)
             if getattr(self, "graph_replay", False) and inject is None and record is None:
                 # opt-in (net.graph_replay = True): the forward of this (batch, cloud size, output set) is captured once as
                 # a hipGraph and replayed; the returned tensors are the graph's static outputs, valid until the next call
-                key = (id(pk), tuple(points.shape), bool(FLAGS.train), ops.GEMM_MODE, engine.BRANCH_STREAMS, engine.EVAL_OUTPUTS_ONLY)
+                key = (id(pk), tuple(points.shape), bool(FLAGS.train), ops.GEMM_MODE, engine.BRANCH_STREAMS, lean)
                 graphs = self.__dict__.setdefault("_graphs", {})
                 if key not in graphs:
                     graphs.clear()                      # one resident graph: its private pool holds every activation
                     graphs[key] = engine.GraphedForward(pk, points.shape[0], points.shape[1], points.device, bool(FLAGS.train),
-                                                        1, FLAGS.gcn_n_num, FLAGS.obj_c)
+                                                        1, FLAGS.gcn_n_num, FLAGS.obj_c, outputs_only=lean)
                 return dict(graphs[key](points, obj_id, sample_idx))
             return engine.posenet_forward(pk, points, obj_id, bool(FLAGS.train), sample_idx, inject, record,
-                                          FLAGS.gcn_n_num, FLAGS.obj_c)
+                                          FLAGS.gcn_n_num, FLAGS.obj_c, outputs_only=lean)

@@ -290,6 +290,16 @@ def split_w(W, check=True):
     return out
 
 
+def split_rows(ws, a, b=None):
+    """rows [a, b) of a pack-time split weight, keeping the power of two a pre-scaled weight carries (split_w's .tgp_unscale is a
+    Python attribute that plain slicing would drop: the product would silently come out 2^k too small)"""
+    out = ws[a:b]
+    unscale = getattr(ws, "tgp_unscale", None)
+    if unscale is not None:
+        out.tgp_unscale = unscale
+    return out
+
+
 def split_f16(W):
     """W (..., rows, K) fp32 -> int16 tensor (..., rows, ldo // 16, 2, 16) of fp16 bit patterns (hi, lo per K-tile)."""
     W = W.contiguous()
@@ -414,7 +424,13 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
     operand (views into wider buffers are fine); all sizes/strides are explicit.  k_alg: the layer's
     true input width when K includes zero padding (only used for FLOP accounting in bench.py)."""
     split16 = w_split is not None and GEMM_MODE != "fp32" and w_split.shape[-2] == 2 and not ksplit_chunk
-    pp = a_planes is not None and w_planes is not None and GEMM_MODE == "split16" and PLANES
+    # the pre-split kernel serves the launches the split tile kernels serve (so that results do not depend on whether planes were
+    # handed in: launches too small for them run on the exact-fp32 small kernel either way)
+    tile = _routes_to_big_tile(M, N, batch, True) and not ksplit_chunk
+    pp = a_planes is not None and w_planes is not None and GEMM_MODE == "split16" and PLANES and tile and w_split is not None
+    late_planes = None
+    if c_planes is not None and GEMM_MODE == "split16" and PLANES and not (tile and w_split is not None):
+        late_planes, c_planes = c_planes, None          # a small launch: its result is split by a launch of its own below
     timed = GEMM_TIMER is not None and pred is None and (GEMM_TIMER_ALL or pp or _routes_to_big_tile(M, N, batch, split16))   # (a predicated
     # launch is a repair path that normally does nothing: it has no place in a FLOP rate)
     if timed:
@@ -458,6 +474,12 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
     if c_planes is not None and GEMM_MODE == "split16" and PLANES:
         a.C_planes, a.c_kt, a.cp_col0, a.c_amax = _p(c_planes.buf), c_planes.kt, int(cp_col0), _p(c_planes.amax)
     check(_lib.lib().tgp_gemm_f32(ctypes.byref(a), _stream(A)), "tgp_gemm_f32")
+    if late_planes is not None:
+        if C is None or batch != 1 or (cp_col0 & 15):
+            raise ValueError("gemm: result planes of a small launch need its fp32 result")
+        Kc = N - c_col0
+        check(_lib.lib().tgp_planes_split_cols(_p(C), M, Kc, ldc, _p(late_planes.buf), late_planes.kt, int(cp_col0), _p(late_planes.amax),
+                                               _stream(A)), "tgp_planes_split_cols")
     if timed:
         e1.record(torch.cuda.current_stream(A.device))
         # flops_ref: what this launch stands for in the reference's formulation (the factored wide layers run fewer FLOPs)

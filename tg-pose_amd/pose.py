@@ -18,12 +18,14 @@ def generate_RT(R, f, T, mode="vec", sym=None):
     return ops.generate_rt(R[0], R[1], f[0], f[1], T, sym)
 
 
-def infer_device(net, pts, cat, ms, sym, max_batch=256):
+def infer_device(net, pts, cat, ms, sym, max_batch=256, eval_outputs_only=None):
     """One or more forwards over (n,N,3) clouds already on the device -> (pred_RTs (n,4,4), pred_scales (n,3)) device tensors;
-    nothing synchronises (the caller decides when to copy back)."""
+    nothing synchronises (the caller decides when to copy back).  eval_outputs_only: handed to each forward (None = the net's /
+    the process's setting): the six pose outputs are all this function reads."""
     rts, scales = [], []
+    kw = {} if eval_outputs_only is None else dict(eval_outputs_only=bool(eval_outputs_only))
     for lo in range(0, pts.shape[0], max_batch):
-        out = net(pts[lo:lo + max_batch], cat[lo:lo + max_batch])
+        out = net(pts[lo:lo + max_batch], cat[lo:lo + max_batch], **kw)
         rts.append(generate_RT([out["p_green_R"], out["p_red_R"]], [out["f_green_R"], out["f_red_R"]], out["Pred_T"],
                                mode="vec", sym=sym[lo:lo + max_batch]))
         scales.append(out["Pred_s"] + ms[lo:lo + max_batch])
