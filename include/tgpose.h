@@ -98,6 +98,14 @@ int tgp_orl_global(const float *feat, int ldf, const int32_t *idx, int B, int n,
  * g as above (optionally stored to g_out, may be NULL), rb[b,:] = g[b,:] @ W2^T with w2t = W2 transposed (C,C). */
 int tgp_orl_rowbias(const float *feat, int ldf, const int32_t *idx, int B, int n, int k, int C, float *partial,
                     const float *w2t, float *g_out, float *rb, tgp_stream_t stream);
+/* (ABI 5) the same, and feat -- the A operand of the layer's last GEMM (gcn3d.py:108-112: conv2's feature half) -- also written as
+ * blocked fp16 planes (tgp_gemm_args.A_planes: `kts` K-tiles per row block, K-tile c / 16 for channel c) with the per-row-block
+ * magnitudes in amax (zero-filled by the caller; may be NULL).  xyz_tile (may be NULL; HSlayer_surface): points (B*n, 3) written as
+ * K-tile C / 16 = (x, y, z, 0, ...), the STE convolution's extra K columns.  TGP_EUNSUPPORTED where the LDS-staged form does not
+ * serve the shape (the caller falls back to tgp_orl_rowbias and an fp32 operand). */
+int tgp_orl_rowbias_planes(const float *feat, int ldf, const int32_t *idx, int B, int n, int k, int C, float *partial,
+                           const float *w2t, float *g_out, float *rb, void *planes, int kts, uint32_t *amax, const float *xyz_tile,
+                           tgp_stream_t stream);
 
 /* gcn3d.py:219-245 Pool_layer.forward with the random subsample (randperm, :242) supplied by the
  * host: out_f[b,m,:] = max_{j<kpool} feat[b, idx[b, sample[m], j], :], out_xyz[b,m] = xyz[b, sample[m]].

@@ -3493,3 +3493,27 @@ def test_forward_on_planes_bit_identical_to_forward_without(ops, B, N):
             ops.PLANES = old
     for k in got[0]:
         assert torch.equal(got[0][k], got[1][k]), k
+
+
+@pytest.mark.parametrize("B,n,C,k,with_xyz", [(3, 1028, 128, 20, True), (2, 257, 256, 20, False), (4, 64, 512, 8, False), (2, 100, 128, 12, True)])
+def test_orl_rowbias_planes_equal_split_of_the_table(ops, B, n, C, k, with_xyz):
+    """tgp_orl_rowbias_planes: the ORL pooling's LDS-staged table leaves as the fp16 planes of the layer's last GEMM operand (one
+    K-tile per 16-channel slice; conv_0: one more tile (x, y, z, 0 ...)) -- same row bias as tgp_orl_rowbias, planes and per-block
+    magnitudes equal to the stand-alone split of [table | xyz 0], objects that straddle 32-row blocks included (n = 1028, 257, 100)."""
+    gen = torch.Generator().manual_seed(B * n + C)
+    feat = g(torch.randn(B, n, C, generator=gen))
+    xyz = g(torch.randn(B, n, 3, generator=gen))
+    idx = g(torch.randint(0, n, (B, n, k), generator=gen).int())
+    w2t = g(torch.randn(C, C, generator=gen) / C ** 0.5)
+    rb0 = ops.orl_rowbias(feat, idx, w2t)
+    K = C + 4 if with_xyz else C
+    P = ops.Planes(B * n, K, DEV)
+    P.buf.fill_(0xAB)
+    rb1, got = ops.orl_rowbias(feat, idx, w2t, planes=P, xyz_tile=xyz if with_xyz else None)
+    assert got is P and torch.equal(rb0, rb1)
+    full = torch.cat([feat.view(B * n, C), xyz.view(B * n, 3), torch.zeros(B * n, 1, device=DEV)], 1) if with_xyz else feat.view(B * n, C)
+    want, amax = _ref_planes(full, K)
+    nblk = want.shape[0]
+    rows_ok = (torch.arange(nblk * 32, device=DEV) < B * n).view(nblk, 1, 1, 1, 32, 1)
+    assert bool(((P.buf.view(nblk, P.kt, 2, 2, 32, 16) == want.view(nblk, P.kt, 2, 2, 32, 16)) | ~rows_ok).all())
+    assert torch.equal(P.amax, amax)

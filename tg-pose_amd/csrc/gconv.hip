@@ -426,12 +426,32 @@ __global__ __launch_bounds__(256) void orl_partial_kernel(const float *__restric
 // channel pair) and reproduces the summation order of orl_partial_kernel exactly (slot w sums points w, w+4, ... of the
 // tile, then ((s0 + s1) + s2) + s3), so `partial` is bit-identical.
 #define ORL_CH 16
+// (round 4) A 16-channel slice of the table is one K-tile of the layer's last GEMM, whose A operand the table is: while the slice sits
+// in LDS the workgroup also writes it as fp16 hi / lo planes in the blocked layout of the pre-split GEMM (include/tgpose.h,
+// tgp_gemm_args.A_planes) -- every element of the table is then read once for both purposes, the pieces leave as 512-byte runs --
+// with the per-row-block magnitudes of that kernel's range guard.  xyz_tile (conv_0): the workgroup of slice 0 also writes K-tile
+// C / 16 = (x, y, z, 0, 0 ...), the STE convolution's four extra K columns (engine.surface_layer).
+typedef _Float16 ol_f16x4 __attribute__((ext_vector_type(4)));
+typedef float ol_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ol_split(const float4 v, uint2 &hi, uint2 &lo)
+{
+    const ol_f32x4 x = {v.x, v.y, v.z, v.w};
+    const ol_f16x4 h = __builtin_convertvector(x, ol_f16x4);
+    const ol_f32x4 rest = x - __builtin_convertvector(h, ol_f32x4);
+    const ol_f16x4 l = __builtin_convertvector(rest, ol_f16x4);
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+}
+
 __global__ __launch_bounds__(1024) void orl_lds_kernel(const float *__restrict__ feat, int ldf, const int32_t *__restrict__ idx, int B,
-                                                       int n, int k, int C, float *__restrict__ partial, int ptiles)
+                                                       int n, int k, int C, float *__restrict__ partial, int ptiles,
+                                                       char *__restrict__ planes, int kts, uint32_t *__restrict__ amax,
+                                                       const float *__restrict__ xyz_tile)
 {
     extern __shared__ __attribute__((aligned(16))) float ol_smem[];
     float *s_tab = ol_smem;                          // [n][ORL_CH]
     float *s_red = ol_smem + (size_t)n * ORL_CH;     // [ptiles][4][ORL_CH]
+    uint32_t *s_amax = reinterpret_cast<uint32_t *>(s_red + (size_t)ptiles * 4 * ORL_CH);   // [n / 32 + 2] (planes only)
     int b, chunk;
     if (!tgp_xcd_object_tile(blockIdx.x, B, C / ORL_CH, b, chunk)) return;
     const int c0 = chunk * ORL_CH;
@@ -441,7 +461,46 @@ __global__ __launch_bounds__(1024) void orl_lds_kernel(const float *__restrict__
         *reinterpret_cast<float4 *>(s_tab + row * ORL_CH + q * 4) =
             *reinterpret_cast<const float4 *>(feat + ((int64_t)b * n + row) * ldf + c0 + q * 4);
     }
+    const int rb0 = (int)(((int64_t)b * n) >> 5), nrb = (int)((((int64_t)b * n + n - 1) >> 5) - rb0 + 1);
+    if (planes)
+        for (int e = tid; e < nrb; e += nthr) s_amax[e] = 0u;
     __syncthreads();
+    if (planes) {
+        // piece (row, h) = 8 channels of one row: lanes 0-31 of a wave take 32 consecutive rows' h = 0, lanes 32-63 their h = 1
+        const int tiles = (xyz_tile && chunk == 0) ? 2 : 1;
+        for (int tl = 0; tl < tiles; ++tl)
+            for (int e = tid; e < ((n + 31) & ~31) * 2; e += nthr) {
+                const int row = (e >> 6) * 32 + (e & 31), h = (e >> 5) & 1;
+                if (row >= n) continue;
+                const int64_t gr = (int64_t)b * n + row;
+                float4 v0, v1;
+                if (tl == 0) {
+                    v0 = *reinterpret_cast<const float4 *>(s_tab + row * ORL_CH + h * 8);
+                    v1 = *reinterpret_cast<const float4 *>(s_tab + row * ORL_CH + h * 8 + 4);
+                } else {
+                    const float *pc = xyz_tile + gr * 3;
+                    v0 = h == 0 ? make_float4(pc[0], pc[1], pc[2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                uint2 h0, l0, h1, l1;
+                ol_split(v0, h0, l0);
+                ol_split(v1, h1, l1);
+                const int kt = tl == 0 ? chunk : C / ORL_CH;
+                char *o = planes + ((gr >> 5) * kts + kt) * 2048 + h * 512 + (int)(gr & 31) * 16;
+                *reinterpret_cast<uint4 *>(o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                *reinterpret_cast<uint4 *>(o + 1024) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                const uint32_t bt[8] = {__float_as_uint(v0.x), __float_as_uint(v0.y), __float_as_uint(v0.z), __float_as_uint(v0.w),
+                                        __float_as_uint(v1.x), __float_as_uint(v1.y), __float_as_uint(v1.z), __float_as_uint(v1.w)};
+                uint32_t m = 0u;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) m = (bt[q] & 0x7fffffffu) > m ? (bt[q] & 0x7fffffffu) : m;
+                if (m) atomicMax(s_amax + (int)((gr >> 5) - rb0), m);
+            }
+        __syncthreads();
+        if (amax)
+            for (int e = tid; e < nrb; e += nthr)
+                if (s_amax[e]) atomicMax(amax + rb0 + e, s_amax[e]);
+    }
     constexpr int PC = ORL_CH / 2;
     for (int t = tid; t < ptiles * 4 * PC; t += nthr) {
         const int pair = t % PC, w = (t / PC) & 3, pt = t / (4 * PC);
@@ -477,10 +536,11 @@ static constexpr int tgp_orl_lds_mode = 1;
 
 // returns true when the LDS form was launched
 static bool orl_lds_launch(const float *feat, int ldf, const int32_t *idx, int B, int n, int k, int C, float *partial, int ptiles,
-                           hipStream_t stream, int &rc)
+                           hipStream_t stream, int &rc, char *planes = nullptr, int kts = 0, uint32_t *amax = nullptr,
+                           const float *xyz_tile = nullptr)
 {
     rc = 0;
-    const size_t lds = ((size_t)n * ORL_CH + (size_t)ptiles * 4 * ORL_CH) * sizeof(float);
+    const size_t lds = ((size_t)n * ORL_CH + (size_t)ptiles * 4 * ORL_CH + (planes ? n / 32 + 4 : 0)) * sizeof(float);
     if (!tgp_orl_lds_mode || lds > 72 * 1024 || C % ORL_CH) return false;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
@@ -494,7 +554,7 @@ static bool orl_lds_launch(const float *feat, int ldf, const int32_t *idx, int B
     const int slots = ptiles * 4 * (ORL_CH / 2);
     const int threads = slots >= 768 ? 1024 : (slots >= 384 ? 512 : 256);
     hipLaunchKernelGGL(orl_lds_kernel, dim3(tgp_xcd_grid(B, C / ORL_CH)), dim3(threads), lds, stream, feat, ldf, idx, B, n, k, C, partial,
-                       ptiles);
+                       ptiles, planes, kts, amax, xyz_tile);
     rc = TGP_LAUNCH_RESULT();
     return true;
 }
@@ -589,6 +649,30 @@ extern "C" int tgp_orl_rowbias(const float *feat, int ldf, const int32_t *idx, i
         if (lrc) return lrc;
     } else if (C == 128) ORL_GO(128) else if (C == 256) ORL_GO(256) else ORL_GO(512)
 #undef ORL_GO
+    hipLaunchKernelGGL(orl_finish_project_kernel, dim3(B, C / 64), dim3(256), 0, tgp_hs(stream), partial, n, C, ptiles, w2t, g_out,
+                       rb);
+    return TGP_LAUNCH_RESULT();
+}
+
+// tgp_orl_rowbias that also leaves feat -- the A operand of the layer's last GEMM -- as blocked fp16 planes (see orl_lds_kernel);
+// only where the LDS form serves the shape: TGP_EUNSUPPORTED otherwise (the caller then uses tgp_orl_rowbias and an fp32 operand)
+extern "C" int tgp_orl_rowbias_planes(const float *feat, int ldf, const int32_t *idx, int B, int n, int k, int C, float *partial,
+                                      const float *w2t, float *g_out, float *rb, void *planes, int kts, uint32_t *amax,
+                                      const float *xyz_tile, tgp_stream_t stream)
+{
+    TGP_REQUIRE(feat && idx && partial && w2t && rb && planes && B > 0 && n > 0 && k > 0);
+    if (k > GC_MAXK || !(C == 128 || C == 256 || C == 512)) return TGP_EUNSUPPORTED;
+    TGP_REQUIRE(ldf >= C && (ldf & 3) == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(partial) & 15) == 0 && (reinterpret_cast<uintptr_t>(planes) & 15) == 0);
+    TGP_REQUIRE(kts >= C / 16 + (xyz_tile ? 1 : 0));
+    const int ptiles = tgp_cdiv(n, ORL_PTS);
+    const size_t lds = ((size_t)n * ORL_CH + (size_t)ptiles * 4 * ORL_CH + n / 32 + 4) * sizeof(float);
+    if (!tgp_orl_lds_mode || lds > 72 * 1024) return TGP_EUNSUPPORTED;
+    int lrc = 0;
+    if (!orl_lds_launch(feat, ldf, idx, B, n, k, C, partial, ptiles, tgp_hs(stream), lrc, reinterpret_cast<char *>(planes), kts, amax,
+                        xyz_tile))
+        return TGP_EUNSUPPORTED;
+    if (lrc) return lrc;
     hipLaunchKernelGGL(orl_finish_project_kernel, dim3(B, C / 64), dim3(256), 0, tgp_hs(stream), partial, n, C, ptiles, w2t, g_out,
                        rb);
     return TGP_LAUNCH_RESULT();

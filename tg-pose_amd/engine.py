@@ -76,6 +76,8 @@ def pack_encoder(sd, e, device):
     # and a GEMM launch of its own (30 us of the serial forward)
     c0["w1x"] = torch.cat([c0["w1"], c0["ste"]], dim=1).contiguous()                   # (128, 132)
     c0["w1x_s"] = ops.split_w(c0["w1x"])
+    if ops.planes_on():
+        c0["w1x_p"] = ops.planes_w(c0["w1x"])
     conv.append(c0)
     for i, (cin, cout) in enumerate(LEVEL_CH, start=1):
         p = e + "conv_%d." % i
@@ -90,6 +92,8 @@ def pack_encoder(sd, e, device):
         w2 = sd[p + "conv2.weight"][:, :, 0]
         c["w1"], c["w2"] = w2[:, :cout].contiguous(), w2[:, cout:].contiguous()
         c["w1_s"] = ops.split_w(c["w1"])
+        if ops.planes_on():
+            c["w1_p"] = ops.planes_w(c["w1"])
         c["w2t"] = c["w2"].t().contiguous()
         if i <= 3:
             c["scale"], c["shift"] = _bn_fold(sd, e + "bn%d" % i)
@@ -301,17 +305,23 @@ class Graphs(object):
         return idx
 
 
-def surface_layer(c, xyz, idx_rf, idx_orl, out, scale=None, shift=None, act=None, out_p=None):
+def surface_layer(c, xyz, idx_rf, idx_orl, out, scale=None, shift=None, act=None, out_p=None, amax_ws=None):
     """HSlayer_surface.forward (gcn3d.py:78-89) + the caller's activation, written to `out` (B,n,C) view (and, out_p, as the fp16
     planes the next layer's projection GEMM stages by LDS-DMA)."""
     B, n, _ = xyz.shape
     C = c["C"]
     gx = torch.empty(B, n, C + 4, device=xyz.device, dtype=torch.float32)          # [g | x y z 0]
     g = ops.gconv_surface(xyz, idx_rf, c["sdn"], 7, C, out=gx[:, :, :C], xyz_pad=True)
-    rb = ops.orl_rowbias(g, idx_orl, c["w2t"]) if "w2t" in c else ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
+    gp = None
+    if out_p is not None and "w1x_p" in c and "w2t" in c:
+        # the ORL pooling stages g in LDS anyway: it leaves [g | x y z 0] as fp16 planes, the last GEMM's operand (csrc/gconv.hip)
+        rb, gp = ops.orl_rowbias(g, idx_orl, c["w2t"], planes=ops.Planes(B * n, C + 4, xyz.device, amax_buf=amax_ws), xyz_tile=xyz)
+    else:
+        rb = ops.orl_rowbias(g, idx_orl, c["w2t"]) if "w2t" in c else ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
     # conv2(cat[g, global]) + g + STE(xyz) (gcn3d.py:87-89,108-112): W1 g + STE xyz is one product over the padded row
     ops.linear_rows(gx, c["w1x"], out=out, rowbias=rb, rows_per_obj=n, res1=g, scale=scale, shift=shift,
-                    act=0 if act is None else 1, slope=0.0, w_split=c.get("w1x_s"), k_alg=C + 3, c_planes=out_p)
+                    act=0 if act is None else 1, slope=0.0, w_split=c.get("w1x_s"), k_alg=C + 3, c_planes=out_p,
+                    a_planes=gp, w_planes=c.get("w1x_p") if gp is not None else None)
     return out
 
 
@@ -334,7 +344,7 @@ def _beside(device, fn, tag="knn"):
     return res, join
 
 
-def hs_layer(c, xyz, fmap, idx_rf, idx_orl, out, scale=None, shift=None, act=None, fmap_p=None, out_p=None, out_col0=0):
+def hs_layer(c, xyz, fmap, idx_rf, idx_orl, out, scale=None, shift=None, act=None, fmap_p=None, out_p=None, out_col0=0, amax_ws=None):
     """HS_layer.forward (gcn3d.py:142-155) + the caller's BatchNorm(eval)/ReLU, written to `out`.
     idx_rf / idx_orl may be callables: they are then evaluated on a side stream (the feature-space kNN -- distance GEMM +
     selection -- and the level's xyz kNN depend only on the layer's inputs) while this stream runs the projection GEMM."""
@@ -354,9 +364,14 @@ def hs_layer(c, xyz, fmap, idx_rf, idx_orl, out, scale=None, shift=None, act=Non
     if join is not None:
         torch.cuda.current_stream(xyz.device).wait_event(join)
     g = ops.gconv_hs(xyz, idx_rf, proj9, c["sdn"], 7, C)
-    rb = ops.orl_rowbias(g, idx_orl, c["w2t"]) if "w2t" in c else ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
+    gp = None
+    if amax_ws is not None and "w1_p" in c and "w2t" in c:
+        rb, gp = ops.orl_rowbias(g, idx_orl, c["w2t"], planes=ops.Planes(B * n, C, xyz.device, amax_buf=amax_ws))
+    else:
+        rb = ops.orl_rowbias(g, idx_orl, c["w2t"]) if "w2t" in c else ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
     ops.linear_rows(g, c["w1"], out=out, rowbias=rb, rows_per_obj=n, res1=g, res2=proj9[:, :, 8 * C:], scale=scale,
-                    shift=shift, act=0 if act is None else 1, slope=0.0, w_split=c.get("w1_s"), c_planes=out_p, cp_col0=out_col0)
+                    shift=shift, act=0 if act is None else 1, slope=0.0, w_split=c.get("w1_s"), c_planes=out_p, cp_col0=out_col0,
+                    a_planes=gp, w_planes=c.get("w1_p") if gp is not None else None)
     return out
 
 
@@ -386,11 +401,11 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, 
     pl = arena.planes(B, N, N1, N2) if (arena is not None and factored and ops.planes_on()) else {}
     fm0 = feat[:, :, 0:128]
     surface_layer(cv[0], xyz, graphs.get("conv_0.rf", lambda: xyz_graph(0, xyz, kmax)),
-                  graphs.get("conv_0.orl_xyz", lambda: xyz_graph(0, xyz, kmax)), fm0, act="relu", out_p=pl.get("fm0"))
+                  graphs.get("conv_0.orl_xyz", lambda: xyz_graph(0, xyz, kmax)), fm0, act="relu", out_p=pl.get("fm0"), amax_ws=pl.get("amax_g0"))
     fm1 = feat[:, :, 128:256]
     hs_layer(cv[1], xyz, fm0, lambda: graphs.get("conv_1.rf", lambda: ops.knn_feat(fm0, kmax)),
              graphs.get("conv_1.orl_xyz", lambda: xyz_graph(0, xyz, kmax)), fm1, cv[1]["scale"], cv[1]["shift"], "relu",
-             fmap_p=pl.get("fm0"))
+             fmap_p=pl.get("fm0"), amax_ws=pl.get("amax_g1"))
     v1, fp1 = ops.pool(xyz, fm1, graphs.get("pool_1.xyz", lambda: xyz_graph(0, xyz, kmax)), s1, kpool=4)
     if pl:
         ops.planes_split(fp1.view(B * N1, -1), out=pl["fp1"])
@@ -400,11 +415,11 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, 
     fm2, fm3 = fm23[:, :, :256], fm23[:, :, 256:]
     hs_layer(cv[2], v1, fp1, lambda: graphs.get("conv_2.rf", lambda: ops.knn_feat(fp1, k1)),
              lambda: graphs.get("conv_2.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm2, cv[2]["scale"], cv[2]["shift"], "relu",
-             fmap_p=pl.get("fp1"), out_p=pl.get("fm23"), out_col0=0)
+             fmap_p=pl.get("fp1"), out_p=pl.get("fm23"), out_col0=0, amax_ws=pl.get("amax_g2"))
     # (conv_3 reads the first 256 columns of the fm_2 | fm_3 planes, whose per-block magnitudes cover fm_2 alone at this point)
     hs_layer(cv[3], v1, fm2, lambda: graphs.get("conv_3.rf", lambda: ops.knn_feat(fm2, k1)),
              graphs.get("conv_3.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm3, cv[3]["scale"], cv[3]["shift"], "relu",
-             fmap_p=pl.get("fm23"), out_p=pl.get("fm23"), out_col0=256)
+             fmap_p=pl.get("fm23"), out_p=pl.get("fm23"), out_col0=256, amax_ws=pl.get("amax_g3"))
     v2, fp2 = ops.pool(v1, fm3, graphs.get("pool_2.xyz", lambda: xyz_graph(1, v1, k1)), s2, kpool=4)
     if pl:
         ops.planes_split(fp2.view(B * N2, -1), out=pl["fp2"])
@@ -429,7 +444,7 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, 
     k2 = min(kmax, N2 // 8)
     fm4 = torch.empty(B, N2, 512, device=dev, dtype=torch.float32)
     hs_layer(cv[4], v2, fp2, lambda: graphs.get("conv_4.rf", lambda: ops.knn_feat(fp2, k2)),
-             lambda: graphs.get("conv_4.orl_xyz", lambda: xyz_graph(2, v2, k2)), fm4, fmap_p=pl.get("fp2"), out_p=pl.get("fm4"))
+             lambda: graphs.get("conv_4.orl_xyz", lambda: xyz_graph(2, v2, k2)), fm4, fmap_p=pl.get("fp2"), out_p=pl.get("fm4"), amax_ws=pl.get("amax_g4"))
 
     near1 = graphs.get("up_1", lambda: ops.nn1(xyz, v1)).view(B, N)
     near2 = graphs.get("up_2", lambda: ops.nn1(xyz, v2)).view(B, N)
@@ -464,10 +479,10 @@ class Arena(object):
     def __init__(self, B, dev, N=0):
         n5, n2, nb = B * 1024, 3 * B * 256, B * FEAT_LD
         # (round 4) + the per-32-row-block magnitudes of the activations that travel as fp16 planes (Arena.planes): five tensors
-        # of B*N rows, two of B*N/4, two of B*N/16
+        # of B*N rows, two of B*N/4, two of B*N/16, and the five graph-convolution outputs (the layers' last GEMM operands)
         N1 = int(N / 4)
         blk = lambda rows: (rows + 31) // 32
-        na = 5 * blk(B * N) + 2 * blk(B * N1) + 2 * blk(B * int(N1 / 4)) if N else 0
+        na = 7 * blk(B * N) + 4 * blk(B * N1) + 3 * blk(B * int(N1 / 4)) if N else 0
         buf = torch.zeros(n5 + n2 + 8 + nb + na, device=dev, dtype=torch.int32)
         self.keys5 = buf[:n5].view(B, 1024)
         self.keys2 = buf[n5:n5 + n2].view(3, B, 256)
@@ -484,13 +499,18 @@ class Arena(object):
             dev = self.amax.device
             spec = (("fm0", B * N, 128), ("fine", B * N, FINE_K), ("d1", B * N, 512), ("d2", B * N, 512), ("d3", B * N, 256),
                     ("fp1", B * N1, 128), ("fm23", B * N1, 512), ("fp2", B * N2, 256), ("fm4", B * N2, 512))
-            need = sum((rows + 31) // 32 for _, rows, _ in spec)
+            need = sum((rows + 31) // 32 for _, rows, _ in spec) + 2 * ((B * N + 31) // 32) + 2 * ((B * N1 + 31) // 32) + (B * N2 + 31) // 32
             if self.amax.numel() < need:
                 raise RuntimeError("Arena built without room for the planes' magnitudes")
             o, self._pl = 0, {}
             for name, rows, K in spec:
                 nb = (rows + 31) // 32
                 self._pl[name] = ops.Planes(rows, K, dev, amax_buf=self.amax[o:o + nb])
+                o += nb
+            # magnitude words of the graph convolutions' outputs (their planes are allocated by the layers)
+            for name, rows in (("amax_g0", B * N), ("amax_g1", B * N), ("amax_g2", B * N1), ("amax_g3", B * N1), ("amax_g4", B * N2)):
+                nb = (rows + 31) // 32
+                self._pl[name] = self.amax[o:o + nb]
                 o += nb
         return self._pl
 

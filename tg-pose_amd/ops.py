@@ -190,17 +190,27 @@ def orl_global(feat, idx):
 
 
 @_timed("graph")
-def orl_rowbias(feat, idx, w2t):
-    """feat (B,n,C), idx (B,n,k), w2t (C,C) = W2^T -> rb (B,C) = mean_i max_j feat[idx] @ W2^T"""
+def orl_rowbias(feat, idx, w2t, planes=None, xyz_tile=None):
+    """feat (B,n,C), idx (B,n,k), w2t (C,C) = W2^T -> rb (B,C) = mean_i max_j feat[idx] @ W2^T.
+    planes (a Planes of B*n rows): feat is also written as fp16 planes -- it is the A operand of the layer's last GEMM -- by the
+    kernel that stages it in LDS anyway (tgp_orl_rowbias_planes; xyz_tile (B,n,3): one more K-tile (x, y, z, 0 ...) behind the C
+    channels).  Returns (rb, planes or None): None where that form does not serve the shape and nothing was written."""
     feat, ldf = _rows(feat, "feat")
     _i32(idx, "idx")
     B, n, C = feat.shape
     k = idx.shape[2]
     partial = torch.empty(_lib.lib().tgp_orl_partial_floats(B, n, C), device=feat.device, dtype=torch.float32)
     rb = torch.empty(B, C, device=feat.device, dtype=torch.float32)
+    if planes is not None:
+        rc = _lib.lib().tgp_orl_rowbias_planes(_p(feat), ldf, _p(idx), B, n, k, C, _p(partial), _p(w2t), None, _p(rb), _p(planes.buf),
+                                               planes.kt, _p(planes.amax), _p(xyz_tile), _stream(feat))
+        if rc == 0:
+            return rb, planes
+        if rc != -2:
+            check(rc, "tgp_orl_rowbias_planes")
     check(_lib.lib().tgp_orl_rowbias(_p(feat), ldf, _p(idx), B, n, k, C, _p(partial), _p(w2t), None, _p(rb), _stream(feat)),
           "tgp_orl_rowbias")
-    return rb
+    return (rb, None) if planes is not None else rb
 
 
 @_timed("graph")
