@@ -214,6 +214,13 @@ typedef struct tgp_gemm_args {
     const void *W_planes; int w_kt;
     void *C_planes; int c_kt; int cp_col0; uint32_t *c_amax;
     int pp_config;
+    /* (ABI 5) Planes-only tensors.  With C_planes, C and colmax_keys may both be NULL: the result exists as planes only.  A launch
+     * whose A_planes come without the fp32 operand (A == NULL) cannot recompute a tile that its magnitude words put outside fp16's
+     * comfortable range: it computes the tile on the split anyway and sets *range_flag = 1 (device int, zeroed by the caller;
+     * required then) -- the caller follows the chain with its fp32 form predicated on that flag (`pred`), as tgp_heads_fused's
+     * callers do.  A chain of layers whose activations feed only the next GEMM (the decoder, FaceRecon.py:112-117) then writes and
+     * reads 4 bytes per element instead of 8 + 4. */
+    int *range_flag;
 } tgp_gemm_args;
 
 /* W (rows, K) fp32, row stride ld -> out[rows][ldo/16][3][16] bf16: per 16-wide K-tile the hi, mid and lo terms
@@ -588,6 +595,14 @@ typedef struct tgp_heads_fused_args {
      * heads x 128-point workgroups, one per CU and round: B = 32, N = 1028 is 771 workgroups = 3.01 rounds of 256, and the
      * three workgroups of the fourth round cost a quarter of the kernel's time (profiles/r02_g_heads_fused_stamps.txt). */
     int rows;
+    /* (ABI 5) fine_planes (may be NULL): the same features as blocked fp16 planes (tgp_gemm_args.A_planes' layout, fine_kt >= 17
+     * K-tiles per row block, columns K.. zero; fine_amax: the per-row-block magnitude words, may be NULL): the kernel then loads its
+     * points' operand fragments as 1 KB runs instead of splitting fp32 rows -- same bits.  `fine` is still required (the repair). */
+    const void *fine_planes; int fine_kt; const uint32_t *fine_amax;
+    /* (ABI 5) workgroups: 0 = one per CU, each walking its share of the heads x 128-point tiles (the next tile's operands arrive
+     * during the current tile's last channel block); > 0: that many (>= the tile count: one tile per workgroup, the round-3 form;
+     * a measurement handle).  Results do not depend on it. */
+    int workgroups;
 } tgp_heads_fused_args;
 int tgp_heads_fused(const tgp_heads_fused_args *args, tgp_stream_t stream);
 /* conv -> BatchNorm(eval) -> LeakyReLU -> max over each object's points of a factored layer whose activation only feeds the max

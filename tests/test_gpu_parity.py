@@ -3517,3 +3517,87 @@ def test_orl_rowbias_planes_equal_split_of_the_table(ops, B, n, C, k, with_xyz):
     rows_ok = (torch.arange(nblk * 32, device=DEV) < B * n).view(nblk, 1, 1, 1, 32, 1)
     assert bool(((P.buf.view(nblk, P.kt, 2, 2, 32, 16) == want.view(nblk, P.kt, 2, 2, 32, 16)) | ~rows_ok).all())
     assert torch.equal(P.amax, amax)
+
+
+@pytest.mark.parametrize("B,N", [(9, 1028), (3, 300)])
+def test_heads_fused_persistent_and_planes_forms_bit_identical(ops, B, N):
+    """The fused heads kernel as a persistent grid (one workgroup per CU walking its tiles, the next tile's operands prefetched under
+    the current tile's last channel block) against one workgroup per tile, and with the points' fragments loaded from the fine
+    buffer's fp16 planes against the in-kernel split of its fp32 rows: the same MFMA sequence per wave either way -- every output
+    bit for bit.  B = 9, N = 1028 gives 219 tiles: under one per CU; B = 3, N = 300 a partial last 32-row block."""
+    from tgpose_amd import FLAGS
+    net = _net(12)
+    FLAGS.train = 0
+    pts, obj = synth_points(B, N, 41)
+    torch.manual_seed(8)
+    i1 = torch.randperm(N)[: N // 4]
+    smp = (i1, torch.randperm(N // 4)[: N // 16])
+    got = []
+    for persistent, planes in ((True, True), (False, True), (True, False), (False, False)):
+        old = ops.HEADS_PERSISTENT, ops.HEADS_PLANES
+        ops.HEADS_PERSISTENT, ops.HEADS_PLANES = persistent, planes
+        try:
+            with torch.no_grad():
+                got.append({k: v.clone() for k, v in net(g(pts), g(obj), sample_idx=smp).items()})
+        finally:
+            ops.HEADS_PERSISTENT, ops.HEADS_PLANES = old
+    for other in got[1:]:
+        for k in got[0]:
+            assert torch.equal(got[0][k], other[k]), k
+
+
+def test_heads_fused_persistent_many_tiles_per_workgroup(ops):
+    """B = 40 objects of 1028 points: 3 x 322 = 966 tiles on 256 workgroups -- every workgroup walks three or four tiles, heads change
+    inside a workgroup's walk -- against one workgroup per tile."""
+    from tgpose_amd import FLAGS
+    net = _net(13)
+    FLAGS.train = 0
+    pts, obj = synth_points(40, 1028, 43)
+    got = []
+    torch.manual_seed(9)
+    i1 = torch.randperm(1028)[:257]
+    smp = (i1, torch.randperm(257)[:64])
+    for persistent in (True, False):
+        old, ops.HEADS_PERSISTENT = ops.HEADS_PERSISTENT, persistent
+        try:
+            with torch.no_grad():
+                got.append({k: v.clone() for k, v in net(g(pts), g(obj), sample_idx=smp).items()})
+        finally:
+            ops.HEADS_PERSISTENT = old
+    for k in got[0]:
+        assert torch.equal(got[0][k], got[1][k]), k
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e6, 1e-5])
+def test_decoder_chain_on_planes_only(ops, scale):
+    """engine.DEC_PLANES_ONLY: the decoder's inner activations exist as fp16 planes only (each layer's epilogue writes the next one's
+    operand; no fp32 copies).  scale 1: bit-identical reconstruction to the forward without planes.  scale 1e6 / 1e-5 on the first
+    decoder layer's BatchNorm puts its activation beyond fp16's range / under 2^-4 everywhere: the consuming layer cannot recompute
+    such tiles (it has no fp32 operand), raises the chain's flag on the device, and the predicated fp32 chain supplies the result --
+    again the bits of the forward without planes, nothing read back."""
+    from tgpose_amd import PoseNet9D, seeded_state_dict, FLAGS, engine
+    sd = seeded_state_dict(16)
+    for k in ("weight", "bias"):
+        sd["face_all.decoder.conv1d_block.1." + k] = sd["face_all.decoder.conv1d_block.1." + k] * scale
+    net = PoseNet9D()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    FLAGS.train = 0
+    B, N = 3, 1028
+    pts, obj = synth_points(B, N, 45)
+    torch.manual_seed(10)
+    i1 = torch.randperm(N)[: N // 4]
+    smp = (i1, torch.randperm(N // 4)[: N // 16])
+    pk = net.packed(DEV)
+    got = []
+    for planes, only in ((True, True), (False, False)):
+        old = ops.PLANES, engine.DEC_PLANES_ONLY
+        ops.PLANES, engine.DEC_PLANES_ONLY = planes, only
+        try:
+            probe = {}
+            with torch.no_grad():
+                engine.posenet_forward(pk, g(pts), g(obj), False, sample_idx=smp, probe=probe)
+            got.append(probe["recon"].clone())
+        finally:
+            ops.PLANES, engine.DEC_PLANES_ONLY = old
+    assert torch.isfinite(got[0]).all() and torch.equal(got[0], got[1])

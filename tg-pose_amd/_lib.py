@@ -44,6 +44,7 @@ class GemmArgs(ctypes.Structure):
         ("W_planes", c_vp), ("w_kt", c_int),
         ("C_planes", c_vp), ("c_kt", c_int), ("cp_col0", c_int), ("c_amax", c_vp),
         ("pp_config", c_int),
+        ("range_flag", c_vp),
     ]
 
 
@@ -76,6 +77,8 @@ class HeadsFusedArgs(ctypes.Structure):
         ("M", c_int), ("rows_per_obj", c_int), ("B", c_int), ("heads", c_int),
         ("overflow", c_vp),
         ("rows", c_int),
+        ("fine_planes", c_vp), ("fine_kt", c_int), ("fine_amax", c_vp),
+        ("workgroups", c_int),
     ]
 
 

@@ -1251,9 +1251,9 @@ static int launch_main(GemmParams &p, hipStream_t stream)
 
 extern "C" int tgp_gemm_f32(const tgp_gemm_args *a, tgp_stream_t stream)
 {
-    TGP_REQUIRE(a && a->A && a->W && (a->C || a->colmax_keys));
+    TGP_REQUIRE(a && (a->A || a->A_planes) && a->W && (a->C || a->colmax_keys || a->C_planes));
     TGP_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0);
-    TGP_REQUIRE((a->K & 3) == 0 && (a->lda & 3) == 0 && (a->ldw & 3) == 0 && a->lda >= a->K && a->ldw >= a->K);
+    TGP_REQUIRE((a->K & 3) == 0 && (a->ldw & 3) == 0 && a->ldw >= a->K && (!a->A || ((a->lda & 3) == 0 && a->lda >= a->K)));
     TGP_REQUIRE((reinterpret_cast<uintptr_t>(a->A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a->W) & 15) == 0);
     TGP_REQUIRE(a->c_col0 >= 0 && a->c_col0 <= a->N && (!a->C || a->ldc >= a->N - a->c_col0));
     TGP_REQUIRE(!(a->rowbias || a->colmax_keys) || a->rows_per_obj > 0);
@@ -1294,6 +1294,7 @@ extern "C" int tgp_gemm_f32(const tgp_gemm_args *a, tgp_stream_t stream)
         p.Ap = reinterpret_cast<const char *>(a->A_planes), p.a_kt = a->a_kt, p.a_amax = a->a_amax;
         p.Wp = reinterpret_cast<const char *>(a->W_planes), p.w_kt = a->w_kt;
         p.c_scale = a->c_scale;
+        p.range_flag = a->range_flag;
         TGP_REQUIRE(vec_epilogue_ok(p));
         p.vec_epi = 1;
         return tgp_launch_gemm_pp(p, a->pp_config, tgp_hs(stream));

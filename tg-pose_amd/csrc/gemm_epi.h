@@ -80,6 +80,7 @@ struct GemmParams {
     int c_kt, cp_col0;           // K-tiles per row block of Cp; plane column of the launch's output column c_col0
     uint32_t *c_amax;            // per 32-row block of the result: atomicMax of the bits of |v| over the columns written
     int pp_tiles_m, pp_tiles_n;  // tile grid of the pre-split kernel
+    int *range_flag;             // planes-only operand (A == NULL): raised instead of the exact recomputation
 };
 
 // byte offset of (row, 4 consecutive plane columns pc .. pc + 3, pc % 4 == 0) in the hi plane of a blocked-planes buffer; lo is + 1024

@@ -61,6 +61,12 @@ __device__ __forceinline__ void gemm_pp_tile(const GemmParams &p, const int m0, 
             am = v > am ? v : am;
         }
         exact = am >= 0x477fe000u || (am != 0u && am < 0x3d800000u);       // >= 65504 | all below 2^-4 (and not all zero)
+        if (exact && !p.A) {
+            // a planes-only operand: nothing to recompute from.  The tile runs on the split (its result is wrong or imprecise) and
+            // the flag tells the caller's predicated fp32 chain to redo the layer(s)
+            if (threadIdx.x == 0) atomicOr(p.range_flag, 1);
+            exact = false;
+        }
     }
     if (!exact) {
         // ---- staging: piece c = j * NW + wave of a stage is this wave's j-th instruction
@@ -411,7 +417,7 @@ int tgp_launch_gemm_pp(GemmParams &p, int config, hipStream_t stream)
 {
     TGP_REQUIRE(p.Ap && p.Wp && p.batch == 1 && !p.ksplit && !p.a_scale);
     TGP_REQUIRE(p.a_kt >= (p.K + 15) / 16 && p.w_kt >= (p.K + 15) / 16);
-    TGP_REQUIRE(!p.a_amax || (p.A && p.W));                 // the guard's exact path reads the fp32 operands
+    TGP_REQUIRE(!p.a_amax || (p.A && p.W) || (!p.A && p.range_flag));    // the guard's exact path reads the fp32 operands
     if (!config) config = pp_auto_config(p);
     // the epilogue keeps two objects per wave tile: its per-object bias / max over points need rows_per_obj >= the wave tile's rows
     if (p.rowbias || p.cm) {

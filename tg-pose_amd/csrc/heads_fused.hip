@@ -46,7 +46,8 @@ struct HeadsParams {
     uint32_t *keys;                       // (heads, B, 256)
     int *overflow;
     int M, rows_per_obj, B, heads, tiles;
-    unsigned long long *stamps;           // development builds: per workgroup, wave 0's accumulated time per phase
+    // (round 4) the points' features as blocked fp16 planes (tgp_gemm_args.A_planes' layout): fragments load as 1 KB runs, no split
+    const char *fine_pl; int fine_kt; const uint32_t *fine_amax;
 };
 
 __device__ __forceinline__ void hf_split(const float4 v, uint2 &hi, uint2 &lo)
@@ -59,55 +60,73 @@ __device__ __forceinline__ void hf_split(const float4 v, uint2 &hi, uint2 &lo)
     lo = __builtin_bit_cast(uint2, l);
 }
 
+// PERSISTENT (round 4): the grid is one workgroup per CU and every workgroup walks the tiles t = blockIdx.x, + gridDim.x, ... (head-major,
+// so the workgroups running at any moment share a head's weights in L2).  As one workgroup per tile, a tile was prologue (34 strided
+// loads per lane + their split, the first weight block's DMA from cold) -> 32 channel blocks -> epilogue, and a quarter of a
+// workgroup's ~125 us lay outside the channel-block loop with nothing to overlap it (one wave per SIMD, 144 KB of LDS: nothing else
+// fits on the CU).  Here the next tile's operands arrive during the current tile's LAST channel block: its first weight block by
+// the same double-buffered DMA that feeds every block (the chain of blocks simply continues across tiles), its points' fragments by
+// loads issued right after the last use of the current ones (conv1 of block 31) and in flight under conv2 of block 31 and the
+// tile's epilogue.
+template <bool PLANES>
 __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char hf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int hd = blockIdx.x / p.tiles, ptile = blockIdx.x % p.tiles;
-    const int m0 = ptile * 128 + wave * 32;                     // the wave's first point (may lie past M: then the wave only helps staging)
-    const int row = min(m0 + r, p.M - 1);
+    const int total = p.heads * p.tiles;
+    int t = blockIdx.x;
+    if (t >= total) return;
 
-    // ---- the wave's points as B fragments: fp16 hi / lo planes of fine[row][16 s + 8 h .. + 7]
-    uint4 bh[HF_STEPS], bl[HF_STEPS];
-    float amax = 0.f, poison = 0.f;                             // range guard: the largest magnitude this lane splits into fp16; NaN once
-                                                                // it has met a NaN or an infinity (0 x inf = NaN; fmaxf drops NaNs)
-    {
-        const float *fr = p.fine + (int64_t)row * p.ldf + 8 * h;
+    uint4 bh[HF_STEPS], bl[HF_STEPS];     // the wave's points as B fragments: fp16 hi / lo planes of fine[row][16 s + 8 h .. + 7]
+    // range guard state of the tile being loaded: the largest magnitude this lane splits into fp16 (NaN-poisoned once it met a NaN
+    // or an infinity); with planes, the producer's per-block magnitude word says the same
+    float amax_ld = 0.f, poison_ld = 0.f;
+    const int nblk = (p.M + 31) >> 5;
+    auto load_b = [&](const int ptile) {
+        const int m0 = ptile * 128 + wave * 32;
+        amax_ld = 0.f, poison_ld = 0.f;
+        if constexpr (PLANES) {
+            const int rb = min(m0 >> 5, nblk - 1);
+            const char *src = p.fine_pl + (int64_t)rb * p.fine_kt * 2048 + lane * 16;
 #pragma unroll
-        for (int s = 0; s < HF_STEPS; ++s) {
-            float4 v0 = *reinterpret_cast<const float4 *>(fr + 16 * s), v1 = *reinterpret_cast<const float4 *>(fr + 16 * s + 4);
-            if (s == HF_STEPS - 1) {                            // the K tail: columns >= K are not the caller's to define
-                const int k0 = 16 * s + 8 * h;
-                v0.x = k0 + 0 < p.K ? v0.x : 0.f, v0.y = k0 + 1 < p.K ? v0.y : 0.f, v0.z = k0 + 2 < p.K ? v0.z : 0.f, v0.w = k0 + 3 < p.K ? v0.w : 0.f;
-                v1.x = k0 + 4 < p.K ? v1.x : 0.f, v1.y = k0 + 5 < p.K ? v1.y : 0.f, v1.z = k0 + 6 < p.K ? v1.z : 0.f, v1.w = k0 + 7 < p.K ? v1.w : 0.f;
+            for (int s = 0; s < HF_STEPS; ++s) {
+                bh[s] = *reinterpret_cast<const uint4 *>(src + s * 2048);
+                bl[s] = *reinterpret_cast<const uint4 *>(src + s * 2048 + 1024);
             }
-            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))));
-            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w))));
-            poison += 0.f * (((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w)));
-            uint2 h0, l0, h1, l1;
-            hf_split(v0, h0, l0), hf_split(v1, h1, l1);
-            bh[s] = make_uint4(h0.x, h0.y, h1.x, h1.y), bl[s] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            if (m0 + 32 > p.M) {                                    // (wave-uniform) rows past the end were never written: zero them
+                const bool dead = m0 + r >= p.M;
+#pragma unroll
+                for (int s = 0; s < HF_STEPS; ++s)
+                    if (dead) bh[s] = make_uint4(0u, 0u, 0u, 0u), bl[s] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            const uint32_t am = p.fine_amax ? p.fine_amax[rb] : 0x3f800000u;
+            amax_ld = __uint_as_float(am < 0x7f800000u ? am : 0x7f800000u);   // inf for an inf / NaN block: !(amax < 65504) below
+        } else {
+            const int row = min(m0 + r, p.M - 1);
+            const float *fr = p.fine + (int64_t)row * p.ldf + 8 * h;
+#pragma unroll
+            for (int s = 0; s < HF_STEPS; ++s) {
+                float4 v0 = *reinterpret_cast<const float4 *>(fr + 16 * s), v1 = *reinterpret_cast<const float4 *>(fr + 16 * s + 4);
+                if (s == HF_STEPS - 1) {                            // the K tail: columns >= K are not the caller's to define
+                    const int k0 = 16 * s + 8 * h;
+                    v0.x = k0 + 0 < p.K ? v0.x : 0.f, v0.y = k0 + 1 < p.K ? v0.y : 0.f, v0.z = k0 + 2 < p.K ? v0.z : 0.f, v0.w = k0 + 3 < p.K ? v0.w : 0.f;
+                    v1.x = k0 + 4 < p.K ? v1.x : 0.f, v1.y = k0 + 5 < p.K ? v1.y : 0.f, v1.z = k0 + 6 < p.K ? v1.z : 0.f, v1.w = k0 + 7 < p.K ? v1.w : 0.f;
+                }
+                amax_ld = fmaxf(amax_ld, fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))));
+                amax_ld = fmaxf(amax_ld, fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w))));
+                poison_ld += 0.f * (((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w)));
+                uint2 h0, l0, h1, l1;
+                hf_split(v0, h0, l0), hf_split(v1, h1, l1);
+                bh[s] = make_uint4(h0.x, h0.y, h1.x, h1.y), bl[s] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            }
         }
-    }
-    const float amax_in = amax;                                 // the largest magnitude among this lane's input features
-    const int i1 = p.idx1[row], i2 = p.idx2[row];
-    const float *g1p = p.p1 + (int64_t)i1 * p.ldp1 + hd * HF_C1 + 4 * h;       // + cb * 32 + 8 m: four channels of the lane
-    const float *g2p = p.p2 + (int64_t)i2 * p.ldp2 + hd * HF_C1 + 4 * h;
+    };
 
-    hf32x16 acc2[HF_C2 / 32];
-#pragma unroll
-    for (int ob = 0; ob < HF_C2 / 32; ++ob)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc2[ob][e] = 0.f;
-
-    // ---- staging of channel block cb: conv1 weight rows, their epilogue vectors, the permuted conv2 weight block, by LDS-DMA
-    // (global_load_lds_dwordx4: no register destination -- through registers the 17 staged 16-byte pieces per thread did not fit
-    // beside the operand fragments and accumulators, the compiler parked them in scratch and serialised every load: 1.6 ms).
-    // A wave-instruction fills 1 KB of LDS linearly (wave-uniform base + 16 x lane), so the padded image is written as it lies:
-    // kilobyte j of the buffer is wave (j % 4)'s instruction j / 4; a lane that lands on a row's padding piece re-reads the row's
-    // last piece.  The 72 instructions of a block are 1152 cycles of the CU's vector-memory path (64 B per clock): issued in one
-    // burst they stalled the waves for 23 of a workgroup's 125 us, so they are issued one at a time between phase 2's MFMA groups.
+    // ---- staging of a channel block: conv1 weight rows, their epilogue vectors, the permuted conv2 weight block, by LDS-DMA
+    // (global_load_lds_dwordx4: no register destination).  A wave-instruction fills 1 KB of LDS linearly (wave-uniform base + 16 x
+    // lane), so the padded image is written as it lies: kilobyte j of the buffer is wave (j % 4)'s instruction j / 4; a lane that
+    // lands on a row's padding piece re-reads the row's last piece.  Issued one at a time between the MFMA groups.
     static_assert(HF_NDMA == 18 && HF_ABYTES / 1024 == 35, "the region tests below");
     int dma_off[HF_NDMA];                                       // the lane's source offset of its j0-th instruction (block-invariant)
 #pragma unroll
@@ -123,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
             dma_off[j0] = (rw * 8 + (pc < 8 ? pc : 7)) * 16;
         }
     }
-    auto dma = [&](int cb, int buf, int j0) {
+    auto dma = [&](const int hd, const int cb, const int buf, const int j0) {
         const int j = j0 * 4 + wave;                             // wave-uniform
         const char *src;
         if (j < 35) src = reinterpret_cast<const char *>(p.wa_s) + ((int64_t)hd * HF_C1 + cb * 32) * (HF_STEPS * 64);
@@ -131,155 +150,166 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
             const float *v = lane < 8 ? p.bias1 : lane < 16 ? p.scale1 : p.shift1;
             src = reinterpret_cast<const char *>(v + hd * HF_C1 + cb * 32);
         } else src = reinterpret_cast<const char *>(p.w2p) + ((int64_t)hd * HF_NCB + cb) * (HF_C2 * 128);
-        // As inline assembly: through the builtin the compiler, which cannot know that the DMA fills the OTHER buffer, drained
-        // vmcnt before every LDS read that followed one (phase 2: 52 -> 182 us).  Opaque to its counters, so the waits are written
-        // by hand: vmcnt(0) before the barrier that ends the block; no compiler-visible vector load is in flight meanwhile.
-        // The LDS base travels in m0 as a register-constrained INPUT ("{m0}"): the compiler writes m0 itself and knows it is
-        // live here (round 2 wrote it inside the asm and listed it as a clobber, which the compiler does not promise to honour
-        // for a reserved register); the s_nop covers the one wait state between an m0 write and an LDS-DMA instruction.
+        // inline assembly: opaque to the compiler's counters (no vmcnt(0) before the LDS reads that follow); vmcnt(0) is written by
+        // hand before the barrier that ends a block.  The LDS base travels in m0 as a register-constrained input.
         const uint32_t lds = __builtin_amdgcn_readfirstlane(
             (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)(hf_smem + buf * HF_BUF + j * 1024));
         asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + dma_off[j0]), "{m0}"(lds) : "memory");
     };
+
+    int hd = t / p.tiles, ptile = t - hd * p.tiles;
+    load_b(ptile);
 #pragma unroll
-    for (int j0 = 0; j0 < HF_NDMA; ++j0) dma(0, 0, j0);
+    for (int j0 = 0; j0 < HF_NDMA; ++j0) dma(hd, 0, 0, j0);
     __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0): this wave's DMA has landed
     __syncthreads();
 
-    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, t_prev = p.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
-#define HF_STAMP(i)                                                  \
-    if (p.stamps) {                                                  \
-        const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); \
-        tph[i] += t_now - t_prev, t_prev = t_now;                    \
-    }
-    for (int cb = 0; cb < HF_NCB; ++cb) {
-        const char *base = hf_smem + (cb & 1) * HF_BUF;
-        // the lane's gathered coarse products for this block: consumed after phase 1
-        float4 g1[4], g2[4];
+    int par = 0;                                                // LDS buffer of the current channel block (blocks alternate across tiles too)
+    for (;;) {
+        const int tn = t + (int)gridDim.x;
+        const bool more = tn < total;
+        const int hd_n = more ? tn / p.tiles : hd, ptile_n = more ? tn - hd_n * p.tiles : ptile;
+        const int m0 = ptile * 128 + wave * 32;                 // the wave's first point (may lie past M: then the wave only helps staging)
+        const int row = min(m0 + r, p.M - 1);
+        float amax = amax_ld, poison = poison_ld;
+        const float amax_in = amax_ld;
+        const int i1 = p.idx1[row], i2 = p.idx2[row];
+        const float *g1p = p.p1 + (int64_t)i1 * p.ldp1 + hd * HF_C1 + 4 * h;       // + cb * 32 + 8 m: four channels of the lane
+        const float *g2p = p.p2 + (int64_t)i2 * p.ldp2 + hd * HF_C1 + 4 * h;
+
+        hf32x16 acc2[HF_C2 / 32];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            g1[m] = *reinterpret_cast<const float4 *>(g1p + cb * 32 + 8 * m);
-            g2[m] = *reinterpret_cast<const float4 *>(g2p + cb * 32 + 8 * m);
-        }
-        // ---- phase 1: conv1, 32 channels x 32 points
-        hf32x16 acc1;
+        for (int ob = 0; ob < HF_C2 / 32; ++ob)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
-        const char *arow = base + r * HF_AROW + h * 16;
-        {
-            // fragments two steps ahead of their MFMAs: with one wave per SIMD nothing else hides the LDS latency
-            uint4 fh0 = *reinterpret_cast<const uint4 *>(arow), fl0 = *reinterpret_cast<const uint4 *>(arow + 32);
-            uint4 fh1 = *reinterpret_cast<const uint4 *>(arow + 64), fl1 = *reinterpret_cast<const uint4 *>(arow + 64 + 32);
-#pragma unroll
-            for (int s = 0; s < HF_STEPS; ++s) {
-                uint4 fh2 = fh1, fl2 = fl1;
-                if (s + 2 < HF_STEPS) {
-                    fh2 = *reinterpret_cast<const uint4 *>(arow + (s + 2) * 64);
-                    fl2 = *reinterpret_cast<const uint4 *>(arow + (s + 2) * 64 + 32);
-                }
-                // smallest terms first, as in the tile kernel: lo x hi, hi x lo, hi x hi
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, fl0), __builtin_bit_cast(hf16x8, bh[s]), acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, fh0), __builtin_bit_cast(hf16x8, bl[s]), acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, fh0), __builtin_bit_cast(hf16x8, bh[s]), acc1, 0, 0, 0);
-                // the next block's operands, 8 of the 18 pieces here (the rest in phase 2): they target the other buffer, whose
-                // last readers passed the barrier; the epilogue's wait for its gathered rows covers them too (they are older by then)
-                if (s >= 1 && s <= 8 && cb + 1 < HF_NCB) dma(cb + 1, (cb + 1) & 1, s - 1);
-                __builtin_amdgcn_sched_barrier(0);                // keep the lookahead: do not sink the reads to their uses
-                fh0 = fh1, fl0 = fl1, fh1 = fh2, fl1 = fl2;
-            }
-        }
-        HF_STAMP(0)
-        // ---- epilogue 1: element e of the lane is channel 4 h + (e & 3) + 8 (e >> 2) of the block, point r
-        uint4 a2h[2], a2l[2];
-        {
-            const float *pv = reinterpret_cast<const float *>(base + HF_ABYTES) + 4 * h;
-            uint2 hh[4], ll[4];
+            for (int e = 0; e < 16; ++e) acc2[ob][e] = 0.f;
+
+        for (int cb = 0; cb < HF_NCB; ++cb, par ^= 1) {
+            const char *base = hf_smem + par * HF_BUF;
+            const bool last = cb + 1 == HF_NCB;
+            const bool stage = !last || more;                    // a block follows: this tile's next one, or the next tile's first
+            const int hd_s = last ? hd_n : hd, cb_s = last ? 0 : cb + 1;
+            // the lane's gathered coarse products for this block: consumed after phase 1
+            float4 g1[4], g2[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const float4 b = *reinterpret_cast<const float4 *>(pv + 8 * m), sc = *reinterpret_cast<const float4 *>(pv + 32 + 8 * m),
-                             sh = *reinterpret_cast<const float4 *>(pv + 64 + 8 * m);
-                float4 v = make_float4(acc1[4 * m], acc1[4 * m + 1], acc1[4 * m + 2], acc1[4 * m + 3]);
-                v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
-                v.x += g1[m].x, v.y += g1[m].y, v.z += g1[m].z, v.w += g1[m].w;
-                v.x += g2[m].x, v.y += g2[m].y, v.z += g2[m].z, v.w += g2[m].w;
-                v.x = v.x * sc.x + sh.x, v.y = v.y * sc.y + sh.y, v.z = v.z * sc.z + sh.z, v.w = v.w * sc.w + sh.w;
-                v.x = v.x > 0.f ? v.x : v.x * 0.f, v.y = v.y > 0.f ? v.y : v.y * 0.f;
-                v.z = v.z > 0.f ? v.z : v.z * 0.f, v.w = v.w > 0.f ? v.w : v.w * 0.f;
-                poison += 0.f * ((v.x + v.y) + (v.z + v.w));
-                amax = fmaxf(amax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));     // (v >= 0 after the ReLU)
-                hf_split(v, hh[m], ll[m]);
+                g1[m] = *reinterpret_cast<const float4 *>(g1p + cb * 32 + 8 * m);
+                g2[m] = *reinterpret_cast<const float4 *>(g2p + cb * 32 + 8 * m);
             }
-            a2h[0] = make_uint4(hh[0].x, hh[0].y, hh[1].x, hh[1].y), a2h[1] = make_uint4(hh[2].x, hh[2].y, hh[3].x, hh[3].y);
-            a2l[0] = make_uint4(ll[0].x, ll[0].y, ll[1].x, ll[1].y), a2l[1] = make_uint4(ll[2].x, ll[2].y, ll[3].x, ll[3].y);
-        }
-        HF_STAMP(1)
-        HF_STAMP(2)
-        // ---- phase 2: conv2 partial sums over this block's 32 channels, 32 points x 256 outputs
-        const char *wrow = base + HF_ABYTES + HF_PBYTES + r * HF_WROW + h * 16;
-        {
-            constexpr int NOB = HF_C2 / 32;
-            auto wfrag = [&](int q, int plane) {                  // q = s2 * NOB + ob
-                return *reinterpret_cast<const uint4 *>(wrow + (q % NOB) * 32 * HF_WROW + (q / NOB) * 64 + plane * 32);
-            };
-            uint4 wh0 = wfrag(0, 0), wl0 = wfrag(0, 1), wh1 = wfrag(1, 0), wl1 = wfrag(1, 1);
+            // ---- phase 1: conv1, 32 channels x 32 points
+            hf32x16 acc1;
 #pragma unroll
-            for (int q = 0; q < 2 * NOB; ++q) {
-                uint4 wh2 = wh1, wl2 = wl1;
-                if (q + 2 < 2 * NOB) wh2 = wfrag(q + 2, 0), wl2 = wfrag(q + 2, 1);
-                const int s2 = q / NOB, ob = q % NOB;
-                acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2h[s2]), __builtin_bit_cast(hf16x8, wl0), acc2[ob], 0, 0, 0);
-                acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2l[s2]), __builtin_bit_cast(hf16x8, wh0), acc2[ob], 0, 0, 0);
-                acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2h[s2]), __builtin_bit_cast(hf16x8, wh0), acc2[ob], 0, 0, 0);
-                if (q < HF_NDMA - 8 && cb + 1 < HF_NCB) dma(cb + 1, (cb + 1) & 1, q + 8);   // the other 10, one per MFMA group
-                __builtin_amdgcn_sched_barrier(0);
-                wh0 = wh1, wl0 = wl1, wh1 = wh2, wl1 = wl2;
+            for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
+            const char *arow = base + r * HF_AROW + h * 16;
+            {
+                // fragments two steps ahead of their MFMAs: with one wave per SIMD nothing else hides the LDS latency
+                uint4 fh0 = *reinterpret_cast<const uint4 *>(arow), fl0 = *reinterpret_cast<const uint4 *>(arow + 32);
+                uint4 fh1 = *reinterpret_cast<const uint4 *>(arow + 64), fl1 = *reinterpret_cast<const uint4 *>(arow + 64 + 32);
+#pragma unroll
+                for (int s = 0; s < HF_STEPS; ++s) {
+                    uint4 fh2 = fh1, fl2 = fl1;
+                    if (s + 2 < HF_STEPS) {
+                        fh2 = *reinterpret_cast<const uint4 *>(arow + (s + 2) * 64);
+                        fl2 = *reinterpret_cast<const uint4 *>(arow + (s + 2) * 64 + 32);
+                    }
+                    // smallest terms first, as in the tile kernel: lo x hi, hi x lo, hi x hi
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, fl0), __builtin_bit_cast(hf16x8, bh[s]), acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, fh0), __builtin_bit_cast(hf16x8, bl[s]), acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, fh0), __builtin_bit_cast(hf16x8, bh[s]), acc1, 0, 0, 0);
+                    // the next block's operands, 8 of the 18 pieces here (the rest in phase 2): they target the other buffer, whose
+                    // last readers passed the barrier
+                    if (s >= 1 && s <= 8 && stage) dma(hd_s, cb_s, par ^ 1, s - 1);
+                    __builtin_amdgcn_sched_barrier(0);                // keep the lookahead: do not sink the reads to their uses
+                    fh0 = fh1, fl0 = fl1, fh1 = fh2, fl1 = fl2;
+                }
             }
+            // the current points' fragments have had their last use: the next tile's start to arrive under conv2 and the epilogue
+            if (last && more) load_b(ptile_n);
+            // ---- epilogue 1: element e of the lane is channel 4 h + (e & 3) + 8 (e >> 2) of the block, point r
+            uint4 a2h[2], a2l[2];
+            {
+                const float *pv = reinterpret_cast<const float *>(base + HF_ABYTES) + 4 * h;
+                uint2 hh[4], ll[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float4 b = *reinterpret_cast<const float4 *>(pv + 8 * m), sc = *reinterpret_cast<const float4 *>(pv + 32 + 8 * m),
+                                 sh = *reinterpret_cast<const float4 *>(pv + 64 + 8 * m);
+                    float4 v = make_float4(acc1[4 * m], acc1[4 * m + 1], acc1[4 * m + 2], acc1[4 * m + 3]);
+                    v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+                    v.x += g1[m].x, v.y += g1[m].y, v.z += g1[m].z, v.w += g1[m].w;
+                    v.x += g2[m].x, v.y += g2[m].y, v.z += g2[m].z, v.w += g2[m].w;
+                    v.x = v.x * sc.x + sh.x, v.y = v.y * sc.y + sh.y, v.z = v.z * sc.z + sh.z, v.w = v.w * sc.w + sh.w;
+                    v.x = v.x > 0.f ? v.x : v.x * 0.f, v.y = v.y > 0.f ? v.y : v.y * 0.f;
+                    v.z = v.z > 0.f ? v.z : v.z * 0.f, v.w = v.w > 0.f ? v.w : v.w * 0.f;
+                    poison += 0.f * ((v.x + v.y) + (v.z + v.w));
+                    amax = fmaxf(amax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));     // (v >= 0 after the ReLU)
+                    hf_split(v, hh[m], ll[m]);
+                }
+                a2h[0] = make_uint4(hh[0].x, hh[0].y, hh[1].x, hh[1].y), a2h[1] = make_uint4(hh[2].x, hh[2].y, hh[3].x, hh[3].y);
+                a2l[0] = make_uint4(ll[0].x, ll[0].y, ll[1].x, ll[1].y), a2l[1] = make_uint4(ll[2].x, ll[2].y, ll[3].x, ll[3].y);
+            }
+            // ---- phase 2: conv2 partial sums over this block's 32 channels, 32 points x 256 outputs
+            const char *wrow = base + HF_ABYTES + HF_PBYTES + r * HF_WROW + h * 16;
+            {
+                constexpr int NOB = HF_C2 / 32;
+                auto wfrag = [&](int q, int plane) {                  // q = s2 * NOB + ob
+                    return *reinterpret_cast<const uint4 *>(wrow + (q % NOB) * 32 * HF_WROW + (q / NOB) * 64 + plane * 32);
+                };
+                uint4 wh0 = wfrag(0, 0), wl0 = wfrag(0, 1), wh1 = wfrag(1, 0), wl1 = wfrag(1, 1);
+#pragma unroll
+                for (int q = 0; q < 2 * NOB; ++q) {
+                    uint4 wh2 = wh1, wl2 = wl1;
+                    if (q + 2 < 2 * NOB) wh2 = wfrag(q + 2, 0), wl2 = wfrag(q + 2, 1);
+                    const int s2 = q / NOB, ob = q % NOB;
+                    acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2h[s2]), __builtin_bit_cast(hf16x8, wl0), acc2[ob], 0, 0, 0);
+                    acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2l[s2]), __builtin_bit_cast(hf16x8, wh0), acc2[ob], 0, 0, 0);
+                    acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2h[s2]), __builtin_bit_cast(hf16x8, wh0), acc2[ob], 0, 0, 0);
+                    if (q < HF_NDMA - 8 && stage) dma(hd_s, cb_s, par ^ 1, q + 8);   // the other 10, one per MFMA group
+                    __builtin_amdgcn_sched_barrier(0);
+                    wh0 = wh1, wl0 = wl1, wh1 = wh2, wl1 = wl2;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): this wave's share of the next block has landed
+            __syncthreads();                                         // ... everybody's has, and this buffer's readers are done
         }
-        HF_STAMP(3)
-        __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): this wave's share of the next block has landed
-        __syncthreads();                                         // ... everybody's has, and this buffer's readers are done
-        HF_STAMP(4)
-    }
 
-    if (p.stamps && tid == 0) {
+        // ---- epilogue 2: lane (out column r of block ob, half h) holds points (e & 3) + 8 (e >> 2) + 4 h of the wave's 32.
+        // fp16 range guard: a lane that split a magnitude >= 65504 (or met a NaN) spoils its wave's sums.  With a flag to raise, the wave
+        // writes no keys and the caller's predicated two-launch form (guarded arithmetic) supplies them; without one, NaN keys are loud.
+        // And the small side: a wave whose input features are ALL below 2^-4 (and not all zero) would lose relative precision in every
+        // product of conv1 (gemm.hip, small side of the range guard): same treatment.
+        if (m0 < p.M) {
+            const bool tiny_in = __ballot(amax_in >= 0.0625f) == 0ull && __ballot(amax_in > 0.f) != 0ull;
+            if (p.overflow && (tiny_in || __ballot(!(amax < 65504.f) || poison != poison) != 0ull)) {
+                if (lane == 0) atomicOr(p.overflow, 1);
+            } else {
+                const int obj0 = m0 / p.rows_per_obj, bound = (obj0 + 1) * p.rows_per_obj;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) p.stamps[6 * (size_t)blockIdx.x + i] = tph[i];
-        p.stamps[6 * (size_t)blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
-    }
-    // ---- epilogue 2: lane (out column r of block ob, half h) holds points (e & 3) + 8 (e >> 2) + 4 h of the wave's 32
-    if (m0 >= p.M) return;
-    // fp16 range guard: a lane that split a magnitude >= 65504 (or met a NaN) spoils its wave's sums.  With a flag to raise, the wave
-    // writes no keys and the caller's predicated two-launch form (guarded arithmetic) supplies them; without one, NaN keys are loud.
-    // (round 3) and the small side: a wave whose input features are ALL below 2^-4 (and not all zero) would lose relative precision
-    // in every product of conv1 (fp16 reproduces an operand to an absolute 3e-8 at best: gemm.hip, small side of the range guard): same treatment.
-    const bool tiny_in = __ballot(amax_in >= 0.0625f) == 0ull && __ballot(amax_in > 0.f) != 0ull;
-    if (p.overflow && (tiny_in || __ballot(!(amax < 65504.f) || poison != poison) != 0ull)) {
-        if (lane == 0) atomicOr(p.overflow, 1);
-        return;
-    }
-    const int obj0 = m0 / p.rows_per_obj, bound = (obj0 + 1) * p.rows_per_obj;
+                for (int ob = 0; ob < HF_C2 / 32; ++ob) {
+                    const int o = hd * HF_C2 + ob * 32 + r;
+                    const float b2 = p.bias2[o], sc2 = p.scale2[o], sh2 = p.shift2[o];
+                    uint32_t k0 = 0, k1 = 0;
 #pragma unroll
-    for (int ob = 0; ob < HF_C2 / 32; ++ob) {
-        const int o = hd * HF_C2 + ob * 32 + r;
-        const float b2 = p.bias2[o], sc2 = p.scale2[o], sh2 = p.shift2[o];
-        uint32_t k0 = 0, k1 = 0;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int prow = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            float v = acc2[ob][e] + b2;
-            v = v * sc2 + sh2;
-            v = v > 0.f ? v : v * 0.f;
-            const uint32_t key = prow < p.M ? tgp_float_key(v) : 0u;
-            if (prow >= bound) k1 = key > k1 ? key : k1;
-            else k0 = key > k0 ? key : k0;
+                    for (int e = 0; e < 16; ++e) {
+                        const int prow = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        float v = acc2[ob][e] + b2;
+                        v = v * sc2 + sh2;
+                        v = v > 0.f ? v : v * 0.f;
+                        const uint32_t key = prow < p.M ? tgp_float_key(v) : 0u;
+                        if (prow >= bound) k1 = key > k1 ? key : k1;
+                        else k0 = key > k0 ? key : k0;
+                    }
+                    const uint32_t o0 = (uint32_t)__shfl_xor((int)k0, 32, 64), o1 = (uint32_t)__shfl_xor((int)k1, 32, 64);
+                    k0 = o0 > k0 ? o0 : k0, k1 = o1 > k1 ? o1 : k1;
+                    if (h == 0) {
+                        uint32_t *kp = p.keys + ((int64_t)hd * p.B + obj0) * HF_C2 + ob * 32 + r;
+                        if (k0) atomicMax(kp, k0);
+                        if (k1) atomicMax(kp + HF_C2, k1);
+                    }
+                }
+            }
         }
-        const uint32_t o0 = (uint32_t)__shfl_xor((int)k0, 32, 64), o1 = (uint32_t)__shfl_xor((int)k1, 32, 64);
-        k0 = o0 > k0 ? o0 : k0, k1 = o1 > k1 ? o1 : k1;
-        if (h == 0) {
-            uint32_t *kp = p.keys + ((int64_t)hd * p.B + obj0) * HF_C2 + ob * 32 + r;
-            if (k0) atomicMax(kp, k0);
-            if (k1) atomicMax(kp + HF_C2, k1);
-        }
+        if (!more) break;
+        t = tn, hd = hd_n, ptile = ptile_n;
     }
 }
 
@@ -514,13 +544,6 @@ extern "C" int tgp_heads_pack_w2(const float *w2, int heads, void *out, tgp_stre
     return TGP_LAUNCH_RESULT();
 }
 
-#ifdef TGP_DEV
-static unsigned long long *tgp_heads_stamps = nullptr;
-extern "C" void tgp_debug_set_heads_stamps(unsigned long long *buf) { tgp_heads_stamps = buf; }
-#else
-static constexpr unsigned long long *tgp_heads_stamps = nullptr;
-#endif
-
 extern "C" int tgp_heads_fused(const tgp_heads_fused_args *a, tgp_stream_t stream)
 {
     TGP_REQUIRE(a && a->fine && a->wa_s && a->p1 && a->p2 && a->idx1 && a->idx2 && a->bias1 && a->scale1 && a->shift1 && a->w2p &&
@@ -545,14 +568,30 @@ extern "C" int tgp_heads_fused(const tgp_heads_fused_args *a, tgp_stream_t strea
         TGP_REQUIRE(a->rows <= a->M && a->rows % 128 == 0);
         p.M = a->rows, p.tiles = a->rows / 128;
     }
-    p.stamps = tgp_heads_stamps;
+    p.fine_pl = reinterpret_cast<const char *>(a->fine_planes), p.fine_kt = a->fine_kt, p.fine_amax = a->fine_amax;
+    TGP_REQUIRE(!p.fine_pl || (p.fine_kt >= HF_STEPS && (reinterpret_cast<uintptr_t>(p.fine_pl) & 15) == 0));
     static bool attr_set = false;
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(heads_fused_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HF_BUF);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(heads_fused_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HF_BUF);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(heads_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * HF_BUF);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(heads_fused_kernel, dim3(p.heads * p.tiles), dim3(256), 2 * HF_BUF, tgp_hs(stream), p);
+    // persistent: one workgroup per CU (144 KB of LDS, 512 registers per lane: nothing else fits beside it), each walking its tiles
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    const int total = p.heads * p.tiles;
+    TGP_REQUIRE(a->workgroups >= 0);
+    const int want = a->workgroups > 0 ? a->workgroups : cus;
+    const dim3 grid(total < want ? total : want);
+    if (p.fine_pl) hipLaunchKernelGGL(heads_fused_kernel<true>, grid, dim3(256), 2 * HF_BUF, tgp_hs(stream), p);
+    else hipLaunchKernelGGL(heads_fused_kernel<false>, grid, dim3(256), 2 * HF_BUF, tgp_hs(stream), p);
     return TGP_LAUNCH_RESULT();
 }

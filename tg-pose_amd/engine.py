@@ -254,6 +254,7 @@ COARSE_SIDE = os.environ.get("TGP_COARSE_SIDE", "0") != "0"
 # reference's FLOPs).  A deployment switch; the bench's headline and every parity test run the full forward.
 EVAL_OUTPUTS_ONLY = os.environ.get("TGP_EVAL_OUTPUTS_ONLY", "0") != "0"
 HEADS_TAIL = os.environ.get("TGP_HEADS_TAIL", "0") != "0"
+DEC_PLANES_ONLY = os.environ.get("TGP_DEC_PLANES_ONLY", "0") != "0"     # the decoder's inner activations as fp16 planes only
 REPAIR_OBJS = 16        # objects per chunk of the fused heads kernel's fp16-range repair (wide_gemm_factored)
 
 
@@ -488,6 +489,7 @@ class Arena(object):
         self.keys2 = buf[n5:n5 + n2].view(3, B, 256)
         self.over5 = buf[n5 + n2:n5 + n2 + 1]
         self.over2 = buf[n5 + n2 + 4:n5 + n2 + 5]
+        self.dec_flag = buf[n5 + n2 + 6:n5 + n2 + 7]              # the planes-only decoder chain's range flag
         self.back = buf[n5 + n2 + 8:n5 + n2 + 8 + nb].view(torch.float32).view(B, FEAT_LD)
         self.amax = buf[n5 + n2 + 8 + nb:]
         self._pl = None
@@ -638,7 +640,7 @@ def wide_gemm_factored(pk, fine, inter, P1, P2, N, arena=None, heads_only=False)
             keys2, overflow = ops.heads_fused(fine.view(M, -1), FINE_K, f["Wa_s"][1024:], P1[:, 1024:], inter["near1"], P2[:, 1024:],
                                               inter["near2"], w["bias"][1024:], w["scale"][1024:], w["shift"][1024:], f["w2p"],
                                               w["b2"], w["scale2"], w["shift2"], B, N, k_alg=w["k_alg"], keys=arena.keys2,
-                                              overflow=arena.over2, rows=rows)
+                                              overflow=arena.over2, rows=rows, fine_planes=(inter.get("planes") or {}).get("fine"))
             if tail is not None:
                 torch.cuda.current_stream(dev).wait_event(tail)
             # fp16 range repair, decided on the device: a wave of the fused kernel that met a magnitude beyond fp16's range wrote no
@@ -671,7 +673,7 @@ def wide_gemm_factored(pk, fine, inter, P1, P2, N, arena=None, heads_only=False)
     return keys5, H
 
 
-def decoder_forward_factored(pk, fine, inter, P1, P2, back, N):
+def decoder_forward_factored(pk, fine, inter, P1, P2, back, N, arena=None):
     """decoder_forward with the first conv factored like the wide layer (its coarse products are columns 4096.. of P1 / P2)."""
     w0, b0, sc0, sh0 = pk.dec[0][:4]
     f = pk.fact
@@ -681,18 +683,44 @@ def decoder_forward_factored(pk, fine, inter, P1, P2, back, N):
     # (the light fused kernel in a storing form was measured for this layer: 110 us against 96 us on the tile kernel -- with 512
     # channels a workgroup has 8 channel blocks to amortise its set-up over, and 4-byte stores of 16 points per lane)
     pl = inter.get("planes") or {}
-    x = torch.empty(B, N, 512, device=fine.device, dtype=torch.float32)
-    # the chain fine -> 512 -> 512 -> 256 -> 128 on the pre-split kernel: each layer's epilogue leaves the next one's operand planes
-    # (the fp32 copies are still written: a tile outside fp16's range recomputes from them, csrc/gemm_pp.hip)
-    ops.gemm(fine, f["dec_a"], x, M=M, N=512, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=512, bias=b0, rowbias=rb, rows_per_obj=N,
-             scale=sc0, shift=sh0, act=1, w_split=f["dec_a_s"], gather1=(P1[:, 4096:], P1.shape[1], inter["near1"]),
-             gather2=(P2[:, 4096:], P2.shape[1], inter["near2"]), flops_ref=2.0 * M * 512 * FEAT_C, a_planes=pl.get("fine"),
-             w_planes=f.get("dec_a_p"), c_planes=pl.get("d1") if pl.get("fine") is not None else None)
-    xp = pl.get("d1") if pl.get("fine") is not None else None
-    for (w, b, sc, sh, ws, wp), nxt in zip(pk.dec[1:], ("d2", "d3", None)):
-        x = ops.linear_rows(x, w, bias=b, scale=sc, shift=sh, act=1, w_split=ws, a_planes=xp if wp is not None else None, w_planes=wp,
-                            c_planes=pl.get(nxt) if (nxt and xp is not None and wp is not None) else None)
-        xp = pl.get(nxt) if (nxt and xp is not None and wp is not None) else None
+    dev = fine.device
+    gk = dict(M=M, N=512, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=512, bias=b0, rowbias=rb, rows_per_obj=N, scale=sc0, shift=sh0, act=1,
+              w_split=f["dec_a_s"], gather1=(P1[:, 4096:], P1.shape[1], inter["near1"]),
+              gather2=(P2[:, 4096:], P2.shape[1], inter["near2"]))
+    chain = pl.get("fine") is not None and f.get("dec_a_p") is not None and all(d[5] is not None for d in pk.dec[1:])
+    widths = [512] + [d[0].shape[0] for d in pk.dec[1:]]                  # 512, 512, 256, 128
+    if chain and DEC_PLANES_ONLY and arena is not None and all(ops._routes_to_big_tile(M, n, 1, True) for n in widths):
+        # The chain fine -> 512 -> 512 -> 256 -> 128 with its three inner activations as fp16 planes ONLY: each layer's epilogue
+        # writes the next one's operand (4 bytes per element written and read, instead of 8 + 4).  A tile whose magnitude words lie
+        # outside fp16's range cannot be recomputed without the fp32 operand: it raises arena.dec_flag, and the fp32 chain follows
+        # predicated on the flag (four launches that normally return at once, as after the fused heads kernel).
+        flag = arena.dec_flag
+        ops.gemm(fine, f["dec_a"], None, flops_ref=2.0 * M * 512 * FEAT_C, a_planes=pl["fine"], w_planes=f["dec_a_p"], c_planes=pl["d1"], **gk)
+        xp = pl["d1"]
+        x = torch.empty(M, widths[-1], device=dev, dtype=torch.float32)
+        for i, ((w, b, sc, sh, ws, wp), nxt) in enumerate(zip(pk.dec[1:], ("d2", "d3", None))):
+            ops.gemm(None, w, x if nxt is None else None, M=M, N=w.shape[0], K=w.shape[1], lda=0, ldw=w.shape[1], ldc=w.shape[0], bias=b,
+                     scale=sc, shift=sh, act=1, w_split=ws, a_planes=xp, w_planes=wp, c_planes=pl.get(nxt) if nxt else None, range_flag=flag)
+            xp = pl.get(nxt) if nxt else None
+        y = torch.empty(M, 512, device=dev, dtype=torch.float32)          # the repair chain's activations (untouched while the flag is 0)
+        ops.gemm(fine, f["dec_a"], y, flops_ref=0, pred=flag, **gk)
+        for w, b, sc, sh, ws, _wp in pk.dec[1:]:
+            out = x if w.shape[0] == widths[-1] else torch.empty(M, w.shape[0], device=dev, dtype=torch.float32)
+            ops.gemm(y, w, out, M=M, N=w.shape[0], K=w.shape[1], lda=w.shape[1], ldw=w.shape[1], ldc=w.shape[0], bias=b, scale=sc,
+                     shift=sh, act=1, w_split=ws, flops_ref=0, pred=flag)
+            y = out
+        x = x.view(B, N, -1)
+    else:
+        x = torch.empty(B, N, 512, device=dev, dtype=torch.float32)
+        # the chain on the pre-split kernel: each layer's epilogue leaves the next one's operand planes (the fp32 copies are written
+        # too: a tile outside fp16's range recomputes from them, csrc/gemm_pp.hip)
+        ops.gemm(fine, f["dec_a"], x, flops_ref=2.0 * M * 512 * FEAT_C, a_planes=pl.get("fine"), w_planes=f.get("dec_a_p"),
+                 c_planes=pl.get("d1") if chain else None, **gk)
+        xp = pl.get("d1") if chain else None
+        for (w, b, sc, sh, ws, wp), nxt in zip(pk.dec[1:], ("d2", "d3", None)):
+            x = ops.linear_rows(x, w, bias=b, scale=sc, shift=sh, act=1, w_split=ws, a_planes=xp if wp is not None else None, w_planes=wp,
+                                c_planes=pl.get(nxt) if (nxt and xp is not None and wp is not None) else None)
+            xp = pl.get(nxt) if (nxt and xp is not None and wp is not None) else None
     recon = ops.linear_rows(x, pk.dec_out[0], bias=pk.dec_out[1])
     # rows are in the sorted order of encoder_forward(factored=True): put the (B,N,3) result back in point order
     return torch.empty_like(recon).scatter_(1, inter["order"].unsqueeze(-1).expand(-1, -1, 3), recon)
@@ -804,7 +832,7 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
     if factored:
         P1, P2 = coarse_products(pk, inter)
         wide = lambda: wide_gemm_factored(pk, feat, inter, P1, P2, N, arena)
-        decode = lambda back: decoder_forward_factored(pk, feat, inter, P1, P2, back, N)
+        decode = lambda back: decoder_forward_factored(pk, feat, inter, P1, P2, back, N, arena)
     else:
         P1 = P2 = None
         wide = lambda: wide_gemm(pk, feat, N)

@@ -274,6 +274,8 @@ def fill_tail(obj_id, xyz_c, feat, col0, n_cls):
 # split_w() packs weights for the mode current at pack time; gemm() reads the kind off the packed tensor's shape.
 GEMM_MODE = "split16"
 PLANES = os.environ.get("TGP_PLANES", "1") != "0"     # activations also as fp16 planes, consumers on the pre-split kernel (split16 mode)
+HEADS_PERSISTENT = os.environ.get("TGP_HEADS_PERSISTENT", "0") != "0"   # measurement switches of the fused heads kernel (ABI 5)
+HEADS_PLANES = os.environ.get("TGP_HEADS_PLANES", "1") != "0"
 
 
 FP16_SAFE = 32768.0          # |w| at or above this is pre-scaled before the fp16 split (fp16's largest finite value is 65504)
@@ -429,7 +431,7 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
          rows_per_obj=0, res1=None, ldr1=0, res2=None, ldr2=0, scale=None, shift=None, act=0, slope=0.0,
          colmax_keys=None, k_alg=None, slope_vec=None, cm_cols=0, c_col0=0, batch=1, batch_strides=None, w_split=None,
          a_scale=None, c_scale=None, ksplit_chunk=0, gather1=None, gather2=None, flops_ref=None, epilogue=0, pred=None,
-         row_base=0, a_planes=None, w_planes=None, c_planes=None, cp_col0=0, pp_config=0):
+         row_base=0, a_planes=None, w_planes=None, c_planes=None, cp_col0=0, pp_config=0, range_flag=None):
     """Raw call into tgp_gemm_f32.  A/W/C/res* are tensors whose data_ptr is the first element of the
     operand (views into wider buffers are fine); all sizes/strides are explicit.  k_alg: the layer's
     true input width when K includes zero padding (only used for FLOP accounting in bench.py)."""
@@ -443,11 +445,18 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
         late_planes, c_planes = c_planes, None          # a small launch: its result is split by a launch of its own below
     timed = GEMM_TIMER is not None and pred is None and (GEMM_TIMER_ALL or pp or _routes_to_big_tile(M, N, batch, split16))   # (a predicated
     # launch is a repair path that normally does nothing: it has no place in a FLOP rate)
+    if A is None:                                # a planes-only operand (tgp_gemm_args.range_flag)
+        if not pp or range_flag is None:
+            raise ValueError("gemm: an operand without its fp32 form needs both operands' planes, a tile-kernel launch and a range flag")
+        A = a_planes.buf                         # (device / stream of the launch)
+        a_ptr, lda = None, 0
+    else:
+        a_ptr = _p(A)
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(A.device))
     a = GemmArgs()
-    a.A, a.lda, a.W, a.ldw = _p(A), lda, _p(W), ldw
+    a.A, a.lda, a.W, a.ldw = a_ptr, lda, _p(W), ldw
     a.C, a.ldc = (_p(C), ldc) if C is not None else (None, 0)
     a.M, a.N, a.K = M, N, K
     a.bias = _p(bias)
@@ -481,6 +490,7 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
         a.A_planes, a.a_kt, a.a_amax = _p(a_planes.buf), a_planes.kt, _p(a_planes.amax)
         a.W_planes, a.w_kt = _p(w_planes.buf), w_planes.kt
         a.pp_config = int(pp_config)
+        a.range_flag = _p(range_flag)
     if c_planes is not None and GEMM_MODE == "split16" and PLANES:
         a.C_planes, a.c_kt, a.cp_col0, a.c_amax = _p(c_planes.buf), c_planes.kt, int(cp_col0), _p(c_planes.amax)
     check(_lib.lib().tgp_gemm_f32(ctypes.byref(a), _stream(A)), "tgp_gemm_f32")
@@ -537,7 +547,7 @@ def heads_pack_w2(W2):
 
 
 def heads_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias1, scale1, shift1, w2p, bias2, scale2, shift2, B, rows_per_obj, k_alg=None,
-                keys=None, overflow=None, rows=0):
+                keys=None, overflow=None, rows=0, fine_planes=None):
     """conv1 -> BN -> ReLU -> conv2 -> BN -> ReLU -> max over points of the three heads (tgp_heads_fused): keys (heads, B, 256)
     and the device flag (1,) int32 that a wave raises instead of writing keys when it met a magnitude beyond fp16's range.
     fine (M, ldf); p1 / p2: 2-D views whose column 0 is the first head's first channel (row stride = their .stride(0))."""
@@ -564,6 +574,9 @@ def heads_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias1, scale1, shift1, w2p, b
     a.M, a.rows_per_obj, a.B, a.heads = M, rows_per_obj, B, heads
     a.overflow = _p(overflow)
     a.rows = int(rows)
+    if fine_planes is not None and planes_on() and HEADS_PLANES:      # the points' features as fp16 planes: operand fragments load as they lie
+        a.fine_planes, a.fine_kt, a.fine_amax = _p(fine_planes.buf), fine_planes.kt, _p(fine_planes.amax)
+    a.workgroups = 0 if HEADS_PERSISTENT else 1 << 30
     check(_lib.lib().tgp_heads_fused(ctypes.byref(a), _stream(fine)), "tgp_heads_fused")
     if timed:
         e1.record(torch.cuda.current_stream(fine.device))
