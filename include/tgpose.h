@@ -61,6 +61,11 @@ int64_t tgp_knn_feat_workspace_bytes(int B, int n, int d);
  * feat (B,n,d) with row stride ld; d a multiple of 32, d <= 480. */
 int tgp_knn_feat(const float *feat, int ld, int B, int n, int d, int k, int32_t *idx, void *workspace,
                  int64_t workspace_bytes, tgp_stream_t stream);
+/* (ABI 5) the same with the kernel form chosen by the caller -- 0: the library's choice; 1: 32-row blocks, one workgroup per CU
+ * (v_mfma_f32_32x32x2_f32); 2: 16-row blocks, two workgroups per CU whose distance and selection phases overlap
+ * (v_mfma_f32_16x16x4_f32, the same ascending-k chain).  Identical index lists; a measurement / test handle. */
+int tgp_knn_feat_form(const float *feat, int ld, int B, int n, int d, int k, int32_t *idx, void *workspace, int64_t workspace_bytes,
+                      int form, tgp_stream_t stream);
 
 /* gcn3d.py:26-35 get_nearest_index: for each of n target points the nearest of m source points
  * by fl(fl(|s|^2 + |t|^2) - 2<t,s>), lowest index on ties.  idx (B,n). */
@@ -113,6 +118,12 @@ int tgp_orl_rowbias_planes(const float *feat, int ldf, const int32_t *idx, int B
 int tgp_pool_fwd(const float *xyz, const float *feat, int ldf, const int32_t *idx, int ldi, const int32_t *sample,
                  int B, int n, int n_out, int kpool, int C, float *out_xyz, float *out_f, int ldo,
                  tgp_stream_t stream);
+/* (ABI 5) the same, the pooled features also written as blocked fp16 planes (tgp_gemm_args.A_planes; kts >= C / 16 K-tiles per row
+ * block) with their per-row-block magnitude words (amax, zero-filled by the caller; may be NULL): they are the A operand of the next
+ * layer's projection GEMM.  C / 4 a divisor of 64, else TGP_EUNSUPPORTED. */
+int tgp_pool_fwd_planes(const float *xyz, const float *feat, int ldf, const int32_t *idx, int ldi, const int32_t *sample, int B, int n,
+                        int n_out, int kpool, int C, float *out_xyz, float *out_f, int ldo, void *planes, int kts, uint32_t *amax,
+                        tgp_stream_t stream);
 
 /* gcn3d.py:38-46 indexing_neighbor_new with one neighbour (FaceRecon.py:69-73 nearest up-sampling):
  * dst[b,i,0:C] = src[b, idx[b,i], 0:C]. */
@@ -619,6 +630,7 @@ typedef struct tgp_conv_max_fused_args {
     uint32_t *keys; int ldk;
     int M; int rows_per_obj; int C;
     int *overflow;
+    const void *fine_planes; int fine_kt; const uint32_t *fine_amax;      /* (ABI 5) as in tgp_heads_fused_args */
 } tgp_conv_max_fused_args;
 int tgp_conv_max_fused(const tgp_conv_max_fused_args *args, tgp_stream_t stream);
 /* w2 (heads, 256, 1024) fp32 -> heads * 1024 * 256 * 2 fp16 in the kernel's operand order (hi / lo planes, K permuted). */

@@ -124,6 +124,10 @@ def test_knn_feat_bit_exact_vs_oracle(ops, B, n, d, k, ld):
     want = _clib.knn(x.numpy(), k)
     got = ops.knn_feat(g(buf)[:, :, :d], k).cpu().numpy()
     assert np.array_equal(got, want)
+    # both forms of the fused kernel (round 4): 32-row blocks on v_mfma_f32_32x32x2_f32, 16-row blocks on v_mfma_f32_16x16x4_f32 --
+    # the same ascending-k chain per distance, so the same index lists (other shapes: the form is ignored)
+    for form in (1, 2):
+        assert np.array_equal(ops.knn_feat(g(buf)[:, :, :d], k, form=form).cpu().numpy(), want), form
 
 
 @pytest.mark.parametrize("B,n,d,k", [(2, 1028, 128, 20), (2, 257, 256, 20), (1, 1152, 128, 20)])
@@ -136,8 +140,8 @@ def test_knn_feat_coincident_rows_take_the_serial_selection(ops, B, n, d, k):
     x[:, n // 2:] = 0.0                           # half of the cloud has dead features
     x[:, : n // 4] = x[:, :1]                     # a quarter repeats one row
     want = _clib.knn(x.numpy(), k)
-    got = ops.knn_feat(g(x), k).cpu().numpy()
-    assert np.array_equal(got, want)
+    for form in (0, 1, 2):
+        assert np.array_equal(ops.knn_feat(g(x), k, form=form).cpu().numpy(), want), form
 
 
 @pytest.mark.parametrize("key,k", [("feat", 20), ("feat256", 8)])
@@ -3601,3 +3605,22 @@ def test_decoder_chain_on_planes_only(ops, scale):
         finally:
             ops.PLANES, engine.DEC_PLANES_ONLY = old
     assert torch.isfinite(got[0]).all() and torch.equal(got[0], got[1])
+
+
+@pytest.mark.parametrize("B,n,C", [(3, 1028, 128), (2, 257, 256), (2, 100, 64), (2, 64, 512)])
+def test_pool_planes_equal_split_of_the_pooled_features(ops, B, n, C):
+    """tgp_pool_fwd_planes: Pool_layer's output also as the fp16 planes of the next projection GEMM's operand, written by the pooling
+    kernel itself (C <= 256; wider rows fall back to a split of the result): same pooled features, planes and magnitude words equal to
+    the stand-alone split."""
+    gen = torch.Generator().manual_seed(B + n + C)
+    xyz, feat = g(torch.randn(B, n, 3, generator=gen)), g(torch.randn(B, n, C, generator=gen))
+    idx = g(torch.randint(0, n, (B, n, 4), generator=gen).int())
+    sample = g(torch.randperm(n, generator=gen)[: n // 4].int())
+    v0, f0 = ops.pool(xyz, feat, idx, sample)
+    P = ops.Planes(B * (n // 4), C, DEV)
+    v1, f1 = ops.pool(xyz, feat, idx, sample, planes=P)
+    assert torch.equal(v0, v1) and torch.equal(f0, f1)
+    want, amax = _ref_planes(f0.view(-1, C))
+    nblk = want.shape[0]
+    rows_ok = (torch.arange(nblk * 32, device=DEV) < B * (n // 4)).view(nblk, 1, 1, 1, 32, 1)
+    assert bool(((P.buf.view(nblk, P.kt, 2, 2, 32, 16) == want.view(nblk, P.kt, 2, 2, 32, 16)) | ~rows_ok).all()) and torch.equal(P.amax, amax)

@@ -60,6 +60,7 @@ class ConvMaxFusedArgs(ctypes.Structure):
         ("keys", c_vp), ("ldk", c_int),
         ("M", c_int), ("rows_per_obj", c_int), ("C", c_int),
         ("overflow", c_vp),
+        ("fine_planes", c_vp), ("fine_kt", c_int), ("fine_amax", c_vp),
     ]
 
 
@@ -91,6 +92,7 @@ SIGNATURES = {
     "tgp_knn_xyz": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "tgp_knn_feat_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
     "tgp_knn_feat": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp]),
+    "tgp_knn_feat_form": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_int, c_vp]),
     "tgp_nn1": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "tgp_normalize_dirs": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "tgp_normalize_dirs_bwd": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp]),
@@ -101,6 +103,8 @@ SIGNATURES = {
     "tgp_orl_rowbias": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tgp_orl_rowbias_planes": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "tgp_pool_fwd": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
+    "tgp_pool_fwd_planes": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_int,
+                                    c_vp, c_vp]),
     "tgp_gather_rows": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     "tgp_fill_tail": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
     "tgp_split_bf16": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp]),

@@ -343,20 +343,14 @@ class _BNActPool(Function):
 
 
 def _running(bn):
-    """the module's buffers for ops.bn_train(running=...): moved by the statistics kernel (was: four torch launches per module)"""
-    if bn is None or not bn.track_running_stats or bn.momentum is None:
-        return None
-    return bn.running_mean, bn.running_var, bn.momentum, bn.num_batches_tracked
-
-
-def _update_running(bn, mean, var, rows):
+    """the module's buffers for ops.bn_train(running=...): moved by the statistics kernel (was: four torch launches per module).
+    momentum=None (torch's cumulative moving average, 1 / num_batches_tracked) is not implemented by that kernel and is refused
+    rather than silently leaving the running statistics untouched; the reference's modules all use the default 0.1."""
     if bn is None or not bn.track_running_stats:
-        return
-    m = bn.momentum
-    with torch.no_grad():
-        bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
-        bn.running_var.mul_(1 - m).add_(var, alpha=m * rows / max(rows - 1, 1))
-        bn.num_batches_tracked.add_(1)
+        return None
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative average) is not supported by the training path")
+    return bn.running_mean, bn.running_var, bn.momentum, bn.num_batches_tracked
 
 
 def bn_act(x, bn, act=1, slope=0.0):
@@ -828,7 +822,7 @@ class GraphedStep(object):
 
     _FOREIGN = "AccumulateGrad node's stream does not match"
 
-    def __init__(self, params, step_fn, cloud_sizes, device, cut=None, between=None, after=None, own_pool=False):
+    def __init__(self, params, step_fn, cloud_sizes, device, cut=None, between=None, after=None, own_pool=False, buckets=None):
         """cut: an EncoderCut that step_fn hands to net1's forward.  The step is then captured as TWO graphs sharing one memory
         pool -- (1) forwards + loss + backward of everything after the encoder, (2) the encoder's backward -- and replayed with
         ``between()`` called after the first has been enqueued (the data-parallel trainer starts the late layers' gradient
@@ -843,6 +837,7 @@ class GraphedStep(object):
         self.samples = [(torch.zeros(a, dtype=torch.int32, device=dev), torch.zeros(b, dtype=torch.int32, device=dev))
                         for a, b in self.counts]
         self.cut, self.between, self.after = cut, between, after
+        self.buckets = buckets           # shard.GradBuckets whose flat buffers the gradients are views of (zeroed in two fills)
 
         def run():
             o = 0
@@ -899,9 +894,15 @@ class GraphedStep(object):
             cut.clear()
 
     def _zero(self):
-        for p in self.params:
-            if p.grad is not None:
-                p.grad.zero_()
+        """gradients to zero before a replay: the flat buckets in two fills when the gradients are their views (overlap=True), else
+        one multi-tensor launch (round 3 issued one fill per parameter: 164 launches in front of every replay)"""
+        grads = [p.grad for p in self.params if p.grad is not None]
+        if self.buckets is not None:
+            self.buckets.zero_()
+            lo_hi = [(f.data_ptr(), f.data_ptr() + 4 * f.numel()) for f in self.buckets.flat]
+            grads = [g for g in grads if not any(lo <= g.data_ptr() < hi for lo, hi in lo_hi)]
+        if grads:
+            torch._foreach_zero_(grads)
 
     def _draw(self, sample_idx):
         if sample_idx is None:

@@ -680,14 +680,19 @@ extern "C" int tgp_orl_rowbias_planes(const float *feat, int ldf, const int32_t 
 
 // ---------------------------------------------------------------------------------------------------
 // Pool_layer: neighbour max at the sampled rows only (the reference computes all n rows and keeps n/4)
+// planes != NULL (round 4): the pooled features -- the A operand of the next layer's projection GEMM -- are also written as blocked
+// fp16 planes (include/tgpose.h, tgp_gemm_args.A_planes) with their per-row-block magnitude words; C4 a divisor of 64, so a wave
+// holds whole rows and at most two row blocks
 __global__ void pool_kernel(const float *__restrict__ xyz, const float *__restrict__ feat, int ldf,
                             const int32_t *__restrict__ idx, int ldi, const int32_t *__restrict__ sample, int B, int n,
-                            int n_out, int kpool, int C4, float *__restrict__ out_xyz, float *__restrict__ out_f, int ldo)
+                            int n_out, int kpool, int C4, float *__restrict__ out_xyz, float *__restrict__ out_f, int ldo,
+                            char *__restrict__ planes, int kts, uint32_t *__restrict__ amax)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (int64_t)B * n_out * C4) return;
-    const int c4 = (int)(t % C4);
-    const int64_t pm = t / C4;
+    const bool live = t < (int64_t)B * n_out * C4;
+    const int64_t tc = live ? t : 0;
+    const int c4 = (int)(tc % C4);
+    const int64_t pm = tc / C4;
     const int mrow = (int)(pm % n_out), b = (int)(pm / n_out);
     const int s = sample[mrow];
     const int32_t *nb = idx + ((int64_t)b * n + s) * ldi;
@@ -696,11 +701,41 @@ __global__ void pool_kernel(const float *__restrict__ xyz, const float *__restri
         const float4 v = *reinterpret_cast<const float4 *>(feat + ((int64_t)b * n + nb[j]) * ldf + 4 * c4);
         m.x = fmaxf(m.x, v.x), m.y = fmaxf(m.y, v.y), m.z = fmaxf(m.z, v.z), m.w = fmaxf(m.w, v.w);
     }
-    *reinterpret_cast<float4 *>(out_f + pm * ldo + 4 * c4) = m;
-    if (c4 == 0) {
-        const float *p = xyz + ((int64_t)b * n + s) * 3;
-        float *o = out_xyz + pm * 3;
-        o[0] = p[0], o[1] = p[1], o[2] = p[2];
+    if (live) {
+        *reinterpret_cast<float4 *>(out_f + pm * ldo + 4 * c4) = m;
+        if (c4 == 0) {
+            const float *p = xyz + ((int64_t)b * n + s) * 3;
+            float *o = out_xyz + pm * 3;
+            o[0] = p[0], o[1] = p[1], o[2] = p[2];
+        }
+    }
+    if (planes) {                                                    // (kernel-uniform)
+        uint32_t mb = 0u;
+        if (live) {
+            uint2 ph, pl;
+            ol_split(m, ph, pl);
+            const int pc = 4 * c4;
+            char *dst = planes + ((pm >> 5) * kts + (pc >> 4)) * 2048 + ((pc >> 3) & 1) * 512 + (int)(pm & 31) * 16 + (pc & 4) * 2;
+            *reinterpret_cast<uint2 *>(dst) = ph;
+            *reinterpret_cast<uint2 *>(dst + 1024) = pl;
+            const uint32_t b0 = __float_as_uint(m.x) & 0x7fffffffu, b1 = __float_as_uint(m.y) & 0x7fffffffu;
+            const uint32_t b2 = __float_as_uint(m.z) & 0x7fffffffu, b3 = __float_as_uint(m.w) & 0x7fffffffu;
+            mb = max(max(b0, b1), max(b2, b3));
+        }
+        if (amax) {
+            // the wave's rows lie in at most two row blocks: the first lane's and the next
+            const int64_t rb0 = __shfl(pm >> 5, 0, 64);
+            uint32_t m0 = (live && (pm >> 5) == rb0) ? mb : 0u, m1 = (live && (pm >> 5) != rb0) ? mb : 0u;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                m0 = max(m0, (uint32_t)__shfl_xor((int)m0, o, 64));
+                m1 = max(m1, (uint32_t)__shfl_xor((int)m1, o, 64));
+            }
+            if ((threadIdx.x & 63) == 0) {
+                if (m0) atomicMax(amax + rb0, m0);
+                if (m1) atomicMax(amax + rb0 + 1, m1);
+            }
+        }
     }
 }
 
@@ -714,7 +749,23 @@ extern "C" int tgp_pool_fwd(const float *xyz, const float *feat, int ldf, const 
     TGP_REQUIRE((reinterpret_cast<uintptr_t>(feat) & 15) == 0 && (reinterpret_cast<uintptr_t>(out_f) & 15) == 0);
     const int64_t total = (int64_t)B * n_out * (C / 4);
     hipLaunchKernelGGL(pool_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), xyz, feat, ldf, idx, ldi,
-                       sample, B, n, n_out, kpool, C / 4, out_xyz, out_f, ldo);
+                       sample, B, n, n_out, kpool, C / 4, out_xyz, out_f, ldo, nullptr, 0, nullptr);
+    return TGP_LAUNCH_RESULT();
+}
+
+extern "C" int tgp_pool_fwd_planes(const float *xyz, const float *feat, int ldf, const int32_t *idx, int ldi,
+                                   const int32_t *sample, int B, int n, int n_out, int kpool, int C, float *out_xyz, float *out_f,
+                                   int ldo, void *planes, int kts, uint32_t *amax, tgp_stream_t stream)
+{
+    TGP_REQUIRE(xyz && feat && idx && sample && out_xyz && out_f && planes);
+    TGP_REQUIRE(B > 0 && n > 0 && n_out > 0 && n_out <= n && kpool > 0 && ldi >= kpool && C > 0 && (C & 15) == 0);
+    TGP_REQUIRE(ldf >= C && ldo >= C && (ldf & 3) == 0 && (ldo & 3) == 0 && kts >= C / 16);
+    TGP_REQUIRE((reinterpret_cast<uintptr_t>(feat) & 15) == 0 && (reinterpret_cast<uintptr_t>(out_f) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(planes) & 15) == 0);
+    if (64 % (C / 4)) return TGP_EUNSUPPORTED;                          // a wave holds whole rows: C = 16 .. 256 in powers of two
+    const int64_t total = (int64_t)B * n_out * (C / 4);
+    hipLaunchKernelGGL(pool_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), xyz, feat, ldf, idx, ldi,
+                       sample, B, n, n_out, kpool, C / 4, out_xyz, out_f, ldo, reinterpret_cast<char *>(planes), kts, amax);
     return TGP_LAUNCH_RESULT();
 }
 

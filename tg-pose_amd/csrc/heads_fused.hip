@@ -335,8 +335,10 @@ struct ConvMaxParams {
     int *overflow;
     int M, rows_per_obj, C, tiles, chunks;
     int main_tiles;                       // tiles [0, main_tiles) are cut into `chunks` channel chunks, the others into one per block
+    const char *fine_pl; int fine_kt; const uint32_t *fine_amax;      // (round 4) the points' features as blocked fp16 planes
 };
 
+template <bool PLANES>
 __global__ __launch_bounds__(256, 2) void conv_max_fused_kernel(ConvMaxParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char hf_smem[];
@@ -361,7 +363,24 @@ __global__ __launch_bounds__(256, 2) void conv_max_fused_kernel(ConvMaxParams p)
 
     uint4 ah[HF_STEPS], al[HF_STEPS];     // the wave's points: A fragments, fp16 hi / lo planes of fine[row][16 s + 8 h .. + 7]
     float amax = 0.f, poison = 0.f;
-    {
+    if constexpr (PLANES) {
+        // the fragments as they lie in the fine buffer's planes (1 KB runs per K-tile and plane), the block's magnitude word for the guard
+        const int rb = min(m0 >> 5, ((p.M + 31) >> 5) - 1);
+        const char *src = p.fine_pl + (int64_t)rb * p.fine_kt * 2048 + lane * 16;
+#pragma unroll
+        for (int s = 0; s < HF_STEPS; ++s) {
+            ah[s] = *reinterpret_cast<const uint4 *>(src + s * 2048);
+            al[s] = *reinterpret_cast<const uint4 *>(src + s * 2048 + 1024);
+        }
+        if (m0 + 32 > p.M) {                                        // rows past the end were never written
+            const bool dead = m0 + r >= p.M;
+#pragma unroll
+            for (int s = 0; s < HF_STEPS; ++s)
+                if (dead) ah[s] = make_uint4(0u, 0u, 0u, 0u), al[s] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        const uint32_t am = p.fine_amax ? p.fine_amax[rb] : 0x3f800000u;
+        amax = __uint_as_float(am < 0x7f800000u ? am : 0x7f800000u);
+    } else {
         const float *fr = p.fine + (int64_t)row * p.ldf + 8 * h;
 #pragma unroll
         for (int s = 0; s < HF_STEPS; ++s) {
@@ -500,19 +519,25 @@ extern "C" int tgp_conv_max_fused(const tgp_conv_max_fused_args *a, tgp_stream_t
     p.bias = a->bias, p.scale = a->scale, p.shift = a->shift, p.slope = a->slope;
     p.keys = a->keys, p.ldk = a->ldk, p.overflow = a->overflow;
     p.M = a->M, p.rows_per_obj = a->rows_per_obj, p.C = a->C, p.tiles = tgp_cdiv(a->M, 128);
+    p.fine_pl = reinterpret_cast<const char *>(a->fine_planes), p.fine_kt = a->fine_kt, p.fine_amax = a->fine_amax;
+    TGP_REQUIRE(!p.fine_pl || (p.fine_kt >= HF_STEPS && (reinterpret_cast<uintptr_t>(p.fine_pl) & 15) == 0));
     // channel chunks: enough workgroups for two per CU; a few tiles past a whole number of rounds go in single channel blocks
     p.chunks = (p.C / 32) >= 2 && p.tiles < 512 ? 2 : 1;
     const int round_tiles = 512 / p.chunks, over = p.tiles % round_tiles;
     p.main_tiles = (p.tiles > round_tiles && over > 0 && over <= 8) ? p.tiles - over : p.tiles;
     static bool attr_set = false;
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_max_fused_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CM_BUF);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_max_fused_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CM_BUF);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_max_fused_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CM_BUF);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const int grid = p.main_tiles * p.chunks + (p.tiles - p.main_tiles) * (p.C / 32);
-    hipLaunchKernelGGL(conv_max_fused_kernel, dim3(grid), dim3(256), 2 * CM_BUF, tgp_hs(stream), p);
+    if (p.fine_pl) hipLaunchKernelGGL(conv_max_fused_kernel<true>, dim3(grid), dim3(256), 2 * CM_BUF, tgp_hs(stream), p);
+    else hipLaunchKernelGGL(conv_max_fused_kernel<false>, dim3(grid), dim3(256), 2 * CM_BUF, tgp_hs(stream), p);
     return TGP_LAUNCH_RESULT();
 }
 

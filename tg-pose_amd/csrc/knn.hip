@@ -11,6 +11,8 @@
 // winner) emit the neighbours in ascending (distance, index) order.  No N x N matrix exists for
 // the 3-d case (the object's cloud sits in LDS as float4 {x,y,z,|p|^2}); the feature-space case
 // reads rows of a distance matrix produced by the MFMA GEMM (gemm.hip, DIST epilogue).
+#include <stdlib.h>
+
 #include "tgp_common.h"
 
 #define KNN_MAX_POINTS 2048
@@ -640,6 +642,118 @@ __global__ __launch_bounds__(512, 2) void knn_feat_fused_kernel(const float *__r
     if (st) st[3] = __builtin_amdgcn_s_memrealtime();
 }
 
+// ------------------------------------------------------------------------------------------------
+// (round 4) The same on 16-row blocks: 256 threads, v_mfma_f32_16x16x4_f32, 16 x ldw distances in LDS (<= 74 KB) -- TWO workgroups per
+// CU.  The 32-row form holds the CU alone (135 KB of LDS) and runs its two phases one after the other: 28 us of matrix work during
+// which the vector pipe idles, 11 us of selection during which the matrix cores idle (profiles/r02_f_knn_feat_fused_*.txt).  Two
+// independent half-size workgroups drift apart by themselves, one selecting while the other multiplies; the producer / consumer split
+// INSIDE a workgroup (round 2) failed because one MFMA wave per SIMD could not feed the pipe -- here every wave keeps four
+// independent accumulator chains (four interleaved column sets), enough to fill it alone.
+// Arithmetic: lane (c, g) of the 16x16x4 instruction supplies k = 4 s + g of row / column c in step s, and the matrix core adds the
+// four products to the accumulator in ascending k with one rounding each -- the same chain as two steps of the 32x32x2 form, so the
+// distances carry the same bits (tests/test_gpu_parity.py::test_knn_feat_bit_exact_vs_oracle runs both forms).
+// Operands: A = the block's 16 rows, one float per lane and step (registers); B = four column sets at once -- lane (c, g) loads the
+// float4 xt[k][64 grp + 4 c ..+3] (a wave-instruction reads four 256-byte runs), component j being column 64 grp + 4 c + j of set j.
+typedef float knn_f32x4 __attribute__((ext_vector_type(4)));
+
+#define KF16_ROWS 16
+template <int DIM, int NT, int CH>
+__global__ __launch_bounds__(256, 2) void knn_feat_fused16_kernel(const float *__restrict__ xt, const float *__restrict__ q, int B, int n, int k,
+                                                                  int32_t *__restrict__ idx, int nrb, int ldw)
+{
+    extern __shared__ __attribute__((aligned(16))) float dblk16[];    // [16][ldw]
+    __shared__ uint32_t s_lmin[4][64];
+    __shared__ __attribute__((aligned(16))) uint2 s_list[4][72];
+    constexpr int STEPS = DIM / 4;                                    // MFMA steps per column group (k quads)
+    constexpr int NCHUNK = STEPS / CH;
+    constexpr int RING = 4;
+    static_assert(NCHUNK % RING == 0, "the chunk ring's phase must repeat per column group");
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    int b, rb;
+    if (!tgp_xcd_object_tile(blockIdx.x, B, nrb, b, rb)) return;
+    const int i0 = rb * KF16_ROWS;
+    const float *xo = xt + (size_t)b * DIM * ldw + (size_t)g * ldw;   // + 4 s ldw: the lane's k of step s
+    const float *qb = q + (size_t)b * n;
+    const int ngrp = (ldw + 63) >> 6;                                  // column groups of 64 (the last may hold 32: ldw % 32 == 0)
+    {
+        float a[STEPS];
+#pragma unroll
+        for (int s2 = 0; s2 < STEPS; ++s2) a[s2] = xo[(size_t)4 * s2 * ldw + i0 + c];
+        float qrow[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qrow[e] = qb[min(i0 + 4 * g + e, n - 1)];
+        float4 buf[RING][CH];
+        auto fetch = [&](int grp, int cc, float4 (&dst)[CH]) {
+            // (a group past ldw -- the half group of an odd number of 32-column blocks -- re-reads the previous columns; masked below)
+            const int col = min(64 * grp + 4 * c, ldw - 4);
+            const float *br = xo + (size_t)4 * cc * CH * ldw + col;
+#pragma unroll
+            for (int t = 0; t < CH; ++t) dst[t] = *reinterpret_cast<const float4 *>(br + (size_t)4 * t * ldw);
+        };
+        if (wave < ngrp) {
+#pragma unroll
+            for (int cc = 0; cc < RING - 1; ++cc) fetch(wave, cc, buf[cc]);
+        }
+        for (int grp = wave; grp < ngrp; grp += 4) {
+            knn_f32x4 acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = knn_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int cc = 0; cc < NCHUNK; ++cc) {
+                constexpr int AHEAD = RING - 1;
+                if (cc + AHEAD < NCHUNK) fetch(grp, cc + AHEAD, buf[(cc + AHEAD) % RING]);
+                else if (grp + 4 < ngrp) fetch(grp + 4, cc + AHEAD - NCHUNK, buf[(cc + AHEAD) % RING]);
+#pragma unroll
+                for (int t = 0; t < CH; ++t) {                        // ascending k: step s = cc CH + t takes k = 4 s + g
+                    const float av = a[cc * CH + t];
+                    const float4 bv = buf[cc % RING][t];
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.y, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.z, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.w, acc[3], 0, 0, 0);
+                }
+            }
+            // accumulator element e of lane (c, g) in set j: row 4 g + e, column 64 grp + 4 c + j
+            const int col0 = 64 * grp + 4 * c;
+            if (col0 < ldw) {
+                float qc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qc[j] = qb[min(col0 + j, n - 1)];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float4 o;
+                    float *op = reinterpret_cast<float *>(&o);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float t1 = acc[j][e] * -2.0f;           // inner * (-2)
+                        const float t2 = t1 + qc[j];                  // + quadratic.unsqueeze(1)
+                        op[j] = col0 + j < n ? t2 + qrow[e] : INFINITY;   // + quadratic.unsqueeze(2)
+                    }
+                    *reinterpret_cast<float4 *>(dblk16 + (4 * g + e) * ldw + col0) = o;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: four rows per wave
+#pragma unroll 1
+    for (int rr = 0; rr < 4; ++rr) {
+        const int lrow = wave * 4 + rr, i = i0 + lrow;
+        if (i >= n) break;                                            // wave-uniform
+        uint32_t key[NT];
+        const float *row = dblk16 + lrow * ldw;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = lane + (t << 6);
+            key[t] = tgp_float_key(j < n ? row[j] : INFINITY);
+        }
+        int32_t *out = idx + ((size_t)b * n + i) * k;
+        if (!wave_select_ranked<NT>(key, lane, k, out, s_lmin[wave], s_list[wave]))
+            wave_select_serial_keys<NT>(key, lane, k, out);
+    }
+}
+
 #ifdef TGP_DEV
 static unsigned long long *tgp_knn_stamps = nullptr;
 extern "C" void tgp_debug_set_knn_stamps(unsigned long long *buf) { tgp_knn_stamps = buf; }
@@ -717,10 +831,25 @@ extern "C" int64_t tgp_knn_feat_workspace_bytes(int B, int n, int d)
     return (extra + (int64_t)B * n) * (int64_t)sizeof(float);
 }
 
+// form: 0 = the library's choice, 1 = 32-row blocks (one workgroup per CU), 2 = 16-row blocks (two per CU)
 template <int DIM, int NT, int CH>
-static int launch_knn_fused(const float *xt, const float *q, int B, int n, int k, int32_t *idx, hipStream_t stream)
+static int launch_knn_fused(const float *xt, const float *q, int B, int n, int k, int32_t *idx, hipStream_t stream, int form)
 {
     const int ncb = tgp_cdiv(n, 32), ldw = ncb * 32;
+    if (form != 1) {
+        const int nrb16 = tgp_cdiv(n, KF16_ROWS);
+        const size_t lds16 = (size_t)KF16_ROWS * ldw * sizeof(float);
+        static bool attr16 = false;
+        if (!attr16) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(knn_feat_fused16_kernel<DIM, NT, CH / 2>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, KF16_ROWS * KF_MAX_LDW * (int)sizeof(float));
+            if (e != hipSuccess) return (int)e;
+            attr16 = true;
+        }
+        hipLaunchKernelGGL((knn_feat_fused16_kernel<DIM, NT, CH / 2>), dim3(tgp_xcd_grid(B, nrb16)), dim3(256), lds16, stream, xt, q, B, n, k,
+                           idx, nrb16, ldw);
+        return TGP_LAUNCH_RESULT();
+    }
     // a tail of at most 8 rows (and fewer than there are full blocks) rides along with the first blocks instead of forming its own
     const int tail = n % KF_ROWS, n_extra = (tail > 0 && tail <= 8 && tail <= n / KF_ROWS) ? tail : 0;
     const int nrb = n_extra ? n / KF_ROWS : tgp_cdiv(n, KF_ROWS);
@@ -737,10 +866,18 @@ static int launch_knn_fused(const float *xt, const float *q, int B, int n, int k
     return TGP_LAUNCH_RESULT();
 }
 
+extern "C" int tgp_knn_feat_form(const float *feat, int ld, int B, int n, int d, int k, int32_t *idx, void *workspace,
+                                 int64_t workspace_bytes, int form, tgp_stream_t stream);
 extern "C" int tgp_knn_feat(const float *feat, int ld, int B, int n, int d, int k, int32_t *idx, void *workspace,
                             int64_t workspace_bytes, tgp_stream_t stream)
 {
-    TGP_REQUIRE(feat && idx && workspace);
+    return tgp_knn_feat_form(feat, ld, B, n, d, k, idx, workspace, workspace_bytes, 0, stream);
+}
+
+extern "C" int tgp_knn_feat_form(const float *feat, int ld, int B, int n, int d, int k, int32_t *idx, void *workspace,
+                                 int64_t workspace_bytes, int form, tgp_stream_t stream)
+{
+    TGP_REQUIRE(feat && idx && workspace && form >= 0 && form <= 2);
     const int chk = knn_check(B, n, k);
     if (chk) return chk;
     if (d <= 0 || (d & 31) || (d >> 5) >= 16) return TGP_EUNSUPPORTED;
@@ -755,7 +892,7 @@ extern "C" int tgp_knn_feat(const float *feat, int ld, int B, int n, int d, int 
     if (fused) {
         hipLaunchKernelGGL(knn_prep_kernel, dim3(ldt / 32, B), dim3(256), 0, tgp_hs(stream), feat, ld, n, d, D, ldt, q);
 #define LAUNCH_FUSED(NT) \
-    (d == 128 ? launch_knn_fused<128, NT, 8>(D, q, B, n, k, idx, tgp_hs(stream)) : launch_knn_fused<256, NT, 8>(D, q, B, n, k, idx, tgp_hs(stream)))
+    (d == 128 ? launch_knn_fused<128, NT, 8>(D, q, B, n, k, idx, tgp_hs(stream), form) : launch_knn_fused<256, NT, 8>(D, q, B, n, k, idx, tgp_hs(stream), form))
         if (nt <= 1) return LAUNCH_FUSED(1);
         if (nt <= 2) return LAUNCH_FUSED(2);
         if (nt <= 5) return LAUNCH_FUSED(5);

@@ -254,7 +254,7 @@ COARSE_SIDE = os.environ.get("TGP_COARSE_SIDE", "0") != "0"
 # reference's FLOPs).  A deployment switch; the bench's headline and every parity test run the full forward.
 EVAL_OUTPUTS_ONLY = os.environ.get("TGP_EVAL_OUTPUTS_ONLY", "0") != "0"
 HEADS_TAIL = os.environ.get("TGP_HEADS_TAIL", "0") != "0"
-DEC_PLANES_ONLY = os.environ.get("TGP_DEC_PLANES_ONLY", "0") != "0"     # the decoder's inner activations as fp16 planes only
+DEC_PLANES_ONLY = os.environ.get("TGP_DEC_PLANES_ONLY", "1") != "0"     # the decoder's inner activations as fp16 planes only
 REPAIR_OBJS = 16        # objects per chunk of the fused heads kernel's fp16-range repair (wide_gemm_factored)
 
 
@@ -407,9 +407,7 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, 
     hs_layer(cv[1], xyz, fm0, lambda: graphs.get("conv_1.rf", lambda: ops.knn_feat(fm0, kmax)),
              graphs.get("conv_1.orl_xyz", lambda: xyz_graph(0, xyz, kmax)), fm1, cv[1]["scale"], cv[1]["shift"], "relu",
              fmap_p=pl.get("fm0"), amax_ws=pl.get("amax_g1"))
-    v1, fp1 = ops.pool(xyz, fm1, graphs.get("pool_1.xyz", lambda: xyz_graph(0, xyz, kmax)), s1, kpool=4)
-    if pl:
-        ops.planes_split(fp1.view(B * N1, -1), out=pl["fp1"])
+    v1, fp1 = ops.pool(xyz, fm1, graphs.get("pool_1.xyz", lambda: xyz_graph(0, xyz, kmax)), s1, kpool=4, planes=pl.get("fp1"))
 
     k1 = min(kmax, N1 // 8)
     fm23 = torch.empty(B, N1, 512, device=dev, dtype=torch.float32)      # fm_2 | fm_3 side by side: one GEMM operand when factored
@@ -421,9 +419,7 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, 
     hs_layer(cv[3], v1, fm2, lambda: graphs.get("conv_3.rf", lambda: ops.knn_feat(fm2, k1)),
              graphs.get("conv_3.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm3, cv[3]["scale"], cv[3]["shift"], "relu",
              fmap_p=pl.get("fm23"), out_p=pl.get("fm23"), out_col0=256, amax_ws=pl.get("amax_g3"))
-    v2, fp2 = ops.pool(v1, fm3, graphs.get("pool_2.xyz", lambda: xyz_graph(1, v1, k1)), s2, kpool=4)
-    if pl:
-        ops.planes_split(fp2.view(B * N2, -1), out=pl["fp2"])
+    v2, fp2 = ops.pool(v1, fm3, graphs.get("pool_2.xyz", lambda: xyz_graph(1, v1, k1)), s2, kpool=4, planes=pl.get("fp2"))
 
     P1 = P1_join = None
     if factored and getattr(pk, "fact", None) is not None:
@@ -599,7 +595,7 @@ def wide_gemm_factored(pk, fine, inter, P1, P2, N, arena=None, heads_only=False)
         elif light:
             keys5, over5 = ops.conv_max_fused(fine.view(M, -1), FINE_K, f["Wa_s"], P1, inter["near1"], P2, inter["near2"],
                                               w["bias"][:1024], w["scale"][:1024], w["shift"][:1024], 0.2, B, N, k_alg=w["k_alg"],
-                                              keys=arena.keys5, overflow=arena.over5)
+                                              keys=arena.keys5, overflow=arena.over5, fine_planes=(inter.get("planes") or {}).get("fine"))
         if not heads_only:
             ops.gemm(fine, f["Wa"], None, M=M, N=1024, K=FINE_K, lda=FINE_LD, ldw=FINE_LD, ldc=0, bias=w["bias"],
                      scale=w["scale"], shift=w["shift"], act=1, slope_vec=w["slope"], colmax_keys=keys5, cm_cols=1024,

@@ -103,8 +103,11 @@ def knn_xyz(xyz, k):
     return idx
 
 
+KNN_FEAT_FORM = int(os.environ.get("TGP_KNN_FEAT_FORM", "0"))     # 0: the library's choice (tgp_knn_feat_form)
+
+
 @_timed("graph")
-def knn_feat(feat, k, workspace=None):
+def knn_feat(feat, k, workspace=None, form=None):
     """feat (B,n,d) rows contiguous (row stride may exceed d) -> idx (B,n,k) int32"""
     feat, ld = _rows(feat, "feat")
     B, n, d = feat.shape
@@ -112,8 +115,9 @@ def knn_feat(feat, k, workspace=None):
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty((need + 3) // 4, device=feat.device, dtype=torch.float32)
     idx = torch.empty(B, n, k, device=feat.device, dtype=torch.int32)
-    check(_lib.lib().tgp_knn_feat(_p(feat), ld, B, n, d, int(k), _p(idx), _p(workspace),
-                                  workspace.numel() * workspace.element_size(), _stream(feat)), "tgp_knn_feat")
+    check(_lib.lib().tgp_knn_feat_form(_p(feat), ld, B, n, d, int(k), _p(idx), _p(workspace),
+                                       workspace.numel() * workspace.element_size(), KNN_FEAT_FORM if form is None else int(form),
+                                       _stream(feat)), "tgp_knn_feat")
     return idx
 
 
@@ -214,8 +218,9 @@ def orl_rowbias(feat, idx, w2t, planes=None, xyz_tile=None):
 
 
 @_timed("graph")
-def pool(xyz, feat, idx, sample, kpool=4, out_f=None):
-    """xyz (B,n,3), feat (B,n,C), idx (B,n,>=kpool) int32, sample (n_out,) int32 -> (xyz_p, feat_p)"""
+def pool(xyz, feat, idx, sample, kpool=4, out_f=None, planes=None):
+    """xyz (B,n,3), feat (B,n,C), idx (B,n,>=kpool) int32, sample (n_out,) int32 -> (xyz_p, feat_p); planes (a Planes of B*n_out
+    rows): feat_p also as fp16 planes, by the same kernel where the shape allows, else by a split of the result"""
     _f32(xyz, "xyz", 3)
     feat, ldf = _rows(feat, "feat")
     _i32(idx, "idx"), _i32(sample, "sample")
@@ -225,8 +230,17 @@ def pool(xyz, feat, idx, sample, kpool=4, out_f=None):
     if out_f is None:
         out_f = torch.empty(B, n_out, C, device=xyz.device, dtype=torch.float32)
     out_f, ldo = _rows(out_f, "out_f")
+    if planes is not None:
+        rc = _lib.lib().tgp_pool_fwd_planes(_p(xyz), _p(feat), ldf, _p(idx), idx.shape[2], _p(sample), B, n, n_out, kpool, C,
+                                            _p(out_xyz), _p(out_f), ldo, _p(planes.buf), planes.kt, _p(planes.amax), _stream(xyz))
+        if rc == 0:
+            return out_xyz, out_f
+        if rc != -2:
+            check(rc, "tgp_pool_fwd_planes")
     check(_lib.lib().tgp_pool_fwd(_p(xyz), _p(feat), ldf, _p(idx), idx.shape[2], _p(sample), B, n, n_out, kpool, C,
                                   _p(out_xyz), _p(out_f), ldo, _stream(xyz)), "tgp_pool_fwd")
+    if planes is not None:
+        planes_split.__wrapped__(out_f.view(B * n_out, -1), K=C, out=planes)
     return out_xyz, out_f
 
 
@@ -587,7 +601,8 @@ def heads_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias1, scale1, shift1, w2p, b
     return keys, overflow
 
 
-def conv_max_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias, scale, shift, slope, B, rows_per_obj, k_alg=None, keys=None, overflow=None):
+def conv_max_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias, scale, shift, slope, B, rows_per_obj, k_alg=None, keys=None, overflow=None,
+                   fine_planes=None):
     """conv -> BN -> LeakyReLU -> max over points of a factored layer (tgp_conv_max_fused): keys (B, C) and the overflow flag."""
     fine, ldf = _rows(fine, "fine")
     C = bias.numel()
@@ -609,6 +624,8 @@ def conv_max_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias, scale, shift, slope,
     a.keys, a.ldk = _p(keys), C
     a.M, a.rows_per_obj, a.C = M, rows_per_obj, C
     a.overflow = _p(overflow)
+    if fine_planes is not None and planes_on() and HEADS_PLANES:
+        a.fine_planes, a.fine_kt, a.fine_amax = _p(fine_planes.buf), fine_planes.kt, _p(fine_planes.amax)
     check(_lib.lib().tgp_conv_max_fused(ctypes.byref(a), _stream(fine)), "tgp_conv_max_fused")
     if timed:
         e1.record(torch.cuda.current_stream(fine.device))

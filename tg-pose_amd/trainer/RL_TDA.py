@@ -183,9 +183,9 @@ class RT_TDA_Trainer(object):
         if total is not None and self.loss_is_nan(total):
             print('Found nan in total loss')
             self._exchanged = False
-            for p in self.net1.parameters():
-                if p.grad is not None:
-                    p.grad.zero_()
+            grads = [p.grad for p in self.net1.parameters() if p.grad is not None]
+            if grads:
+                torch._foreach_zero_(grads)
             return False
         if not self._exchanged:
             shard.allreduce_gradients(self.net1.parameters())
@@ -254,7 +254,7 @@ class RT_TDA_Trainer(object):
             self._buckets = None                                  # an earlier overlap capture's buckets no longer describe this step
 
         g = GraphedStep(list(self.net1.parameters()), step_fn, [N, N], dev, cut=cut, between=between, after=after,
-                        own_pool="ownpool" in _debug)
+                        own_pool="ownpool" in _debug, buckets=self._buckets)
         self._graphed = g
 
         def step(db=None, sample_idx=None):
