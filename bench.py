@@ -203,14 +203,24 @@ ALGO_BYTES_B32 = {
 }
 
 
-def _kernel_traffic():
+def _kernel_traffic(gemm_algo=None):
     """Per-kernel HBM-side traffic from the latest COMMITTED PMC passes (FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc runs,
     corrected as MI355X_MICROARCH.md prescribes: bytes = (2 FETCH + WRITE) KB; scripts/pmc_traffic.py) -- not a measurement of this
-    run, and labelled so in the line.  -> ([{kernel, launches, bytes_per_launch, algorithmic_bytes_per_launch, ratio}], source)"""
+    run, and labelled so in the line.  -> ([{kernel, launches, bytes_per_launch, algorithmic_bytes_per_launch, ratio}], source).
+    gemm_algo = (launches per forward, algorithmic bytes per forward) of the tile-GEMM launches this run timed: the tile GEMM kernels
+    serve many shapes each, so they get ONE family row -- the PMC bytes of every gemm_pp / gemm_split kernel per forward against the
+    algorithmic bytes of the forward's tile-GEMM launches."""
     try:
         path = _latest_profile("r*_pmc_traffic.json")
         pmc = json.load(open(path))["kernels"]
         rows = []
+        fam = [(k, v) for k, v in pmc.items() if "gemm_pp_kernel" in k or "gemm_split" in k]
+        if fam and gemm_algo and gemm_algo[0]:
+            fwd = max(1, round(sum(v["launches"] for _, v in fam) / gemm_algo[0]))            # forwards in the PMC passes
+            per_fwd = sum(v["launches"] * v["bytes_per_launch_corrected"] for _, v in fam) / fwd
+            rows.append({"kernel": "tile GEMM family (every gemm_pp_kernel<*> / gemm_split*_kernel launch of a forward)",
+                         "launches": int(gemm_algo[0]), "bytes_per_launch": int(per_fwd / gemm_algo[0]),
+                         "algorithmic_bytes_per_launch": int(gemm_algo[1] / gemm_algo[0]), "ratio": round(per_fwd / gemm_algo[1], 2)})
         for k, v in pmc.items():
             if "at::native" in k or "rocclr" in k or v["bytes_per_launch_corrected"] < 2e6:
                 continue
@@ -372,7 +382,7 @@ def main():
     B = args.batch
     torch.manual_seed(rank)
     step_no = [0]
-    replayers, one_in_flight, trainer = None, None, None
+    replayers, one_in_flight, two_in_flight, trainer = None, None, None, None
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if (args.streams > 1 and args.workload == "forward") else [None]
 
     if args.workload == "forward":
@@ -432,7 +442,9 @@ def main():
 
             def step():
                 loss = graphed_step()
-                trainer.finish_step()
+                # total=loss: the reference loop's per-iteration NaN test (trainer/RL_TDA.py:217-220) with its host read of the loss is
+                # part of the step, as in the reference (round-3 advisor: it was left out of the timed step)
+                trainer.finish_step(total=loss)
                 return loss
         else:
             def step():
@@ -516,9 +528,27 @@ def main():
                     solo(*batches[0])
             fence()
             one_in_flight = world * B * args.steps / (time.perf_counter() - t2)
+            # ... and with TWO branched replays in flight, the bench's default until round 2: keeps rounds comparable across the
+            # change of default (round-3 advisor)
+            if len(streams) >= 2 and len(batches) >= 2:
+                _engine.BRANCH_STREAMS = True
+                pair = [solo, _engine.GraphedForward(net.packed(dev), B, N_POINTS, dev, train_keys=False)]
+                _engine.BRANCH_STREAMS = branch
+                for i in range(4):
+                    with torch.cuda.stream(streams[i % 2]):
+                        pair[i % 2](*batches[i % 2])
+                fence()
+                t3 = time.perf_counter()
+                for i in range(args.steps):
+                    with torch.cuda.stream(streams[i % 2]):
+                        pair[i % 2](*batches[i % 2])
+                fence()
+                two_in_flight = world * B * args.steps / (time.perf_counter() - t3)
+                del pair
 
     if rank == 0:
-        traffic, traffic_src = _kernel_traffic()
+        tile = [t for t in timer if len(t) > 6 and t[6] == "tile"]
+        traffic, traffic_src = _kernel_traffic((len(tile) / max(k_roof, 1), sum(t[5] for t in tile) / max(k_roof, 1)) if tile and args.workload == "forward" else None)
         launches = len(timer)
         ksec = sum(e0.elapsed_time(e1) for e0, e1, *_ in timer) * 1e-3
         kflop = sum(f for _, _, f, *_ in timer)
@@ -530,7 +560,8 @@ def main():
             peak_basis = ("algorithmic fp32 FLOPs; each fp32 product costs 6 bf16 MFMA terms (3-term operand split), so "
                           "the bound is the dense bf16 MFMA peak 2500 TFLOP/s / 6; for scale, the fp32 MFMA peak is 157.3")
         elif args.gemm == "split16":
-            kernel_name = "gemm_split_kernel<f16> (+ heads_fused_kernel / conv_max_fused_kernel: the same 3-term fp16 MFMA arithmetic)"
+            kernel_name = ("gemm_pp_kernel<*> (both operands as fp16 planes) / gemm_split*_kernel<f16> (+ heads_fused_kernel / "
+                           "conv_max_fused_kernel: the same 3-term fp16 MFMA arithmetic)")
             peak = PEAK_BF16_MFMA_TFLOPS / 3.0
             peak_basis = ("algorithmic fp32 FLOPs; each fp32 product costs 3 fp16 MFMA terms (2-term operand split), so the "
                           "bound is the dense fp16 MFMA peak 2500 TFLOP/s / 3; for scale, the fp32 MFMA peak is 157.3")
@@ -571,6 +602,7 @@ def main():
                        "objects_per_gpu": B, "points": N_POINTS, "replicas": world, "batches_in_flight": len(streams),
                        "full_forward": not (fwd and args.eval_outputs_only),
                        "side_branches_in_a_forward": bool(_engine.BRANCH_STREAMS),
+                       **({} if fwd else {"nan_test_in_step": True}),
                        "hipgraph": {0: "off", 1: "whole batch" if replayers is None else "whole batch, one captured forward per stream",
                                     2: "two half batches on forked streams"}[args.graph]},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
@@ -610,6 +642,8 @@ def main():
                          % (flop_fwd / 1e9, GRAPH_CLASS_BYTES / 1e6, B)}
         if one_in_flight is not None:
             line["config"]["objects_per_s_one_batch_in_flight"] = round(one_in_flight, 1)     # this rank's clock, not max-over-ranks
+        if two_in_flight is not None:
+            line["config"]["objects_per_s_two_batches_in_flight"] = round(two_in_flight, 1)   # (two branched replays: the default of rounds 1-2)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(line), flush=True)

@@ -518,7 +518,12 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
         e1.record(torch.cuda.current_stream(A.device))
         # flops_ref: what this launch stands for in the reference's formulation (the factored wide layers run fewer FLOPs)
         fl = 2.0 * M * N * (k_alg or K) * batch
-        GEMM_TIMER.append((e0, e1, fl, (M, N, K, batch), fl if flops_ref is None else float(flops_ref)))
+        # algorithmic bytes of the launch (SURVEY 8d's rule: every operand once): A, W, the stored result (and its planes), plain and
+        # gathered residuals -- bench.py sets them against the PMC traffic of the tile-GEMM kernel family
+        nb = batch * 4.0 * (M * K + N * K + (M * (N - c_col0) if C is not None else 0) + (M * (N - c_col0) if c_planes is not None else 0)
+                            + (M * N if res1 is not None else 0) + (M * N if res2 is not None else 0)
+                            + (gather1[0].shape[0] * N if gather1 is not None else 0) + (gather2[0].shape[0] * N if gather2 is not None else 0))
+        GEMM_TIMER.append((e0, e1, fl, (M, N, K, batch), fl if flops_ref is None else float(flops_ref), nb, "tile"))
     return C
 
 
