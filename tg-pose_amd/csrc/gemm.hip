@@ -1145,7 +1145,7 @@ static int launch_split(GemmParams &p, hipStream_t stream)
     // 256 x 128 tiles on two 512-thread workgroups per CU.  Measured over the forward's 15 tile-kernel launches, each timed
     // alone: 139 us average against 154 us with square tiles only (the wide layer alone would lose: 1.04 -> 1.32 ms)
     const int64_t sq_tiles = (int64_t)tgp_cdiv(p.M, GEMM_BIG) * tgp_cdiv(p.N, GEMM_BIG) * p.batch;
-    // (round 2, re-measured on the forward's shapes with the current epilogues, scripts/route_ab.py: between one and 1.5 rounds of
+    // (round 2, re-measured on the forward's shapes with the current epilogues, a since-deleted A/B script: between one and 1.5 rounds of
     // square tiles the 1024-thread form is the faster one -- M = 32896, N = 512, K = 512: 85 vs 97 us; M = 8224, N = 2304,
     // K = 256: 54 vs 58 us -- below one round the two-workgroups-per-CU form wins by 25-30 %)
     const bool narrow = p.N <= 256 || sq_tiles < (int64_t)resident_slots();

@@ -657,11 +657,19 @@ __global__ __launch_bounds__(512, 2) void knn_feat_fused_kernel(const float *__r
 typedef float knn_f32x4 __attribute__((ext_vector_type(4)));
 
 #define KF16_ROWS 16
+// Tail rows: the network's clouds are 16 m + 4 (1028) or 16 m + 1 (257) rows, and a last block with 4 / 1 live rows per object is a
+// whole extra round of workgroups (2080 = 4.06 rounds of 512 slots; 544 = 1.06).  As in the 32-row form, a short tail (n_extra <= 8
+// rows) rides along: block rb < n_extra also takes row 16 nrb + rb, its distances computed on the vector pipe (the same ascending-k
+// FMA chain) by waves 1-3 -- which have one column group less than wave 0 -- into a 17th LDS row that wave 3 selects after its four.
+// Start skew: the two workgroups of a CU start together and would run their phases in step (both multiplying, then both selecting --
+// the overlap this form exists for would never happen); the workgroups of the launch's second half-round (the second slot of every
+// CU, as the dispatcher deals them) therefore begin with a pause of about one selection phase, once.
 template <int DIM, int NT, int CH>
 __global__ __launch_bounds__(256, 2) void knn_feat_fused16_kernel(const float *__restrict__ xt, const float *__restrict__ q, int B, int n, int k,
-                                                                  int32_t *__restrict__ idx, int nrb, int ldw)
+                                                                  int32_t *__restrict__ idx, int nrb, int ldw, int n_extra, int skew_lo,
+                                                                  int skew_hi, int skew_sleeps)
 {
-    extern __shared__ __attribute__((aligned(16))) float dblk16[];    // [16][ldw]
+    extern __shared__ __attribute__((aligned(16))) float dblk16[];    // [16 (+ 1 with a tail row)][ldw]
     __shared__ uint32_t s_lmin[4][64];
     __shared__ __attribute__((aligned(16))) uint2 s_list[4][72];
     constexpr int STEPS = DIM / 4;                                    // MFMA steps per column group (k quads)
@@ -676,6 +684,10 @@ __global__ __launch_bounds__(256, 2) void knn_feat_fused16_kernel(const float *_
     const float *xo = xt + (size_t)b * DIM * ldw + (size_t)g * ldw;   // + 4 s ldw: the lane's k of step s
     const float *qb = q + (size_t)b * n;
     const int ngrp = (ldw + 63) >> 6;                                  // column groups of 64 (the last may hold 32: ldw % 32 == 0)
+    const bool has_extra = rb < n_extra;                              // workgroup-uniform
+    const int ix = nrb * KF16_ROWS + rb;                              // the tail row this block takes along
+    if ((int)blockIdx.x >= skew_lo && (int)blockIdx.x < skew_hi)
+        for (int z = 0; z < skew_sleeps; ++z) __builtin_amdgcn_s_sleep(127);      // 127 x 64 cycles each
     {
         float a[STEPS];
 #pragma unroll
@@ -735,11 +747,40 @@ __global__ __launch_bounds__(256, 2) void knn_feat_fused16_kernel(const float *_
             }
         }
     }
+    if (has_extra && wave != 0) {
+        // the tail row against every column: inner = x[0] y[0], then fmaf in ascending k -- what the MFMA chain computes.  Waves 1-3:
+        // three columns per thread and pass, their chains interleaved (48 loads in flight)
+        const float *xa = xt + (size_t)b * DIM * ldw;
+        const float qx = qb[ix];
+        const int t0 = (wave - 1) * 64 + lane;
+        for (int cbase = t0; cbase < ldw; cbase += 3 * 192) {
+            const int c0 = cbase, c1 = cbase + 192, c2 = cbase + 384;
+            const int l0 = c0, l1 = min(c1, ldw - 1), l2 = min(c2, ldw - 1);
+            const float x0 = xa[ix];
+            float in0 = x0 * xa[l0], in1 = x0 * xa[l1], in2 = x0 * xa[l2];
+#pragma unroll 16
+            for (int kk = 1; kk < DIM; ++kk) {
+                const float xv = xa[(size_t)kk * ldw + ix];
+                in0 = fmaf(xv, xa[(size_t)kk * ldw + l0], in0);
+                in1 = fmaf(xv, xa[(size_t)kk * ldw + l1], in1);
+                in2 = fmaf(xv, xa[(size_t)kk * ldw + l2], in2);
+            }
+            auto put = [&](int col, float inner) {
+                if (col < ldw) {
+                    const float t1 = inner * -2.0f;
+                    const float t2 = t1 + qb[min(col, n - 1)];
+                    dblk16[KF16_ROWS * ldw + col] = col < n ? t2 + qx : INFINITY;
+                }
+            };
+            put(c0, in0), put(c1, in1), put(c2, in2);
+        }
+    }
     __syncthreads();
-    // ---- phase 2: four rows per wave
+    // ---- phase 2: four rows per wave (wave 3: the tail row as its fifth)
 #pragma unroll 1
-    for (int rr = 0; rr < 4; ++rr) {
-        const int lrow = wave * 4 + rr, i = i0 + lrow;
+    for (int rr = 0; rr < 5; ++rr) {
+        if (rr == 4 && !(has_extra && wave == 3)) break;              // wave-uniform
+        const int lrow = rr == 4 ? KF16_ROWS : wave * 4 + rr, i = rr == 4 ? ix : i0 + lrow;
         if (i >= n) break;                                            // wave-uniform
         uint32_t key[NT];
         const float *row = dblk16 + lrow * ldw;
@@ -837,17 +878,29 @@ static int launch_knn_fused(const float *xt, const float *q, int B, int n, int k
 {
     const int ncb = tgp_cdiv(n, 32), ldw = ncb * 32;
     if (form != 1) {
-        const int nrb16 = tgp_cdiv(n, KF16_ROWS);
-        const size_t lds16 = (size_t)KF16_ROWS * ldw * sizeof(float);
+        const int tail16 = n % KF16_ROWS, n_extra16 = (tail16 > 0 && tail16 <= 8 && tail16 <= n / KF16_ROWS) ? tail16 : 0;
+        const int nrb16 = n_extra16 ? n / KF16_ROWS : tgp_cdiv(n, KF16_ROWS);
+        const size_t lds16 = (size_t)(KF16_ROWS + (n_extra16 ? 1 : 0)) * ldw * sizeof(float);
         static bool attr16 = false;
         if (!attr16) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(knn_feat_fused16_kernel<DIM, NT, CH / 2>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, KF16_ROWS * KF_MAX_LDW * (int)sizeof(float));
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (KF16_ROWS + 1) * KF_MAX_LDW * (int)sizeof(float));
             if (e != hipSuccess) return (int)e;
             attr16 = true;
         }
-        hipLaunchKernelGGL((knn_feat_fused16_kernel<DIM, NT, CH / 2>), dim3(tgp_xcd_grid(B, nrb16)), dim3(256), lds16, stream, xt, q, B, n, k,
-                           idx, nrb16, ldw);
+        // start skew of the second half-round (see the kernel): only when the launch fills both slots of every CU for several rounds
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                cus = 256;
+        }
+        const int grid16 = tgp_xcd_grid(B, nrb16);
+        const bool skew = form != 3 && grid16 >= 4 * cus;
+        // ~ one selection phase: 16 rows x ~0.7 us per row and wave of four -> ~10 us at n = 1028, scaled with the row length
+        const int sleeps = skew ? (int)((int64_t)10 * n / 1028 * 2000 / (127 * 64)) + 1 : 0;
+        hipLaunchKernelGGL((knn_feat_fused16_kernel<DIM, NT, CH / 2>), dim3(grid16), dim3(256), lds16, stream, xt, q, B, n, k,
+                           idx, nrb16, ldw, n_extra16, skew ? cus : 0, skew ? 2 * cus : 0, sleeps);
         return TGP_LAUNCH_RESULT();
     }
     // a tail of at most 8 rows (and fewer than there are full blocks) rides along with the first blocks instead of forming its own
@@ -877,7 +930,7 @@ extern "C" int tgp_knn_feat(const float *feat, int ld, int B, int n, int d, int 
 extern "C" int tgp_knn_feat_form(const float *feat, int ld, int B, int n, int d, int k, int32_t *idx, void *workspace,
                                  int64_t workspace_bytes, int form, tgp_stream_t stream)
 {
-    TGP_REQUIRE(feat && idx && workspace && form >= 0 && form <= 2);
+    TGP_REQUIRE(feat && idx && workspace && form >= 0 && form <= 3);
     const int chk = knn_check(B, n, k);
     if (chk) return chk;
     if (d <= 0 || (d & 31) || (d >> 5) >= 16) return TGP_EUNSUPPORTED;

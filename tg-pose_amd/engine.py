@@ -242,7 +242,7 @@ _SIDE = {}
 BRANCH_STREAMS = True   # run the PH-tail -> decoder chain beside the head chain on a second HIP stream
 FACTORED = True         # eval forward: the layers over the concat buffer run factored over the upsampling (pack_factored)
 HEADS_FUSED = True      # ... and the heads' conv1 -> conv2 -> max as one kernel (csrc/heads_fused.hip) instead of two GEMM launches
-# Two more side branches, built and measured in round 3 (scripts/branch_ab.py, scripts/queues_ab.py; profiles/r03_branch_ab.txt) and
+# Two more side branches, built and measured in round 3 (scripts/branch_ab.py; profiles/r03_branch_ab.txt) and
 # left OFF: the level-1 coarse product beside conv_4, and the rows behind the fused heads kernel's last full round (771 workgroups
 # = 3.01 rounds of 256) on the tile kernels beside it.  One batch in flight: +1 .. 3 % (a chip-filling GEMM beside a chain of small
 # launches does not shorten the chain -- its workgroups hold every CU, and the small launches wait for them).  Two batches in
