@@ -661,13 +661,12 @@ typedef float knn_f32x4 __attribute__((ext_vector_type(4)));
 // whole extra round of workgroups (2080 = 4.06 rounds of 512 slots; 544 = 1.06).  As in the 32-row form, a short tail (n_extra <= 8
 // rows) rides along: block rb < n_extra also takes row 16 nrb + rb, its distances computed on the vector pipe (the same ascending-k
 // FMA chain) by waves 1-3 -- which have one column group less than wave 0 -- into a 17th LDS row that wave 3 selects after its four.
-// Start skew: the two workgroups of a CU start together and would run their phases in step (both multiplying, then both selecting --
-// the overlap this form exists for would never happen); the workgroups of the launch's second half-round (the second slot of every
-// CU, as the dispatcher deals them) therefore begin with a pause of about one selection phase, once.
+// (Measured and dropped: a start skew -- the workgroups of the launch's second half-round, i.e. the second slot of every CU, pausing for
+// about one selection phase once, so that the two workgroups of a CU would not run their phases in step: 18.92 k against 18.97 k
+// objects/s without it, two runs each on one box; the workgroups drift apart by themselves within a round.)
 template <int DIM, int NT, int CH>
 __global__ __launch_bounds__(256, 2) void knn_feat_fused16_kernel(const float *__restrict__ xt, const float *__restrict__ q, int B, int n, int k,
-                                                                  int32_t *__restrict__ idx, int nrb, int ldw, int n_extra, int skew_lo,
-                                                                  int skew_hi, int skew_sleeps)
+                                                                  int32_t *__restrict__ idx, int nrb, int ldw, int n_extra)
 {
     extern __shared__ __attribute__((aligned(16))) float dblk16[];    // [16 (+ 1 with a tail row)][ldw]
     __shared__ uint32_t s_lmin[4][64];
@@ -686,8 +685,6 @@ __global__ __launch_bounds__(256, 2) void knn_feat_fused16_kernel(const float *_
     const int ngrp = (ldw + 63) >> 6;                                  // column groups of 64 (the last may hold 32: ldw % 32 == 0)
     const bool has_extra = rb < n_extra;                              // workgroup-uniform
     const int ix = nrb * KF16_ROWS + rb;                              // the tail row this block takes along
-    if ((int)blockIdx.x >= skew_lo && (int)blockIdx.x < skew_hi)
-        for (int z = 0; z < skew_sleeps; ++z) __builtin_amdgcn_s_sleep(127);      // 127 x 64 cycles each
     {
         float a[STEPS];
 #pragma unroll
@@ -888,19 +885,9 @@ static int launch_knn_fused(const float *xt, const float *q, int B, int n, int k
             if (e != hipSuccess) return (int)e;
             attr16 = true;
         }
-        // start skew of the second half-round (see the kernel): only when the launch fills both slots of every CU for several rounds
-        static int cus = 0;
-        if (!cus) {
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-                cus = 256;
-        }
-        const int grid16 = tgp_xcd_grid(B, nrb16);
-        const bool skew = form != 3 && grid16 >= 4 * cus;
-        // ~ one selection phase: 16 rows x ~0.7 us per row and wave of four -> ~10 us at n = 1028, scaled with the row length
-        const int sleeps = skew ? (int)((int64_t)10 * n / 1028 * 2000 / (127 * 64)) + 1 : 0;
-        hipLaunchKernelGGL((knn_feat_fused16_kernel<DIM, NT, CH / 2>), dim3(grid16), dim3(256), lds16, stream, xt, q, B, n, k,
-                           idx, nrb16, ldw, n_extra16, skew ? cus : 0, skew ? 2 * cus : 0, sleeps);
+        // (four steps per prefetched chunk, three chunks ahead; eight measured the same: 18.68 vs 18.67 k objects/s)
+        hipLaunchKernelGGL((knn_feat_fused16_kernel<DIM, NT, CH / 2>), dim3(tgp_xcd_grid(B, nrb16)), dim3(256), lds16, stream, xt, q, B, n, k,
+                           idx, nrb16, ldw, n_extra16);
         return TGP_LAUNCH_RESULT();
     }
     // a tail of at most 8 rows (and fewer than there are full blocks) rides along with the first blocks instead of forming its own
@@ -930,7 +917,7 @@ extern "C" int tgp_knn_feat(const float *feat, int ld, int B, int n, int d, int 
 extern "C" int tgp_knn_feat_form(const float *feat, int ld, int B, int n, int d, int k, int32_t *idx, void *workspace,
                                  int64_t workspace_bytes, int form, tgp_stream_t stream)
 {
-    TGP_REQUIRE(feat && idx && workspace && form >= 0 && form <= 3);
+    TGP_REQUIRE(feat && idx && workspace && form >= 0 && form <= 2);
     const int chk = knn_check(B, n, k);
     if (chk) return chk;
     if (d <= 0 || (d & 31) || (d >> 5) >= 16) return TGP_EUNSUPPORTED;
