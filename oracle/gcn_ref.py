@@ -83,6 +83,17 @@ class GraphCache(object):
 
 
 # ----------------------------------------------------------------------------- layers
+def tapv(P, name, t):
+    """(tests: decision forcing, posenet_ref.posenet_forward(force=...)) the value of intermediate `name` replaced by the recorded one,
+    gradients flowing through as if it were this tensor"""
+    if P.get("_record") is not None:
+        P["_record"][name] = t.detach().clone()
+    f = P.get("_force")
+    if f is None or name not in f:
+        return t
+    return t + (f[name].to(t.dtype).view(t.shape) - t).detach()
+
+
 def _pointwise(x, w):
     """Conv1d(kernel 1, no bias) on channel-last rows: x (B,n,Cin), w (Cout,Cin,1) -> (B,n,Cout)."""
     return F.conv1d(x.transpose(1, 2), w).transpose(1, 2).contiguous()
@@ -111,7 +122,8 @@ def surface_conv(P, name, xyz, k, cache):
     theta = torch.relu(dirs @ sdn)
     B, n = xyz.shape[:2]
     theta = theta.reshape(B, n, k, S, -1).max(dim=2)[0].mean(dim=2)  # max over k, mean over S
-    return _orl_forward(P, name, theta, xyz, k, cache) + f_ste
+    theta = tapv(P, name + ".g", theta)
+    return tapv(P, name + ".out", _orl_forward(P, name, theta, xyz, k, cache) + f_ste)
 
 
 def hs_conv(P, name, xyz, fmap, k, cache):
@@ -125,11 +137,11 @@ def hs_conv(P, name, xyz, fmap, k, cache):
     sdn = F.normalize(P[name + ".directions"], dim=0)
     B, n = xyz.shape[:2]
     theta = torch.relu(dirs @ sdn).reshape(B, n, k, -1)               # (B,n,k,S*cout)
-    proj = fmap @ W + bias                                            # (B,n,(S+1)*cout)
+    proj = tapv(P, name + ".proj", fmap @ W + bias)                   # (B,n,(S+1)*cout)
     center, support = proj[:, :, :cout], proj[:, :, cout:]
     act = (theta * gather_rows(support, idx)).view(B, n, k, S, cout)
-    feature = center + act.max(dim=2)[0].mean(dim=2)
-    return _orl_forward(P, name, feature, xyz, k, cache) + f_ste
+    feature = tapv(P, name + ".g", center + act.max(dim=2)[0].mean(dim=2))
+    return tapv(P, name + ".out", _orl_forward(P, name, feature, xyz, k, cache) + f_ste)
 
 
 def pool(xyz, fmap, sample_idx, cache, tag, k=4):

@@ -31,6 +31,45 @@ def _bn(P, name, x):
                         P[name + ".bias"], False, 0.0, BN_EPS)
 
 
+def _act(P, z, slope=0.0, cf=False):
+    """ReLU / LeakyReLU.  With forced decisions (P["_force"], tests): activation number i of the forward takes its mask -- which
+    elements pass -- and its value from the recorded output "act.i" of the run under test; the gradient is this run's, through the
+    recorded mask.  (The forward's activations are numbered in call order, the same on both sides.)"""
+    f = P.get("_force")
+    if f is None:
+        y = F.leaky_relu(z, slope) if slope else torch.relu(z)
+        if P.get("_record") is not None:            # (self-check of the forcing machinery: channel-last, like the run under test)
+            i = P["_act_i"] = P.get("_act_i", -1) + 1
+            P["_record"]["act.%d" % i] = (y.transpose(1, 2) if (cf and y.dim() == 3) else y).detach().contiguous().clone()
+        return y
+    i = P["_act_i"] = P.get("_act_i", -1) + 1
+    y_rec = f["act.%d" % i].to(z.dtype)
+    if cf and z.dim() == 3:                         # recorded channel-last (B, n, C), computed channel-first (B, C, n)
+        y_rec = y_rec.reshape(z.shape[0], -1, z.shape[1]).transpose(1, 2)
+    y_rec = y_rec.reshape(z.shape)
+    on = (y_rec > 0).to(z.dtype)
+    y = z * (on + slope * (1 - on))
+    return y + (y_rec - y).detach()
+
+
+def _act_maxpool(P, z, slope=0.0):
+    """max over the points (last dim) of act(z), z (B, C, n) -> (B, C).  Forced: pooled output number i takes the recorded winner per
+    (object, channel) and the recorded sign."""
+    f = P.get("_force")
+    if f is None:
+        y, arg = torch.max(F.leaky_relu(z, slope) if slope else torch.relu(z), 2)
+        if P.get("_record") is not None:
+            i = P["_pool_i"] = P.get("_pool_i", -1) + 1
+            P["_record"]["pool.%d" % i] = (arg.int(), y.detach().clone())
+        return y
+    i = P["_pool_i"] = P.get("_pool_i", -1) + 1
+    arg, pooled = f["pool.%d" % i]
+    zz = z.gather(2, arg.long().unsqueeze(2)).squeeze(2)
+    on = (pooled > 0).to(z.dtype)
+    y = zz * (on + slope * (1 - on))
+    return y + (pooled.to(z.dtype) - y).detach()
+
+
 def _bn_rows(P, name, x):
     """BatchNorm1d applied to channel-last rows (B,n,C), as FaceRecon.py:58-65 does via transposes."""
     return _bn(P, name, x.transpose(1, 2)).transpose(1, 2)
@@ -47,12 +86,12 @@ def encoder(P, pre, xyz, cat_id, sample_idx, cache, flags):
     kmax = flags["gcn_n_num"]
     one_hot = torch.zeros(B, flags["obj_c"]).scatter_(1, cat_id.view(-1, 1).long(), 1)
 
-    fm0 = torch.relu(G.surface_conv(P, enc + "conv_0", xyz, kmax, cache))
-    fm1 = torch.relu(_bn_rows(P, enc + "bn1", G.hs_conv(P, enc + "conv_1", xyz, fm0, kmax, cache)))
+    fm0 = _act(P, G.surface_conv(P, enc + "conv_0", xyz, kmax, cache))
+    fm1 = _act(P, _bn_rows(P, enc + "bn1", G.hs_conv(P, enc + "conv_1", xyz, fm0, kmax, cache)))
     v1, fp1 = G.pool(xyz, fm1, sample_idx[0], cache, enc + "pool_1")
     k1 = min(kmax, v1.shape[1] // 8)
-    fm2 = torch.relu(_bn_rows(P, enc + "bn2", G.hs_conv(P, enc + "conv_2", v1, fp1, k1, cache)))
-    fm3 = torch.relu(_bn_rows(P, enc + "bn3", G.hs_conv(P, enc + "conv_3", v1, fm2, k1, cache)))
+    fm2 = _act(P, _bn_rows(P, enc + "bn2", G.hs_conv(P, enc + "conv_2", v1, fp1, k1, cache)))
+    fm3 = _act(P, _bn_rows(P, enc + "bn3", G.hs_conv(P, enc + "conv_3", v1, fm2, k1, cache)))
     v2, fp2 = G.pool(v1, fm3, sample_idx[1], cache, enc + "pool_2")
     k2 = min(kmax, v2.shape[1] // 8)
     fm4 = G.hs_conv(P, enc + "conv_4", v2, fp2, k2, cache)
@@ -70,10 +109,13 @@ def ph_predictor(P, pre, feat):
     """PH_Predictor.forward: feat (B,N,1286) -> feat_ph (B,1286,N), h1, h2 (B,2500)."""
     ph = pre + "ph_pred."
     B, N, _ = feat.shape
-    x = F.leaky_relu(_bn(P, ph + "conv_5.1", _conv(P, ph + "conv_5.0", feat.permute(0, 2, 1))), 0.2)
-    g = F.adaptive_max_pool1d(x, 1).view(B, -1)
+    if P.get("_force") is None and P.get("_record") is None:
+        x = F.leaky_relu(_bn(P, ph + "conv_5.1", _conv(P, ph + "conv_5.0", feat.permute(0, 2, 1))), 0.2)
+        g = F.adaptive_max_pool1d(x, 1).view(B, -1)
+    else:
+        g = _act_maxpool(P, _bn(P, ph + "conv_5.1", _conv(P, ph + "conv_5.0", feat.permute(0, 2, 1))), 0.2)
     g = torch.cat((g, g), 1)
-    g = F.leaky_relu(_bn(P, ph + "bn5", F.linear(g, P[ph + "linear1.weight"])), 0.2)
+    g = _act(P, _bn(P, ph + "bn5", F.linear(g, P[ph + "linear1.weight"])), 0.2)
     pi1 = F.linear(g, P[ph + "linear2.weight"], P[ph + "linear2.bias"])
     pi2 = F.linear(g, P[ph + "linear3.weight"], P[ph + "linear3.bias"])
     back1 = F.linear(pi1, P[ph + "linear4.weight"], P[ph + "linear4.bias"])
@@ -86,17 +128,20 @@ def decoder(P, pre, x):
     """Face_Dec.forward: (B,1286,N) -> recon (B,N,3)."""
     d = pre + "decoder."
     for conv, bn in (("0", "1"), ("3", "4"), ("6", "7")):
-        x = torch.relu(_bn(P, d + "conv1d_block." + bn, _conv(P, d + "conv1d_block." + conv, x)))
-    x = torch.relu(_bn(P, d + "recon_head.1", _conv(P, d + "recon_head.0", x)))
+        x = _act(P, _bn(P, d + "conv1d_block." + bn, _conv(P, d + "conv1d_block." + conv, x)), cf=True)
+    x = _act(P, _bn(P, d + "recon_head.1", _conv(P, d + "recon_head.0", x)), cf=True)
     return _conv(P, d + "recon_head.3", x).permute(0, 2, 1)
 
 
 def point_head(P, name, x):
     """Rot_green / Rot_red / Pose_Ts body: (B,C,N) -> (B,out)."""
-    x = torch.relu(_bn(P, name + ".bn1", _conv(P, name + ".conv1", x)))
-    x = torch.relu(_bn(P, name + ".bn2", _conv(P, name + ".conv2", x)))
-    x = torch.max(x, 2, keepdim=True)[0]
-    x = torch.relu(_bn(P, name + ".bn3", _conv(P, name + ".conv3", x)))
+    x = _act(P, _bn(P, name + ".bn1", _conv(P, name + ".conv1", x)), cf=True)
+    if P.get("_force") is None and P.get("_record") is None:
+        x = torch.relu(_bn(P, name + ".bn2", _conv(P, name + ".conv2", x)))
+        x = torch.max(x, 2, keepdim=True)[0]
+    else:
+        x = _act_maxpool(P, _bn(P, name + ".bn2", _conv(P, name + ".conv2", x))).unsqueeze(2)
+    x = _act(P, _bn(P, name + ".bn3", _conv(P, name + ".conv3", x)), cf=True)
     return _conv(P, name + ".conv4", x).squeeze(2)
 
 
@@ -104,7 +149,7 @@ DEFAULT_FLAGS = dict(gcn_n_num=20, gcn_sup_num=7, obj_c=6)
 
 
 def posenet_forward(P, points, obj_id, sample_idx=None, train_keys=False, mode="exact", inject=None,
-                    flags=None, want_intermediates=False, bn_train=False):
+                    flags=None, want_intermediates=False, bn_train=False, force=None, record=None):
     """PoseNet9D(only_encoder=False).forward in eval mode, or (bn_train=True) in training mode with dropout
     disabled; then out["_bn_new"] holds every BatchNorm buffer after the step.
 
@@ -117,6 +162,13 @@ def posenet_forward(P, points, obj_id, sample_idx=None, train_keys=False, mode="
     P = dict(P)
     P["_support_num"] = flags["gcn_sup_num"]
     P["_bn_train"], P["_bn_new"] = bool(bn_train), {}
+    if force is not None:
+        # tests (decision forcing): intermediates and decisions recorded from the run under test -- layer outputs by name, activation
+        # outputs and pooled winners in call order -- replace this run's values / ReLU masks / max-over-points winners, so that its
+        # autograd differentiates the SAME piecewise-linear branch of the network as the run under test
+        P["_force"] = force
+    if record is not None:
+        P["_record"] = record                       # the same intermediates / decisions of THIS run, under the same names
     cache = G.GraphCache(mode=mode, inject=inject)
     B, N, _ = points.shape
     if sample_idx is None:

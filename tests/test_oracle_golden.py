@@ -458,3 +458,41 @@ def test_category_cloud_fixture_is_the_references_data():
         r = L.r_dcd(torch.from_numpy(g["points_category"]), out["recon"], torch.from_numpy(g["gt_R"]), out["p_green_R"], out["f_green_R"],
                     out["p_red_R"], out["f_red_R"], out["Pred_T"], out["Pred_s"], torch.from_numpy(g["sym"]))
     assert np.allclose(r.numpy(), g["r_dcd"], rtol=1e-4)
+
+
+def test_oracle_forced_decisions_reproduce_a_free_run():
+    """The decision-forcing hooks of the oracle (posenet_forward(force=...), used by the GPU test of the whole network's gradient):
+    a run forced with the intermediates and decisions recorded from a free run of the SAME oracle reproduces that run's outputs and
+    parameter gradients (the forced run differentiates the same branch at the same values); forcing with another input's decisions
+    changes the gradients (the hooks do act)."""
+    from oracle import posenet_ref as PR
+    from tgpose_amd import seeded_state_dict
+    from tests.util import synth_points
+    sd = seeded_state_dict(3)
+    B, N = 3, 256
+    torch.manual_seed(1)
+    i1 = torch.randperm(N)[: N // 4]
+    smp = (i1, torch.randperm(N // 4)[: N // 16])
+
+    def run(pts, obj, force=None, record=None):
+        P = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running_" not in k else v.clone()) for k, v in sd.items()}
+        out = PR.posenet_forward(P, pts, obj, sample_idx=smp, train_keys=True, mode="exact", bn_train=True, force=force, record=record)
+        out.pop("_bn_new")
+        gen = torch.Generator().manual_seed(0)
+        loss = sum((v * torch.randn(v.shape, generator=gen)).sum() * (1e-3 if k == "feat" else 1e-2) for k, v in out.items())
+        loss.backward()
+        return out, {k: v.grad for k, v in P.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None}
+    pts, obj = synth_points(B, N, 5)
+    rec = {}
+    out0, g0 = run(pts, obj, record=rec)
+    assert sum(k.startswith("act.") for k in rec) == 15 and sum(k.startswith("pool.") for k in rec) == 4
+    out1, g1 = run(pts, obj, force=rec)
+    for k in out0:
+        assert torch.allclose(out0[k], out1[k], atol=1e-6, rtol=0), k
+    for k in g0:
+        assert (g0[k] - g1[k]).norm() <= 1e-5 * (g0[k].norm() + 1e-12), k
+    pts2, obj2 = synth_points(B, N, 6)
+    rec2 = {}
+    run(pts2, obj2, record=rec2)
+    _, g2 = run(pts, obj, force=rec2)
+    assert any((g0[k] - g2[k]).norm() > 1e-2 * g0[k].norm() for k in g0)

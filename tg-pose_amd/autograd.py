@@ -330,6 +330,8 @@ class _BNActPool(Function):
         _, mean, var = ops.bn_train(x, gamma, beta, BN_EPS, act, slope, want_out=False, colmax_keys=keys, rows_per_obj=n,
                                     running=_running(bn))
         pooled, arg = ops.colmax_arg(x, B, n, bn=(mean, var, gamma, beta), act=act, slope=slope)
+        if TAPS is not None:
+            _tap_seq("pool", (arg.detach().cpu() % n, pooled.detach().cpu()))
         ctx.save_for_backward(x, mean, var, gamma, beta, arg)
         ctx.act, ctx.slope = act, slope
         return pooled
@@ -353,8 +355,29 @@ def _running(bn):
     return bn.running_mean, bn.running_var, bn.momentum, bn.num_batches_tracked
 
 
+# tests (tests/test_gpu_parity.py::test_backward_full_network_with_forced_decisions): a dict that receives, on the host, the layer outputs
+# (by name), every activation's output ("act.i", call order) and every pooled layer's winners and values ("pool.i") of a training
+# forward -- the decisions of this run, which the CPU oracle then takes over (oracle.posenet_ref.posenet_forward(force=...)).
+TAPS = None
+
+
+def _tap(name, t):
+    if TAPS is not None:
+        TAPS[name] = t.detach().cpu()
+    return t
+
+
+def _tap_seq(kind, value):
+    if TAPS is not None:
+        i = TAPS["_n_" + kind] = TAPS.get("_n_" + kind, -1) + 1
+        TAPS["%s.%d" % (kind, i)] = value
+
+
 def bn_act(x, bn, act=1, slope=0.0):
-    return _BNAct.apply(x, bn.weight, bn.bias, bn, act, slope)
+    y = _BNAct.apply(x, bn.weight, bn.bias, bn, act, slope)
+    if TAPS is not None:
+        _tap_seq("act", y.detach().cpu())
+    return y
 
 
 def bn_act_pool(x, bn, act=1, slope=0.0):
@@ -588,21 +611,23 @@ def _orl(layer, g, idx_orl, rev=None):
 def _surface(layer, xyz, graphs, kmax):
     C = layer.kernel_num
     sdn = _NormalizeDirs.apply(layer.directions)
-    g = _GConvSurface.apply(xyz, graphs("conv_0.rf", 0, xyz, kmax), sdn, C)
+    pre = getattr(getattr(graphs, "g", None), "prefix", "")
+    g = _tap(pre + "conv_0.g", _GConvSurface.apply(xyz, graphs("conv_0.rf", 0, xyz, kmax), sdn, C))
     idx_orl = graphs("conv_0.orl_xyz", 0, xyz, kmax)
     out = _orl(layer, g, idx_orl, _reverse(graphs, idx_orl, xyz.shape[1]))
-    return _LinearEpi.apply(_pad4(xyz), _pad4(_w2(layer.STE_layer)), None, None, out, False)      # STE(xyz) + out
+    return _tap(pre + "conv_0.out", _LinearEpi.apply(_pad4(xyz), _pad4(_w2(layer.STE_layer)), None, None, out, False))   # STE(xyz) + out
 
 
 def _hs(layer, name, xyz, fm, graphs, level, k):
     C = layer.out_channel
     sdn = _NormalizeDirs.apply(layer.directions)
     idx_rf = graphs(name + ".rf", None, fm, k)
-    proj = linear(fm, layer.weights.t(), layer.bias)                      # (B, n, 8C) = [centre | support]
-    g = _GConvHS.apply(xyz, idx_rf, proj, sdn, C, _reverse(graphs, idx_rf, xyz.shape[1]))
+    pre = getattr(getattr(graphs, "g", None), "prefix", "")
+    proj = _tap(pre + name + ".proj", linear(fm, layer.weights.t(), layer.bias))     # (B, n, 8C) = [centre | support]
+    g = _tap(pre + name + ".g", _GConvHS.apply(xyz, idx_rf, proj, sdn, C, _reverse(graphs, idx_rf, xyz.shape[1])))
     idx_orl = graphs(name + ".orl_xyz", level, xyz, k)
     out = _orl(layer, g, idx_orl, _reverse(graphs, idx_orl, xyz.shape[1]))
-    return _LinearEpi.apply(fm, _w2(layer.STE_layer), None, None, out, False)                          # STE(fm) + out
+    return _tap(pre + name + ".out", _LinearEpi.apply(fm, _w2(layer.STE_layer), None, None, out, False))      # STE(fm) + out
 
 
 class _GraphSource(object):
@@ -645,6 +670,8 @@ def encoder(enc, xyz, obj_id, sample_idx, graphs, kmax=20, n_cls=6):
     s1 = sample_idx[0].to(device=dev, dtype=torch.int32)
     s2 = sample_idx[1].to(device=dev, dtype=torch.int32)
     fm0 = torch.relu(_surface(enc.conv_0, xyz, graphs, kmax))
+    if TAPS is not None:
+        _tap_seq("act", fm0.detach().cpu())
     fm1 = bn_act(_hs(enc.conv_1, "conv_1", xyz, fm0, graphs, 0, kmax), enc.bn1)
     v1, fp1 = _PoolMax.apply(xyz, fm1, graphs("pool_1.xyz", 0, xyz, kmax), s1)
     k1 = min(kmax, v1.shape[1] // 8)
