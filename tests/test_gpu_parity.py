@@ -3687,11 +3687,11 @@ def test_backward_full_network_with_forced_decisions(ops, gemm_mode):
     replaces the oracle's value (so every max over neighbours sees the same candidates), each recorded activation supplies the ReLU
     mask, each recorded winner the max over points (oracle.posenet_ref.posenet_forward(force=...), itself checked on the CPU by
     tests/test_oracle_golden.py::test_oracle_forced_decisions_reproduce_a_free_run).  What is left between the two gradients is
-    rounding: every one of the 103 parameters within 2e-3 relative L2 (B = 3, N = 1028, fp16-split GEMMs and exact-fp32 GEMMs), and
+    rounding: every parameter within 2e-3 relative L2 (B = 4, N = 1028, fp16-split GEMMs and exact-fp32 GEMMs; median ~3e-5), and
     the count of visible ReLU decisions that differ in the free-running oracle is printed beside it."""
     from tgpose_amd import FLAGS, seeded_state_dict, autograd
     _, _, PR = _oracle()
-    B, N, seed = 3, 1028, 44
+    B, N, seed = 4, 1028, 44
     sd = seeded_state_dict(seed)
     pts, obj = synth_points(B, N, seed)
     torch.manual_seed(seed)
@@ -3728,6 +3728,10 @@ def test_backward_full_network_with_forced_decisions(ops, gemm_mode):
     rel = {k: (got[k].cpu() - w).norm().item() / (w.norm().item() + GRAD_ATOL) for k, w in want.items()}
     print("forced-decision backward %s: worst |dg|/|g| %.2e (%s), median %.2e; free-running oracle differs in %d of %d visible ReLU decisions"
           % (gemm_mode, max(rel.values()), max(rel, key=rel.get), sorted(rel.values())[len(rel) // 2], flipped, relu_cols[0].numel()))
-    bad = {k: v for k, v in rel.items() if v > 2e-3}
+    for k in sorted(rel, key=rel.get, reverse=True)[:6]:
+        print("|dg|_2 / (|g|_2 + %.0e)  %-46s %.2e   (|g|_2 %.3e)" % (GRAD_ATOL, k, rel[k], want[k].norm().item()))
+    # conv biases in front of a BatchNorm (and what only reaches the loss through such a pair at B = 4) have a gradient that is zero in
+    # exact arithmetic: both sides return rounding noise there, held to an absolute bar
+    bad = {k: v for k, v in rel.items() if (v > 2e-3 if want[k].norm().item() >= GRAD_ATOL else (got[k].cpu() - want[k]).norm().item() > 2e-4)}
     assert not bad, bad
-    assert len(want) >= 100
+    assert len(want) >= 100 and sum(want[k].norm().item() >= GRAD_ATOL for k in want) >= 80
