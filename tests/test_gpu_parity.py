@@ -1891,7 +1891,9 @@ def test_encoder_from_seam_operators_trains_like_the_reference(ops, monkeypatch,
         rel = (a - r).norm().item() / max(r.norm().item(), 1e-12)
         worst = max(worst, rel)
         # default mode: a few neighbour winners change (test_hs_layer_backward_vs_oracle_autograd); the HS layers' biases, whose
-        # gradient exists only through those winners, feel it most: the network-level bar (GRAD_TOL) applies there
+        # gradient exists only through those winners, feel it most: the network-level bar (GRAD_TOL) applies there.  That the 3e-2
+        # is decisions and not kernels is what test_backward_full_network_with_forced_decisions shows: with the HIP run's branch
+        # forced on the oracle, the same arithmetic holds 2e-3 on every parameter of the whole network at N = 1028 (median 6e-6).
         assert rel <= (2e-3 if gemm_mode == "fp32" else GRAD_TOL), (k, rel)
     # and under no_grad the same modules run the fused kernels and return plain tensors
     torch.manual_seed(99)
