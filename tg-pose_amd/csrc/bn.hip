@@ -95,8 +95,10 @@ __global__ __launch_bounds__(256) void bn_stats_partial_v4_kernel(const float *_
 // 64 columns x 4 chunk groups per workgroup: group g merges the chunks [g * per, (g + 1) * per) in order, the four group results
 // are merged in group order (a fixed tree: deterministic)
 // run_mean / run_var / batches (may be NULL): nn.BatchNorm1d's buffers, moved here instead of by four tiny torch launches per
-// module and step -- running <- (1 - m) running + m batch, the variance with the unbiased factor rows / (rows - 1), in the two
-// roundings of `running.mul_(1 - m).add_(batch, alpha = m)`; num_batches_tracked += 1.
+// module and step -- running <- (1 - m) running + m batch, the variance with the unbiased factor rows / (rows - 1);
+// num_batches_tracked += 1.  (Two roundings per buffer, as `running.mul_(1 - m).add_(batch, alpha = m)` has, but the factor is
+// folded as (m * unbias) * var where torch forms the unbiased variance first: the running variance can differ from torch's sequence
+// in the last bit -- tests hold the buffers to 1e-6.)
 __global__ __launch_bounds__(256) void bn_stats_finish_v4_kernel(const float *__restrict__ partial, int chunks, int C, int64_t rows,
                                                                  float *__restrict__ mean, float *__restrict__ var,
                                                                  float *__restrict__ run_mean, float *__restrict__ run_var, float momentum,
@@ -181,6 +183,7 @@ extern "C" int tgp_bn_stats_running(const float *x, int ld, int64_t rows, int C,
 {
     TGP_REQUIRE(x && mean && var && workspace && rows > 0 && C > 0 && ld >= C);
     TGP_REQUIRE((run_mean == nullptr) == (run_var == nullptr) && momentum >= 0.f && momentum <= 1.f);
+    TGP_REQUIRE(!(run_mean && rows < 2));      // nn.BatchNorm1d refuses one value per channel in training: no unbiased variance
     const float unbias = (float)((double)rows / (double)(rows > 1 ? rows - 1 : 1));
     if (bn_vec_ok(x, ld, C) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
         const int vchunks = tgp_cdiv(rows, BNV_CHUNK);

@@ -233,8 +233,6 @@ __global__ __launch_bounds__(1024) void gconv_lds_kernel(const float4 *__restric
     }
     const int q = tid % PC, pl = tid / PC, pstep = nthr / PC;
     const int cb = c0 + q * 2;
-    const int k4 = k >> 2;
-    const bool vec_idx = (k & 3) == 0 && k <= 32 && (reinterpret_cast<uintptr_t>(idx) & 15) == 0;
     float2 sd[GC_S][3];
 #pragma unroll
     for (int sidx = 0; sidx < GC_S; ++sidx)
@@ -248,9 +246,10 @@ __global__ __launch_bounds__(1024) void gconv_lds_kernel(const float4 *__restric
         for (int sidx = 0; sidx < GC_S; ++sidx) m[sidx] = make_float2(-INFINITY, -INFINITY);
         const int32_t *nbrs = idx + rowi * k;
         const float4 *udir = dirs + rowi * k;
-        // (round 4) the neighbour list in 16-byte pieces issued together ahead of the walk (k % 4 == 0, k <= 32): the table reads no
-        // longer wait for an index load each
-        auto visit = [&](const int nb, const float4 u) {
+#pragma unroll 4
+        for (int j = 0; j < k; ++j) {
+            const int nb = nbrs[j];
+            const float4 u = udir[j];
             const float ux = u.x, uy = u.y, uz = u.z;
             const float *trow = s_tab + nb * ROW + q * 2;
 #pragma unroll
@@ -261,22 +260,6 @@ __global__ __launch_bounds__(1024) void gconv_lds_kernel(const float4 *__restric
                 t = pk_max(t, f32x2{0.f, 0.f}) * f32x2{sup.x, sup.y};
                 m[sidx].x = fmaxf(m[sidx].x, t.x), m[sidx].y = fmaxf(m[sidx].y, t.y);
             }
-        };
-        if (vec_idx) {
-            int4 nq[8];
-#pragma unroll
-            for (int qq = 0; qq < 8; ++qq) nq[qq] = qq < k4 ? reinterpret_cast<const int4 *>(nbrs)[qq] : make_int4(0, 0, 0, 0);
-#pragma unroll
-            for (int qq = 0; qq < 8; ++qq) {
-                if (qq >= k4) break;                                  // workgroup-uniform
-                visit(nq[qq].x, udir[4 * qq]);
-                visit(nq[qq].y, udir[4 * qq + 1]);
-                visit(nq[qq].z, udir[4 * qq + 2]);
-                visit(nq[qq].w, udir[4 * qq + 3]);
-            }
-        } else {
-#pragma unroll 4
-            for (int j = 0; j < k; ++j) visit(nbrs[j], udir[j]);
         }
         float2 acc = m[0];   // torch.mean over the 7 supports: sequential sum, then / 7
 #pragma unroll
@@ -442,6 +425,10 @@ __global__ __launch_bounds__(256) void orl_partial_kernel(const float *__restric
 // (n = 1028: 66 KB), every row read from global memory once instead of ~k times.  A thread owns (point tile, wave slot,
 // channel pair) and reproduces the summation order of orl_partial_kernel exactly (slot w sums points w, w+4, ... of the
 // tile, then ((s0 + s1) + s2) + s3), so `partial` is bit-identical.
+// (Round 4, measured and dropped: the point's neighbour list as 16-byte loads issued together ahead of the walk, here and in
+// gconv_lds_kernel, instead of one index load per neighbour inside the 4-times unrolled loop: 25.6 -> 30.7 us (n = 1028), 56 -> 67 us for
+// the LDS graph convolution at n = 257 -- the unrolled loop already keeps four index loads in flight, and the eight predicated
+// 16-byte loads per point serialise ahead of the first table read.)
 #define ORL_CH 16
 // (round 4) A 16-channel slice of the table is one K-tile of the layer's last GEMM, whose A operand the table is: while the slice sits
 // in LDS the workgroup also writes it as fp16 hi / lo planes in the blocked layout of the pre-split GEMM (include/tgpose.h,
@@ -519,8 +506,6 @@ __global__ __launch_bounds__(1024) void orl_lds_kernel(const float *__restrict__
                 if (s_amax[e]) atomicMax(amax + rb0 + e, s_amax[e]);
     }
     constexpr int PC = ORL_CH / 2;
-    const int k4 = k >> 2;
-    const bool vec_idx = (k & 3) == 0 && k <= 32 && (reinterpret_cast<uintptr_t>(idx) & 15) == 0;
     for (int t = tid; t < ptiles * 4 * PC; t += nthr) {
         const int pair = t % PC, w = (t / PC) & 3, pt = t / (4 * PC);
         float2 sum = make_float2(0.f, 0.f);
@@ -529,28 +514,10 @@ __global__ __launch_bounds__(1024) void orl_lds_kernel(const float *__restrict__
             if (i >= n) break;
             const int32_t *nb = idx + ((int64_t)b * n + i) * k;
             float2 m = make_float2(-INFINITY, -INFINITY);
-            if (vec_idx) {
-                // (round 4) the point's neighbour list as up to eight 16-byte loads issued together, before the walk: with the indices
-                // loaded one by one inside the loop every LDS read waited for its own global load (SQ: 83 % of the waves' cycles parked)
-                int4 nq[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) nq[q] = q < k4 ? reinterpret_cast<const int4 *>(nb)[q] : make_int4(0, 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    if (q >= k4) break;                               // workgroup-uniform
-                    const float2 v0 = *reinterpret_cast<const float2 *>(s_tab + nq[q].x * ORL_CH + pair * 2);
-                    const float2 v1 = *reinterpret_cast<const float2 *>(s_tab + nq[q].y * ORL_CH + pair * 2);
-                    const float2 v2 = *reinterpret_cast<const float2 *>(s_tab + nq[q].z * ORL_CH + pair * 2);
-                    const float2 v3 = *reinterpret_cast<const float2 *>(s_tab + nq[q].w * ORL_CH + pair * 2);
-                    m.x = fmaxf(fmaxf(m.x, fmaxf(v0.x, v1.x)), fmaxf(v2.x, v3.x));
-                    m.y = fmaxf(fmaxf(m.y, fmaxf(v0.y, v1.y)), fmaxf(v2.y, v3.y));
-                }
-            } else {
 #pragma unroll 4
-                for (int j = 0; j < k; ++j) {
-                    const float2 v = *reinterpret_cast<const float2 *>(s_tab + nb[j] * ORL_CH + pair * 2);
-                    m.x = fmaxf(m.x, v.x), m.y = fmaxf(m.y, v.y);
-                }
+            for (int j = 0; j < k; ++j) {
+                const float2 v = *reinterpret_cast<const float2 *>(s_tab + nb[j] * ORL_CH + pair * 2);
+                m.x = fmaxf(m.x, v.x), m.y = fmaxf(m.y, v.y);
             }
             sum.x += m.x, sum.y += m.y;
         }
