@@ -6,6 +6,8 @@
 // rows (float4 per lane, whole 512 B..1 KiB row segments per wave-instruction) -- nothing of size
 // k*7*C ever exists.  All workgroups of one object are placed on one XCD (tgp_xcd_object_tile) so
 // the object's projection table (n x 8C floats, 3.7 MB at n=1028, C=128) is served from that L2.
+#include <stdlib.h>
+
 #include "tgp_common.h"
 
 #define GC_S 7          // support directions per kernel (config/config.py:44 gcn_sup_num)
@@ -337,6 +339,9 @@ static int gconv_launch(const float *xyz, const int32_t *idx, const float *proj,
                         int k, int C, float *out, int ldo, hipStream_t stream, int xyz_pad = 0)
 {
     const int ptiles = tgp_cdiv(n, GC_PTS);
+    // (round 4, measured: capping the workgroups per CU at 4 / 3 / 2 with unused dynamic LDS -- to keep one object's 3.7 MB table in
+    // the XCD's L2 instead of two -- leaves conv_1's launch at 138 us in every case: the kernel is bound by vector-instruction issue,
+    // 4.6e7 wave instructions of which three quarters are theta, not by its L2 misses)
 #define GC_GO(CC)                                                                                                     \
     {                                                                                                                 \
         const int tiles = ptiles * RowLanes<CC>::CHUNKS;                                                              \
