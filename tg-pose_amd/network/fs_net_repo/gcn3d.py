@@ -21,14 +21,6 @@ import torch.nn as nn
 from ... import engine, ops
 
 
-def _need_eval(module):
-    """modules with BatchNorm whose fused forward exists for eval mode only (FaceRecon.py's stand-alone forwards)"""
-    if module.training:
-        raise NotImplementedError(
-            "%s.forward stand-alone runs the fused eval-mode pipeline; in training mode call it through "
-            "PoseNet9D.forward (batch-statistics BatchNorm, dropout and autograd live there)" % type(module).__name__)
-
-
 def _tracked(*tensors):
     """does this call have to be recorded by autograd?"""
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
