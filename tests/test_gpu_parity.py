@@ -3765,8 +3765,8 @@ def test_submodules_stand_alone_in_eval_and_training_mode(ops):
         green = net.rot_green(feat_g)
         pg = green[:, 1:] / (torch.norm(green[:, 1:], dim=1, keepdim=True) + 1e-6)
         assert (pg - full["p_green_R"]).abs().max().item() <= 2e-5
-        ts = net.ts(torch.cat([feat, xyz], dim=2).permute(0, 2, 1))
-        assert (ts[:, 0:3] + mean[:, 0] - full["Pred_T"]).abs().max().item() <= 2e-5
+        xt, xs = net.ts(torch.cat([feat, xyz], dim=2).permute(0, 2, 1))          # (PoseTs.py:45 returns the two halves)
+        assert (xt + mean[:, 0] - full["Pred_T"]).abs().max().item() <= 2e-5 and (xs - full["Pred_s"]).abs().max().item() <= 2e-5
         enc_feat, _ = net.face_all.encoder(xyz, dobj)          # (its own subsample draws: shape only)
         assert enc_feat.shape == (B, N, 1286)
     # training mode

@@ -52,8 +52,8 @@ class Face_Enc(_WithBuffers):
         if self.training:
             from ... import autograd as tgp_autograd
             xyz = _xyz(vertices)
-            feat = tgp_autograd.encoder(self, xyz, cat_id.to(dev), engine.draw_sample_idx(xyz.shape[1]),
-                                        tgp_autograd._GraphSource(dev, None, None, ""), self.neighbor_num, FLAGS.obj_c)
+            feat, _parts = tgp_autograd.encoder(self, xyz, cat_id.to(dev), engine.draw_sample_idx(xyz.shape[1]),
+                                                tgp_autograd._GraphSource(dev, None, None, ""), self.neighbor_num, FLAGS.obj_c)
             feat = feat[:, :, : engine.FEAT_C]
             return feat, feat.permute(0, 2, 1)
         conv = self._packed(lambda: engine.pack_encoder(engine._dev_sd(self.state_dict(), dev), "", dev))
@@ -137,12 +137,20 @@ class FaceNet(_WithBuffers):
         if self.training:
             from ... import autograd as tgp_autograd
             xyz = _xyz(vertices)
-            featp = tgp_autograd.encoder(self.encoder, xyz, cat_id.to(dev), engine.draw_sample_idx(xyz.shape[1]),
-                                         tgp_autograd._GraphSource(dev, None, None, "encoder."), self.encoder.neighbor_num, FLAGS.obj_c)
+            featp, parts = tgp_autograd.encoder(self.encoder, xyz, cat_id.to(dev), engine.draw_sample_idx(xyz.shape[1]),
+                                                tgp_autograd._GraphSource(dev, None, None, "encoder."), self.encoder.neighbor_num,
+                                                FLAGS.obj_c)
+            # the layers over `feat` as PoseNet9D.forward runs them: factored over the up-sampling when the encoder hands out the
+            # operands (autograd.FACTORED), else over the padded concat buffer
+            x5 = xd = None
+            if parts is not None:
+                dec0 = self.decoder.conv1d_block[0]
+                x5, xd = tgp_autograd.feat_consumers_factored(parts, [(tgp_autograd._w2(self.ph_pred.conv_5[0]), None),
+                                                                      (tgp_autograd._w2(dec0), dec0.bias)])
             h1 = h2 = back = None
             if pred_PH:
-                back, h1, h2 = tgp_autograd.ph_predictor(self.ph_pred, featp)
-            recon = tgp_autograd.decoder(self.decoder, featp, back)
+                back, h1, h2 = tgp_autograd.ph_predictor(self.ph_pred, featp, x5)
+            recon = tgp_autograd.decoder(self.decoder, featp, back, xd)
             f = featp[:, :, : engine.FEAT_C]
             return recon, f, f.permute(0, 2, 1), h1, h2
         pk = self._packed(lambda: engine.Packed(self.state_dict(), dev, face="", with_heads=False))
