@@ -111,6 +111,14 @@ int tgp_orl_rowbias(const float *feat, int ldf, const int32_t *idx, int B, int n
 int tgp_orl_rowbias_planes(const float *feat, int ldf, const int32_t *idx, int B, int n, int k, int C, float *partial,
                            const float *w2t, float *g_out, float *rb, void *planes, int kts, uint32_t *amax, const float *xyz_tile,
                            tgp_stream_t stream);
+/* (ABI 6) tgp_orl_rowbias / tgp_orl_rowbias_planes (planes may be NULL) as ONE launch: the pooling kernel finishes the mean over
+ * points and the projection itself -- each of an object's C / 16 workgroups adds its 16-channel slice of g @ W2^T to `contrib`
+ * (B * (C / 16) * C floats of scratch) and the last one to arrive (tickets: B ints, zero on entry, zero again on return) sums the
+ * slices in chunk order, so rb does not depend on the arrival order.  rb agrees with tgp_orl_rowbias to rounding (another summation
+ * order), g_out bit for bit.  TGP_EUNSUPPORTED (nothing launched) where the LDS-staged form does not serve the shape. */
+int tgp_orl_rowbias_fused(const float *feat, int ldf, const int32_t *idx, int B, int n, int k, int C, const float *w2t,
+                          float *g_out, float *rb, void *planes, int kts, uint32_t *amax, const float *xyz_tile, float *contrib,
+                          int32_t *tickets, tgp_stream_t stream);
 
 /* gcn3d.py:219-245 Pool_layer.forward with the random subsample (randperm, :242) supplied by the
  * host: out_f[b,m,:] = max_{j<kpool} feat[b, idx[b, sample[m], j], :], out_xyz[b,m] = xyz[b, sample[m]].

@@ -3407,7 +3407,7 @@ def test_gemm_pp_bit_identical_to_split_kernel(ops, M, N, K, rpo):
     Ap, Wp = ops.planes_split(A, K=K), ops.planes_w(W[:, :K].contiguous())
     ref_pl, ref_amax = _ref_planes(C0)
     rows_ok = (torch.arange(ref_pl.shape[0] * 32, device=DEV) < M).view(-1, 1, 1, 1, 32, 1)
-    for cfg in (0, 1, 2, 3, 4, 5, 6, 7):
+    for cfg in (0, 1, 2, 3, 4, 5, 6, 7, 8):
         keys = torch.zeros_like(keys0)
         C = torch.full((M, N - c0), 7.0, device=DEV)
         Cp = ops.Planes(M, N - c0, DEV)
@@ -3439,7 +3439,7 @@ def test_gemm_pp_gathered_residuals_bit_identical(ops):
     keys0, C0 = torch.zeros(B, N, dtype=torch.int32, device=DEV), torch.empty(M, N, device=DEV)
     ops.gemm(A, W, C0, colmax_keys=keys0, **kw)
     Ap, Wp = ops.planes_split(A, K=K), ops.planes_w(W[:, :K].contiguous())
-    for cfg in (0, 1, 3, 4, 5):
+    for cfg in (0, 1, 3, 4, 5, 8):
         keys, C = torch.zeros_like(keys0), torch.empty_like(C0)
         ops.gemm(A, W, C, colmax_keys=keys, a_planes=Ap, w_planes=Wp, pp_config=cfg, **kw)
         assert torch.equal(C, C0) and torch.equal(keys, keys0), cfg
@@ -3459,7 +3459,7 @@ def test_gemm_pp_range_guard(ops):
     want = A.double() @ W.double().t()
     dA, dW = g(A), g(W)
     Ap, Wp = ops.planes_split(dA), ops.planes_w(dW)
-    for cfg in (1, 3, 4, 5):
+    for cfg in (1, 3, 4, 5, 8):
         C = torch.empty(M, N, device=DEV)
         ops.gemm(dA, dW, C, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, w_split=ops.split_w(dW), a_planes=Ap, w_planes=Wp, pp_config=cfg)
         err = (C.cpu().double() - want).abs().amax(dim=1) / want.abs().amax(dim=1)
@@ -3523,6 +3523,42 @@ def test_orl_rowbias_planes_equal_split_of_the_table(ops, B, n, C, k, with_xyz):
     rows_ok = (torch.arange(nblk * 32, device=DEV) < B * n).view(nblk, 1, 1, 1, 32, 1)
     assert bool(((P.buf.view(nblk, P.kt, 2, 2, 32, 16) == want.view(nblk, P.kt, 2, 2, 32, 16)) | ~rows_ok).all())
     assert torch.equal(P.amax, amax)
+
+
+@pytest.mark.parametrize("B,n,C,k,with_planes", [(32, 1028, 128, 20, True), (5, 257, 256, 20, True), (4, 64, 512, 8, True), (3, 100, 128, 12, False),
+                                                 (40, 64, 512, 8, False)])
+def test_orl_rowbias_one_launch_form(ops, B, n, C, k, with_planes):
+    """tgp_orl_rowbias_fused: the pooling kernel finishes the mean over points and the projection itself (a ticket per object; the
+    last of its C / 16 workgroups sums the 16-channel slices in chunk order).  Against the two-launch form: the same planes and
+    magnitudes bit for bit, the row bias to rounding (another summation order, fp64 restatement as the judge), the tickets handed
+    back as zero, and the same bits on every repetition -- whichever workgroup arrives last."""
+    gen = torch.Generator().manual_seed(B * n + C + 1)
+    feat = g(torch.randn(B, n, C, generator=gen))
+    idx = g(torch.randint(0, n, (B, n, k), generator=gen).int())
+    w2t = g(torch.randn(C, C, generator=gen) / C ** 0.5)
+    rb0 = ops.orl_rowbias(feat, idx, w2t)
+    tickets = torch.zeros(B, device=DEV, dtype=torch.int32)
+    runs = []
+    for _ in range(4):
+        if with_planes:
+            P = ops.Planes(B * n, C, DEV)
+            P.buf.fill_(0xAB)
+            rb, got = ops.orl_rowbias(feat, idx, w2t, planes=P, tickets=tickets)
+            assert got is P
+            P0 = ops.Planes(B * n, C, DEV)
+            P0.buf.fill_(0xAB)
+            ops.orl_rowbias(feat, idx, w2t, planes=P0)
+            assert torch.equal(P.buf, P0.buf) and torch.equal(P.amax, P0.amax)
+        else:
+            rb = ops.orl_rowbias(feat, idx, w2t, tickets=tickets)
+        assert int(tickets.abs().sum()) == 0
+        runs.append(rb)
+    assert all(torch.equal(runs[0], r) for r in runs[1:])
+    gmax = feat.double().view(B, n, C)[torch.arange(B, device=DEV).view(B, 1, 1), idx.long()].max(2)[0].mean(1)      # (B, C)
+    want = gmax @ w2t.double()
+    scale = float(want.abs().max())
+    assert float((runs[0].double() - want).abs().max()) <= 2e-6 * scale
+    assert float((rb0.double() - want).abs().max()) <= 2e-6 * scale
 
 
 @pytest.mark.parametrize("B,N", [(9, 1028), (3, 300)])

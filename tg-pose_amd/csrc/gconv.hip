@@ -455,7 +455,9 @@ __device__ __forceinline__ void ol_split(const float4 v, uint2 &hi, uint2 &lo)
 __global__ __launch_bounds__(1024) void orl_lds_kernel(const float *__restrict__ feat, int ldf, const int32_t *__restrict__ idx, int B,
                                                        int n, int k, int C, float *__restrict__ partial, int ptiles,
                                                        char *__restrict__ planes, int kts, uint32_t *__restrict__ amax,
-                                                       const float *__restrict__ xyz_tile)
+                                                       const float *__restrict__ xyz_tile, const float *__restrict__ w2t,
+                                                       float *__restrict__ g_out, float *__restrict__ rb, float *contrib,
+                                                       int *tickets)
 {
     extern __shared__ __attribute__((aligned(16))) float ol_smem[];
     float *s_tab = ol_smem;                          // [n][ORL_CH]
@@ -529,11 +531,53 @@ __global__ __launch_bounds__(1024) void orl_lds_kernel(const float *__restrict__
         *reinterpret_cast<float2 *>(s_red + (pt * 4 + w) * ORL_CH + pair * 2) = sum;
     }
     __syncthreads();
-    for (int t = tid; t < ptiles * ORL_CH; t += nthr) {
-        const int pt = t / ORL_CH, c = t % ORL_CH;
-        const float *r = s_red + pt * 4 * ORL_CH + c;
-        partial[((int64_t)b * ptiles + pt) * C + c0 + c] = ((r[0] + r[ORL_CH]) + r[2 * ORL_CH]) + r[3 * ORL_CH];
+    if (!tickets) {
+        for (int t = tid; t < ptiles * ORL_CH; t += nthr) {
+            const int pt = t / ORL_CH, c = t % ORL_CH;
+            const float *r = s_red + pt * 4 * ORL_CH + c;
+            partial[((int64_t)b * ptiles + pt) * C + c0 + c] = ((r[0] + r[ORL_CH]) + r[2 * ORL_CH]) + r[3 * ORL_CH];
+        }
+        return;
     }
+    // ---- fused finish (round 4; tgp_orl_rowbias_fused): this workgroup holds every point tile of its 16 channels, so their mean
+    // over points g (orl_finish_kernel's sum, term by term) needs no other workgroup; its share of the projection
+    // rb[b, :] = g[b, :] @ W2^T is the 16-row slice  contrib[b, chunk, o] = sum_c g[c0 + c] w2t[c0 + c, o]  (one fmaf chain), and
+    // the LAST of the object's C / 16 workgroups to arrive (a ticket per object; release / acquire fences around it) adds the
+    // slices in chunk order -- a fixed order whichever workgroup that is -- and hands the ticket back as 0.
+    float *s_g = s_tab;                              // the table is no longer read
+    int *s_last = reinterpret_cast<int *>(s_tab + ORL_CH);
+    if (tid < ORL_CH) {
+        float sum = 0.f;
+        for (int pt = 0; pt < ptiles; ++pt) {
+            const float *r = s_red + pt * 4 * ORL_CH + tid;
+            sum += ((r[0] + r[ORL_CH]) + r[2 * ORL_CH]) + r[3 * ORL_CH];
+        }
+        sum = sum / (float)n;
+        s_g[tid] = sum;
+        if (g_out) g_out[(int64_t)b * C + c0 + tid] = sum;
+    }
+    __syncthreads();
+    const int nch = C / ORL_CH;
+    for (int o = tid; o < C; o += nthr) {
+        float acc = 0.f;
+        const float *w = w2t + (int64_t)c0 * C + o;
+#pragma unroll
+        for (int c = 0; c < ORL_CH; ++c) acc = fmaf(s_g[c], w[(int64_t)c * C], acc);
+        contrib[((int64_t)b * nch + chunk) * C + o] = acc;
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) *s_last = atomicAdd(tickets + b, 1) == nch - 1;
+    __syncthreads();
+    if (!*s_last) return;
+    __threadfence();
+    for (int o = tid; o < C; o += nthr) {
+        float sum = 0.f;
+        for (int ch = 0; ch < nch; ++ch)
+            sum += __hip_atomic_load(contrib + ((int64_t)b * nch + ch) * C + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rb[(int64_t)b * C + o] = sum;
+    }
+    if (tid == 0) tickets[b] = 0;
 }
 
 #ifdef TGP_DEV   // development builds only: 0 = always the gather-from-L2 kernel
@@ -546,7 +590,8 @@ static constexpr int tgp_orl_lds_mode = 1;
 // returns true when the LDS form was launched
 static bool orl_lds_launch(const float *feat, int ldf, const int32_t *idx, int B, int n, int k, int C, float *partial, int ptiles,
                            hipStream_t stream, int &rc, char *planes = nullptr, int kts = 0, uint32_t *amax = nullptr,
-                           const float *xyz_tile = nullptr)
+                           const float *xyz_tile = nullptr, const float *w2t = nullptr, float *g_out = nullptr, float *rb = nullptr,
+                           float *contrib = nullptr, int *tickets = nullptr)
 {
     rc = 0;
     const size_t lds = ((size_t)n * ORL_CH + (size_t)ptiles * 4 * ORL_CH + (planes ? n / 32 + 4 : 0)) * sizeof(float);
@@ -563,7 +608,7 @@ static bool orl_lds_launch(const float *feat, int ldf, const int32_t *idx, int B
     const int slots = ptiles * 4 * (ORL_CH / 2);
     const int threads = slots >= 768 ? 1024 : (slots >= 384 ? 512 : 256);
     hipLaunchKernelGGL(orl_lds_kernel, dim3(tgp_xcd_grid(B, C / ORL_CH)), dim3(threads), lds, stream, feat, ldf, idx, B, n, k, C, partial,
-                       ptiles, planes, kts, amax, xyz_tile);
+                       ptiles, planes, kts, amax, xyz_tile, w2t, g_out, rb, contrib, tickets);
     rc = TGP_LAUNCH_RESULT();
     return true;
 }
@@ -685,6 +730,30 @@ extern "C" int tgp_orl_rowbias_planes(const float *feat, int ldf, const int32_t 
     hipLaunchKernelGGL(orl_finish_project_kernel, dim3(B, C / 64), dim3(256), 0, tgp_hs(stream), partial, n, C, ptiles, w2t, g_out,
                        rb);
     return TGP_LAUNCH_RESULT();
+}
+
+// tgp_orl_rowbias[_planes] as ONE launch: the mean over points and the projection are finished inside the pooling kernel (see
+// orl_lds_kernel).  contrib: B * (C / 16) * C floats of scratch; tickets: B ints, zero on entry and zero again on return (one
+// buffer serves every call that is ordered after the previous one).  planes may be NULL.  rb sums its C / 16 slices in another
+// order than orl_finish_project_kernel: the two forms agree to rounding, not bit for bit.  TGP_EUNSUPPORTED where the LDS form
+// does not serve the shape (nothing launched).
+extern "C" int tgp_orl_rowbias_fused(const float *feat, int ldf, const int32_t *idx, int B, int n, int k, int C, const float *w2t,
+                                     float *g_out, float *rb, void *planes, int kts, uint32_t *amax, const float *xyz_tile,
+                                     float *contrib, int32_t *tickets, tgp_stream_t stream)
+{
+    TGP_REQUIRE(feat && idx && w2t && rb && contrib && tickets && B > 0 && n > 0 && k > 0);
+    if (k > GC_MAXK || !(C == 128 || C == 256 || C == 512)) return TGP_EUNSUPPORTED;
+    TGP_REQUIRE(ldf >= C && (ldf & 3) == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(planes) & 15) == 0);
+    TGP_REQUIRE(!planes || kts >= C / 16 + (xyz_tile ? 1 : 0));
+    const int ptiles = tgp_cdiv(n, ORL_PTS);
+    const size_t lds = ((size_t)n * ORL_CH + (size_t)ptiles * 4 * ORL_CH + n / 32 + 4) * sizeof(float);
+    if (!tgp_orl_lds_mode || lds > 72 * 1024 || n < 2) return TGP_EUNSUPPORTED;
+    int lrc = 0;
+    if (!orl_lds_launch(feat, ldf, idx, B, n, k, C, nullptr, ptiles, tgp_hs(stream), lrc, reinterpret_cast<char *>(planes), kts, amax,
+                        xyz_tile, w2t, g_out, rb, contrib, tickets))
+        return TGP_EUNSUPPORTED;
+    return lrc;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -20,6 +20,19 @@
 
 #define PP_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(0x0f70 | ((N) & 15) | (((N) >> 4) << 14))
 
+#ifdef TGP_DEV   // development build: wall-clock stamps (100 MHz) per workgroup -- entry, first stage landed, K loop done, epilogue done
+__device__ unsigned long long *tgp_pp_stamps = nullptr;
+extern "C" int tgp_debug_set_pp_stamps(void *buf)
+{
+    unsigned long long *b = reinterpret_cast<unsigned long long *>(buf);
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(tgp_pp_stamps), &b, sizeof(b));
+}
+#define PP_STAMP(I)                                                                                   \
+    if (tgp_pp_stamps && threadIdx.x == 0) tgp_pp_stamps[(size_t)blockIdx.x * 4 + (I)] = wall_clock64();
+#else
+#define PP_STAMP(I)
+#endif
+
 template <int BM, int BN, int NWM, int NWN, int KTS, int STAGES>
 __device__ __forceinline__ void gemm_pp_tile(const GemmParams &p, const int m0, const int n0, char *smem)
 {
@@ -30,7 +43,7 @@ __device__ __forceinline__ void gemm_pp_tile(const GemmParams &p, const int m0, 
     constexpr int NI = NCH / NW;                           // LDS-DMA instructions per wave and step
     constexpr int STAGE_BYTES = NCH * 1024;
     constexpr int D = STAGES - 1;                          // steps of prefetch
-    static_assert(NCH % NW == 0 && STAGES >= 2 && STAGES <= 3, "piece / wave mapping");
+    static_assert(NCH % NW == 0 && STAGES >= 2 && STAGES <= 5 && (STAGES - 2) * NI <= 63, "piece / wave mapping");
     static_assert(STAGES * STAGE_BYTES >= NW * 4096, "the epilogue turns blocks through 4 KB per wave");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -106,9 +119,14 @@ __device__ __forceinline__ void gemm_pp_tile(const GemmParams &p, const int m0, 
         for (int s = 0; s < numS; ++s) {
             // step s's pieces have landed (this wave's; after the barrier everybody's), and everybody has finished reading the
             // stage that step s + D is about to overwrite (it held step s - 1)
-            if (D == 1 || s + 1 >= numS) PP_WAIT_VM(0);
-            else PP_WAIT_VM(NI);
+            // (still in flight behind step s's pieces: the steps issued after it, min(D - 1, numS - 1 - s) of them)
+            const int ahead = min(D - 1, numS - 1 - s);
+            if (ahead <= 0) PP_WAIT_VM(0);
+            else if (ahead == 1) PP_WAIT_VM(NI);
+            else if (ahead == 2) PP_WAIT_VM(2 * NI);
+            else PP_WAIT_VM(3 * NI);
             __builtin_amdgcn_s_barrier();
+            if (s == 0) { PP_STAMP(1) }
             if (s + D < numS) dma(s + D, (s + D) % STAGES);
             const char *st = smem + (s % STAGES) * STAGE_BYTES + lane * 16;
 #pragma unroll
@@ -138,6 +156,7 @@ __device__ __forceinline__ void gemm_pp_tile(const GemmParams &p, const int m0, 
             }
         }
         __builtin_amdgcn_s_barrier();                                      // every fragment read is done: the stages become epilogue scratch
+        PP_STAMP(2)
     } else {
         // exact fp32 recomputation straight from global memory (v_mfma_f32_32x32x2_f32; lane (r, h) supplies k = 8 t + 4 h + s to
         // sub-step s of the 8-wide group t), same accumulator layout: gemm_split_tile's fallback
@@ -182,6 +201,7 @@ __device__ __forceinline__ void gemm_pp_tile(const GemmParams &p, const int m0, 
     }
     // (one instance whose planes output is a run-time branch: two inlined instances spilled 73 registers at the 128-register shapes)
     gemm_epilogue_lds<TM, TN, WTM, WTN, true>(p, acc, m0, n0, 0, wm, wn, r, h, reinterpret_cast<float *>(smem) + wave * 1024);
+    PP_STAMP(3)
 }
 
 // Workgroups are dealt round-robin to the 8 XCDs; the remap gives each XCD a contiguous range of tiles (N fastest), so the tiles
@@ -197,6 +217,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPE) void gemm_pp_kernel(GemmParams
 {
     extern __shared__ __attribute__((aligned(1024))) char pp_smem[];
     if (p.pred && *p.pred == 0) return;
+    PP_STAMP(0)
     const int L = pp_xcd_remap((int)blockIdx.x, p.pp_tiles_m * p.pp_tiles_n);
     gemm_pp_tile<BM, BN, NWM, NWN, KTS, STAGES>(p, (L / p.pp_tiles_n) * BM, (L % p.pp_tiles_n) * BN, pp_smem);
 }
@@ -408,7 +429,9 @@ static int pp_launch(GemmParams &p, hipStream_t stream)
 // outputs) is better on 256 x 128 with three stages.
 static int pp_auto_config(const GemmParams &p)
 {
-    if (p.N <= 512) return 5;
+    // N <= 512: the 64 x 128 tile; with more tiles than four per CU hold, its 96-register build (five per CU: decoder's first
+    // layer 65.7 -> 59.1 us, its 512-wide layers 2-4 %; the single-round launches of the encoder are 1-6 % slower on it)
+    if (p.N <= 512) return (int64_t)((p.M + 63) / 64) * ((p.N + 127) / 128) > 1024 ? 8 : 5;
     if (p.K >= 512 && (int64_t)p.M * p.N >= (1ll << 25)) return 3;
     return 4;
 }
@@ -422,7 +445,7 @@ int tgp_launch_gemm_pp(GemmParams &p, int config, hipStream_t stream)
     // the epilogue keeps two objects per wave tile: its per-object bias / max over points need rows_per_obj >= the wave tile's rows
     if (p.rowbias || p.cm) {
         TGP_REQUIRE(p.rows_per_obj >= 32);
-        if (p.rows_per_obj < 64) config = 5;
+        if (p.rows_per_obj < 64 && config != 8) config = 5;
         else if (p.rows_per_obj < 128 && config == 1) config = 4;
     }
     switch (config) {
@@ -433,6 +456,7 @@ int tgp_launch_gemm_pp(GemmParams &p, int config, hipStream_t stream)
     case 5: return pp_launch<64, 128, 2, 2, 1, 2, 4>(p, stream);
     case 6: return pp_launch<128, 128, 2, 2, 2, 2, 2>(p, stream);
     case 7: return pp_launch<128, 256, 2, 4, 1, 3, 4>(p, stream);
+    case 8: return pp_launch<64, 128, 2, 2, 1, 2, 5>(p, stream);     // config 5 held to 96 registers: five workgroups per CU
     default: return TGP_EINVAL;
     }
 }

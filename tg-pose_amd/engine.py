@@ -306,7 +306,7 @@ class Graphs(object):
         return idx
 
 
-def surface_layer(c, xyz, idx_rf, idx_orl, out, scale=None, shift=None, act=None, out_p=None, amax_ws=None):
+def surface_layer(c, xyz, idx_rf, idx_orl, out, scale=None, shift=None, act=None, out_p=None, amax_ws=None, tickets=None):
     """HSlayer_surface.forward (gcn3d.py:78-89) + the caller's activation, written to `out` (B,n,C) view (and, out_p, as the fp16
     planes the next layer's projection GEMM stages by LDS-DMA)."""
     B, n, _ = xyz.shape
@@ -316,7 +316,8 @@ def surface_layer(c, xyz, idx_rf, idx_orl, out, scale=None, shift=None, act=None
     gp = None
     if out_p is not None and "w1x_p" in c and "w2t" in c:
         # the ORL pooling stages g in LDS anyway: it leaves [g | x y z 0] as fp16 planes, the last GEMM's operand (csrc/gconv.hip)
-        rb, gp = ops.orl_rowbias(g, idx_orl, c["w2t"], planes=ops.Planes(B * n, C + 4, xyz.device, amax_buf=amax_ws), xyz_tile=xyz)
+        rb, gp = ops.orl_rowbias(g, idx_orl, c["w2t"], planes=ops.Planes(B * n, C + 4, xyz.device, amax_buf=amax_ws), xyz_tile=xyz,
+                                 tickets=tickets)
     else:
         rb = ops.orl_rowbias(g, idx_orl, c["w2t"]) if "w2t" in c else ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
     # conv2(cat[g, global]) + g + STE(xyz) (gcn3d.py:87-89,108-112): W1 g + STE xyz is one product over the padded row
@@ -345,7 +346,8 @@ def _beside(device, fn, tag="knn"):
     return res, join
 
 
-def hs_layer(c, xyz, fmap, idx_rf, idx_orl, out, scale=None, shift=None, act=None, fmap_p=None, out_p=None, out_col0=0, amax_ws=None):
+def hs_layer(c, xyz, fmap, idx_rf, idx_orl, out, scale=None, shift=None, act=None, fmap_p=None, out_p=None, out_col0=0, amax_ws=None,
+             tickets=None):
     """HS_layer.forward (gcn3d.py:142-155) + the caller's BatchNorm(eval)/ReLU, written to `out`.
     idx_rf / idx_orl may be callables: they are then evaluated on a side stream (the feature-space kNN -- distance GEMM +
     selection -- and the level's xyz kNN depend only on the layer's inputs) while this stream runs the projection GEMM."""
@@ -367,7 +369,7 @@ def hs_layer(c, xyz, fmap, idx_rf, idx_orl, out, scale=None, shift=None, act=Non
     g = ops.gconv_hs(xyz, idx_rf, proj9, c["sdn"], 7, C)
     gp = None
     if amax_ws is not None and "w1_p" in c and "w2t" in c:
-        rb, gp = ops.orl_rowbias(g, idx_orl, c["w2t"], planes=ops.Planes(B * n, C, xyz.device, amax_buf=amax_ws))
+        rb, gp = ops.orl_rowbias(g, idx_orl, c["w2t"], planes=ops.Planes(B * n, C, xyz.device, amax_buf=amax_ws), tickets=tickets)
     else:
         rb = ops.orl_rowbias(g, idx_orl, c["w2t"]) if "w2t" in c else ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
     ops.linear_rows(g, c["w1"], out=out, rowbias=rb, rows_per_obj=n, res1=g, res2=proj9[:, :, 8 * C:], scale=scale,
@@ -402,11 +404,11 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, 
     pl = arena.planes(B, N, N1, N2) if (arena is not None and factored and ops.planes_on()) else {}
     fm0 = feat[:, :, 0:128]
     surface_layer(cv[0], xyz, graphs.get("conv_0.rf", lambda: xyz_graph(0, xyz, kmax)),
-                  graphs.get("conv_0.orl_xyz", lambda: xyz_graph(0, xyz, kmax)), fm0, act="relu", out_p=pl.get("fm0"), amax_ws=pl.get("amax_g0"))
+                  graphs.get("conv_0.orl_xyz", lambda: xyz_graph(0, xyz, kmax)), fm0, act="relu", out_p=pl.get("fm0"), amax_ws=pl.get("amax_g0"), tickets=pl.get("tick0"))
     fm1 = feat[:, :, 128:256]
     hs_layer(cv[1], xyz, fm0, lambda: graphs.get("conv_1.rf", lambda: ops.knn_feat(fm0, kmax)),
              graphs.get("conv_1.orl_xyz", lambda: xyz_graph(0, xyz, kmax)), fm1, cv[1]["scale"], cv[1]["shift"], "relu",
-             fmap_p=pl.get("fm0"), amax_ws=pl.get("amax_g1"))
+             fmap_p=pl.get("fm0"), amax_ws=pl.get("amax_g1"), tickets=pl.get("tick1"))
     v1, fp1 = ops.pool(xyz, fm1, graphs.get("pool_1.xyz", lambda: xyz_graph(0, xyz, kmax)), s1, kpool=4, planes=pl.get("fp1"))
 
     k1 = min(kmax, N1 // 8)
@@ -414,11 +416,11 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, 
     fm2, fm3 = fm23[:, :, :256], fm23[:, :, 256:]
     hs_layer(cv[2], v1, fp1, lambda: graphs.get("conv_2.rf", lambda: ops.knn_feat(fp1, k1)),
              lambda: graphs.get("conv_2.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm2, cv[2]["scale"], cv[2]["shift"], "relu",
-             fmap_p=pl.get("fp1"), out_p=pl.get("fm23"), out_col0=0, amax_ws=pl.get("amax_g2"))
+             fmap_p=pl.get("fp1"), out_p=pl.get("fm23"), out_col0=0, amax_ws=pl.get("amax_g2"), tickets=pl.get("tick2"))
     # (conv_3 reads the first 256 columns of the fm_2 | fm_3 planes, whose per-block magnitudes cover fm_2 alone at this point)
     hs_layer(cv[3], v1, fm2, lambda: graphs.get("conv_3.rf", lambda: ops.knn_feat(fm2, k1)),
              graphs.get("conv_3.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm3, cv[3]["scale"], cv[3]["shift"], "relu",
-             fmap_p=pl.get("fm23"), out_p=pl.get("fm23"), out_col0=256, amax_ws=pl.get("amax_g3"))
+             fmap_p=pl.get("fm23"), out_p=pl.get("fm23"), out_col0=256, amax_ws=pl.get("amax_g3"), tickets=pl.get("tick3"))
     v2, fp2 = ops.pool(v1, fm3, graphs.get("pool_2.xyz", lambda: xyz_graph(1, v1, k1)), s2, kpool=4, planes=pl.get("fp2"))
 
     P1 = P1_join = None
@@ -441,7 +443,7 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, 
     k2 = min(kmax, N2 // 8)
     fm4 = torch.empty(B, N2, 512, device=dev, dtype=torch.float32)
     hs_layer(cv[4], v2, fp2, lambda: graphs.get("conv_4.rf", lambda: ops.knn_feat(fp2, k2)),
-             lambda: graphs.get("conv_4.orl_xyz", lambda: xyz_graph(2, v2, k2)), fm4, fmap_p=pl.get("fp2"), out_p=pl.get("fm4"), amax_ws=pl.get("amax_g4"))
+             lambda: graphs.get("conv_4.orl_xyz", lambda: xyz_graph(2, v2, k2)), fm4, fmap_p=pl.get("fp2"), out_p=pl.get("fm4"), amax_ws=pl.get("amax_g4"), tickets=pl.get("tick4"))
 
     near1 = graphs.get("up_1", lambda: ops.nn1(xyz, v1)).view(B, N)
     near2 = graphs.get("up_2", lambda: ops.nn1(xyz, v2)).view(B, N)
@@ -480,6 +482,7 @@ class Arena(object):
         N1 = int(N / 4)
         blk = lambda rows: (rows + 31) // 32
         na = 7 * blk(B * N) + 4 * blk(B * N1) + 3 * blk(B * int(N1 / 4)) if N else 0
+        na += 5 * B if N else 0                  # + the five graph-convolution layers' tickets (ops.orl_rowbias, one-launch form)
         buf = torch.zeros(n5 + n2 + 8 + nb + na, device=dev, dtype=torch.int32)
         self.keys5 = buf[:n5].view(B, 1024)
         self.keys2 = buf[n5:n5 + n2].view(3, B, 256)
@@ -498,6 +501,7 @@ class Arena(object):
             spec = (("fm0", B * N, 128), ("fine", B * N, FINE_K), ("d1", B * N, 512), ("d2", B * N, 512), ("d3", B * N, 256),
                     ("fp1", B * N1, 128), ("fm23", B * N1, 512), ("fp2", B * N2, 256), ("fm4", B * N2, 512))
             need = sum((rows + 31) // 32 for _, rows, _ in spec) + 2 * ((B * N + 31) // 32) + 2 * ((B * N1 + 31) // 32) + (B * N2 + 31) // 32
+            need += 5 * B
             if self.amax.numel() < need:
                 raise RuntimeError("Arena built without room for the planes' magnitudes")
             o, self._pl = 0, {}
@@ -510,6 +514,9 @@ class Arena(object):
                 nb = (rows + 31) // 32
                 self._pl[name] = self.amax[o:o + nb]
                 o += nb
+            for i in range(5):                     # per layer and object: zero here, handed back as zero by the kernel
+                self._pl["tick%d" % i] = self.amax[o:o + B]
+                o += B
         return self._pl
 
 

@@ -194,17 +194,28 @@ def orl_global(feat, idx):
 
 
 @_timed("graph")
-def orl_rowbias(feat, idx, w2t, planes=None, xyz_tile=None):
+def orl_rowbias(feat, idx, w2t, planes=None, xyz_tile=None, tickets=None):
     """feat (B,n,C), idx (B,n,k), w2t (C,C) = W2^T -> rb (B,C) = mean_i max_j feat[idx] @ W2^T.
     planes (a Planes of B*n rows): feat is also written as fp16 planes -- it is the A operand of the layer's last GEMM -- by the
     kernel that stages it in LDS anyway (tgp_orl_rowbias_planes; xyz_tile (B,n,3): one more K-tile (x, y, z, 0 ...) behind the C
-    channels).  Returns (rb, planes or None): None where that form does not serve the shape and nothing was written."""
+    channels).  Returns (rb, planes or None): None where that form does not serve the shape and nothing was written.
+    tickets (B int32 zeros, handed back as zeros): the one-launch form (tgp_orl_rowbias_fused) where the shape allows."""
     feat, ldf = _rows(feat, "feat")
     _i32(idx, "idx")
     B, n, C = feat.shape
     k = idx.shape[2]
-    partial = torch.empty(_lib.lib().tgp_orl_partial_floats(B, n, C), device=feat.device, dtype=torch.float32)
     rb = torch.empty(B, C, device=feat.device, dtype=torch.float32)
+    if tickets is not None and ORL_FUSED:
+        contrib = torch.empty(B * (C // 16) * C, device=feat.device, dtype=torch.float32)
+        rc = _lib.lib().tgp_orl_rowbias_fused(_p(feat), ldf, _p(idx), B, n, k, C, _p(w2t), None, _p(rb),
+                                              _p(planes.buf) if planes is not None else None, planes.kt if planes is not None else 0,
+                                              _p(planes.amax) if planes is not None else None, _p(xyz_tile), _p(contrib), _p(tickets),
+                                              _stream(feat))
+        if rc == 0:
+            return (rb, planes) if planes is not None else rb
+        if rc != -2:
+            check(rc, "tgp_orl_rowbias_fused")
+    partial = torch.empty(_lib.lib().tgp_orl_partial_floats(B, n, C), device=feat.device, dtype=torch.float32)
     if planes is not None:
         rc = _lib.lib().tgp_orl_rowbias_planes(_p(feat), ldf, _p(idx), B, n, k, C, _p(partial), _p(w2t), None, _p(rb), _p(planes.buf),
                                                planes.kt, _p(planes.amax), _p(xyz_tile), _stream(feat))
@@ -288,6 +299,7 @@ def fill_tail(obj_id, xyz_c, feat, col0, n_cls):
 # split_w() packs weights for the mode current at pack time; gemm() reads the kind off the packed tensor's shape.
 GEMM_MODE = "split16"
 PLANES = os.environ.get("TGP_PLANES", "1") != "0"     # activations also as fp16 planes, consumers on the pre-split kernel (split16 mode)
+ORL_FUSED = os.environ.get("TGP_ORL_FUSED", "1") != "0"      # the ORL pooling, its mean and its projection as one launch
 HEADS_PERSISTENT = os.environ.get("TGP_HEADS_PERSISTENT", "0") != "0"   # measurement switches of the fused heads kernel (ABI 5)
 HEADS_PLANES = os.environ.get("TGP_HEADS_PLANES", "1") != "0"
 
