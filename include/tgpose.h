@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 5
+#define TGP_ABI_VERSION 6
 #define TGP_EINVAL (-1)       /* null pointer / non-positive size / misaligned stride */
 #define TGP_EUNSUPPORTED (-2) /* shape outside what the kernels are built for */
 
@@ -240,6 +240,14 @@ typedef struct tgp_gemm_args {
      * callers do.  A chain of layers whose activations feed only the next GEMM (the decoder, FaceRecon.py:112-117) then writes and
      * reads 4 bytes per element instead of 8 + 4. */
     int *range_flag;
+    /* (ABI 6) The per-object vector layers (M <= 32, the weight-streaming kernel; refused elsewhere), FaceRecon.py:145-165:
+     *   a_keys != 0: A holds the order-preserving max keys a colmax_keys launch left (uint32), decoded as they are loaded -- no
+     *     decode launch; a_wrap > 0 (% 4 == 0): column k of the operand is key k % a_wrap, i.e. cat((max, max), 1)
+     *     (FaceRecon.py:148) is never built.
+     *   C_sigmoid != NULL: 1 / (1 + exp(-v)) of every stored value is also written there (row stride ldc): the PH predictor's
+     *     nn.Sigmoid (FaceRecon.py:156,162) without a launch of its own. */
+    int a_keys; int a_wrap;
+    float *C_sigmoid;
 } tgp_gemm_args;
 
 /* W (rows, K) fp32, row stride ld -> out[rows][ldo/16][3][16] bf16: per 16-wide K-tile the hi, mid and lo terms
@@ -282,6 +290,22 @@ int tgp_sigmoid(const float *x, float *y, int64_t count, tgp_stream_t stream);
  * heads' outputs as rows of one (3, B, 8) buffer, read here in place). */
 int tgp_head_post(const float *green, const float *red, const float *ts, int ldg, int ldr, int ldt, const float *mean, int B,
                   float *p_green, float *p_red, float *f_green, float *f_red, float *pred_T, float *pred_s, tgp_stream_t stream);
+
+/* (ABI 6) The three pose heads after their max over points as ONE launch (PoseR.py:37-43, PoseTs.py:43-49 in eval mode, then
+ * PoseNet9D.py:57-66): keys2 (3, B, 256) the order-preserving max keys of conv2's output (heads rot_green, rot_red, ts);
+ * w3t (3, 256, 256) conv3's weights TRANSPOSED (input channel major); b3 / scale3 / shift3 (3, 256) bias and BatchNorm fold;
+ * w4 (3, 8, 256) conv4 with its 4 / 4 / 6 rows zero-padded to 8, b4 (3, 8); outputs as tgp_head_post's; raw (may be NULL)
+ * receives conv4's (3, B, 8) outputs. */
+int tgp_pose_tail(const uint32_t *keys2, const float *w3t, const float *b3, const float *scale3, const float *shift3,
+                  const float *w4, const float *b4, const float *mean, int B, float *p_green, float *p_red, float *f_green,
+                  float *f_red, float *pred_T, float *pred_s, float *raw, tgp_stream_t stream);
+
+/* (ABI 6) A per-point layer with n_out <= 4 outputs whose rows leave in another order -- the decoder's last conv
+ * (FaceRecon.py:117) behind the row sort of the factored layers: out[obj, map[obj, i], j] = bias[j] + sum_k x[obj, i, k] W[j, k]
+ * for the `rows` rows of x (row stride ld, K % 4 == 0), objects of rows_per_obj rows; map (int64, relative to the object; NULL =
+ * identity); out (rows, n_out) contiguous.  TGP_EUNSUPPORTED for other n_out. */
+int tgp_rows_out(const float *x, int ld, int64_t rows, int K, const float *W, int ldw, const float *bias, int n_out,
+                 const int64_t *map, int rows_per_obj, float *out, tgp_stream_t stream);
 
 /* PoseNet9D.py:71 recon + mean, in place on recon (B,n,3). */
 int tgp_add_mean(float *recon, const float *mean, int B, int n, tgp_stream_t stream);

@@ -3561,6 +3561,85 @@ def test_orl_rowbias_one_launch_form(ops, B, n, C, k, with_planes):
     assert float((rb0.double() - want).abs().max()) <= 2e-6 * scale
 
 
+@pytest.mark.parametrize("B", [1, 32, 45])
+def test_pose_tail_one_launch_vs_the_chain_and_fp64(ops, B):
+    """tgp_pose_tail (the heads' conv3 -> BatchNorm -> ReLU -> conv4 and the formulas of PoseNet9D.py:57-66, per head and object in
+    one launch) against the launches it replaces (key decode, two batched vector GEMMs, tgp_head_post) and an fp64 restatement."""
+    from tgpose_amd import engine
+    pk = engine.Packed(_net(5).state_dict(), DEV)
+    w = pk.wide
+    gen = torch.Generator().manual_seed(B)
+    pooled = g(torch.randn(3, B, 256, generator=gen).abs())
+    keys2 = torch.zeros(3, B, 256, device=DEV, dtype=torch.int32)
+    ops.gemm(pooled.view(3 * B, 256), g(torch.eye(256)), None, M=3 * B, N=256, K=256, lda=256, ldw=256, ldc=0, colmax_keys=keys2.view(3 * B, 256),
+             rows_per_obj=1)
+    assert torch.equal(ops.colmax_decode(keys2.view(3 * B, 256)), pooled.view(3 * B, 256))
+    mean = g(torch.randn(B, 3, generator=gen))
+    raw = torch.empty(3, B, 8, device=DEV)
+    got = ops.pose_tail(keys2, w["W3t"], w["b3"], w["scale3"], w["shift3"], w["W4"], w["b4"], mean, raw=raw)
+    old = engine.POSE_TAIL
+    engine.POSE_TAIL = False
+    try:
+        want = engine.head_chain(pk, keys2, B, 1, mean)
+    finally:
+        engine.POSE_TAIL = old
+    for a, b, name in zip(got, want, ("p_green", "p_red", "f_green", "f_red", "Pred_T", "Pred_s")):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), name
+    x = pooled.double()
+    y = torch.einsum("hbk,hok->hbo", x, w["W3"].double()) + w["b3"].double()[:, None]
+    y = torch.relu(y * w["scale3"].double()[:, None] + w["shift3"].double()[:, None])
+    o = torch.einsum("hbk,hjk->hbj", y, w["W4"].double()) + w["b4"].double()[:, None]
+    assert float((raw.double() - o).abs().max()) <= 2e-5 * float(o.abs().max())
+    gr, rd, ts = o[0], o[1], o[2]
+    ref = (gr[:, 1:4] / (gr[:, 1:4].norm(dim=1, keepdim=True) + 1e-6), rd[:, 1:4] / (rd[:, 1:4].norm(dim=1, keepdim=True) + 1e-6),
+           torch.sigmoid(gr[:, 0]), torch.sigmoid(rd[:, 0]), ts[:, :3] + mean.double(), ts[:, 3:6])
+    for a, b, name in zip(got, ref, ("p_green", "p_red", "f_green", "f_red", "Pred_T", "Pred_s")):
+        assert float((a.double() - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max())), name
+
+
+@pytest.mark.parametrize("B,n,K,n_out", [(32, 1028, 128, 3), (3, 100, 128, 3), (2, 257, 64, 4), (5, 33, 256, 1)])
+def test_rows_out_equals_linear_then_scatter(ops, B, n, K, n_out):
+    """tgp_rows_out: a narrow last layer and the scatter that undoes the factored layers' row sort, as one launch
+    (FaceRecon.py:117 behind engine.encoder_forward's sort), against linear + scatter_ and an fp64 restatement; rows of a wider
+    buffer (row stride > K) and the identity order included."""
+    gen = torch.Generator().manual_seed(B * n + K)
+    wide = g(torch.randn(B, n, K + 8, generator=gen))
+    x = wide[:, :, :K]
+    w = g(torch.randn(n_out, K, generator=gen) / K ** 0.5)
+    b = g(torch.randn(n_out, generator=gen))
+    order = g(torch.stack([torch.randperm(n, generator=gen) for _ in range(B)]))
+    got = ops.rows_out(x, w, b, order)
+    lin = x.double() @ w.double().t() + b.double()
+    want = torch.empty_like(lin).scatter_(1, order.unsqueeze(-1).expand(-1, -1, n_out), lin)
+    assert float((got.double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
+    assert float((ops.rows_out(x, w, None, None).double() - (lin - b.double())).abs().max()) <= 2e-6 * max(1.0, float(lin.abs().max()))
+
+
+def test_ph_tail_on_keys_with_sigmoid_epilogue_vs_five_launches(ops):
+    """PH_Predictor's vector layers (FaceRecon.py:145-165): the first reads conv_5's max keys as they lie (decoded on load, the
+    duplicated cat((max, max), 1) as a wrapped column index), the sigmoid leaves from the second one's epilogue -- against the
+    five-launch form (key decode, three layers, sigmoid): the same kernel, the same operands, every output bit for bit."""
+    from tgpose_amd import engine
+    pk = engine.Packed(_net(6).state_dict(), DEV)
+    B = 32
+    gen = torch.Generator().manual_seed(3)
+    act = g(torch.randn(B * 40, 1024, generator=gen))
+    keys = torch.zeros(B, 1024, device=DEV, dtype=torch.int32)
+    ops.gemm(act, g(torch.eye(1024)), None, M=B * 40, N=1024, K=1024, lda=1024, ldw=1024, ldc=0, colmax_keys=keys, rows_per_obj=40)
+    res = []
+    for fused in (True, False):
+        old = engine.PH_TAIL_FUSED
+        engine.PH_TAIL_FUSED = fused
+        try:
+            h1, h2, back = engine.ph_tail(pk.ph, keys, B, DEV)
+        finally:
+            engine.PH_TAIL_FUSED = old
+        res.append((h1.clone(), h2.clone(), back.clone()))
+    for a, b, name in zip(res[0], res[1], ("h1", "h2", "back")):
+        assert torch.equal(a, b), name
+    assert float(res[0][0].min()) >= 0.0 and float(res[0][0].max()) <= 1.0 and float(res[0][2].abs().max()) > 0
+
+
 @pytest.mark.parametrize("B,N", [(9, 1028), (3, 300)])
 def test_heads_fused_persistent_and_planes_forms_bit_identical(ops, B, N):
     """The fused heads kernel as a persistent grid (one workgroup per CU walking its tiles, the next tile's operands prefetched under

@@ -45,6 +45,8 @@ class GemmArgs(ctypes.Structure):
         ("C_planes", c_vp), ("c_kt", c_int), ("cp_col0", c_int), ("c_amax", c_vp),
         ("pp_config", c_int),
         ("range_flag", c_vp),
+        ("a_keys", c_int), ("a_wrap", c_int),
+        ("C_sigmoid", c_vp),
     ]
 
 
@@ -179,6 +181,8 @@ SIGNATURES = {
     "tgp_cloud_select": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, c_vp, c_vp]),
     "tgp_pose_rotation_fwd": (c_int, [c_vp] * 6 + [c_int, c_vp, c_vp, c_vp]),
     "tgp_pose_rotation_bwd": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp]),
+    "tgp_rows_out": (c_int, [c_vp, c_int, c_i64, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
+    "tgp_pose_tail": (c_int, [c_vp] * 8 + [c_int] + [c_vp] * 8),
     "tgp_head_post_bwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int] + [c_vp] * 10),
     "tgp_transpose_both": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
     "tgp_gemm_tn_split": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp]),

@@ -941,7 +941,7 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmPara
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int row = c16 + 16 * t;
-        arow[t] = A + (int64_t)(row < p.M ? row : p.M - 1) * p.lda + 4 * q;
+        arow[t] = A + (int64_t)(row < p.M ? row : p.M - 1) * p.lda;
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -962,9 +962,14 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmPara
             const int k = (c0 + u * SKINNY_WAVES) * 16;
             const bool ok = k + 4 * q < p.K;          // K % 4 == 0; also false for chunks past the end
             const int kc = ok ? k : 0;
+            int ka = kc + 4 * q;
+            if (p.a_wrap) ka = ka % p.a_wrap;                // cat((max, max), 1) without the copy (workgroup-uniform branch)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const float4 av = *reinterpret_cast<const float4 *>(arow[t] + kc);
+                float4 av = *reinterpret_cast<const float4 *>(arow[t] + ka);
+                if (p.a_keys)                                // max keys as the colmax epilogues left them: decoded here
+                    av = make_float4(tgp_key_float(__float_as_uint(av.x)), tgp_key_float(__float_as_uint(av.y)),
+                                     tgp_key_float(__float_as_uint(av.z)), tgp_key_float(__float_as_uint(av.w)));
                 a[u][t] = ok ? av : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
@@ -1007,6 +1012,7 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmPara
             if (p.scale) v = v * p.scale[vo + col] + (p.shift ? p.shift[vo + col] : 0.f);
             if (p.act == 1) v = v > 0.f ? v : v * p.slope;
             p.C[(int64_t)z * p.sC + (int64_t)m * p.ldc + col] = v;
+            if (p.Csig) p.Csig[(int64_t)m * p.ldc + col] = 1.0f / (1.0f + expf(-v));
         }
     }
 }
@@ -1255,7 +1261,7 @@ extern "C" int tgp_gemm_f32(const tgp_gemm_args *a, tgp_stream_t stream)
 {
     TGP_REQUIRE(a && (a->A || a->A_planes) && a->W && (a->C || a->colmax_keys || a->C_planes));
     TGP_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0);
-    TGP_REQUIRE((a->K & 3) == 0 && (a->ldw & 3) == 0 && a->ldw >= a->K && (!a->A || ((a->lda & 3) == 0 && a->lda >= a->K)));
+    TGP_REQUIRE((a->K & 3) == 0 && (a->ldw & 3) == 0 && a->ldw >= a->K && (!a->A || ((a->lda & 3) == 0 && (a->lda >= a->K || (a->a_wrap > 0 && a->lda >= a->a_wrap)))));
     TGP_REQUIRE((reinterpret_cast<uintptr_t>(a->A) & 15) == 0 && (reinterpret_cast<uintptr_t>(a->W) & 15) == 0);
     TGP_REQUIRE(a->c_col0 >= 0 && a->c_col0 <= a->N && (!a->C || a->ldc >= a->N - a->c_col0));
     TGP_REQUIRE(!(a->rowbias || a->colmax_keys) || a->rows_per_obj > 0);
@@ -1312,8 +1318,11 @@ extern "C" int tgp_gemm_f32(const tgp_gemm_args *a, tgp_stream_t stream)
     // a_scale / c_scale / ksplit_chunk are implemented by the fp16 split tile kernels only: refuse launches that route elsewhere
     TGP_REQUIRE(!(a->a_scale || a->c_scale || a->ksplit_chunk) ||
                 (a->W_split && a->w_split_kind == 1 && a->M > 32 && a->N > 64 && (mid_tiles >= resident_slots() / 2 || small_split)));
+    TGP_REQUIRE(!(a->a_keys || a->a_wrap || a->C_sigmoid) || (a->M <= 32 && a->C && plain && p.batch == 1));
+    TGP_REQUIRE(a->a_wrap >= 0 && (a->a_wrap & 3) == 0 && (!a->a_wrap || a->lda >= a->a_wrap));
     if (a->M <= 32 && a->C && plain) {
         TGP_REQUIRE(!p.Cp);
+        p.a_keys = a->a_keys, p.a_wrap = a->a_wrap, p.Csig = a->C_sigmoid;
         if ((int64_t)tgp_cdiv(a->N, 32) * p.batch >= resident_slots() / 2)
             hipLaunchKernelGGL((skinny_gemm_kernel<2, 8>), dim3(tgp_cdiv(a->N, 32), p.batch), dim3(512), 0, tgp_hs(stream), p);
         else
@@ -1466,6 +1475,118 @@ extern "C" int tgp_head_post(const float *green, const float *red, const float *
     TGP_REQUIRE(ldg >= 4 && ldr >= 4 && ldt >= 6);
     hipLaunchKernelGGL(head_post_kernel, dim3(tgp_cdiv(B, 64)), dim3(64), 0, tgp_hs(stream), green, red, ts, ldg, ldr, ldt, mean, B,
                        p_green, p_red, f_green, f_red, pred_T, pred_s);
+    return TGP_LAUNCH_RESULT();
+}
+
+// The three pose heads after their max over points, per (head, object) in ONE launch (round 4; was colmax_decode + two batched
+// skinny GEMMs + head_post): the pooled keys -> conv3 (+ bias, BatchNorm fold, ReLU) -> conv4 (+ bias) -> the head's share of
+// PoseNet9D.py:57-66 (PoseR.py:37-43, PoseTs.py:43-49; dropout is the identity in eval mode).  256 threads: thread o owns conv3's
+// output channel o -- one fmaf chain over the 256 inputs in ascending order, reading W3 transposed (consecutive threads, consecutive
+// floats) --, conv4's 8 x 256 products are split over 32 lanes per output and added by xor-shuffles in a fixed tree.
+__global__ __launch_bounds__(256) void pose_tail_kernel(const uint32_t *__restrict__ keys2, const float *__restrict__ w3t,
+                                                        const float *__restrict__ b3, const float *__restrict__ scale3,
+                                                        const float *__restrict__ shift3, const float *__restrict__ w4,
+                                                        const float *__restrict__ b4, const float *__restrict__ mean, int B,
+                                                        float *__restrict__ pg, float *__restrict__ pr, float *__restrict__ fg,
+                                                        float *__restrict__ fr, float *__restrict__ pT, float *__restrict__ ps,
+                                                        float *__restrict__ raw)
+{
+    __shared__ float x[256], y[256], o[8];
+    const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    x[t] = tgp_key_float(keys2[((int64_t)h * B + b) * 256 + t]);
+    __syncthreads();
+    float acc = 0.f;
+    const float *w = w3t + (int64_t)h * 256 * 256 + t;
+#pragma unroll 16
+    for (int k = 0; k < 256; ++k) acc = fmaf(x[k], w[k * 256], acc);
+    float v = acc + b3[h * 256 + t];
+    v = v * scale3[h * 256 + t] + shift3[h * 256 + t];
+    v = v > 0.f ? v : v * 0.f;
+    y[t] = v;
+    __syncthreads();
+    const int j = t >> 5, l = t & 31;
+    float part = 0.f;
+    const float *w4r = w4 + ((int64_t)h * 8 + j) * 256;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part = fmaf(y[l + 32 * i], w4r[l + 32 * i], part);
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
+    if (l == 0) {
+        const float r = part + b4[h * 8 + j];
+        o[j] = r;
+        if (raw) raw[((int64_t)h * B + b) * 8 + j] = r;
+    }
+    __syncthreads();
+    if (t != 0) return;
+    if (h < 2) {
+        // torch.norm(v, dim=1): sqrt of the sum of squares; PoseNet9D.py:57-58 divides by (norm + 1e-6)
+        const float nrm = sqrtf((o[1] * o[1] + o[2] * o[2]) + o[3] * o[3]) + 1e-6f;
+        float *pv = h == 0 ? pg : pr, *fv = h == 0 ? fg : fr;
+        for (int c = 0; c < 3; ++c) pv[b * 3 + c] = o[1 + c] / nrm;
+        fv[b] = 1.0f / (1.0f + expf(-o[0]));
+    } else {
+        for (int c = 0; c < 3; ++c) {
+            pT[b * 3 + c] = o[c] + mean[b * 3 + c];
+            ps[b * 3 + c] = o[3 + c];
+        }
+    }
+}
+
+extern "C" int tgp_pose_tail(const uint32_t *keys2, const float *w3t, const float *b3, const float *scale3, const float *shift3,
+                             const float *w4, const float *b4, const float *mean, int B, float *p_green, float *p_red, float *f_green,
+                             float *f_red, float *pred_T, float *pred_s, float *raw, tgp_stream_t stream)
+{
+    TGP_REQUIRE(keys2 && w3t && b3 && scale3 && shift3 && w4 && b4 && mean && B > 0);
+    TGP_REQUIRE(p_green && p_red && f_green && f_red && pred_T && pred_s);
+    hipLaunchKernelGGL(pose_tail_kernel, dim3(3, B), dim3(256), 0, tgp_hs(stream), keys2, w3t, b3, scale3, shift3, w4, b4, mean, B,
+                       p_green, p_red, f_green, f_red, pred_T, pred_s, raw);
+    return TGP_LAUNCH_RESULT();
+}
+
+// A per-point layer with at most four outputs whose rows leave in another order (round 4; the decoder's recon_head.3,
+// FaceRecon.py:117, behind the factored layers' row sort: was a 64 x 64-tile GEMM launch on N = 3 plus a scatter):
+// out[obj, map[obj, i], j] = bias[j] + sum_k x[obj, i, k] W[j, k].  32 lanes per row, 16 bytes per lane and step (a row of 128
+// floats is one coalesced 512-byte read), partial sums added by xor-shuffles in a fixed tree.
+template <int NO>
+__global__ __launch_bounds__(256) void rows_out_kernel(const float *__restrict__ x, int ld, int64_t rows, int K,
+                                                       const float *__restrict__ W, int ldw, const float *__restrict__ bias,
+                                                       const int64_t *__restrict__ map, int rows_per_obj, float *__restrict__ out)
+{
+    const int l = threadIdx.x & 31;
+    const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int64_t rr = row < rows ? row : rows - 1;            // (whole waves reach the shuffles)
+    float acc[NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) acc[j] = 0.f;
+    for (int k4 = l; k4 < K / 4; k4 += 32) {
+        const float4 xv = *reinterpret_cast<const float4 *>(x + rr * ld + 4 * k4);
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            const float4 wv = *reinterpret_cast<const float4 *>(W + (int64_t)j * ldw + 4 * k4);
+            acc[j] = fmaf(xv.w, wv.w, fmaf(xv.z, wv.z, fmaf(xv.y, wv.y, fmaf(xv.x, wv.x, acc[j]))));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NO; ++j)
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) acc[j] += __shfl_xor(acc[j], m, 64);
+    if (l != 0 || row >= rows) return;
+    const int64_t dst = map ? (row / rows_per_obj) * rows_per_obj + map[row] : row;
+#pragma unroll
+    for (int j = 0; j < NO; ++j) out[dst * NO + j] = acc[j] + (bias ? bias[j] : 0.f);
+}
+
+extern "C" int tgp_rows_out(const float *x, int ld, int64_t rows, int K, const float *W, int ldw, const float *bias, int n_out,
+                            const int64_t *map, int rows_per_obj, float *out, tgp_stream_t stream)
+{
+    TGP_REQUIRE(x && W && out && rows > 0 && K > 0 && (K & 3) == 0 && ld >= K && ldw >= K && (ld & 3) == 0 && (ldw & 3) == 0);
+    TGP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0);
+    TGP_REQUIRE(!map || (rows_per_obj > 0 && rows % rows_per_obj == 0));
+    if (n_out < 1 || n_out > 4) return TGP_EUNSUPPORTED;
+    const dim3 grid((unsigned)tgp_cdiv(rows, 8));
+#define RO_GO(NO) hipLaunchKernelGGL(rows_out_kernel<NO>, grid, dim3(256), 0, tgp_hs(stream), x, ld, rows, K, W, ldw, bias, map, rows_per_obj, out)
+    if (n_out == 1) RO_GO(1); else if (n_out == 2) RO_GO(2); else if (n_out == 3) RO_GO(3); else RO_GO(4);
+#undef RO_GO
     return TGP_LAUNCH_RESULT();
 }
 

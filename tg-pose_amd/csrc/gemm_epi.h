@@ -65,6 +65,8 @@ struct GemmParams {
     const float *gres1, *gres2;
     const int32_t *gidx1, *gidx2;
     int ldg1, ldg2;
+    int a_keys, a_wrap;          // skinny kernel: A holds max keys (decoded on load), column k of the operand is key k % a_wrap
+    float *Csig;                 // skinny kernel: sigmoid of the stored values
     int vec_epi;                 // every epilogue operand is 16-byte addressable: the split kernels use gemm_epilogue_lds
     int scalar_epi;              // caller asked for the register-direct epilogue (tgp_gemm_args.epilogue == 1)
     const int *pred;             // device flag: the launch does nothing while *pred == 0 (tgp_gemm_args.pred; split tile kernels)

@@ -85,7 +85,9 @@ __global__ void center_mean_serial_kernel(const float *__restrict__ points, int 
 // object: threads sum the runs, three threads then replay the merges in order.  Bit-identical to the
 // serial routine above (tests compare both against torch on the CPU).
 #define CM_MAX_RUNS 128
-__global__ __launch_bounds__(256) void center_mean_kernel(const float *__restrict__ points, int n, float *__restrict__ mean)
+// out != NULL (round 4): the workgroup also writes its object's centred points -- tgp_center as one launch
+__global__ __launch_bounds__(256) void center_mean_kernel(const float *__restrict__ points, int n, float *__restrict__ mean,
+                                                          float *__restrict__ out)
 {
     __shared__ float part[3][4][CM_MAX_RUNS + 1];
     const int b = blockIdx.x;
@@ -123,8 +125,15 @@ __global__ __launch_bounds__(256) void center_mean_kernel(const float *__restric
         float s = fin[0] + fin[1];
         s = s + fin[2];
         s = s + fin[3];
-        mean[b * 3 + c] = (0.f + s) / (float)n;
+        const float mu = (0.f + s) / (float)n;
+        mean[b * 3 + c] = mu;
+        part[c][0][0] = mu;
     }
+    if (!out) return;
+    __syncthreads();
+    const float m3[3] = {part[0][0][0], part[1][0][0], part[2][0][0]};
+    float *o = out + (size_t)b * n * 3;
+    for (int t = threadIdx.x; t < n * 3; t += blockDim.x) o[t] = in[t] - m3[t % 3];
 }
 
 __global__ void center_sub_kernel(const float *__restrict__ points, const float *__restrict__ mean, int n,
@@ -141,11 +150,11 @@ __global__ void center_sub_kernel(const float *__restrict__ points, const float 
 extern "C" int tgp_center(const float *points, int B, int n, float *xyz_c, float *mean, tgp_stream_t stream)
 {
     TGP_REQUIRE(points && xyz_c && mean && B > 0 && n > 0);
-    if (n / 64 < CM_MAX_RUNS)
-        hipLaunchKernelGGL(center_mean_kernel, dim3(B), dim3(256), 0, tgp_hs(stream), points, n, mean);
-    else
-        hipLaunchKernelGGL(center_mean_serial_kernel, dim3(tgp_cdiv(B * 3, 64)), dim3(64), 0, tgp_hs(stream), points, B, n,
-                           mean);
+    if (n / 64 < CM_MAX_RUNS) {
+        hipLaunchKernelGGL(center_mean_kernel, dim3(B), dim3(256), 0, tgp_hs(stream), points, n, mean, xyz_c);
+        return TGP_LAUNCH_RESULT();
+    }
+    hipLaunchKernelGGL(center_mean_serial_kernel, dim3(tgp_cdiv(B * 3, 64)), dim3(64), 0, tgp_hs(stream), points, B, n, mean);
     const int64_t total = (int64_t)B * n * 3;
     hipLaunchKernelGGL(center_sub_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), points, mean, n,
                        total, xyz_c);

@@ -161,6 +161,7 @@ def pack_wide(ph, heads, bn_names=None):
     w["W4"] = torch.stack([_pad_rows(hd["c4"][0], 8) for hd in heads]).contiguous()
     w["b4"] = torch.stack([_pad_rows(hd["c4"][1].unsqueeze(1), 8)[:, 0] for hd in heads]).contiguous()
     w["n_out"] = [hd["c4"][0].shape[0] for hd in heads]
+    w["W3t"] = w["W3"].transpose(1, 2).contiguous() if tuple(w["W3"].shape) == (3, 256, 256) else None     # ops.pose_tail
     if _FOLDS is not None and bn_names is not None:      # the concatenated copies must follow the running statistics too
         _FOLDS.append((bn_names["conv5"], w["scale"][0:1024], w["shift"][0:1024]))
         for i, h in enumerate(bn_names["heads"]):
@@ -314,12 +315,14 @@ def surface_layer(c, xyz, idx_rf, idx_orl, out, scale=None, shift=None, act=None
     gx = torch.empty(B, n, C + 4, device=xyz.device, dtype=torch.float32)          # [g | x y z 0]
     g = ops.gconv_surface(xyz, idx_rf, c["sdn"], 7, C, out=gx[:, :, :C], xyz_pad=True)
     gp = None
+    if tickets is None and ops.ORL_FUSED and "w2t" in c:      # (outside the arena: the concat-buffer path) the same kernel, so the same bits
+        tickets = torch.zeros(B, device=xyz.device, dtype=torch.int32)
     if out_p is not None and "w1x_p" in c and "w2t" in c:
         # the ORL pooling stages g in LDS anyway: it leaves [g | x y z 0] as fp16 planes, the last GEMM's operand (csrc/gconv.hip)
         rb, gp = ops.orl_rowbias(g, idx_orl, c["w2t"], planes=ops.Planes(B * n, C + 4, xyz.device, amax_buf=amax_ws), xyz_tile=xyz,
                                  tickets=tickets)
     else:
-        rb = ops.orl_rowbias(g, idx_orl, c["w2t"]) if "w2t" in c else ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
+        rb = ops.orl_rowbias(g, idx_orl, c["w2t"], tickets=tickets) if "w2t" in c else ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
     # conv2(cat[g, global]) + g + STE(xyz) (gcn3d.py:87-89,108-112): W1 g + STE xyz is one product over the padded row
     ops.linear_rows(gx, c["w1x"], out=out, rowbias=rb, rows_per_obj=n, res1=g, scale=scale, shift=shift,
                     act=0 if act is None else 1, slope=0.0, w_split=c.get("w1x_s"), k_alg=C + 3, c_planes=out_p,
@@ -368,10 +371,12 @@ def hs_layer(c, xyz, fmap, idx_rf, idx_orl, out, scale=None, shift=None, act=Non
         torch.cuda.current_stream(xyz.device).wait_event(join)
     g = ops.gconv_hs(xyz, idx_rf, proj9, c["sdn"], 7, C)
     gp = None
+    if tickets is None and ops.ORL_FUSED and "w2t" in c:
+        tickets = torch.zeros(B, device=xyz.device, dtype=torch.int32)
     if amax_ws is not None and "w1_p" in c and "w2t" in c:
         rb, gp = ops.orl_rowbias(g, idx_orl, c["w2t"], planes=ops.Planes(B * n, C, xyz.device, amax_buf=amax_ws), tickets=tickets)
     else:
-        rb = ops.orl_rowbias(g, idx_orl, c["w2t"]) if "w2t" in c else ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
+        rb = ops.orl_rowbias(g, idx_orl, c["w2t"], tickets=tickets) if "w2t" in c else ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
     ops.linear_rows(g, c["w1"], out=out, rowbias=rb, rows_per_obj=n, res1=g, res2=proj9[:, :, 8 * C:], scale=scale,
                     shift=shift, act=0 if act is None else 1, slope=0.0, w_split=c.get("w1_s"), c_planes=out_p, cp_col0=out_col0,
                     a_planes=gp, w_planes=c.get("w1_p") if gp is not None else None)
@@ -522,13 +527,26 @@ class Arena(object):
 
 def ph_tail(ph, keys, B, dev, back=None):
     """PH_Predictor after the max over points (FaceRecon.py:145-165): keys = colmax keys of conv_5."""
-    g = ops.colmax_decode(keys, out2=True)                                       # cat((max, max), 1)
-    fa = ops.linear_rows(g, ph["l1"], scale=ph["bn5"][0], shift=ph["bn5"][1], act=1, slope=0.2)
-    pi = ops.linear_rows(fa, ph["l23"][0], bias=ph["l23"][1])                    # (B, 5000) = [pi1 | pi2]
     if back is None:
         back = torch.zeros(B, FEAT_LD, device=dev, dtype=torch.float32)
-    ops.linear_rows(pi, ph["l45"][0], bias=ph["l45"][1], out=back[:, :FEAT_C])   # pi1_1 + pi2_1
-    h = ops.sigmoid(pi)
+    l1, (w23, b23) = ph["l1"], ph["l23"]
+    if PH_TAIL_FUSED and B <= 32 and keys.is_contiguous() and l1.shape[1] == 2 * keys.shape[1]:
+        # (round 4) the vector layers read the max keys as they lie -- decoded on load, cat((max, max), 1) as a wrapped column
+        # index -- and the sigmoid leaves from the epilogue of the layer it follows: three launches instead of five
+        fa = torch.empty(B, l1.shape[0], device=dev, dtype=torch.float32)
+        ops.gemm(keys, l1, fa, M=B, N=l1.shape[0], K=l1.shape[1], lda=keys.shape[1], ldw=l1.shape[1], ldc=l1.shape[0],
+                 scale=ph["bn5"][0], shift=ph["bn5"][1], act=1, slope=0.2, a_keys=True, a_wrap=keys.shape[1])
+        pi = torch.empty(B, w23.shape[0], device=dev, dtype=torch.float32)
+        h = torch.empty_like(pi)
+        ops.gemm(fa, w23, pi, M=B, N=w23.shape[0], K=w23.shape[1], lda=fa.shape[1], ldw=w23.shape[1], ldc=w23.shape[0], bias=b23,
+                 c_sigmoid=h)
+        ops.linear_rows(pi, ph["l45"][0], bias=ph["l45"][1], out=back[:, :FEAT_C])
+    else:
+        g = ops.colmax_decode(keys, out2=True)                                       # cat((max, max), 1)
+        fa = ops.linear_rows(g, l1, scale=ph["bn5"][0], shift=ph["bn5"][1], act=1, slope=0.2)
+        pi = ops.linear_rows(fa, w23, bias=b23)                                      # (B, 5000) = [pi1 | pi2]
+        ops.linear_rows(pi, ph["l45"][0], bias=ph["l45"][1], out=back[:, :FEAT_C])   # pi1_1 + pi2_1
+        h = ops.sigmoid(pi)
     nc = ph["n_code"]
     return h[:, :nc], h[:, nc:], back
 
@@ -724,14 +742,22 @@ def decoder_forward_factored(pk, fine, inter, P1, P2, back, N, arena=None):
             x = ops.linear_rows(x, w, bias=b, scale=sc, shift=sh, act=1, w_split=ws, a_planes=xp if wp is not None else None, w_planes=wp,
                                 c_planes=pl.get(nxt) if (nxt and xp is not None and wp is not None) else None)
             xp = pl.get(nxt) if (nxt and xp is not None and wp is not None) else None
+    # rows are in the sorted order of encoder_forward(factored=True): the (B,N,3) result goes back in point order
+    if ROWS_OUT and pk.dec_out[0].shape[0] <= 4 and pk.dec_out[0].shape[1] % 4 == 0:
+        return ops.rows_out(x, pk.dec_out[0], pk.dec_out[1], inter["order"].contiguous())
     recon = ops.linear_rows(x, pk.dec_out[0], bias=pk.dec_out[1])
-    # rows are in the sorted order of encoder_forward(factored=True): put the (B,N,3) result back in point order
     return torch.empty_like(recon).scatter_(1, inter["order"].unsqueeze(-1).expand(-1, -1, 3), recon)
 
 
-def head_chain(pk, H, B, N):
+PH_TAIL_FUSED = os.environ.get("TGP_PH_TAIL_FUSED", "1") != "0"   # PH predictor's vector layers: key decode and sigmoid inside them
+ROWS_OUT = os.environ.get("TGP_ROWS_OUT", "1") != "0"        # the decoder's last conv and the un-sort of its rows as one launch
+POSE_TAIL = os.environ.get("TGP_POSE_TAIL", "1") != "0"      # conv3, conv4 and the output formulas of the heads as one launch
+
+
+def head_chain(pk, H, B, N, mean=None):
     """The three heads after conv1: conv2 (+BN, ReLU, max over points) as one batched launch, then conv3 / conv4
-    batched over the heads.  Returns [green (B,4), red (B,4), ts (B,6)]."""
+    batched over the heads.  Returns [green (B,4), red (B,4), ts (B,6)]; with `mean` (the clouds' centres) the six pose outputs
+    of PoseNet9D.py:57-66 (p_green_R, p_red_R, f_green_R, f_red_R, Pred_T, Pred_s) instead."""
     dev = H.device
     w = pk.wide
     M = B * N
@@ -742,6 +768,8 @@ def head_chain(pk, H, B, N):
         ops.gemm(H, w["W2"], None, M=M, N=256, K=1024, lda=3072, ldw=1024, ldc=0, bias=w["b2"], scale=w["scale2"],
                  shift=w["shift2"], act=1, slope=0.0, colmax_keys=keys2, rows_per_obj=N, batch=3,
                  batch_strides=(1024, 256 * 1024, 0, 256, B * 256), w_split=w["W2s"])
+    if mean is not None and POSE_TAIL and w.get("W3t") is not None:
+        return ops.pose_tail(keys2.contiguous(), w["W3t"], w["b3"], w["scale3"], w["shift3"], w["W4"], w["b4"], mean)
     pooled = ops.colmax_decode(keys2.view(3 * B, 256))                          # (3B, 256)
     # conv3 (+BN, ReLU), dropout(eval) = identity, conv4: two batched launches for the three heads
     x3 = torch.empty(3, B, 256, device=dev, dtype=torch.float32)
@@ -750,7 +778,8 @@ def head_chain(pk, H, B, N):
     o4 = torch.empty(3, B, 8, device=dev, dtype=torch.float32)
     ops.gemm(x3, w["W4"], o4, M=B, N=8, K=256, lda=256, ldw=256, ldc=8, bias=w["b4"], batch=3,
              batch_strides=(B * 256, 8 * 256, B * 8, 8, 0))
-    return [o4[i, :, : w["n_out"][i]] for i in range(3)]          # views of the (3, B, 8) buffer: tgp_head_post takes row strides
+    green, red, ts = [o4[i, :, : w["n_out"][i]] for i in range(3)]  # views of the (3, B, 8) buffer: tgp_head_post takes row strides
+    return (green, red, ts) if mean is None else ops.head_post(green, red, ts, mean)
 
 
 def wide_forward(pk, feat, N):
@@ -829,8 +858,7 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
     if heads_only:
         P1, P2 = coarse_products(pk, inter, heads_only=True)
         _, H = wide_gemm_factored(pk, feat, inter, P1, P2, N, arena, heads_only=True)
-        green, red, ts = head_chain(pk, H(), B, N)
-        pg, pr, fg, fr, pT, ps = ops.head_post(green, red, ts, mean)
+        pg, pr, fg, fr, pT, ps = head_chain(pk, H(), B, N, mean)
         return dict(p_green_R=pg, p_red_R=pr, f_green_R=fg, f_red_R=fr, Pred_T=pT, Pred_s=ps)
     if factored:
         P1, P2 = coarse_products(pk, inter)
@@ -859,16 +887,15 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
         if not torch.cuda.is_current_stream_capturing():      # a captured graph owns its pool: nothing to protect
             for t in (keys5, H, feat, h1, h2, back, recon) + ((P1, P2, inter["near1"], inter["near2"]) if factored else ()):
                 t.record_stream(side)
-        green, red, ts = head_chain(pk, H, B, N)
+        pg, pr, fg, fr, pT, ps = head_chain(pk, H, B, N, mean)
         cur.wait_event(join)
     else:
         keys5, H = wide()
         if callable(H):
             H = H()
-        green, red, ts = head_chain(pk, H, B, N)
+        pg, pr, fg, fr, pT, ps = head_chain(pk, H, B, N, mean)
         h1, h2, back = ph_tail(pk.ph, keys5, B, points.device, arena.back if arena is not None else None)
         recon = decode(back)
-    pg, pr, fg, fr, pT, ps = ops.head_post(green, red, ts, mean)
     out = dict()
     if probe is not None:
         probe.update(recon=recon + mean.view(B, 1, 3), h1=h1, h2=h2, keys5=keys5)

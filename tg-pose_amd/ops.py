@@ -457,7 +457,8 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
          rows_per_obj=0, res1=None, ldr1=0, res2=None, ldr2=0, scale=None, shift=None, act=0, slope=0.0,
          colmax_keys=None, k_alg=None, slope_vec=None, cm_cols=0, c_col0=0, batch=1, batch_strides=None, w_split=None,
          a_scale=None, c_scale=None, ksplit_chunk=0, gather1=None, gather2=None, flops_ref=None, epilogue=0, pred=None,
-         row_base=0, a_planes=None, w_planes=None, c_planes=None, cp_col0=0, pp_config=0, range_flag=None):
+         row_base=0, a_planes=None, w_planes=None, c_planes=None, cp_col0=0, pp_config=0, range_flag=None, a_keys=False, a_wrap=0,
+         c_sigmoid=None):
     """Raw call into tgp_gemm_f32.  A/W/C/res* are tensors whose data_ptr is the first element of the
     operand (views into wider buffers are fine); all sizes/strides are explicit.  k_alg: the layer's
     true input width when K includes zero padding (only used for FLOP accounting in bench.py)."""
@@ -519,6 +520,7 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
         a.range_flag = _p(range_flag)
     if c_planes is not None and GEMM_MODE == "split16" and PLANES:
         a.C_planes, a.c_kt, a.cp_col0, a.c_amax = _p(c_planes.buf), c_planes.kt, int(cp_col0), _p(c_planes.amax)
+    a.a_keys, a.a_wrap, a.C_sigmoid = int(bool(a_keys)), int(a_wrap), _p(c_sigmoid)
     check(_lib.lib().tgp_gemm_f32(ctypes.byref(a), _stream(A)), "tgp_gemm_f32")
     if late_planes is not None:
         if C is None or batch != 1 or (cp_col0 & 15):
@@ -692,6 +694,38 @@ def head_post(green, red, ts, mean):
     pT, ps = torch.empty(B, 3, device=dev), torch.empty(B, 3, device=dev)
     check(_lib.lib().tgp_head_post(_p(green), _p(red), _p(ts), green.stride(0), red.stride(0), ts.stride(0), _p(mean), B, _p(pg),
                                    _p(pr), _p(fg), _p(fr), _p(pT), _p(ps), _stream(green)), "tgp_head_post")
+    return pg, pr, fg, fr, pT, ps
+
+
+def rows_out(x, w, bias=None, order=None):
+    """x (B,n,K), w (n_out <= 4, K), order (B,n) int64 or None -> out (B,n,n_out) with out[b, order[b,i]] = x[b,i] @ w^T + bias
+    (tgp_rows_out: a narrow last layer and the scatter that undoes a row sort, one launch)"""
+    x, ld = _rows(x, "x")
+    B, n, K = x.shape
+    if not w.is_contiguous() or w.shape[1] != K:
+        raise ValueError("rows_out: w (n_out, K) contiguous expected")
+    if order is not None and (order.dtype != torch.int64 or not order.is_contiguous() or tuple(order.shape) != (B, n)):
+        raise ValueError("rows_out: order (B,n) int64 contiguous expected")
+    out = torch.empty(B, n, w.shape[0], device=x.device, dtype=torch.float32)
+    check(_lib.lib().tgp_rows_out(_p(x), ld, B * n, K, _p(w), w.stride(0), _p(bias), w.shape[0], _p(order), n, _p(out), _stream(x)),
+          "tgp_rows_out")
+    return out
+
+
+def pose_tail(keys2, w3t, b3, scale3, shift3, w4, b4, mean, raw=None):
+    """keys2 (3,B,256) int32 max keys of the heads' conv2 -> the six pose outputs (tgp_pose_tail: conv3, conv4 and head_post as one
+    launch); raw (3,B,8): conv4's outputs"""
+    B, dev = keys2.shape[1], keys2.device
+    pg, pr = torch.empty(B, 3, device=dev), torch.empty(B, 3, device=dev)
+    fg, fr = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    pT, ps = torch.empty(B, 3, device=dev), torch.empty(B, 3, device=dev)
+    for t in (keys2, w3t, b3, scale3, shift3, w4, b4, mean):
+        if not t.is_contiguous():
+            raise ValueError("pose_tail: contiguous operands expected")
+    if tuple(w3t.shape) != (3, 256, 256) or tuple(w4.shape) != (3, 8, 256) or tuple(keys2.shape) != (3, B, 256):
+        raise ValueError("pose_tail: shapes")
+    check(_lib.lib().tgp_pose_tail(_p(keys2), _p(w3t), _p(b3), _p(scale3), _p(shift3), _p(w4), _p(b4), _p(mean), B, _p(pg), _p(pr),
+                                   _p(fg), _p(fr), _p(pT), _p(ps), _p(raw), _stream(keys2)), "tgp_pose_tail")
     return pg, pr, fg, fr, pT, ps
 
 
