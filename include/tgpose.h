@@ -66,10 +66,20 @@ int tgp_knn_feat(const float *feat, int ld, int B, int n, int d, int k, int32_t 
  * (v_mfma_f32_16x16x4_f32, the same ascending-k chain).  Identical index lists; a measurement / test handle. */
 int tgp_knn_feat_form(const float *feat, int ld, int B, int n, int d, int k, int32_t *idx, void *workspace, int64_t workspace_bytes,
                       int form, tgp_stream_t stream);
+/* (ABI 6) tgp_knn_feat that also leaves, beside each list, the unit directions from the point to its selected neighbours in the
+ * level's coordinates xyz (B, n, 3) (gcn3d.py:48-58 get_neighbor_direction_norm): dirs (B, n, k) float4 = (x, y, z, 0), 16-byte
+ * aligned -- what tgp_gconv_hs_fwd_dirs takes, so the graph convolution that walks the list needs no direction launch.  The fused
+ * kernel's shapes only (d = 128 / 256, n <= 1056): TGP_EUNSUPPORTED otherwise, nothing launched. */
+int tgp_knn_feat_dirs(const float *feat, int ld, int B, int n, int d, int k, int32_t *idx, void *workspace,
+                      int64_t workspace_bytes, const float *xyz, float *dirs, tgp_stream_t stream);
 
 /* gcn3d.py:26-35 get_nearest_index: for each of n target points the nearest of m source points
  * by fl(fl(|s|^2 + |t|^2) - 2<t,s>), lowest index on ties.  idx (B,n). */
 int tgp_nn1(const float *target, const float *source, int B, int n, int m, int32_t *idx, tgp_stream_t stream);
+/* (ABI 6) tgp_nn1 of the same targets against two clouds in one launch: the two nearest-coarse-point look-ups of the up-sampling
+ * (FaceRecon.py:71-77).  Same results as two tgp_nn1 calls. */
+int tgp_nn1_pair(const float *target, const float *source1, const float *source2, int B, int n, int m1, int m2, int32_t *idx1,
+                 int32_t *idx2, tgp_stream_t stream);
 
 /* ---- graph convolution --------------------------------------------------------------------- */
 
@@ -92,6 +102,10 @@ int tgp_gconv_surface_fwd(const float *xyz, const int32_t *idx, const float *sdn
  * with it, clouds whose support table fits LDS in channel slices take the LDS-staged kernel (same results). */
 int tgp_gconv_hs_fwd(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B,
                      int n, int k, int S, int C, float *out, int ldo, float *dirs_ws, tgp_stream_t stream);
+/* (ABI 6) tgp_gconv_hs_fwd with the unit neighbour directions supplied (tgp_knn_feat_dirs): the LDS-staged kernel alone.
+ * TGP_EUNSUPPORTED (nothing launched) where that kernel does not serve the shape: the caller uses tgp_gconv_hs_fwd. */
+int tgp_gconv_hs_fwd_dirs(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B,
+                          int n, int k, int S, int C, float *out, int ldo, const float *dirs, tgp_stream_t stream);
 
 /* gcn3d.py:210-217 get_ORL_global: g[b,c] = mean_i max_j feat[b, idx[b,i,j], c].
  * partial: scratch of tgp_orl_partial_floats(B,n,C) floats.  out (B,C). */

@@ -1,15 +1,13 @@
 """One eval forward's kernel launches, in order, from a rocprofv3 kernel trace of serial eager forwards
 (`rocprofv3 --kernel-trace --output-format csv -d DIR -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --graph 0 --streams 1
---no-branch-streams --min-seconds 0`): the last forward of the trace, from its center_mean_kernel to its head_post_kernel.
+--no-branch-streams --min-seconds 0`): the last-but-one forward of the trace, from its center_mean_kernel to the launch before the next forward's.
 usage: python scripts/forward_launches.py <kernel_trace.csv> [out.txt]"""
 import csv
 import sys
 
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("center_mean_kernel")]
-ends = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("head_post_kernel")]
-i1 = ends[-1]
-i0 = max(i for i in starts if i < i1)
+i0, i1 = starts[-2], starts[-1] - 1            # the last forward that is followed by another one: up to the next forward's first launch
 fwd = rows[i0:i1 + 1]
 t0 = int(fwd[0]["Start_Timestamp"])
 out = open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout

@@ -180,6 +180,31 @@ def test_nearest_index_bit_exact(ops, B, n, m):
     want = _clib.nn1(pts.numpy(), src.numpy())
     got = ops.nn1(g(pts), g(src)).cpu().numpy()
     assert np.array_equal(got, want)
+    # the two up-sampling look-ups as one launch (tgp_nn1_pair): the same lists
+    src2 = src[:, : max(1, m // 4)].contiguous()
+    p1, p2 = ops.nn1_pair(g(pts), g(src), g(src2))
+    assert np.array_equal(p1.cpu().numpy(), want) and np.array_equal(p2.cpu().numpy(), _clib.nn1(pts.numpy(), src2.numpy()))
+
+
+@pytest.mark.parametrize("B,n,d,k", [(32, 257, 128, 20), (5, 257, 256, 20), (32, 64, 256, 8), (3, 100, 128, 12)])
+def test_knn_feat_leaves_the_neighbour_directions(ops, B, n, d, k):
+    """tgp_knn_feat_dirs: the selecting waves also write the unit directions to the row's neighbours (gcn3d.py:48-58), and
+    tgp_gconv_hs_fwd_dirs walks them without a direction launch: the same lists, and a graph convolution bit-identical to the one
+    that computes its directions itself."""
+    gen = torch.Generator().manual_seed(n * d + k)
+    feat = g(torch.randn(B, n, d, generator=gen))
+    xyz = g(torch.randn(B, n, 3, generator=gen))
+    C = 256 if n > 64 else 512
+    proj = g(torch.randn(B, n, 9 * C, generator=gen))
+    sdn = g(torch.nn.functional.normalize(torch.randn(3, 7 * C, generator=gen), dim=0))
+    idx0 = ops.knn_feat(feat, k)
+    idx1, dirs = ops.knn_feat(feat, k, xyz=xyz)
+    assert torch.equal(idx0, idx1) and dirs is not None
+    nb = xyz[torch.arange(B, device=DEV).view(B, 1, 1), idx0.long()] - xyz.unsqueeze(2)                 # (B,n,k,3)
+    assert float((dirs[..., :3] - nb / nb.norm(dim=-1, keepdim=True).clamp_min(1e-12)).abs().max()) <= 1e-6 and float(dirs[..., 3].abs().max()) == 0.0
+    want = ops.gconv_hs(xyz, idx0, proj, sdn, 7, C)
+    got = ops.gconv_hs(xyz, idx1, proj, sdn, 7, C, dirs=dirs)
+    assert torch.equal(want, got)
 
 
 def test_nearest_index_vs_reference_golden(ops):

@@ -95,11 +95,14 @@ SIGNATURES = {
     "tgp_knn_feat_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
     "tgp_knn_feat": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp]),
     "tgp_knn_feat_form": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_int, c_vp]),
+    "tgp_knn_feat_dirs": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "tgp_nn1": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    "tgp_nn1_pair": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_normalize_dirs": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "tgp_normalize_dirs_bwd": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp]),
     "tgp_gconv_surface_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),
     "tgp_gconv_hs_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
+    "tgp_gconv_hs_fwd_dirs": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "tgp_orl_partial_floats": (c_i64, [c_int, c_int, c_int]),
     "tgp_orl_global": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_orl_rowbias": (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -199,7 +202,7 @@ SIGNATURES = {
     "tgp_cloud_sample": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, ctypes.c_uint64, c_vp, c_vp]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 

@@ -299,7 +299,7 @@ static constexpr int tgp_gconv_lds_mode = 1;
 #endif
 
 static int gconv_lds_launch(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B, int n, int k,
-                            int C, float *out, int ldo, float *dirs_ws, hipStream_t stream, bool &done)
+                            int C, float *out, int ldo, float *dirs_ws, hipStream_t stream, bool &done, bool have_dirs = false)
 {
     done = false;
     if (!tgp_gconv_lds_mode || !dirs_ws) return 0;          // without the directions' scratch: the L2-gather kernel
@@ -318,7 +318,7 @@ static int gconv_lds_launch(const float *xyz, const int32_t *idx, const float *p
     done = true;
     float4 *dirs = reinterpret_cast<float4 *>(dirs_ws);
     const int64_t nd = (int64_t)B * n * k;
-    hipLaunchKernelGGL(nbr_dirs_kernel, dim3(tgp_cdiv(nd, 256)), dim3(256), 0, stream, xyz, idx, B, n, k, dirs);
+    if (!have_dirs) hipLaunchKernelGGL(nbr_dirs_kernel, dim3(tgp_cdiv(nd, 256)), dim3(256), 0, stream, xyz, idx, B, n, k, dirs);
     if (ch == 16) return gconv_lds_go<16>(dirs, idx, proj, ldp, sdn, B, n, k, C, out, ldo, bytes(16), stream);
     if (ch == 8) return gconv_lds_go<8>(dirs, idx, proj, ldp, sdn, B, n, k, C, out, ldo, bytes(8), stream);
     return gconv_lds_go<4>(dirs, idx, proj, ldp, sdn, B, n, k, C, out, ldo, bytes(4), stream);
@@ -373,6 +373,21 @@ extern "C" int tgp_gconv_hs_fwd(const float *xyz, const int32_t *idx, const floa
     const int rc = gconv_lds_launch(xyz, idx, proj, ldp, sdn, B, n, k, C, out, ldo, dirs_ws, tgp_hs(stream), done);
     if (done || rc) return rc;
     return gconv_launch<false>(xyz, idx, proj, ldp, sdn, B, n, k, C, out, ldo, tgp_hs(stream));
+}
+
+// tgp_gconv_hs_fwd with the unit neighbour directions already in `dirs` (B, n, k) float4 -- tgp_knn_feat_dirs wrote them beside
+// the list -- : the LDS-staged kernel alone.  TGP_EUNSUPPORTED (nothing launched) where that kernel does not serve the shape.
+extern "C" int tgp_gconv_hs_fwd_dirs(const float *xyz, const int32_t *idx, const float *proj, int ldp, const float *sdn, int B,
+                                     int n, int k, int S, int C, float *out, int ldo, const float *dirs, tgp_stream_t stream)
+{
+    const int chk = gconv_check(xyz, idx, sdn, out, B, n, k, S, C, ldo);
+    if (chk) return chk;
+    TGP_REQUIRE(proj && ldp >= (S + 1) * C && (ldp & 3) == 0 && (reinterpret_cast<uintptr_t>(proj) & 15) == 0);
+    TGP_REQUIRE(dirs && (reinterpret_cast<uintptr_t>(dirs) & 15) == 0);
+    bool done = false;
+    const int rc = gconv_lds_launch(xyz, idx, proj, ldp, sdn, B, n, k, C, out, ldo, const_cast<float *>(dirs), tgp_hs(stream), done, true);
+    if (rc) return rc;
+    return done ? 0 : TGP_EUNSUPPORTED;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -542,7 +557,7 @@ __global__ __launch_bounds__(1024) void orl_lds_kernel(const float *__restrict__
     // ---- fused finish (round 4; tgp_orl_rowbias_fused): this workgroup holds every point tile of its 16 channels, so their mean
     // over points g (orl_finish_kernel's sum, term by term) needs no other workgroup; its share of the projection
     // rb[b, :] = g[b, :] @ W2^T is the 16-row slice  contrib[b, chunk, o] = sum_c g[c0 + c] w2t[c0 + c, o]  (one fmaf chain), and
-    // the LAST of the object's C / 16 workgroups to arrive (a ticket per object; release / acquire fences around it) adds the
+    // the LAST of the object's C / 16 workgroups to arrive (a ticket per object, taken after the slice's stores are acknowledged) adds the
     // slices in chunk order -- a fixed order whichever workgroup that is -- and hands the ticket back as 0.
     float *s_g = s_tab;                              // the table is no longer read
     int *s_last = reinterpret_cast<int *>(s_tab + ORL_CH);
@@ -563,18 +578,25 @@ __global__ __launch_bounds__(1024) void orl_lds_kernel(const float *__restrict__
         const float *w = w2t + (int64_t)c0 * C + o;
 #pragma unroll
         for (int c = 0; c < ORL_CH; ++c) acc = fmaf(s_g[c], w[(int64_t)c * C], acc);
-        contrib[((int64_t)b * nch + chunk) * C + o] = acc;
+        // (agent-scope atomic store and load: they travel to the point where every XCD sees them, sc1, and stay out of the
+        // fences.  A __threadfence() here is a write-back of the XCD's whole L2 per wave -- with the planes this kernel has just
+        // written sitting in it the launch took 60-100 us instead of 13-29.)
+        __hip_atomic_store(contrib + ((int64_t)b * nch + chunk) * C + o, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __threadfence();
-    __syncthreads();
+    __syncthreads();                                 // every wave has waited for its stores' acknowledgements (vmcnt) before the barrier
     if (tid == 0) *s_last = atomicAdd(tickets + b, 1) == nch - 1;
     __syncthreads();
     if (!*s_last) return;
-    __threadfence();
     for (int o = tid; o < C; o += nthr) {
         float sum = 0.f;
-        for (int ch = 0; ch < nch; ++ch)
-            sum += __hip_atomic_load(contrib + ((int64_t)b * nch + ch) * C + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int ch0 = 0; ch0 < nch; ch0 += 8) {          // nch = 8, 16 or 32; eight loads in flight, added in chunk order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = __hip_atomic_load(contrib + ((int64_t)b * nch + ch0 + u) * C + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u];
+        }
         rb[(int64_t)b * C + o] = sum;
     }
     if (tid == 0) tickets[b] = 0;

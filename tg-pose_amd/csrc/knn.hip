@@ -673,9 +673,27 @@ typedef float knn_f32x4 __attribute__((ext_vector_type(4)));
 // (Measured and dropped: a start skew -- the workgroups of the launch's second half-round, i.e. the second slot of every CU, pausing for
 // about one selection phase once, so that the two workgroups of a CU would not run their phases in step: 18.92 k against 18.97 k
 // objects/s without it, two runs each on one box; the workgroups drift apart by themselves within a round.)
+// (round 4) The unit directions to a row's neighbours (gcn3d.py:48-58 get_neighbor_direction_norm), for the LDS-staged graph
+// convolution that walks this list next (gconv.hip, nbr_dirs_kernel: the same arithmetic) -- written by the wave that has just
+// selected the row, instead of by a launch of its own.  The wave reads its own list back: its stores are acknowledged (vmcnt 0)
+// and the loads go past the L1 (sc1).
+__device__ __forceinline__ void knn_emit_dirs(const float *__restrict__ xyz, float4 *__restrict__ dirs, const int32_t *out,
+                                              const int64_t rowi, const int b, const int n, const int k, const int lane)
+{
+    __builtin_amdgcn_s_waitcnt(0x0f70);                               // vmcnt(0)
+    if (lane >= k) return;
+    const int nb = __hip_atomic_load(out + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float *pc = xyz + rowi * 3;
+    const float *pn = xyz + ((int64_t)b * n + nb) * 3;
+    const float dx = pn[0] - pc[0], dy = pn[1] - pc[1], dz = pn[2] - pc[2];
+    const float nrm = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-12f);
+    dirs[rowi * k + lane] = make_float4(dx / nrm, dy / nrm, dz / nrm, 0.f);
+}
+
 template <int DIM, int NT, int CH>
 __global__ __launch_bounds__(256, 2) void knn_feat_fused16_kernel(const float *__restrict__ xt, const float *__restrict__ q, int B, int n, int k,
-                                                                  int32_t *__restrict__ idx, int nrb, int ldw, int n_extra)
+                                                                  int32_t *__restrict__ idx, int nrb, int ldw, int n_extra,
+                                                                  const float *__restrict__ xyz, float4 *__restrict__ dirs)
 {
     extern __shared__ __attribute__((aligned(16))) float dblk16[];    // [16 (+ 1 with a tail row)][ldw]
     __shared__ uint32_t s_lmin[4][64];
@@ -798,6 +816,7 @@ __global__ __launch_bounds__(256, 2) void knn_feat_fused16_kernel(const float *_
         int32_t *out = idx + ((size_t)b * n + i) * k;
         if (!wave_select_ranked<NT>(key, lane, k, out, s_lmin[wave], s_list[wave]))
             wave_select_serial_keys<NT>(key, lane, k, out);
+        if (dirs) knn_emit_dirs(xyz, dirs, out, (int64_t)b * n + i, b, n, k, lane);      // workgroup-uniform
     }
 }
 
@@ -880,7 +899,8 @@ extern "C" int64_t tgp_knn_feat_workspace_bytes(int B, int n, int d)
 
 // form: 0 = the library's choice, 1 = 32-row blocks (one workgroup per CU), 2 = 16-row blocks (two per CU)
 template <int DIM, int NT, int CH>
-static int launch_knn_fused(const float *xt, const float *q, int B, int n, int k, int32_t *idx, hipStream_t stream, int form)
+static int launch_knn_fused(const float *xt, const float *q, int B, int n, int k, int32_t *idx, hipStream_t stream, int form,
+                            const float *xyz = nullptr, float4 *dirs = nullptr)
 {
     const int ncb = tgp_cdiv(n, 32), ldw = ncb * 32;
     if (form != 1) {
@@ -896,9 +916,10 @@ static int launch_knn_fused(const float *xt, const float *q, int B, int n, int k
         }
         // (four steps per prefetched chunk, three chunks ahead; eight measured the same: 18.68 vs 18.67 k objects/s)
         hipLaunchKernelGGL((knn_feat_fused16_kernel<DIM, NT, CH / 2>), dim3(tgp_xcd_grid(B, nrb16)), dim3(256), lds16, stream, xt, q, B, n, k,
-                           idx, nrb16, ldw, n_extra16);
+                           idx, nrb16, ldw, n_extra16, xyz, dirs);
         return TGP_LAUNCH_RESULT();
     }
+    if (dirs) return TGP_EUNSUPPORTED;
     // a tail of at most 8 rows (and fewer than there are full blocks) rides along with the first blocks instead of forming its own
     const int tail = n % KF_ROWS, n_extra = (tail > 0 && tail <= 8 && tail <= n / KF_ROWS) ? tail : 0;
     const int nrb = n_extra ? n / KF_ROWS : tgp_cdiv(n, KF_ROWS);
@@ -923,8 +944,28 @@ extern "C" int tgp_knn_feat(const float *feat, int ld, int B, int n, int d, int 
     return tgp_knn_feat_form(feat, ld, B, n, d, k, idx, workspace, workspace_bytes, 0, stream);
 }
 
+static int knn_feat_go(const float *feat, int ld, int B, int n, int d, int k, int32_t *idx, void *workspace, int64_t workspace_bytes,
+                       int form, const float *xyz, float4 *dirs, tgp_stream_t stream);
+
 extern "C" int tgp_knn_feat_form(const float *feat, int ld, int B, int n, int d, int k, int32_t *idx, void *workspace,
                                  int64_t workspace_bytes, int form, tgp_stream_t stream)
+{
+    return knn_feat_go(feat, ld, B, n, d, k, idx, workspace, workspace_bytes, form, nullptr, nullptr, stream);
+}
+
+// tgp_knn_feat that also leaves the unit directions to the selected neighbours in the points' xyz (B, n, 3): dirs (B, n, k) float4
+// (x, y, z, 0), what tgp_gconv_hs_fwd_dirs takes.  Only the shapes the fused 16-row kernel serves: TGP_EUNSUPPORTED otherwise
+// (nothing launched).
+extern "C" int tgp_knn_feat_dirs(const float *feat, int ld, int B, int n, int d, int k, int32_t *idx, void *workspace,
+                                 int64_t workspace_bytes, const float *xyz, float *dirs, tgp_stream_t stream)
+{
+    TGP_REQUIRE(xyz && dirs && (reinterpret_cast<uintptr_t>(dirs) & 15) == 0);
+    if (!knn_feat_fused_ok(n, d)) return TGP_EUNSUPPORTED;
+    return knn_feat_go(feat, ld, B, n, d, k, idx, workspace, workspace_bytes, 0, xyz, reinterpret_cast<float4 *>(dirs), stream);
+}
+
+static int knn_feat_go(const float *feat, int ld, int B, int n, int d, int k, int32_t *idx, void *workspace, int64_t workspace_bytes,
+                       int form, const float *xyz, float4 *dirs, tgp_stream_t stream)
 {
     TGP_REQUIRE(feat && idx && workspace && form >= 0 && form <= 2);
     const int chk = knn_check(B, n, k);
@@ -941,7 +982,8 @@ extern "C" int tgp_knn_feat_form(const float *feat, int ld, int B, int n, int d,
     if (fused) {
         hipLaunchKernelGGL(knn_prep_kernel, dim3(ldt / 32, B), dim3(256), 0, tgp_hs(stream), feat, ld, n, d, D, ldt, q);
 #define LAUNCH_FUSED(NT) \
-    (d == 128 ? launch_knn_fused<128, NT, 8>(D, q, B, n, k, idx, tgp_hs(stream), form) : launch_knn_fused<256, NT, 8>(D, q, B, n, k, idx, tgp_hs(stream), form))
+    (d == 128 ? launch_knn_fused<128, NT, 8>(D, q, B, n, k, idx, tgp_hs(stream), form, xyz, dirs)                     \
+              : launch_knn_fused<256, NT, 8>(D, q, B, n, k, idx, tgp_hs(stream), form, xyz, dirs))
         if (nt <= 1) return LAUNCH_FUSED(1);
         if (nt <= 2) return LAUNCH_FUSED(2);
         if (nt <= 5) return LAUNCH_FUSED(5);
@@ -971,29 +1013,17 @@ extern "C" int tgp_knn_feat_form(const float *feat, int ld, int B, int n, int d,
 // ------------------------------------------------------------------------------------------------
 // get_nearest_index: one thread per target point, source cloud staged through LDS in chunks.
 #define NN1_CHUNK 1024
-__global__ __launch_bounds__(256) void nn1_kernel(const float *__restrict__ tgt, const float *__restrict__ src, int B,
-                                                  int n, int m, int32_t *__restrict__ idx, int tiles_per_obj)
+// one source cloud against the workgroup's 256 targets: returns the lane's nearest source point (first index on ties)
+__device__ __forceinline__ int nn1_scan(const float *__restrict__ src, const int m, const float tx, const float ty, const float tz,
+                                        const float qt, float4 *s)
 {
-    __shared__ float4 s[NN1_CHUNK];
-    int b, tile;
-    if (!tgp_xcd_object_tile(blockIdx.x, B, tiles_per_obj, b, tile)) return;
-    const int i = tile * 256 + threadIdx.x;
-    const bool live = i < n;
-    float tx = 0.f, ty = 0.f, tz = 0.f, qt = 0.f;
-    if (live) {
-        const float *t = tgt + ((size_t)b * n + i) * 3;
-        tx = t[0], ty = t[1], tz = t[2];
-        qt = tx * tx;
-        qt = qt + ty * ty;
-        qt = qt + tz * tz;
-    }
     float best = 0.f;
     int besti = 0;
     for (int j0 = 0; j0 < m; j0 += NN1_CHUNK) {
         const int cnt = min(NN1_CHUNK, m - j0);
         __syncthreads();
         for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
-            const float *p = src + ((size_t)b * m + j0 + j) * 3;
+            const float *p = src + (size_t)(j0 + j) * 3;
             const float x = p[0], y = p[1], z = p[2];
             float q = x * x;
             q = q + y * y;
@@ -1014,7 +1044,33 @@ __global__ __launch_bounds__(256) void nn1_kernel(const float *__restrict__ tgt,
             }
         }
     }
-    if (live) idx[(size_t)b * n + i] = besti;
+    return besti;
+}
+
+// src2 != NULL (round 4, tgp_nn1_pair): the same targets against a second cloud in the same launch (the two up-sampling look-ups
+// of Face_Enc.forward, FaceRecon.py:71-77)
+__global__ __launch_bounds__(256) void nn1_kernel(const float *__restrict__ tgt, const float *__restrict__ src, int B,
+                                                  int n, int m, int32_t *__restrict__ idx, int tiles_per_obj,
+                                                  const float *__restrict__ src2, int m2, int32_t *__restrict__ idx2)
+{
+    __shared__ float4 s[NN1_CHUNK];
+    int b, tile;
+    if (!tgp_xcd_object_tile(blockIdx.x, B, tiles_per_obj, b, tile)) return;
+    const int i = tile * 256 + threadIdx.x;
+    const bool live = i < n;
+    float tx = 0.f, ty = 0.f, tz = 0.f, qt = 0.f;
+    if (live) {
+        const float *t = tgt + ((size_t)b * n + i) * 3;
+        tx = t[0], ty = t[1], tz = t[2];
+        qt = tx * tx;
+        qt = qt + ty * ty;
+        qt = qt + tz * tz;
+    }
+    const int b1 = nn1_scan(src + (size_t)b * m * 3, m, tx, ty, tz, qt, s);
+    if (live) idx[(size_t)b * n + i] = b1;
+    if (!src2) return;
+    const int b2 = nn1_scan(src2 + (size_t)b * m2 * 3, m2, tx, ty, tz, qt, s);
+    if (live) idx2[(size_t)b * n + i] = b2;
 }
 
 extern "C" int tgp_nn1(const float *target, const float *source, int B, int n, int m, int32_t *idx, tgp_stream_t stream)
@@ -1022,6 +1078,16 @@ extern "C" int tgp_nn1(const float *target, const float *source, int B, int n, i
     TGP_REQUIRE(target && source && idx && B > 0 && n > 0 && m > 0);
     const int tiles = tgp_cdiv(n, 256);
     hipLaunchKernelGGL(nn1_kernel, dim3(tgp_xcd_grid(B, tiles)), dim3(256), 0, tgp_hs(stream), target, source, B, n, m,
-                       idx, tiles);
+                       idx, tiles, nullptr, 0, nullptr);
+    return TGP_LAUNCH_RESULT();
+}
+
+extern "C" int tgp_nn1_pair(const float *target, const float *source1, const float *source2, int B, int n, int m1, int m2,
+                            int32_t *idx1, int32_t *idx2, tgp_stream_t stream)
+{
+    TGP_REQUIRE(target && source1 && source2 && idx1 && idx2 && B > 0 && n > 0 && m1 > 0 && m2 > 0);
+    const int tiles = tgp_cdiv(n, 256);
+    hipLaunchKernelGGL(nn1_kernel, dim3(tgp_xcd_grid(B, tiles)), dim3(256), 0, tgp_hs(stream), target, source1, B, n, m1,
+                       idx1, tiles, source2, m2, idx2);
     return TGP_LAUNCH_RESULT();
 }

@@ -357,19 +357,23 @@ def hs_layer(c, xyz, fmap, idx_rf, idx_orl, out, scale=None, shift=None, act=Non
     B, n, _ = xyz.shape
     C = c["C"]
     join = None
+    dirs = None
     if callable(idx_rf) or callable(idx_orl):
+        def lists():
+            # (idx_rf() may return (idx, dirs): ops.knn_feat(xyz=...) -- flat, so that _beside sees every tensor)
+            rf = idx_rf() if callable(idx_rf) else idx_rf
+            rf, dr = rf if isinstance(rf, tuple) else (rf, None)
+            return rf, dr, (idx_orl() if callable(idx_orl) else idx_orl)
         if BRANCH_STREAMS:
-            (idx_rf, idx_orl), join = _beside(xyz.device, lambda: (idx_rf() if callable(idx_rf) else idx_rf,
-                                                                   idx_orl() if callable(idx_orl) else idx_orl))
+            (idx_rf, dirs, idx_orl), join = _beside(xyz.device, lists)
         else:
-            idx_rf = idx_rf() if callable(idx_rf) else idx_rf
-            idx_orl = idx_orl() if callable(idx_orl) else idx_orl
+            idx_rf, dirs, idx_orl = lists()
     # (B,n,9C): centre|support|STE.  fmap_p: the input's fp16 planes, written by its producer -- the GEMM then runs on the
     # pre-split kernel (csrc/gemm_pp.hip), bit-identical results
     proj9 = ops.linear_rows(fmap, c["wcat"], bias=c["bcat"], w_split=c.get("wcat_s"), a_planes=fmap_p, w_planes=c.get("wcat_p"))
     if join is not None:
         torch.cuda.current_stream(xyz.device).wait_event(join)
-    g = ops.gconv_hs(xyz, idx_rf, proj9, c["sdn"], 7, C)
+    g = ops.gconv_hs(xyz, idx_rf, proj9, c["sdn"], 7, C, dirs=dirs)
     gp = None
     if tickets is None and ops.ORL_FUSED and "w2t" in c:
         tickets = torch.zeros(B, device=xyz.device, dtype=torch.int32)
@@ -419,11 +423,18 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, 
     k1 = min(kmax, N1 // 8)
     fm23 = torch.empty(B, N1, 512, device=dev, dtype=torch.float32)      # fm_2 | fm_3 side by side: one GEMM operand when factored
     fm2, fm3 = fm23[:, :, :256], fm23[:, :, 256:]
-    hs_layer(cv[2], v1, fp1, lambda: graphs.get("conv_2.rf", lambda: ops.knn_feat(fp1, k1)),
+    def feat_graph(name, fmap, k, pts):
+        """the layer's feature-space list; at the pooled levels (LDS-staged graph convolution) with the unit directions to the
+        selected neighbours, written by the selecting kernel -- unless the lists are injected / recorded (tests)"""
+        if graphs.inject or graphs.record is not None or not KNN_DIRS:
+            return graphs.get(name, lambda: ops.knn_feat(fmap, k))
+        return ops.knn_feat(fmap, k, xyz=pts)
+
+    hs_layer(cv[2], v1, fp1, lambda: feat_graph("conv_2.rf", fp1, k1, v1),
              lambda: graphs.get("conv_2.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm2, cv[2]["scale"], cv[2]["shift"], "relu",
              fmap_p=pl.get("fp1"), out_p=pl.get("fm23"), out_col0=0, amax_ws=pl.get("amax_g2"), tickets=pl.get("tick2"))
     # (conv_3 reads the first 256 columns of the fm_2 | fm_3 planes, whose per-block magnitudes cover fm_2 alone at this point)
-    hs_layer(cv[3], v1, fm2, lambda: graphs.get("conv_3.rf", lambda: ops.knn_feat(fm2, k1)),
+    hs_layer(cv[3], v1, fm2, lambda: feat_graph("conv_3.rf", fm2, k1, v1),
              graphs.get("conv_3.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm3, cv[3]["scale"], cv[3]["shift"], "relu",
              fmap_p=pl.get("fm23"), out_p=pl.get("fm23"), out_col0=256, amax_ws=pl.get("amax_g3"), tickets=pl.get("tick3"))
     v2, fp2 = ops.pool(v1, fm3, graphs.get("pool_2.xyz", lambda: xyz_graph(1, v1, k1)), s2, kpool=4, planes=pl.get("fp2"))
@@ -447,11 +458,14 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, 
 
     k2 = min(kmax, N2 // 8)
     fm4 = torch.empty(B, N2, 512, device=dev, dtype=torch.float32)
-    hs_layer(cv[4], v2, fp2, lambda: graphs.get("conv_4.rf", lambda: ops.knn_feat(fp2, k2)),
+    hs_layer(cv[4], v2, fp2, lambda: feat_graph("conv_4.rf", fp2, k2, v2),
              lambda: graphs.get("conv_4.orl_xyz", lambda: xyz_graph(2, v2, k2)), fm4, fmap_p=pl.get("fp2"), out_p=pl.get("fm4"), amax_ws=pl.get("amax_g4"), tickets=pl.get("tick4"))
 
-    near1 = graphs.get("up_1", lambda: ops.nn1(xyz, v1)).view(B, N)
-    near2 = graphs.get("up_2", lambda: ops.nn1(xyz, v2)).view(B, N)
+    if graphs.inject or graphs.record is not None:
+        near1 = graphs.get("up_1", lambda: ops.nn1(xyz, v1)).view(B, N)
+        near2 = graphs.get("up_2", lambda: ops.nn1(xyz, v2)).view(B, N)
+    else:
+        near1, near2 = ops.nn1_pair(xyz, v1, v2)          # both look-ups in one launch (same results)
     inter = dict(fm_2=fm2, fm_3=fm3, fm_4=fm4, v_pool_1=v1, v_pool_2=v2)
     if factored:
         ops.fill_tail(obj_id.reshape(-1).float(), xyz, feat, 256, n_cls)
@@ -749,6 +763,7 @@ def decoder_forward_factored(pk, fine, inter, P1, P2, back, N, arena=None):
     return torch.empty_like(recon).scatter_(1, inter["order"].unsqueeze(-1).expand(-1, -1, 3), recon)
 
 
+KNN_DIRS = os.environ.get("TGP_KNN_DIRS", "1") != "0"        # feature kNN leaves the unit neighbour directions beside its lists
 PH_TAIL_FUSED = os.environ.get("TGP_PH_TAIL_FUSED", "1") != "0"   # PH predictor's vector layers: key decode and sigmoid inside them
 ROWS_OUT = os.environ.get("TGP_ROWS_OUT", "1") != "0"        # the decoder's last conv and the un-sort of its rows as one launch
 POSE_TAIL = os.environ.get("TGP_POSE_TAIL", "1") != "0"      # conv3, conv4 and the output formulas of the heads as one launch
@@ -1002,8 +1017,11 @@ def encoder_forward_train(pk, bn, points_c, obj_id, sample_idx, graphs, kmax=20,
     fm4 = torch.empty(B, N2, 512, device=dev, dtype=torch.float32)
     hs_layer(cv[4], v2, fp2, graphs.get("conv_4.rf", lambda: ops.knn_feat(fp2, k2)),
              graphs.get("conv_4.orl_xyz", lambda: xyz_graph(2, v2, k2)), fm4)
-    near1 = graphs.get("up_1", lambda: ops.nn1(xyz, v1)).view(B, N)
-    near2 = graphs.get("up_2", lambda: ops.nn1(xyz, v2)).view(B, N)
+    if graphs.inject or graphs.record is not None:
+        near1 = graphs.get("up_1", lambda: ops.nn1(xyz, v1)).view(B, N)
+        near2 = graphs.get("up_2", lambda: ops.nn1(xyz, v2)).view(B, N)
+    else:
+        near1, near2 = ops.nn1_pair(xyz, v1, v2)          # both look-ups in one launch (same results)
     ops.gather_rows(fm2, near1, feat[:, :, 256:512])
     ops.gather_rows(fm3, near1, feat[:, :, 512:768])
     ops.gather_rows(fm4, near2, feat[:, :, 768:1280])

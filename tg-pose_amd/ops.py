@@ -107,18 +107,30 @@ KNN_FEAT_FORM = int(os.environ.get("TGP_KNN_FEAT_FORM", "0"))     # 0: the libra
 
 
 @_timed("graph")
-def knn_feat(feat, k, workspace=None, form=None):
-    """feat (B,n,d) rows contiguous (row stride may exceed d) -> idx (B,n,k) int32"""
+def knn_feat(feat, k, workspace=None, form=None, xyz=None):
+    """feat (B,n,d) rows contiguous (row stride may exceed d) -> idx (B,n,k) int32.
+    xyz (B,n,3): returns (idx, dirs) -- dirs (B,n,k,4) the unit directions to the selected neighbours (tgp_knn_feat_dirs: written by
+    the selecting waves; gconv_hs(dirs=...) takes them) or None where the fused kernel does not serve the shape."""
     feat, ld = _rows(feat, "feat")
     B, n, d = feat.shape
     need = _lib.lib().tgp_knn_feat_workspace_bytes(B, n, d)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty((need + 3) // 4, device=feat.device, dtype=torch.float32)
     idx = torch.empty(B, n, k, device=feat.device, dtype=torch.int32)
+    if xyz is not None:
+        _f32(xyz, "xyz", 3)
+        dirs = torch.empty(B, n, k, 4, device=feat.device, dtype=torch.float32)
+        rc = _lib.lib().tgp_knn_feat_dirs(_p(feat), ld, B, n, d, int(k), _p(idx), _p(workspace), workspace.numel() * workspace.element_size(),
+                                          _p(xyz.contiguous()), _p(dirs), _stream(feat))
+        if rc == 0:
+            return idx, dirs
+        if rc != -2:
+            check(rc, "tgp_knn_feat_dirs")
+        dirs = None
     check(_lib.lib().tgp_knn_feat_form(_p(feat), ld, B, n, d, int(k), _p(idx), _p(workspace),
                                        workspace.numel() * workspace.element_size(), KNN_FEAT_FORM if form is None else int(form),
                                        _stream(feat)), "tgp_knn_feat")
-    return idx
+    return idx if xyz is None else (idx, None)
 
 
 @_timed("graph")
@@ -131,6 +143,19 @@ def nn1(target, source):
     idx = torch.empty(B, n, device=target.device, dtype=torch.int32)
     check(_lib.lib().tgp_nn1(_p(target), _p(source), B, n, m, _p(idx), _stream(target)), "tgp_nn1")
     return idx
+
+
+def nn1_pair(target, source1, source2):
+    """nn1(target, source1), nn1(target, source2) in one launch"""
+    for t, nm in ((target, "target"), (source1, "source1"), (source2, "source2")):
+        _f32(t, nm, 3)
+    target, source1, source2 = target.contiguous(), source1.contiguous(), source2.contiguous()
+    B, n, _ = target.shape
+    i1 = torch.empty(B, n, device=target.device, dtype=torch.int32)
+    i2 = torch.empty(B, n, device=target.device, dtype=torch.int32)
+    check(_lib.lib().tgp_nn1_pair(_p(target), _p(source1), _p(source2), B, n, source1.shape[1], source2.shape[1], _p(i1), _p(i2),
+                                  _stream(target)), "tgp_nn1_pair")
+    return i1, i2
 
 
 def normalize_dirs(directions):
@@ -165,13 +190,22 @@ def gconv_surface(xyz, idx, sdn, S, C, out=None, xyz_pad=False):
 
 
 @_timed("graph")
-def gconv_hs(xyz, idx, proj, sdn, S, C, out=None):
+def gconv_hs(xyz, idx, proj, sdn, S, C, out=None, dirs=None):
+    """dirs (B,n,k,4): the unit neighbour directions knn_feat(xyz=...) left beside idx (no direction launch)"""
     _f32(xyz, "xyz", 3), _i32(idx, "idx")
     proj, ldp = _rows(proj, "proj")
     B, n, k = idx.shape
     if out is None:
         out = torch.empty(B, n, C, device=xyz.device, dtype=torch.float32)
     out, ldo = _rows(out, "out")
+    if dirs is not None:
+        if tuple(dirs.shape) != (B, n, k, 4) or not dirs.is_contiguous():
+            raise ValueError("gconv_hs: dirs (B,n,k,4) contiguous expected")
+        rc = _lib.lib().tgp_gconv_hs_fwd_dirs(_p(xyz), _p(idx), _p(proj), ldp, _p(sdn), B, n, k, S, C, _p(out), ldo, _p(dirs), _stream(xyz))
+        if rc == 0:
+            return out
+        if rc != -2:
+            check(rc, "tgp_gconv_hs_fwd_dirs")
     # scratch for the unit neighbour directions: only the LDS-staged kernel (pooled levels) uses it
     dirs = torch.empty(B * n * k * 4, device=xyz.device, dtype=torch.float32) if n * 7 * 8 * 4 <= 72 * 1024 else None
     check(_lib.lib().tgp_gconv_hs_fwd(_p(xyz), _p(idx), _p(proj), ldp, _p(sdn), B, n, k, S, C, _p(out), ldo,
