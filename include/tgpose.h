@@ -47,6 +47,9 @@ int tgp_knn_max_k(void);
  * points (B,n,3) -> xyz_c (B,n,3), mean (B,3).  The column sums follow ATen's cascade order so
  * that the centred cloud is bit-identical to the CPU path (the kNN order depends on it). */
 int tgp_center(const float *points, int B, int n, float *xyz_c, float *mean, tgp_stream_t stream);
+/* (ABI 6) tgp_center that also clears zero_words 32-bit words at `zero` (the forward's zero-initialised scratch: max keys, range
+ * flags, magnitude words, tickets) in the same launch; every later launch of the forward is ordered behind it. */
+int tgp_center_zero(const float *points, int B, int n, float *xyz_c, float *mean, void *zero, int64_t zero_words, tgp_stream_t stream);
 
 /* ---- graph construction ------------------------------------------------------------------- */
 
@@ -80,6 +83,10 @@ int tgp_nn1(const float *target, const float *source, int B, int n, int m, int32
  * (FaceRecon.py:71-77).  Same results as two tgp_nn1 calls. */
 int tgp_nn1_pair(const float *target, const float *source1, const float *source2, int B, int n, int m1, int m2, int32_t *idx1,
                  int32_t *idx2, tgp_stream_t stream);
+/* (ABI 6) tgp_nn1_pair whose launch also writes tgp_fill_tail's columns for the targets (target = the centred cloud xyz_c):
+ * feat[b, i, col0 ...] = one-hot(obj_id[b]) | target[b, i] | 0 ... up to ld.  feat NULL = tgp_nn1_pair. */
+int tgp_nn1_pair_tail(const float *target, const float *source1, const float *source2, int B, int n, int m1, int m2, int32_t *idx1,
+                      int32_t *idx2, const float *obj_id, int n_cls, float *feat, int ld, int col0, tgp_stream_t stream);
 
 /* ---- graph convolution --------------------------------------------------------------------- */
 

@@ -3656,13 +3656,17 @@ def test_ph_tail_on_keys_with_sigmoid_epilogue_vs_five_launches(ops):
         old = engine.PH_TAIL_FUSED
         engine.PH_TAIL_FUSED = fused
         try:
-            h1, h2, back = engine.ph_tail(pk.ph, keys, B, DEV)
+            h1, h2, back, _ = engine.ph_tail(pk.ph, keys, B, DEV)
         finally:
             engine.PH_TAIL_FUSED = old
         res.append((h1.clone(), h2.clone(), back.clone()))
     for a, b, name in zip(res[0], res[1], ("h1", "h2", "back")):
         assert torch.equal(a, b), name
     assert float(res[0][0].min()) >= 0.0 and float(res[0][0].max()) <= 1.0 and float(res[0][2].abs().max()) > 0
+    # the decoder's per-object bias W0 back straight from [pi1 | pi2] through the composed weight (Packed.rb_w) against W0 (back)
+    _, _, none, rb = engine.ph_tail(pk.ph, keys, B, DEV, rb_w=pk.rb_w)
+    want = res[0][2][:, : engine.FEAT_C].double() @ pk.dec[0][0][:, : engine.FEAT_C].double().t()
+    assert none is None and float((rb.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
 
 
 @pytest.mark.parametrize("B,N", [(9, 1028), (3, 300)])

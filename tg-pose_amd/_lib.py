@@ -91,6 +91,7 @@ SIGNATURES = {
     "tgp_knn_max_points": (c_int, []),
     "tgp_knn_max_k": (c_int, []),
     "tgp_center": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "tgp_center_zero": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "tgp_knn_xyz": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "tgp_knn_feat_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
     "tgp_knn_feat": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp]),
@@ -98,6 +99,7 @@ SIGNATURES = {
     "tgp_knn_feat_dirs": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "tgp_nn1": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "tgp_nn1_pair": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "tgp_nn1_pair_tail": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_vp]),
     "tgp_normalize_dirs": (c_int, [c_vp, c_int, c_vp, c_vp]),
     "tgp_normalize_dirs_bwd": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp]),
     "tgp_gconv_surface_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp]),

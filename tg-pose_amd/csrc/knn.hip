@@ -86,9 +86,13 @@ __global__ void center_mean_serial_kernel(const float *__restrict__ points, int 
 // serial routine above (tests compare both against torch on the CPU).
 #define CM_MAX_RUNS 128
 // out != NULL (round 4): the workgroup also writes its object's centred points -- tgp_center as one launch
+// zero != NULL: the launch first clears zero_words 32-bit words there (the forward's arena of max keys, flags and magnitude words:
+// tgp_center_zero) -- every later launch of the forward is ordered behind this one
 __global__ __launch_bounds__(256) void center_mean_kernel(const float *__restrict__ points, int n, float *__restrict__ mean,
-                                                          float *__restrict__ out)
+                                                          float *__restrict__ out, uint32_t *__restrict__ zero, int64_t zero_words)
 {
+    if (zero)
+        for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < zero_words; t += (int64_t)gridDim.x * blockDim.x) zero[t] = 0u;
     __shared__ float part[3][4][CM_MAX_RUNS + 1];
     const int b = blockIdx.x;
     const float *in = points + (size_t)b * n * 3;
@@ -147,12 +151,26 @@ __global__ void center_sub_kernel(const float *__restrict__ points, const float 
     out[t] = points[t] - mean[b * 3 + c];
 }
 
+extern "C" int tgp_center_zero(const float *points, int B, int n, float *xyz_c, float *mean, void *zero, int64_t zero_words,
+                               tgp_stream_t stream);
 extern "C" int tgp_center(const float *points, int B, int n, float *xyz_c, float *mean, tgp_stream_t stream)
 {
-    TGP_REQUIRE(points && xyz_c && mean && B > 0 && n > 0);
+    return tgp_center_zero(points, B, n, xyz_c, mean, nullptr, 0, stream);
+}
+
+extern "C" int tgp_center_zero(const float *points, int B, int n, float *xyz_c, float *mean, void *zero, int64_t zero_words,
+                               tgp_stream_t stream)
+{
+    TGP_REQUIRE(points && xyz_c && mean && B > 0 && n > 0 && zero_words >= 0 && (!zero_words || zero));
+    TGP_REQUIRE((reinterpret_cast<uintptr_t>(zero) & 3) == 0);
     if (n / 64 < CM_MAX_RUNS) {
-        hipLaunchKernelGGL(center_mean_kernel, dim3(B), dim3(256), 0, tgp_hs(stream), points, n, mean, xyz_c);
+        hipLaunchKernelGGL(center_mean_kernel, dim3(B), dim3(256), 0, tgp_hs(stream), points, n, mean, xyz_c,
+                           zero_words ? reinterpret_cast<uint32_t *>(zero) : nullptr, zero_words);
         return TGP_LAUNCH_RESULT();
+    }
+    if (zero_words) {
+        const hipError_t e = hipMemsetAsync(zero, 0, (size_t)zero_words * 4, tgp_hs(stream));
+        if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(center_mean_serial_kernel, dim3(tgp_cdiv(B * 3, 64)), dim3(64), 0, tgp_hs(stream), points, B, n, mean);
     const int64_t total = (int64_t)B * n * 3;
@@ -1051,7 +1069,9 @@ __device__ __forceinline__ int nn1_scan(const float *__restrict__ src, const int
 // of Face_Enc.forward, FaceRecon.py:71-77)
 __global__ __launch_bounds__(256) void nn1_kernel(const float *__restrict__ tgt, const float *__restrict__ src, int B,
                                                   int n, int m, int32_t *__restrict__ idx, int tiles_per_obj,
-                                                  const float *__restrict__ src2, int m2, int32_t *__restrict__ idx2)
+                                                  const float *__restrict__ src2, int m2, int32_t *__restrict__ idx2,
+                                                  const float *__restrict__ obj_id, int n_cls, float *__restrict__ feat, int ld,
+                                                  int col0)
 {
     __shared__ float4 s[NN1_CHUNK];
     int b, tile;
@@ -1066,6 +1086,15 @@ __global__ __launch_bounds__(256) void nn1_kernel(const float *__restrict__ tgt,
         qt = qt + ty * ty;
         qt = qt + tz * tz;
     }
+    if (feat && live) {
+        // the point's row of the concat buffer behind the feature maps: one-hot category | x y z | zero padding (tgp_fill_tail;
+        // FaceRecon.py:54,78-79) -- this kernel already has one thread per point and its coordinates
+        const int cls = (int)obj_id[b];
+        float *f = feat + ((size_t)b * n + i) * ld + col0;
+        for (int c = 0; c < n_cls; ++c) f[c] = (c == cls) ? 1.f : 0.f;
+        f[n_cls + 0] = tx, f[n_cls + 1] = ty, f[n_cls + 2] = tz;
+        for (int c = n_cls + 3; c < ld - col0; ++c) f[c] = 0.f;
+    }
     const int b1 = nn1_scan(src + (size_t)b * m * 3, m, tx, ty, tz, qt, s);
     if (live) idx[(size_t)b * n + i] = b1;
     if (!src2) return;
@@ -1078,16 +1107,28 @@ extern "C" int tgp_nn1(const float *target, const float *source, int B, int n, i
     TGP_REQUIRE(target && source && idx && B > 0 && n > 0 && m > 0);
     const int tiles = tgp_cdiv(n, 256);
     hipLaunchKernelGGL(nn1_kernel, dim3(tgp_xcd_grid(B, tiles)), dim3(256), 0, tgp_hs(stream), target, source, B, n, m,
-                       idx, tiles, nullptr, 0, nullptr);
+                       idx, tiles, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, 0);
     return TGP_LAUNCH_RESULT();
 }
 
+extern "C" int tgp_nn1_pair_tail(const float *target, const float *source1, const float *source2, int B, int n, int m1, int m2,
+                                 int32_t *idx1, int32_t *idx2, const float *obj_id, int n_cls, float *feat, int ld, int col0,
+                                 tgp_stream_t stream);
 extern "C" int tgp_nn1_pair(const float *target, const float *source1, const float *source2, int B, int n, int m1, int m2,
                             int32_t *idx1, int32_t *idx2, tgp_stream_t stream)
 {
+    return tgp_nn1_pair_tail(target, source1, source2, B, n, m1, m2, idx1, idx2, nullptr, 0, nullptr, 0, 0, stream);
+}
+
+// tgp_nn1_pair that also writes the targets' tail columns of the concat buffer (tgp_fill_tail's: target = the centred cloud)
+extern "C" int tgp_nn1_pair_tail(const float *target, const float *source1, const float *source2, int B, int n, int m1, int m2,
+                                 int32_t *idx1, int32_t *idx2, const float *obj_id, int n_cls, float *feat, int ld, int col0,
+                                 tgp_stream_t stream)
+{
     TGP_REQUIRE(target && source1 && source2 && idx1 && idx2 && B > 0 && n > 0 && m1 > 0 && m2 > 0);
+    TGP_REQUIRE(!feat || (obj_id && n_cls > 0 && col0 >= 0 && ld >= col0 + n_cls + 3));
     const int tiles = tgp_cdiv(n, 256);
     hipLaunchKernelGGL(nn1_kernel, dim3(tgp_xcd_grid(B, tiles)), dim3(256), 0, tgp_hs(stream), target, source1, B, n, m1,
-                       idx1, tiles, source2, m2, idx2);
+                       idx1, tiles, source2, m2, idx2, obj_id, n_cls, feat, ld, col0);
     return TGP_LAUNCH_RESULT();
 }

@@ -185,6 +185,12 @@ class Packed(object):
             self.conv = pack_encoder(sd, face + "encoder.", device)
             self.ph = pack_ph(sd, face + "ph_pred.")
             self.dec, self.dec_out = pack_decoder(sd, face + "decoder.")
+            # (round 4) The topology code reaches the decoder only as a per-object bias of its first conv:
+            # conv(feat + back) = conv(feat) + W0 back with back = L45 [pi1 | pi2] + b45 (FaceRecon.py:158-165,112), so
+            # W0 back = (W0 L45) pi + W0 b45: one (512, 5000) vector layer instead of the (1286, 5000) one and the (512, 1286)
+            # one behind it.  The product of the two weights is taken in fp64 and rounded once.
+            w0d, (w45, b45) = self.dec[0][0][:, :FEAT_C].double(), self.ph["l45"]
+            self.rb_w = ((w0d @ w45.double()).float().contiguous(), (w0d @ b45.double()).float().contiguous())
             self.heads = {h: pack_head(sd, h + ".") for h in HEAD_ORDER} if with_heads else {}
             if with_heads:
                 self.wide = pack_wide(self.ph, [self.heads[h] for h in HEAD_ORDER],
@@ -464,11 +470,15 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, 
     if graphs.inject or graphs.record is not None:
         near1 = graphs.get("up_1", lambda: ops.nn1(xyz, v1)).view(B, N)
         near2 = graphs.get("up_2", lambda: ops.nn1(xyz, v2)).view(B, N)
+        tail_done = False
     else:
-        near1, near2 = ops.nn1_pair(xyz, v1, v2)          # both look-ups in one launch (same results)
+        # both look-ups in one launch (same results), which also writes the buffer's tail columns when they sit behind fm_1
+        near1, near2 = ops.nn1_pair(xyz, v1, v2, tail=(obj_id.reshape(-1).float().contiguous(), feat, 256, n_cls) if factored else None)
+        tail_done = factored
     inter = dict(fm_2=fm2, fm_3=fm3, fm_4=fm4, v_pool_1=v1, v_pool_2=v2)
     if factored:
-        ops.fill_tail(obj_id.reshape(-1).float(), xyz, feat, 256, n_cls)
+        if not tail_done:
+            ops.fill_tail(obj_id.reshape(-1).float(), xyz, feat, 256, n_cls)
         # Everything downstream of the concat buffer in eval mode is a per-point layer followed by a max over the object's
         # points, so the order of an object's rows is free: put the points that share their nearest coarse points next to each
         # other.  A 64-row wave tile of the fine GEMM then fetches ~4 + ~16 distinct coarse rows instead of 128 scattered ones
@@ -494,7 +504,7 @@ class Arena(object):
     fp16-range flags, the zero-padded topology back-projection -- carved out of ONE buffer zeroed by ONE fill (round 2: five
     fills of 4-5 us each per forward)."""
 
-    def __init__(self, B, dev, N=0):
+    def __init__(self, B, dev, N=0, zeroed=True):
         n5, n2, nb = B * 1024, 3 * B * 256, B * FEAT_LD
         # (round 4) + the per-32-row-block magnitudes of the activations that travel as fp16 planes (Arena.planes): five tensors
         # of B*N rows, two of B*N/4, two of B*N/16, and the five graph-convolution outputs (the layers' last GEMM operands)
@@ -502,7 +512,9 @@ class Arena(object):
         blk = lambda rows: (rows + 31) // 32
         na = 7 * blk(B * N) + 4 * blk(B * N1) + 3 * blk(B * int(N1 / 4)) if N else 0
         na += 5 * B if N else 0                  # + the five graph-convolution layers' tickets (ops.orl_rowbias, one-launch form)
-        buf = torch.zeros(n5 + n2 + 8 + nb + na, device=dev, dtype=torch.int32)
+        # zeroed=False: the caller clears `buf` before the first use (posenet_forward: in the centring launch, ops.center(zero=))
+        buf = (torch.zeros if zeroed else torch.empty)(n5 + n2 + 8 + nb + na, device=dev, dtype=torch.int32)
+        self.buf = buf
         self.keys5 = buf[:n5].view(B, 1024)
         self.keys2 = buf[n5:n5 + n2].view(3, B, 256)
         self.over5 = buf[n5 + n2:n5 + n2 + 1]
@@ -539,9 +551,11 @@ class Arena(object):
         return self._pl
 
 
-def ph_tail(ph, keys, B, dev, back=None):
-    """PH_Predictor after the max over points (FaceRecon.py:145-165): keys = colmax keys of conv_5."""
-    if back is None:
+def ph_tail(ph, keys, B, dev, back=None, rb_w=None):
+    """PH_Predictor after the max over points (FaceRecon.py:145-165): keys = colmax keys of conv_5.  Returns h1, h2, back, rb:
+    back = pi1_1 + pi2_1 (B, FEAT_LD) -- or, with rb_w = Packed.rb_w, back None and rb (B, 512) the decoder's per-object bias
+    W0 back computed straight from [pi1 | pi2]."""
+    if back is None and rb_w is None:
         back = torch.zeros(B, FEAT_LD, device=dev, dtype=torch.float32)
     l1, (w23, b23) = ph["l1"], ph["l23"]
     if PH_TAIL_FUSED and B <= 32 and keys.is_contiguous() and l1.shape[1] == 2 * keys.shape[1]:
@@ -554,15 +568,18 @@ def ph_tail(ph, keys, B, dev, back=None):
         h = torch.empty_like(pi)
         ops.gemm(fa, w23, pi, M=B, N=w23.shape[0], K=w23.shape[1], lda=fa.shape[1], ldw=w23.shape[1], ldc=w23.shape[0], bias=b23,
                  c_sigmoid=h)
-        ops.linear_rows(pi, ph["l45"][0], bias=ph["l45"][1], out=back[:, :FEAT_C])
     else:
         g = ops.colmax_decode(keys, out2=True)                                       # cat((max, max), 1)
         fa = ops.linear_rows(g, l1, scale=ph["bn5"][0], shift=ph["bn5"][1], act=1, slope=0.2)
         pi = ops.linear_rows(fa, w23, bias=b23)                                      # (B, 5000) = [pi1 | pi2]
-        ops.linear_rows(pi, ph["l45"][0], bias=ph["l45"][1], out=back[:, :FEAT_C])   # pi1_1 + pi2_1
         h = ops.sigmoid(pi)
+    rb = None
+    if rb_w is not None:
+        back, rb = None, ops.linear_rows(pi, rb_w[0], bias=rb_w[1])
+    else:
+        ops.linear_rows(pi, ph["l45"][0], bias=ph["l45"][1], out=back[:, :FEAT_C])   # pi1_1 + pi2_1
     nc = ph["n_code"]
-    return h[:, :nc], h[:, nc:], back
+    return h[:, :nc], h[:, nc:], back, rb
 
 
 def ph_forward(pk, feat, N):
@@ -572,7 +589,7 @@ def ph_forward(pk, feat, N):
     keys = torch.zeros(B, 1024, device=feat.device, dtype=torch.int32)
     ops.linear_rows(feat, ph["w5"], scale=ph["bn5c"][0], shift=ph["bn5c"][1], act=1, slope=0.2, want_out=False,
                     colmax_keys=keys, rows_per_obj=N, k_alg=FEAT_C)
-    return ph_tail(ph, keys, B, feat.device)
+    return ph_tail(ph, keys, B, feat.device)[:3]
 
 
 def wide_gemm(pk, feat, N):
@@ -685,7 +702,7 @@ def wide_gemm_factored(pk, fine, inter, P1, P2, N, arena=None, heads_only=False)
             # sits in every captured forward's pool although the launches normally return at once: the repair therefore walks
             # the batch in chunks of REPAIR_OBJS objects through ONE chunk-sized buffer (tgp_gemm_args.row_base addresses the
             # chunk's objects in the max over points): two predicated launches per chunk.
-            Rr = min(M, REPAIR_OBJS * N)
+            Rr = M if B <= 2 * REPAIR_OBJS else REPAIR_OBJS * N       # (up to 2 x REPAIR_OBJS objects: one chunk, two launches)
             H = torch.empty(Rr, 3072, device=dev, dtype=torch.float32)
             f2, n1v, n2v = fine.view(M, -1), inter["near1"].view(-1), inter["near2"].view(-1)
             for r0 in range(0, M, Rr):
@@ -708,13 +725,15 @@ def wide_gemm_factored(pk, fine, inter, P1, P2, N, arena=None, heads_only=False)
     return keys5, H
 
 
-def decoder_forward_factored(pk, fine, inter, P1, P2, back, N, arena=None):
-    """decoder_forward with the first conv factored like the wide layer (its coarse products are columns 4096.. of P1 / P2)."""
+def decoder_forward_factored(pk, fine, inter, P1, P2, back, N, arena=None, rb=None):
+    """decoder_forward with the first conv factored like the wide layer (its coarse products are columns 4096.. of P1 / P2).
+    rb: W0 back, where the caller has it already (ph_tail(rb_w=...))."""
     w0, b0, sc0, sh0 = pk.dec[0][:4]
     f = pk.fact
     B = fine.shape[0]
     M = B * N
-    rb = ops.linear_rows(back, w0) if back is not None else None
+    if rb is None:
+        rb = ops.linear_rows(back, w0) if back is not None else None
     # (the light fused kernel in a storing form was measured for this layer: 110 us against 96 us on the tile kernel -- with 512
     # channels a workgroup has 8 channel blocks to amortise its set-up over, and 4-byte stores of 16 points per lane)
     pl = inter.get("planes") or {}
@@ -763,6 +782,7 @@ def decoder_forward_factored(pk, fine, inter, P1, P2, back, N, arena=None):
     return torch.empty_like(recon).scatter_(1, inter["order"].unsqueeze(-1).expand(-1, -1, 3), recon)
 
 
+PH_RB_COMPOSED = os.environ.get("TGP_PH_RB_COMPOSED", "1") != "0"   # decoder's per-object bias from [pi1 | pi2] through W0 L45
 KNN_DIRS = os.environ.get("TGP_KNN_DIRS", "1") != "0"        # feature kNN leaves the unit neighbour directions beside its lists
 PH_TAIL_FUSED = os.environ.get("TGP_PH_TAIL_FUSED", "1") != "0"   # PH predictor's vector layers: key decode and sigmoid inside them
 ROWS_OUT = os.environ.get("TGP_ROWS_OUT", "1") != "0"        # the decoder's last conv and the un-sort of its rows as one launch
@@ -809,7 +829,7 @@ def head_tail(hd, pooled):
     return ops.linear_rows(x, hd["c4"][0], bias=hd["c4"][1])
 
 
-def decoder_forward(pk, feat, back, N):
+def decoder_forward(pk, feat, back, N, rb=None):
     """Face_Dec.forward on feat + back (FaceRecon.py:165,112-117) -> recon (B,N,3).
 
     conv(feat + back) = conv(feat) + W @ back: the broadcast add of the topology code becomes a
@@ -817,7 +837,8 @@ def decoder_forward(pk, feat, back, N):
     B = feat.shape[0]
     w0, b0, sc0, sh0, ws0 = pk.dec[0][:5]
     x = feat
-    rb = ops.linear_rows(back, w0) if back is not None else None
+    if rb is None:
+        rb = ops.linear_rows(back, w0) if back is not None else None
     x = ops.linear_rows(x, w0, bias=b0, rowbias=rb, rows_per_obj=N, scale=sc0, shift=sh0, act=1, k_alg=FEAT_C, w_split=ws0)
     for w, b, sc, sh, ws, _ in pk.dec[1:]:
         x = ops.linear_rows(x, w, bias=b, scale=sc, shift=sh, act=1, w_split=ws)
@@ -859,10 +880,11 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
     if sample_idx is None:
         sample_idx = draw_sample_idx(N)
     points = points.contiguous().float()
-    xyz, mean = ops.center(points)
     graphs = Graphs(points.device, inject, record)
     factored = FACTORED and not train_keys          # the concat buffer is an output only with the training keys
-    arena = Arena(B, points.device, N) if factored else None       # zeroed on this stream before any branch forks
+    # (zeroed on this stream before any branch forks: by the centring launch itself)
+    arena = Arena(B, points.device, N, zeroed=False) if factored else None
+    xyz, mean = ops.center(points, zero=arena.buf if arena is not None else None)
     feat, inter = encoder_forward(pk, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls, factored=factored, arena=arena)
     # EVAL_OUTPUTS_ONLY: the six-key eval dict (PoseNet9D.py:85-90) needs neither the PH predictor nor the decoder -- the reference
     # computes both and drops them.  Off by default: the bench's headline is the full forward (SURVEY 8d's algorithmic figures).
@@ -878,11 +900,12 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
     if factored:
         P1, P2 = coarse_products(pk, inter)
         wide = lambda: wide_gemm_factored(pk, feat, inter, P1, P2, N, arena)
-        decode = lambda back: decoder_forward_factored(pk, feat, inter, P1, P2, back, N, arena)
+        decode = lambda back, rb: decoder_forward_factored(pk, feat, inter, P1, P2, back, N, arena, rb)
     else:
         P1 = P2 = None
         wide = lambda: wide_gemm(pk, feat, N)
-        decode = lambda back: decoder_forward(pk, feat, back, N)
+        decode = lambda back, rb: decoder_forward(pk, feat, back, N, rb)
+    rb_w = getattr(pk, "rb_w", None) if PH_RB_COMPOSED else None
     if BRANCH_STREAMS:
         # after the fused wide GEMM the head chain (conv2 -> max -> conv3 -> conv4) and the PH tail -> decoder chain are
         # independent: the second runs on a side stream and fills the tail rounds / skinny launches of the first
@@ -893,14 +916,14 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
         fork.record(cur)
         with torch.cuda.stream(side):
             side.wait_event(fork)
-            h1, h2, back = ph_tail(pk.ph, keys5, B, points.device, arena.back if arena is not None else None)
-            recon = decode(back)
+            h1, h2, back, rb = ph_tail(pk.ph, keys5, B, points.device, arena.back if arena is not None else None, rb_w)
+            recon = decode(back, rb)
             join = torch.cuda.Event()
             join.record(side)
         if callable(H):
             H = H()                                           # the fused heads kernel, beside the side branch
         if not torch.cuda.is_current_stream_capturing():      # a captured graph owns its pool: nothing to protect
-            for t in (keys5, H, feat, h1, h2, back, recon) + ((P1, P2, inter["near1"], inter["near2"]) if factored else ()):
+            for t in (keys5, H, feat, h1, h2, recon) + ((back,) if back is not None else (rb,)) + ((P1, P2, inter["near1"], inter["near2"]) if factored else ()):
                 t.record_stream(side)
         pg, pr, fg, fr, pT, ps = head_chain(pk, H, B, N, mean)
         cur.wait_event(join)
@@ -909,8 +932,8 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
         if callable(H):
             H = H()
         pg, pr, fg, fr, pT, ps = head_chain(pk, H, B, N, mean)
-        h1, h2, back = ph_tail(pk.ph, keys5, B, points.device, arena.back if arena is not None else None)
-        recon = decode(back)
+        h1, h2, back, rb = ph_tail(pk.ph, keys5, B, points.device, arena.back if arena is not None else None, rb_w)
+        recon = decode(back, rb)
     out = dict()
     if probe is not None:
         probe.update(recon=recon + mean.view(B, 1, 3), h1=h1, h2=h2, keys5=keys5)

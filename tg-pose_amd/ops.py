@@ -80,13 +80,18 @@ def graph_node_counts(raw_graph):
 
 
 @_timed("graph")
-def center(points):
-    """points (B,n,3) -> (xyz_c (B,n,3), mean (B,3))"""
+def center(points, zero=None):
+    """points (B,n,3) -> (xyz_c (B,n,3), mean (B,3)); zero (a contiguous 4-byte tensor): cleared by the same launch"""
     _f32(points, "points", 3)
     points = points.contiguous()
     B, n, _ = points.shape
     xyz = torch.empty_like(points)
     mean = torch.empty(B, 3, device=points.device, dtype=torch.float32)
+    if zero is not None:
+        if not zero.is_contiguous() or zero.element_size() != 4 or zero.device != points.device:
+            raise ValueError("center: zero must be a contiguous 4-byte tensor on the points' device")
+        check(_lib.lib().tgp_center_zero(_p(points), B, n, _p(xyz), _p(mean), _p(zero), zero.numel(), _stream(points)), "tgp_center_zero")
+        return xyz, mean
     check(_lib.lib().tgp_center(_p(points), B, n, _p(xyz), _p(mean), _stream(points)), "tgp_center")
     return xyz, mean
 
@@ -145,16 +150,23 @@ def nn1(target, source):
     return idx
 
 
-def nn1_pair(target, source1, source2):
-    """nn1(target, source1), nn1(target, source2) in one launch"""
+def nn1_pair(target, source1, source2, tail=None):
+    """nn1(target, source1), nn1(target, source2) in one launch; tail = (obj_id (B,) float, feat (B,n,ld), col0, n_cls): the launch
+    also writes fill_tail(obj_id, target, feat, col0, n_cls)"""
     for t, nm in ((target, "target"), (source1, "source1"), (source2, "source2")):
         _f32(t, nm, 3)
     target, source1, source2 = target.contiguous(), source1.contiguous(), source2.contiguous()
     B, n, _ = target.shape
     i1 = torch.empty(B, n, device=target.device, dtype=torch.int32)
     i2 = torch.empty(B, n, device=target.device, dtype=torch.int32)
-    check(_lib.lib().tgp_nn1_pair(_p(target), _p(source1), _p(source2), B, n, source1.shape[1], source2.shape[1], _p(i1), _p(i2),
-                                  _stream(target)), "tgp_nn1_pair")
+    obj_id, feat, col0, n_cls, ld = None, None, 0, 0, 0
+    if tail is not None:
+        obj_id, feat, col0, n_cls = tail
+        feat, ld = _rows(feat, "feat")
+        if tuple(feat.shape[:2]) != (B, n) or obj_id.numel() != B or not obj_id.is_contiguous() or obj_id.dtype != torch.float32:
+            raise ValueError("nn1_pair: tail = (obj_id (B,) float32, feat (B,n,ld), col0, n_cls)")
+    check(_lib.lib().tgp_nn1_pair_tail(_p(target), _p(source1), _p(source2), B, n, source1.shape[1], source2.shape[1], _p(i1), _p(i2),
+                                       _p(obj_id), int(n_cls), _p(feat), ld, int(col0), _stream(target)), "tgp_nn1_pair_tail")
     return i1, i2
 
 
