@@ -20,6 +20,10 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_V
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/sq3 -- python3 $R/bench.py $SERIAL > /dev/null 2>> $O/prof.err
 python3 $R/scripts/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json > /dev/null 2>> $O/prof.err
 python3 $R/scripts/sq_counters.py $O/sq_counters_forward.txt $O/sq1 $O/sq2 $O/sq3 > /dev/null 2>> $O/prof.err
+python3 $R/scripts/forward_launches.py $(find $O/prof_serial -name "*kernel_trace.csv" | head -1) $O/forward_launches_one_forward.txt >> $O/prof.err 2>&1
+python3 $R/bench.py --no-cpu-baseline --eval-outputs-only > $O/bench_eval_outputs_only.jsonl 2>> $O/bench.err
+python3 $R/bench.py --no-cpu-baseline --workload train_step > $O/train_step.jsonl 2>> $O/bench.err
+python3 $R/bench.py --no-cpu-baseline --workload train_step --batch 256 --steps 5 --warmup 2 > $O/b256_train.jsonl 2>> $O/bench.err
 # keep the merge small: summaries only
 find $O -name "*counter_collection.csv" -delete
 find $O -name "*kernel_trace.csv" -size +20M -delete

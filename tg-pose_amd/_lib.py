@@ -5,6 +5,7 @@ never routes through the CPU oracle or through torch ops for the hot layers.
 """
 import ctypes
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtgpose_hip.so")
@@ -227,6 +228,22 @@ def lib():
             fn.argtypes = args
         if handle.tgp_version() != ABI_VERSION:
             raise TgpError("tgpose_amd: ABI version mismatch (%d != %d)" % (handle.tgp_version(), ABI_VERSION))
+        if os.environ.get("TGP_TRACE", "0") != "0":
+            # diagnosis: every entry point announces itself on stderr before it launches (with HIP_LAUNCH_BLOCKING=1 the last
+            # name printed is the launch that faulted)
+            class _Traced(object):
+                def __init__(self, h):
+                    self._h = h
+
+                def __getattr__(self, name):
+                    fn = getattr(self._h, name)
+
+                    def call(*a):
+                        sys.stderr.write("tgp: %s\n" % name)
+                        sys.stderr.flush()
+                        return fn(*a)
+                    return call
+            handle = _Traced(handle)
         _lib = handle
     return _lib
 

@@ -946,7 +946,7 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmPara
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int col = nb + c16 + 16 * t;
-        wrow[t] = W + (int64_t)(col < p.N ? col : p.N - 1) * p.ldw + 4 * q;
+        wrow[t] = W + (int64_t)(col < p.N ? col : p.N - 1) * p.ldw;
     }
     f32x4v acc[2][NT];
 #pragma unroll
@@ -961,8 +961,11 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmPara
         for (int u = 0; u < SKINNY_UNROLL; ++u) {
             const int k = (c0 + u * SKINNY_WAVES) * 16;
             const bool ok = k + 4 * q < p.K;          // K % 4 == 0; also false for chunks past the end
-            const int kc = ok ? k : 0;
-            int ka = kc + 4 * q;
+            // a lane whose quad lies past K reads the row's first quad instead (and discards it).  It used to read at 4 q past the
+            // row start whatever K was: with K = 4 (the heads' conv4 backward, dy (32, 4)) up to 48 bytes beyond the operand's last
+            // row -- a memory fault once such a tensor ended at the end of a mapped segment (round 4, the trainer step at B = 32).
+            const int kc = ok ? k + 4 * q : 0;
+            int ka = kc;
             if (p.a_wrap) ka = ka % p.a_wrap;                // cat((max, max), 1) without the copy (workgroup-uniform branch)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
