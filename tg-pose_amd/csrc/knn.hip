@@ -900,6 +900,49 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__
     if (l8 == 0 && j0 + r < n) q[(size_t)b * n + j0 + r] = 0.f + fin;
 }
 
+// The same with 16-byte global accesses (round 4): a quarter of the load / store instructions -- thread (row r, l8) loads the
+// float4 at columns 4 (l8 + 8 i) of its row (eight lanes = 128 contiguous bytes), the transposed block leaves as float4 along the
+// points.  The LDS tile and the norm's arithmetic are those of the kernel above (same values, same order: bit-identical norms).
+// Needs x 16-byte addressable (base and ld): the launcher falls back to the scalar kernel otherwise.
+__global__ __launch_bounds__(256) void knn_prep_v4_kernel(const float *__restrict__ x, int ld, int n, int d, float *__restrict__ xt, int ldt,
+                                                          float *__restrict__ q)
+{
+    __shared__ float tile[4][32][33];
+    const int b = blockIdx.y, j0 = blockIdx.x * 32;
+    const int r = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < d; c0 += 128) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j0 + r < n && c0 + g * 32 < d) v = *reinterpret_cast<const float4 *>(x + ((size_t)b * n + j0 + r) * ld + c0 + g * 32 + 4 * l8);
+            tile[g][r][4 * l8 + 0] = v.x, tile[g][r][4 * l8 + 1] = v.y, tile[g][r][4 * l8 + 2] = v.z, tile[g][r][4 * l8 + 3] = v.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (c0 + g * 32 >= d) break;
+            // transposed block: thread (column r of the group, points 4 l8 .. 4 l8 + 3)
+            const float4 t4 = make_float4(tile[g][4 * l8 + 0][r], tile[g][4 * l8 + 1][r], tile[g][4 * l8 + 2][r], tile[g][4 * l8 + 3][r]);
+            *reinterpret_cast<float4 *>(xt + ((size_t)b * d + c0 + g * 32 + r) * ldt + j0 + 4 * l8) = t4;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {       // groups ascending, then ATen's four interleaved accumulators
+                const float v = tile[g][r][kk * 8 + l8];
+                acc[kk] = acc[kk] + v * v;
+            }
+        }
+        __syncthreads();
+    }
+    float p = acc[0] + acc[1];
+    p = p + acc[2];
+    p = p + acc[3];
+    float fin = 0.f;
+    const int base = (threadIdx.x & 63) & ~7;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) fin = fin + __shfl(p, base + l, 64);
+    if (l8 == 0 && j0 + r < n) q[(size_t)b * n + j0 + r] = 0.f + fin;
+}
+
 // does the fused (matrix-free) kernel serve this shape?
 static bool knn_feat_fused_ok(int n, int d)
 {
@@ -998,7 +1041,10 @@ static int knn_feat_go(const float *feat, int ld, int B, int n, int d, int k, in
     const int64_t rows = (int64_t)B * n;
     const int nt = tgp_cdiv(n, 64);
     if (fused) {
-        hipLaunchKernelGGL(knn_prep_kernel, dim3(ldt / 32, B), dim3(256), 0, tgp_hs(stream), feat, ld, n, d, D, ldt, q);
+        if ((reinterpret_cast<uintptr_t>(feat) & 15) == 0 && (reinterpret_cast<uintptr_t>(D) & 15) == 0)
+            hipLaunchKernelGGL(knn_prep_v4_kernel, dim3(ldt / 32, B), dim3(256), 0, tgp_hs(stream), feat, ld, n, d, D, ldt, q);
+        else
+            hipLaunchKernelGGL(knn_prep_kernel, dim3(ldt / 32, B), dim3(256), 0, tgp_hs(stream), feat, ld, n, d, D, ldt, q);
 #define LAUNCH_FUSED(NT) \
     (d == 128 ? launch_knn_fused<128, NT, 8>(D, q, B, n, k, idx, tgp_hs(stream), form, xyz, dirs)                     \
               : launch_knn_fused<256, NT, 8>(D, q, B, n, k, idx, tgp_hs(stream), form, xyz, dirs))
