@@ -221,6 +221,9 @@ __global__ __launch_bounds__(1024) void gconv_lds_kernel(const float4 *__restric
     constexpr int QC = CH / 4;                 // float4 chunks per table row segment (fill)
     constexpr int PC = CH / 2;                 // channel pairs per workgroup: a thread owns (point, pair) -- 42 direction
     constexpr int ROW = GC_S * CH;             // registers instead of 84, which keeps 4 waves per SIMD
+    // (Round 4, three measurements on the 60 us launches of conv_2 / conv_3, none of which moved them: 25 % fewer vector instructions
+    // (the ReLU as an output clamp, see pk_max above): 61 us; the next four neighbours' ids and directions requested before this
+    // trip's arithmetic: 64 us; table rows padded against bank conflicts (below): 62 us.)
     // (Measured and dropped, round 4: a row stride of GC_S * CH + 2 floats.  A wave's 16 points read 16 neighbour rows at the same
     // (support, pair) offset, and with 56 / 112-float rows those start in 4 / 2 bank groups -- 50 % / 32 % of the LDS-busy cycles are
     // conflicts in the SQ counters -- but spreading them over 16 changed nothing: 62 vs 60 us, 19 vs 19.  The kernel waits on the
