@@ -3579,6 +3579,15 @@ def test_orl_rowbias_one_launch_form(ops, B, n, C, k, with_planes):
         assert int(tickets.abs().sum()) == 0
         runs.append(rb)
     assert all(torch.equal(runs[0], r) for r in runs[1:])
+    # the slices' scratch comes back from the allocator with the previous call's slices in it: alternate with other features, so that a
+    # slice read before its store has landed (the first build took the ticket without waiting for the stores' acknowledgements)
+    # would be the OTHER input's and show
+    feat2 = g(torch.randn(B, n, C, generator=gen))
+    first2 = ops.orl_rowbias(feat2, idx, w2t, tickets=tickets).clone()
+    for _ in range(25):
+        assert torch.equal(ops.orl_rowbias(feat, idx, w2t, tickets=tickets), runs[0])
+        assert torch.equal(ops.orl_rowbias(feat2, idx, w2t, tickets=tickets), first2)
+    assert int(tickets.abs().sum()) == 0
     gmax = feat.double().view(B, n, C)[torch.arange(B, device=DEV).view(B, 1, 1), idx.long()].max(2)[0].mean(1)      # (B, C)
     want = gmax @ w2t.double()
     scale = float(want.abs().max())

@@ -564,7 +564,8 @@ __global__ __launch_bounds__(1024) void orl_lds_kernel(const float *__restrict__
     // ---- fused finish (round 4; tgp_orl_rowbias_fused): this workgroup holds every point tile of its 16 channels, so their mean
     // over points g (orl_finish_kernel's sum, term by term) needs no other workgroup; its share of the projection
     // rb[b, :] = g[b, :] @ W2^T is the 16-row slice  contrib[b, chunk, o] = sum_c g[c0 + c] w2t[c0 + c, o]  (one fmaf chain), and
-    // the LAST of the object's C / 16 workgroups to arrive (a ticket per object, taken after the slice's stores are acknowledged) adds the
+    // the LAST of the object's C / 16 workgroups to arrive (a ticket per object, taken after the slice's stores are acknowledged:
+    // s_waitcnt vmcnt(0) by hand) adds the
     // slices in chunk order -- a fixed order whichever workgroup that is -- and hands the ticket back as 0.
     float *s_g = s_tab;                              // the table is no longer read
     int *s_last = reinterpret_cast<int *>(s_tab + ORL_CH);
@@ -590,7 +591,12 @@ __global__ __launch_bounds__(1024) void orl_lds_kernel(const float *__restrict__
         // written sitting in it the launch took 60-100 us instead of 13-29.)
         __hip_atomic_store(contrib + ((int64_t)b * nch + chunk) * C + o, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();                                 // every wave has waited for its stores' acknowledgements (vmcnt) before the barrier
+    // The slice's stores must be ACKNOWLEDGED before the ticket is taken.  __syncthreads() does not do that: a workgroup-scope
+    // release on gfx950 (all waves of a workgroup share one L1) carries no vmcnt wait for global stores -- the first build relied on
+    // it, and the object's last workgroup could read a slice still in flight (one captured-vs-eager trainer comparison in ~6
+    // failed).  Written by hand:
+    __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0)
+    __syncthreads();
     if (tid == 0) *s_last = atomicAdd(tickets + b, 1) == nch - 1;
     __syncthreads();
     if (!*s_last) return;
