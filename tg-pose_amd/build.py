@@ -35,6 +35,8 @@ def build(force=False, verbose=True, dev=False):
     package itself -- a script points tgpose_amd._lib.LIB_PATH at it before the first call)."""
     if dev == "bnscalar":      # A/B measurement build: BatchNorm passes on the scalar kernels
         return _build(os.path.join(HERE, "libtgpose_hip_bnscalar.so"), SOURCES, ["-DTGP_BN_SCALAR"], ".bs.o", verbose)
+    if dev == "predbig":       # A/B measurement build: predicated (repair) launches on the large tile shapes, as before round 4
+        return _build(os.path.join(HERE, "libtgpose_hip_predbig.so"), SOURCES, ["-DTGP_PRED_BIG"], ".pb.o", verbose)
     if dev == "noguard":       # A/B measurement build: the product library without the fp16 range guard of the split GEMM
         return _build(os.path.join(HERE, "libtgpose_hip_noguard.so"), SOURCES, ["-DTGP_NO_RANGE_GUARD"], ".ng.o", verbose)
     if dev:
@@ -72,4 +74,4 @@ def _build(LIB, sources, extra, suffix, verbose):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, dev="noguard" if "--noguard" in sys.argv else "bnscalar" if "--bnscalar" in sys.argv else "--dev" in sys.argv)
+    build(force="--force" in sys.argv, dev="predbig" if "--predbig" in sys.argv else "noguard" if "--noguard" in sys.argv else "bnscalar" if "--bnscalar" in sys.argv else "--dev" in sys.argv)

@@ -786,16 +786,32 @@ __global__ __launch_bounds__(512, 4) void gemm_split512_kernel(GemmParams p)
 // registers): four times as many, four times shorter workgroups, and BN = 128 keeps the whole output row of the C = 128 layers
 // in one workgroup, so the large operand (the activations) is still read once.  Same K order per output element (16-wide steps,
 // three terms): results are bit-identical to the larger tiles'.
-template <int PD, bool F16, bool PLANES = false>
+// PLOOP (round 4): the form every PREDICATED launch takes (tgp_gemm_args.pred: the fp16-range repairs, which normally return at
+// once).  A repair used to be launched on the tile shape its size called for -- up to 1560 workgroups of 1024 threads and 98 KB of
+// LDS each, every one of which has to become resident before it can read the flag and leave: 27 us per empty launch with four
+// batches in flight, four to eight such launches per forward.  Here at most 256 workgroups of this small tile walk the launch's
+// tiles (same K order per output element, so the same bits as any other tile shape); how fast a repair runs does not matter.
+// (Effect on the default line, A/B of two builds on one box, four runs each: 19.57 vs 19.43 k objects/s median, ranges overlapping --
+// the stalls were stream latency that the other batches in flight already covered.)
+template <int PD, bool F16, bool PLANES = false, bool PLOOP = false>
 __global__ __launch_bounds__(256, 4) void gemm_split256_kernel(GemmParams p)
 {
     __shared__ __attribute__((aligned(16))) char smem[(PD > 0 ? 2 : 1) * (F16 ? 2 : 3) * ((64 + 128) * 48 + 64)];
     if (p.pred && *p.pred == 0) return;      // a repair launch whose condition did not arise (workgroup-uniform)
-    int L = (int)blockIdx.x;
     const int per_batch = p.tiles_m_small * p.tiles_n_small;
-    const int z = L / per_batch;
-    L -= z * per_batch;
-    gemm_split_tile<64, 128, 2, 2, PD, F16, false, 1, (PD > 0 ? 2 : 1), PLANES>(p, (L / p.tiles_n_small) * 64, (L % p.tiles_n_small) * 128, z, smem);
+    if constexpr (PLOOP) {
+        const int total = per_batch * p.batch;
+        for (int L0 = (int)blockIdx.x; L0 < total; L0 += (int)gridDim.x) {
+            const int z = L0 / per_batch, L = L0 - z * per_batch;
+            gemm_split_tile<64, 128, 2, 2, PD, F16, false, 1, (PD > 0 ? 2 : 1), PLANES>(p, (L / p.tiles_n_small) * 64, (L % p.tiles_n_small) * 128, z, smem);
+            __syncthreads();                 // the tile's epilogue has turned its blocks through the stages the next prologue fills
+        }
+    } else {
+        int L = (int)blockIdx.x;
+        const int z = L / per_batch;
+        L -= z * per_batch;
+        gemm_split_tile<64, 128, 2, 2, PD, F16, false, 1, (PD > 0 ? 2 : 1), PLANES>(p, (L / p.tiles_n_small) * 64, (L % p.tiles_n_small) * 128, z, smem);
+    }
 }
 
 // W (rows, K) fp32 row stride ld -> out[rows][ldo / 16][3][16] bf16 (hi, mid, lo per K-tile), zero padded to ldo
@@ -1171,6 +1187,18 @@ static int launch_split(GemmParams &p, hipStream_t stream)
     const int64_t tiles512 = (int64_t)tgp_cdiv(p.M, GEMM_BIG) * tgp_cdiv(p.N, 128) * p.batch;
     // (round 4, measured: raising this threshold so that more -- or all -- of the trainer's fp32-operand launches take the small tile,
     // as the pre-split kernel's measurements suggested, leaves the trainer's step where it is: 17.2-17.6 ms at every setting)
+#ifndef TGP_PRED_BIG        // (A/B measurement build: predicated launches on the tile shape their size calls for, as before)
+    if (p.pred && p.split_f16 && !p.ksplit && !p.Cp && tgp_split_variant == 7) {
+        // a predicated (repair) launch: a small grid of small workgroups walking the tiles (gemm_split256_kernel, PLOOP)
+        p.mt_big = 0, p.tiles_big = 0, p.tiles_n_big = 1;
+        p.tiles_m_small = tgp_cdiv(p.M, 64), p.tiles_n_small = tgp_cdiv(p.N, 128);
+        p.nseg = 0, p.seg_small = 0;
+        p.stamps = nullptr;
+        const int64_t total = (int64_t)p.tiles_m_small * p.tiles_n_small * p.batch;
+        hipLaunchKernelGGL((gemm_split256_kernel<2, true, false, true>), dim3((unsigned)(total < 256 ? total : 256)), dim3(256), 0, stream, p);
+        return TGP_LAUNCH_RESULT();
+    }
+#endif
     if (p.Cp || (p.split_f16 && !p.ksplit && !p.gres1 && !p.gres2 && !force512 && tgp_split_variant == 7 &&
                  tiles512 * 10 < 3 * 2 * (int64_t)resident_slots())) {
         p.mt_big = 0, p.tiles_big = 0, p.tiles_n_big = 1;
