@@ -34,8 +34,10 @@ SHAPES = [
 ]
 lib.tgp_debug_set_pp_stamps.argtypes = [ctypes.c_void_p]
 lib.tgp_debug_set_pp_stamps.restype = ctypes.c_int
-stamps = torch.zeros(1 << 16, 4, device=dev, dtype=torch.int64)
+stamps = torch.zeros((1 << 18) + (1 << 17), device=dev, dtype=torch.int64)      # 64 K workgroups x 4 wall stamps, then x 2 shader-clock stamps
 assert lib.tgp_debug_set_pp_stamps(stamps.data_ptr()) == 0
+lib.tgp_debug_set_pp_knobs.argtypes = [ctypes.c_int]
+KNOBS = [int(x) for x in os.environ.get("TGP_PP_KNOBS", "0").split(",")]     # timing-only variants (garbage results): see csrc/gemm_pp.hip
 for name, M, N, K, fl, cfg in SHAPES:
     A = torch.randn(M, K, device=dev)
     W = (torch.randn(N, K, device=dev) / K ** 0.5).contiguous()
@@ -51,18 +53,23 @@ for name, M, N, K, fl, cfg in SHAPES:
                   res2=torch.randn(M, N, device=dev), ldr2=N)
     C = torch.empty(M, N, device=dev)
     Cp = ops.Planes(M, N, dev)
-    for with_planes in (False, True):
+    for with_planes, knob in [(False, k) for k in KNOBS] + ([(True, 0)] if KNOBS == [0] else []):
+        assert lib.tgp_debug_set_pp_knobs(knob) == 0
         for _ in range(3):
             stamps.zero_()
             torch.cuda.synchronize()
             ops.gemm(A, W, C, a_planes=Ap, w_planes=Wp, pp_config=cfg, c_planes=Cp if with_planes else None, **kw)
             torch.cuda.synchronize()
-        s = stamps.cpu()
-        s = s[s[:, 3] != 0].double() / 100.0           # us
+        raw = stamps.cpu()
+        s = raw[: 1 << 18].view(-1, 4)
+        cyc = raw[1 << 18:].view(-1, 2)
+        live = s[:, 3] != 0
+        mhz = float(((cyc[live, 1] - cyc[live, 0]).double() / ((s[live, 3] - s[live, 0]).double() / 100.0)).median())
+        s = s[live].double() / 100.0           # us
         t0 = s[:, 0].min()
         med = lambda v: float(v.median())
-        say("%-12s M=%6d N=%5d K=%4d cfg %d planes-out %d | %4d workgroups, span %6.1f us; last entry at %5.1f; per workgroup (median / max): "
-            "to first stage %5.2f / %5.2f, K loop %5.2f / %5.2f, epilogue %5.2f / %5.2f, total %5.2f / %5.2f"
-            % (name, M, N, K, cfg, with_planes, s.shape[0], float(s[:, 3].max() - t0), float(s[:, 0].max() - t0),
+        say("%-12s M=%6d N=%5d K=%4d cfg %d knobs %d planes-out %d | %4d workgroups, span %6.1f us; last entry at %5.1f; per workgroup (median / max): "
+            "to first stage %5.2f / %5.2f, K loop %5.2f / %5.2f, epilogue %5.2f / %5.2f, total %5.2f / %5.2f; shader clock %4.0f MHz"
+            % (name, M, N, K, cfg, knob, with_planes, s.shape[0], float(s[:, 3].max() - t0), float(s[:, 0].max() - t0),
                med(s[:, 1] - s[:, 0]), float((s[:, 1] - s[:, 0]).max()), med(s[:, 2] - s[:, 1]), float((s[:, 2] - s[:, 1]).max()),
-               med(s[:, 3] - s[:, 2]), float((s[:, 3] - s[:, 2]).max()), med(s[:, 3] - s[:, 0]), float((s[:, 3] - s[:, 0]).max())))
+               med(s[:, 3] - s[:, 2]), float((s[:, 3] - s[:, 2]).max()), med(s[:, 3] - s[:, 0]), float((s[:, 3] - s[:, 0]).max()), mhz))

@@ -27,10 +27,20 @@ extern "C" int tgp_debug_set_pp_stamps(void *buf)
     unsigned long long *b = reinterpret_cast<unsigned long long *>(buf);
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(tgp_pp_stamps), &b, sizeof(b));
 }
+// (stamps 0 .. 3: wall clock; the shader clock at stamps 0 and 3 goes to slots 4 and 5 of a second table behind the first:
+// shader cycles per microsecond of the workgroup's lifetime = the clock the kernel actually ran at)
 #define PP_STAMP(I)                                                                                   \
-    if (tgp_pp_stamps && threadIdx.x == 0) tgp_pp_stamps[(size_t)blockIdx.x * 4 + (I)] = wall_clock64();
+    if (tgp_pp_stamps && threadIdx.x == 0) {                                                          \
+        tgp_pp_stamps[(size_t)blockIdx.x * 4 + (I)] = wall_clock64();                                 \
+        if ((I) == 0 || (I) == 3) tgp_pp_stamps[(size_t)(1 << 18) + (size_t)blockIdx.x * 2 + ((I) == 3)] = __builtin_readcyclecounter(); \
+    }
+// timing-only knobs (results are garbage): 1 = A fragments read once, 2 = W fragments read once, 4 = no LDS-DMA after the prologue
+__device__ int tgp_pp_knobs = 0;
+extern "C" int tgp_debug_set_pp_knobs(int v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(tgp_pp_knobs), &v, sizeof(v)); }
+#define PP_KNOB(B) (tgp_pp_knobs & (B))
 #else
 #define PP_STAMP(I)
+#define PP_KNOB(B) 0
 #endif
 
 template <int BM, int BN, int NWM, int NWN, int KTS, int STAGES>
@@ -116,6 +126,9 @@ __device__ __forceinline__ void gemm_pp_tile(const GemmParams &p, const int m0, 
 #pragma unroll
         for (int d = 0; d < D; ++d)
             if (d < numS) dma(d, d);
+#ifdef TGP_DEV
+        uint4 keep_a[TM][2] = {}, keep_b[TN][2] = {};
+#endif
         for (int s = 0; s < numS; ++s) {
             // step s's pieces have landed (this wave's; after the barrier everybody's), and everybody has finished reading the
             // stage that step s + D is about to overwrite (it held step s - 1)
@@ -127,7 +140,7 @@ __device__ __forceinline__ void gemm_pp_tile(const GemmParams &p, const int m0, 
             else PP_WAIT_VM(3 * NI);
             __builtin_amdgcn_s_barrier();
             if (s == 0) { PP_STAMP(1) }
-            if (s + D < numS) dma(s + D, (s + D) % STAGES);
+            if (s + D < numS && !PP_KNOB(4)) dma(s + D, (s + D) % STAGES);
             const char *st = smem + (s % STAGES) * STAGE_BYTES + lane * 16;
 #pragma unroll
             for (int t = 0; t < KTS; ++t) {
@@ -137,13 +150,29 @@ __device__ __forceinline__ void gemm_pp_tile(const GemmParams &p, const int m0, 
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
+                    {
+#ifdef TGP_DEV
+                        if (PP_KNOB(1) && s > 0) { a[i][q] = keep_a[i][q]; continue; }
+#endif
                         a[i][q] = *reinterpret_cast<const uint4 *>(st + (((wm * TM + i) * KTS + t) * 2 + q) * 1024);
+#ifdef TGP_DEV
+                        keep_a[i][q] = a[i][q];
+#endif
+                    }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     uint4 b[2];
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
+                    {
+#ifdef TGP_DEV
+                        if (PP_KNOB(2) && s > 0) { b[q] = keep_b[j][q]; continue; }
+#endif
                         b[q] = *reinterpret_cast<const uint4 *>(st + (((ABLK + wn * TN + j) * KTS + t) * 2 + q) * 1024);
+#ifdef TGP_DEV
+                        keep_b[j][q] = b[q];
+#endif
+                    }
                     // smallest terms first, as in gemm_split_tile: hi x lo, lo x hi, hi x hi; consecutive MFMAs walk the column's accumulators
 #define PP_TERM(QA, QB)                                                                                                  \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                     \
@@ -457,6 +486,9 @@ int tgp_launch_gemm_pp(GemmParams &p, int config, hipStream_t stream)
     case 6: return pp_launch<128, 128, 2, 2, 2, 2, 2>(p, stream);
     case 7: return pp_launch<128, 256, 2, 4, 1, 3, 4>(p, stream);
     case 8: return pp_launch<64, 128, 2, 2, 1, 2, 5>(p, stream);     // config 5 held to 96 registers: five workgroups per CU
+    // (measured and removed, round 4: <64, 128, 2, 2, 1, 3, 4> -- three stages at four workgroups per CU -- and <192, 128, 2, 2, 1, 2, 3>
+    // -- 688 workgroups for 768 slots, i.e. the decoder's 32896 rows without a last partial round: both within 2 % of configs 4 / 5 / 8
+    // on every launch of the forward (profiles/r04_g_gemm_pp_knobs.txt has the knob runs that go with it))
     default: return TGP_EINVAL;
     }
 }
