@@ -34,7 +34,8 @@ extern "C" int tgp_debug_set_pp_stamps(void *buf)
         tgp_pp_stamps[(size_t)blockIdx.x * 4 + (I)] = wall_clock64();                                 \
         if ((I) == 0 || (I) == 3) tgp_pp_stamps[(size_t)(1 << 18) + (size_t)blockIdx.x * 2 + ((I) == 3)] = __builtin_readcyclecounter(); \
     }
-// timing-only knobs (results are garbage): 1 = A fragments read once, 2 = W fragments read once, 4 = no LDS-DMA after the prologue
+// timing-only knobs (results are garbage): 1 = A fragments read once, 2 = W fragments read once, 4 = no LDS-DMA after the prologue,
+// 8 = no fragment reads and no MFMAs (the staging pipeline alone)
 __device__ int tgp_pp_knobs = 0;
 extern "C" int tgp_debug_set_pp_knobs(int v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(tgp_pp_knobs), &v, sizeof(v)); }
 #define PP_KNOB(B) (tgp_pp_knobs & (B))
@@ -145,6 +146,7 @@ __device__ __forceinline__ void gemm_pp_tile(const GemmParams &p, const int m0, 
 #pragma unroll
             for (int t = 0; t < KTS; ++t) {
                 if (KTS > 1 && s * KTS + t >= KT) break;                   // workgroup-uniform
+                if (PP_KNOB(8)) break;                                     // (timing only: the staging pipeline alone)
                 uint4 a[TM][2];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
