@@ -161,9 +161,13 @@ __device__ __forceinline__ void gemm_pp_tile(const GemmParams &p, const int m0, 
                         keep_a[i][q] = a[i][q];
 #endif
                     }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    uint4 b[2];
+                // The step's W fragments: all of them before the first MFMA where the registers allow (the small tile: +8), so that a
+                // step waits for LDS once.  Loaded column by column into ONE pair of registers -- what the larger wave tiles still do
+                // -- every column's reads sit behind the previous column's MFMAs with an lgkmcnt(0) in between: four LDS round
+                // trips per step of six MFMAs on the 64 x 128 tile.
+                constexpr bool ALLB = TM * TN <= 2;
+                uint4 bb[ALLB ? TN : 1][2];
+                auto load_b = [&](const int j, uint4 (&b)[2]) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
                     {
@@ -175,6 +179,16 @@ __device__ __forceinline__ void gemm_pp_tile(const GemmParams &p, const int m0, 
                         keep_b[j][q] = b[q];
 #endif
                     }
+                };
+                if constexpr (ALLB) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) load_b(j, bb[j]);
+                    __builtin_amdgcn_sched_barrier(0);                     // keep the reads up here: the scheduler sinks them to their uses
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (!ALLB) load_b(j, bb[0]);
+                    const uint4 (&b)[2] = bb[ALLB ? j : 0];
                     // smallest terms first, as in gemm_split_tile: hi x lo, lo x hi, hi x hi; consecutive MFMAs walk the column's accumulators
 #define PP_TERM(QA, QB)                                                                                                  \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                     \
