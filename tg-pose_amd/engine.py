@@ -256,6 +256,9 @@ HEADS_FUSED = True      # ... and the heads' conv1 -> conv2 -> max as one kernel
 # flight (the bench default): 17.7 k -> 15.3 k objects/s.  hipGraph runs a graph's extra branches on ONE pool of internal streams
 # per device shared by every graph in flight (DEBUG_HIP_FORCE_GRAPH_QUEUES / GPU_MAX_HW_QUEUES = 8 / 16 changed nothing), so the
 # branches of two replays queue behind each other.
+# (Round 4, the same for a third extra branch -- the up-sampling look-ups, the row sort and the sorted fine buffer beside conv_4, 70 us of
+# launches that need only coordinates and fm_0 / fm_1: one batch in flight 15.70 -> 15.74 k alone, 15.83 k with COARSE_SIDE alone, 15.36 k
+# with both.  Not kept.)
 COARSE_SIDE = os.environ.get("TGP_COARSE_SIDE", "0") != "0"
 # Eval forward without the layers whose results the six-key eval dict does not return (PH predictor, decoder: 30 % of the
 # reference's FLOPs).  A deployment switch; the bench's headline and every parity test run the full forward.
