@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TGP_ABI_VERSION 6
+#define TGP_ABI_VERSION 7
 #define TGP_EINVAL (-1)       /* null pointer / non-positive size / misaligned stride */
 #define TGP_EUNSUPPORTED (-2) /* shape outside what the kernels are built for */
 
@@ -634,39 +634,37 @@ int tgp_sort_by_parent(const int32_t *near1, const int32_t *near2, int B, int n,
 /* The pose heads' conv1 -> BatchNorm(eval) -> ReLU -> conv2 -> BatchNorm(eval) -> ReLU -> max over each object's points as one
  * kernel (PoseR.py:26-36 Rot_green / Rot_red, PoseTs.py:31-42 Pose_Ts; eval mode), on the factored form of conv1 (this repo's
  * engine): conv1(feat)[m] = W_fine . fine[m] + p1[idx1[m]] + p2[idx2[m]].  The (M, heads * 1024) activation is never written.
- *   fine (M, ldf) fp32, K = its live columns (256 < K <= 272 = ldf's first 17 K-tiles); wa_s = tgp_split_f16 planes of the heads'
- *   conv1 weights over fine, (heads * 1024) rows with ldo = 272; p1 / p2: rows of per-coarse-point products, columns
- *   head * 1024 + channel at the pointers given, row strides ldp1 / ldp2; idx1 / idx2 (M) rows of p1 / p2 per point;
- *   bias1 / scale1 / shift1 (heads * 1024): conv1 bias and BatchNorm fold; w2p = tgp_heads_pack_w2(conv2 weights);
+ *   fine (M, ldf) fp32, K = its live columns (256 < K <= 272 = ldf's first 17 K-tiles);
+ *   wa_planes (ABI 7) = the heads' conv1 weights over fine, (heads * 1024) rows x 272 columns, as BLOCKED fp16 planes
+ *   (tgp_planes_split with kts = 17: the layout of tgp_gemm_args.W_planes; one 32-channel block is 34 contiguous KB);
+ *   p1 / p2: rows of per-coarse-point products, columns head * 1024 + channel at the pointers given, row strides ldp1 / ldp2;
+ *   idx1 / idx2 (M) rows of p1 / p2 per point;
+ *   w2p (ABI 7) = tgp_heads_pack_w2(conv2 weights, conv1 bias and BatchNorm fold): tgp_heads_w2_bytes(heads) bytes;
  *   bias2 / scale2 / shift2 (heads * 256); keys (heads, B, 256) order-preserving keys of the maxima (tgp_colmax_decode), zeroed by
  *   the caller; M = B * rows_per_obj. */
 typedef struct tgp_heads_fused_args {
     const float *fine; int ldf; int K;
-    const void *wa_s;
+    const void *wa_planes;
     const float *p1; int ldp1; const int32_t *idx1;
     const float *p2; int ldp2; const int32_t *idx2;
-    const float *bias1; const float *scale1; const float *shift1;
     const void *w2p;
     const float *bias2; const float *scale2; const float *shift2;
     uint32_t *keys;
     int M; int rows_per_obj; int B; int heads;
-    /* fp16 range: a wave that meets a fine feature or a conv1 activation of magnitude >= 65504 (or a NaN) writes no keys for its
-     * 32 points and sets *overflow = 1 (device int, zeroed by the caller; NULL: such waves write NaN keys).  The caller then runs
-     * the two-launch form predicated on the flag (tgp_gemm_args.pred), which recomputes every key in guarded arithmetic. */
+    /* fp16 range: a wave whose fine features or conv1 activations leave fp16's range (a magnitude that rounds to infinity, a NaN: its
+     * conv2 sums are then non-finite), or whose fine features all lie under 2^-4, writes no keys for its 32 points and sets
+     * *overflow = 1 (device int, zeroed by the caller; NULL: such waves write whatever keys their sums give -- NaN keys are loud).
+     * The caller then runs the two-launch form predicated on the flag (tgp_gemm_args.pred), which recomputes every key in guarded
+     * arithmetic. */
     int *overflow;
     /* (ABI 4) rows > 0: only the first `rows` rows (a multiple of 128) of every head are processed here; the caller supplies the
      * keys of rows [rows, M) through tgp_gemm_f32 (row_base = rows), merging into the same key buffer.  The grid is
-     * heads x 128-point workgroups, one per CU and round: B = 32, N = 1028 is 771 workgroups = 3.01 rounds of 256, and the
-     * three workgroups of the fourth round cost a quarter of the kernel's time (profiles/r02_g_heads_fused_stamps.txt). */
+     * heads x 128-point workgroups, one per CU and round. */
     int rows;
     /* (ABI 5) fine_planes (may be NULL): the same features as blocked fp16 planes (tgp_gemm_args.A_planes' layout, fine_kt >= 17
      * K-tiles per row block, columns K.. zero; fine_amax: the per-row-block magnitude words, may be NULL): the kernel then loads its
      * points' operand fragments as 1 KB runs instead of splitting fp32 rows -- same bits.  `fine` is still required (the repair). */
     const void *fine_planes; int fine_kt; const uint32_t *fine_amax;
-    /* (ABI 5) workgroups: 0 = one per CU, each walking its share of the heads x 128-point tiles (the next tile's operands arrive
-     * during the current tile's last channel block); > 0: that many (>= the tile count: one tile per workgroup, the round-3 form;
-     * a measurement handle).  Results do not depend on it. */
-    int workgroups;
 } tgp_heads_fused_args;
 int tgp_heads_fused(const tgp_heads_fused_args *args, tgp_stream_t stream);
 /* conv -> BatchNorm(eval) -> LeakyReLU -> max over each object's points of a factored layer whose activation only feeds the max
@@ -686,8 +684,12 @@ typedef struct tgp_conv_max_fused_args {
     const void *fine_planes; int fine_kt; const uint32_t *fine_amax;      /* (ABI 5) as in tgp_heads_fused_args */
 } tgp_conv_max_fused_args;
 int tgp_conv_max_fused(const tgp_conv_max_fused_args *args, tgp_stream_t stream);
-/* w2 (heads, 256, 1024) fp32 -> heads * 1024 * 256 * 2 fp16 in the kernel's operand order (hi / lo planes, K permuted). */
-int tgp_heads_pack_w2(const float *w2, int heads, void *out, tgp_stream_t stream);
+/* (ABI 7) w2 (heads, 256, 1024) fp32 and the heads' conv1 bias / BatchNorm scale / shift (heads * 1024 each) -> the kernel's operand:
+ * per (head, block of 32 conv1 channels) 33 KB = conv2's fp16 hi / lo planes in MFMA fragment order (K permuted to the order the
+ * conv1 accumulators leave the channels in) + the block's bias | scale | shift.  out: tgp_heads_w2_bytes(heads) bytes, 16-byte aligned. */
+int64_t tgp_heads_w2_bytes(int heads);
+int tgp_heads_pack_w2(const float *w2, const float *bias1, const float *scale1, const float *shift1, int heads, void *out,
+                      tgp_stream_t stream);
 
 /* ---- the factored wide layers in TRAINING (ABI 4; this repo's engine, no reference counterpart: the reference multiplies the
  * up-sampled copies, FaceRecon.py:70-77) -----------------------------------------------------------------------------------------

@@ -2252,8 +2252,8 @@ def test_fused_kernels_vs_fp64(ops, B, N):
     b2, sc2, sh2 = (torch.randn(heads, 256, generator=gen) * 0.1, torch.rand(heads, 256, generator=gen) + 0.5, torch.randn(heads, 256, generator=gen) * 0.1)
     d = lambda t: g(t.contiguous())
     was = ops.split_f16(d(Wa))
-    keys2, over = ops.heads_fused(d(fine), K, was[1024:], d(P1)[:, 1024:], d(idx1), d(P2)[:, 1024:], d(idx2), d(bias)[1024:], d(scale)[1024:],
-                                  d(shift)[1024:], ops.heads_pack_w2(d(W2)), d(b2), d(sc2), d(sh2), B, N)
+    keys2, over = ops.heads_fused(d(fine), K, ops.heads_planes_w(d(Wa)[1024:]), d(P1)[:, 1024:], d(idx1), d(P2)[:, 1024:], d(idx2),
+                                  ops.heads_pack_w2(d(W2), d(bias)[1024:], d(scale)[1024:], d(shift)[1024:]), d(b2), d(sc2), d(sh2), B, N)
     keys5, over5 = ops.conv_max_fused(d(fine), K, was, d(P1), d(idx1), d(P2), d(idx2), d(bias)[:1024], d(scale)[:1024], d(shift)[:1024],
                                       0.2, B, N)
     assert int(over.item()) == 0 and int(over5.item()) == 0
@@ -2288,9 +2288,9 @@ def test_fused_kernels_flag_tiny_inputs(ops):
     W2 = torch.randn(heads, 256, 1024, generator=gen) / 32.0
     d = lambda t: g(t.contiguous())
     was = ops.split_f16(d(Wa))
-    keys2, over = ops.heads_fused(d(fine), K, was[1024:], d(P1)[:, 1024:], d(idx1), d(P2)[:, 1024:], d(idx2), d(z)[1024:], d(o)[1024:],
-                                  d(z)[1024:], ops.heads_pack_w2(d(W2)), d(z)[:768].view(3, 256), d(o)[:768].view(3, 256),
-                                  d(z)[:768].view(3, 256), B, N)
+    keys2, over = ops.heads_fused(d(fine), K, ops.heads_planes_w(d(Wa)[1024:]), d(P1)[:, 1024:], d(idx1), d(P2)[:, 1024:], d(idx2),
+                                  ops.heads_pack_w2(d(W2), d(z)[1024:], d(o)[1024:], d(z)[1024:]), d(z)[:768].view(3, 256),
+                                  d(o)[:768].view(3, 256), d(z)[:768].view(3, 256), B, N)
     keys5, over5 = ops.conv_max_fused(d(fine), K, was, d(P1), d(idx1), d(P2), d(idx2), d(z)[:1024], d(o)[:1024], d(z)[:1024], 0.2, B, N)
     assert int(over.item()) == 1 and int(over5.item()) == 1
     assert int(keys2.abs().max().item()) == 0 and int(keys5.abs().max().item()) == 0        # flagged waves wrote nothing
@@ -3678,12 +3678,11 @@ def test_ph_tail_on_keys_with_sigmoid_epilogue_vs_five_launches(ops):
     assert none is None and float((rb.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
 
 
-@pytest.mark.parametrize("B,N", [(9, 1028), (3, 300)])
-def test_heads_fused_persistent_and_planes_forms_bit_identical(ops, B, N):
-    """The fused heads kernel as a persistent grid (one workgroup per CU walking its tiles, the next tile's operands prefetched under
-    the current tile's last channel block) against one workgroup per tile, and with the points' fragments loaded from the fine
-    buffer's fp16 planes against the in-kernel split of its fp32 rows: the same MFMA sequence per wave either way -- every output
-    bit for bit.  B = 9, N = 1028 gives 219 tiles: under one per CU; B = 3, N = 300 a partial last 32-row block."""
+@pytest.mark.parametrize("B,N", [(9, 1028), (3, 300), (40, 1028)])
+def test_heads_fused_planes_and_split_forms_bit_identical(ops, B, N):
+    """The fused heads kernel with the points' fragments loaded from the fine buffer's fp16 planes against the in-kernel split of its
+    fp32 rows: the same MFMA sequence per wave either way -- every output bit for bit.  B = 9, N = 1028 gives 219 tiles: under one per
+    CU; B = 3, N = 300 a partial last 32-row block; B = 40 gives 966 tiles: several rounds of workgroups, a partial last tile."""
     from tgpose_amd import FLAGS
     net = _net(12)
     FLAGS.train = 0
@@ -3692,39 +3691,44 @@ def test_heads_fused_persistent_and_planes_forms_bit_identical(ops, B, N):
     i1 = torch.randperm(N)[: N // 4]
     smp = (i1, torch.randperm(N // 4)[: N // 16])
     got = []
-    for persistent, planes in ((True, True), (False, True), (True, False), (False, False)):
-        old = ops.HEADS_PERSISTENT, ops.HEADS_PLANES
-        ops.HEADS_PERSISTENT, ops.HEADS_PLANES = persistent, planes
+    for planes in (True, False):
+        old = ops.HEADS_PLANES
+        ops.HEADS_PLANES = planes
         try:
             with torch.no_grad():
                 got.append({k: v.clone() for k, v in net(g(pts), g(obj), sample_idx=smp).items()})
         finally:
-            ops.HEADS_PERSISTENT, ops.HEADS_PLANES = old
-    for other in got[1:]:
-        for k in got[0]:
-            assert torch.equal(got[0][k], other[k]), k
-
-
-def test_heads_fused_persistent_many_tiles_per_workgroup(ops):
-    """B = 40 objects of 1028 points: 3 x 322 = 966 tiles on 256 workgroups -- every workgroup walks three or four tiles, heads change
-    inside a workgroup's walk -- against one workgroup per tile."""
-    from tgpose_amd import FLAGS
-    net = _net(13)
-    FLAGS.train = 0
-    pts, obj = synth_points(40, 1028, 43)
-    got = []
-    torch.manual_seed(9)
-    i1 = torch.randperm(1028)[:257]
-    smp = (i1, torch.randperm(257)[:64])
-    for persistent in (True, False):
-        old, ops.HEADS_PERSISTENT = ops.HEADS_PERSISTENT, persistent
-        try:
-            with torch.no_grad():
-                got.append({k: v.clone() for k, v in net(g(pts), g(obj), sample_idx=smp).items()})
-        finally:
-            ops.HEADS_PERSISTENT = old
+            ops.HEADS_PLANES = old
     for k in got[0]:
         assert torch.equal(got[0][k], got[1][k]), k
+
+
+def test_heads_fused_keys_do_not_depend_on_the_batch_around_an_object(ops):
+    """The kernel's sums per point are a fixed sequence of products (channel blocks ascending, split terms in a fixed order) whatever
+    tile, wave or workgroup the point falls into: an object's keys inside a batch of 5 objects of 1001 points (waves straddle objects,
+    the last tile is partial) equal the keys of that object processed alone, bit for bit."""
+    gen = torch.Generator().manual_seed(77)
+    B, N, K, heads = 5, 1001, 268, 3
+    M = B * N
+    fine = torch.randn(M, 272, generator=gen)
+    fine[:, K:] = 0
+    Wa = torch.randn(heads * 1024, 272, generator=gen) / K ** 0.5
+    Wa[:, K:] = 0
+    n1, n2 = B * 250, B * 62
+    P1, P2 = torch.randn(n1, 3072, generator=gen), torch.randn(n2, 3072, generator=gen)
+    idx1 = torch.randint(0, n1, (M,), generator=gen, dtype=torch.int32)
+    idx2 = torch.randint(0, n2, (M,), generator=gen, dtype=torch.int32)
+    vec = [torch.randn(3072, generator=gen) * 0.1, torch.rand(3072, generator=gen) + 0.5, torch.randn(3072, generator=gen) * 0.1]
+    W2 = torch.randn(heads, 256, 1024, generator=gen) / 32.0
+    v2 = [torch.randn(heads, 256, generator=gen) * 0.1, torch.rand(heads, 256, generator=gen) + 0.5, torch.randn(heads, 256, generator=gen) * 0.1]
+    d = lambda t: g(t.contiguous())
+    wap, w2p = ops.heads_planes_w(d(Wa)), ops.heads_pack_w2(d(W2), *[d(v) for v in vec])
+    run = lambda rows, b: ops.heads_fused(d(fine[rows]), K, wap, d(P1), d(idx1[rows]), d(P2), d(idx2[rows]), w2p, *[d(v) for v in v2], b, N)
+    keys, over = run(slice(0, M), B)
+    assert int(over.item()) == 0
+    for b in (0, 3, 4):
+        kb, ob = run(slice(b * N, (b + 1) * N), 1)
+        assert int(ob.item()) == 0 and torch.equal(kb[:, 0], keys[:, b]), b
 
 
 @pytest.mark.parametrize("scale", [1.0, 1e6, 1e-5])

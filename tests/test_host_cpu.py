@@ -41,7 +41,7 @@ def test_c_abi_argument_errors_do_not_launch():
     a = _lib.GemmArgs()
     assert h.tgp_gemm_f32(a, None) == -1
     assert h.tgp_heads_fused(_lib.HeadsFusedArgs(), None) == -1 and h.tgp_conv_max_fused(_lib.ConvMaxFusedArgs(), None) == -1
-    assert h.tgp_heads_pack_w2(None, 3, None, None) == -1
+    assert h.tgp_heads_pack_w2(None, None, None, None, 3, None, None) == -1 and h.tgp_heads_w2_bytes(3) == 3 * 32 * 33 * 1024
     # (ABI 5) blocked fp16 planes: 2 KB per (32 rows, 16 columns) chunk; a split without buffers is refused
     assert h.tgp_planes_bytes(32896, 268) == 1028 * 17 * 2048 and h.tgp_planes_bytes(1, 1) == 2048 and h.tgp_planes_bytes(0, 16) == 0
     assert h.tgp_planes_split(None, 4, 16, 16, None, 1, None, None) == -1

@@ -71,10 +71,9 @@ class HeadsFusedArgs(ctypes.Structure):
     """struct tgp_heads_fused_args (include/tgpose.h)"""
     _fields_ = [
         ("fine", c_vp), ("ldf", c_int), ("K", c_int),
-        ("wa_s", c_vp),
+        ("wa_planes", c_vp),
         ("p1", c_vp), ("ldp1", c_int), ("idx1", c_vp),
         ("p2", c_vp), ("ldp2", c_int), ("idx2", c_vp),
-        ("bias1", c_vp), ("scale1", c_vp), ("shift1", c_vp),
         ("w2p", c_vp),
         ("bias2", c_vp), ("scale2", c_vp), ("shift2", c_vp),
         ("keys", c_vp),
@@ -82,7 +81,6 @@ class HeadsFusedArgs(ctypes.Structure):
         ("overflow", c_vp),
         ("rows", c_int),
         ("fine_planes", c_vp), ("fine_kt", c_int), ("fine_amax", c_vp),
-        ("workgroups", c_int),
     ]
 
 
@@ -181,7 +179,8 @@ SIGNATURES = {
     "tgp_canonicalize": (c_int, [c_vp] * 9 + [c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_heads_fused": (c_int, [ctypes.POINTER(HeadsFusedArgs), c_vp]),
     "tgp_conv_max_fused": (c_int, [ctypes.POINTER(ConvMaxFusedArgs), c_vp]),
-    "tgp_heads_pack_w2": (c_int, [c_vp, c_int, c_vp, c_vp]),
+    "tgp_heads_pack_w2": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "tgp_heads_w2_bytes": (c_i64, [c_int]),
     "tgp_sort_by_parent": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tgp_roi_cloud": (c_int, [c_vp] * 7 + [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_cloud_select": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, c_vp, c_vp]),
@@ -205,7 +204,7 @@ SIGNATURES = {
     "tgp_cloud_sample": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, ctypes.c_uint64, c_vp, c_vp]),
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 

@@ -287,12 +287,9 @@ static int gconv_lds_go(const float4 *dirs, const int32_t *idx, const float *pro
                         int C, float *out, int ldo, size_t lds, hipStream_t stream)
 {
     auto fn = gconv_lds_kernel<CH>;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static TgpLdsAttr attr;
+    if (lds > 64 * 1024)
+        if (const int e = tgp_lds_attr(attr, reinterpret_cast<const void *>(fn), 150 * 1024)) return e;
     const int threads = lds > 72 * 1024 ? 1024 : 512;
     hipLaunchKernelGGL(fn, dim3(tgp_xcd_grid(B, C / CH)), dim3(threads), lds, stream, dirs, idx, proj, ldp, sdn, B, n, k, C, out, ldo);
     return TGP_LAUNCH_RESULT();
@@ -631,14 +628,10 @@ static bool orl_lds_launch(const float *feat, int ldf, const int32_t *idx, int B
     rc = 0;
     const size_t lds = ((size_t)n * ORL_CH + (size_t)ptiles * 4 * ORL_CH + (planes ? n / 32 + 4 : 0)) * sizeof(float);
     if (!tgp_orl_lds_mode || lds > 72 * 1024 || C % ORL_CH) return false;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(orl_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
-        if (e != hipSuccess) {
-            rc = (int)e;
-            return true;
-        }
-        attr_set = true;
+    static TgpLdsAttr attr;
+    if (lds > 64 * 1024) {
+        rc = tgp_lds_attr(attr, reinterpret_cast<const void *>(orl_lds_kernel), 72 * 1024);
+        if (rc) return true;
     }
     const int slots = ptiles * 4 * (ORL_CH / 2);
     const int threads = slots >= 768 ? 1024 : (slots >= 384 ? 512 : 256);

@@ -1036,12 +1036,6 @@ __global__ __launch_bounds__(64 * SKINNY_WAVES) void skinny_gemm_kernel(GemmPara
     }
 }
 
-static int set_lds_limit(const void *fn, size_t lds)
-{
-    if (lds <= 64 * 1024) return 0; // > 64 KiB of dynamic LDS needs the opt-in
-    return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-}
-
 static int resident_slots(void)
 {
     static int slots = 0;
@@ -1278,12 +1272,8 @@ static int launch_main(GemmParams &p, hipStream_t stream)
     }
     const int total = q.tiles_big + q.tiles_m_small * q.tiles_n_small * q.batch;
     const size_t lds = (size_t)2 * (128 + 128) * (32 + GEMM_LDPAD) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        const int e = set_lds_limit(reinterpret_cast<const void *>(gemm_main256_kernel), lds);
-        if (e) return e;
-        attr_set = true;
-    }
+    static TgpLdsAttr attr;
+    if (const int e = tgp_lds_attr(attr, reinterpret_cast<const void *>(gemm_main256_kernel), (int)lds)) return e;
     hipLaunchKernelGGL(gemm_main256_kernel, dim3(total), dim3(256), lds, stream, q);
     return TGP_LAUNCH_RESULT();
 }

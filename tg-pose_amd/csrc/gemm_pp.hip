@@ -387,13 +387,8 @@ static int planes_launch(const float *X, int rows, int K, int ld, int C, char *o
                      (!dst || ((ldd & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0)) && C <= nkt * 16;
     if (vec) {
         const size_t lds = (size_t)32 * (nkt * 16 + 4) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(planes_rows_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 32 * (PLANES_ROWS_MAX_KT * 16 + 4) * 4);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
+        static TgpLdsAttr attr;
+        if (const int e = tgp_lds_attr(attr, reinterpret_cast<const void *>(planes_rows_kernel), 32 * (PLANES_ROWS_MAX_KT * 16 + 4) * 4)) return e;
         hipLaunchKernelGGL(planes_rows_kernel, dim3(nblk), dim3(256), lds, stream, X, rows, K, ld, C, out, kts, amax, idx, n_src, n_out, dst,
                            ldd, kt0, nkt);
         return TGP_LAUNCH_RESULT();
@@ -453,13 +448,9 @@ template <int BM, int BN, int NWM, int NWN, int KTS, int STAGES, int WPE>
 static int pp_launch(GemmParams &p, hipStream_t stream)
 {
     constexpr int lds = STAGES * ((BM + BN) / 32) * KTS * 2 * 1024;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_pp_kernel<BM, BN, NWM, NWN, KTS, STAGES, WPE>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static TgpLdsAttr attr;                    // (one per instance of this template)
+    if (lds > 64 * 1024)
+        if (const int e = tgp_lds_attr(attr, reinterpret_cast<const void *>(gemm_pp_kernel<BM, BN, NWM, NWN, KTS, STAGES, WPE>), lds)) return e;
     p.pp_tiles_m = tgp_cdiv(p.M, BM), p.pp_tiles_n = tgp_cdiv(p.N, BN);
     hipLaunchKernelGGL((gemm_pp_kernel<BM, BN, NWM, NWN, KTS, STAGES, WPE>), dim3(p.pp_tiles_m * p.pp_tiles_n), dim3(64 * NWM * NWN),
                        lds, stream, p);

@@ -160,13 +160,8 @@ extern "C" int tgp_gemm_tn_split(const float *a, int lda, const float *b, int ld
     TGP_REQUIRE((int64_t)Z * chunk >= rows);
     if ((N & 3) || (K & 3) || (lda & 3) || (ldb & 3) || ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15))
         return TGP_EUNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_split_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TS_STAGE);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static TgpLdsAttr attr;
+    if (const int e = tgp_lds_attr(attr, reinterpret_cast<const void *>(gemm_tn_split_kernel), 2 * TS_STAGE)) return e;
     const dim3 grid(tgp_cdiv(N, TS_T) * tgp_cdiv(K, TS_T), Z);
     hipLaunchKernelGGL(gemm_tn_split_kernel, grid, dim3(1024), 2 * TS_STAGE, tgp_hs(stream), a, lda, b, ldb, rows, N, K, scale, chunk, parts);
     return TGP_LAUNCH_RESULT();

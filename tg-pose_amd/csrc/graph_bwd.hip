@@ -80,13 +80,8 @@ extern "C" int tgp_reverse_graph(const int32_t *idx, int B, int n_rows, int k, i
     const size_t lds = ((size_t)n_rows * k + 2 * (size_t)n_src) * sizeof(int);
     if (k > 64 || n_src > RG_MAX_SRC || lds > RG_LDS_MAX || (int64_t)B * n_rows * k >= 0x7fffffff || n_rows >= (1 << 25))
         return TGP_EUNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(reverse_graph_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS_MAX);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static TgpLdsAttr attr;
+    if (const int e = tgp_lds_attr(attr, reinterpret_cast<const void *>(reverse_graph_kernel), RG_LDS_MAX)) return e;
     hipLaunchKernelGGL(reverse_graph_kernel, dim3(B, B < 64 ? 4 : 1), dim3(RG_THREADS), lds, tgp_hs(stream), idx, B, n_rows, k, n_src, rptr, rent);
     return TGP_LAUNCH_RESULT();
 }

@@ -3,17 +3,17 @@
 //
 // As two launches the path writes and re-reads the (B*N, 3 x 1024) activation (404 MB at B = 32) and spends most of its time in
 // the first launch's gather epilogue.  Here the activation never leaves the CU.  A wave owns 32 points of one head:
-//   phase 1, per block of 32 conv1 channels:  acc1[channel][point] = W_fine[channel][:] . fine[point][:]   (K = 268, 17 steps of
+//   conv1, per block of 32 channels:  acc1[channel][point] = W_fine[channel][:] . fine[point][:]   (K = 268, 17 steps of
 //            v_mfma_f32_32x32x16_f16 x 3 split terms; the weights' fp16 planes come from LDS, the points' from registers);
 //   epilogue 1 in registers: + bias + P1[near1(point)] + P2[near2(point)] (the coarse products of the factored layer), BatchNorm
 //            fold, ReLU -- in the two-launch form's order -- then split into fp16 hi / lo;
-//   phase 2: the MFMA accumulator layout gives lane (point r, half h) channels {4h + (e & 3) + 8 (e >> 2)} of the block: exactly a
+//   conv2:   the MFMA accumulator layout gives lane (point r, half h) channels {4h + (e & 3) + 8 (e >> 2)} of the block: exactly a
 //            32x32x16 A-operand fragment (8 k-values per lane) if conv2's K order is permuted accordingly.  The permutation is
 //            applied to W2 when it is packed (heads_pack_w2_kernel), so the 16 values feed two MFMA steps of
 //            acc2[point][out] += H[point][channels] . W2[out][channels] without touching LDS;
 //   after the 32 channel blocks: + bias2, BatchNorm fold, ReLU, max over the object's points as order-preserving keys (atomicMax).
 // One wave per SIMD (the points' fine features as B fragments: 136 registers, conv2's accumulators: 128), four waves per
-// workgroup sharing the LDS-staged weight blocks (double buffered: 2 x (34.5 + 36 KB)).
+// workgroup sharing the LDS-staged weight blocks (double buffered: 2 x 67 KB).
 #include "tgp_common.h"
 #include "../../include/tgpose.h"
 
@@ -26,28 +26,21 @@ typedef float hf32x16 __attribute__((ext_vector_type(16)));
 #define HF_C1 1024                  // conv1 channels per head
 #define HF_C2 256                   // conv2 channels per head
 #define HF_NCB (HF_C1 / 32)
-#define HF_AROW (HF_STEPS * 64 + 16)      // LDS row of the conv1 weight block: 17 steps x 2 planes x 32 B, + 16 B (conflict-free b128)
-#define HF_WROW (2 * 64 + 16)             // LDS row of the conv2 weight block: 2 steps x 2 planes x 32 B, + 16 B
-// every region a whole number of kilobytes: one LDS-DMA wave-instruction (64 lanes x 16 B) then lies inside one region
-#define HF_ABYTES (35 * 1024)             // 32 rows x 1104 B = 35328, padded
-#define HF_PBYTES 1024                    // bias | scale | shift of the block's 32 channels (384 B used)
-#define HF_WBYTES (HF_C2 * HF_WROW)       // 36864 = 36 KB
-#define HF_BUF (HF_ABYTES + HF_PBYTES + HF_WBYTES)
-#define HF_NDMA (HF_BUF / 1024 / 4)       // 18 wave-instructions per wave and block
+#define HF_AROW (HF_STEPS * 64 + 16)      // (conv_max_fused_kernel) LDS row of a conv weight block: 17 steps x 2 planes x 32 B, + 16 B (conflict-free b128)
 
 struct HeadsParams {
     const float *fine; int ldf, K;
-    const uint16_t *wa_s;                 // [heads * 1024][17][2][16] fp16
     const float *p1; int ldp1; const int32_t *idx1;
     const float *p2; int ldp2; const int32_t *idx2;
-    const float *bias1, *scale1, *shift1; // heads * 1024
-    const uint16_t *w2p;                  // [heads][32][256][2][2][16] fp16
     const float *bias2, *scale2, *shift2; // heads * 256
     uint32_t *keys;                       // (heads, B, 256)
     int *overflow;
     int M, rows_per_obj, B, heads, tiles;
-    // (round 4) the points' features as blocked fp16 planes (tgp_gemm_args.A_planes' layout): fragments load as 1 KB runs, no split
+    // the points' features as blocked fp16 planes (tgp_gemm_args.A_planes' layout): fragments load as 1 KB runs, no split
     const char *fine_pl; int fine_kt; const uint32_t *fine_amax;
+    const char *wa_pl;                     // conv1 weights of the heads as blocked planes: [head * 32 + block][17][2][h][r][8] fp16
+    const char *w2b;                       // [head][block][33 pieces]: conv2 weights [2 steps][8 out blocks][2 planes][h][r][8] fp16, K permuted; vectors
+    unsigned long long *stamps;            // (development build) per-wave cycle stamps
 };
 
 __device__ __forceinline__ void hf_split(const float4 v, uint2 &hi, uint2 &lo)
@@ -60,258 +53,392 @@ __device__ __forceinline__ void hf_split(const float4 v, uint2 &hi, uint2 &lo)
     lo = __builtin_bit_cast(uint2, l);
 }
 
-// PERSISTENT (round 4): the grid is one workgroup per CU and every workgroup walks the tiles t = blockIdx.x, + gridDim.x, ... (head-major,
-// so the workgroups running at any moment share a head's weights in L2).  As one workgroup per tile, a tile was prologue (34 strided
-// loads per lane + their split, the first weight block's DMA from cold) -> 32 channel blocks -> epilogue, and a quarter of a
-// workgroup's ~125 us lay outside the channel-block loop with nothing to overlap it (one wave per SIMD, 144 KB of LDS: nothing else
-// fits on the CU).  Here the next tile's operands arrive during the current tile's LAST channel block: its first weight block by
-// the same double-buffered DMA that feeds every block (the chain of blocks simply continues across tiles), its points' fragments by
-// loads issued right after the last use of the current ones (conv1 of block 31) and in flight under conv2 of block 31 and the
-// tile's epilogue.
-template <bool PLANES>
+// ------------------------------------------------------------------------------------------------------------------------
+// The heads kernel (round 5 form): every non-matrix instruction sits BETWEEN the matrix instructions.
+//
+// What the stamps and timing knobs of the round-2..4 kernel said (scripts/heads_time.py; per workgroup 227 k shader cycles at 1.8 GHz, 101 k of
+// them the 3168 MFMAs): with ONE wave per SIMD and in-order issue, a run of MFMAs that accumulate into the same registers blocks
+// the instruction stream -- each waits for its predecessor -- so whatever follows the run can hide behind its LAST MFMA only.
+// The old loop issues three dependent MFMAs, then the step's LDS reads, its DMA piece and (after conv1) 184 vector instructions
+// of epilogue 1 (that loop: git history, csrc/heads_fused.hip before round 5): their issue time ADDS to the matrix time (removing the DMA, the gathers, the fragment reads or epilogue 1 each
+// shortened the kernel by nearly that part's full issue time).  Here:
+//   * every MFMA is followed by its own slice of the other work, fenced by sched_barrier so that the compiler keeps it there: a gap
+//     holds <= ~24 cycles of issue (two fragment reads, or one DMA piece, or one gather, or 3-4 vector instructions);
+//   * iteration i runs conv1 of block i with epilogue 1 of block i - 1 in its gaps (stage A), then conv2 of block i - 1 with the
+//     gathers of block i, the DMA and the accumulator read-out in its gaps (stage B);
+//   * the weight images are FRAGMENT-BLOCKED in memory (conv1: the blocked planes of tgp_gemm_args.W_planes, one 32-channel block
+//     = 34 contiguous KB; conv2 + the block's bias | scale | shift: 33 contiguous 1 KB pieces per block in lane order), so an
+//     LDS-DMA piece is a linear 1 KB copy -- scalar base + one vector offset, no branches, no per-lane offset table, no row
+//     padding, 67 pieces per block instead of 72 -- and every fragment read is ds_read_b128 at base + 16 x lane + immediate;
+//   * epilogue 1 is 88 vector instructions per block instead of 184 (ReLU as max(v, -0), the low plane by one mixed-precision
+//     fma per element, no per-block range tracking: a magnitude beyond fp16's range makes every conv2 sum of its point
+//     non-finite, which epilogue 2 sees);
+//   * epilogue 2 is branch-free, its 24 per-lane vectors loaded under the last block's conv2.
+// Same products in the same order as that kernel: bit-identical keys (checked against it on the benchmark's shape and on odd ones
+// before it was removed).
+#define HP_APIECES (2 * HF_STEPS)          // conv1 weight block: 17 K-tiles x 2 planes
+#define HP_WPIECES 33                      // conv2 weight block (2 steps x 8 out blocks x 2 planes) + 1 piece of epilogue vectors
+#define HP_PPIECE (HP_APIECES + 32)        // bias | scale | shift of the block (384 B used)
+#define HP_PIECES (HP_APIECES + HP_WPIECES)   // 67
+#define HP_BUF (HP_PIECES * 1024)
+#define HP_NDMA ((HP_PIECES + 3) / 4)      // 17 wave-instructions per wave and unit (piece j = 4 j0 + wave; piece 67 does not exist)
+#define HP_DMA_A 10                        // DMA pieces of a unit issued in stage A (one per K-step from step 0), the other 7 in stage B
+#define HP_SB() __builtin_amdgcn_sched_barrier(0)
+
+template <bool PLANES, bool STAMPS, int KNOB = 0>
 __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char hf_smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int total = p.heads * p.tiles;
-    int t = blockIdx.x;
-    if (t >= total) return;
+    const int t = blockIdx.x;
+    if (t >= p.heads * p.tiles) return;
+    const int hd = t / p.tiles, ptile = t - hd * p.tiles;
+    const int m0 = ptile * 128 + wave * 32;                     // the wave's first point (may lie past M: then the wave only helps staging)
+    const int row = min(m0 + r, p.M - 1);
+#define HP_T() (STAMPS ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
+    const unsigned long long t_entry = HP_T(), w_entry = STAMPS ? wall_clock64() : 0ull;
+    unsigned long long t_a = 0, t_b = 0, t_bar = 0;
 
-    uint4 bh[HF_STEPS], bl[HF_STEPS];     // the wave's points as B fragments: fp16 hi / lo planes of fine[row][16 s + 8 h .. + 7]
-    // range guard state of the tile being loaded: the largest magnitude this lane splits into fp16 (NaN-poisoned once it met a NaN
-    // or an infinity); with planes, the producer's per-block magnitude word says the same
-    float amax_ld = 0.f, poison_ld = 0.f;
-    const int nblk = (p.M + 31) >> 5;
-    auto load_b = [&](const int ptile) {
-        const int m0 = ptile * 128 + wave * 32;
-        amax_ld = 0.f, poison_ld = 0.f;
-        if constexpr (PLANES) {
-            const int rb = min(m0 >> 5, nblk - 1);
-            const char *src = p.fine_pl + (int64_t)rb * p.fine_kt * 2048 + lane * 16;
-#pragma unroll
-            for (int s = 0; s < HF_STEPS; ++s) {
-                bh[s] = *reinterpret_cast<const uint4 *>(src + s * 2048);
-                bl[s] = *reinterpret_cast<const uint4 *>(src + s * 2048 + 1024);
-            }
-            if (m0 + 32 > p.M) {                                    // (wave-uniform) rows past the end were never written: zero them
-                const bool dead = m0 + r >= p.M;
-#pragma unroll
-                for (int s = 0; s < HF_STEPS; ++s)
-                    if (dead) bh[s] = make_uint4(0u, 0u, 0u, 0u), bl[s] = make_uint4(0u, 0u, 0u, 0u);
-            }
-            const uint32_t am = p.fine_amax ? p.fine_amax[rb] : 0x3f800000u;
-            amax_ld = __uint_as_float(am < 0x7f800000u ? am : 0x7f800000u);   // inf for an inf / NaN block: !(amax < 65504) below
-        } else {
-            const int row = min(m0 + r, p.M - 1);
-            const float *fr = p.fine + (int64_t)row * p.ldf + 8 * h;
-#pragma unroll
-            for (int s = 0; s < HF_STEPS; ++s) {
-                float4 v0 = *reinterpret_cast<const float4 *>(fr + 16 * s), v1 = *reinterpret_cast<const float4 *>(fr + 16 * s + 4);
-                if (s == HF_STEPS - 1) {                            // the K tail: columns >= K are not the caller's to define
-                    const int k0 = 16 * s + 8 * h;
-                    v0.x = k0 + 0 < p.K ? v0.x : 0.f, v0.y = k0 + 1 < p.K ? v0.y : 0.f, v0.z = k0 + 2 < p.K ? v0.z : 0.f, v0.w = k0 + 3 < p.K ? v0.w : 0.f;
-                    v1.x = k0 + 4 < p.K ? v1.x : 0.f, v1.y = k0 + 5 < p.K ? v1.y : 0.f, v1.z = k0 + 6 < p.K ? v1.z : 0.f, v1.w = k0 + 7 < p.K ? v1.w : 0.f;
-                }
-                amax_ld = fmaxf(amax_ld, fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))));
-                amax_ld = fmaxf(amax_ld, fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w))));
-                poison_ld += 0.f * (((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w)));
-                uint2 h0, l0, h1, l1;
-                hf_split(v0, h0, l0), hf_split(v1, h1, l1);
-                bh[s] = make_uint4(h0.x, h0.y, h1.x, h1.y), bl[s] = make_uint4(l0.x, l0.y, l1.x, l1.y);
-            }
+    // ---- staging of a unit u = { conv1 weights of block u + 1 | conv2 weights and epilogue vectors of block u } into buffer buf: piece
+    // j = 4 j0 + wave is 1 KB at offset 1024 j of the buffer and of the unit's image in memory (pieces 0 .. 33 from the conv1
+    // planes, 34 .. 66 from the conv2 image), so a piece is { LDS base + 4096 j0, scalar source base, vector offset + 4096 j0 }
+    const uint32_t voff0 = lane * 16 + wave * 1024;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)hf_smem) + wave * 1024;
+    const char *a_src, *w_src, *mid_src;                         // scalar bases of the unit being staged (set per iteration)
+    auto dma_unit = [&](const int u) {
+        const int ua = u + 1 < HF_NCB ? u + 1 : HF_NCB - 1;     // (the last unit has no next conv1 block: it re-reads the last one)
+        a_src = p.wa_pl + (int64_t)(hd * HF_NCB + ua) * (HP_APIECES * 1024);
+        w_src = p.w2b + (int64_t)(hd * HF_NCB + (u < 0 ? 0 : u)) * (HP_WPIECES * 1024) - HP_APIECES * 1024;
+        mid_src = wave < 2 ? a_src : w_src;                      // pieces 32 .. 35: two of each image
+    };
+    auto dma = [&](const int buf, const int j0) {
+        if (KNOB & 1) return;
+        const char *src = j0 * 4 + 3 < HP_APIECES ? a_src : j0 * 4 >= HP_APIECES ? w_src : mid_src;
+        if (j0 == HP_NDMA - 1 && (HP_PIECES & 3) != 0) {         // the last round of pieces is short: wave 3 repeats its previous piece
+            const uint32_t lds = lds0 + buf * HP_BUF + (wave < (HP_PIECES & 3) ? j0 : j0 - 1) * 4096;
+            const uint32_t vo = voff0 + (wave < (HP_PIECES & 3) ? j0 : j0 - 1) * 4096;
+            asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(src), "{m0}"(lds) : "memory");
+            return;
         }
+        const uint32_t lds = lds0 + buf * HP_BUF + j0 * 4096;
+        const uint32_t vo = voff0 + j0 * 4096;
+        // inline assembly: opaque to the compiler's counters (no vmcnt(0) before the LDS reads that follow); vmcnt(0) is written by
+        // hand before the barrier that ends an iteration.  The LDS base travels in m0 as a register-constrained input.
+        asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(src), "{m0}"(lds) : "memory");
     };
 
-    // ---- staging of a channel block: conv1 weight rows, their epilogue vectors, the permuted conv2 weight block, by LDS-DMA
-    // (global_load_lds_dwordx4: no register destination).  A wave-instruction fills 1 KB of LDS linearly (wave-uniform base + 16 x
-    // lane), so the padded image is written as it lies: kilobyte j of the buffer is wave (j % 4)'s instruction j / 4; a lane that
-    // lands on a row's padding piece re-reads the row's last piece.  Issued one at a time between the MFMA groups.
-    static_assert(HF_NDMA == 18 && HF_ABYTES / 1024 == 35, "the region tests below");
-    int dma_off[HF_NDMA];                                       // the lane's source offset of its j0-th instruction (block-invariant)
+    // the first unit (its conv1 half: weights of block 0), then the wave's points as B fragments: fp16 hi / lo planes of fine[row][16 s + 8 h .. + 7]
+    dma_unit(-1);
+    {
+        const char *keep = w_src;
+        w_src = a_src, mid_src = a_src;                          // (conv2 pieces of "unit -1": any valid source, never read)
 #pragma unroll
-    for (int j0 = 0; j0 < HF_NDMA; ++j0) {
-        const int j = j0 * 4 + wave;
-        if (j < 35) {                                            // conv1 weight rows: 69 pieces per LDS row, 68 in memory
-            const int c = j * 64 + lane, rw = c / 69, pc = c % 69;
-            dma_off[j0] = rw < 32 ? (rw * 68 + (pc < 68 ? pc : 67)) * 16 : 0;
-        } else if (j == 35) {                                    // bias | scale | shift: 8 pieces each
-            dma_off[j0] = lane < 24 ? (lane & 7) * 16 : 0;
-        } else {                                                 // conv2 weight rows: 9 pieces per LDS row, 8 in memory
-            const int c = (j - 36) * 64 + lane, rw = c / 9, pc = c % 9;
-            dma_off[j0] = (rw * 8 + (pc < 8 ? pc : 7)) * 16;
+        for (int j0 = 0; j0 <= (HP_APIECES - 1) / 4; ++j0) {
+            const uint32_t lds = lds0 + j0 * 4096;
+            const uint32_t vo = voff0 + j0 * 4096;
+            if (j0 * 4 + 3 < HP_APIECES || wave < (HP_APIECES & 3))
+                asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(a_src), "{m0}"(lds) : "memory");
+        }
+        w_src = keep;
+    }
+    uint4 bh[HF_STEPS], bl[HF_STEPS];
+    float amax_in = 0.f, poison_in = 0.f;
+    if constexpr (PLANES) {
+        const int nblk = (p.M + 31) >> 5;
+        const int rb = min(m0 >> 5, nblk - 1);
+        const char *src = p.fine_pl + (int64_t)rb * p.fine_kt * 2048 + lane * 16;
+#pragma unroll
+        for (int s = 0; s < HF_STEPS; ++s) {
+            bh[s] = *reinterpret_cast<const uint4 *>(src + s * 2048);
+            bl[s] = *reinterpret_cast<const uint4 *>(src + s * 2048 + 1024);
+        }
+        if (m0 + 32 > p.M) {                                        // (wave-uniform) rows past the end were never written: zero them
+            const bool dead = m0 + r >= p.M;
+#pragma unroll
+            for (int s = 0; s < HF_STEPS; ++s)
+                if (dead) bh[s] = make_uint4(0u, 0u, 0u, 0u), bl[s] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        const uint32_t am = p.fine_amax ? p.fine_amax[rb] : 0x3f800000u;
+        amax_in = __uint_as_float(am < 0x7f800000u ? am : 0x7f800000u);   // inf for an inf / NaN block: !(amax < 65504) below
+    } else {
+        const float *fr = p.fine + (int64_t)row * p.ldf + 8 * h;
+#pragma unroll
+        for (int s = 0; s < HF_STEPS; ++s) {
+            float4 v0 = *reinterpret_cast<const float4 *>(fr + 16 * s), v1 = *reinterpret_cast<const float4 *>(fr + 16 * s + 4);
+            if (s == HF_STEPS - 1) {                                // the K tail: columns >= K are not the caller's to define
+                const int k0 = 16 * s + 8 * h;
+                v0.x = k0 + 0 < p.K ? v0.x : 0.f, v0.y = k0 + 1 < p.K ? v0.y : 0.f, v0.z = k0 + 2 < p.K ? v0.z : 0.f, v0.w = k0 + 3 < p.K ? v0.w : 0.f;
+                v1.x = k0 + 4 < p.K ? v1.x : 0.f, v1.y = k0 + 5 < p.K ? v1.y : 0.f, v1.z = k0 + 6 < p.K ? v1.z : 0.f, v1.w = k0 + 7 < p.K ? v1.w : 0.f;
+            }
+            amax_in = fmaxf(amax_in, fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))));
+            amax_in = fmaxf(amax_in, fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w))));
+            poison_in += 0.f * (((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w)));
+            uint2 h0, l0, h1, l1;
+            hf_split(v0, h0, l0), hf_split(v1, h1, l1);
+            bh[s] = make_uint4(h0.x, h0.y, h1.x, h1.y), bl[s] = make_uint4(l0.x, l0.y, l1.x, l1.y);
         }
     }
-    auto dma = [&](const int hd, const int cb, const int buf, const int j0) {
-        const int j = j0 * 4 + wave;                             // wave-uniform
-        const char *src;
-        if (j < 35) src = reinterpret_cast<const char *>(p.wa_s) + ((int64_t)hd * HF_C1 + cb * 32) * (HF_STEPS * 64);
-        else if (j == 35) {
-            const float *v = lane < 8 ? p.bias1 : lane < 16 ? p.scale1 : p.shift1;
-            src = reinterpret_cast<const char *>(v + hd * HF_C1 + cb * 32);
-        } else src = reinterpret_cast<const char *>(p.w2p) + ((int64_t)hd * HF_NCB + cb) * (HF_C2 * 128);
-        // inline assembly: opaque to the compiler's counters (no vmcnt(0) before the LDS reads that follow); vmcnt(0) is written by
-        // hand before the barrier that ends a block.  The LDS base travels in m0 as a register-constrained input.
-        const uint32_t lds = __builtin_amdgcn_readfirstlane(
-            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)(hf_smem + buf * HF_BUF + j * 1024));
-        asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + dma_off[j0]), "{m0}"(lds) : "memory");
+    const int i1 = p.idx1[row], i2 = p.idx2[row];
+    const float *g1p = p.p1 + (int64_t)i1 * p.ldp1 + hd * HF_C1 + 4 * h;           // + cb * 32 + 8 m: four channels of the lane
+    const float *g2p = p.p2 + (int64_t)i2 * p.ldp2 + hd * HF_C1 + 4 * h;
+
+    hf32x16 acc2[HF_C2 / 32];
+#pragma unroll
+    for (int ob = 0; ob < HF_C2 / 32; ++ob)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[ob][e] = 0.f;
+
+    float4 g1[4], g2[4];                   // the lane's gathered coarse products of the block whose epilogue 1 comes next
+    float pre[16];                         // that block's conv1 sums (element e: channel 4 h + (e & 3) + 8 (e >> 2), point r)
+    uint4 a2h[2], a2l[2];                  // ... and its activations as conv2's A fragments
+    auto gather1 = [&](const int cb, const int k) {                // k = 0 .. 7: one 16-byte load
+        const int m = k >> 1;
+        if (KNOB & 2) { (k & 1 ? g2[m] : g1[m]) = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+        if (k & 1) g2[m] = *reinterpret_cast<const float4 *>(g2p + cb * 32 + 8 * m);
+        else g1[m] = *reinterpret_cast<const float4 *>(g1p + cb * 32 + 8 * m);
     };
 
-    int hd = t / p.tiles, ptile = t - hd * p.tiles;
-    load_b(ptile);
+    // ---- epilogue 1 of a block in slices, one per MFMA gap of the next block's conv1 (k = 0 .. 33): group m (four channels of the lane)
+    // computes at k = 8 m + 2 .. 8 m + 7 on vectors read three gaps earlier; element by element in the two-launch form's order:
+    // + bias, + P1 row, + P2 row, BatchNorm fold, ReLU, fp16 hi / lo
+    float4 e_b, e_sc, e_sh, e_v;
+    uint2 hh[4], ll[4];
+    float e_lo[4];
+    auto epi1_read = [&](const char *base, const int m) {
+        const float *pv = reinterpret_cast<const float *>(base + HP_PPIECE * 1024) + 4 * h + 8 * m;
+        e_b = *reinterpret_cast<const float4 *>(pv), e_sc = *reinterpret_cast<const float4 *>(pv + 32);
+        e_sh = *reinterpret_cast<const float4 *>(pv + 64);
+    };
+    auto epi1 = [&](const char *base, const int k) {
+        if (k >= 7 && (k - 7) % 8 == 0 && (k - 7) / 8 + 1 < 4) epi1_read(base, (k - 7) / 8 + 1);     // k = 7, 15, 23: the next group's vectors
+        if (k < 2) return;
+        const int m = (k - 2) >> 3, ph = (k - 2) & 7;             // four vector instructions per gap
+        if (ph == 0) {
+            e_v = make_float4(pre[4 * m], pre[4 * m + 1], pre[4 * m + 2], pre[4 * m + 3]);
+            e_v.x += e_b.x, e_v.y += e_b.y, e_v.z += e_b.z, e_v.w += e_b.w;
+        } else if (ph == 1) {
+            e_v.x += g1[m].x, e_v.y += g1[m].y, e_v.z += g1[m].z, e_v.w += g1[m].w;
+        } else if (ph == 2) {
+            e_v.x += g2[m].x, e_v.y += g2[m].y, e_v.z += g2[m].z, e_v.w += g2[m].w;
+        } else if (ph == 3) {
+            e_v.x *= e_sc.x, e_v.y *= e_sc.y, e_v.z *= e_sc.z, e_v.w *= e_sc.w;
+        } else if (ph == 4) {
+            e_v.x += e_sh.x, e_v.y += e_sh.y, e_v.z += e_sh.z, e_v.w += e_sh.w;
+        } else if (ph == 5) {
+            // ReLU as max(v, -0): v for v > 0, +0 for +0, -0 for v < 0 and for -0 -- what `v > 0 ? v : v * 0` gives for every number.  A
+            // NaN would become -0 here; an infinity stays: either makes the point's conv2 sums non-finite through the planes of
+            // the block that produced it (an infinity) or came from non-finite operands (the input guard): epilogue 2 flags both
+            e_v.x = fmaxf(e_v.x, -0.f), e_v.y = fmaxf(e_v.y, -0.f), e_v.z = fmaxf(e_v.z, -0.f), e_v.w = fmaxf(e_v.w, -0.f);
+        } else if (ph == 6) {
+            // hi = fp16(v); lo = fp16(v - hi), the difference by one mixed-precision fma per element (hi -> fp32 is exact, one rounding:
+            // the value hf_split's convert-and-subtract gives)
+            const hf32x4 x = {e_v.x, e_v.y, e_v.z, e_v.w};
+            hh[m] = __builtin_bit_cast(uint2, __builtin_convertvector(x, hf16x4));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(e_lo[0]) : "v"(hh[m].x), "v"(e_v.x));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(e_lo[1]) : "v"(hh[m].x), "v"(e_v.y));
+        } else {
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(e_lo[2]) : "v"(hh[m].y), "v"(e_v.z));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(e_lo[3]) : "v"(hh[m].y), "v"(e_v.w));
+            const hf32x4 rest = {e_lo[0], e_lo[1], e_lo[2], e_lo[3]};
+            ll[m] = __builtin_bit_cast(uint2, __builtin_convertvector(rest, hf16x4));
+        }
+    };
+    auto epi1_pack = [&]() {
+        a2h[0] = make_uint4(hh[0].x, hh[0].y, hh[1].x, hh[1].y), a2h[1] = make_uint4(hh[2].x, hh[2].y, hh[3].x, hh[3].y);
+        a2l[0] = make_uint4(ll[0].x, ll[0].y, ll[1].x, ll[1].y), a2l[1] = make_uint4(ll[2].x, ll[2].y, ll[3].x, ll[3].y);
+    };
+
+    // ---- stage A: conv1 of block i (32 channels x 32 points, 17 steps x 3 split terms).  Gap 3 s: the fragments of step s + 2 and
+    // a DMA piece; gaps 3 s + 1, 3 s + 2: slices 2 s, 2 s + 1 of the previous block's epilogue 1
+    hf32x16 acc1;
+    auto stage_a = [&](const char *base, const bool with_e1, const int wbuf, const bool all_dma) {
 #pragma unroll
-    for (int j0 = 0; j0 < HF_NDMA; ++j0) dma(hd, 0, 0, j0);
+        for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
+        const char *arow = base + lane * 16;
+        // fragments two steps ahead of their MFMAs: with one wave per SIMD nothing else hides the LDS latency
+        uint4 fh0 = *reinterpret_cast<const uint4 *>(arow), fl0 = *reinterpret_cast<const uint4 *>(arow + 1024);
+        uint4 fh1 = *reinterpret_cast<const uint4 *>(arow + 2048), fl1 = *reinterpret_cast<const uint4 *>(arow + 3072);
+        if (with_e1) epi1_read(base, 0);
+        HP_SB();
+#pragma unroll
+        for (int s = 0; s < HF_STEPS; ++s) {
+            uint4 fh2 = fh1, fl2 = fl1;
+            // smallest terms first, as in the tile kernel: lo x hi, hi x lo, hi x hi
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, fl0), __builtin_bit_cast(hf16x8, bh[s]), acc1, 0, 0, 0);
+            HP_SB();
+            if (s + 2 < HF_STEPS && !(KNOB & 4)) {
+                fh2 = *reinterpret_cast<const uint4 *>(arow + (s + 2) * 2048);
+                fl2 = *reinterpret_cast<const uint4 *>(arow + (s + 2) * 2048 + 1024);
+            }
+            // the next unit's pieces target the other buffer, whose last readers passed the barrier
+            if (all_dma) dma(wbuf, s);
+            else if (s < HP_DMA_A) dma(wbuf, s);
+            HP_SB();
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, fh0), __builtin_bit_cast(hf16x8, bl[s]), acc1, 0, 0, 0);
+            HP_SB();
+            if (with_e1) epi1(base, 2 * s);
+            HP_SB();
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, fh0), __builtin_bit_cast(hf16x8, bh[s]), acc1, 0, 0, 0);
+            HP_SB();
+            if (with_e1) epi1(base, 2 * s + 1);
+            HP_SB();
+            fh0 = fh1, fl0 = fl1, fh1 = fh2, fl1 = fl2;
+        }
+        if (with_e1) epi1_pack();
+    };
+    // ---- stage B: conv2 partial sums over the PREVIOUS block's 32 channels (32 points x 256 outputs, 2 steps x 8 out blocks x 3 terms).
+    // Gap 3 q: the fragments of group q + 2; gap 3 q + 1: a DMA piece (q <= 8); gap 3 q + 2: one gather of this block (q <= 7), then
+    // its conv1 sums out of the accumulators, two per gap
+    auto stage_b = [&](const char *base, const int gcb, const bool copy_pre, const bool stage, const int wbuf) {
+        const char *wrow = base + HP_APIECES * 1024 + lane * 16;
+        constexpr int NQ = 2 * (HF_C2 / 32);
+        auto wfrag = [&](int q, int plane) { return *reinterpret_cast<const uint4 *>(wrow + (q * 2 + plane) * 1024); };
+        uint4 wh0 = wfrag(0, 0), wl0 = wfrag(0, 1), wh1 = wfrag(1, 0), wl1 = wfrag(1, 1);
+        HP_SB();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            uint4 wh2 = wh1, wl2 = wl1;
+            const int s2 = q / (HF_C2 / 32), ob = q % (HF_C2 / 32);
+            acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2h[s2]), __builtin_bit_cast(hf16x8, wl0), acc2[ob], 0, 0, 0);
+            HP_SB();
+            if (q + 2 < NQ && !(KNOB & 4)) wh2 = wfrag(q + 2, 0), wl2 = wfrag(q + 2, 1);
+            HP_SB();
+            acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2l[s2]), __builtin_bit_cast(hf16x8, wh0), acc2[ob], 0, 0, 0);
+            HP_SB();
+            if (stage && q + HP_DMA_A < HP_NDMA) dma(wbuf, q + HP_DMA_A);
+            HP_SB();
+            acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2h[s2]), __builtin_bit_cast(hf16x8, wh0), acc2[ob], 0, 0, 0);
+            HP_SB();
+            if (gcb >= 0 && q < 8) gather1(gcb, q);
+            if (copy_pre && q >= 8) pre[2 * (q - 8)] = acc1[2 * (q - 8)], pre[2 * (q - 8) + 1] = acc1[2 * (q - 8) + 1];
+            HP_SB();
+            wh0 = wh1, wl0 = wl1, wh1 = wh2, wl1 = wl2;
+        }
+    };
+
     __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0): this wave's DMA has landed
     __syncthreads();
+    const unsigned long long t_pro = HP_T();
 
-    int par = 0;                                                // LDS buffer of the current channel block (blocks alternate across tiles too)
-    for (;;) {
-        const int tn = t + (int)gridDim.x;
-        const bool more = tn < total;
-        const int hd_n = more ? tn / p.tiles : hd, ptile_n = more ? tn - hd_n * p.tiles : ptile;
-        const int m0 = ptile * 128 + wave * 32;                 // the wave's first point (may lie past M: then the wave only helps staging)
-        const int row = min(m0 + r, p.M - 1);
-        float amax = amax_ld, poison = poison_ld;
-        const float amax_in = amax_ld;
-        const int i1 = p.idx1[row], i2 = p.idx2[row];
-        const float *g1p = p.p1 + (int64_t)i1 * p.ldp1 + hd * HF_C1 + 4 * h;       // + cb * 32 + 8 m: four channels of the lane
-        const float *g2p = p.p2 + (int64_t)i2 * p.ldp2 + hd * HF_C1 + 4 * h;
-
-        hf32x16 acc2[HF_C2 / 32];
+    // iteration 0: conv1 of block 0, gathers of block 0, the whole unit 0 (no conv2 to spread it through)
 #pragma unroll
-        for (int ob = 0; ob < HF_C2 / 32; ++ob)
+    for (int k = 0; k < 8; ++k) gather1(0, k);
+    dma_unit(0);
+    stage_a(hf_smem, false, 1, true);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc2[ob][e] = 0.f;
-
-        for (int cb = 0; cb < HF_NCB; ++cb, par ^= 1) {
-            const char *base = hf_smem + par * HF_BUF;
-            const bool last = cb + 1 == HF_NCB;
-            const bool stage = !last || more;                    // a block follows: this tile's next one, or the next tile's first
-            const int hd_s = last ? hd_n : hd, cb_s = last ? 0 : cb + 1;
-            // the lane's gathered coarse products for this block: consumed after phase 1
-            float4 g1[4], g2[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                g1[m] = *reinterpret_cast<const float4 *>(g1p + cb * 32 + 8 * m);
-                g2[m] = *reinterpret_cast<const float4 *>(g2p + cb * 32 + 8 * m);
-            }
-            // ---- phase 1: conv1, 32 channels x 32 points
-            hf32x16 acc1;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
-            const char *arow = base + r * HF_AROW + h * 16;
-            {
-                // fragments two steps ahead of their MFMAs: with one wave per SIMD nothing else hides the LDS latency
-                uint4 fh0 = *reinterpret_cast<const uint4 *>(arow), fl0 = *reinterpret_cast<const uint4 *>(arow + 32);
-                uint4 fh1 = *reinterpret_cast<const uint4 *>(arow + 64), fl1 = *reinterpret_cast<const uint4 *>(arow + 64 + 32);
-#pragma unroll
-                for (int s = 0; s < HF_STEPS; ++s) {
-                    uint4 fh2 = fh1, fl2 = fl1;
-                    if (s + 2 < HF_STEPS) {
-                        fh2 = *reinterpret_cast<const uint4 *>(arow + (s + 2) * 64);
-                        fl2 = *reinterpret_cast<const uint4 *>(arow + (s + 2) * 64 + 32);
-                    }
-                    // smallest terms first, as in the tile kernel: lo x hi, hi x lo, hi x hi
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, fl0), __builtin_bit_cast(hf16x8, bh[s]), acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, fh0), __builtin_bit_cast(hf16x8, bl[s]), acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, fh0), __builtin_bit_cast(hf16x8, bh[s]), acc1, 0, 0, 0);
-                    // the next block's operands, 8 of the 18 pieces here (the rest in phase 2): they target the other buffer, whose
-                    // last readers passed the barrier
-                    if (s >= 1 && s <= 8 && stage) dma(hd_s, cb_s, par ^ 1, s - 1);
-                    __builtin_amdgcn_sched_barrier(0);                // keep the lookahead: do not sink the reads to their uses
-                    fh0 = fh1, fl0 = fl1, fh1 = fh2, fl1 = fl2;
-                }
-            }
-            // the current points' fragments have had their last use: the next tile's start to arrive under conv2 and the epilogue
-            if (last && more) load_b(ptile_n);
-            // ---- epilogue 1: element e of the lane is channel 4 h + (e & 3) + 8 (e >> 2) of the block, point r
-            uint4 a2h[2], a2l[2];
-            {
-                const float *pv = reinterpret_cast<const float *>(base + HF_ABYTES) + 4 * h;
-                uint2 hh[4], ll[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const float4 b = *reinterpret_cast<const float4 *>(pv + 8 * m), sc = *reinterpret_cast<const float4 *>(pv + 32 + 8 * m),
-                                 sh = *reinterpret_cast<const float4 *>(pv + 64 + 8 * m);
-                    float4 v = make_float4(acc1[4 * m], acc1[4 * m + 1], acc1[4 * m + 2], acc1[4 * m + 3]);
-                    v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
-                    v.x += g1[m].x, v.y += g1[m].y, v.z += g1[m].z, v.w += g1[m].w;
-                    v.x += g2[m].x, v.y += g2[m].y, v.z += g2[m].z, v.w += g2[m].w;
-                    v.x = v.x * sc.x + sh.x, v.y = v.y * sc.y + sh.y, v.z = v.z * sc.z + sh.z, v.w = v.w * sc.w + sh.w;
-                    v.x = v.x > 0.f ? v.x : v.x * 0.f, v.y = v.y > 0.f ? v.y : v.y * 0.f;
-                    v.z = v.z > 0.f ? v.z : v.z * 0.f, v.w = v.w > 0.f ? v.w : v.w * 0.f;
-                    poison += 0.f * ((v.x + v.y) + (v.z + v.w));
-                    amax = fmaxf(amax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));     // (v >= 0 after the ReLU)
-                    hf_split(v, hh[m], ll[m]);
-                }
-                a2h[0] = make_uint4(hh[0].x, hh[0].y, hh[1].x, hh[1].y), a2h[1] = make_uint4(hh[2].x, hh[2].y, hh[3].x, hh[3].y);
-                a2l[0] = make_uint4(ll[0].x, ll[0].y, ll[1].x, ll[1].y), a2l[1] = make_uint4(ll[2].x, ll[2].y, ll[3].x, ll[3].y);
-            }
-            // ---- phase 2: conv2 partial sums over this block's 32 channels, 32 points x 256 outputs
-            const char *wrow = base + HF_ABYTES + HF_PBYTES + r * HF_WROW + h * 16;
-            {
-                constexpr int NOB = HF_C2 / 32;
-                auto wfrag = [&](int q, int plane) {                  // q = s2 * NOB + ob
-                    return *reinterpret_cast<const uint4 *>(wrow + (q % NOB) * 32 * HF_WROW + (q / NOB) * 64 + plane * 32);
-                };
-                uint4 wh0 = wfrag(0, 0), wl0 = wfrag(0, 1), wh1 = wfrag(1, 0), wl1 = wfrag(1, 1);
-#pragma unroll
-                for (int q = 0; q < 2 * NOB; ++q) {
-                    uint4 wh2 = wh1, wl2 = wl1;
-                    if (q + 2 < 2 * NOB) wh2 = wfrag(q + 2, 0), wl2 = wfrag(q + 2, 1);
-                    const int s2 = q / NOB, ob = q % NOB;
-                    acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2h[s2]), __builtin_bit_cast(hf16x8, wl0), acc2[ob], 0, 0, 0);
-                    acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2l[s2]), __builtin_bit_cast(hf16x8, wh0), acc2[ob], 0, 0, 0);
-                    acc2[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, a2h[s2]), __builtin_bit_cast(hf16x8, wh0), acc2[ob], 0, 0, 0);
-                    if (q < HF_NDMA - 8 && stage) dma(hd_s, cb_s, par ^ 1, q + 8);   // the other 10, one per MFMA group
-                    __builtin_amdgcn_sched_barrier(0);
-                    wh0 = wh1, wl0 = wl1, wh1 = wh2, wl1 = wl2;
-                }
-            }
-            __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): this wave's share of the next block has landed
-            __syncthreads();                                         // ... everybody's has, and this buffer's readers are done
-        }
-
-        // ---- epilogue 2: lane (out column r of block ob, half h) holds points (e & 3) + 8 (e >> 2) + 4 h of the wave's 32.
-        // fp16 range guard: a lane that split a magnitude >= 65504 (or met a NaN) spoils its wave's sums.  With a flag to raise, the wave
-        // writes no keys and the caller's predicated two-launch form (guarded arithmetic) supplies them; without one, NaN keys are loud.
-        // And the small side: a wave whose input features are ALL below 2^-4 (and not all zero) would lose relative precision in every
-        // product of conv1 (gemm.hip, small side of the range guard): same treatment.
-        if (m0 < p.M) {
-            const bool tiny_in = __ballot(amax_in >= 0.0625f) == 0ull && __ballot(amax_in > 0.f) != 0ull;
-            if (p.overflow && (tiny_in || __ballot(!(amax < 65504.f) || poison != poison) != 0ull)) {
-                if (lane == 0) atomicOr(p.overflow, 1);
-            } else {
-                const int obj0 = m0 / p.rows_per_obj, bound = (obj0 + 1) * p.rows_per_obj;
-#pragma unroll
-                for (int ob = 0; ob < HF_C2 / 32; ++ob) {
-                    const int o = hd * HF_C2 + ob * 32 + r;
-                    const float b2 = p.bias2[o], sc2 = p.scale2[o], sh2 = p.shift2[o];
-                    uint32_t k0 = 0, k1 = 0;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int prow = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        float v = acc2[ob][e] + b2;
-                        v = v * sc2 + sh2;
-                        v = v > 0.f ? v : v * 0.f;
-                        const uint32_t key = prow < p.M ? tgp_float_key(v) : 0u;
-                        if (prow >= bound) k1 = key > k1 ? key : k1;
-                        else k0 = key > k0 ? key : k0;
-                    }
-                    const uint32_t o0 = (uint32_t)__shfl_xor((int)k0, 32, 64), o1 = (uint32_t)__shfl_xor((int)k1, 32, 64);
-                    k0 = o0 > k0 ? o0 : k0, k1 = o1 > k1 ? o1 : k1;
-                    if (h == 0) {
-                        uint32_t *kp = p.keys + ((int64_t)hd * p.B + obj0) * HF_C2 + ob * 32 + r;
-                        if (k0) atomicMax(kp, k0);
-                        if (k1) atomicMax(kp + HF_C2, k1);
-                    }
-                }
-            }
-        }
-        if (!more) break;
-        t = tn, hd = hd_n, ptile = ptile_n;
+    for (int e = 0; e < 16; ++e) pre[e] = acc1[e];
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    // iterations 1 .. 31: buffer i & 1 holds { conv1 weights of block i | conv2 weights and vectors of block i - 1 }
+#pragma unroll 1
+    for (int i = 1; i < HF_NCB; ++i) {
+        const char *base = hf_smem + (i & 1) * HP_BUF;
+        const unsigned long long t0 = HP_T();
+        dma_unit(i);
+        stage_a(base, true, (i & 1) ^ 1, false);
+        if (STAMPS) HP_SB();
+        const unsigned long long t1 = HP_T();
+        if (STAMPS) HP_SB();
+        stage_b(base, i, true, true, (i & 1) ^ 1);
+        if (STAMPS) HP_SB();
+        const unsigned long long t2 = HP_T();
+        __builtin_amdgcn_s_waitcnt(0x0f70);                      // vmcnt(0): this wave's share of the next unit has landed (and its gathers)
+        __syncthreads();                                         // ... everybody's has, and this buffer's readers are done
+        const unsigned long long t3 = HP_T();
+        t_a += t1 - t0, t_b += t2 - t1, t_bar += t3 - t2;
     }
+    const unsigned long long t_loop = HP_T();
+    // iteration 32: epilogue 1 and conv2 of block 31; the vectors of epilogue 2 arrive meanwhile
+    float b2v[HF_C2 / 32], sc2v[HF_C2 / 32], sh2v[HF_C2 / 32];
+#pragma unroll
+    for (int ob = 0; ob < HF_C2 / 32; ++ob) {
+        const int o = hd * HF_C2 + ob * 32 + r;
+        b2v[ob] = p.bias2[o], sc2v[ob] = p.scale2[o], sh2v[ob] = p.shift2[o];
+    }
+    {
+        const char *base = hf_smem + (HF_NCB & 1) * HP_BUF;
+        epi1_read(base, 0);
+#pragma unroll
+        for (int k = 0; k < 2 * HF_STEPS; ++k) epi1(base, k);
+        epi1_pack();
+        stage_b(base, -1, false, false, 0);
+    }
+    const unsigned long long t_last = HP_T();
+
+    // ---- epilogue 2: lane (out column r of block ob, half h) holds points (e & 3) + 8 (e >> 2) + 4 h of the wave's 32.
+    // fp16 range guard: a wave whose input features or conv1 activations left fp16's range (or held a NaN) has non-finite sums.  With a
+    // flag to raise, the wave writes no keys and the caller's predicated two-launch form (guarded arithmetic) supplies them; without
+    // one, NaN keys are loud.  And the small side: a wave whose input features are ALL below 2^-4 (and not all zero) would lose
+    // relative precision in every product of conv1 (gemm.hip, small side of the range guard): same treatment.
+    if (m0 < p.M) {
+        const int obj0 = m0 / p.rows_per_obj, bound = (obj0 + 1) * p.rows_per_obj;
+        uint32_t *kp = p.keys + ((int64_t)hd * p.B + obj0) * HF_C2 + r;
+        const bool plain = m0 + 32 <= bound && m0 + 32 <= p.M;     // (wave-uniform) the usual wave: 32 live points of one object
+        uint32_t k0[HF_C2 / 32], k1[HF_C2 / 32];
+        bool finite = true;
+        if (plain) {
+#pragma unroll
+            for (int ob = 0; ob < HF_C2 / 32; ++ob) {
+                uint32_t ka = 0;
+                float big = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc2[ob][e] + b2v[ob];
+                    v = v * sc2v[ob] + sh2v[ob];
+                    v = v > 0.f ? v : v * 0.f;
+                    big = fmaxf(big, v), finite &= v == v;
+                    const uint32_t key = tgp_float_key(v);
+                    ka = key > ka ? key : ka;
+                }
+                finite &= big < __builtin_inff();
+                k0[ob] = ka, k1[ob] = 0;
+            }
+        } else {                                                   // a wave that straddles two objects, or the batch's end
+#pragma unroll
+            for (int ob = 0; ob < HF_C2 / 32; ++ob) {
+                uint32_t ka = 0, kb = 0;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int prow = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    float v = acc2[ob][e] + b2v[ob];
+                    v = v * sc2v[ob] + sh2v[ob];
+                    v = v > 0.f ? v : v * 0.f;
+                    const bool live = prow < p.M;
+                    finite &= !live || (v == v && v < __builtin_inff());
+                    const uint32_t key = live ? tgp_float_key(v) : 0u;
+                    const uint32_t xa = prow >= bound ? 0u : key, xb = prow >= bound ? key : 0u;
+                    ka = xa > ka ? xa : ka, kb = xb > kb ? xb : kb;
+                }
+                k0[ob] = ka, k1[ob] = kb;
+            }
+        }
+        const bool tiny_in = __ballot(amax_in >= 0.0625f) == 0ull && __ballot(amax_in > 0.f) != 0ull;
+        const bool bad = tiny_in || __ballot(!(amax_in < 65504.f) || poison_in != poison_in || !finite) != 0ull;
+        if (p.overflow && bad) {
+            if (lane == 0) atomicOr(p.overflow, 1);
+        } else {
+#pragma unroll
+            for (int ob = 0; ob < HF_C2 / 32; ++ob) {
+                uint32_t ka = k0[ob], kb = k1[ob];
+                const uint32_t o0 = (uint32_t)__shfl_xor((int)ka, 32, 64), o1 = (uint32_t)__shfl_xor((int)kb, 32, 64);
+                ka = o0 > ka ? o0 : ka, kb = o1 > kb ? o1 : kb;
+                if (h == 0) {
+                    if (ka) atomicMax(kp + ob * 32, ka);
+                    if (kb) atomicMax(kp + ob * 32 + HF_C2, kb);
+                }
+            }
+        }
+    }
+    if (STAMPS && p.stamps && lane == 0) {
+        unsigned long long *o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 12;
+        const unsigned long long t_end = HP_T();
+        o[0] = t_pro - t_entry, o[1] = t_loop - t_pro, o[2] = t_end - t_last, o[3] = t_last - t_loop, o[4] = t_a, o[5] = 0, o[6] = t_b, o[7] = t_bar;
+        o[8] = t_end - t_entry, o[9] = wall_clock64() - w_entry, o[10] = w_entry, o[11] = 0;
+    }
+#undef HP_T
 }
+
 
 // ------------------------------------------------------------------------------------------------------------------------
 // conv -> BatchNorm -> LeakyReLU -> max over points of a factored layer whose activation only feeds the max (conv_5 of Face_Enc,
@@ -525,66 +652,77 @@ extern "C" int tgp_conv_max_fused(const tgp_conv_max_fused_args *a, tgp_stream_t
     p.chunks = (p.C / 32) >= 2 && p.tiles < 512 ? 2 : 1;
     const int round_tiles = 512 / p.chunks, over = p.tiles % round_tiles;
     p.main_tiles = (p.tiles > round_tiles && over > 0 && over <= 8) ? p.tiles - over : p.tiles;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_max_fused_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CM_BUF);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_max_fused_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CM_BUF);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static TgpLdsAttr attr_t, attr_f;
+    if (const int e = tgp_lds_attr(attr_t, reinterpret_cast<const void *>(conv_max_fused_kernel<true>), 2 * CM_BUF)) return e;
+    if (const int e = tgp_lds_attr(attr_f, reinterpret_cast<const void *>(conv_max_fused_kernel<false>), 2 * CM_BUF)) return e;
     const int grid = p.main_tiles * p.chunks + (p.tiles - p.main_tiles) * (p.C / 32);
     if (p.fine_pl) hipLaunchKernelGGL(conv_max_fused_kernel<true>, dim3(grid), dim3(256), 2 * CM_BUF, tgp_hs(stream), p);
     else hipLaunchKernelGGL(conv_max_fused_kernel<false>, dim3(grid), dim3(256), 2 * CM_BUF, tgp_hs(stream), p);
     return TGP_LAUNCH_RESULT();
 }
 
-// W2 (heads, 256, 1024) fp32 -> [head][channel block][out][step][plane][16] fp16 with conv2's K order permuted to the layout the
-// conv1 accumulators leave the channels in: slot 8 h + t of step s2 is channel 32 cb + 16 s2 + 8 (t >> 2) + 4 h + (t & 3)
-__global__ void heads_pack_w2_kernel(const float *__restrict__ w2, int heads, uint16_t *__restrict__ out)
+// W2 (heads, 256, 1024) fp32 + the heads' conv1 epilogue vectors -> per (head, channel block) 33 pieces of 1 KB:
+// pieces (s2 * 8 + ob) * 2 + plane: [lane = 32 h + r][8] fp16 in the lane order of the B operand (lane (r, h): out column 32 ob + r,
+// k slots 8 h .. 8 h + 7 of step s2), conv2's K order permuted to the layout the conv1 accumulators leave the channels in (slot
+// 8 h + t of step s2 is channel 32 cb + 16 s2 + 8 (t >> 2) + 4 h + (t & 3)); piece 32: bias | scale | shift of the block's 32
+// channels as 3 x 32 floats (the rest of the piece is zero)
+__global__ void heads_pack_w2_kernel(const float *__restrict__ w2, const float *__restrict__ bias1, const float *__restrict__ scale1,
+                                      const float *__restrict__ shift1, int heads, uint16_t *__restrict__ out)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)heads * HF_NCB * HF_C2 * 32;
     if (t >= total) return;
-    const int slot = (int)(t & 15), s2 = (int)((t >> 4) & 1), o = (int)((t >> 5) % HF_C2);
-    const int cb = (int)((t >> 5) / HF_C2 % HF_NCB), hd = (int)((t >> 5) / HF_C2 / HF_NCB);
-    const int hh = slot >> 3, tt = slot & 7;
+    const int tt = (int)(t & 7), rr = (int)((t >> 3) & 31), hh = (int)((t >> 8) & 1), ob = (int)((t >> 9) & 7), s2 = (int)((t >> 12) & 1);
+    const int cb = (int)((t >> 13) % HF_NCB), hd = (int)((t >> 13) / HF_NCB);
     const int ch = 32 * cb + 16 * s2 + 8 * (tt >> 2) + 4 * hh + (tt & 3);
-    const float v = w2[((int64_t)hd * HF_C2 + o) * HF_C1 + ch];
+    const float v = w2[((int64_t)hd * HF_C2 + ob * 32 + rr) * HF_C1 + ch];
     const _Float16 hi = (_Float16)v;
     const _Float16 lo = (_Float16)(v - (float)hi);
-    uint16_t *dst = out + ((((int64_t)hd * HF_NCB + cb) * HF_C2 + o) * 2 + s2) * 32;
-    dst[slot] = __builtin_bit_cast(uint16_t, hi);
-    dst[16 + slot] = __builtin_bit_cast(uint16_t, lo);
+    uint16_t *blk = out + ((int64_t)hd * HF_NCB + cb) * (HP_WPIECES * 512);
+    uint16_t *dst = blk + (int64_t)((s2 * 8 + ob) * 2) * 512 + (hh * 32 + rr) * 8 + tt;
+    dst[0] = __builtin_bit_cast(uint16_t, hi);
+    dst[512] = __builtin_bit_cast(uint16_t, lo);
+    const int q = (int)(t & 8191);                               // the block's thread index: the first 256 fill the vector piece
+    if (q < 256) {
+        float *pv = reinterpret_cast<float *>(blk + 32 * 512);
+        const int c = hd * HF_C1 + cb * 32 + (q & 31);
+        pv[q] = q < 32 ? bias1[c] : q < 64 ? scale1[c] : q < 96 ? shift1[c] : 0.f;
+    }
 }
 
-extern "C" int tgp_heads_pack_w2(const float *w2, int heads, void *out, tgp_stream_t stream)
+extern "C" int64_t tgp_heads_w2_bytes(int heads) { return heads > 0 ? (int64_t)heads * HF_NCB * HP_WPIECES * 1024 : 0; }
+
+extern "C" int tgp_heads_pack_w2(const float *w2, const float *bias1, const float *scale1, const float *shift1, int heads, void *out,
+                                 tgp_stream_t stream)
 {
-    TGP_REQUIRE(w2 && out && heads > 0);
+    TGP_REQUIRE(w2 && bias1 && scale1 && shift1 && out && heads > 0);
     const int64_t total = (int64_t)heads * HF_NCB * HF_C2 * 32;
-    hipLaunchKernelGGL(heads_pack_w2_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), w2, heads,
+    hipLaunchKernelGGL(heads_pack_w2_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), w2, bias1, scale1, shift1, heads,
                        reinterpret_cast<uint16_t *>(out));
     return TGP_LAUNCH_RESULT();
 }
 
+#ifdef TGP_DEV   // development build: per-wave cycle stamps and timing-only knobs (scripts/heads_time.py)
+static unsigned long long *tgp_heads_stamps = nullptr;
+static int tgp_heads_knobs = 0;
+extern "C" int tgp_debug_set_heads_stamps(void *buf) { tgp_heads_stamps = reinterpret_cast<unsigned long long *>(buf); return 0; }
+extern "C" int tgp_debug_set_heads_knobs(int v) { tgp_heads_knobs = v; return 0; }
+#endif
+
 extern "C" int tgp_heads_fused(const tgp_heads_fused_args *a, tgp_stream_t stream)
 {
-    TGP_REQUIRE(a && a->fine && a->wa_s && a->p1 && a->p2 && a->idx1 && a->idx2 && a->bias1 && a->scale1 && a->shift1 && a->w2p &&
-                a->bias2 && a->scale2 && a->shift2 && a->keys);
+    TGP_REQUIRE(a && a->fine && a->wa_planes && a->p1 && a->p2 && a->idx1 && a->idx2 && a->w2p && a->bias2 && a->scale2 && a->shift2 &&
+                a->keys);
     TGP_REQUIRE(a->M > 0 && a->B > 0 && a->heads > 0 && a->rows_per_obj >= 32 && (int64_t)a->B * a->rows_per_obj == a->M);
     TGP_REQUIRE(a->K > 0 && a->K <= 16 * HF_STEPS && a->K > 16 * (HF_STEPS - 1) && a->ldf >= 16 * HF_STEPS && (a->ldf & 3) == 0);
     TGP_REQUIRE((a->ldp1 & 3) == 0 && (a->ldp2 & 3) == 0 && a->ldp1 >= a->heads * HF_C1 && a->ldp2 >= a->heads * HF_C1);
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    TGP_REQUIRE(al16(a->fine) && al16(a->wa_s) && al16(a->p1) && al16(a->p2) && al16(a->bias1) && al16(a->scale1) && al16(a->shift1) &&
-                al16(a->w2p));
+    TGP_REQUIRE(al16(a->fine) && al16(a->wa_planes) && al16(a->p1) && al16(a->p2) && al16(a->w2p));
     HeadsParams p;
     p.fine = a->fine, p.ldf = a->ldf, p.K = a->K;
-    p.wa_s = reinterpret_cast<const uint16_t *>(a->wa_s);
+    p.wa_pl = reinterpret_cast<const char *>(a->wa_planes);
     p.p1 = a->p1, p.ldp1 = a->ldp1, p.idx1 = a->idx1, p.p2 = a->p2, p.ldp2 = a->ldp2, p.idx2 = a->idx2;
-    p.bias1 = a->bias1, p.scale1 = a->scale1, p.shift1 = a->shift1;
-    p.w2p = reinterpret_cast<const uint16_t *>(a->w2p);
+    p.w2b = reinterpret_cast<const char *>(a->w2p);
     p.bias2 = a->bias2, p.scale2 = a->scale2, p.shift2 = a->shift2;
     p.keys = a->keys;
     p.overflow = a->overflow;
@@ -595,28 +733,43 @@ extern "C" int tgp_heads_fused(const tgp_heads_fused_args *a, tgp_stream_t strea
     }
     p.fine_pl = reinterpret_cast<const char *>(a->fine_planes), p.fine_kt = a->fine_kt, p.fine_amax = a->fine_amax;
     TGP_REQUIRE(!p.fine_pl || (p.fine_kt >= HF_STEPS && (reinterpret_cast<uintptr_t>(p.fine_pl) & 15) == 0));
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(heads_fused_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HF_BUF);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(heads_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * HF_BUF);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    p.stamps = nullptr;
+    // one workgroup per 128-point tile and head; a CU holds one (134 KB of LDS, one wave per SIMD)
+    const dim3 grid(p.heads * p.tiles);
+    static TgpLdsAttr attr;
+#define HF_LAUNCH(...)                                                                                       \
+    do {                                                                                                     \
+        const int e_ = tgp_lds_attr(attr, reinterpret_cast<const void *>(heads_fused_kernel<__VA_ARGS__>), 2 * HP_BUF);   \
+        if (e_) return e_;                                                                                   \
+        hipLaunchKernelGGL((heads_fused_kernel<__VA_ARGS__>), grid, dim3(256), 2 * HP_BUF, tgp_hs(stream), p); \
+        return TGP_LAUNCH_RESULT();                                                                          \
+    } while (0)
+#ifdef TGP_DEV
+    static TgpLdsAttr attr_s, attr_k[4];
+    if (p.fine_pl && tgp_heads_stamps) {
+        p.stamps = tgp_heads_stamps;
+        const int e_ = tgp_lds_attr(attr_s, reinterpret_cast<const void *>(heads_fused_kernel<true, true, 0>), 2 * HP_BUF);
+        if (e_) return e_;
+        hipLaunchKernelGGL((heads_fused_kernel<true, true, 0>), grid, dim3(256), 2 * HP_BUF, tgp_hs(stream), p);
+        return TGP_LAUNCH_RESULT();
     }
-    // persistent: one workgroup per CU (144 KB of LDS, 512 registers per lane: nothing else fits beside it), each walking its tiles
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
+#define HF_KNOB(I, N)                                                                                        \
+    if (p.fine_pl && tgp_heads_knobs == N) {                                                                 \
+        const int e_ = tgp_lds_attr(attr_k[I], reinterpret_cast<const void *>(heads_fused_kernel<true, false, N>), 2 * HP_BUF); \
+        if (e_) return e_;                                                                                   \
+        hipLaunchKernelGGL((heads_fused_kernel<true, false, N>), grid, dim3(256), 2 * HP_BUF, tgp_hs(stream), p); \
+        return TGP_LAUNCH_RESULT();                                                                          \
     }
-    const int total = p.heads * p.tiles;
-    TGP_REQUIRE(a->workgroups >= 0);
-    const int want = a->workgroups > 0 ? a->workgroups : cus;
-    const dim3 grid(total < want ? total : want);
-    if (p.fine_pl) hipLaunchKernelGGL(heads_fused_kernel<true>, grid, dim3(256), 2 * HF_BUF, tgp_hs(stream), p);
-    else hipLaunchKernelGGL(heads_fused_kernel<false>, grid, dim3(256), 2 * HF_BUF, tgp_hs(stream), p);
-    return TGP_LAUNCH_RESULT();
+    HF_KNOB(0, 1) HF_KNOB(1, 2) HF_KNOB(2, 4) HF_KNOB(3, 7)
+#undef HF_KNOB
+#endif
+    static TgpLdsAttr attr_f;
+    if (p.fine_pl) HF_LAUNCH(true, false, 0);
+    {
+        const int e_ = tgp_lds_attr(attr_f, reinterpret_cast<const void *>(heads_fused_kernel<false, false, 0>), 2 * HP_BUF);
+        if (e_) return e_;
+        hipLaunchKernelGGL((heads_fused_kernel<false, false, 0>), grid, dim3(256), 2 * HP_BUF, tgp_hs(stream), p);
+        return TGP_LAUNCH_RESULT();
+    }
+#undef HF_LAUNCH
 }

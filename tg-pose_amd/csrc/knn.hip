@@ -968,13 +968,9 @@ static int launch_knn_fused(const float *xt, const float *q, int B, int n, int k
         const int tail16 = n % KF16_ROWS, n_extra16 = (tail16 > 0 && tail16 <= 8 && tail16 <= n / KF16_ROWS) ? tail16 : 0;
         const int nrb16 = n_extra16 ? n / KF16_ROWS : tgp_cdiv(n, KF16_ROWS);
         const size_t lds16 = (size_t)(KF16_ROWS + (n_extra16 ? 1 : 0)) * ldw * sizeof(float);
-        static bool attr16 = false;
-        if (!attr16) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(knn_feat_fused16_kernel<DIM, NT, CH / 2>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (KF16_ROWS + 1) * KF_MAX_LDW * (int)sizeof(float));
-            if (e != hipSuccess) return (int)e;
-            attr16 = true;
-        }
+        static TgpLdsAttr attr16;
+        if (const int e = tgp_lds_attr(attr16, reinterpret_cast<const void *>(knn_feat_fused16_kernel<DIM, NT, CH / 2>),
+                                       (KF16_ROWS + 1) * KF_MAX_LDW * (int)sizeof(float))) return e;
         // (four steps per prefetched chunk, three chunks ahead; eight measured the same: 18.68 vs 18.67 k objects/s)
         hipLaunchKernelGGL((knn_feat_fused16_kernel<DIM, NT, CH / 2>), dim3(tgp_xcd_grid(B, nrb16)), dim3(256), lds16, stream, xt, q, B, n, k,
                            idx, nrb16, ldw, n_extra16, xyz, dirs);
@@ -985,13 +981,9 @@ static int launch_knn_fused(const float *xt, const float *q, int B, int n, int k
     const int tail = n % KF_ROWS, n_extra = (tail > 0 && tail <= 8 && tail <= n / KF_ROWS) ? tail : 0;
     const int nrb = n_extra ? n / KF_ROWS : tgp_cdiv(n, KF_ROWS);
     const size_t lds = (size_t)(KF_ROWS + (n_extra ? 1 : 0)) * ldw * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(knn_feat_fused_kernel<DIM, NT, CH>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (KF_ROWS + 1) * KF_MAX_LDW * (int)sizeof(float));
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static TgpLdsAttr attr;
+    if (const int e = tgp_lds_attr(attr, reinterpret_cast<const void *>(knn_feat_fused_kernel<DIM, NT, CH>),
+                                   (KF_ROWS + 1) * KF_MAX_LDW * (int)sizeof(float))) return e;
     hipLaunchKernelGGL((knn_feat_fused_kernel<DIM, NT, CH>), dim3(tgp_xcd_grid(B, nrb)), dim3(512), lds, stream, xt, q, B, n, k, idx, nrb, ncb,
                        ldw, n_extra, tgp_knn_stamps);
     return TGP_LAUNCH_RESULT();

@@ -20,6 +20,24 @@ static inline hipStream_t tgp_hs(tgp_stream_t s) { return (hipStream_t)s; }
 
 static inline int tgp_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: a process that runs on a second GPU after the
+// first needs it set there too (a launch asking for more than 64 KB of LDS fails without it).  One TgpLdsAttr per kernel
+// instance remembers the devices it has been set on; returns 0 or the hipError_t.
+struct TgpLdsAttr {
+    bool done[64] = {};
+};
+static inline int tgp_lds_attr(TgpLdsAttr &st, const void *fn, int bytes)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev >= 0 && dev < 64 && st.done[dev]) return 0;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    if (dev >= 0 && dev < 64) st.done[dev] = true;
+    return 0;
+}
+
 // Objects are dealt to XCDs so that all workgroups of one object run on one XCD (its gathered
 // tables then stay in that XCD's 4 MiB L2).  Workgroups are dispatched round-robin over the 8
 // XCDs, so linear block id L sits on XCD-group L % 8; this is a speed hint only, correctness

@@ -232,10 +232,11 @@ def pack_factored(wide, dec0):
         for k in ("dec_a", "Wb", "Wc"):
             f[k + "_p"] = ops.planes_w(f[k])
     # the fused heads kernel (conv1 -> conv2 -> max in one launch) takes fp16 operands without a pack-time rescale
-    f["w2p"] = None
+    f["w2p"] = f["Wa_hp"] = None
     if (ops.GEMM_MODE == "split16" and getattr(f["Wa_s"], "tgp_unscale", None) is None
             and float(wide["W2"].abs().max()) < ops.FP16_SAFE):
-        f["w2p"] = ops.heads_pack_w2(wide["W2"])
+        f["w2p"] = ops.heads_pack_w2(wide["W2"], wide["bias"][1024:], wide["scale"][1024:], wide["shift"][1024:])
+        f["Wa_hp"] = ops.heads_planes_w(f["Wa"][1024:])
     return f
 
 
@@ -692,8 +693,8 @@ def wide_gemm_factored(pk, fine, inter, P1, P2, N, arena=None, heads_only=False)
                             t.record_stream(_side_stream(dev, (SIDE_TAG, "heads_tail")))
                 else:
                     tail_rows()
-            keys2, overflow = ops.heads_fused(fine.view(M, -1), FINE_K, f["Wa_s"][1024:], P1[:, 1024:], inter["near1"], P2[:, 1024:],
-                                              inter["near2"], w["bias"][1024:], w["scale"][1024:], w["shift"][1024:], f["w2p"],
+            keys2, overflow = ops.heads_fused(fine.view(M, -1), FINE_K, f["Wa_hp"], P1[:, 1024:], inter["near1"], P2[:, 1024:],
+                                              inter["near2"], f["w2p"],
                                               w["b2"], w["scale2"], w["shift2"], B, N, k_alg=w["k_alg"], keys=arena.keys2,
                                               overflow=arena.over2, rows=rows, fine_planes=(inter.get("planes") or {}).get("fine"))
             if tail is not None:

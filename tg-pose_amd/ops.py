@@ -346,8 +346,7 @@ def fill_tail(obj_id, xyz_c, feat, col0, n_cls):
 GEMM_MODE = "split16"
 PLANES = os.environ.get("TGP_PLANES", "1") != "0"     # activations also as fp16 planes, consumers on the pre-split kernel (split16 mode)
 ORL_FUSED = os.environ.get("TGP_ORL_FUSED", "1") != "0"      # the ORL pooling, its mean and its projection as one launch
-HEADS_PERSISTENT = os.environ.get("TGP_HEADS_PERSISTENT", "0") != "0"   # measurement switches of the fused heads kernel (ABI 5)
-HEADS_PLANES = os.environ.get("TGP_HEADS_PLANES", "1") != "0"
+HEADS_PLANES = os.environ.get("TGP_HEADS_PLANES", "1") != "0"   # measurement switch of the fused kernels: fragments from the fine planes
 
 
 FP16_SAFE = 32768.0          # |w| at or above this is pre-scaled before the fp16 split (fp16's largest finite value is 65504)
@@ -614,25 +613,41 @@ def linear_rows(x, weight, bias=None, scale=None, shift=None, act=0, slope=0.0, 
     return out
 
 
-def heads_pack_w2(W2):
-    """conv2 weights of the heads (heads, 256, 1024) fp32 -> the fused heads kernel's operand (fp16 hi / lo planes, K permuted)"""
+def heads_pack_w2(W2, bias1, scale1, shift1):
+    """conv2 weights of the heads (heads, 256, 1024) fp32 and the heads' conv1 bias / BatchNorm scale / shift (heads * 1024 each) ->
+    the fused heads kernel's operand: per (head, 32-channel block) conv2's fp16 hi / lo planes in MFMA fragment order (K permuted)
+    and the block's three vectors (tgp_heads_pack_w2, ABI 7)"""
     W2 = W2.contiguous()
     heads = W2.shape[0]
     if tuple(W2.shape[1:]) != (256, 1024):
         raise ValueError("heads_pack_w2: (heads, 256, 1024) expected")
-    out = torch.empty(heads, 32, 256, 2, 2, 16, device=W2.device, dtype=torch.int16)
-    check(_lib.lib().tgp_heads_pack_w2(_p(W2), heads, _p(out), _stream(W2)), "tgp_heads_pack_w2")
+    vec = [v.contiguous() for v in (bias1, scale1, shift1)]
+    if any(v.numel() != heads * 1024 for v in vec):
+        raise ValueError("heads_pack_w2: bias1 / scale1 / shift1 of heads * 1024 channels expected")
+    out = torch.empty(_lib.lib().tgp_heads_w2_bytes(heads), device=W2.device, dtype=torch.uint8)
+    check(_lib.lib().tgp_heads_pack_w2(_p(W2), _p(vec[0]), _p(vec[1]), _p(vec[2]), heads, _p(out), _stream(W2)), "tgp_heads_pack_w2")
+    out.tgp_heads = heads
     return out
 
 
-def heads_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias1, scale1, shift1, w2p, bias2, scale2, shift2, B, rows_per_obj, k_alg=None,
+def heads_planes_w(Wa_heads):
+    """conv1 weights of the heads over the fine buffer (heads * 1024, ld >= 268) -> blocked fp16 planes with 17 K-tiles (the fused heads
+    kernel's wa_planes)"""
+    Wa_heads, ld = _rows(Wa_heads, "Wa_heads")
+    return planes_split(Wa_heads, K=min(Wa_heads.shape[-1], 272), kt=17, amax=False)
+
+
+def heads_fused(fine, K, wa_planes, p1, idx1, p2, idx2, w2p, bias2, scale2, shift2, B, rows_per_obj, k_alg=None,
                 keys=None, overflow=None, rows=0, fine_planes=None):
     """conv1 -> BN -> ReLU -> conv2 -> BN -> ReLU -> max over points of the three heads (tgp_heads_fused): keys (heads, B, 256)
     and the device flag (1,) int32 that a wave raises instead of writing keys when it met a magnitude beyond fp16's range.
-    fine (M, ldf); p1 / p2: 2-D views whose column 0 is the first head's first channel (row stride = their .stride(0))."""
+    fine (M, ldf); wa_planes: heads_planes_w(conv1 weights of the heads); w2p: heads_pack_w2(...) (conv2 weights + conv1's bias /
+    scale / shift); p1 / p2: 2-D views whose column 0 is the first head's first channel (row stride = their .stride(0))."""
     fine, ldf = _rows(fine, "fine")
-    heads = w2p.shape[0]
+    heads = w2p.tgp_heads
     M = B * rows_per_obj
+    if wa_planes.kt != 17 or wa_planes.rows != heads * 1024:
+        raise ValueError("heads_fused: wa_planes must hold heads * 1024 rows in 17 K-tiles (ops.heads_planes_w)")
     if keys is None:          # (the eval forward hands in zeroed slices of its one per-forward arena instead)
         keys = torch.zeros(heads, B, 256, device=fine.device, dtype=torch.int32)
     if overflow is None:
@@ -643,10 +658,9 @@ def heads_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias1, scale1, shift1, w2p, b
         e0.record(torch.cuda.current_stream(fine.device))
     a = _lib.HeadsFusedArgs()
     a.fine, a.ldf, a.K = _p(fine), ldf, K
-    a.wa_s = _p(wa_s)
+    a.wa_planes = _p(wa_planes.buf)
     a.p1, a.ldp1, a.idx1 = _p(p1), p1.stride(0), _p(idx1)
     a.p2, a.ldp2, a.idx2 = _p(p2), p2.stride(0), _p(idx2)
-    a.bias1, a.scale1, a.shift1 = _p(bias1), _p(scale1), _p(shift1)
     a.w2p = _p(w2p)
     a.bias2, a.scale2, a.shift2 = _p(bias2), _p(scale2), _p(shift2)
     a.keys = _p(keys)
@@ -655,7 +669,6 @@ def heads_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias1, scale1, shift1, w2p, b
     a.rows = int(rows)
     if fine_planes is not None and planes_on() and HEADS_PLANES:      # the points' features as fp16 planes: operand fragments load as they lie
         a.fine_planes, a.fine_kt, a.fine_amax = _p(fine_planes.buf), fine_planes.kt, _p(fine_planes.amax)
-    a.workgroups = 0 if HEADS_PERSISTENT else 1 << 30
     check(_lib.lib().tgp_heads_fused(ctypes.byref(a), _stream(fine)), "tgp_heads_fused")
     if timed:
         e1.record(torch.cuda.current_stream(fine.device))
