@@ -686,7 +686,8 @@ typedef struct tgp_conv_max_fused_args {
 int tgp_conv_max_fused(const tgp_conv_max_fused_args *args, tgp_stream_t stream);
 /* (ABI 7) w2 (heads, 256, 1024) fp32 and the heads' conv1 bias / BatchNorm scale / shift (heads * 1024 each) -> the kernel's operand:
  * per (head, block of 32 conv1 channels) 33 KB = conv2's fp16 hi / lo planes in MFMA fragment order (K permuted to the order the
- * conv1 accumulators leave the channels in) + the block's bias | scale | shift.  out: tgp_heads_w2_bytes(heads) bytes, 16-byte aligned. */
+ * conv1 accumulators leave the channels in) + the block's bias | scale | shift.  out: tgp_heads_w2_bytes(heads) bytes, 16-byte aligned.
+ * w2 == NULL: only the vectors are rewritten, in place (the BatchNorm fold follows the running statistics; the weights do not). */
 int64_t tgp_heads_w2_bytes(int heads);
 int tgp_heads_pack_w2(const float *w2, const float *bias1, const float *scale1, const float *shift1, int heads, void *out,
                       tgp_stream_t stream);

@@ -675,13 +675,15 @@ __global__ void heads_pack_w2_kernel(const float *__restrict__ w2, const float *
     const int tt = (int)(t & 7), rr = (int)((t >> 3) & 31), hh = (int)((t >> 8) & 1), ob = (int)((t >> 9) & 7), s2 = (int)((t >> 12) & 1);
     const int cb = (int)((t >> 13) % HF_NCB), hd = (int)((t >> 13) / HF_NCB);
     const int ch = 32 * cb + 16 * s2 + 8 * (tt >> 2) + 4 * hh + (tt & 3);
-    const float v = w2[((int64_t)hd * HF_C2 + ob * 32 + rr) * HF_C1 + ch];
-    const _Float16 hi = (_Float16)v;
-    const _Float16 lo = (_Float16)(v - (float)hi);
     uint16_t *blk = out + ((int64_t)hd * HF_NCB + cb) * (HP_WPIECES * 512);
-    uint16_t *dst = blk + (int64_t)((s2 * 8 + ob) * 2) * 512 + (hh * 32 + rr) * 8 + tt;
-    dst[0] = __builtin_bit_cast(uint16_t, hi);
-    dst[512] = __builtin_bit_cast(uint16_t, lo);
+    if (w2) {                                                    // (NULL: only the vectors are refreshed -- the BatchNorm fold moved)
+        const float v = w2[((int64_t)hd * HF_C2 + ob * 32 + rr) * HF_C1 + ch];
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        uint16_t *dst = blk + (int64_t)((s2 * 8 + ob) * 2) * 512 + (hh * 32 + rr) * 8 + tt;
+        dst[0] = __builtin_bit_cast(uint16_t, hi);
+        dst[512] = __builtin_bit_cast(uint16_t, lo);
+    }
     const int q = (int)(t & 8191);                               // the block's thread index: the first 256 fill the vector piece
     if (q < 256) {
         float *pv = reinterpret_cast<float *>(blk + 32 * 512);
@@ -695,7 +697,7 @@ extern "C" int64_t tgp_heads_w2_bytes(int heads) { return heads > 0 ? (int64_t)h
 extern "C" int tgp_heads_pack_w2(const float *w2, const float *bias1, const float *scale1, const float *shift1, int heads, void *out,
                                  tgp_stream_t stream)
 {
-    TGP_REQUIRE(w2 && bias1 && scale1 && shift1 && out && heads > 0);
+    TGP_REQUIRE(bias1 && scale1 && shift1 && out && heads > 0);
     const int64_t total = (int64_t)heads * HF_NCB * HF_C2 * 32;
     hipLaunchKernelGGL(heads_pack_w2_kernel, dim3(tgp_cdiv(total, 256)), dim3(256), 0, tgp_hs(stream), w2, bias1, scale1, shift1, heads,
                        reinterpret_cast<uint16_t *>(out));

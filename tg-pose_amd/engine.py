@@ -205,6 +205,10 @@ class Packed(object):
             sc, sh = _fold_values(sd, name)
             scale.copy_(sc)
             shift.copy_(sh)
+        f = getattr(self, "fact", None)
+        if f is not None and f.get("w2p") is not None:      # the fused heads kernel reads conv1's fold from inside its packed operand
+            w = self.wide
+            ops.heads_repack_vectors(f["w2p"], w["bias"][1024:], w["scale"][1024:], w["shift"][1024:])
 
 
 FINE_K = 268            # fm_0 | fm_1 | one-hot | xyz | 3 zero columns: the part of `feat` that differs from point to point

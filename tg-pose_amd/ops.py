@@ -630,6 +630,13 @@ def heads_pack_w2(W2, bias1, scale1, shift1):
     return out
 
 
+def heads_repack_vectors(w2p, bias1, scale1, shift1):
+    """rewrite, in place, the conv1 bias / BatchNorm scale / shift inside a heads_pack_w2 operand (the fold moved with the running
+    statistics; the weights did not): a captured forward that holds the operand's address follows"""
+    vec = [v.contiguous() for v in (bias1, scale1, shift1)]
+    check(_lib.lib().tgp_heads_pack_w2(None, _p(vec[0]), _p(vec[1]), _p(vec[2]), w2p.tgp_heads, _p(w2p), _stream(w2p)), "tgp_heads_pack_w2")
+
+
 def heads_planes_w(Wa_heads):
     """conv1 weights of the heads over the fine buffer (heads * 1024, ld >= 268) -> blocked fp16 planes with 17 K-tiles (the fused heads
     kernel's wa_planes)"""
