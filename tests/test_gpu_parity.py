@@ -518,8 +518,11 @@ def test_gemm_fused_column_ranges_and_batch(ops):
         assert (got[z] - wz).abs().max().item() < 3e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(32, 2500, 1024), (32, 1024, 2048), (6, 1286, 2500), (1, 4, 256), (17, 259, 256)])
+@pytest.mark.parametrize("M,N,K", [(32, 2500, 1024), (32, 1024, 2048), (6, 1286, 2500), (1, 4, 256), (17, 259, 256),
+                                   (32, 256, 4), (32, 8, 4), (17, 64, 12)])
 def test_gemm_skinny_rows_vs_fp64(ops, M, N, K):
+    """(the K < 16 shapes: a wave's first 16-wide chunk is partly or wholly past K -- the masking of the weight-streaming kernel's
+    operand loads, csrc/gemm.hip skinny_gemm_kernel; (32, 4) x (N, 4) is the backward of the heads' conv4)"""
     gen = torch.Generator().manual_seed(M * N + K)
     A, W = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen) / K ** 0.5
     bias, scale, shift = torch.randn(N, generator=gen), torch.rand(N, generator=gen) + 0.5, torch.randn(N, generator=gen)
@@ -528,6 +531,26 @@ def test_gemm_skinny_rows_vs_fp64(ops, M, N, K):
     assert (out.cpu().double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
     plain = ops.linear_rows(g(A), g(W))
     assert (plain.cpu().double() - _gemm_ref(A, W)).abs().max().item() < 2e-5
+
+
+def test_gemm_skinny_operands_at_the_end_of_their_allocation(ops):
+    """Regression canary for the round-4 fault (commit 5cc7e90): skinny_gemm_kernel let a lane whose 4-float quad lay past K read at
+    row + 4 * (lane / 16) anyway and discarded the value -- with K = 4 up to 48 bytes beyond the operand.  Here both operands are the
+    LAST bytes of allocations that are whole segments of the caching allocator (12 MiB: requests of 10 MiB and more are served by a
+    hipMalloc of their own, rounded to 2 MiB), so a read past the operand leaves the allocation.  The value check cannot see a
+    discarded read; a fault would."""
+    seg = 12 * 1024 * 1024
+    gen = torch.Generator().manual_seed(4)
+    for M, N, K in ((32, 8, 4), (32, 256, 4), (17, 64, 12)):
+        A, W = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen)
+        bufa, bufw = torch.empty(seg // 4, device=DEV), torch.empty(seg // 4, device=DEV)
+        a = bufa[seg // 4 - M * K:].view(M, K)
+        w = bufw[seg // 4 - N * K:].view(N, K)
+        a.copy_(A), w.copy_(W)
+        out = ops.linear_rows(a, w)
+        torch.cuda.synchronize()
+        assert (out.cpu().double() - _gemm_ref(A, W)).abs().max().item() < 2e-5
+        del a, w, bufa, bufw
 
 
 def test_gemm_views_into_wider_buffers(ops):
@@ -2541,8 +2564,10 @@ def test_tda_loss_large_batch_and_graph_capture(ops):
 
 
 def test_two_replays_in_flight_equal_serial(ops):
-    """bench.py's default keeps two captured forwards in flight on two HIP streams.  Each GraphedForward owns its static inputs,
-    outputs and activation pool, so concurrent replays must return exactly what the same batches return one after the other."""
+    """Two captured forwards (with their side branches) in flight on two HIP streams -- bench.py's default of rounds 1-2, still
+    reported as objects_per_s_two_batches_in_flight.  Each GraphedForward owns its static inputs, outputs and activation pool, so
+    concurrent replays must return exactly what the same batches return one after the other.  (The form the headline is quoted on
+    is test_four_branch_free_replays_in_flight_at_the_benchmark_size.)"""
     from tgpose_amd import FLAGS, engine
     net = _net(3)
     FLAGS.train = 0
@@ -2574,6 +2599,54 @@ def test_two_replays_in_flight_equal_serial(ops):
     for want, have in zip(serial, got):
         for k in want:
             assert torch.equal(want[k], have[k]), k
+
+
+def test_four_branch_free_replays_in_flight_at_the_benchmark_size(ops):
+    """The execution form of bench.py's default line: FOUR branch-free GraphedForward replayers (engine.BRANCH_STREAMS off while they
+    are captured) of B = 32 objects x N = 1028 points, one per HIP stream, all in flight at once.  Per-arena tickets, range flags and
+    per-capture scratch make that safe by construction; this asserts it at the size the number is quoted on: two rounds of four
+    overlapping replays equal, bit for bit, the same eight batches replayed one at a time and the eager forward."""
+    from tgpose_amd import FLAGS, engine
+    net = _net(3)
+    FLAGS.train = 0
+    B, N, S = 32, 1028, 4
+    pk = net.packed(DEV)
+    old = engine.BRANCH_STREAMS
+    engine.BRANCH_STREAMS = False
+    try:
+        reps = [engine.GraphedForward(pk, B, N, torch.device(DEV), train_keys=False) for _ in range(S)]
+        streams = [torch.cuda.Stream() for _ in range(S)]
+        data = []
+        for seed in range(21, 21 + 2 * S):
+            pts, obj = synth_points(B, N, seed)
+            torch.manual_seed(seed)
+            i1 = torch.randperm(N)[: N // 4]
+            data.append((g(pts), g(obj), (i1, torch.randperm(i1.numel())[: i1.numel() // 4])))
+        serial = []
+        for i, (pts, obj, smp) in enumerate(data):
+            serial.append({k: v.clone() for k, v in reps[i % S](pts, obj, smp).items()})
+            torch.cuda.synchronize()
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
+        got = []
+        for rnd in range(2):
+            outs = []
+            for i in range(S):
+                pts, obj, smp = data[S * rnd + i]
+                with torch.cuda.stream(streams[i]):
+                    outs.append(reps[i](pts, obj, smp))
+            torch.cuda.synchronize()
+            got += [{k: v.clone() for k, v in o.items()} for o in outs]
+        for want, have in zip(serial, got):
+            for k in want:
+                assert torch.equal(want[k], have[k]), k
+        with torch.no_grad():                                     # ... and the eager launches of the same forward
+            for j in (0, 2 * S - 1):
+                eager = net(data[j][0], data[j][1], sample_idx=data[j][2])
+                for k in eager:
+                    assert torch.equal(eager[k], serial[j][k]), k
+    finally:
+        engine.BRANCH_STREAMS = old
 
 
 # ----------------------------------------------------------------------------- input side (depth image -> cloud), SURVEY 8 f-4

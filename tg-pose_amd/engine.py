@@ -531,6 +531,19 @@ class Arena(object):
         self.back = buf[n5 + n2 + 8:n5 + n2 + 8 + nb].view(torch.float32).view(B, FEAT_LD)
         self.amax = buf[n5 + n2 + 8 + nb:]
         self._pl = None
+        self._repair = None
+
+    def repair_scratch(self, floats):
+        """One fp32 scratch for the forward's fp16-range REPAIR launches (the fused heads' two-launch form, the planes-only decoder's
+        fp32 chain): they are predicated on device flags and normally return at once, so their activations are never touched --
+        and, in a forward without side branches, they run one after the other on one stream: both take views of the same
+        buffer (a B = 32 capture keeps 404 MB for them instead of 575).  With side branches the two run concurrently and the
+        second caller gets memory of its own."""
+        if BRANCH_STREAMS:
+            return torch.empty(floats, device=self.buf.device, dtype=torch.float32)
+        if self._repair is None or self._repair.numel() < floats:
+            self._repair = torch.empty(floats, device=self.buf.device, dtype=torch.float32)
+        return self._repair[:floats]
 
     def planes(self, B, N, N1, N2):
         """the forward's plane buffers (uninitialised; every chunk a consumer reads is written by a producer first) over the
@@ -711,7 +724,7 @@ def wide_gemm_factored(pk, fine, inter, P1, P2, N, arena=None, heads_only=False)
             # the batch in chunks of REPAIR_OBJS objects through ONE chunk-sized buffer (tgp_gemm_args.row_base addresses the
             # chunk's objects in the max over points): two predicated launches per chunk.
             Rr = M if B <= 2 * REPAIR_OBJS else REPAIR_OBJS * N       # (up to 2 x REPAIR_OBJS objects: one chunk, two launches)
-            H = torch.empty(Rr, 3072, device=dev, dtype=torch.float32)
+            H = arena.repair_scratch(Rr * 3072).view(Rr, 3072)
             f2, n1v, n2v = fine.view(M, -1), inter["near1"].view(-1), inter["near2"].view(-1)
             for r0 in range(0, M, Rr):
                 Mt = min(Rr, M - r0)
@@ -764,10 +777,15 @@ def decoder_forward_factored(pk, fine, inter, P1, P2, back, N, arena=None, rb=No
             ops.gemm(None, w, x if nxt is None else None, M=M, N=w.shape[0], K=w.shape[1], lda=0, ldw=w.shape[1], ldc=w.shape[0], bias=b,
                      scale=sc, shift=sh, act=1, w_split=ws, a_planes=xp, w_planes=wp, c_planes=pl.get(nxt) if nxt else None, range_flag=flag)
             xp = pl.get(nxt) if nxt else None
-        y = torch.empty(M, 512, device=dev, dtype=torch.float32)          # the repair chain's activations (untouched while the flag is 0)
+        # the repair chain's activations (untouched while the flag is 0): 512 | 512 | 256 columns out of the forward's repair scratch
+        rs = arena.repair_scratch(M * sum(widths[:-1]))
+        offs = [0]
+        for n in widths[:-1]:
+            offs.append(offs[-1] + M * n)
+        y = rs[offs[0]:offs[1]].view(M, 512)
         ops.gemm(fine, f["dec_a"], y, flops_ref=0, pred=flag, **gk)
-        for w, b, sc, sh, ws, _wp in pk.dec[1:]:
-            out = x if w.shape[0] == widths[-1] else torch.empty(M, w.shape[0], device=dev, dtype=torch.float32)
+        for li, (w, b, sc, sh, ws, _wp) in enumerate(pk.dec[1:]):
+            out = x if w.shape[0] == widths[-1] else rs[offs[li + 1]:offs[li + 2]].view(M, w.shape[0])
             ops.gemm(y, w, out, M=M, N=w.shape[0], K=w.shape[1], lda=w.shape[1], ldw=w.shape[1], ldc=w.shape[0], bias=b, scale=sc,
                      shift=sh, act=1, w_split=ws, flops_ref=0, pred=flag)
             y = out

@@ -571,6 +571,10 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
         if C is None or batch != 1 or (cp_col0 & 15):
             raise ValueError("gemm: result planes of a small launch need its fp32 result")
         Kc = N - c_col0
+        if Kc % 16 and (cp_col0 // 16 + (Kc + 15) // 16) < late_planes.kt:
+            # the split kernel zero-fills the tail of its last K-tile: inside a wider planes buffer (fm2 | fm3) that tile belongs to
+            # the neighbouring column range (the C-side rule of the C_planes path, csrc/gemm.hip)
+            raise ValueError("gemm: result planes into a column range of a wider buffer need a multiple of 16 columns")
         check(_lib.lib().tgp_planes_split_cols(_p(C), M, Kc, ldc, _p(late_planes.buf), late_planes.kt, int(cp_col0), _p(late_planes.amax),
                                                _stream(A)), "tgp_planes_split_cols")
     if timed:
