@@ -148,8 +148,17 @@ def point_head(P, name, x):
 DEFAULT_FLAGS = dict(gcn_n_num=20, gcn_sup_num=7, obj_c=6)
 
 
+def proj_layer(P, face, feat_t):
+    """Face_Enc.proj_layer (FaceRecon.py:32-35, applied at :80-84 when enable_proj): Conv1d 1286 -> 1286 (no bias) + BatchNorm1d +
+    LeakyReLU(0.2) + Conv1d 1286 -> 1286 (no bias) on feat_global (B, 1286, N)."""
+    pl = face + "encoder.proj_layer."
+    x = F.conv1d(feat_t, P[pl + "0.weight"])
+    x = F.leaky_relu(_bn(P, pl + "1", x), 0.2)
+    return F.conv1d(x, P[pl + "3.weight"])
+
+
 def posenet_forward(P, points, obj_id, sample_idx=None, train_keys=False, mode="exact", inject=None,
-                    flags=None, want_intermediates=False, bn_train=False, force=None, record=None):
+                    flags=None, want_intermediates=False, bn_train=False, force=None, record=None, enable_proj=False):
     """PoseNet9D(only_encoder=False).forward in eval mode, or (bn_train=True) in training mode with dropout
     disabled; then out["_bn_new"] holds every BatchNorm buffer after the step.
 
@@ -199,7 +208,7 @@ def posenet_forward(P, points, obj_id, sample_idx=None, train_keys=False, mode="
     if train_keys:
         out["h1"], out["h2"] = h1, h2
         out["feat"] = feat
-        out["feat_global"] = feat_t.max(2)[0]
+        out["feat_global"] = (proj_layer(P, "face_all.", feat_t) if enable_proj else feat_t).max(2)[0]     # PoseNet9D.py:49-50
     if bn_train:
         out["_bn_new"] = P["_bn_new"]
     if want_intermediates:
@@ -210,7 +219,7 @@ def posenet_forward(P, points, obj_id, sample_idx=None, train_keys=False, mode="
 
 
 def encoder_only_forward(P, points, obj_id, sample_idx=None, mode="exact", inject=None, flags=None, bn_train=False,
-                         want_intermediates=False):
+                         want_intermediates=False, enable_proj=False):
     """PoseNet9D(only_encoder=True).forward (PoseNet9D.py:35-45; the trainer's net2): encoder + decoder on the plain
     feature (pred_PH=False, FaceRecon.py:190-199), keys prefixed face_enc."""
     flags = dict(DEFAULT_FLAGS, **(flags or {}))
@@ -225,7 +234,8 @@ def encoder_only_forward(P, points, obj_id, sample_idx=None, mode="exact", injec
     xyz = points - points.mean(dim=1, keepdim=True)
     feat, inter = encoder(P, "face_enc.", xyz, obj_id, sample_idx, cache, flags)
     recon = decoder(P, "face_enc.", feat.permute(0, 2, 1))
-    out = dict(feat_global=feat.permute(0, 2, 1).max(2)[0], recon=recon)
+    feat_t = feat.permute(0, 2, 1)
+    out = dict(feat_global=(proj_layer(P, "face_enc.", feat_t) if enable_proj else feat_t).max(2)[0], recon=recon)     # PoseNet9D.py:39-41
     if bn_train:
         out["_bn_new"] = P["_bn_new"]
     if want_intermediates:

@@ -126,7 +126,7 @@ def gen_layers():
 
 
 # ----------------------------------------------------------------------------- full forward
-def run_reference(net, pts, obj, seed, train):
+def run_reference(net, pts, obj, seed, train, enable_proj=False, grad=False):
     """Reference forward with every get_neighbor_index / get_nearest_index result recorded."""
     knn_rec, nn_rec = [], []
     o_knn, o_nn = ref_gcn.get_neighbor_index, ref_gcn.get_nearest_index
@@ -145,8 +145,8 @@ def run_reference(net, pts, obj, seed, train):
     try:
         FLAGS.train = train
         torch.manual_seed(seed)
-        with torch.no_grad():
-            out = net(pts, obj)
+        with torch.set_grad_enabled(grad):
+            out = net(pts, obj, enable_proj=True) if enable_proj else net(pts, obj)
     finally:
         ref_gcn.get_neighbor_index, ref_gcn.get_nearest_index = o_knn, o_nn
     names = ["conv_0.rf", "conv_0.orl_xyz", "conv_1.rf", "conv_1.orl_xyz", "pool_1.xyz", "conv_2.rf",
@@ -219,6 +219,45 @@ def gen_forward_train(name, B, N, wseed, pseed, fseed, steps=2):
         arrays["idx." + k] = small_idx(v)
     for k, v in net.state_dict().items():
         if "running_" in k or "num_batches" in k:
+            arrays["bn." + k] = v
+    save(name, **arrays)
+
+
+def gen_proj(name, B, N, wseed, pseed, fseed):
+    """enable_proj=True (FaceRecon.py:32-35,80-84; PoseNet9D.py:33,39,49): feat_global = max over points of proj_layer(feat).
+    The reference in eval mode (running statistics), and in training mode (batch statistics; dropout p = 0) with the gradients of
+    sum(feat_global ** 2) with respect to the projection head's own parameters and the moved BatchNorm buffers."""
+    sd = iw.seeded_state_dict(wseed)
+    pts, obj = synth_points(B, N, pseed)
+    net = RefPoseNet9D().eval()
+    net.load_state_dict(sd, strict=True)
+    out_eval, idx = run_reference(net, pts, obj, fseed, train=1, enable_proj=True)
+    plain, _ = run_reference(net, pts, obj, fseed, train=1)
+    assert not torch.equal(plain["feat_global"], out_eval["feat_global"])
+    net = RefPoseNet9D().train()
+    net.load_state_dict(sd, strict=True)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    out_tr, idx2 = run_reference(net, pts, obj, fseed, train=1, enable_proj=True, grad=True)
+    (out_tr["feat_global"] ** 2).sum().backward()
+    i1, i2 = sample_indices(N, fseed)
+    pl = "face_all.encoder.proj_layer."
+    arrays = dict(weight_seed=np.int64(wseed), forward_seed=np.int64(fseed), points=pts, obj_id=obj,
+                  sample_idx_1=small_idx(i1), sample_idx_2=small_idx(i2))
+    arrays["eval.feat_global"] = out_eval["feat_global"]
+    arrays["train.feat_global"] = out_tr["feat_global"].detach()
+    for k, v in idx.items():
+        arrays["idx." + k] = small_idx(v)
+    for k, v in idx2.items():
+        arrays["idx_train." + k] = small_idx(v)
+    params = dict(net.named_parameters())
+    for k in ("0.weight", "1.weight", "1.bias", "3.weight"):
+        g = params[pl + k].grad
+        arrays["grad." + k] = g if g.numel() < 4096 else g.reshape(g.shape[0], -1)[:, :16].contiguous()     # (a column slice of the big ones)
+        arrays["gradnorm." + k] = g.double().norm().float()
+    for k, v in net.state_dict().items():
+        if k.startswith(pl) and ("running_" in k or "num_batches" in k):
             arrays["bn." + k] = v
     save(name, **arrays)
 
@@ -830,6 +869,8 @@ def main():
         return gen_recon_completion()
     if sys.argv[1:] == ["input_side"]:
         return gen_input_side()
+    if sys.argv[1:] == ["proj"]:
+        return gen_proj("proj_b2_n256.npz", 2, 256, wseed=5, pseed=7, fseed=37)
     if sys.argv[1:] == ["train_step"]:
         gen_train_step()
         return gen_category_clouds()
@@ -848,6 +889,7 @@ def main():
     gen_forward("forward_b3_n256.npz", 3, 256, wseed=1, pseed=2, fseed=9, keep_feat_rows=96)
     gen_forward_train("forward_train_b4_n256.npz", 4, 256, wseed=2, pseed=5, fseed=31)
     gen_backward("backward_b3_n256.npz", 3, 256, wseed=3, pseed=6, fseed=33)
+    gen_proj("proj_b2_n256.npz", 2, 256, wseed=5, pseed=7, fseed=37)
     gen_chamfer()
     gen_input_side()        # last: it installs a cv2 stand-in
     gen_train_loader()

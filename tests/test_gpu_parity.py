@@ -894,6 +894,73 @@ def test_training_forward_vs_reference_golden(ops):
         FLAGS.train = 0
 
 
+def test_enable_proj_vs_reference_golden(ops):
+    """enable_proj=True of the module seam (PoseNet9D.py:33,39,49; FaceRecon.py:32-35,80-84): feat_global through Face_Enc.proj_layer --
+    two GEMMs on the concat buffer, BatchNorm + LeakyReLU in the first one's epilogue (eval) or as a batch-statistics pass (training),
+    the max over points in the second one's -- against the reference's own run (tests/golden/proj_b2_n256.npz): eval mode and
+    training mode under no_grad at 1e-4, the moved BatchNorm buffers, and (autograd path) the gradients of sum(feat_global ** 2) with
+    respect to the head's parameters at the bar of the other gradient tests.  The encoder-only net and the stand-alone sub-modules
+    take the same argument."""
+    from tgpose_amd import FLAGS, PoseNet9D, seeded_state_dict
+    from tests.test_oracle_golden import golden_proj_case
+    gd, pts, obj, sample, inj = golden_proj_case(False)
+    inj = {k: v.int() for k, v in inj.items()}
+    net = _net(int(gd["weight_seed"]))
+    FLAGS.train = 1
+    try:
+        with torch.no_grad():
+            out = net(g(pts), g(obj), True, sample_idx=sample, inject=inj)
+            plain = net(g(pts), g(obj), sample_idx=sample, inject=inj)
+        assert np.allclose(out["feat_global"].cpu().numpy(), gd["eval.feat_global"], atol=1e-4, rtol=0)
+        for k in plain:
+            if k != "feat_global":
+                assert torch.equal(plain[k], out[k]), k            # nothing else changes
+        assert not torch.allclose(plain["feat_global"], out["feat_global"], atol=1e-2)
+        # the stand-alone encoder module: the projected (B, 1286, N) tensor itself
+        _, prj = net.face_all.encoder(g(pts) - g(pts).mean(1, keepdim=True), g(obj), True)
+        assert prj.shape == (2, 1286, 256)
+        # training mode: no_grad (the trainer's net2), then with autograd
+        gd, pts, obj, sample, inj = golden_proj_case(True)
+        inj = {k: v.int() for k, v in inj.items()}
+        net = _train_net(int(gd["weight_seed"]))
+        sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+        with torch.no_grad():
+            out = net(g(pts), g(obj), True, sample_idx=sample, inject=inj)
+        assert np.allclose(out["feat_global"].cpu().numpy(), gd["train.feat_global"], atol=1e-4, rtol=0)
+        sd = {k: v.cpu() for k, v in net.state_dict().items()}
+        for k in gd.files:
+            if k.startswith("bn."):
+                assert np.allclose(sd[k[3:]].numpy(), gd[k], atol=1e-5, rtol=1e-4), k
+        net.load_state_dict(sd0)
+        out = net(g(pts), g(obj), True, sample_idx=sample, inject=inj)
+        assert np.allclose(out["feat_global"].detach().cpu().numpy(), gd["train.feat_global"], atol=1e-4, rtol=0)
+        (out["feat_global"] ** 2).sum().backward()
+        params = dict(net.named_parameters())
+        pl = "face_all.encoder.proj_layer."
+        for k in ("0.weight", "1.weight", "1.bias", "3.weight"):
+            gr = params[pl + k].grad.cpu()
+            norm = float(gd["gradnorm." + k])
+            assert abs(float(gr.double().norm()) - norm) <= GRAD_TOL * norm, (k, float(gr.double().norm()), norm)
+            part = gr if gr.numel() < 4096 else gr.reshape(gr.shape[0], -1)[:, :16]
+            assert np.abs(part.numpy() - gd["grad." + k]).max() <= GRAD_TOL * norm, k
+    finally:
+        FLAGS.train = 0
+    # the encoder-only net (the trainer's net2, PoseNet9D.py:35-45) against the oracle
+    _, _, PR = _oracle()
+    net2 = PoseNet9D(only_encoder=True)
+    sd2 = seeded_state_dict(6, only_encoder=True)
+    net2.load_state_dict(sd2, strict=True)
+    net2 = net2.to(DEV).eval()
+    p2, o2 = synth_points(2, 256, 9)
+    torch.manual_seed(3)
+    i1 = torch.randperm(256)[:64]
+    smp = (i1, torch.randperm(64)[:16])
+    with torch.no_grad():
+        want, inter = PR.encoder_only_forward(sd2, p2, o2, sample_idx=smp, mode="exact", enable_proj=True, want_intermediates=True)
+        got = net2(g(p2), g(o2), True, sample_idx=smp, inject=inter["indices"])
+    assert torch.allclose(got["feat_global"].cpu(), want["feat_global"], atol=1e-4, rtol=0)
+
+
 @pytest.mark.parametrize("B,N,seed,tol", [(4, 1028, 21, 1e-4), (3, 512, 22, 1e-4), (2, 512, 22, 2e-3)])
 def test_training_forward_vs_oracle(ops, B, N, seed, tol):
     """Teacher-forced on the oracle's graphs, 1e-4.  B = 2 is the ill-conditioned corner of the reference's own maths:

@@ -149,6 +149,44 @@ def test_forward_training_mode_vs_reference(mode, inject):
         assert np.allclose(sd[k[3:]].numpy(), g[k], atol=1e-5, rtol=1e-5), k
 
 
+def golden_proj_case(train):
+    g = golden("proj_b2_n256.npz")
+    pts, obj = torch.from_numpy(g["points"]), torch.from_numpy(g["obj_id"])
+    sample = (torch.from_numpy(g["sample_idx_1"].astype(np.int64)), torch.from_numpy(g["sample_idx_2"].astype(np.int64)))
+    pre = "idx_train." if train else "idx."
+    inj = {k[len(pre):]: torch.from_numpy(g[k].astype(np.int64)) for k in g.files if k.startswith(pre)}
+    return g, pts, obj, sample, inj
+
+
+def test_enable_proj_vs_reference():
+    """enable_proj=True (FaceRecon.py:32-35,80-84; PoseNet9D.py:49-50): feat_global = max over points of proj_layer(feat), against the
+    reference run with enable_proj=True in eval mode and in training mode (batch statistics; the projection head's BatchNorm
+    buffers after the step; the gradients of sum(feat_global ** 2) with respect to the head's own parameters)."""
+    g, pts, obj, sample, inj = golden_proj_case(False)
+    sd = seeded_state_dict(int(g["weight_seed"]))
+    with torch.no_grad():
+        out = PR.posenet_forward(sd, pts, obj, sample_idx=sample, train_keys=True, mode="exact", inject=inj, enable_proj=True)
+        plain = PR.posenet_forward(sd, pts, obj, sample_idx=sample, train_keys=True, mode="exact", inject=inj)
+    assert np.allclose(out["feat_global"].numpy(), g["eval.feat_global"], atol=2e-5, rtol=0)
+    assert not np.allclose(plain["feat_global"].numpy(), g["eval.feat_global"], atol=1e-2, rtol=0)
+    g, pts, obj, sample, inj = golden_proj_case(True)
+    pl = "face_all.encoder.proj_layer."
+    P = {k: (v.clone().requires_grad_(True) if k.startswith(pl) and v.dtype.is_floating_point and "running_" not in k else v.clone())
+         for k, v in sd.items()}
+    out = PR.posenet_forward(P, pts, obj, sample_idx=sample, train_keys=True, mode="exact", inject=inj, bn_train=True, enable_proj=True)
+    assert np.allclose(out["feat_global"].detach().numpy(), g["train.feat_global"], atol=2e-5, rtol=0)
+    for k in g.files:
+        if k.startswith("bn."):
+            assert np.allclose(out["_bn_new"][k[3:]].numpy(), g[k], atol=1e-5, rtol=1e-5), k
+    (out["feat_global"] ** 2).sum().backward()
+    for k in ("0.weight", "1.weight", "1.bias", "3.weight"):
+        gr = P[pl + k].grad
+        norm = float(g["gradnorm." + k])
+        assert abs(float(gr.double().norm()) - norm) <= 1e-3 * norm, k
+        part = gr if gr.numel() < 4096 else gr.reshape(gr.shape[0], -1)[:, :16]
+        assert np.abs(part.numpy() - g["grad." + k]).max() <= 1e-3 * norm, k
+
+
 def golden_backward_case():
     g = golden("backward_b3_n256.npz")
     seed = int(g["forward_seed"])

@@ -748,7 +748,19 @@ def point_head(hd, feat, x=None):
     return linear(x, _w2(hd.conv4), hd.conv4.bias)
 
 
-def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6, cut=None):
+def proj_global(enc, feat):
+    """feat_global with enable_proj=True (FaceRecon.py:32-35,80-84; PoseNet9D.py:39-41,49-50): max over the points of
+    proj_layer(feat) = conv(LeakyReLU(BatchNorm(conv(feat)))), differentiable; feat (B, N, FEAT_C) rows"""
+    B, N, C = feat.shape
+    pl = enc.proj_layer
+    x = linear(_pad4(feat.reshape(B * N, C)), _pad4(_w2(pl[0])))
+    x = bn_act(x, pl[1], act=1, slope=0.2)
+    y = linear(_pad4(x), _pad4(_w2(pl[3])))
+    return colmax(y.view(B, N, -1))
+
+
+def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6, cut=None,
+                    enable_proj=False):
     """PoseNet9D.forward (PoseNet9D.py:33-91) with autograd; net is the drop-in module (training mode).
     cut: an EncoderCut to split the backward at the encoder's output `feat` (GraphedStep's two-segment form: everything after
     `feat` is differentiated first, the encoder afterwards, so that the late layers' gradients can travel meanwhile)."""
@@ -767,7 +779,8 @@ def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=Non
         feat, parts = encoder(face.encoder, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
         dec0 = face.decoder.conv1d_block[0]
         xd = feat_consumers_factored(parts, [(_w2(dec0), dec0.bias)])[0] if parts is not None else None
-        return dict(feat_global=colmax(feat[:, :, :FEAT_C] if parts is None else feat), recon=decoder(face.decoder, feat, None, xd))
+        fo = feat[:, :, :FEAT_C] if parts is None else feat
+        return dict(feat_global=proj_global(face.encoder, fo) if enable_proj else colmax(fo), recon=decoder(face.decoder, feat, None, xd))
     face = net.face_all
     graphs = _GraphSource(points.device, inject, record, "face_all.encoder.")
     feat, parts = encoder(face.encoder, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
@@ -797,7 +810,7 @@ def posenet_forward(net, points, obj_id, train_keys, sample_idx=None, inject=Non
     if train_keys:
         out["h1"], out["h2"] = h1, h2
         out["feat"] = feat[:, :, :FEAT_C] if parts is None else feat
-        out["feat_global"] = colmax(out["feat"])
+        out["feat_global"] = proj_global(face.encoder, out["feat"]) if enable_proj else colmax(out["feat"])
     return out
 
 

@@ -211,6 +211,44 @@ class Packed(object):
             ops.heads_repack_vectors(f["w2p"], w["bias"][1024:], w["scale"][1024:], w["shift"][1024:])
 
 
+PROJ_LD = 1288          # FEAT_C padded to whole float4: row stride of the projection head's inner activation
+
+
+def proj_operands(sd, face, device):
+    """Face_Enc.proj_layer (FaceRecon.py:32-35; applied to feat_global when enable_proj, :80-84) as GEMM operands over the concat
+    buffer: Conv1d 1286 -> 1286 (no bias) | BatchNorm1d | LeakyReLU(0.2) | Conv1d 1286 -> 1286 (no bias).  Rows / columns are
+    zero-padded to the buffers' strides (1292 in, 1288 between and out).  Built on first use: the reference's callers never pass
+    enable_proj (its 3.31 M parameters are in every checkpoint all the same)."""
+    pl = face + "encoder.proj_layer."
+    sd = _dev_sd({k: v for k, v in sd.items() if k.startswith(pl)}, device)
+    w1 = _pad_rows(_pad_cols(sd[pl + "0.weight"][:, :, 0], FEAT_LD), PROJ_LD).contiguous()
+    w2 = _pad_rows(_pad_cols(sd[pl + "3.weight"][:, :, 0], PROJ_LD), PROJ_LD).contiguous()
+    return dict(name=pl + "1", w1=w1, w2=w2, w1s=ops.split_w(w1), w2s=ops.split_w(w2))
+
+
+def proj_feat_global(po, feat, sd=None, bn=None):
+    """feat_global with enable_proj=True (PoseNet9D.py:39-41,49-50): max over each object's points of proj_layer(feat).  feat: the
+    concat buffer (B, N, FEAT_LD).  bn: the training-mode BatchNorm applier (batch statistics, moves the buffers); else the eval
+    fold of the running statistics in sd.  The second conv's activation is never stored: its epilogue keeps the maxima as keys."""
+    B, N, ld = feat.shape
+    if ld != FEAT_LD or feat.stride(1) != FEAT_LD:
+        raise ValueError("proj_feat_global: the concat buffer (row stride %d) expected" % FEAT_LD)
+    M = B * N
+    dev = feat.device
+    f2 = feat.view(M, FEAT_LD)
+    if bn is None:
+        scale, shift = _fold_values(sd, po["name"])
+        one, zero = torch.ones(PROJ_LD - FEAT_C, device=dev), torch.zeros(PROJ_LD - FEAT_C, device=dev)
+        h = ops.linear_rows(f2, po["w1"], scale=torch.cat([scale.to(dev), one]), shift=torch.cat([shift.to(dev), zero]), act=1, slope=0.2,
+                            w_split=po["w1s"])
+    else:
+        h = ops.linear_rows(f2, po["w1"], w_split=po["w1s"])
+        bn(po["name"], h[:, :FEAT_C], act=1, slope=0.2)
+    keys = torch.zeros(B, PROJ_LD, device=dev, dtype=torch.int32)
+    ops.linear_rows(h, po["w2"], colmax_keys=keys, rows_per_obj=N, want_out=False, w_split=po["w2s"])
+    return ops.colmax_decode(keys)[:, :FEAT_C].contiguous()
+
+
 FINE_K = 268            # fm_0 | fm_1 | one-hot | xyz | 3 zero columns: the part of `feat` that differs from point to point
 FINE_LD = 272
 
@@ -894,7 +932,7 @@ def draw_sample_idx(N):
 
 
 def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6, probe=None,
-                    outputs_only=None):
+                    outputs_only=None, proj=None):
     """PoseNet9D(only_encoder=False).forward in eval mode (PoseNet9D.py:46-91).
     probe (tests): a dict that receives what the six-key eval result does not return -- recon (with the cloud's mean added), h1,
     h2, feat_global -- so that the factored / fused eval paths' decoder and PH branch can be compared with the concat path's."""
@@ -969,11 +1007,12 @@ def posenet_forward(pk, points, obj_id, train_keys, sample_idx=None, inject=None
     if train_keys:
         out["h1"], out["h2"] = h1, h2
         out["feat"] = feat[:, :, :FEAT_C]
-        out["feat_global"] = ops.colmax(feat[:, :, :FEAT_C])
+        # (proj: enable_proj=True -- (operands, state dict); PoseNet9D.py:49-50)
+        out["feat_global"] = ops.colmax(feat[:, :, :FEAT_C]) if proj is None else proj_feat_global(proj[0], feat, sd=proj[1])
     return out
 
 
-def encoder_only_forward(pk, points, obj_id, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6):
+def encoder_only_forward(pk, points, obj_id, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6, proj=None):
     """PoseNet9D(only_encoder=True).forward (PoseNet9D.py:35-45): encoder + decoder without the PH branch."""
     B, N, _ = points.shape
     if sample_idx is None:
@@ -982,7 +1021,8 @@ def encoder_only_forward(pk, points, obj_id, sample_idx=None, inject=None, recor
     graphs = Graphs(points.device, inject, record, prefix="face_enc.encoder.")
     feat, _ = encoder_forward(pk, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
     recon = decoder_forward(pk, feat, None, N)
-    return dict(feat_global=ops.colmax(feat[:, :, :FEAT_C]), recon=recon)
+    fg = ops.colmax(feat[:, :, :FEAT_C]) if proj is None else proj_feat_global(proj[0], feat, sd=proj[1])
+    return dict(feat_global=fg, recon=recon)
 
 
 # =====================================================================================================
@@ -1092,7 +1132,7 @@ def decoder_forward_train(pk, bn, feat, back, N):
 
 
 def posenet_forward_train(pk, sd, points, obj_id, train_keys, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6,
-                          dropout_p=(0.5, 0.2), update_running=True, generator=None):
+                          dropout_p=(0.5, 0.2), update_running=True, generator=None, proj=None):
     """PoseNet9D(only_encoder=False).forward with module.training == True (no autograd)."""
     B, N, _ = points.shape
     if B < 2:     # bn5 / the heads' bn3 normalise over the B pooled rows; torch refuses a single row the same way
@@ -1150,12 +1190,12 @@ def posenet_forward_train(pk, sd, points, obj_id, train_keys, sample_idx=None, i
     if train_keys:
         out["h1"], out["h2"] = hcode[:, :nc], hcode[:, nc:]
         out["feat"] = feat[:, :, :FEAT_C]
-        out["feat_global"] = ops.colmax(feat[:, :, :FEAT_C])
+        out["feat_global"] = ops.colmax(feat[:, :, :FEAT_C]) if proj is None else proj_feat_global(proj[0], feat, bn=bn)
     return out
 
 
 def encoder_only_forward_train(pk, sd, points, obj_id, sample_idx=None, inject=None, record=None, kmax=20, n_cls=6,
-                               update_running=True):
+                               update_running=True, proj=None):
     """PoseNet9D(only_encoder=True).forward in training mode (the reference's net2)."""
     B, N, _ = points.shape
     if sample_idx is None:
@@ -1165,7 +1205,8 @@ def encoder_only_forward_train(pk, sd, points, obj_id, sample_idx=None, inject=N
     graphs = Graphs(points.device, inject, record, prefix="face_enc.encoder.")
     feat = encoder_forward_train(pk, bn, xyz, obj_id.to(points.device), sample_idx, graphs, kmax, n_cls)
     recon = decoder_forward_train(pk, bn, feat, None, N)
-    return dict(feat_global=ops.colmax(feat[:, :, :FEAT_C]), recon=recon)
+    fg = ops.colmax(feat[:, :, :FEAT_C]) if proj is None else proj_feat_global(proj[0], feat, bn=bn)
+    return dict(feat_global=fg, recon=recon)
 
 
 # =====================================================================================================

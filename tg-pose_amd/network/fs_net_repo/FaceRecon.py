@@ -40,14 +40,36 @@ class Face_Enc(_WithBuffers):
         self.bn1 = nn.BatchNorm1d(128)
         self.bn2 = nn.BatchNorm1d(256)
         self.bn3 = nn.BatchNorm1d(256)
-        # present in every reference checkpoint, never used by the forward path (enable_proj=False everywhere)
+        # the projection head of feat_global (enable_proj=True; the reference's own callers never pass it)
         self.proj_layer = nn.Sequential(nn.Conv1d(1286, 1286, kernel_size=1, bias=False), nn.BatchNorm1d(1286),
                                         nn.LeakyReLU(negative_slope=0.2), nn.Conv1d(1286, 1286, kernel_size=1, bias=False))
 
+    def project(self, feat_buf):
+        """proj_layer on the rows of the encoder's output (FaceRecon.py:80-84, enable_proj=True): feat_buf (B, N, >= 1286 columns:
+        the concat buffer in eval mode, the autograd path's feature in training mode) -> feat_global_prj (B, 1286, N)."""
+        B, N = feat_buf.shape[:2]
+        C = engine.FEAT_C
+        if self.training:
+            from ... import autograd as tgp_autograd
+            pl = self.proj_layer
+            x = tgp_autograd.linear(tgp_autograd._pad4(feat_buf[:, :, :C].reshape(B * N, C)), tgp_autograd._pad4(tgp_autograd._w2(pl[0])))
+            x = tgp_autograd.bn_act(x, pl[1], act=1, slope=0.2)
+            y = tgp_autograd.linear(tgp_autograd._pad4(x), tgp_autograd._pad4(tgp_autograd._w2(pl[3])))
+            return y.view(B, N, C).permute(0, 2, 1)
+        dev = feat_buf.device
+        sd = {"proj_layer." + k: v for k, v in self.proj_layer.state_dict().items()}
+        po = engine.proj_operands({"encoder." + k: v for k, v in sd.items()}, "", dev)
+        scale, shift = engine._fold_values(engine._dev_sd({"encoder." + k: v for k, v in sd.items()}, dev), po["name"])
+        pad = engine.PROJ_LD - C
+        h = ops.linear_rows(feat_buf.reshape(B * N, feat_buf.shape[2]), po["w1"][:, : feat_buf.shape[2]].contiguous(),
+                            scale=torch.cat([scale, torch.ones(pad, device=dev)]), shift=torch.cat([shift, torch.zeros(pad, device=dev)]),
+                            act=1, slope=0.2)
+        y = ops.linear_rows(h, po["w2"])
+        return y.view(B, N, -1)[:, :, :C].permute(0, 2, 1)
+
     def forward(self, vertices, cat_id, enable_proj=False):
-        """vertices (B,N,3) already centred, cat_id (B,1) -> feat (B,N,1286), feat_global (B,1286,N)."""
-        if enable_proj:
-            raise NotImplementedError("enable_proj=True is never used by the reference's train/eval path")
+        """vertices (B,N,3) already centred, cat_id (B,1) -> feat (B,N,1286), feat_global (B,1286,N) [through proj_layer when
+        enable_proj, FaceRecon.py:80-84]."""
         dev = vertices.device
         if self.training:
             from ... import autograd as tgp_autograd
@@ -55,14 +77,15 @@ class Face_Enc(_WithBuffers):
             feat, _parts = tgp_autograd.encoder(self, xyz, cat_id.to(dev), engine.draw_sample_idx(xyz.shape[1]),
                                                 tgp_autograd._GraphSource(dev, None, None, ""), self.neighbor_num, FLAGS.obj_c)
             feat = feat[:, :, : engine.FEAT_C]
-            return feat, feat.permute(0, 2, 1)
+            return feat, (self.project(feat) if enable_proj else feat.permute(0, 2, 1))
         conv = self._packed(lambda: engine.pack_encoder(engine._dev_sd(self.state_dict(), dev), "", dev))
         pk = type("EncPack", (), dict(conv=conv))
         xyz = vertices.detach().float().contiguous()
         feat, _ = engine.encoder_forward(pk, xyz, cat_id, engine.draw_sample_idx(xyz.shape[1]),
                                          engine.Graphs(dev), self.neighbor_num, FLAGS.obj_c)
+        prj = self.project(feat) if enable_proj else None
         feat = feat[:, :, : engine.FEAT_C]
-        return feat, feat.permute(0, 2, 1)
+        return feat, (prj if enable_proj else feat.permute(0, 2, 1))
 
 
 class Face_Dec(_WithBuffers):
@@ -130,9 +153,8 @@ class FaceNet(_WithBuffers):
         self.ph_pred = PH_Predictor()
 
     def forward(self, vertices, cat_id, enable_proj=False, pred_PH=True):
-        """-> recon (B,N,3), feat (B,N,1286), feat_global (B,1286,N), h1, h2   (FaceRecon.py:178-200)"""
-        if enable_proj:
-            raise NotImplementedError("enable_proj=True is never used by the reference's train/eval path")
+        """-> recon (B,N,3), feat (B,N,1286), feat_global (B,1286,N) [through the encoder's proj_layer when enable_proj], h1, h2
+        (FaceRecon.py:178-200)"""
         dev = vertices.device
         if self.training:
             from ... import autograd as tgp_autograd
@@ -152,7 +174,7 @@ class FaceNet(_WithBuffers):
                 back, h1, h2 = tgp_autograd.ph_predictor(self.ph_pred, featp, x5)
             recon = tgp_autograd.decoder(self.decoder, featp, back, xd)
             f = featp[:, :, : engine.FEAT_C]
-            return recon, f, f.permute(0, 2, 1), h1, h2
+            return recon, f, (self.encoder.project(f) if enable_proj else f.permute(0, 2, 1)), h1, h2
         pk = self._packed(lambda: engine.Packed(self.state_dict(), dev, face="", with_heads=False))
         xyz = vertices.detach().float().contiguous()
         N = xyz.shape[1]
@@ -163,4 +185,4 @@ class FaceNet(_WithBuffers):
             h1, h2, back = engine.ph_forward(pk, feat, N)
         recon = engine.decoder_forward(pk, feat, back, N)
         f = feat[:, :, : engine.FEAT_C]
-        return recon, f, f.permute(0, 2, 1), h1, h2
+        return recon, f, (self.encoder.project(feat) if enable_proj else f.permute(0, 2, 1)), h1, h2
