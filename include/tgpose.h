@@ -327,6 +327,10 @@ int tgp_pose_tail(const uint32_t *keys2, const float *w3t, const float *b3, cons
  * identity); out (rows, n_out) contiguous.  TGP_EUNSUPPORTED for other n_out. */
 int tgp_rows_out(const float *x, int ld, int64_t rows, int K, const float *W, int ldw, const float *bias, int n_out,
                  const int64_t *map, int rows_per_obj, float *out, tgp_stream_t stream);
+/* (ABI 7) the same, predicated: the launch returns at once while *pred == 0 (pred may be NULL: always runs) -- the last step of a repair
+ * chain (tgp_gemm_args.pred) whose result replaces tgp_dec_fused's rows */
+int tgp_rows_out_pred(const float *x, int ld, int64_t rows, int K, const float *W, int ldw, const float *bias, int n_out,
+                      const int64_t *map, int rows_per_obj, float *out, const int *pred, tgp_stream_t stream);
 
 /* PoseNet9D.py:71 recon + mean, in place on recon (B,n,3). */
 int tgp_add_mean(float *recon, const float *mean, int B, int n, tgp_stream_t stream);
@@ -691,6 +695,34 @@ int tgp_conv_max_fused(const tgp_conv_max_fused_args *args, tgp_stream_t stream)
 int64_t tgp_heads_w2_bytes(int heads);
 int tgp_heads_pack_w2(const float *w2, const float *bias1, const float *scale1, const float *shift1, int heads, void *out,
                       tgp_stream_t stream);
+
+/* (ABI 7) The decoder behind its first conv as ONE kernel (FaceRecon.py:105-117 Face_Dec in eval mode: conv 512 -> 512, 512 -> 256,
+ * 256 -> 128, each + BatchNorm + ReLU, then conv 128 -> 3), csrc/dec_fused.hip: a wave owns 32 points for the whole chain, no activation
+ * between the layers leaves its registers.
+ *   h1_planes: the first conv's activation (M, 512) as blocked fp16 planes (tgp_gemm_args.C_planes of that launch, h1_kt >= 32 K-tiles
+ *   per row block); h1_amax: its per-32-row-block magnitude words (may be NULL);
+ *   units = tgp_dec_pack(W2 (512, 512), W3 (256, 512), W4 (128, 256)) (tgp_dec_pack_bytes() bytes, 16-byte aligned): the three weights
+ *   as fp16 hi / lo MFMA fragments in staging order, W3 / W4 with K permuted to the order the accumulators hold the channels in;
+ *   vec[l][0 / 1 / 2]: bias / BatchNorm scale / shift of layer l + 2 (512, 256, 128 floats; read at every launch: they follow a refold);
+ *   w5 (3, 128) and b5 (3): the last conv; map (may be NULL) as tgp_rows_out's: out row of row i = (i / rows_per_obj) * rows_per_obj + map[i];
+ *   out (M, 3);
+ *   flag: device int (zeroed by the caller; required): raised when the operand's magnitude words or any sum of the chain leave fp16's
+ *   range (or the operand's block lies wholly under 2^-4): `out` is then not to be trusted and the caller's predicated fp32 chain
+ *   (tgp_gemm_args.pred) redoes the layers.  Layer 2's sums equal tgp_gemm_f32's on the same planes bit for bit; layers 3, 4 and the
+ *   last conv add the same products in another order (agreement to rounding). */
+typedef struct tgp_dec_fused_args {
+    const void *h1_planes; int h1_kt; const uint32_t *h1_amax;
+    const void *units;
+    const float *vec[3][3];
+    const float *w5; const float *b5;
+    const int64_t *map; int rows_per_obj;
+    float *out;
+    int *flag;
+    int M;
+} tgp_dec_fused_args;
+int tgp_dec_fused(const tgp_dec_fused_args *args, tgp_stream_t stream);
+int64_t tgp_dec_pack_bytes(void);
+int tgp_dec_pack(const float *w2, const float *w3, const float *w4, void *out, tgp_stream_t stream);
 
 /* ---- the factored wide layers in TRAINING (ABI 4; this repo's engine, no reference counterpart: the reference multiplies the
  * up-sampled copies, FaceRecon.py:70-77) -----------------------------------------------------------------------------------------

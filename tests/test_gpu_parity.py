@@ -3872,12 +3872,17 @@ def test_heads_fused_keys_do_not_depend_on_the_batch_around_an_object(ops):
 
 
 @pytest.mark.parametrize("scale", [1.0, 1e6, 1e-5])
-def test_decoder_chain_on_planes_only(ops, scale):
-    """engine.DEC_PLANES_ONLY: the decoder's inner activations exist as fp16 planes only (each layer's epilogue writes the next one's
-    operand; no fp32 copies).  scale 1: bit-identical reconstruction to the forward without planes.  scale 1e6 / 1e-5 on the first
-    decoder layer's BatchNorm puts its activation beyond fp16's range / under 2^-4 everywhere: the consuming layer cannot recompute
-    such tiles (it has no fp32 operand), raises the chain's flag on the device, and the predicated fp32 chain supplies the result --
-    again the bits of the forward without planes, nothing read back."""
+@pytest.mark.parametrize("fused", [False, True])
+def test_decoder_chain_on_planes_only(ops, scale, fused):
+    """engine.DEC_PLANES_ONLY: the decoder's inner activations never exist in fp32 -- as fp16 planes only between tile launches (each
+    layer's epilogue writes the next one's operand; fused = False), or not at all outside the registers (engine.DEC_FUSED, round 5: the
+    layers behind the first conv as ONE launch, csrc/dec_fused.hip).
+    scale 1: the reconstruction of the forward without planes -- bit for bit on the tile launches; within 2e-6 of the output's scale
+    for the fused kernel (its 512 -> 512 layer adds the same products in the same order, the two after it sum the sixteen products of a
+    K-step in another order and the last conv sums per half wave first: agreement to rounding).
+    scale 1e6 / 1e-5 on the first decoder layer's BatchNorm puts its activation beyond fp16's range / under 2^-4 everywhere: the consumer
+    cannot recompute (it has no fp32 operand), raises the chain's flag on the device, and the predicated fp32 chain supplies the result --
+    in both forms the bits of the forward without planes, nothing read back."""
     from tgpose_amd import PoseNet9D, seeded_state_dict, FLAGS, engine
     sd = seeded_state_dict(16)
     for k in ("weight", "bias"):
@@ -3892,18 +3897,55 @@ def test_decoder_chain_on_planes_only(ops, scale):
     i1 = torch.randperm(N)[: N // 4]
     smp = (i1, torch.randperm(N // 4)[: N // 16])
     pk = net.packed(DEV)
+    assert pk.dec_units is not None
     got = []
     for planes, only in ((True, True), (False, False)):
-        old = ops.PLANES, engine.DEC_PLANES_ONLY
-        ops.PLANES, engine.DEC_PLANES_ONLY = planes, only
+        old = ops.PLANES, engine.DEC_PLANES_ONLY, engine.DEC_FUSED
+        ops.PLANES, engine.DEC_PLANES_ONLY, engine.DEC_FUSED = planes, only, fused
         try:
             probe = {}
             with torch.no_grad():
                 engine.posenet_forward(pk, g(pts), g(obj), False, sample_idx=smp, probe=probe)
             got.append(probe["recon"].clone())
         finally:
-            ops.PLANES, engine.DEC_PLANES_ONLY = old
-    assert torch.isfinite(got[0]).all() and torch.equal(got[0], got[1])
+            ops.PLANES, engine.DEC_PLANES_ONLY, engine.DEC_FUSED = old
+    assert torch.isfinite(got[0]).all()
+    if fused and scale == 1.0:
+        mean = g(pts).mean(1, keepdim=True)
+        err = (got[0] - got[1]).abs().max().item()
+        assert err <= 2e-6 * max(1.0, (got[1] - mean).abs().max().item()), err
+    else:
+        assert torch.equal(got[0], got[1])
+
+
+def test_dec_fused_vs_fp64_and_partial_tiles(ops):
+    """tgp_dec_fused at the operator level on random operands: B = 3 objects of 301 points (M = 903: a partial last 32-row block, a partial
+    last 128-row tile), rows leaving through a permutation per object -- against an fp64 restatement of relu(bn(conv)) x 3 -> conv, at
+    the bar of the split GEMM per layer (3e-6 of the output's scale; three layers)."""
+    gen = torch.Generator().manual_seed(9)
+    B, N = 3, 301
+    M = B * N
+    d = lambda t: g(t.contiguous())
+    H1 = torch.relu(torch.randn(M, 512, generator=gen))
+    Ws = [torch.randn(n, k, generator=gen) / k ** 0.5 for n, k in ((512, 512), (256, 512), (128, 256))]
+    vecs = [(torch.randn(n, generator=gen) * 0.1, torch.rand(n, generator=gen) + 0.5, torch.randn(n, generator=gen) * 0.1) for n in (512, 256, 128)]
+    w5, b5 = torch.randn(3, 128, generator=gen) / 11.0, torch.randn(3, generator=gen)
+    order = torch.stack([torch.randperm(N, generator=gen) for _ in range(B)])
+    flag = torch.zeros(1, device=DEV, dtype=torch.int32)
+    out = ops.dec_fused(ops.planes_split(d(H1), K=512), ops.dec_pack(*[d(w) for w in Ws]), [[d(v) for v in vv] for vv in vecs], d(w5), d(b5),
+                        d(order), N, flag).view(B, N, 3)
+    x = H1.double()
+    for i in range(3):
+        x = torch.relu((x @ Ws[i].double().t() + vecs[i][0].double()) * vecs[i][1].double() + vecs[i][2].double())
+    y = (x @ w5.double().t() + b5.double()).view(B, N, 3)
+    ref = torch.empty(B, N, 3, dtype=torch.float64).scatter_(1, order.unsqueeze(-1).expand(-1, -1, 3), y)
+    assert int(flag.item()) == 0
+    assert (out.cpu().double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    # a magnitude beyond fp16's range in the operand's planes raises the flag
+    H1[5, 7] = 1e5
+    flag.zero_()
+    ops.dec_fused(ops.planes_split(d(H1), K=512), ops.dec_pack(*[d(w) for w in Ws]), [[d(v) for v in vv] for vv in vecs], d(w5), d(b5), d(order), N, flag)
+    assert int(flag.item()) == 1
 
 
 @pytest.mark.parametrize("B,n,C", [(3, 1028, 128), (2, 257, 256), (2, 100, 64), (2, 64, 512)])

@@ -84,6 +84,20 @@ class HeadsFusedArgs(ctypes.Structure):
     ]
 
 
+class DecFusedArgs(ctypes.Structure):
+    """struct tgp_dec_fused_args (include/tgpose.h)"""
+    _fields_ = [
+        ("h1_planes", c_vp), ("h1_kt", c_int), ("h1_amax", c_vp),
+        ("units", c_vp),
+        ("vec", (c_vp * 3) * 3),
+        ("w5", c_vp), ("b5", c_vp),
+        ("map", c_vp), ("rows_per_obj", c_int),
+        ("out", c_vp),
+        ("flag", c_vp),
+        ("M", c_int),
+    ]
+
+
 SIGNATURES = {
     "tgp_version": (c_int, []),
     "tgp_graph_node_counts": (c_int, [c_vp, c_vp]),
@@ -181,12 +195,16 @@ SIGNATURES = {
     "tgp_conv_max_fused": (c_int, [ctypes.POINTER(ConvMaxFusedArgs), c_vp]),
     "tgp_heads_pack_w2": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "tgp_heads_w2_bytes": (c_i64, [c_int]),
+    "tgp_dec_fused": (c_int, [ctypes.POINTER(DecFusedArgs), c_vp]),
+    "tgp_dec_pack_bytes": (c_i64, []),
+    "tgp_dec_pack": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tgp_sort_by_parent": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tgp_roi_cloud": (c_int, [c_vp] * 7 + [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_cloud_select": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, c_vp, c_vp]),
     "tgp_pose_rotation_fwd": (c_int, [c_vp] * 6 + [c_int, c_vp, c_vp, c_vp]),
     "tgp_pose_rotation_bwd": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp]),
     "tgp_rows_out": (c_int, [c_vp, c_int, c_i64, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
+    "tgp_rows_out_pred": (c_int, [c_vp, c_int, c_i64, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "tgp_pose_tail": (c_int, [c_vp] * 8 + [c_int] + [c_vp] * 8),
     "tgp_head_post_bwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int] + [c_vp] * 10),
     "tgp_transpose_both": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),

@@ -1571,8 +1571,10 @@ extern "C" int tgp_pose_tail(const uint32_t *keys2, const float *w3t, const floa
 template <int NO>
 __global__ __launch_bounds__(256) void rows_out_kernel(const float *__restrict__ x, int ld, int64_t rows, int K,
                                                        const float *__restrict__ W, int ldw, const float *__restrict__ bias,
-                                                       const int64_t *__restrict__ map, int rows_per_obj, float *__restrict__ out)
+                                                       const int64_t *__restrict__ map, int rows_per_obj, float *__restrict__ out,
+                                                       const int *__restrict__ pred)
 {
+    if (pred && *pred == 0) return;              // a repair launch whose condition did not arise
     const int l = threadIdx.x & 31;
     const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
     const int64_t rr = row < rows ? row : rows - 1;            // (whole waves reach the shuffles)
@@ -1597,15 +1599,23 @@ __global__ __launch_bounds__(256) void rows_out_kernel(const float *__restrict__
     for (int j = 0; j < NO; ++j) out[dst * NO + j] = acc[j] + (bias ? bias[j] : 0.f);
 }
 
+extern "C" int tgp_rows_out_pred(const float *x, int ld, int64_t rows, int K, const float *W, int ldw, const float *bias, int n_out,
+                                 const int64_t *map, int rows_per_obj, float *out, const int *pred, tgp_stream_t stream);
 extern "C" int tgp_rows_out(const float *x, int ld, int64_t rows, int K, const float *W, int ldw, const float *bias, int n_out,
                             const int64_t *map, int rows_per_obj, float *out, tgp_stream_t stream)
+{
+    return tgp_rows_out_pred(x, ld, rows, K, W, ldw, bias, n_out, map, rows_per_obj, out, nullptr, stream);
+}
+
+extern "C" int tgp_rows_out_pred(const float *x, int ld, int64_t rows, int K, const float *W, int ldw, const float *bias, int n_out,
+                                 const int64_t *map, int rows_per_obj, float *out, const int *pred, tgp_stream_t stream)
 {
     TGP_REQUIRE(x && W && out && rows > 0 && K > 0 && (K & 3) == 0 && ld >= K && ldw >= K && (ld & 3) == 0 && (ldw & 3) == 0);
     TGP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0);
     TGP_REQUIRE(!map || (rows_per_obj > 0 && rows % rows_per_obj == 0));
     if (n_out < 1 || n_out > 4) return TGP_EUNSUPPORTED;
     const dim3 grid((unsigned)tgp_cdiv(rows, 8));
-#define RO_GO(NO) hipLaunchKernelGGL(rows_out_kernel<NO>, grid, dim3(256), 0, tgp_hs(stream), x, ld, rows, K, W, ldw, bias, map, rows_per_obj, out)
+#define RO_GO(NO) hipLaunchKernelGGL(rows_out_kernel<NO>, grid, dim3(256), 0, tgp_hs(stream), x, ld, rows, K, W, ldw, bias, map, rows_per_obj, out, pred)
     if (n_out == 1) RO_GO(1); else if (n_out == 2) RO_GO(2); else if (n_out == 3) RO_GO(3); else RO_GO(4);
 #undef RO_GO
     return TGP_LAUNCH_RESULT();

@@ -196,6 +196,11 @@ class Packed(object):
                 self.wide = pack_wide(self.ph, [self.heads[h] for h in HEAD_ORDER],
                                       dict(conv5=face + "ph_pred.conv_5.1", heads=[h + "." for h in HEAD_ORDER]))
                 self.fact = pack_factored(self.wide, self.dec[0])
+            # the fused decoder kernel's staging image of the three inner weights (fp16 operands without a pack-time rescale)
+            self.dec_units = None
+            if (ops.planes_on() and [tuple(d[0].shape) for d in self.dec[1:]] == [(512, 512), (256, 512), (128, 256)]
+                    and tuple(self.dec_out[0].shape) == (3, 128) and all(d[5] is not None and d[5].tgp_unscale is None for d in self.dec[1:])):
+                self.dec_units = ops.dec_pack(self.dec[1][0], self.dec[2][0], self.dec[3][0])
         finally:
             _FOLDS = None
 
@@ -308,6 +313,7 @@ COARSE_SIDE = os.environ.get("TGP_COARSE_SIDE", "0") != "0"
 EVAL_OUTPUTS_ONLY = os.environ.get("TGP_EVAL_OUTPUTS_ONLY", "0") != "0"
 HEADS_TAIL = os.environ.get("TGP_HEADS_TAIL", "0") != "0"
 DEC_PLANES_ONLY = os.environ.get("TGP_DEC_PLANES_ONLY", "1") != "0"     # the decoder's inner activations as fp16 planes only
+DEC_FUSED = os.environ.get("TGP_DEC_FUSED", "1") != "0"     # ... and everything behind its first conv as one launch (csrc/dec_fused.hip)
 REPAIR_OBJS = 16        # objects per chunk of the fused heads kernel's fp16-range repair (wide_gemm_factored)
 
 
@@ -811,7 +817,14 @@ def decoder_forward_factored(pk, fine, inter, P1, P2, back, N, arena=None, rb=No
         ops.gemm(fine, f["dec_a"], None, flops_ref=2.0 * M * 512 * FEAT_C, a_planes=pl["fine"], w_planes=f["dec_a_p"], c_planes=pl["d1"], **gk)
         xp = pl["d1"]
         x = torch.empty(M, widths[-1], device=dev, dtype=torch.float32)
-        for i, ((w, b, sc, sh, ws, wp), nxt) in enumerate(zip(pk.dec[1:], ("d2", "d3", None))):
+        fused = DEC_FUSED and ROWS_OUT and getattr(pk, "dec_units", None) is not None
+        if fused:
+            # (round 5) 512 -> 512 -> 256 -> 128 -> 3 and the un-sort of the rows as ONE launch: no activation between the layers leaves
+            # the registers.  Same flag: a wave whose operand block or sums leave fp16's range raises it and the predicated fp32 chain
+            # below -- now with a predicated last step -- rewrites the reconstruction.
+            recon = ops.dec_fused(xp, pk.dec_units, [d[1:4] for d in pk.dec[1:]], pk.dec_out[0], pk.dec_out[1], inter["order"].contiguous(),
+                                  N, flag).view(B, N, 3)
+        for i, ((w, b, sc, sh, ws, wp), nxt) in enumerate(() if fused else zip(pk.dec[1:], ("d2", "d3", None))):
             ops.gemm(None, w, x if nxt is None else None, M=M, N=w.shape[0], K=w.shape[1], lda=0, ldw=w.shape[1], ldc=w.shape[0], bias=b,
                      scale=sc, shift=sh, act=1, w_split=ws, a_planes=xp, w_planes=wp, c_planes=pl.get(nxt) if nxt else None, range_flag=flag)
             xp = pl.get(nxt) if nxt else None
@@ -828,6 +841,8 @@ def decoder_forward_factored(pk, fine, inter, P1, P2, back, N, arena=None, rb=No
                      shift=sh, act=1, w_split=ws, flops_ref=0, pred=flag)
             y = out
         x = x.view(B, N, -1)
+        if fused:
+            return ops.rows_out(x, pk.dec_out[0], pk.dec_out[1], inter["order"].contiguous(), out=recon, pred=flag)
     else:
         x = torch.empty(B, N, 512, device=dev, dtype=torch.float32)
         # the chain on the pre-split kernel: each layer's epilogue leaves the next one's operand planes (the fp32 copies are written

@@ -690,6 +690,49 @@ def heads_fused(fine, K, wa_planes, p1, idx1, p2, idx2, w2p, bias2, scale2, shif
     return keys, overflow
 
 
+def dec_pack(w2, w3, w4):
+    """the decoder's 512 -> 512, 512 -> 256, 256 -> 128 weights -> the fused decoder kernel's staging image (tgp_dec_pack)"""
+    if tuple(w2.shape) != (512, 512) or tuple(w3.shape) != (256, 512) or tuple(w4.shape) != (128, 256):
+        raise ValueError("dec_pack: weights of (512, 512), (256, 512), (128, 256) expected")
+    out = torch.empty(_lib.lib().tgp_dec_pack_bytes(), device=w2.device, dtype=torch.uint8)
+    check(_lib.lib().tgp_dec_pack(_p(w2.contiguous()), _p(w3.contiguous()), _p(w4.contiguous()), _p(out), _stream(w2)), "tgp_dec_pack")
+    return out
+
+
+def dec_fused(h1_planes, units, vecs, w5, b5, order, rows_per_obj, flag, out=None):
+    """The decoder behind its first conv as one launch (tgp_dec_fused): h1_planes = the first conv's activation (M, 512) as planes;
+    vecs = ((bias, scale, shift) of the 512 -> 512 layer, of 512 -> 256, of 256 -> 128); w5 (3, 128), b5 (3); order (B, n) int64 (the
+    sort's permutation) or None; flag (1,) int32 (zeroed by the caller).  -> (M, 3) rows in point order"""
+    M = h1_planes.rows
+    if h1_planes.K != 512:
+        raise ValueError("dec_fused: a (M, 512) operand expected")
+    if out is None:
+        out = torch.empty(M, 3, device=units.device, dtype=torch.float32)
+    a = _lib.DecFusedArgs()
+    a.h1_planes, a.h1_kt, a.h1_amax = _p(h1_planes.buf), h1_planes.kt, _p(h1_planes.amax)
+    a.units = _p(units)
+    keep = []
+    for l in range(3):
+        for v in range(3):
+            t = vecs[l][v].contiguous()
+            keep.append(t)
+            a.vec[l][v] = t.data_ptr()
+    w5c, b5c = w5.contiguous(), b5.contiguous()
+    a.w5, a.b5 = _p(w5c), _p(b5c)
+    a.map, a.rows_per_obj = _p(order), int(rows_per_obj)
+    a.out, a.flag, a.M = _p(out), _p(flag), M
+    timed = GEMM_TIMER is not None
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(units.device))
+    check(_lib.lib().tgp_dec_fused(ctypes.byref(a), _stream(units)), "tgp_dec_fused")
+    if timed:
+        e1.record(torch.cuda.current_stream(units.device))
+        fl = 2.0 * M * (512 * 512 + 256 * 512 + 128 * 256 + 3 * 128)
+        GEMM_TIMER.append((e0, e1, fl, (M, 512 + 256 + 128 + 3, 512, 1), fl))
+    return out
+
+
 def conv_max_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias, scale, shift, slope, B, rows_per_obj, k_alg=None, keys=None, overflow=None,
                    fine_planes=None):
     """conv -> BN -> LeakyReLU -> max over points of a factored layer (tgp_conv_max_fused): keys (B, C) and the overflow flag."""
@@ -767,18 +810,20 @@ def head_post(green, red, ts, mean):
     return pg, pr, fg, fr, pT, ps
 
 
-def rows_out(x, w, bias=None, order=None):
+def rows_out(x, w, bias=None, order=None, out=None, pred=None):
     """x (B,n,K), w (n_out <= 4, K), order (B,n) int64 or None -> out (B,n,n_out) with out[b, order[b,i]] = x[b,i] @ w^T + bias
-    (tgp_rows_out: a narrow last layer and the scatter that undoes a row sort, one launch)"""
+    (tgp_rows_out: a narrow last layer and the scatter that undoes a row sort, one launch).  pred: device int -- the launch returns at
+    once while it is 0 (the last step of a repair chain, writing into `out`)"""
     x, ld = _rows(x, "x")
     B, n, K = x.shape
     if not w.is_contiguous() or w.shape[1] != K:
         raise ValueError("rows_out: w (n_out, K) contiguous expected")
     if order is not None and (order.dtype != torch.int64 or not order.is_contiguous() or tuple(order.shape) != (B, n)):
         raise ValueError("rows_out: order (B,n) int64 contiguous expected")
-    out = torch.empty(B, n, w.shape[0], device=x.device, dtype=torch.float32)
-    check(_lib.lib().tgp_rows_out(_p(x), ld, B * n, K, _p(w), w.stride(0), _p(bias), w.shape[0], _p(order), n, _p(out), _stream(x)),
-          "tgp_rows_out")
+    if out is None:
+        out = torch.empty(B, n, w.shape[0], device=x.device, dtype=torch.float32)
+    check(_lib.lib().tgp_rows_out_pred(_p(x), ld, B * n, K, _p(w), w.stride(0), _p(bias), w.shape[0], _p(order), n, _p(out), _p(pred),
+                                       _stream(x)), "tgp_rows_out")
     return out
 
 
