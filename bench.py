@@ -190,17 +190,49 @@ def _latest_profile(pattern, skip=("input_side",)):
 
 # Algorithmic bytes per launch (B = 32, N = 1028) of the kernels that serve ONE shape per forward: unique inputs read once + outputs
 # written once (SURVEY.md 8d's rule), fp32 unless noted.  Kernels that serve several shapes (the tile GEMMs) carry no single figure.
+# Keys are PREFIXES of the profiler's kernel names (template arguments that do not change the shape are left out).
 ALGO_BYTES_B32 = {
     # fine (32896 x 272) + the heads' columns of both coarse products (8224 + 2048 rows x 3072) + fp16 weight planes
     # (3 x 1024 x 272 + 3 x 256 x 1024, two planes) + keys: 35.8 + 101.1 + 25.2 + 6.5 MB
-    "heads_fused_kernel": 35.8e6 + 101.1e6 + 25.2e6 + 6.5e6,
+    "void heads_fused_kernel": 35.8e6 + 101.1e6 + 25.2e6 + 6.5e6,
     # fine + conv_5's 1024 columns of the coarse products + weights: 35.8 + 33.7 + 8.4 + 1.1 MB
-    "conv_max_fused_kernel": 35.8e6 + 33.7e6 + 8.4e6 + 1.1e6,
+    "void conv_max_fused_kernel": 35.8e6 + 33.7e6 + 8.4e6 + 1.1e6,
+    # the first decoder conv's activation as planes (32896 x 512 x 4 B), the three inner weights, the rows out + their map
+    "dec_fused_kernel": 67.4e6 + 1.7e6 + 0.4e6 + 0.3e6,
     "void gconv_kernel<128, false>": 4.83e6 * 32,       # conv_1's graph convolution, SURVEY 8d: 4.83 MB per object
     "void gconv_kernel<128, true>": 0.62e6 * 32,        # conv_0
+    # conv_2 / conv_3 (n = 257, C = 256): centre + 7 support blocks of the projection (8224 x 2048 x 4 B), directions, lists, output
+    "void gconv_lds_kernel<8>": 67.4e6 + 2.6e6 + 0.7e6 + 8.4e6,
+    "void gconv_lds_kernel<16>": 33.6e6 + 0.3e6 + 4.2e6,                      # conv_4 (n = 64, C = 512)
+    # five launches per forward (n = 1028 C = 128 twice, n = 257 C = 256 twice, n = 64 C = 512): table in, lists in, table out as planes;
+    # their mean: (2 x 36.3 + 2 x 17.5 + 8.5) / 5 MB
+    "orl_lds_kernel": 23.2e6,
+    "void knn_feat_fused16_kernel<128, 17": 0.61e6 * 32,                      # conv_1's feature-space graph, SURVEY 8d: 0.61 MB per object
+    "void knn_feat_fused16_kernel<256, 5": 0.28e6 * 32,                       # conv_3 (n = 257, d = 256)
+    "void knn_feat_fused16_kernel<128, 5": 0.15e6 * 32,                       # conv_2 (n = 257, d = 128)
+    "void knn_feat_fused16_kernel<256, 1": 0.07e6 * 32,                       # conv_4 (n = 64, d = 256)
     "void knn_feat_fused_kernel<128, 17, 8>": 0.61e6 * 32,
     "void knn_xyz_kernel<17>": 0.10e6 * 32,
 }
+
+
+def _algo_bytes(kernel_name):
+    best = None
+    for k, v in ALGO_BYTES_B32.items():
+        if kernel_name.startswith(k) and (best is None or len(k) > len(best[0])):
+            best = (k, v)
+    return best[1] if best else None
+
+
+# Compute floors of the graph / HBM class (B = 32, N = 1028), for the compute-aware bound beside the HBM one:
+#   * feature-space kNN: the distance products must be exact fp32 in ascending k (bit-exact lists): v_mfma_f32_16x16x4_f32 at the
+#     fp32 matrix peak 157.3 TFLOP/s; SURVEY 8d: 273.7 + 17.1 + 34.0 + 2.1 MFLOP per object;
+#   * graph convolutions: relu(dir . support_dir) * support, max, mean on the vector pipes at the fp32 vector peak 157.3 TFLOP/s;
+#     147.4 + 165.8 + 82.9 + 82.9 + 16.5 MFLOP per object (the formula's FLOPs: the instruction count is higher);
+#   * everything else of the class (ORL pooling, pooling, up-sampling, gathers, sorts): HBM.
+GRAPH_KNN_FLOP, GRAPH_KNN_BYTES = (273.7 + 17.1 + 34.0 + 2.1) * 1e6, (0.61 + 0.15 + 0.28 + 0.07) * 1e6
+GRAPH_GCONV_FLOP, GRAPH_GCONV_BYTES = (147.4 + 165.8 + 82.9 + 82.9 + 16.5) * 1e6, (0.62 + 4.83 + 2.39 + 2.39 + 1.18) * 1e6
+PEAK_F32_VECTOR = 157.3e12
 
 
 def _kernel_traffic(gemm_algo=None):
@@ -224,7 +256,7 @@ def _kernel_traffic(gemm_algo=None):
         for k, v in pmc.items():
             if "at::native" in k or "rocclr" in k or v["bytes_per_launch_corrected"] < 2e6:
                 continue
-            algo = ALGO_BYTES_B32.get(k)
+            algo = _algo_bytes(k)
             rows.append({"kernel": k, "launches": v["launches"], "bytes_per_launch": v["bytes_per_launch_corrected"],
                          "algorithmic_bytes_per_launch": int(algo) if algo else None,
                          "ratio": round(v["bytes_per_launch_corrected"] / algo, 2) if algo else None})
@@ -615,6 +647,23 @@ def main():
                          "launches_timed": launches, "avg_launch_us": round(1e6 * ksec / max(launches, 1), 2),
                          "share_of_step": round(ksec / roof_elapsed, 4), "measured": roof_note},
         }
+        #  the same launches priced one by one at THEIR roof: a launch is bound by
+        # max(executed FLOPs / MFMA roof of the GEMM mode, algorithmic bytes / HBM peak) -- the layers' last GEMMs (N = K = 128) and the
+        # K = 128 projections are HBM-bound launches that the class-wide "mfma" fraction above prices on the wrong roof
+        priced = [t for t in timer if len(t) > 5 and t[5]]
+        if priced and ksec > 0:
+            roof = peak * 1e12
+            b_mfma = [t[2] / roof for t in priced]
+            b_hbm = [t[5] / HBM_PEAK for t in priced]
+            bound = sum(max(a, b) for a, b in zip(b_mfma, b_hbm))
+            psec = sum(t[0].elapsed_time(t[1]) for t in priced) * 1e-3
+            n_hbm = sum(1 for a, b in zip(b_mfma, b_hbm) if b > a)
+            line["roofline"]["per_launch"] = {
+                "frac": round(bound / psec, 4), "launches_priced": len(priced), "of_them_hbm_bound": n_hbm,
+                "bound_us_per_forward": round(1e6 * bound / max(k_roof, 1), 1), "measured_us_per_forward": round(1e6 * psec / max(k_roof, 1), 1),
+                "hbm_bound_launches_us_per_forward": round(1e6 * sum(t[0].elapsed_time(t[1]) * 1e-3 for t, a, b in zip(priced, b_mfma, b_hbm) if b > a) / max(k_roof, 1), 1),
+                "basis": "per launch max(executed FLOPs / %.0f TFLOP/s, algorithmic bytes / 8 TB/s), summed, over the summed launch times "
+                         "(tile GEMMs: A + W + result(s) + residuals once; fused kernels: their operands once)" % peak}
         if kflop_ref != kflop and ksec > 0:
             # the layers over the concat buffer run factored over the nearest-neighbour upsampling (DESIGN.md "Factored wide
             # layers"): `achieved` counts the FLOPs the kernels execute; for comparison, the same time priced in the FLOPs of
@@ -632,6 +681,16 @@ def main():
                 "algorithmic_bytes_per_object": GRAPH_CLASS_BYTES, "ms_per_forward": round(1e3 * gsec, 4), "launches_per_forward": len(graph_cls) // k_roof,
                 "kernels": "kNN (xyz + feature space incl. the distance GEMM), graph convolution, ORL pooling, pooling, gathers, "
                            "row sort, tails, per-object post-processing; serial launches as for `roofline`"}
+            # compute-aware bound of the class (item 7): the exact-fp32 distance products of the feature-space kNN on the fp32 matrix
+            # peak, the graph convolutions' formula on the fp32 vector peak, the rest at HBM speed
+            rest_bytes = GRAPH_CLASS_BYTES - GRAPH_KNN_BYTES - GRAPH_GCONV_BYTES
+            cb = B * (max(GRAPH_KNN_FLOP / (PEAK_F32_MFMA_TFLOPS * 1e12), GRAPH_KNN_BYTES / HBM_PEAK)
+                      + max(GRAPH_GCONV_FLOP / PEAK_F32_VECTOR, GRAPH_GCONV_BYTES / HBM_PEAK) + rest_bytes / HBM_PEAK)
+            line["roofline_graph_class"]["compute_aware"] = {
+                "bound_ms_per_forward": round(1e3 * cb, 4), "frac": round(cb / gsec, 4),
+                "basis": "feature-space kNN: %.0f MFLOP per object of exact fp32 MFMA at 157.3 TFLOP/s; graph convolutions: %.0f MFLOP per object "
+                         "at the fp32 vector peak 157.3 TFLOP/s; the other %.1f MB per object at 8 TB/s"
+                         % (GRAPH_KNN_FLOP / 1e6, GRAPH_GCONV_FLOP / 1e6, rest_bytes / 1e6)}
             flop_fwd = kflop / k_roof
             mfma_roof = {"split16": FP16_MFMA_PEAK / 3.0, "split": FP16_MFMA_PEAK / 6.0, "fp32": PEAK_F32_MFMA_TFLOPS * 1e12}[args.gemm]
             bound_s = flop_fwd / mfma_roof + GRAPH_CLASS_BYTES * B / HBM_PEAK

@@ -476,12 +476,16 @@ __global__ __launch_bounds__(1024) void orl_lds_kernel(const float *__restrict__
                                                        char *__restrict__ planes, int kts, uint32_t *__restrict__ amax,
                                                        const float *__restrict__ xyz_tile, const float *__restrict__ w2t,
                                                        float *__restrict__ g_out, float *__restrict__ rb, float *contrib,
-                                                       int *tickets)
+                                                       int *tickets, int lds_idx)
 {
     extern __shared__ __attribute__((aligned(16))) float ol_smem[];
     float *s_tab = ol_smem;                          // [n][ORL_CH]
     float *s_red = ol_smem + (size_t)n * ORL_CH;     // [ptiles][4][ORL_CH]
-    uint32_t *s_amax = reinterpret_cast<uint32_t *>(s_red + (size_t)ptiles * 4 * ORL_CH);   // [n / 32 + 2] (planes only)
+    uint32_t *s_amax = reinterpret_cast<uint32_t *>(s_red + (size_t)ptiles * 4 * ORL_CH);   // [n / 32 + 4] (planes only)
+    // (round 5) the object's neighbour lists as 16-bit ids, [n][k], behind the magnitudes (lds_idx: the launch made room for them):
+    // the walk below was a chain  global index load (an L2 round trip) -> LDS row read  per neighbour, 320 of them per thread
+    // (84 % of the wave cycles parked in the SQ counters); with the lists in LDS both links are LDS reads
+    uint16_t *s_idx = lds_idx ? reinterpret_cast<uint16_t *>(s_amax + (planes ? n / 32 + 4 : 0)) : nullptr;
     int b, chunk;
     if (!tgp_xcd_object_tile(blockIdx.x, B, C / ORL_CH, b, chunk)) return;
     const int c0 = chunk * ORL_CH;
@@ -494,6 +498,14 @@ __global__ __launch_bounds__(1024) void orl_lds_kernel(const float *__restrict__
     const int rb0 = (int)(((int64_t)b * n) >> 5), nrb = (int)((((int64_t)b * n + n - 1) >> 5) - rb0 + 1);
     if (planes)
         for (int e = tid; e < nrb; e += nthr) s_amax[e] = 0u;
+    if (s_idx) {
+        const int32_t *src = idx + (int64_t)b * n * k;
+        const int total = n * k;                                  // (n * k % 4 == 0 and the lists 16-byte aligned: checked by the launch)
+        for (int e = tid * 4; e < total; e += nthr * 4) {
+            const int4 v = *reinterpret_cast<const int4 *>(src + e);
+            *reinterpret_cast<uint2 *>(s_idx + e) = make_uint2((uint32_t)v.x | ((uint32_t)v.y << 16), (uint32_t)v.z | ((uint32_t)v.w << 16));
+        }
+    }
     __syncthreads();
     if (planes) {
         // piece (row, h) = 8 channels of one row: lanes 0-31 of a wave take 32 consecutive rows' h = 0, lanes 32-63 their h = 1
@@ -540,10 +552,19 @@ __global__ __launch_bounds__(1024) void orl_lds_kernel(const float *__restrict__
             if (i >= n) break;
             const int32_t *nb = idx + ((int64_t)b * n + i) * k;
             float2 m = make_float2(-INFINITY, -INFINITY);
+            if (s_idx) {
+                const uint16_t *nl = s_idx + i * k;
 #pragma unroll 4
-            for (int j = 0; j < k; ++j) {
-                const float2 v = *reinterpret_cast<const float2 *>(s_tab + nb[j] * ORL_CH + pair * 2);
-                m.x = fmaxf(m.x, v.x), m.y = fmaxf(m.y, v.y);
+                for (int j = 0; j < k; ++j) {
+                    const float2 v = *reinterpret_cast<const float2 *>(s_tab + (int)nl[j] * ORL_CH + pair * 2);
+                    m.x = fmaxf(m.x, v.x), m.y = fmaxf(m.y, v.y);
+                }
+            } else {
+#pragma unroll 4
+                for (int j = 0; j < k; ++j) {
+                    const float2 v = *reinterpret_cast<const float2 *>(s_tab + nb[j] * ORL_CH + pair * 2);
+                    m.x = fmaxf(m.x, v.x), m.y = fmaxf(m.y, v.y);
+                }
             }
             sum.x += m.x, sum.y += m.y;
         }
@@ -621,11 +642,12 @@ __global__ __launch_bounds__(1024) void orl_lds_kernel(const float *__restrict__
     if (tid == 0) tickets[b] = 0;
 }
 
-#ifdef TGP_DEV   // development builds only: 0 = always the gather-from-L2 kernel
-int tgp_orl_lds_mode = 1;
+#ifdef TGP_DEV   // development builds only: 0 = always the gather-from-L2 kernel; neighbour lists staged in LDS or read from memory
+int tgp_orl_lds_mode = 1, tgp_orl_idx_mode = 1;
 extern "C" void tgp_debug_set_orl_lds(int v) { tgp_orl_lds_mode = v; }
+extern "C" void tgp_debug_set_orl_idx(int v) { tgp_orl_idx_mode = v; }
 #else
-static constexpr int tgp_orl_lds_mode = 1;
+static constexpr int tgp_orl_lds_mode = 1, tgp_orl_idx_mode = 1;
 #endif
 
 // returns true when the LDS form was launched
@@ -635,17 +657,22 @@ static bool orl_lds_launch(const float *feat, int ldf, const int32_t *idx, int B
                            float *contrib = nullptr, int *tickets = nullptr)
 {
     rc = 0;
-    const size_t lds = ((size_t)n * ORL_CH + (size_t)ptiles * 4 * ORL_CH + (planes ? n / 32 + 4 : 0)) * sizeof(float);
+    size_t lds = ((size_t)n * ORL_CH + (size_t)ptiles * 4 * ORL_CH + (planes ? n / 32 + 4 : 0)) * sizeof(float);
     if (!tgp_orl_lds_mode || lds > 72 * 1024 || C % ORL_CH) return false;
+    // the neighbour lists as 16-bit ids beside the table (n = 1028, k = 20: 41 KB) when they fit and can be read 16 bytes at a time
+    const size_t idx_bytes = (size_t)n * k * 2;
+    const int lds_idx = n <= 65535 && ((n * k) & 3) == 0 && (reinterpret_cast<uintptr_t>(idx) & 15) == 0 && lds + idx_bytes <= 150 * 1024 &&
+                        tgp_orl_idx_mode;
+    if (lds_idx) lds += idx_bytes;
     static TgpLdsAttr attr;
     if (lds > 64 * 1024) {
-        rc = tgp_lds_attr(attr, reinterpret_cast<const void *>(orl_lds_kernel), 72 * 1024);
+        rc = tgp_lds_attr(attr, reinterpret_cast<const void *>(orl_lds_kernel), 150 * 1024);
         if (rc) return true;
     }
     const int slots = ptiles * 4 * (ORL_CH / 2);
     const int threads = slots >= 768 ? 1024 : (slots >= 384 ? 512 : 256);
     hipLaunchKernelGGL(orl_lds_kernel, dim3(tgp_xcd_grid(B, C / ORL_CH)), dim3(threads), lds, stream, feat, ldf, idx, B, n, k, C, partial,
-                       ptiles, planes, kts, amax, xyz_tile, w2t, g_out, rb, contrib, tickets);
+                       ptiles, planes, kts, amax, xyz_tile, w2t, g_out, rb, contrib, tickets, lds_idx);
     rc = TGP_LAUNCH_RESULT();
     return true;
 }

@@ -685,8 +685,11 @@ def heads_fused(fine, K, wa_planes, p1, idx1, p2, idx2, w2p, bias2, scale2, shif
         e1.record(torch.cuda.current_stream(fine.device))
         Mk = rows if rows else M                                     # rows this launch processed
         conv2 = 2.0 * Mk * 256 * 1024 * heads
+        # algorithmic bytes (SURVEY 8d's rule, every operand once): the points' features, the heads' columns of both coarse products,
+        # the weights (conv1 planes + the packed conv2 image), the keys
+        nb = 4.0 * (Mk * 272 + (p1.shape[0] + p2.shape[0]) * heads * 1024 + heads * 1024 * 272 + heads * 256 * 1024 + heads * B * 256)
         GEMM_TIMER.append((e0, e1, 2.0 * Mk * heads * 1024 * K + conv2, (Mk, heads * 1024, K, 1),
-                           2.0 * Mk * heads * 1024 * (k_alg or K) + conv2))
+                           2.0 * Mk * heads * 1024 * (k_alg or K) + conv2, nb, "fused"))
     return keys, overflow
 
 
@@ -729,7 +732,8 @@ def dec_fused(h1_planes, units, vecs, w5, b5, order, rows_per_obj, flag, out=Non
     if timed:
         e1.record(torch.cuda.current_stream(units.device))
         fl = 2.0 * M * (512 * 512 + 256 * 512 + 128 * 256 + 3 * 128)
-        GEMM_TIMER.append((e0, e1, fl, (M, 512 + 256 + 128 + 3, 512, 1), fl))
+        nb = 4.0 * (M * 512 + 512 * 512 + 256 * 512 + 128 * 256 + M * 3) + 8.0 * M
+        GEMM_TIMER.append((e0, e1, fl, (M, 512 + 256 + 128 + 3, 512, 1), fl, nb, "fused"))
     return out
 
 
@@ -761,7 +765,8 @@ def conv_max_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias, scale, shift, slope,
     check(_lib.lib().tgp_conv_max_fused(ctypes.byref(a), _stream(fine)), "tgp_conv_max_fused")
     if timed:
         e1.record(torch.cuda.current_stream(fine.device))
-        GEMM_TIMER.append((e0, e1, 2.0 * M * C * K, (M, C, K, 1), 2.0 * M * C * (k_alg or K)))
+        nb = 4.0 * (M * 272 + (p1.shape[0] + p2.shape[0]) * C + C * 272 + B * C)
+        GEMM_TIMER.append((e0, e1, 2.0 * M * C * K, (M, C, K, 1), 2.0 * M * C * (k_alg or K), nb, "fused"))
     return keys, overflow
 
 
