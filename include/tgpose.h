@@ -722,7 +722,30 @@ typedef struct tgp_dec_fused_args {
 } tgp_dec_fused_args;
 int tgp_dec_fused(const tgp_dec_fused_args *args, tgp_stream_t stream);
 int64_t tgp_dec_pack_bytes(void);
-int tgp_dec_pack(const float *w2, const float *w3, const float *w4, void *out, tgp_stream_t stream);
+/* h1_permuted: the operand's planes hold the channels in accumulator order (tgp_dec_l1's output) instead of the natural one
+ * (tgp_gemm_args.C_planes): W2's K order is then permuted like W3's / W4's. */
+int tgp_dec_pack(const float *w2, const float *w3, const float *w4, int h1_permuted, void *out, tgp_stream_t stream);
+/* (ABI 7) The decoder's FIRST conv (FaceRecon.py:112, factored form: W_fine . fine[m] + p1[idx1[m]] + p2[idx2[m]] + rowbias[object],
+ * BatchNorm(eval) + ReLU; 512 channels) in the fused heads kernel's style, writing the activation as the operand tgp_dec_fused loads:
+ *   fine_planes (M rows, fine_kt >= 17 K-tiles) / fine_amax: the points' features as blocked planes; wa_planes: the conv's weights over
+ *   fine (512, 272) as blocked planes with 17 K-tiles; p1 / p2 / idx1 / idx2 as tgp_heads_fused (pointers at the conv's first channel);
+ *   bias / scale / shift (512); rowbias (may be NULL): (objects, >= 512) per-object bias, row stride ldrb, objects of rows_per_obj rows;
+ *   h1_planes (M rows x 512, h1_kt >= 32 K-tiles) receives fp16 hi / lo planes whose K order is the ACCUMULATOR order (slot 8 h + t of
+ *   K-tile 2 b + s = channel 32 b + 16 s + 8 (t >> 2) + 4 h + (t & 3)): consumed by tgp_dec_fused with tgp_dec_pack(h1_permuted = 1), not by
+ *   tgp_gemm_f32; h1_amax: per-32-row-block magnitude words (zeroed by the caller; may be NULL); flag as tgp_dec_fused's.  Values equal
+ *   the tile kernel's for the same layer bit for bit. */
+typedef struct tgp_dec_l1_args {
+    const void *fine_planes; int fine_kt; const uint32_t *fine_amax;
+    const void *wa_planes;
+    const float *p1; int ldp1; const int32_t *idx1;
+    const float *p2; int ldp2; const int32_t *idx2;
+    const float *bias; const float *scale; const float *shift;
+    const float *rowbias; int ldrb; int rows_per_obj;
+    void *h1_planes; int h1_kt; uint32_t *h1_amax;
+    int *flag;
+    int M;
+} tgp_dec_l1_args;
+int tgp_dec_l1(const tgp_dec_l1_args *args, tgp_stream_t stream);
 
 /* ---- the factored wide layers in TRAINING (ABI 4; this repo's engine, no reference counterpart: the reference multiplies the
  * up-sampled copies, FaceRecon.py:70-77) -----------------------------------------------------------------------------------------

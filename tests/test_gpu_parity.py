@@ -3872,11 +3872,12 @@ def test_heads_fused_keys_do_not_depend_on_the_batch_around_an_object(ops):
 
 
 @pytest.mark.parametrize("scale", [1.0, 1e6, 1e-5])
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [0, 1, 2])
 def test_decoder_chain_on_planes_only(ops, scale, fused):
     """engine.DEC_PLANES_ONLY: the decoder's inner activations never exist in fp32 -- as fp16 planes only between tile launches (each
     layer's epilogue writes the next one's operand; fused = False), or not at all outside the registers (engine.DEC_FUSED, round 5: the
-    layers behind the first conv as ONE launch, csrc/dec_fused.hip).
+    layers behind the first conv as ONE launch, csrc/dec_fused.hip; fused = 2 = the default: also the first conv on the fused heads
+    kernel's conv1 half, engine.DEC_L1, handing its result over as fragments in accumulator order).
     scale 1: the reconstruction of the forward without planes -- bit for bit on the tile launches; within 2e-6 of the output's scale
     for the fused kernel (its 512 -> 512 layer adds the same products in the same order, the two after it sum the sixteen products of a
     K-step in another order and the last conv sums per half wave first: agreement to rounding).
@@ -3900,15 +3901,15 @@ def test_decoder_chain_on_planes_only(ops, scale, fused):
     assert pk.dec_units is not None
     got = []
     for planes, only in ((True, True), (False, False)):
-        old = ops.PLANES, engine.DEC_PLANES_ONLY, engine.DEC_FUSED
-        ops.PLANES, engine.DEC_PLANES_ONLY, engine.DEC_FUSED = planes, only, fused
+        old = ops.PLANES, engine.DEC_PLANES_ONLY, engine.DEC_FUSED, engine.DEC_L1
+        ops.PLANES, engine.DEC_PLANES_ONLY, engine.DEC_FUSED, engine.DEC_L1 = planes, only, fused > 0, fused > 1
         try:
             probe = {}
             with torch.no_grad():
                 engine.posenet_forward(pk, g(pts), g(obj), False, sample_idx=smp, probe=probe)
             got.append(probe["recon"].clone())
         finally:
-            ops.PLANES, engine.DEC_PLANES_ONLY, engine.DEC_FUSED = old
+            ops.PLANES, engine.DEC_PLANES_ONLY, engine.DEC_FUSED, engine.DEC_L1 = old
     assert torch.isfinite(got[0]).all()
     if fused and scale == 1.0:
         mean = g(pts).mean(1, keepdim=True)

@@ -98,6 +98,21 @@ class DecFusedArgs(ctypes.Structure):
     ]
 
 
+class DecL1Args(ctypes.Structure):
+    """struct tgp_dec_l1_args (include/tgpose.h)"""
+    _fields_ = [
+        ("fine_planes", c_vp), ("fine_kt", c_int), ("fine_amax", c_vp),
+        ("wa_planes", c_vp),
+        ("p1", c_vp), ("ldp1", c_int), ("idx1", c_vp),
+        ("p2", c_vp), ("ldp2", c_int), ("idx2", c_vp),
+        ("bias", c_vp), ("scale", c_vp), ("shift", c_vp),
+        ("rowbias", c_vp), ("ldrb", c_int), ("rows_per_obj", c_int),
+        ("h1_planes", c_vp), ("h1_kt", c_int), ("h1_amax", c_vp),
+        ("flag", c_vp),
+        ("M", c_int),
+    ]
+
+
 SIGNATURES = {
     "tgp_version": (c_int, []),
     "tgp_graph_node_counts": (c_int, [c_vp, c_vp]),
@@ -197,7 +212,8 @@ SIGNATURES = {
     "tgp_heads_w2_bytes": (c_i64, [c_int]),
     "tgp_dec_fused": (c_int, [ctypes.POINTER(DecFusedArgs), c_vp]),
     "tgp_dec_pack_bytes": (c_i64, []),
-    "tgp_dec_pack": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "tgp_dec_pack": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "tgp_dec_l1": (c_int, [ctypes.POINTER(DecL1Args), c_vp]),
     "tgp_sort_by_parent": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tgp_roi_cloud": (c_int, [c_vp] * 7 + [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "tgp_cloud_select": (c_int, [c_vp] * 5 + [c_int, c_int, c_int, c_vp, c_vp]),

@@ -304,6 +304,234 @@ __global__ __launch_bounds__(256, 1) void dec_fused_kernel(DecParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The decoder's FIRST conv (FaceRecon.py:112 conv1d_block[0..2] on the factored form of this repo's engine:
+// conv(feat)[m] = W_fine . fine[m] + P1[idx1[m]] + P2[idx2[m]] + per-object bias, then BatchNorm(eval) + ReLU) as the conv1 half of
+// heads_fused.hip's kernel: a wave owns 32 points, their fine features stay in registers as B fragments, the weights' 32-channel
+// blocks arrive by linear LDS-DMA, and block i's 51 MFMAs carry block i - 1's epilogue, this block's gathers and block i - 2's
+// stores in their gaps.  The activation leaves as the operand dec_fused_kernel loads: fp16 hi / lo fragments in the order the
+// accumulators hold the channels (slot 8 h + t of K-tile 2 b + s2 = channel 32 b + 16 s2 + 8 (t >> 2) + 4 h + (t & 3)): a lane stores the
+// 16 bytes it will later load, so the tile GEMM's LDS transposition (and its 4 x 2056 workgroups) is not needed; W2's K order is
+// permuted to match when it is packed.  Per 32-row block the largest activation goes to the magnitude words (the consumer's guard).
+#define DL_NCB (DF_C1 / 32)
+#define DL_STEPS 17                        // K steps over the fine buffer: 272 / 16
+#define DL_APIECES (2 * DL_STEPS)
+#define DL_ABUF (DL_APIECES * 1024)
+#define DL_NDMA 9                          // piece j = 4 j0 + wave < 34
+
+struct DecL1Params {
+    const char *fine_pl; int fine_kt; const uint32_t *fine_amax;
+    const char *wa_pl;                     // (512, 272) as blocked planes, 17 K-tiles per 32-channel block
+    const float *p1; int ldp1; const int32_t *idx1;
+    const float *p2; int ldp2; const int32_t *idx2;
+    const float *bias, *scale, *shift;     // 512
+    const float *rowbias; int ldrb, rows_per_obj;      // (may be NULL) per-object bias (B, 512)
+    char *h1_pl; int h1_kt; uint32_t *h1_amax;          // out: the activation as planes in accumulator order, its magnitude words
+    int *flag;
+    int M, tiles;
+};
+
+struct DlG {                               // a block's gathered terms of the lane's four channel groups
+    float4 g1[4], g2[4], rb[4];
+};
+
+__global__ __launch_bounds__(256, 1) void dec_l1_kernel(DecL1Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) char dl_smem[];       // 2 x DL_ABUF, then 3 x 512 floats
+    float *s_vec = reinterpret_cast<float *>(dl_smem + 2 * DL_ABUF);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x;
+    if (tile >= p.tiles) return;
+    const int m0 = tile * 128 + wave * 32;
+    const int row = min(m0 + r, p.M - 1);
+    const int nblk = (p.M + 31) >> 5;
+    const int rb = min(m0 >> 5, nblk - 1);
+
+    const uint32_t voff0 = lane * 16 + wave * 1024;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)dl_smem) + wave * 1024;
+    const char *u_src = p.wa_pl;
+    auto dma = [&](const int buf, const int j0) {
+        if (j0 * 4 + 3 >= DL_APIECES && wave >= (DL_APIECES & 3)) return;      // pieces 34, 35 do not exist
+        const uint32_t lds = lds0 + buf * DL_ABUF + j0 * 4096;
+        const uint32_t vo = voff0 + j0 * 4096;
+        asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(u_src), "{m0}"(lds) : "memory");
+    };
+#pragma unroll
+    for (int j0 = 0; j0 < DL_NDMA; ++j0) dma(0, j0);
+    for (int i = tid; i < 3 * DF_C1; i += 256) s_vec[i] = (i < DF_C1 ? p.bias : i < 2 * DF_C1 ? p.scale : p.shift)[i % DF_C1];
+    // the wave's points as B fragments (as heads_fused_kernel)
+    uint4 bh[DL_STEPS], bl[DL_STEPS];
+    {
+        const char *src = p.fine_pl + (int64_t)rb * p.fine_kt * 2048 + lane * 16;
+#pragma unroll
+        for (int s = 0; s < DL_STEPS; ++s) {
+            bh[s] = *reinterpret_cast<const uint4 *>(src + s * 2048);
+            bl[s] = *reinterpret_cast<const uint4 *>(src + s * 2048 + 1024);
+        }
+        if (m0 + 32 > p.M) {
+            const bool dead = m0 + r >= p.M;
+#pragma unroll
+            for (int s = 0; s < DL_STEPS; ++s)
+                if (dead) bh[s] = make_uint4(0u, 0u, 0u, 0u), bl[s] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        // the input side of the fp16 range guard, as in the tile kernels: a block that cannot be split faithfully raises the chain's flag
+        if (p.fine_amax && m0 < p.M) {
+            const uint32_t am = p.fine_amax[rb];
+            if ((am >= 0x477fe000u || (am != 0u && am < 0x3d800000u)) && lane == 0) atomicOr(p.flag, 1);
+        }
+    }
+    const int i1 = p.idx1[row], i2 = p.idx2[row];
+    const float *g1p = p.p1 + (int64_t)i1 * p.ldp1 + 4 * h;               // + cb * 32 + 8 m: four channels of the lane
+    const float *g2p = p.p2 + (int64_t)i2 * p.ldp2 + 4 * h;
+    const float *rbp = p.rowbias ? p.rowbias + (int64_t)(row / p.rows_per_obj) * p.ldrb + 4 * h : nullptr;
+    char *h1 = p.h1_pl + (int64_t)rb * p.h1_kt * 2048 + lane * 16;          // + ((2 cb + s2) * 2 + plane) * 1024
+
+    df32x16 acc[2];
+    DlG g[2];
+    uint32_t a2[2][16];                    // a block's activations as packed fp16: [0..7] hi (K-tile 2 b: 0..3, 2 b + 1: 4..7), [8..15] lo
+    float amax = 0.f;
+    auto gather1 = [&](DlG &d, const int cb, const int i) {              // i = 0 .. 11: one 16-byte load
+        const int m = i & 3, which = i >> 2;
+        if (which == 0) d.g1[m] = *reinterpret_cast<const float4 *>(g1p + cb * 32 + 8 * m);
+        else if (which == 1) d.g2[m] = *reinterpret_cast<const float4 *>(g2p + cb * 32 + 8 * m);
+        else d.rb[m] = rbp ? *reinterpret_cast<const float4 *>(rbp + cb * 32 + 8 * m) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store1 = [&](const uint32_t (&a)[16], const int cb, const int i) {   // i = 0 .. 3: (K-tile of the block, plane)
+        const int s2 = i >> 1, plane = i & 1;
+        if (m0 >= p.M) return;
+        *reinterpret_cast<uint4 *>(h1 + ((2 * cb + s2) * 2 + plane) * 1024) =
+            make_uint4(a[plane * 8 + s2 * 4], a[plane * 8 + s2 * 4 + 1], a[plane * 8 + s2 * 4 + 2], a[plane * 8 + s2 * 4 + 3]);
+    };
+    // epilogue of a block in 32 slices of a few vector instructions each; group m = four channels 4 h + 8 m .. + 3 takes slices 8 m .. 8 m + 7
+    // (its vectors are read from LDS four slices earlier); in the tile kernel's order: + bias, + P1 row, + P2 row, + per-object bias,
+    // BatchNorm fold, ReLU
+    float4 e_b, e_sc, e_sh, e_bn, e_scn, e_shn, e_v;
+    float e_l4[4];
+    auto epi_read = [&](const int cb, const int m) {
+        const float *pv = s_vec + 32 * cb + 4 * h + 8 * m;
+        e_bn = *reinterpret_cast<const float4 *>(pv), e_scn = *reinterpret_cast<const float4 *>(pv + DF_C1);
+        e_shn = *reinterpret_cast<const float4 *>(pv + 2 * DF_C1);
+    };
+    auto epi = [&](const df32x16 &ac, const DlG &d, uint32_t (&a)[16], const int cb, const int sl) {
+        const int m = sl >> 3, ph = sl & 7;
+        if (ph == 0) {
+            e_b = e_bn, e_sc = e_scn, e_sh = e_shn;
+            e_v = make_float4(ac[4 * m], ac[4 * m + 1], ac[4 * m + 2], ac[4 * m + 3]);
+        } else if (ph == 1) {
+            e_v.x += e_b.x, e_v.y += e_b.y, e_v.z += e_b.z, e_v.w += e_b.w;
+        } else if (ph == 2) {
+            e_v.x += d.g1[m].x, e_v.y += d.g1[m].y, e_v.z += d.g1[m].z, e_v.w += d.g1[m].w;
+        } else if (ph == 3) {
+            e_v.x += d.g2[m].x, e_v.y += d.g2[m].y, e_v.z += d.g2[m].z, e_v.w += d.g2[m].w;
+            if (m + 1 < 4) epi_read(cb, m + 1);
+        } else if (ph == 4) {
+            e_v.x += d.rb[m].x, e_v.y += d.rb[m].y, e_v.z += d.rb[m].z, e_v.w += d.rb[m].w;
+        } else if (ph == 5) {
+            e_v.x *= e_sc.x, e_v.y *= e_sc.y, e_v.z *= e_sc.z, e_v.w *= e_sc.w;
+            e_v.x += e_sh.x, e_v.y += e_sh.y;
+        } else if (ph == 6) {
+            e_v.z += e_sh.z, e_v.w += e_sh.w;
+            e_v.x = fmaxf(e_v.x, -0.f), e_v.y = fmaxf(e_v.y, -0.f), e_v.z = fmaxf(e_v.z, -0.f), e_v.w = fmaxf(e_v.w, -0.f);   // ReLU as max(v, -0)
+            amax = fmaxf(amax, fmaxf(fmaxf(e_v.x, e_v.y), fmaxf(e_v.z, e_v.w)));
+        } else {
+            const df32x4 x = {e_v.x, e_v.y, e_v.z, e_v.w};
+            const uint2 hh = __builtin_bit_cast(uint2, __builtin_convertvector(x, df16x4));
+            e_l4[0] = df_mix_lo(hh.x, e_v.x), e_l4[1] = df_mix_hi(hh.x, e_v.y), e_l4[2] = df_mix_lo(hh.y, e_v.z), e_l4[3] = df_mix_hi(hh.y, e_v.w);
+            const df32x4 rest = {e_l4[0], e_l4[1], e_l4[2], e_l4[3]};
+            const uint2 ll = __builtin_bit_cast(uint2, __builtin_convertvector(rest, df16x4));
+            a[2 * m] = hh.x, a[2 * m + 1] = hh.y, a[8 + 2 * m] = ll.x, a[8 + 2 * m + 1] = ll.y;
+        }
+    };
+
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    // iteration cb (0 .. 17): conv1 of block cb (cb < 16) into acc[cb & 1]; in its gaps the weights of block cb + 1, the epilogue of
+    // block cb - 1 (from acc[(cb - 1) & 1], g[(cb - 1) & 1] into a2[(cb - 1) & 1]), the gathers of block cb (into g[cb & 1]) and the
+    // stores of block cb - 2 (from a2[cb & 1]).  MM / E1 / ST: which of the three this instance contains (compile-time).
+#define DL_ITER(CB, P, MM, E1, ST)                                                                                           \
+    {                                                                                                                        \
+        const int cb = (CB);                                                                                                 \
+        const char *arow = dl_smem + (P) * DL_ABUF + lane * 16;                                                              \
+        u_src = p.wa_pl + (int64_t)(cb + 1 < DL_NCB ? cb + 1 : DL_NCB - 1) * DL_ABUF;                                        \
+        df32x16 &ax = acc[(P)];                                                                                              \
+        if (MM) { _Pragma("unroll") for (int e = 0; e < 16; ++e) ax[e] = 0.f; }                                              \
+        uint4 fh0 = *reinterpret_cast<const uint4 *>(arow), fl0 = *reinterpret_cast<const uint4 *>(arow + 1024);             \
+        uint4 fh1 = *reinterpret_cast<const uint4 *>(arow + 2048), fl1 = *reinterpret_cast<const uint4 *>(arow + 3072);      \
+        if (E1) epi_read(cb - 1, 0);                                                                                         \
+        DF_SB();                                                                                                             \
+        _Pragma("unroll") for (int s = 0; s < DL_STEPS; ++s) {                                                               \
+            uint4 fh2 = fh1, fl2 = fl1;                                                                                      \
+            if (MM) ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(df16x8, fl0), __builtin_bit_cast(df16x8, bh[s]), ax, 0, 0, 0); \
+            DF_SB();                                                                                                         \
+            if (s + 2 < DL_STEPS && (MM)) {                                                                                  \
+                fh2 = *reinterpret_cast<const uint4 *>(arow + (s + 2) * 2048);                                               \
+                fl2 = *reinterpret_cast<const uint4 *>(arow + (s + 2) * 2048 + 1024);                                        \
+            }                                                                                                                \
+            if ((MM) && s < DL_NDMA) dma((P) ^ 1, s);                                                                        \
+            if ((MM) && s >= DL_NDMA) {                                                                                      \
+                _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2)                                                             \
+                    if (2 * (s - DL_NDMA) + t2 < 12) gather1(g[(P)], cb, 2 * (s - DL_NDMA) + t2);                            \
+            }                                                                                                                \
+            DF_SB();                                                                                                         \
+            if (MM) ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(df16x8, fh0), __builtin_bit_cast(df16x8, bl[s]), ax, 0, 0, 0); \
+            DF_SB();                                                                                                         \
+            if ((E1) && 2 * s < 32) epi(acc[(P) ^ 1], g[(P) ^ 1], a2[(P) ^ 1], cb - 1, 2 * s);                               \
+            if ((ST) && s >= 2 && s < 6) store1(a2[(P)], cb - 2, s - 2);                                                     \
+            DF_SB();                                                                                                         \
+            if (MM) ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(df16x8, fh0), __builtin_bit_cast(df16x8, bh[s]), ax, 0, 0, 0); \
+            DF_SB();                                                                                                         \
+            if ((E1) && 2 * s + 1 < 32) epi(acc[(P) ^ 1], g[(P) ^ 1], a2[(P) ^ 1], cb - 1, 2 * s + 1);                       \
+            DF_SB();                                                                                                         \
+            fh0 = fh1, fl0 = fl1, fh1 = fh2, fl1 = fl2;                                                                      \
+        }                                                                                                                    \
+        /* the next block's weights have landed; this block's twelve gathers -- issued after the last DMA piece, so the twelve  \
+           youngest operations in flight -- may still be on their way (their first use, in the next iteration, waits for them) */ \
+        if (MM) __builtin_amdgcn_s_waitcnt(0x0f70 | 12); else __builtin_amdgcn_s_waitcnt(0x0f70);                             \
+        __syncthreads();                                                                                                     \
+    }
+    DL_ITER(0, 0, true, false, false)
+    DL_ITER(1, 1, true, true, false)
+#pragma unroll 1
+    for (int c2 = 2; c2 < DL_NCB; c2 += 2) {
+        DL_ITER(c2, 0, true, true, true)
+        DL_ITER(c2 + 1, 1, true, true, true)
+    }
+    DL_ITER(DL_NCB, 0, false, true, true)
+    DL_ITER(DL_NCB + 1, 1, false, false, true)
+#undef DL_ITER
+    // the block's largest activation for the consumer's range guard (bits of a non-negative float order as the floats do)
+    if (m0 < p.M && p.h1_amax) {
+        float m = amax;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0 && m > 0.f) atomicMax(p.h1_amax + rb, __float_as_uint(m));
+    }
+}
+
+extern "C" int tgp_dec_l1(const tgp_dec_l1_args *a, tgp_stream_t stream)
+{
+    TGP_REQUIRE(a && a->fine_planes && a->wa_planes && a->p1 && a->p2 && a->idx1 && a->idx2 && a->bias && a->scale && a->shift &&
+                a->h1_planes && a->flag && a->M > 0);
+    TGP_REQUIRE(a->fine_kt >= DL_STEPS && a->h1_kt >= DF_C1 / 16 && (a->ldp1 & 3) == 0 && (a->ldp2 & 3) == 0 && a->ldp1 >= DF_C1 && a->ldp2 >= DF_C1);
+    TGP_REQUIRE(!a->rowbias || (a->rows_per_obj > 0 && a->M % a->rows_per_obj == 0 && (a->ldrb & 3) == 0 && a->ldrb >= DF_C1));
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    TGP_REQUIRE(al16(a->fine_planes) && al16(a->wa_planes) && al16(a->p1) && al16(a->p2) && al16(a->h1_planes) && al16(a->rowbias));
+    DecL1Params p;
+    p.fine_pl = reinterpret_cast<const char *>(a->fine_planes), p.fine_kt = a->fine_kt, p.fine_amax = a->fine_amax;
+    p.wa_pl = reinterpret_cast<const char *>(a->wa_planes);
+    p.p1 = a->p1, p.ldp1 = a->ldp1, p.idx1 = a->idx1, p.p2 = a->p2, p.ldp2 = a->ldp2, p.idx2 = a->idx2;
+    p.bias = a->bias, p.scale = a->scale, p.shift = a->shift;
+    p.rowbias = a->rowbias, p.ldrb = a->ldrb, p.rows_per_obj = a->rows_per_obj > 0 ? a->rows_per_obj : a->M;
+    p.h1_pl = reinterpret_cast<char *>(a->h1_planes), p.h1_kt = a->h1_kt, p.h1_amax = a->h1_amax;
+    p.flag = a->flag, p.M = a->M, p.tiles = tgp_cdiv(a->M, 128);
+    const int lds = 2 * DL_ABUF + 3 * DF_C1 * 4;
+    static TgpLdsAttr attr;
+    if (const int e = tgp_lds_attr(attr, reinterpret_cast<const void *>(dec_l1_kernel), lds)) return e;
+    hipLaunchKernelGGL(dec_l1_kernel, dim3(p.tiles), dim3(256), lds, tgp_hs(stream), p);
+    return TGP_LAUNCH_RESULT();
+}
+
 // ---- weights -> staging units.  W (N, K) fp32 row-major; a unit is 64 pieces of 1 KB: piece (q * 2 + plane), q = s * (N / 32) + j over the
 // unit's K-steps s and the N / 32 output blocks j, holds [lane = 32 h + r][8 fp16] = W[32 j + r][k(step, 8 h + t)], t = 0 .. 7, as its
 // fp16 hi (plane 0) / lo (plane 1) part.  permuted = 0: k = 16 step + slot (layer 2: the operand planes' natural order); 1: slot
@@ -331,7 +559,7 @@ __global__ void dec_pack_kernel(const float *__restrict__ W, int ld, int N, int 
 
 extern "C" int64_t tgp_dec_pack_bytes(void) { return (int64_t)DF_UNITS * DF_UNIT; }
 
-extern "C" int tgp_dec_pack(const float *w2, const float *w3, const float *w4, void *out, tgp_stream_t stream)
+extern "C" int tgp_dec_pack(const float *w2, const float *w3, const float *w4, int h1_permuted, void *out, tgp_stream_t stream)
 {
     TGP_REQUIRE(w2 && w3 && w4 && out && (reinterpret_cast<uintptr_t>(out) & 15) == 0);
     uint16_t *o = reinterpret_cast<uint16_t *>(out);
@@ -340,7 +568,7 @@ extern "C" int tgp_dec_pack(const float *w2, const float *w3, const float *w4, v
     for (int half = 0; half < 2; ++half) {
         uint16_t *base = o + (int64_t)half * (DF_U2H + DF_U3H) * U;
         hipLaunchKernelGGL(dec_pack_kernel, dim3(256 * DF_C1 / 256), dim3(256), 0, tgp_hs(stream), w2 + (int64_t)half * 256 * DF_C1, DF_C1, 256,
-                           DF_C1, 0, base);
+                           DF_C1, h1_permuted ? 1 : 0, base);
         hipLaunchKernelGGL(dec_pack_kernel, dim3(DF_C3 * 256 / 256), dim3(256), 0, tgp_hs(stream), w3 + half * 256, DF_C1, DF_C3, 256, 1,
                            base + (int64_t)DF_U2H * U);
     }

@@ -201,6 +201,8 @@ class Packed(object):
             if (ops.planes_on() and [tuple(d[0].shape) for d in self.dec[1:]] == [(512, 512), (256, 512), (128, 256)]
                     and tuple(self.dec_out[0].shape) == (3, 128) and all(d[5] is not None and d[5].tgp_unscale is None for d in self.dec[1:])):
                 self.dec_units = ops.dec_pack(self.dec[1][0], self.dec[2][0], self.dec[3][0])
+                # ... and, with the first conv on its own heads-style kernel (ops.dec_l1), whose result arrives in accumulator order
+                self.dec_units_p = ops.dec_pack(self.dec[1][0], self.dec[2][0], self.dec[3][0], h1_permuted=True)
         finally:
             _FOLDS = None
 
@@ -284,6 +286,7 @@ def pack_factored(wide, dec0):
             and float(wide["W2"].abs().max()) < ops.FP16_SAFE):
         f["w2p"] = ops.heads_pack_w2(wide["W2"], wide["bias"][1024:], wide["scale"][1024:], wide["shift"][1024:])
         f["Wa_hp"] = ops.heads_planes_w(f["Wa"][1024:])
+    f["dec_a_hp"] = ops.heads_planes_w(f["dec_a"]) if ops.planes_on() and f["dec_a"].shape[0] == 512 else None
     return f
 
 
@@ -313,6 +316,7 @@ COARSE_SIDE = os.environ.get("TGP_COARSE_SIDE", "0") != "0"
 EVAL_OUTPUTS_ONLY = os.environ.get("TGP_EVAL_OUTPUTS_ONLY", "0") != "0"
 HEADS_TAIL = os.environ.get("TGP_HEADS_TAIL", "0") != "0"
 DEC_PLANES_ONLY = os.environ.get("TGP_DEC_PLANES_ONLY", "1") != "0"     # the decoder's inner activations as fp16 planes only
+DEC_L1 = os.environ.get("TGP_DEC_L1", "1") != "0"           # the decoder's first conv on the fused heads kernel's conv1 half (ops.dec_l1)
 DEC_FUSED = os.environ.get("TGP_DEC_FUSED", "1") != "0"     # ... and everything behind its first conv as one launch (csrc/dec_fused.hip)
 REPAIR_OBJS = 16        # objects per chunk of the fused heads kernel's fp16-range repair (wide_gemm_factored)
 
@@ -814,16 +818,23 @@ def decoder_forward_factored(pk, fine, inter, P1, P2, back, N, arena=None, rb=No
         # outside fp16's range cannot be recomputed without the fp32 operand: it raises arena.dec_flag, and the fp32 chain follows
         # predicated on the flag (four launches that normally return at once, as after the fused heads kernel).
         flag = arena.dec_flag
-        ops.gemm(fine, f["dec_a"], None, flops_ref=2.0 * M * 512 * FEAT_C, a_planes=pl["fine"], w_planes=f["dec_a_p"], c_planes=pl["d1"], **gk)
-        xp = pl["d1"]
-        x = torch.empty(M, widths[-1], device=dev, dtype=torch.float32)
         fused = DEC_FUSED and ROWS_OUT and getattr(pk, "dec_units", None) is not None
+        l1 = fused and DEC_L1 and f.get("dec_a_hp") is not None and getattr(f["dec_a_s"], "tgp_unscale", None) is None
+        if l1:
+            # (round 5) the first conv on the conv1 half of the fused heads kernel: its result goes straight to the fused decoder
+            # kernel as fragments in accumulator order (no LDS transposition, 257 workgroups instead of 2056)
+            xp = ops.dec_l1(pl["fine"], f["dec_a_hp"], P1[:, 4096:], inter["near1"], P2[:, 4096:], inter["near2"], b0, sc0, sh0, rb, N, pl["d1"],
+                            flag, k_alg=FEAT_C)
+        else:
+            ops.gemm(fine, f["dec_a"], None, flops_ref=2.0 * M * 512 * FEAT_C, a_planes=pl["fine"], w_planes=f["dec_a_p"], c_planes=pl["d1"], **gk)
+            xp = pl["d1"]
+        x = torch.empty(M, widths[-1], device=dev, dtype=torch.float32)
         if fused:
             # (round 5) 512 -> 512 -> 256 -> 128 -> 3 and the un-sort of the rows as ONE launch: no activation between the layers leaves
             # the registers.  Same flag: a wave whose operand block or sums leave fp16's range raises it and the predicated fp32 chain
             # below -- now with a predicated last step -- rewrites the reconstruction.
-            recon = ops.dec_fused(xp, pk.dec_units, [d[1:4] for d in pk.dec[1:]], pk.dec_out[0], pk.dec_out[1], inter["order"].contiguous(),
-                                  N, flag).view(B, N, 3)
+            recon = ops.dec_fused(xp, pk.dec_units_p if l1 else pk.dec_units, [d[1:4] for d in pk.dec[1:]], pk.dec_out[0], pk.dec_out[1],
+                                  inter["order"].contiguous(), N, flag).view(B, N, 3)
         for i, ((w, b, sc, sh, ws, wp), nxt) in enumerate(() if fused else zip(pk.dec[1:], ("d2", "d3", None))):
             ops.gemm(None, w, x if nxt is None else None, M=M, N=w.shape[0], K=w.shape[1], lda=0, ldw=w.shape[1], ldc=w.shape[0], bias=b,
                      scale=sc, shift=sh, act=1, w_split=ws, a_planes=xp, w_planes=wp, c_planes=pl.get(nxt) if nxt else None, range_flag=flag)

@@ -693,13 +693,46 @@ def heads_fused(fine, K, wa_planes, p1, idx1, p2, idx2, w2p, bias2, scale2, shif
     return keys, overflow
 
 
-def dec_pack(w2, w3, w4):
-    """the decoder's 512 -> 512, 512 -> 256, 256 -> 128 weights -> the fused decoder kernel's staging image (tgp_dec_pack)"""
+def dec_pack(w2, w3, w4, h1_permuted=False):
+    """the decoder's 512 -> 512, 512 -> 256, 256 -> 128 weights -> the fused decoder kernel's staging image (tgp_dec_pack).
+    h1_permuted: the operand will come from dec_l1 (channels in accumulator order) instead of a tile GEMM's C_planes"""
     if tuple(w2.shape) != (512, 512) or tuple(w3.shape) != (256, 512) or tuple(w4.shape) != (128, 256):
         raise ValueError("dec_pack: weights of (512, 512), (256, 512), (128, 256) expected")
     out = torch.empty(_lib.lib().tgp_dec_pack_bytes(), device=w2.device, dtype=torch.uint8)
-    check(_lib.lib().tgp_dec_pack(_p(w2.contiguous()), _p(w3.contiguous()), _p(w4.contiguous()), _p(out), _stream(w2)), "tgp_dec_pack")
+    check(_lib.lib().tgp_dec_pack(_p(w2.contiguous()), _p(w3.contiguous()), _p(w4.contiguous()), int(bool(h1_permuted)), _p(out),
+                                  _stream(w2)), "tgp_dec_pack")
+    out.tgp_h1_permuted = bool(h1_permuted)
     return out
+
+
+def dec_l1(fine_planes, wa_planes, p1, idx1, p2, idx2, bias, scale, shift, rowbias, rows_per_obj, h1_planes, flag, k_alg=None):
+    """The decoder's first conv on the factored form (tgp_dec_l1): fine_planes (M rows) x wa_planes (512 x 272 as planes, 17 K-tiles:
+    heads_planes_w) + p1[idx1] + p2[idx2] + rowbias[object], BatchNorm fold, ReLU -> h1_planes (M, 512) in ACCUMULATOR channel order
+    (for dec_fused with dec_pack(h1_permuted=True) only).  p1 / p2: 2-D views whose column 0 is the conv's first channel."""
+    M = fine_planes.rows
+    if wa_planes.kt != 17 or wa_planes.rows != 512 or h1_planes.rows != M or h1_planes.K != 512:
+        raise ValueError("dec_l1: wa_planes (512 rows, 17 K-tiles) and h1_planes (M, 512) expected")
+    a = _lib.DecL1Args()
+    a.fine_planes, a.fine_kt, a.fine_amax = _p(fine_planes.buf), fine_planes.kt, _p(fine_planes.amax)
+    a.wa_planes = _p(wa_planes.buf)
+    a.p1, a.ldp1, a.idx1 = _p(p1), p1.stride(0), _p(idx1)
+    a.p2, a.ldp2, a.idx2 = _p(p2), p2.stride(0), _p(idx2)
+    a.bias, a.scale, a.shift = _p(bias), _p(scale), _p(shift)
+    if rowbias is not None:
+        a.rowbias, a.ldrb = _p(rowbias), rowbias.stride(0)
+    a.rows_per_obj = int(rows_per_obj)
+    a.h1_planes, a.h1_kt, a.h1_amax = _p(h1_planes.buf), h1_planes.kt, _p(h1_planes.amax)
+    a.flag, a.M = _p(flag), M
+    timed = GEMM_TIMER is not None
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(p1.device))
+    check(_lib.lib().tgp_dec_l1(ctypes.byref(a), _stream(p1)), "tgp_dec_l1")
+    if timed:
+        e1.record(torch.cuda.current_stream(p1.device))
+        nb = 4.0 * (M * 272 + (p1.shape[0] + p2.shape[0]) * 512 + 512 * 272 + M * 512)
+        GEMM_TIMER.append((e0, e1, 2.0 * M * 512 * 268, (M, 512, 268, 1), 2.0 * M * 512 * (k_alg or 268), nb, "fused"))
+    return h1_planes
 
 
 def dec_fused(h1_planes, units, vecs, w5, b5, order, rows_per_obj, flag, out=None):
