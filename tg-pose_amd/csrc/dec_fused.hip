@@ -329,6 +329,7 @@ struct DecL1Params {
     char *h1_pl; int h1_kt; uint32_t *h1_amax;          // out: the activation as planes in accumulator order, its magnitude words
     int *flag;
     int M, tiles;
+    int main_tiles;                        // tiles [0, main_tiles) are one workgroup each; the others one workgroup per 32-channel block
 };
 
 struct DlG {                               // a block's gathered terms of the lane's four channel groups
@@ -341,7 +342,14 @@ __global__ __launch_bounds__(256, 1) void dec_l1_kernel(DecL1Params p)
     float *s_vec = reinterpret_cast<float *>(dl_smem + 2 * DL_ABUF);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int tile = blockIdx.x;
+    // The benchmark's 32896 points are 257 tiles of 128 on 256 CUs: the 257th would run alone for a whole second round.  Tiles past the
+    // last full round are cut into their 16 channel blocks instead -- each block's result is independent of the others, so the same
+    // bits -- many short workgroups that drain in a fraction of a round (conv_max_fused_kernel's rule).
+    int tile = blockIdx.x, single = -1;
+    if (tile >= p.main_tiles) {
+        const int rest = tile - p.main_tiles;
+        tile = p.main_tiles + rest / DL_NCB, single = rest % DL_NCB;
+    }
     if (tile >= p.tiles) return;
     const int m0 = tile * 128 + wave * 32;
     const int row = min(m0 + r, p.M - 1);
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(256, 1) void dec_l1_kernel(DecL1Params p)
 
     const uint32_t voff0 = lane * 16 + wave * 1024;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)dl_smem) + wave * 1024;
-    const char *u_src = p.wa_pl;
+    const char *u_src = p.wa_pl + (int64_t)(single < 0 ? 0 : single) * DL_ABUF;
     auto dma = [&](const int buf, const int j0) {
         if (j0 * 4 + 3 >= DL_APIECES && wave >= (DL_APIECES & 3)) return;      // pieces 34, 35 do not exist
         const uint32_t lds = lds0 + buf * DL_ABUF + j0 * 4096;
@@ -449,7 +457,7 @@ __global__ __launch_bounds__(256, 1) void dec_l1_kernel(DecL1Params p)
     // iteration cb (0 .. 17): conv1 of block cb (cb < 16) into acc[cb & 1]; in its gaps the weights of block cb + 1, the epilogue of
     // block cb - 1 (from acc[(cb - 1) & 1], g[(cb - 1) & 1] into a2[(cb - 1) & 1]), the gathers of block cb (into g[cb & 1]) and the
     // stores of block cb - 2 (from a2[cb & 1]).  MM / E1 / ST: which of the three this instance contains (compile-time).
-#define DL_ITER(CB, P, MM, E1, ST)                                                                                           \
+#define DL_ITER(CB, P, MM, E1, ST, DM)                                                                                       \
     {                                                                                                                        \
         const int cb = (CB);                                                                                                 \
         const char *arow = dl_smem + (P) * DL_ABUF + lane * 16;                                                              \
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(256, 1) void dec_l1_kernel(DecL1Params p)
                 fh2 = *reinterpret_cast<const uint4 *>(arow + (s + 2) * 2048);                                               \
                 fl2 = *reinterpret_cast<const uint4 *>(arow + (s + 2) * 2048 + 1024);                                        \
             }                                                                                                                \
-            if ((MM) && s < DL_NDMA) dma((P) ^ 1, s);                                                                        \
+            if ((MM) && (DM) && s < DL_NDMA) dma((P) ^ 1, s);                                                                \
             if ((MM) && s >= DL_NDMA) {                                                                                      \
                 _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2)                                                             \
                     if (2 * (s - DL_NDMA) + t2 < 12) gather1(g[(P)], cb, 2 * (s - DL_NDMA) + t2);                            \
@@ -490,15 +498,21 @@ __global__ __launch_bounds__(256, 1) void dec_l1_kernel(DecL1Params p)
         if (MM) __builtin_amdgcn_s_waitcnt(0x0f70 | 12); else __builtin_amdgcn_s_waitcnt(0x0f70);                             \
         __syncthreads();                                                                                                     \
     }
-    DL_ITER(0, 0, true, false, false)
-    DL_ITER(1, 1, true, true, false)
+    if (single >= 0) {                                            // one channel block of a tile behind the last full round
+        DL_ITER(single, 0, true, false, false, false)
+        DL_ITER(single + 1, 1, false, true, false, false)
+        DL_ITER(single + 2, 0, false, false, true, false)
+    } else {
+        DL_ITER(0, 0, true, false, false, true)
+        DL_ITER(1, 1, true, true, false, true)
 #pragma unroll 1
-    for (int c2 = 2; c2 < DL_NCB; c2 += 2) {
-        DL_ITER(c2, 0, true, true, true)
-        DL_ITER(c2 + 1, 1, true, true, true)
+        for (int c2 = 2; c2 < DL_NCB; c2 += 2) {
+            DL_ITER(c2, 0, true, true, true, true)
+            DL_ITER(c2 + 1, 1, true, true, true, true)
+        }
+        DL_ITER(DL_NCB, 0, false, true, true, true)
+        DL_ITER(DL_NCB + 1, 1, false, false, true, true)
     }
-    DL_ITER(DL_NCB, 0, false, true, true)
-    DL_ITER(DL_NCB + 1, 1, false, false, true)
 #undef DL_ITER
     // the block's largest activation for the consumer's range guard (bits of a non-negative float order as the floats do)
     if (m0 < p.M && p.h1_amax) {
@@ -525,10 +539,19 @@ extern "C" int tgp_dec_l1(const tgp_dec_l1_args *a, tgp_stream_t stream)
     p.rowbias = a->rowbias, p.ldrb = a->ldrb, p.rows_per_obj = a->rows_per_obj > 0 ? a->rows_per_obj : a->M;
     p.h1_pl = reinterpret_cast<char *>(a->h1_planes), p.h1_kt = a->h1_kt, p.h1_amax = a->h1_amax;
     p.flag = a->flag, p.M = a->M, p.tiles = tgp_cdiv(a->M, 128);
+    // a few tiles past a whole number of rounds (one workgroup per CU) go in single channel blocks
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    const int over = p.tiles % cus;
+    p.main_tiles = (p.tiles > cus && over > 0 && over <= 8) ? p.tiles - over : p.tiles;
     const int lds = 2 * DL_ABUF + 3 * DF_C1 * 4;
     static TgpLdsAttr attr;
     if (const int e = tgp_lds_attr(attr, reinterpret_cast<const void *>(dec_l1_kernel), lds)) return e;
-    hipLaunchKernelGGL(dec_l1_kernel, dim3(p.tiles), dim3(256), lds, tgp_hs(stream), p);
+    hipLaunchKernelGGL(dec_l1_kernel, dim3(p.main_tiles + (p.tiles - p.main_tiles) * DL_NCB), dim3(256), lds, tgp_hs(stream), p);
     return TGP_LAUNCH_RESULT();
 }
 
