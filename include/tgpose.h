@@ -66,7 +66,9 @@ int tgp_knn_feat(const float *feat, int ld, int B, int n, int d, int k, int32_t 
                  int64_t workspace_bytes, tgp_stream_t stream);
 /* (ABI 5) the same with the kernel form chosen by the caller -- 0: the library's choice; 1: 32-row blocks, one workgroup per CU
  * (v_mfma_f32_32x32x2_f32); 2: 16-row blocks, two workgroups per CU whose distance and selection phases overlap
- * (v_mfma_f32_16x16x4_f32, the same ascending-k chain).  Identical index lists; a measurement / test handle. */
+ * (v_mfma_f32_16x16x4_f32, the same ascending-k chain); 3 (ABI 7): the 16-row arithmetic on producer / consumer waves of one 512-thread
+ * workgroup per CU over a double-buffered LDS image (half of the waves multiply block j + 1 while the other half select block j):
+ * the library's choice where a workgroup gets at least four row blocks to walk.  Identical index lists; a measurement / test handle. */
 int tgp_knn_feat_form(const float *feat, int ld, int B, int n, int d, int k, int32_t *idx, void *workspace, int64_t workspace_bytes,
                       int form, tgp_stream_t stream);
 /* (ABI 6) tgp_knn_feat that also leaves, beside each list, the unit directions from the point to its selected neighbours in the

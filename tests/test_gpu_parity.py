@@ -124,9 +124,10 @@ def test_knn_feat_bit_exact_vs_oracle(ops, B, n, d, k, ld):
     want = _clib.knn(x.numpy(), k)
     got = ops.knn_feat(g(buf)[:, :, :d], k).cpu().numpy()
     assert np.array_equal(got, want)
-    # both forms of the fused kernel (round 4): 32-row blocks on v_mfma_f32_32x32x2_f32, 16-row blocks on v_mfma_f32_16x16x4_f32 --
-    # the same ascending-k chain per distance, so the same index lists (other shapes: the form is ignored)
-    for form in (1, 2):
+    # every form of the fused kernel: 32-row blocks on v_mfma_f32_32x32x2_f32, 16-row blocks on v_mfma_f32_16x16x4_f32 (round 4), and the
+    # 16-row arithmetic on producer / consumer waves over a double-buffered image (round 5) -- the same ascending-k chain per distance,
+    # so the same index lists (other shapes: the form is ignored)
+    for form in (1, 2, 3):
         assert np.array_equal(ops.knn_feat(g(buf)[:, :, :d], k, form=form).cpu().numpy(), want), form
 
 
@@ -140,7 +141,7 @@ def test_knn_feat_coincident_rows_take_the_serial_selection(ops, B, n, d, k):
     x[:, n // 2:] = 0.0                           # half of the cloud has dead features
     x[:, : n // 4] = x[:, :1]                     # a quarter repeats one row
     want = _clib.knn(x.numpy(), k)
-    for form in (0, 1, 2):
+    for form in (0, 1, 2, 3):
         assert np.array_equal(ops.knn_feat(g(x), k, form=form).cpu().numpy(), want), form
 
 

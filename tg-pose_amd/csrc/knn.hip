@@ -306,10 +306,22 @@ __device__ __forceinline__ uint32_t wave_umax(uint32_t v)
 //   3. the survivors are compacted into a per-wave list in LDS (ballot prefix sums), lane l takes survivor l and counts the
 //      survivors that precede it in (key, index) order: that count is its rank; ranks 1 .. k are written out.
 // Returns false (wave-uniform, nothing written) if more than 64 candidates survive; the caller then runs wave_select.
+// (round 5) slot / nbr (may be NULL): the list entry this LANE wrote -- slot in [0, k), its neighbour's id -- or slot = -1: the caller that
+// goes on to use the list (the neighbour directions) has it in registers and need not wait for its own stores and read them back.
+// (round 5) The compiler turned the first form's booleans into 64-bit lane masks in scalar registers: every (key, index) comparison was
+// three vector compares, two scalar mask operations and a select, every conditional list write a save / restore of the execution
+// mask -- ~110 mask operations and ~120 hazard no-ops per row, each a round trip between the vector and the scalar unit on a wave that
+// runs alone: ~10 k cycles per row (scripts/knn_pc_stamps.py), which -- not the matrix pipe -- bounded the fused kernels.  Now an entry is
+// ONE 64-bit integer (key << 32 | index): a comparison is v_cmp_lt_u64 + add-with-carry; and every candidate is WRITTEN, a survivor to
+// its place in the list, the others to a scratch entry of the lane's own (no execution-mask changes).  Same comparisons, same lists.
+#define KNN_LIST 136                       // entries per wave: 64 survivors + 8 sentinels, then one scratch entry per lane
 template <int NT>
 __device__ __forceinline__ bool wave_select_ranked(const uint32_t (&key)[NT], int lane, int k, int32_t *__restrict__ out_row,
-                                                   uint32_t *__restrict__ lmin, uint2 *__restrict__ list /* 72 entries, 16-byte aligned */)
+                                                   uint32_t *__restrict__ lmin, uint2 *__restrict__ list /* KNN_LIST entries, 16-byte aligned */,
+                                                   int *slot = nullptr, int *nbr = nullptr, unsigned long long *ph = nullptr)
 {
+#define KNN_PH(I) do { if (ph) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[I] += t_ - ph[5]; ph[5] = t_; } } while (0)
+    if (ph) ph[5] = __builtin_readcyclecounter();
     uint32_t mn = key[0];
 #pragma unroll
     for (int t = 1; t < NT; ++t) mn = key[t] < mn ? key[t] : mn;
@@ -322,6 +334,7 @@ __device__ __forceinline__ bool wave_select_ranked(const uint32_t (&key)[NT], in
         rank += (v.x < mn) + (v.y < mn) + (v.z < mn) + (v.w < mn);
     }
     const uint32_t tau = wave_umax(rank <= k ? mn : 0u);
+    KNN_PH(0);
     int cnt = 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) cnt += key[t] <= tau;
@@ -337,36 +350,41 @@ __device__ __forceinline__ bool wave_select_ranked(const uint32_t (&key)[NT], in
         pos += (int)(__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) << bit;
         total += __popcll(m) << bit;
     }
+    KNN_PH(1);
     if (total > 64) return false;                                     // wave-uniform
+    // an entry = (index, key) as it lies: read as one 64-bit integer it is key << 32 | index, the (key, index) order
+    unsigned long long *list64 = reinterpret_cast<unsigned long long *>(list);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        if (key[t] <= tau) {
-            list[pos] = make_uint2(key[t], (uint32_t)(lane + (t << 6)));
-            ++pos;
-        }
+        const bool s = key[t] <= tau;
+        list64[s ? pos : 72 + lane] = ((unsigned long long)key[t] << 32) | (uint32_t)(lane + (t << 6));
+        pos += s;
     }
-    if (lane < 8) list[total + lane] = make_uint2(0xffffffffu, 0xffffffffu);     // sentinels: the rank loop reads whole groups of 8
+    if (lane < 8) list64[total + lane] = ~0ull;                       // sentinels: the rank loop reads whole groups of 8
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    const uint2 mine = list[lane < total ? lane : 0];
+    KNN_PH(2);
+    const unsigned long long mine = list64[lane < total ? lane : 0];
     int r = 0;
     for (int j = 0; j < total; j += 8) {                              // wave-uniform trip count; broadcast reads, issued together
-        uint4 e[4];
+        ulonglong2 e[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) e[u] = reinterpret_cast<const uint4 *>(list + j)[u];
+        for (int u = 0; u < 4; ++u) e[u] = reinterpret_cast<const ulonglong2 *>(list64 + j)[u];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            r += (e[u].x < mine.x) || (e[u].x == mine.x && e[u].y < mine.y);
-            r += (e[u].z < mine.x) || (e[u].z == mine.x && e[u].w < mine.y);
-        }
+        for (int u = 0; u < 4; ++u) r += (e[u].x < mine) + (e[u].y < mine);
     }
-    if (lane < total && r >= 1 && r <= k) out_row[r - 1] = (int32_t)mine.y;
+    const bool has = lane < total && r >= 1 && r <= k;
+    if (has) out_row[r - 1] = (int32_t)(uint32_t)mine;
+    if (slot) *slot = has ? r - 1 : -1, *nbr = (int)(uint32_t)mine;
+    KNN_PH(3);
+#undef KNN_PH
     return true;
 }
 
 // The serial form on keys, compact (a runtime loop of k + 1 rounds, each a lane-local scan for the smallest key after the last
 // one emitted plus two wave reductions): the fall-back of wave_select_ranked, rare, so size matters more than speed.
 template <int NT>
-__device__ __forceinline__ void wave_select_serial_keys(const uint32_t (&key)[NT], int lane, int k, int32_t *__restrict__ out_row)
+__device__ __forceinline__ void wave_select_serial_keys(const uint32_t (&key)[NT], int lane, int k, int32_t *__restrict__ out_row,
+                                                        int *slot = nullptr, int *nbr = nullptr)
 {
     uint32_t lastk = 0;
     int lastj = -1, mine = 0;
@@ -386,6 +404,7 @@ __device__ __forceinline__ void wave_select_serial_keys(const uint32_t (&key)[NT
         if (r >= 1 && lane == r - 1) mine = lastj;
     }
     if (lane < k) out_row[lane] = mine;
+    if (slot) *slot = lane < k ? lane : -1, *nbr = mine;
 }
 
 template <int NT>
@@ -394,8 +413,8 @@ __global__ __launch_bounds__(256) void knn_xyz_kernel(const float *__restrict__ 
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *pts = reinterpret_cast<float4 *>(smem);
-    uint2 *s_list = reinterpret_cast<uint2 *>(smem + (size_t)n * sizeof(float4));          // [4 waves][72]
-    uint32_t *s_lmin = reinterpret_cast<uint32_t *>(s_list + 4 * 72);                         // [4 waves][64]
+    uint2 *s_list = reinterpret_cast<uint2 *>(smem + (size_t)n * sizeof(float4));          // [4 waves][KNN_LIST]
+    uint32_t *s_lmin = reinterpret_cast<uint32_t *>(s_list + 4 * KNN_LIST);                   // [4 waves][64]
     int b, tile;
     if (!tgp_xcd_object_tile(blockIdx.x, B, tiles_per_obj, b, tile)) return;
     const float *xb = xyz + (size_t)b * n * 3;
@@ -431,7 +450,7 @@ __global__ __launch_bounds__(256) void knn_xyz_kernel(const float *__restrict__ 
         // rank-counting selection (no chain of k + 1 wave reductions); clouds with many coincident points can leave more than 64
         // candidates under its bound: those rows take the serial form
         int32_t *out = idx + ((size_t)b * n + i) * k;
-        if (!wave_select_ranked<NT>(key, lane, k, out, s_lmin + wave * 64, s_list + wave * 72))
+        if (!wave_select_ranked<NT>(key, lane, k, out, s_lmin + wave * 64, s_list + wave * KNN_LIST))
             wave_select_serial_keys<NT>(key, lane, k, out);
     }
 }
@@ -481,7 +500,7 @@ extern "C" int tgp_knn_xyz(const float *xyz, int B, int n, int k, int32_t *idx, 
     const int rpb = knn_rows_per_block(B, n);
     const int tiles = tgp_cdiv(n, rpb);
     const dim3 grid(tgp_xcd_grid(B, tiles)), block(256);
-    const size_t lds = (size_t)n * sizeof(float4) + 4 * (72 * sizeof(uint2) + 64 * sizeof(uint32_t));
+    const size_t lds = (size_t)n * sizeof(float4) + 4 * (KNN_LIST * sizeof(uint2) + 64 * sizeof(uint32_t));
     const int nt = tgp_cdiv(n, 64);
 #define LAUNCH_XYZ(NT) \
     hipLaunchKernelGGL(knn_xyz_kernel<NT>, grid, block, lds, tgp_hs(stream), xyz, B, n, k, idx, tiles, rpb)
@@ -539,6 +558,19 @@ __global__ __launch_bounds__(256) void sqnorm_aten_kernel(const float *__restric
 // round (1056 blocks = 4.1 rounds, 288 = 1.1).  When the tail is that short (n_extra <= 8 rows) those rows ride along instead:
 // block rb < n_extra also takes row 32 * nrb + rb, its distances computed on the vector pipe (the same ascending-k FMA chain,
 // one column per thread and pass) into a 33rd LDS row, selected by wave 7 after its four rows.
+#ifdef TGP_DEV   // development build: rows whose rank-counting selection met more than 64 survivors and took the serial form
+__device__ unsigned long long tgp_knn_serial_rows = 0ull;
+extern "C" int tgp_debug_knn_serial_rows(unsigned long long *out, int reset)
+{
+    unsigned long long z = 0ull;
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(tgp_knn_serial_rows), sizeof(z));
+    if (e == hipSuccess && reset) e = hipMemcpyToSymbol(HIP_SYMBOL(tgp_knn_serial_rows), &z, sizeof(z));
+    return (int)e;
+}
+#define KNN_COUNT_SERIAL() do { if (lane == 0) atomicAdd(&tgp_knn_serial_rows, 1ull); } while (0)
+#else
+#define KNN_COUNT_SERIAL() do { } while (0)
+#endif
 typedef float knn_f32x16 __attribute__((ext_vector_type(16)));
 
 #define KF_ROWS 32
@@ -555,7 +587,7 @@ __global__ __launch_bounds__(512, 2) void knn_feat_fused_kernel(const float *__r
 {
     extern __shared__ __attribute__((aligned(16))) float dblk[];      // [32 (+ 1 with tail rows)][ldw]
     __shared__ uint32_t s_lmin[8][64];
-    __shared__ __attribute__((aligned(16))) uint2 s_list[8][72];
+    __shared__ __attribute__((aligned(16))) uint2 s_list[8][KNN_LIST];
     constexpr int STEPS = DIM / 2;                                    // MFMA steps per column block (k pairs)
     constexpr int NCHUNK = STEPS / CH;
     constexpr int RING = 4;                                           // B-operand chunks in flight: three ahead of the MFMAs
@@ -695,17 +727,18 @@ typedef float knn_f32x4 __attribute__((ext_vector_type(4)));
 // convolution that walks this list next (gconv.hip, nbr_dirs_kernel: the same arithmetic) -- written by the wave that has just
 // selected the row, instead of by a launch of its own.  The wave reads its own list back: its stores are acknowledged (vmcnt 0)
 // and the loads go past the L1 (sc1).
-__device__ __forceinline__ void knn_emit_dirs(const float *__restrict__ xyz, float4 *__restrict__ dirs, const int32_t *out,
-                                              const int64_t rowi, const int b, const int n, const int k, const int lane)
+__device__ __forceinline__ void knn_emit_dirs(const float *__restrict__ xyz, float4 *__restrict__ dirs, const int slot, const int nb,
+                                              const int64_t rowi, const int b, const int n, const int k)
 {
-    __builtin_amdgcn_s_waitcnt(0x0f70);                               // vmcnt(0)
-    if (lane >= k) return;
-    const int nb = __hip_atomic_load(out + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (round 5) from the selecting lane's registers.  Round 4 read the list back -- `s_waitcnt vmcnt(0)` for the stores' acknowledgements,
+    // then sc1 loads, then the two coordinate loads: four dependent memory round trips per row on a wave that selects four rows per
+    // block, ~5 us each -- which, not the matrix pipe, was what the kernel waited for (its selection phase took ~30 us per block).
+    if (slot < 0) return;
     const float *pc = xyz + rowi * 3;
     const float *pn = xyz + ((int64_t)b * n + nb) * 3;
     const float dx = pn[0] - pc[0], dy = pn[1] - pc[1], dz = pn[2] - pc[2];
     const float nrm = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-12f);
-    dirs[rowi * k + lane] = make_float4(dx / nrm, dy / nrm, dz / nrm, 0.f);
+    dirs[rowi * k + slot] = make_float4(dx / nrm, dy / nrm, dz / nrm, 0.f);
 }
 
 template <int DIM, int NT, int CH>
@@ -715,7 +748,7 @@ __global__ __launch_bounds__(256, 2) void knn_feat_fused16_kernel(const float *_
 {
     extern __shared__ __attribute__((aligned(16))) float dblk16[];    // [16 (+ 1 with a tail row)][ldw]
     __shared__ uint32_t s_lmin[4][64];
-    __shared__ __attribute__((aligned(16))) uint2 s_list[4][72];
+    __shared__ __attribute__((aligned(16))) uint2 s_list[4][KNN_LIST];
     constexpr int STEPS = DIM / 4;                                    // MFMA steps per column group (k quads)
     constexpr int NCHUNK = STEPS / CH;
     constexpr int RING = 4;
@@ -832,17 +865,203 @@ __global__ __launch_bounds__(256, 2) void knn_feat_fused16_kernel(const float *_
             key[t] = tgp_float_key(j < n ? row[j] : INFINITY);
         }
         int32_t *out = idx + ((size_t)b * n + i) * k;
-        if (!wave_select_ranked<NT>(key, lane, k, out, s_lmin[wave], s_list[wave]))
-            wave_select_serial_keys<NT>(key, lane, k, out);
-        if (dirs) knn_emit_dirs(xyz, dirs, out, (int64_t)b * n + i, b, n, k, lane);      // workgroup-uniform
+        int slot, nb;
+        if (!wave_select_ranked<NT>(key, lane, k, out, s_lmin[wave], s_list[wave], &slot, &nb)) {
+            KNN_COUNT_SERIAL();
+            wave_select_serial_keys<NT>(key, lane, k, out, &slot, &nb);
+        }
+        if (dirs) knn_emit_dirs(xyz, dirs, slot, nb, (int64_t)b * n + i, b, n, k);       // workgroup-uniform
+    }
+}
+
+// (round 5) The same two phases as PRODUCER and CONSUMER waves of one workgroup: 512 threads, waves 0-3 compute the distances of row block
+// j + 1 into one half of a double-buffered LDS image (2 x 17 rows x ldw: 144 KB at n = 1028) while waves 4-7 select block j from the
+// other half; one barrier per block; a workgroup walks `bpw` consecutive row blocks of one object (B x 8 workgroups for the
+// benchmark's B = 32, n = 1028: one per CU, ONE round instead of four).  Wave w and wave w + 4 share a SIMD, so every SIMD holds one
+// wave on the matrix pipe and one on the vector / LDS pipes at all times -- in the 16-row form two workgroups per CU were meant to
+// alternate like that but nothing kept them out of phase (SQ counters, round 4: matrix pipe busy 34 %).  Per element the same arithmetic
+// in the same order as knn_feat_fused16_kernel (and the same selection): the same lists, bit for bit.
+// MEASURED, NOT THE DEFAULT (scripts/knn_time.py, scripts/knn_pc_stamps.py, B = 32, n = 1028, d = 128): 255 us against 165-180 us for the
+// 16-row form.  Stamps per wave: producers 26-32 k cycles per block inside their loop, consumers 36-43 k (9-10 k per row, with a selection of
+// ~600 instructions), producers parked at the barrier for 40 % of the kernel.  The premise was wrong: the distance products are exact fp32
+// MFMAs, which run at the fp32 VECTOR rate on the lanes the selection's vector instructions need, so a selecting wave beside a multiplying
+// wave gets a fraction of the SIMD's issue slots (s_setprio 2 for the selectors: -4 %) -- the two phases do not overlap on one SIMD, they add
+// (~17 k cycles of MFMA + ~16 k of selection per block and SIMD: the 16-row form's 163 us) -- and here only four waves select instead of
+// eight.  What it did show: the selection, not the matrix pipe, is the longer half; its rewrite on 64-bit compares (wave_select_ranked)
+// took 7 % off every form.
+template <int DIM, int NT, int CH>
+__global__ __launch_bounds__(512, 2) void knn_feat_pc_kernel(const float *__restrict__ xt, const float *__restrict__ q, int B, int n, int k,
+                                                             int32_t *__restrict__ idx, int nrb, int ldw, int n_extra,
+                                                             const float *__restrict__ xyz, float4 *__restrict__ dirs, int bpw, int chunks,
+                                                             unsigned long long *stamps)
+{
+    extern __shared__ __attribute__((aligned(16))) float dpc[];       // [2][16 + 1][ldw]
+    unsigned long long t_body = 0, t_bar = 0, t_keys = 0;
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    __shared__ uint32_t s_lmin[4][64];
+    __shared__ __attribute__((aligned(16))) uint2 s_list[4][KNN_LIST];
+    constexpr int STEPS = DIM / 4;
+    constexpr int NCHUNK = STEPS / CH;
+    constexpr int RING = 4;
+    static_assert(NCHUNK % RING == 0, "the chunk ring's phase must repeat per column group");
+    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = wave8 & 3, consumer = wave8 >> 2;
+    const int c = lane & 15, g = lane >> 4;
+    int b, chunk;
+    if (!tgp_xcd_object_tile(blockIdx.x, B, chunks, b, chunk)) return;
+    const int rb0 = chunk * bpw, nb = min(nrb, rb0 + bpw) - rb0;
+    // the selecting waves are the second-dispatched half of the workgroup: at equal priority they lose the arbitration for the SIMD's issue
+    // slots against their producer partner on every instruction (micro-architecture guide, "Two waves per SIMD", item 4), and they are the
+    // longer of the two chains
+    if (consumer) __builtin_amdgcn_s_setprio(2);
+    const size_t bufsz = (size_t)(KF16_ROWS + 1) * ldw;
+    const float *qb = q + (size_t)b * n;
+    const int ngrp = (ldw + 63) >> 6;
+    const float *xo = xt + (size_t)b * DIM * ldw + (size_t)g * ldw;
+#pragma unroll 1
+    for (int it = 0; it <= nb; ++it) {
+        const unsigned long long t0 = stamps ? __builtin_readcyclecounter() : 0ull;
+        if (!consumer && it < nb) {
+            // ---- phase 1 of block rb0 + it (knn_feat_fused16_kernel's, on the same four-wave split)
+            const int rb = rb0 + it;
+            const int i0 = rb * KF16_ROWS;
+            float *dblk16 = dpc + (size_t)(it & 1) * bufsz;
+            const bool has_extra = rb < n_extra;
+            const int ix = nrb * KF16_ROWS + rb;
+            {
+                float a[STEPS];
+#pragma unroll
+                for (int s2 = 0; s2 < STEPS; ++s2) a[s2] = xo[(size_t)4 * s2 * ldw + i0 + c];
+                float qrow[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qrow[e] = qb[min(i0 + 4 * g + e, n - 1)];
+                float4 buf[RING][CH];
+                auto fetch = [&](int grp, int cc, float4 (&dst)[CH]) {
+                    const int col = min(64 * grp + 4 * c, ldw - 4);
+                    const float *br = xo + (size_t)4 * cc * CH * ldw + col;
+#pragma unroll
+                    for (int t = 0; t < CH; ++t) dst[t] = *reinterpret_cast<const float4 *>(br + (size_t)4 * t * ldw);
+                };
+                if (wave < ngrp) {
+#pragma unroll
+                    for (int cc = 0; cc < RING - 1; ++cc) fetch(wave, cc, buf[cc]);
+                }
+                for (int grp = wave; grp < ngrp; grp += 4) {
+                    knn_f32x4 acc[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = knn_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int cc = 0; cc < NCHUNK; ++cc) {
+                        constexpr int AHEAD = RING - 1;
+                        if (cc + AHEAD < NCHUNK) fetch(grp, cc + AHEAD, buf[(cc + AHEAD) % RING]);
+                        else if (grp + 4 < ngrp) fetch(grp + 4, cc + AHEAD - NCHUNK, buf[(cc + AHEAD) % RING]);
+#pragma unroll
+                        for (int t = 0; t < CH; ++t) {                // ascending k: step s = cc CH + t takes k = 4 s + g
+                            const float av = a[cc * CH + t];
+                            const float4 bv = buf[cc % RING][t];
+                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.x, acc[0], 0, 0, 0);
+                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.y, acc[1], 0, 0, 0);
+                            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.z, acc[2], 0, 0, 0);
+                            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.w, acc[3], 0, 0, 0);
+                        }
+                    }
+                    const int col0 = 64 * grp + 4 * c;
+                    if (col0 < ldw) {
+                        float qc[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) qc[j] = qb[min(col0 + j, n - 1)];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float4 o;
+                            float *op = reinterpret_cast<float *>(&o);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float t1 = acc[j][e] * -2.0f;           // inner * (-2)
+                                const float t2 = t1 + qc[j];                  // + quadratic.unsqueeze(1)
+                                op[j] = col0 + j < n ? t2 + qrow[e] : INFINITY;   // + quadratic.unsqueeze(2)
+                            }
+                            *reinterpret_cast<float4 *>(dblk16 + (4 * g + e) * ldw + col0) = o;
+                        }
+                    }
+                }
+            }
+            if (has_extra && wave != 0) {
+                const float *xa = xt + (size_t)b * DIM * ldw;
+                const float qx = qb[ix];
+                const int t0 = (wave - 1) * 64 + lane;
+                for (int cbase = t0; cbase < ldw; cbase += 3 * 192) {
+                    const int c0 = cbase, c1 = cbase + 192, c2 = cbase + 384;
+                    const int l0 = c0, l1 = min(c1, ldw - 1), l2 = min(c2, ldw - 1);
+                    const float x0 = xa[ix];
+                    float in0 = x0 * xa[l0], in1 = x0 * xa[l1], in2 = x0 * xa[l2];
+#pragma unroll 16
+                    for (int kk = 1; kk < DIM; ++kk) {
+                        const float xv = xa[(size_t)kk * ldw + ix];
+                        in0 = fmaf(xv, xa[(size_t)kk * ldw + l0], in0);
+                        in1 = fmaf(xv, xa[(size_t)kk * ldw + l1], in1);
+                        in2 = fmaf(xv, xa[(size_t)kk * ldw + l2], in2);
+                    }
+                    auto put = [&](int col, float inner) {
+                        if (col < ldw) {
+                            const float t1 = inner * -2.0f;
+                            const float t2 = t1 + qb[min(col, n - 1)];
+                            dblk16[KF16_ROWS * ldw + col] = col < n ? t2 + qx : INFINITY;
+                        }
+                    };
+                    put(c0, in0), put(c1, in1), put(c2, in2);
+                }
+            }
+        } else if (consumer && it >= 1) {
+            // ---- phase 2 of block rb0 + it - 1: four rows per wave (wave 3: the tail row as its fifth)
+            const int rb = rb0 + it - 1;
+            const int i0 = rb * KF16_ROWS;
+            const float *dblk16 = dpc + (size_t)((it - 1) & 1) * bufsz;
+            const bool has_extra = rb < n_extra;
+            const int ix = nrb * KF16_ROWS + rb;
+#pragma unroll 1
+            for (int rr = 0; rr < 5; ++rr) {
+                if (rr == 4 && !(has_extra && wave == 3)) break;
+                const int lrow = rr == 4 ? KF16_ROWS : wave * 4 + rr, i = rr == 4 ? ix : i0 + lrow;
+                if (i >= n) break;
+                uint32_t key[NT];
+                const float *row = dblk16 + lrow * ldw;
+                const unsigned long long tk0 = stamps ? __builtin_readcyclecounter() : 0ull;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int j = lane + (t << 6);
+                    key[t] = tgp_float_key(j < n ? row[j] : INFINITY);
+                }
+                int32_t *out = idx + ((size_t)b * n + i) * k;
+                int slot, nb;
+                if (stamps) t_keys += __builtin_readcyclecounter() - tk0;
+                if (!wave_select_ranked<NT>(key, lane, k, out, s_lmin[wave], s_list[wave], &slot, &nb, stamps ? ph : nullptr)) {
+                    KNN_COUNT_SERIAL();
+                    wave_select_serial_keys<NT>(key, lane, k, out, &slot, &nb);
+                }
+                if (dirs) knn_emit_dirs(xyz, dirs, slot, nb, (int64_t)b * n + i, b, n, k);
+            }
+        }
+        const unsigned long long t1 = stamps ? __builtin_readcyclecounter() : 0ull;
+        __syncthreads();
+        if (stamps) t_body += t1 - t0, t_bar += __builtin_readcyclecounter() - t1;
+    }
+    if (stamps && lane == 0) {
+        stamps[(size_t)blockIdx.x * 16 + wave8 * 2] = t_body, stamps[(size_t)blockIdx.x * 16 + wave8 * 2 + 1] = t_bar;
+        if (wave8 == 5) {          // one consumer wave's phases: keys, lane minima + bound, count + prefix, compaction, ranks
+            unsigned long long *o = stamps + (size_t)gridDim.x * 16 + (size_t)blockIdx.x * 8;
+            o[0] = t_keys, o[1] = ph[0], o[2] = ph[1], o[3] = ph[2], o[4] = ph[3];
+        }
     }
 }
 
 #ifdef TGP_DEV
 static unsigned long long *tgp_knn_stamps = nullptr;
 extern "C" void tgp_debug_set_knn_stamps(unsigned long long *buf) { tgp_knn_stamps = buf; }
+static int tgp_knn_pc_mode = 0;            // 1: the library picks the producer / consumer form where a workgroup gets >= 4 row blocks (A/B runs)
+extern "C" void tgp_debug_set_knn_pc(int v) { tgp_knn_pc_mode = v; }
 #else
 static constexpr unsigned long long *tgp_knn_stamps = nullptr;
+static constexpr int tgp_knn_pc_mode = 0;  // measured SLOWER (below): form 3 stays a test / measurement handle
 #endif
 
 // implemented in gemm.hip: D[b,i,j] = fl(fl(-2*<x_i,x_j> + q_j) + q_i), natural-k MFMA chain
@@ -968,6 +1187,26 @@ static int launch_knn_fused(const float *xt, const float *q, int B, int n, int k
         const int tail16 = n % KF16_ROWS, n_extra16 = (tail16 > 0 && tail16 <= 8 && tail16 <= n / KF16_ROWS) ? tail16 : 0;
         const int nrb16 = n_extra16 ? n / KF16_ROWS : tgp_cdiv(n, KF16_ROWS);
         const size_t lds16 = (size_t)(KF16_ROWS + (n_extra16 ? 1 : 0)) * ldw * sizeof(float);
+        // (round 5) producer / consumer waves over a double-buffered image: form 3, and the library's choice when a workgroup gets at
+        // least four row blocks of an object to walk (one workgroup per CU: B x chunks of them) and the image fits
+        {
+            static int cus = 0;
+            if (!cus) {
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                    cus = 256;
+            }
+            const size_t ldspc = (size_t)2 * (KF16_ROWS + 1) * ldw * sizeof(float);
+            const int want = B >= cus ? 1 : cus / B;                   // workgroups per object for about one per CU
+            const int bpw = tgp_cdiv(nrb16, want < nrb16 ? want : nrb16), chunks = tgp_cdiv(nrb16, bpw);
+            if (ldspc <= 152 * 1024 && (form == 3 || (form == 0 && bpw >= 4 && tgp_knn_pc_mode))) {
+                static TgpLdsAttr attrpc;
+                if (const int e = tgp_lds_attr(attrpc, reinterpret_cast<const void *>(knn_feat_pc_kernel<DIM, NT, CH / 2>), 152 * 1024)) return e;
+                hipLaunchKernelGGL((knn_feat_pc_kernel<DIM, NT, CH / 2>), dim3(tgp_xcd_grid(B, chunks)), dim3(512), ldspc, stream, xt, q, B, n, k,
+                                   idx, nrb16, ldw, n_extra16, xyz, dirs, bpw, chunks, tgp_knn_stamps);
+                return TGP_LAUNCH_RESULT();
+            }
+        }
         static TgpLdsAttr attr16;
         if (const int e = tgp_lds_attr(attr16, reinterpret_cast<const void *>(knn_feat_fused16_kernel<DIM, NT, CH / 2>),
                                        (KF16_ROWS + 1) * KF_MAX_LDW * (int)sizeof(float))) return e;
@@ -1020,7 +1259,7 @@ extern "C" int tgp_knn_feat_dirs(const float *feat, int ld, int B, int n, int d,
 static int knn_feat_go(const float *feat, int ld, int B, int n, int d, int k, int32_t *idx, void *workspace, int64_t workspace_bytes,
                        int form, const float *xyz, float4 *dirs, tgp_stream_t stream)
 {
-    TGP_REQUIRE(feat && idx && workspace && form >= 0 && form <= 2);
+    TGP_REQUIRE(feat && idx && workspace && form >= 0 && form <= 3);
     const int chk = knn_check(B, n, k);
     if (chk) return chk;
     if (d <= 0 || (d & 31) || (d >> 5) >= 16) return TGP_EUNSUPPORTED;
