@@ -378,21 +378,22 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
         uint32_t k0[HF_C2 / 32], k1[HF_C2 / 32];
         bool finite = true;
         if (plain) {
+            // the maximum is taken on the floats and keyed once per column: the key is order-preserving (and max(-0, +0) = +0 as
+            // key(-0) < key(+0)), so key(max v) = max key(v) for every value that is not a NaN; NaNs and infinities show in the sum of
+            // the pre-activation values (a finite sum of sixteen floats that overflows flags too: the repair then recomputes a tile
+            // that was fine, nothing else).  ReLU as max(v, -0): what `v > 0 ? v : v * 0` gives for every number.
 #pragma unroll
             for (int ob = 0; ob < HF_C2 / 32; ++ob) {
-                uint32_t ka = 0;
-                float big = 0.f;
+                float mx = -0.f, sum = 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     float v = acc2[ob][e] + b2v[ob];
                     v = v * sc2v[ob] + sh2v[ob];
-                    v = v > 0.f ? v : v * 0.f;
-                    big = fmaxf(big, v), finite &= v == v;
-                    const uint32_t key = tgp_float_key(v);
-                    ka = key > ka ? key : ka;
+                    sum += v;
+                    mx = fmaxf(mx, v);
                 }
-                finite &= big < __builtin_inff();
-                k0[ob] = ka, k1[ob] = 0;
+                finite &= sum - sum == 0.f;                          // (inf - inf and NaN - NaN are NaN)
+                k0[ob] = tgp_float_key(mx), k1[ob] = 0;
             }
         } else {                                                   // a wave that straddles two objects, or the batch's end
 #pragma unroll
@@ -421,6 +422,7 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
 #pragma unroll
             for (int ob = 0; ob < HF_C2 / 32; ++ob) {
                 uint32_t ka = k0[ob], kb = k1[ob];
+                if (bad) ka = 0xffc00000u;                             // (no flag to raise: the key of a NaN -- loud)
                 const uint32_t o0 = (uint32_t)__shfl_xor((int)ka, 32, 64), o1 = (uint32_t)__shfl_xor((int)kb, 32, 64);
                 ka = o0 > ka ? o0 : ka, kb = o1 > kb ? o1 : kb;
                 if (h == 0) {
