@@ -199,6 +199,8 @@ ALGO_BYTES_B32 = {
     "void conv_max_fused_kernel": 35.8e6 + 33.7e6 + 8.4e6 + 1.1e6,
     # the first decoder conv's activation as planes (32896 x 512 x 4 B), the three inner weights, the rows out + their map
     "dec_fused_kernel": 67.4e6 + 1.7e6 + 0.4e6 + 0.3e6,
+    # fine + the decoder's 512 columns of the coarse products (8224 + 2048 rows) + weight planes + the activation out as fragments
+    "dec_l1_kernel": 35.8e6 + 16.8e6 + 4.2e6 + 0.6e6 + 67.4e6,
     "void gconv_kernel<128, false>": 4.83e6 * 32,       # conv_1's graph convolution, SURVEY 8d: 4.83 MB per object
     "void gconv_kernel<128, true>": 0.62e6 * 32,        # conv_0
     # conv_2 / conv_3 (n = 257, C = 256): centre + 7 support blocks of the projection (8224 x 2048 x 4 B), directions, lists, output
