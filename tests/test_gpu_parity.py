@@ -3270,6 +3270,63 @@ def test_graphed_training_follows_eager_training(ops):
             assert (weights["graph"][k] - w).abs().max().item() <= 1e-6 * max(w.abs().max().item(), 1.0), k
 
 
+def _flat_tensors(d, prefix=""):
+    out = {}
+    for k, v in d.items():
+        if torch.is_tensor(v):
+            out[prefix + str(k)] = v.detach().clone()
+        elif isinstance(v, dict):
+            out.update(_flat_tensors(v, prefix + str(k) + "."))
+    return out
+
+
+def test_train_step_with_net2_beside_net1_equals_serial(ops):
+    """The trainer's default runs net2's forward (no gradients, its own cloud) on a second stream beside net1's -- a parallel branch
+    of the captured step (trainer/RL_TDA.py: NET2_BESIDE).  Nothing is shared between the two until the losses, so the step must
+    compute bit for bit what the serial order computes: total, every loss term and every parameter gradient, launched eagerly and
+    replayed from a captured graph."""
+    from tgpose_amd import FLAGS
+    from tgpose_amd.trainer import RL_TDA
+    from tgpose_amd.trainer.RL_TDA import total_loss
+    B, N = 8, 512
+    db = {k: g(v) for k, v in _step_db([0, 1, 2, 3, 4, 5, 1, 4], N, 37).items()}
+    torch.manual_seed(5)
+    pair = []
+    for _ in range(2):
+        i1 = torch.randperm(N)[: N // 4]
+        pair.append((i1, torch.randperm(i1.numel())[: i1.numel() // 4]))
+    keep = RL_TDA.NET2_BESIDE
+    out = {}
+    try:
+        for beside in (False, True):
+            RL_TDA.NET2_BESIDE = beside
+            tr = _trainer(17)
+            _, ld = tr.RL_TDA_train_step(db, sample_idx=pair)
+            t = total_loss(ld)
+            t.backward()
+            torch.cuda.synchronize()
+            out[beside, "eager"] = (t.detach().clone(), _flat_tensors(ld),
+                                    [p.grad.detach().clone() for p in tr.net1.parameters() if p.grad is not None])
+            del t, ld
+            tr = _trainer(17)
+            step = tr.graphed_step(db)
+            tot = step(sample_idx=pair)
+            tot = step(sample_idx=pair)                          # a second replay: nothing stale on the side branch
+            torch.cuda.synchronize()
+            out[beside, "graph"] = (tot.detach().clone(), {}, [p.grad.detach().clone() for p in tr.net1.parameters() if p.grad is not None])
+    finally:
+        RL_TDA.NET2_BESIDE = keep
+        FLAGS.train = 0
+    for form in ("eager", "graph"):
+        a, b = out[False, form], out[True, form]
+        assert torch.equal(a[0], b[0]), (form, a[0], b[0])
+        for k in a[1]:
+            assert torch.equal(a[1][k], b[1][k]), (form, k)
+        assert len(a[2]) == len(b[2]) and len(a[2]) > 100
+        for x, y in zip(a[2], b[2]):
+            assert torch.equal(x, y), form
+
+
 def test_overlapped_two_segment_step_equals_single_graph(ops):
     """The data-parallel form of the captured step -- backward split at the encoder's output into two hipGraphs that share a pool,
     gradients in two flat buckets whose exchange hooks run between / after the segments (no-ops in one process) -- computes
