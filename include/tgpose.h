@@ -675,12 +675,14 @@ typedef struct tgp_heads_fused_args {
 int tgp_heads_fused(const tgp_heads_fused_args *args, tgp_stream_t stream);
 /* conv -> BatchNorm(eval) -> LeakyReLU -> max over each object's points of a factored layer whose activation only feeds the max
  * (FaceRecon.py:76-77 conv_5 and the `feat.max(1)` that follows, on the factored form of this repo's engine): operands as for
- * tgp_heads_fused with one "head" of C channels (C % 32 == 0; wa_s / bias / scale / shift / p1 / p2 point at its first channel),
- * slope = the LeakyReLU slope, keys (B, C) row stride ldk zeroed by the caller; p1_rows / p2_rows: rows of p1 / p2 (their
- * element offsets must fit 31 bits); overflow as in tgp_heads_fused (the caller's repair is tgp_gemm_f32 with `pred`). */
+ * tgp_heads_fused with one "head" of C channels (C % 32 == 0; wa_planes / bias / scale / shift / p1 / p2 point at its first channel),
+ * slope = the LeakyReLU slope, 0 <= slope <= 1; keys (B, C) row stride ldk zeroed by the caller; p1_rows / p2_rows: rows of p1 / p2
+ * (p1_rows * ldp1 and p2_rows * ldp2 below 2^30: rows are addressed with 32-bit byte offsets); overflow as in tgp_heads_fused (the
+ * caller's repair is tgp_gemm_f32 with `pred`).  A NaN or an infinity among an object's activations gives that (object, channel) a
+ * NaN's key. */
 typedef struct tgp_conv_max_fused_args {
     const float *fine; int ldf; int K;
-    const void *wa_s;
+    const void *wa_planes;     /* (ABI 7) the layer's (C, K) weight as blocked fp16 planes with 17 K-tiles: tgp_planes_split, the layout of tgp_gemm_args.W_planes */
     const float *p1; int ldp1; int p1_rows; const int32_t *idx1;
     const float *p2; int ldp2; int p2_rows; const int32_t *idx2;
     const float *bias; const float *scale; const float *shift; float slope;

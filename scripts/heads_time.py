@@ -3,7 +3,8 @@
     python scripts/heads_time.py [--rounds 5] [--reps 20] [--points 1028] [--batch 32]
     python scripts/heads_time.py --stamps            # development library: per-wave cycle stamps of the heads kernel's sections
     python scripts/heads_time.py --knobs 0,1,2,4,7   # development library: timing-only builds (1 = no LDS-DMA after the prologue,
-                                                     # 2 = no gathers of the coarse products, 4 = no fragment reads; results are garbage)
+                                                     # 2 = no gathers of the coarse products, 4 = no fragment reads; results are garbage;
+                                                     # heads kernel: 0, 1, 2, 4, 7; conv_5 kernel: 0, 1, 2, 4, 8 = no epilogue)
 """
 import argparse
 import os
@@ -49,6 +50,7 @@ def main():
     was = ops.split_f16(d(Wa))
     pl = ops.planes_split(fine_d, K=K, kt=17)
     wap = ops.heads_planes_w(d(Wa)[1024:])
+    wcp = ops.heads_planes_w(d(Wa)[:1024])
     w2p = ops.heads_pack_w2(d(W2), d(bias)[1024:], d(scale)[1024:], d(shift)[1024:])
     g = dict(P1=d(P1), P2=d(P2), idx1=d(idx1), idx2=d(idx2), bias=d(bias), scale=d(scale), shift=d(shift), b2=d(b2), sc2=d(sc2), sh2=d(sh2))
 
@@ -57,7 +59,7 @@ def main():
                                B, N, fine_planes=pl)
 
     def conv5():
-        return ops.conv_max_fused(fine_d, K, was, g["P1"], g["idx1"], g["P2"], g["idx2"], g["bias"][:1024], g["scale"][:1024],
+        return ops.conv_max_fused(fine_d, K, wcp, g["P1"], g["idx1"], g["P2"], g["idx2"], g["bias"][:1024], g["scale"][:1024],
                                   g["shift"][:1024], 0.2, B, N, fine_planes=pl)
 
     if a.stamps:
@@ -87,7 +89,7 @@ def main():
         print("kernel span from first entry to last exit: %.1f us" % ((w0 + dur).max().item()))
         return
     knobs = [int(k) for k in a.knobs.split(",")] if a.knobs else [0]
-    for name, fn in (("heads_fused", heads_),) + ((("conv_max_fused", conv5),) if not a.knobs else ()):
+    for name, fn in (("heads_fused", heads_), ("conv_max_fused", conv5)):
         times = {k: [] for k in knobs}
         for rnd in range(a.rounds):
             for k in knobs:

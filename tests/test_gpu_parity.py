@@ -2345,7 +2345,7 @@ def test_fused_kernels_vs_fp64(ops, B, N):
     was = ops.split_f16(d(Wa))
     keys2, over = ops.heads_fused(d(fine), K, ops.heads_planes_w(d(Wa)[1024:]), d(P1)[:, 1024:], d(idx1), d(P2)[:, 1024:], d(idx2),
                                   ops.heads_pack_w2(d(W2), d(bias)[1024:], d(scale)[1024:], d(shift)[1024:]), d(b2), d(sc2), d(sh2), B, N)
-    keys5, over5 = ops.conv_max_fused(d(fine), K, was, d(P1), d(idx1), d(P2), d(idx2), d(bias)[:1024], d(scale)[:1024], d(shift)[:1024],
+    keys5, over5 = ops.conv_max_fused(d(fine), K, ops.heads_planes_w(d(Wa)[:1024]), d(P1), d(idx1), d(P2), d(idx2), d(bias)[:1024], d(scale)[:1024], d(shift)[:1024],
                                       0.2, B, N)
     assert int(over.item()) == 0 and int(over5.item()) == 0
     got2 = ops.colmax_decode(keys2.view(heads * B, 256)).view(heads, B, 256).cpu().double()
@@ -2382,7 +2382,7 @@ def test_fused_kernels_flag_tiny_inputs(ops):
     keys2, over = ops.heads_fused(d(fine), K, ops.heads_planes_w(d(Wa)[1024:]), d(P1)[:, 1024:], d(idx1), d(P2)[:, 1024:], d(idx2),
                                   ops.heads_pack_w2(d(W2), d(z)[1024:], d(o)[1024:], d(z)[1024:]), d(z)[:768].view(3, 256),
                                   d(o)[:768].view(3, 256), d(z)[:768].view(3, 256), B, N)
-    keys5, over5 = ops.conv_max_fused(d(fine), K, was, d(P1), d(idx1), d(P2), d(idx2), d(z)[:1024], d(o)[:1024], d(z)[:1024], 0.2, B, N)
+    keys5, over5 = ops.conv_max_fused(d(fine), K, ops.heads_planes_w(d(Wa)[:1024]), d(P1), d(idx1), d(P2), d(idx2), d(z)[:1024], d(o)[:1024], d(z)[:1024], 0.2, B, N)
     assert int(over.item()) == 1 and int(over5.item()) == 1
     assert int(keys2.abs().max().item()) == 0 and int(keys5.abs().max().item()) == 0        # flagged waves wrote nothing
 

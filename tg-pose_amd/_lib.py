@@ -56,7 +56,7 @@ class ConvMaxFusedArgs(ctypes.Structure):
     """struct tgp_conv_max_fused_args (include/tgpose.h)"""
     _fields_ = [
         ("fine", c_vp), ("ldf", c_int), ("K", c_int),
-        ("wa_s", c_vp),
+        ("wa_planes", c_vp),
         ("p1", c_vp), ("ldp1", c_int), ("p1_rows", c_int), ("idx1", c_vp),
         ("p2", c_vp), ("ldp2", c_int), ("p2_rows", c_int), ("idx2", c_vp),
         ("bias", c_vp), ("scale", c_vp), ("shift", c_vp), ("slope", ctypes.c_float),

@@ -16,10 +16,12 @@
 // workgroup sharing the LDS-staged weight blocks (double buffered: 2 x 67 KB).
 #include "tgp_common.h"
 #include "../../include/tgpose.h"
+#include <type_traits>
 
 typedef _Float16 hf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 hf16x4 __attribute__((ext_vector_type(4)));
 typedef float hf32x4 __attribute__((ext_vector_type(4)));
+typedef float hf32x2 __attribute__((ext_vector_type(2)));
 typedef float hf32x16 __attribute__((ext_vector_type(16)));
 
 #define HF_STEPS 17                 // K steps of conv1: 272 / 16
@@ -444,18 +446,29 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
 
 // ------------------------------------------------------------------------------------------------------------------------
 // conv -> BatchNorm -> LeakyReLU -> max over points of a factored layer whose activation only feeds the max (conv_5 of Face_Enc,
-// FaceRecon.py:76-77 `conv_5` + `feat.max(1)`): the fused heads kernel's phase 1 with the operands' roles swapped -- the points'
+// FaceRecon.py:76-77 `conv_5` + `feat.max(1)`): the fused heads kernel's conv1 with the operands' roles swapped -- the points'
 // fragments are the A operand, the weight rows the B operand -- so that a lane holds ONE channel and 16 points: the epilogue's
 // vectors are scalars per lane, the gathered coarse products are 4-byte loads coalesced over the channels, and the max over the
-// points is 15 in-lane maxima + one cross-half shuffle.  No conv2 accumulators: ~190 registers, two waves per SIMD; a workgroup
-// takes 128 points and CBW of the channel blocks (70 KB of LDS: two workgroups per CU).  Same products in the same order as the
-// tile kernel (activation hi x weight lo, lo x hi, hi x hi; K ascending), same epilogue order.
-#define CM_BUF (36 * 1024)                // conv weight rows (35 KB incl. padding) + 1 KB of epilogue vectors
-#define CM_NDMA 9                         // wave-instructions per wave and block
+// points is 15 in-lane maxima + one cross-half shuffle.  No conv2 accumulators: two waves per SIMD; a workgroup takes 128 points and
+// CBW of the channel blocks (68 KB of LDS: two workgroups per CU).  Same products in the same order as the tile kernel (activation
+// hi x weight lo, lo x hi, hi x hi; K ascending), same epilogue order.
+//
+// Round 5: software-pipelined over the channel blocks, as heads_fused_kernel's stage A.  The first form ran a block as gathers ->
+// 51 MFMAs -> ~220 vector instructions of epilogue -> atomics -> vmcnt(0) -> barrier, one phase after the other, and the two
+// workgroups of a CU -- started together -- met in the same phases: matrix cores busy 28 % of the launch.  Now iteration i issues
+// block i's MFMAs into one of two accumulators and places, in the gaps behind them, the fragment reads of the next step, the
+// LDS-DMA of block i + 1's weights, block i - 1's epilogue element by element, and -- as soon as an element has consumed its
+// gathered values -- the gathers of block i into the same registers (a whole iteration ahead of their use).  The iteration's wait
+// is counted (the DMA pieces are older than the last sixteen gathers), so neither gathers nor atomics are waited for at the
+// barrier.  The weights come as blocked fp16 planes (tgp_gemm_args.W_planes' layout, 17 K-tiles: one 32-channel block = 34
+// contiguous 1 KB pieces in lane order): a DMA piece is a linear copy, a fragment read is base + 16 x lane + immediate.
+#define CM_PIECES (2 * HF_STEPS)          // 34 pieces of 1 KB per channel block
+#define CM_BUF (CM_PIECES * 1024)
+#define CM_NDMA ((CM_PIECES + 3) / 4)     // 9 wave-instructions per wave and block (the last round is short: waves 2, 3 repeat a piece)
 
 struct ConvMaxParams {
     const float *fine; int ldf, K;
-    const uint16_t *wa_s;
+    const char *wa_pl;                    // the layer's weights as blocked planes: [block of 32 channels][17][2][h][r][8] fp16
     const float *p1; int ldp1; const int32_t *idx1;
     const float *p2; int ldp2; const int32_t *idx2;
     const float *bias, *scale, *shift;
@@ -467,11 +480,13 @@ struct ConvMaxParams {
     const char *fine_pl; int fine_kt; const uint32_t *fine_amax;      // (round 4) the points' features as blocked fp16 planes
 };
 
-template <bool PLANES>
+__device__ __forceinline__ constexpr int cm_vmcnt(int n) { return 0x0f70 | (n & 15) | ((n >> 4) << 14); }
+
+template <bool PLANES, int KNOB = 0>
 __global__ __launch_bounds__(256, 2) void conv_max_fused_kernel(ConvMaxParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char hf_smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     // The benchmark's 32896 points are 257 tiles of 128: in two chunks each that is 514 workgroups for 512 resident slots, and two of
     // them would run alone for a whole second round.  The tiles past the last full round are cut into single channel blocks
@@ -489,6 +504,21 @@ __global__ __launch_bounds__(256, 2) void conv_max_fused_kernel(ConvMaxParams p)
     }
     const int m0 = ptile * 128 + wave * 32;
     const int row = min(m0 + r, p.M - 1);
+
+    // the first block's weights travel while the points' fragments are fetched
+    const uint32_t voff0 = lane * 16 + wave * 1024;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)hf_smem) + wave * 1024;
+    auto dma = [&](const int cb, const int buf, const int j0) {
+        if ((KNOB & 1) && cb != cb0) return;
+        const char *src = p.wa_pl + (int64_t)cb * CM_BUF;
+        const int jj = (j0 == CM_NDMA - 1 && wave >= (CM_PIECES & 3)) ? j0 - 1 : j0;    // pieces 34, 35 do not exist
+        const uint32_t lds = lds0 + buf * CM_BUF + jj * 4096;
+        const uint32_t vo = voff0 + jj * 4096;
+        // inline assembly: opaque to the compiler's counters; the waits are written by hand before the barrier that ends an iteration
+        asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(src), "{m0}"(lds) : "memory");
+    };
+#pragma unroll
+    for (int j0 = 0; j0 < CM_NDMA; ++j0) dma(cb0, 0, j0);
 
     uint4 ah[HF_STEPS], al[HF_STEPS];     // the wave's points: A fragments, fp16 hi / lo planes of fine[row][16 s + 8 h .. + 7]
     float amax = 0.f, poison = 0.f;
@@ -527,123 +557,166 @@ __global__ __launch_bounds__(256, 2) void conv_max_fused_kernel(ConvMaxParams p)
             ah[s] = make_uint4(h0.x, h0.y, h1.x, h1.y), al[s] = make_uint4(l0.x, l0.y, l1.x, l1.y);
         }
     }
-    // the lane's 16 points (accumulator rows (e & 3) + 8 (e >> 2) + 4 h): element offsets of their coarse products' rows.  They
+    // the lane's 16 points (accumulator rows (e & 3) + 8 (e >> 2) + 4 h): BYTE offsets of their coarse products' rows.  They
     // depend on (h, e) only, so they live in 256 bytes of LDS per wave instead of 32 registers per lane.
-    __shared__ __attribute__((aligned(16))) int s_off[4][2][2][16];
+    __shared__ __attribute__((aligned(16))) uint32_t s_off[4][2][2][16];
     {
         const int lvl = lane >> 5, hh = (lane >> 4) & 1, e = lane & 15;
         const int pr = min(m0 + (e & 3) + 8 * (e >> 2) + 4 * hh, p.M - 1);
-        s_off[wave][lvl][hh][e] = lvl ? p.idx2[pr] * p.ldp2 : p.idx1[pr] * p.ldp1;
+        s_off[wave][lvl][hh][e] = 4u * (uint32_t)(lvl ? p.idx2[pr] * p.ldp2 : p.idx1[pr] * p.ldp1);
     }
     const bool live = m0 < p.M;
     const bool bad = __ballot(!(amax < 65504.f) || poison != poison) != 0ull ||      // fp16 range guard, as in the heads kernel
                      (__ballot(amax >= 0.0625f) == 0ull && __ballot(amax > 0.f) != 0ull);   // ... and its small side (all inputs < 2^-4)
     if (live && bad && p.overflow && lane == 0) atomicOr(p.overflow, 1);
     const int obj0 = m0 / p.rows_per_obj, bound = (obj0 + 1) * p.rows_per_obj;
+    // accumulator element e is the point m0 + (e & 3) + 8 (e >> 2) + 4 h: past the object's last row when that offset reaches lim_b,
+    // past the batch's when it reaches lim_m.  A wave whose 32 points are one object's and exist takes the plain epilogue.
+    const int lim_b = bound - m0 - 4 * h, lim_m = p.M - m0 - 4 * h;
+    const bool plain_wave = m0 + 32 <= bound && m0 + 32 <= p.M;
+    const bool store = live && h == 0 && !(bad && p.overflow);
+    const uint32_t *o1 = s_off[wave][0][h], *o2 = s_off[wave][1][h];
+    const uint32_t r4 = 4u * r;
+    const float ninf = -__builtin_inff();
 
-    int dma_off[CM_NDMA];
-#pragma unroll
-    for (int j0 = 0; j0 < CM_NDMA; ++j0) {
-        const int j = j0 * 4 + wave;
-        if (j < 35) {
-            const int c = j * 64 + lane, rw = c / 69, pc = c % 69;
-            dma_off[j0] = rw < 32 ? (rw * 68 + (pc < 68 ? pc : 67)) * 16 : 0;
-        } else dma_off[j0] = lane < 24 ? (lane & 7) * 16 : 0;
-    }
-    auto dma = [&](int cb, int buf, int j0) {
-        const int j = j0 * 4 + wave;
-        const char *src;
-        if (j < 35) src = reinterpret_cast<const char *>(p.wa_s) + (int64_t)cb * 32 * (HF_STEPS * 64);
-        else {
-            const float *v = lane < 8 ? p.bias : lane < 16 ? p.scale : p.shift;
-            src = reinterpret_cast<const char *>(v + cb * 32);
-        }
-        const uint32_t lds = __builtin_amdgcn_readfirstlane(
-            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)(hf_smem + buf * CM_BUF + j * 1024));
-        asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + dma_off[j0]), "{m0}"(lds) : "memory");
-    };
-#pragma unroll
-    for (int j0 = 0; j0 < CM_NDMA; ++j0) dma(cb0, 0, j0);
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    __syncthreads();
-
-    for (int cb = cb0; cb < cb1; ++cb) {
-        const int buf = (cb - cb0) & 1;
-        const char *base = hf_smem + buf * CM_BUF;
-        float g1[16], g2[16];
-        {
-            const int4 *o1 = reinterpret_cast<const int4 *>(s_off[wave][0][h]), *o2 = reinterpret_cast<const int4 *>(s_off[wave][1][h]);
-            const float *q1 = p.p1 + cb * 32 + r, *q2 = p.p2 + cb * 32 + r;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int4 a = o1[m], c = o2[m];
-                g1[4 * m] = q1[a.x], g1[4 * m + 1] = q1[a.y], g1[4 * m + 2] = q1[a.z], g1[4 * m + 3] = q1[a.w];
-                g2[4 * m] = q2[c.x], g2[4 * m + 1] = q2[c.y], g2[4 * m + 2] = q2[c.z], g2[4 * m + 3] = q2[c.w];
-            }
-        }
-        hf32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        const char *wrow = base + r * HF_AROW + h * 16;
-        {
-            uint4 fh0 = *reinterpret_cast<const uint4 *>(wrow), fl0 = *reinterpret_cast<const uint4 *>(wrow + 32);
-            uint4 fh1 = *reinterpret_cast<const uint4 *>(wrow + 64), fl1 = *reinterpret_cast<const uint4 *>(wrow + 64 + 32);
-#pragma unroll
-            for (int s = 0; s < HF_STEPS; ++s) {
-                uint4 fh2 = fh1, fl2 = fl1;
-                if (s + 2 < HF_STEPS) {
-                    fh2 = *reinterpret_cast<const uint4 *>(wrow + (s + 2) * 64);
-                    fl2 = *reinterpret_cast<const uint4 *>(wrow + (s + 2) * 64 + 32);
+    float g1[16], g2[16];                 // the gathered coarse products of the block whose epilogue comes next
+    float bP, scP, shP, bN, scN, shN;     // bias / scale / shift of the lane's channel: previous block, this block
+    float mx0 = ninf, mx1 = ninf, chk = 0.f, ev = 0.f;
+    uint32_t ea = 0, ec = 0;
+    // (scalar base + 32-bit lane offset: one address add per gather)
+    auto at = [&](const float *base, const uint32_t off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + off); };
+    // block cb's epilogue, slot t of 34: the lane's channel is 32 cb + r, its 16 accumulator elements are 16 points.  Slots 2 e, 2 e + 1:
+    // element e, in the tile kernel's order (+ bias, + P1, + P2, BatchNorm fold, LeakyReLU); its gathered values are replaced by block
+    // cb + 1's as soon as they are consumed (next).  Written for the fewest vector instructions: their issue time ADDS to the matrix
+    // time in this kernel (timing knobs of the development build: without the epilogue 41 us, with its arithmetic alone 60, all of it
+    // 64; packed fp32 pairs are split again by the compiler inside the MFMAs' shadow and only cost registers: 114 us).  The maximum is
+    // taken on the floats -- LeakyReLU with a slope in [0, 1] is max(v, slope v), to the bit -- and keyed once per block; a NaN or an
+    // infinity among the values makes the key a NaN's (chk), as the per-element keys did.  Slots 32, 33: the other half's maxima, the
+    // atomics.
+    auto epi = [&](auto plain, const hf32x16 &acc, const int cb, const int t, const bool next_) {
+        const bool next = next_ && !(KNOB & 16);
+        if (t < 32) {
+            const int e = t >> 1, off = (e & 3) + 8 * (e >> 2);
+            if ((t & 1) == 0) {
+                if (t == 0) mx0 = ninf, mx1 = ninf, chk = 0.f;
+                ev = acc[e] + bP;
+                ev += g1[e];
+                ev += g2[e];
+                ev = ev * scP + shP;
+                if (next) ea = o1[e] + r4, ec = o2[e] + r4;
+            } else {
+                const float v = fmaxf(ev, ev * p.slope);
+                chk = __builtin_fmaf(v, 0.f, chk);
+                if constexpr (decltype(plain)::value) mx0 = fmaxf(mx0, v);
+                else {
+                    const float w = off < lim_m ? v : ninf;
+                    const bool own = off < lim_b;
+                    mx0 = fmaxf(mx0, own ? w : ninf), mx1 = fmaxf(mx1, own ? ninf : w);
                 }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, ah[s]), __builtin_bit_cast(hf16x8, fl0), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, al[s]), __builtin_bit_cast(hf16x8, fh0), acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, ah[s]), __builtin_bit_cast(hf16x8, fh0), acc, 0, 0, 0);
-                if (s >= 1 && s <= CM_NDMA && cb + 1 < cb1) dma(cb + 1, buf ^ 1, s - 1);
-                __builtin_amdgcn_sched_barrier(0);
-                fh0 = fh1, fl0 = fl1, fh1 = fh2, fl1 = fl2;
+                if (next && !(KNOB & 2)) g1[e] = at(p.p1 + (cb + 1) * 32, ea), g2[e] = at(p.p2 + (cb + 1) * 32, ec);
+            }
+        } else if (t == 32) {
+            mx0 = fmaxf(mx0, __shfl_xor(mx0, 32, 64)), chk += __shfl_xor(chk, 32, 64);
+            if constexpr (!decltype(plain)::value) mx1 = fmaxf(mx1, __shfl_xor(mx1, 32, 64));
+        } else {
+            if (store) {
+                uint32_t *kp = p.keys + (int64_t)obj0 * p.ldk + cb * 32 + r;
+                const bool loud = chk != 0.f;                    // (chk is 0 or a NaN)
+                if (mx0 > ninf || loud) atomicMax(kp, loud ? 0xffc00000u : tgp_float_key(mx0));
+                if constexpr (!decltype(plain)::value)
+                    if (mx1 > ninf || loud) atomicMax(kp + p.ldk, loud ? 0xffc00000u : tgp_float_key(mx1));
             }
         }
-        // epilogue: the lane's channel is 32 cb + r, its 16 accumulator elements are 16 points
-        const float *pv = reinterpret_cast<const float *>(base + 35 * 1024);
-        const float b = pv[r], sc = pv[32 + r], sh = pv[64 + r];
-        uint32_t k0 = 0, k1 = 0;
+    };
+    // iteration: block cb's 51 MFMAs into accN; in their gaps the next step's fragments, the DMA of block cb + 1 (with_dma), block
+    // cb - 1's epilogue from accP (with_epi) and block cb's vectors
+    auto iter = [&](auto plain, hf32x16 &accN, const hf32x16 &accP, const int cb, const int buf, const bool with_epi, const bool with_dma) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int prow = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            float v = acc[e] + b;
-            v += g1[e];
-            v += g2[e];
-            v = v * sc + sh;
-            v = v > 0.f ? v : v * p.slope;
-            const uint32_t key = prow < p.M ? tgp_float_key(v) : 0u;
-            if (prow >= bound) k1 = key > k1 ? key : k1;
-            else k0 = key > k0 ? key : k0;
+        for (int e = 0; e < 16; ++e) accN[e] = 0.f;
+        const char *wrow = hf_smem + buf * CM_BUF + lane * 16;
+        // (fragments one step ahead: the SIMD's other wave covers the LDS latency, and the registers are needed)
+        uint4 fh0 = *reinterpret_cast<const uint4 *>(wrow), fl0 = *reinterpret_cast<const uint4 *>(wrow + 1024);
+        HP_SB();
+#pragma unroll
+        for (int s = 0; s < HF_STEPS; ++s) {
+            uint4 fh1 = fh0, fl1 = fl0;
+            accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, ah[s]), __builtin_bit_cast(hf16x8, fl0), accN, 0, 0, 0);
+            HP_SB();
+            if (s + 1 < HF_STEPS && !(KNOB & 4)) {
+                fh1 = *reinterpret_cast<const uint4 *>(wrow + (s + 1) * 2048);
+                fl1 = *reinterpret_cast<const uint4 *>(wrow + (s + 1) * 2048 + 1024);
+            }
+            if (with_dma && s < CM_NDMA) dma(cb + 1, buf ^ 1, s);
+            HP_SB();
+            accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, al[s]), __builtin_bit_cast(hf16x8, fh0), accN, 0, 0, 0);
+            HP_SB();
+            if (with_epi && !(KNOB & 8)) epi(plain, accP, cb - 1, 2 * s, true);
+            HP_SB();
+            accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hf16x8, ah[s]), __builtin_bit_cast(hf16x8, fh0), accN, 0, 0, 0);
+            HP_SB();
+            if (with_epi && !(KNOB & 8)) epi(plain, accP, cb - 1, 2 * s + 1, true);
+            if (s == HF_STEPS - 1) bN = p.bias[cb * 32 + r], scN = p.scale[cb * 32 + r], shN = p.shift[cb * 32 + r];
+            HP_SB();
+            fh0 = fh1, fl0 = fl1;
         }
-        const uint32_t o0 = (uint32_t)__shfl_xor((int)k0, 32, 64), o1 = (uint32_t)__shfl_xor((int)k1, 32, 64);
-        k0 = o0 > k0 ? o0 : k0, k1 = o1 > k1 ? o1 : k1;
-        if (live && h == 0 && !(bad && p.overflow)) {
-            uint32_t *kp = p.keys + (int64_t)obj0 * p.ldk + cb * 32 + r;
-            if (k0) atomicMax(kp, k0);
-            if (k1) atomicMax(kp + p.ldk, k1);
+        bP = bN, scP = scN, shP = shN;
+        if (with_dma) {
+            // this wave's DMA pieces have landed when at most the sixteen gathers issued after the last piece (and whatever followed
+            // them) are outstanding; without an epilogue nothing was issued behind them
+            if (with_epi && !(KNOB & 10)) __builtin_amdgcn_s_waitcnt(cm_vmcnt(16));
+            else __builtin_amdgcn_s_waitcnt(cm_vmcnt(0));
+            __builtin_amdgcn_s_barrier();
         }
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();
-    }
+    };
+    auto run = [&](auto plain) {
+        hf32x16 acc0, acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
+        iter(plain, acc0, acc1, cb0, 0, false, cb0 + 1 < cb1);
+        int cb = cb0 + 1;
+        for (; cb + 1 < cb1; cb += 2) {
+            iter(plain, acc1, acc0, cb, 1, true, true);
+            iter(plain, acc0, acc1, cb + 1, 0, true, cb + 2 < cb1);
+        }
+        if (cb < cb1) {
+            iter(plain, acc1, acc0, cb, 1, true, false);
+#pragma unroll
+            for (int t = 0; t < 34; ++t) epi(plain, acc1, cb, t, false);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 34; ++t) epi(plain, acc0, cb - 1, t, false);
+        }
+    };
+
+#pragma unroll
+    for (int e = 0; e < 16; ++e) g1[e] = at(p.p1 + cb0 * 32, o1[e] + r4), g2[e] = at(p.p2 + cb0 * 32, o2[e] + r4);
+    __builtin_amdgcn_s_waitcnt(cm_vmcnt(0));
+    __syncthreads();
+    if (plain_wave) run(std::true_type{});
+    else run(std::false_type{});
 }
+
+#ifdef TGP_DEV   // development build: per-wave cycle stamps and timing-only knobs (scripts/heads_time.py)
+static unsigned long long *tgp_heads_stamps = nullptr;
+static int tgp_heads_knobs = 0;
+extern "C" int tgp_debug_set_heads_stamps(void *buf) { tgp_heads_stamps = reinterpret_cast<unsigned long long *>(buf); return 0; }
+extern "C" int tgp_debug_set_heads_knobs(int v) { tgp_heads_knobs = v; return 0; }
+#endif
 
 extern "C" int tgp_conv_max_fused(const tgp_conv_max_fused_args *a, tgp_stream_t stream)
 {
-    TGP_REQUIRE(a && a->fine && a->wa_s && a->p1 && a->p2 && a->idx1 && a->idx2 && a->bias && a->scale && a->shift && a->keys);
+    TGP_REQUIRE(a && a->fine && a->wa_planes && a->p1 && a->p2 && a->idx1 && a->idx2 && a->bias && a->scale && a->shift && a->keys);
     TGP_REQUIRE(a->M > 0 && a->C > 0 && (a->C & 31) == 0 && a->rows_per_obj >= 32 && a->M % a->rows_per_obj == 0 && a->ldk >= a->C);
     TGP_REQUIRE(a->K > 0 && a->K <= 16 * HF_STEPS && a->K > 16 * (HF_STEPS - 1) && a->ldf >= 16 * HF_STEPS && (a->ldf & 3) == 0);
     TGP_REQUIRE(a->ldp1 >= a->C && a->ldp2 >= a->C);
-    // the coarse products' rows are addressed with 32-bit element offsets
-    TGP_REQUIRE((int64_t)a->p1_rows * a->ldp1 < (1ll << 31) && (int64_t)a->p2_rows * a->ldp2 < (1ll << 31));
+    // the coarse products' rows are addressed with 32-bit byte offsets
+    TGP_REQUIRE((int64_t)a->p1_rows * a->ldp1 < (1ll << 30) && (int64_t)a->p2_rows * a->ldp2 < (1ll << 30));
+    TGP_REQUIRE(a->slope >= 0.f && a->slope <= 1.f);             // LeakyReLU as max(v, slope v)
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    TGP_REQUIRE(al16(a->fine) && al16(a->wa_s) && al16(a->bias) && al16(a->scale) && al16(a->shift));
+    TGP_REQUIRE(al16(a->fine) && al16(a->wa_planes) && al16(a->bias) && al16(a->scale) && al16(a->shift));
     ConvMaxParams p;
     p.fine = a->fine, p.ldf = a->ldf, p.K = a->K;
-    p.wa_s = reinterpret_cast<const uint16_t *>(a->wa_s);
+    p.wa_pl = reinterpret_cast<const char *>(a->wa_planes);
     p.p1 = a->p1, p.ldp1 = a->ldp1, p.idx1 = a->idx1, p.p2 = a->p2, p.ldp2 = a->ldp2, p.idx2 = a->idx2;
     p.bias = a->bias, p.scale = a->scale, p.shift = a->shift, p.slope = a->slope;
     p.keys = a->keys, p.ldk = a->ldk, p.overflow = a->overflow;
@@ -658,6 +731,17 @@ extern "C" int tgp_conv_max_fused(const tgp_conv_max_fused_args *a, tgp_stream_t
     if (const int e = tgp_lds_attr(attr_t, reinterpret_cast<const void *>(conv_max_fused_kernel<true>), 2 * CM_BUF)) return e;
     if (const int e = tgp_lds_attr(attr_f, reinterpret_cast<const void *>(conv_max_fused_kernel<false>), 2 * CM_BUF)) return e;
     const int grid = p.main_tiles * p.chunks + (p.tiles - p.main_tiles) * (p.C / 32);
+#ifdef TGP_DEV
+    static TgpLdsAttr attr_k[5];
+#define CM_KNOB(I, N)                                                                                        \
+    if (p.fine_pl && tgp_heads_knobs == N) {                                                                 \
+        if (const int e = tgp_lds_attr(attr_k[I], reinterpret_cast<const void *>(conv_max_fused_kernel<true, N>), 2 * CM_BUF)) return e; \
+        hipLaunchKernelGGL((conv_max_fused_kernel<true, N>), dim3(grid), dim3(256), 2 * CM_BUF, tgp_hs(stream), p); \
+        return TGP_LAUNCH_RESULT();                                                                          \
+    }
+    CM_KNOB(0, 1) CM_KNOB(1, 2) CM_KNOB(2, 4) CM_KNOB(3, 8) CM_KNOB(4, 16)
+#undef CM_KNOB
+#endif
     if (p.fine_pl) hipLaunchKernelGGL(conv_max_fused_kernel<true>, dim3(grid), dim3(256), 2 * CM_BUF, tgp_hs(stream), p);
     else hipLaunchKernelGGL(conv_max_fused_kernel<false>, dim3(grid), dim3(256), 2 * CM_BUF, tgp_hs(stream), p);
     return TGP_LAUNCH_RESULT();
@@ -705,13 +789,6 @@ extern "C" int tgp_heads_pack_w2(const float *w2, const float *bias1, const floa
                        reinterpret_cast<uint16_t *>(out));
     return TGP_LAUNCH_RESULT();
 }
-
-#ifdef TGP_DEV   // development build: per-wave cycle stamps and timing-only knobs (scripts/heads_time.py)
-static unsigned long long *tgp_heads_stamps = nullptr;
-static int tgp_heads_knobs = 0;
-extern "C" int tgp_debug_set_heads_stamps(void *buf) { tgp_heads_stamps = reinterpret_cast<unsigned long long *>(buf); return 0; }
-extern "C" int tgp_debug_set_heads_knobs(int v) { tgp_heads_knobs = v; return 0; }
-#endif
 
 extern "C" int tgp_heads_fused(const tgp_heads_fused_args *a, tgp_stream_t stream)
 {

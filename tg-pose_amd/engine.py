@@ -281,11 +281,12 @@ def pack_factored(wide, dec0):
         for k in ("dec_a", "Wb", "Wc"):
             f[k + "_p"] = ops.planes_w(f[k])
     # the fused heads kernel (conv1 -> conv2 -> max in one launch) takes fp16 operands without a pack-time rescale
-    f["w2p"] = f["Wa_hp"] = None
+    f["w2p"] = f["Wa_hp"] = f["Wa_cp"] = None
     if (ops.GEMM_MODE == "split16" and getattr(f["Wa_s"], "tgp_unscale", None) is None
             and float(wide["W2"].abs().max()) < ops.FP16_SAFE):
         f["w2p"] = ops.heads_pack_w2(wide["W2"], wide["bias"][1024:], wide["scale"][1024:], wide["shift"][1024:])
         f["Wa_hp"] = ops.heads_planes_w(f["Wa"][1024:])
+        f["Wa_cp"] = ops.heads_planes_w(f["Wa"][:1024])         # conv_5's rows, for tgp_conv_max_fused
     f["dec_a_hp"] = ops.heads_planes_w(f["dec_a"]) if ops.planes_on() and f["dec_a"].shape[0] == 512 else None
     return f
 
@@ -712,13 +713,13 @@ def wide_gemm_factored(pk, fine, inter, P1, P2, N, arena=None, heads_only=False)
     if HEADS_FUSED and f["w2p"] is not None:
         # conv_5 (N = 1024, only its max over points is used) on the light fused kernel, the heads on theirs; the tile-kernel form
         # of conv_5 follows predicated on the range flag (it normally returns at once)
-        light = P1.numel() < 2 ** 31 and P2.numel() < 2 ** 31      # the light kernel addresses the coarse products with 32-bit offsets
+        light = P1.numel() < 2 ** 30 and P2.numel() < 2 ** 30      # the light kernel addresses the coarse products with 32-bit byte offsets
         over5 = None
         keys5 = None if heads_only else arena.keys5
         if heads_only:
             pass
         elif light:
-            keys5, over5 = ops.conv_max_fused(fine.view(M, -1), FINE_K, f["Wa_s"], P1, inter["near1"], P2, inter["near2"],
+            keys5, over5 = ops.conv_max_fused(fine.view(M, -1), FINE_K, f["Wa_cp"], P1, inter["near1"], P2, inter["near2"],
                                               w["bias"][:1024], w["scale"][:1024], w["shift"][:1024], 0.2, B, N, k_alg=w["k_alg"],
                                               keys=arena.keys5, overflow=arena.over5, fine_planes=(inter.get("planes") or {}).get("fine"))
         if not heads_only:

@@ -770,9 +770,10 @@ def dec_fused(h1_planes, units, vecs, w5, b5, order, rows_per_obj, flag, out=Non
     return out
 
 
-def conv_max_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias, scale, shift, slope, B, rows_per_obj, k_alg=None, keys=None, overflow=None,
+def conv_max_fused(fine, K, wa_planes, p1, idx1, p2, idx2, bias, scale, shift, slope, B, rows_per_obj, k_alg=None, keys=None, overflow=None,
                    fine_planes=None):
-    """conv -> BN -> LeakyReLU -> max over points of a factored layer (tgp_conv_max_fused): keys (B, C) and the overflow flag."""
+    """conv -> BN -> LeakyReLU -> max over points of a factored layer (tgp_conv_max_fused): keys (B, C) and the overflow flag.
+    wa_planes: heads_planes_w(the layer's (C, ld >= 268) weight over the fine buffer)."""
     fine, ldf = _rows(fine, "fine")
     C = bias.numel()
     M = B * rows_per_obj
@@ -786,7 +787,9 @@ def conv_max_fused(fine, K, wa_s, p1, idx1, p2, idx2, bias, scale, shift, slope,
         e0.record(torch.cuda.current_stream(fine.device))
     a = _lib.ConvMaxFusedArgs()
     a.fine, a.ldf, a.K = _p(fine), ldf, K
-    a.wa_s = _p(wa_s)
+    if wa_planes.kt != 17 or wa_planes.rows != C:
+        raise ValueError("conv_max_fused: wa_planes must hold the layer's C rows in 17 K-tiles (ops.heads_planes_w)")
+    a.wa_planes = _p(wa_planes.buf)
     a.p1, a.ldp1, a.p1_rows, a.idx1 = _p(p1), p1.stride(0), p1.shape[0], _p(idx1)
     a.p2, a.ldp2, a.p2_rows, a.idx2 = _p(p2), p2.stride(0), p2.shape[0], _p(idx2)
     a.bias, a.scale, a.shift, a.slope = _p(bias), _p(scale), _p(shift), float(slope)
