@@ -700,6 +700,36 @@ int64_t tgp_heads_w2_bytes(int heads);
 int tgp_heads_pack_w2(const float *w2, const float *bias1, const float *scale1, const float *shift1, int heads, void *out,
                       tgp_stream_t stream);
 
+/* (ABI 7) An HS layer's last GEMM and the NEXT layer's projection GEMM as one kernel (gcn3d.py:87-89 / 108-112 / 147-155 followed by
+ * gcn3d.py:170), csrc/hs_chain.hip, for the two shapes of Face_Enc without a pooling in between: (K1 in 129..144, N1 = 128, N2 = 1152)
+ * and (K1 in 241..256, N1 = 256, N2 = 2304); other shapes: -1 from tgp_hs_chain_pack_bytes, an argument error from the launches.
+ *   c1 = act(bn(A W1^T + rowbias[object] + res1 + res2)) (M, N1), the tile kernel's epilogue order; c2 = c1 W2^T + bias2 (M, N2).
+ *   a_planes / a_kt / a_amax: A (M, K1) as blocked fp16 planes + magnitude words (tgp_gemm_args.A_planes' layout; a_kt >= ceil(K1 / 16));
+ *   units = tgp_hs_chain_pack(W1 (N1, K1), W2 (N2, N1)); rowbias (M / rows_per_obj, N1) or NULL; res1 / res2 (M, N1) or NULL; scale1 /
+ *   shift1 (N1) both or neither; relu != 0: ReLU; c1 also as planes (c1_planes, c1_kt K-tiles per row block, first K-tile c1_kt0) with
+ *   magnitude words c1_amax (all may be NULL);
+ *   flag: device int, zeroed by the caller, raised when the operand or the intermediate leaves the fp16 split's range (>= 65504, NaN, or
+ *   a 32-row block wholly below 2^-4): c1 / c2 are then not to be trusted and the caller's two tgp_gemm_f32 launches follow with
+ *   tgp_gemm_args.pred = flag.  While the flag stays 0 both results equal those two launches' on the same planes bit for bit. */
+typedef struct tgp_hs_chain_args {
+    const void *a_planes; int a_kt; const uint32_t *a_amax;
+    int M; int K1; int N1; int N2;
+    const void *units;
+    const float *rowbias; int ldrb; int rows_per_obj;
+    const float *res1; int ldr1;
+    const float *res2; int ldr2;
+    const float *scale1; const float *shift1;
+    int relu;
+    float *c1; int ldc1;
+    void *c1_planes; int c1_kt; int c1_kt0; uint32_t *c1_amax;
+    const float *bias2;
+    float *c2; int ldc2;
+    int *flag;
+} tgp_hs_chain_args;
+int64_t tgp_hs_chain_pack_bytes(int K1, int N1, int N2);
+int tgp_hs_chain_pack(const float *w1, int ld1, int K1, int N1, const float *w2, int ld2, int N2, void *out, tgp_stream_t stream);
+int tgp_hs_chain(const tgp_hs_chain_args *args, tgp_stream_t stream);
+
 /* (ABI 7) The decoder behind its first conv as ONE kernel (FaceRecon.py:105-117 Face_Dec in eval mode: conv 512 -> 512, 512 -> 256,
  * 256 -> 128, each + BatchNorm + ReLU, then conv 128 -> 3), csrc/dec_fused.hip: a wave owns 32 points for the whole chain, no activation
  * between the layers leaves its registers.

@@ -3647,6 +3647,58 @@ def test_gemm_pp_bit_identical_to_split_kernel(ops, M, N, K, rpo):
     assert bool(((Cp.buf.view(-1, Cp.kt, 2, 2, 32, 16) == ref_pl.view(-1, Cp.kt, 2, 2, 32, 16)) | ~rows_ok).all()) and torch.equal(Cp.amax, ref_amax)
 
 
+@pytest.mark.parametrize("B,n,K1,N1,N2,bn", [(3, 1028, 132, 128, 1152, False), (32, 1028, 132, 128, 1152, False),
+                                               (4, 257, 256, 256, 2304, True), (32, 257, 256, 256, 2304, True)])
+def test_hs_chain_bit_identical_to_two_tile_launches(ops, B, n, K1, N1, N2, bn):
+    """tgp_hs_chain (an HS layer's last GEMM + the next layer's projection in one launch, csrc/hs_chain.hip) against the two
+    tile-kernel launches it replaces, on the same operand planes: the intermediate (fp32, planes, magnitude words) and the projection
+    carry the same bits -- same products, same order, same epilogue order.  Shapes: conv_0 -> conv_1 and conv_2 -> conv_3 of Face_Enc,
+    at batch sizes with partial tiles and waves that straddle objects, and at the benchmark's size (tiles past the last full round
+    take the per-group workgroups).  (Smaller batches: the engine keeps the two launches, which then run on the exact-fp32 kernel.)"""
+    gen = torch.Generator().manual_seed(B * 7 + n + K1)
+    M = B * n
+    ld = (K1 + 3) // 4 * 4
+    A = g(torch.randn(M, ld, generator=gen))
+    W1, W2 = g(torch.randn(N1, K1, generator=gen) / K1 ** 0.5), g(torch.randn(N2, N1, generator=gen) / N1 ** 0.5)
+    rowbias, b2 = g(torch.randn(B, N1, generator=gen)), g(torch.randn(N2, generator=gen))
+    res1 = g(torch.randn(M, N1, generator=gen))
+    wide = g(torch.randn(M, 9 * N1, generator=gen))                 # res2 = the layer's own STE block: a column slice of its projection
+    res2 = wide[:, 8 * N1:] if bn else None
+    scale, shift = (g(torch.rand(N1, generator=gen) + 0.5), g(torch.randn(N1, generator=gen))) if bn else (None, None)
+    Ap = ops.planes_split(A, K=K1)
+    W1p, W2p = ops.planes_w(W1), ops.planes_w(W2)
+    # the two launches, as engine.surface_layer / hs_layer issue them
+    big = torch.full((M, 2 * N1 + 16), 7.0, device=DEV)             # c1 is a column slice of a wider buffer
+    c1_ref = big[:, 16:16 + N1]
+    p_ref = ops.Planes(M, 2 * N1, DEV)
+    ops.linear_rows(A, W1, out=c1_ref, rowbias=rowbias, rows_per_obj=n, res1=res1, res2=res2, scale=scale, shift=shift,
+                    act=1, slope=0.0, a_planes=Ap, w_planes=W1p, c_planes=p_ref, cp_col0=N1, w_split=ops.split_w(W1))
+    c2_ref = ops.linear_rows(c1_ref.contiguous(), W2, bias=b2, a_planes=ops.planes_split(c1_ref.contiguous()), w_planes=W2p, w_split=ops.split_w(W2))
+    # the fused pair
+    units = ops.hs_chain_pack(W1, W2)
+    assert units is not None
+    big2 = torch.full((M, 2 * N1 + 16), 7.0, device=DEV)
+    c1 = big2[:, 16:16 + N1]
+    pl = ops.Planes(M, 2 * N1, DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    c2 = ops.hs_chain(Ap, units, c1, b2, flag, rowbias=rowbias, rows_per_obj=n, res1=res1, res2=res2, scale1=scale, shift1=shift, relu=True,
+                      c1_planes=pl, c1_col0=N1)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    assert torch.equal(big2, big)                                   # c1, and nothing around it
+    assert torch.equal(c2, c2_ref)
+    rows_ok = (torch.arange(pl.buf.shape[0] * 32, device=DEV) < M).view(-1, 1, 1, 1, 32, 1)
+    kt0 = N1 // 16
+    a_, b_ = pl.buf.view(-1, pl.kt, 2, 2, 32, 16)[:, kt0:], p_ref.buf.view(-1, pl.kt, 2, 2, 32, 16)[:, kt0:]
+    assert bool(((a_ == b_) | ~rows_ok).all())
+    assert torch.equal(pl.amax, p_ref.amax)
+    # out of fp16's range: the flag
+    flag.zero_()
+    ops.hs_chain(ops.planes_split(A * 1e6, K=K1), units, c1, b2, flag, rowbias=rowbias, rows_per_obj=n, res1=res1, res2=res2, scale1=scale,
+                 shift1=shift, relu=True)
+    assert int(flag.item()) == 1
+
+
 def test_gemm_pp_gathered_residuals_bit_identical(ops):
     """the factored layers' epilogue (gathered coarse products + per-object bias + max over points) on the pre-split kernel"""
     gen = torch.Generator().manual_seed(78)
@@ -3730,6 +3782,41 @@ def test_forward_on_planes_bit_identical_to_forward_without(ops, B, N):
             assert torch.equal(got[0][k], got[2][k]), k
     scale = (got[2]["recon"] - g(pts).mean(1, keepdim=True)).abs().max().item()
     assert (got[0]["recon"] - got[2]["recon"]).abs().max().item() <= 2e-6 * max(1.0, scale)
+
+
+@pytest.mark.parametrize("B,N", [(8, 1028), (3, 1028)])
+def test_forward_with_chained_layer_tails_bit_identical(ops, B, N):
+    """engine.HS_CHAIN: conv_0's / conv_2's last GEMM together with the next layer's projection (tgp_hs_chain, a forward without
+    side branches) against the same forward with the launches apart: every output, the reconstruction and the PH codes bit for bit;
+    the kernel's flags stay 0.  B = 8: both pairs chained; B = 3: conv_2's pair has too few rows for the tile kernels and stays apart."""
+    from tgpose_amd import FLAGS, engine
+    net = _net(12)
+    FLAGS.train = 0
+    pts, obj = synth_points(B, N, 41)
+    torch.manual_seed(7)
+    i1 = torch.randperm(N)[: N // 4]
+    smp = (i1, torch.randperm(N // 4)[: N // 16])
+    pk = net.packed(DEV)
+    assert pk.chains[0] is not None and pk.chains[1] is not None
+    got, calls = [], []
+    real = ops.hs_chain
+    old = engine.HS_CHAIN, engine.BRANCH_STREAMS
+    try:
+        flags = []
+        ops.hs_chain = lambda *a, **k: (calls.append(a[1].tgp_shape), flags.append(a[4]), real(*a, **k))[2]
+        for on in (True, False):
+            engine.HS_CHAIN, engine.BRANCH_STREAMS = on, False
+            probe = {}
+            with torch.no_grad():
+                out = engine.posenet_forward(pk, g(pts), g(obj), False, sample_idx=smp, probe=probe)
+            got.append({k: v.clone() for k, v in list(out.items()) + [(k, probe[k]) for k in ("recon", "h1", "h2")]})
+            assert all(int(f.item()) == 0 for f in flags)
+    finally:
+        ops.hs_chain = real
+        engine.HS_CHAIN, engine.BRANCH_STREAMS = old
+    assert calls == ([(132, 128, 1152), (256, 256, 2304)] if B == 8 else [(132, 128, 1152)])
+    for k in got[0]:
+        assert torch.equal(got[0][k], got[1][k]), k
 
 
 @pytest.mark.parametrize("B,n,C,k,with_xyz", [(3, 1028, 128, 20, True), (2, 257, 256, 20, False), (4, 64, 512, 8, False), (2, 100, 128, 12, True)])

@@ -98,6 +98,25 @@ class DecFusedArgs(ctypes.Structure):
     ]
 
 
+class HsChainArgs(ctypes.Structure):
+    """struct tgp_hs_chain_args (include/tgpose.h)"""
+    _fields_ = [
+        ("a_planes", c_vp), ("a_kt", c_int), ("a_amax", c_vp),
+        ("M", c_int), ("K1", c_int), ("N1", c_int), ("N2", c_int),
+        ("units", c_vp),
+        ("rowbias", c_vp), ("ldrb", c_int), ("rows_per_obj", c_int),
+        ("res1", c_vp), ("ldr1", c_int),
+        ("res2", c_vp), ("ldr2", c_int),
+        ("scale1", c_vp), ("shift1", c_vp),
+        ("relu", c_int),
+        ("c1", c_vp), ("ldc1", c_int),
+        ("c1_planes", c_vp), ("c1_kt", c_int), ("c1_kt0", c_int), ("c1_amax", c_vp),
+        ("bias2", c_vp),
+        ("c2", c_vp), ("ldc2", c_int),
+        ("flag", c_vp),
+    ]
+
+
 class DecL1Args(ctypes.Structure):
     """struct tgp_dec_l1_args (include/tgpose.h)"""
     _fields_ = [
@@ -211,6 +230,9 @@ SIGNATURES = {
     "tgp_heads_pack_w2": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "tgp_heads_w2_bytes": (c_i64, [c_int]),
     "tgp_dec_fused": (c_int, [ctypes.POINTER(DecFusedArgs), c_vp]),
+    "tgp_hs_chain": (c_int, [ctypes.POINTER(HsChainArgs), c_vp]),
+    "tgp_hs_chain_pack_bytes": (c_i64, [c_int, c_int, c_int]),
+    "tgp_hs_chain_pack": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
     "tgp_dec_pack_bytes": (c_i64, []),
     "tgp_dec_pack": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "tgp_dec_l1": (c_int, [ctypes.POINTER(DecL1Args), c_vp]),

@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["knn.hip", "gemm.hip", "gemm_pp.hip", "gconv.hip", "chamfer.hip", "dcd.hip", "bn.hip", "backward.hip", "gconv_bwd.hip", "evalmetrics.hip", "tdaloss.hip", "inputside.hip", "rowsort.hip", "heads_fused.hip", "dec_fused.hip", "segsum.hip", "graph_bwd.hip", "poserot.hip", "gemm_tn_split.hip", "version.hip"]
+SOURCES = ["knn.hip", "gemm.hip", "gemm_pp.hip", "gconv.hip", "chamfer.hip", "dcd.hip", "bn.hip", "backward.hip", "gconv_bwd.hip", "evalmetrics.hip", "tdaloss.hip", "inputside.hip", "rowsort.hip", "heads_fused.hip", "dec_fused.hip", "hs_chain.hip", "segsum.hip", "graph_bwd.hip", "poserot.hip", "gemm_tn_split.hip", "version.hip"]
 DEV_SOURCES = ["gemm_variants.hip"]     # development build only (--dev): micro-benchmark kernels + the tgp_debug_* switches
 LIB = os.path.join(HERE, "libtgpose_hip.so")
 DEV_LIB = os.path.join(HERE, "libtgpose_hip_dev.so")

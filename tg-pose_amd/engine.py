@@ -197,6 +197,15 @@ class Packed(object):
                                       dict(conv5=face + "ph_pred.conv_5.1", heads=[h + "." for h in HEAD_ORDER]))
                 self.fact = pack_factored(self.wide, self.dec[0])
             # the fused decoder kernel's staging image of the three inner weights (fp16 operands without a pack-time rescale)
+            # the staging images of ops.hs_chain (conv_0 / conv_2's last GEMM + the next layer's projection), when the weights lie
+            # inside fp16's range (no pack-time rescale) and the layers have the two shapes the kernel serves
+            self.chains = [None, None]
+            if ops.planes_on():
+                for i, (a, b, wk) in enumerate(((0, 1, "w1x"), (2, 3, "w1"))):
+                    ca, cb = self.conv[a], self.conv[b]
+                    pa, pb = ca.get(wk + "_p"), cb.get("wcat_p")
+                    if pa is not None and pb is not None and pa.tgp_unscale is None and pb.tgp_unscale is None and "w2t" in ca:
+                        self.chains[i] = ops.hs_chain_pack(ca[wk], cb["wcat"])
             self.dec_units = None
             if (ops.planes_on() and [tuple(d[0].shape) for d in self.dec[1:]] == [(512, 512), (256, 512), (128, 256)]
                     and tuple(self.dec_out[0].shape) == (3, 128) and all(d[5] is not None and d[5].tgp_unscale is None for d in self.dec[1:])):
@@ -319,6 +328,11 @@ HEADS_TAIL = os.environ.get("TGP_HEADS_TAIL", "0") != "0"
 DEC_PLANES_ONLY = os.environ.get("TGP_DEC_PLANES_ONLY", "1") != "0"     # the decoder's inner activations as fp16 planes only
 DEC_L1 = os.environ.get("TGP_DEC_L1", "1") != "0"           # the decoder's first conv on the fused heads kernel's conv1 half (ops.dec_l1)
 DEC_FUSED = os.environ.get("TGP_DEC_FUSED", "1") != "0"     # ... and everything behind its first conv as one launch (csrc/dec_fused.hip)
+# conv_0's / conv_2's last GEMM + the next layer's projection as one launch (csrc/hs_chain.hip, bit-identical results).  Built and measured
+# in round 5, OFF by default: alone the pairs take 71 / 70 us against 83-94 / 73-86 us as two launches, but the kernel holds its CUs
+# exclusively (one wave per SIMD, 150 KB of LDS) while it waits for its 186 MB of stores, and on the four-in-flight line the same-box A/B
+# shows no gain (21.15 k against 21.44 k objects/s, three alternating runs); it also adds two predicated launches per forward.
+HS_CHAIN = os.environ.get("TGP_HS_CHAIN", "0") != "0"
 REPAIR_OBJS = 16        # objects per chunk of the fused heads kernel's fp16-range repair (wide_gemm_factored)
 
 
@@ -370,7 +384,43 @@ class Graphs(object):
         return idx
 
 
-def surface_layer(c, xyz, idx_rf, idx_orl, out, scale=None, shift=None, act=None, out_p=None, amax_ws=None, tickets=None):
+def _chain_ok(chain, gp, out_p, M, act):
+    """may this layer's last GEMM run together with the next layer's projection (ops.hs_chain)?  Only in a forward without side
+    branches (with them the projection runs beside the feature-space kNN, which needs this layer's output first), on planes, with the
+    weights inside fp16's range, and for row counts at which BOTH launches it replaces run on the tile kernels -- it computes their
+    bits, not the exact-fp32 small kernel's."""
+    if chain is None or not HS_CHAIN or BRANCH_STREAMS or gp is None or out_p is None or chain.get("units") is None or act is None:
+        return False
+    _, N1, N2 = chain["units"].tgp_shape
+    return ops._routes_to_big_tile(M, N1, 1, True) and ops._routes_to_big_tile(M, N2, 1, True)
+
+
+def _layer_tail_chained(chain, x, w, last, col0):
+    """the layer's last GEMM (`last`: its ops.linear_rows arguments) + the next layer's projection in one launch; the two launches
+    follow predicated on the kernel's fp16-range flag (they normally return at once).  Leaves the projection in chain["proj9"]."""
+    nxt, flag = chain["next"], chain["flag"]
+    out = last["out"]
+    B, n = out.shape[0], out.shape[1]
+    proj9 = torch.empty(B, n, nxt["wcat"].shape[0], device=out.device, dtype=torch.float32)
+    ops.hs_chain(last["a_planes"], chain["units"], out, nxt["bcat"], flag, rowbias=last["rowbias"], rows_per_obj=last["rows_per_obj"],
+                 res1=last["res1"], res2=last.get("res2"), scale1=last["scale"], shift1=last["shift"], relu=True, c1_planes=last["c_planes"],
+                 c1_col0=col0, c2=proj9.view(B * n, -1))
+    ops.linear_rows(x, w, pred=flag, **last)
+    ops.linear_rows(out, nxt["wcat"], bias=nxt["bcat"], out=proj9, w_split=nxt.get("wcat_s"), a_planes=_cols_view(last["c_planes"], col0, out.shape[-1]),
+                    w_planes=nxt.get("wcat_p"), pred=flag)
+    chain["proj9"] = proj9
+    return out
+
+
+def _cols_view(pl, col0, K):
+    """the planes of columns [col0, col0 + K) of a wider planes buffer as the consumer sees them (same buffer and magnitude words; the
+    projection reads the first K columns when col0 == 0)"""
+    if col0 != 0:
+        raise ValueError("chained layers write their planes at column 0 of the next layer's operand")
+    return pl
+
+
+def surface_layer(c, xyz, idx_rf, idx_orl, out, scale=None, shift=None, act=None, out_p=None, amax_ws=None, tickets=None, chain=None):
     """HSlayer_surface.forward (gcn3d.py:78-89) + the caller's activation, written to `out` (B,n,C) view (and, out_p, as the fp16
     planes the next layer's projection GEMM stages by LDS-DMA)."""
     B, n, _ = xyz.shape
@@ -387,9 +437,11 @@ def surface_layer(c, xyz, idx_rf, idx_orl, out, scale=None, shift=None, act=None
     else:
         rb = ops.orl_rowbias(g, idx_orl, c["w2t"], tickets=tickets) if "w2t" in c else ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
     # conv2(cat[g, global]) + g + STE(xyz) (gcn3d.py:87-89,108-112): W1 g + STE xyz is one product over the padded row
-    ops.linear_rows(gx, c["w1x"], out=out, rowbias=rb, rows_per_obj=n, res1=g, scale=scale, shift=shift,
-                    act=0 if act is None else 1, slope=0.0, w_split=c.get("w1x_s"), k_alg=C + 3, c_planes=out_p,
-                    a_planes=gp, w_planes=c.get("w1x_p") if gp is not None else None)
+    last = dict(out=out, rowbias=rb, rows_per_obj=n, res1=g, scale=scale, shift=shift, act=0 if act is None else 1, slope=0.0,
+                w_split=c.get("w1x_s"), k_alg=C + 3, c_planes=out_p, a_planes=gp, w_planes=c.get("w1x_p") if gp is not None else None)
+    if _chain_ok(chain, gp, out_p, B * n, act):
+        return _layer_tail_chained(chain, gx, c["w1x"], last, 0)
+    ops.linear_rows(gx, c["w1x"], **last)
     return out
 
 
@@ -413,7 +465,7 @@ def _beside(device, fn, tag="knn"):
 
 
 def hs_layer(c, xyz, fmap, idx_rf, idx_orl, out, scale=None, shift=None, act=None, fmap_p=None, out_p=None, out_col0=0, amax_ws=None,
-             tickets=None):
+             tickets=None, chain=None, proj9=None):
     """HS_layer.forward (gcn3d.py:142-155) + the caller's BatchNorm(eval)/ReLU, written to `out`.
     idx_rf / idx_orl may be callables: they are then evaluated on a side stream (the feature-space kNN -- distance GEMM +
     selection -- and the level's xyz kNN depend only on the layer's inputs) while this stream runs the projection GEMM."""
@@ -433,7 +485,8 @@ def hs_layer(c, xyz, fmap, idx_rf, idx_orl, out, scale=None, shift=None, act=Non
             idx_rf, dirs, idx_orl = lists()
     # (B,n,9C): centre|support|STE.  fmap_p: the input's fp16 planes, written by its producer -- the GEMM then runs on the
     # pre-split kernel (csrc/gemm_pp.hip), bit-identical results
-    proj9 = ops.linear_rows(fmap, c["wcat"], bias=c["bcat"], w_split=c.get("wcat_s"), a_planes=fmap_p, w_planes=c.get("wcat_p"))
+    if proj9 is None:         # (else: computed with the previous layer's last GEMM, ops.hs_chain)
+        proj9 = ops.linear_rows(fmap, c["wcat"], bias=c["bcat"], w_split=c.get("wcat_s"), a_planes=fmap_p, w_planes=c.get("wcat_p"))
     if join is not None:
         torch.cuda.current_stream(xyz.device).wait_event(join)
     g = ops.gconv_hs(xyz, idx_rf, proj9, c["sdn"], 7, C, dirs=dirs)
@@ -444,9 +497,12 @@ def hs_layer(c, xyz, fmap, idx_rf, idx_orl, out, scale=None, shift=None, act=Non
         rb, gp = ops.orl_rowbias(g, idx_orl, c["w2t"], planes=ops.Planes(B * n, C, xyz.device, amax_buf=amax_ws), tickets=tickets)
     else:
         rb = ops.orl_rowbias(g, idx_orl, c["w2t"], tickets=tickets) if "w2t" in c else ops.linear_rows(ops.orl_global(g, idx_orl), c["w2"])
-    ops.linear_rows(g, c["w1"], out=out, rowbias=rb, rows_per_obj=n, res1=g, res2=proj9[:, :, 8 * C:], scale=scale,
-                    shift=shift, act=0 if act is None else 1, slope=0.0, w_split=c.get("w1_s"), c_planes=out_p, cp_col0=out_col0,
-                    a_planes=gp, w_planes=c.get("w1_p") if gp is not None else None)
+    last = dict(out=out, rowbias=rb, rows_per_obj=n, res1=g, res2=proj9[:, :, 8 * C:], scale=scale, shift=shift,
+                act=0 if act is None else 1, slope=0.0, w_split=c.get("w1_s"), c_planes=out_p, cp_col0=out_col0, a_planes=gp,
+                w_planes=c.get("w1_p") if gp is not None else None)
+    if _chain_ok(chain, gp, out_p, B * n, act):
+        return _layer_tail_chained(chain, g, c["w1"], last, out_col0)
+    ops.linear_rows(g, c["w1"], **last)
     return out
 
 
@@ -475,12 +531,17 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, 
     # magnitudes (the consumers' fp16 range guard) live in the forward's arena, zeroed by its one fill.
     pl = arena.planes(B, N, N1, N2) if (arena is not None and factored and ops.planes_on()) else {}
     fm0 = feat[:, :, 0:128]
+    # (round 5) conv_0's and conv_2's last GEMM run together with the next layer's projection when the forward has no side branches
+    chains = getattr(pk, "chains", [None, None]) if (pl and arena is not None) else [None, None]
+    ch01 = dict(units=chains[0], next=cv[1], flag=arena.chain_flags[0]) if chains[0] is not None else None
+    ch23 = dict(units=chains[1], next=cv[3], flag=arena.chain_flags[1]) if chains[1] is not None else None
     surface_layer(cv[0], xyz, graphs.get("conv_0.rf", lambda: xyz_graph(0, xyz, kmax)),
-                  graphs.get("conv_0.orl_xyz", lambda: xyz_graph(0, xyz, kmax)), fm0, act="relu", out_p=pl.get("fm0"), amax_ws=pl.get("amax_g0"), tickets=pl.get("tick0"))
+                  graphs.get("conv_0.orl_xyz", lambda: xyz_graph(0, xyz, kmax)), fm0, act="relu", out_p=pl.get("fm0"), amax_ws=pl.get("amax_g0"), tickets=pl.get("tick0"),
+                  chain=ch01)
     fm1 = feat[:, :, 128:256]
     hs_layer(cv[1], xyz, fm0, lambda: graphs.get("conv_1.rf", lambda: ops.knn_feat(fm0, kmax)),
              graphs.get("conv_1.orl_xyz", lambda: xyz_graph(0, xyz, kmax)), fm1, cv[1]["scale"], cv[1]["shift"], "relu",
-             fmap_p=pl.get("fm0"), amax_ws=pl.get("amax_g1"), tickets=pl.get("tick1"))
+             fmap_p=pl.get("fm0"), amax_ws=pl.get("amax_g1"), tickets=pl.get("tick1"), proj9=(ch01 or {}).get("proj9"))
     v1, fp1 = ops.pool(xyz, fm1, graphs.get("pool_1.xyz", lambda: xyz_graph(0, xyz, kmax)), s1, kpool=4, planes=pl.get("fp1"))
 
     k1 = min(kmax, N1 // 8)
@@ -495,11 +556,12 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, 
 
     hs_layer(cv[2], v1, fp1, lambda: feat_graph("conv_2.rf", fp1, k1, v1),
              lambda: graphs.get("conv_2.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm2, cv[2]["scale"], cv[2]["shift"], "relu",
-             fmap_p=pl.get("fp1"), out_p=pl.get("fm23"), out_col0=0, amax_ws=pl.get("amax_g2"), tickets=pl.get("tick2"))
+             fmap_p=pl.get("fp1"), out_p=pl.get("fm23"), out_col0=0, amax_ws=pl.get("amax_g2"), tickets=pl.get("tick2"), chain=ch23)
     # (conv_3 reads the first 256 columns of the fm_2 | fm_3 planes, whose per-block magnitudes cover fm_2 alone at this point)
     hs_layer(cv[3], v1, fm2, lambda: feat_graph("conv_3.rf", fm2, k1, v1),
              graphs.get("conv_3.orl_xyz", lambda: xyz_graph(1, v1, k1)), fm3, cv[3]["scale"], cv[3]["shift"], "relu",
-             fmap_p=pl.get("fm23"), out_p=pl.get("fm23"), out_col0=256, amax_ws=pl.get("amax_g3"), tickets=pl.get("tick3"))
+             fmap_p=pl.get("fm23"), out_p=pl.get("fm23"), out_col0=256, amax_ws=pl.get("amax_g3"), tickets=pl.get("tick3"),
+             proj9=(ch23 or {}).get("proj9"))
     v2, fp2 = ops.pool(v1, fm3, graphs.get("pool_2.xyz", lambda: xyz_graph(1, v1, k1)), s2, kpool=4, planes=pl.get("fp2"))
 
     P1 = P1_join = None
@@ -577,6 +639,7 @@ class Arena(object):
         self.over5 = buf[n5 + n2:n5 + n2 + 1]
         self.over2 = buf[n5 + n2 + 4:n5 + n2 + 5]
         self.dec_flag = buf[n5 + n2 + 6:n5 + n2 + 7]              # the planes-only decoder chain's range flag
+        self.chain_flags = (buf[n5 + n2 + 1:n5 + n2 + 2], buf[n5 + n2 + 2:n5 + n2 + 3])      # ops.hs_chain's (conv_0 -> conv_1, conv_2 -> conv_3)
         self.back = buf[n5 + n2 + 8:n5 + n2 + 8 + nb].view(torch.float32).view(B, FEAT_LD)
         self.amax = buf[n5 + n2 + 8 + nb:]
         self._pl = None

@@ -592,7 +592,7 @@ def gemm(A, W, C=None, *, M=None, N=None, K=None, lda=None, ldw=None, ldc=None, 
 
 def linear_rows(x, weight, bias=None, scale=None, shift=None, act=0, slope=0.0, out=None, rowbias=None,
                 rows_per_obj=0, res1=None, res2=None, colmax_keys=None, want_out=True, k_alg=None, w_split=None,
-                a_scale=None, c_scale=None, flops_ref=None, a_planes=None, w_planes=None, c_planes=None, cp_col0=0):
+                a_scale=None, c_scale=None, flops_ref=None, a_planes=None, w_planes=None, c_planes=None, cp_col0=0, pred=None):
     """x (..., K) rows (row stride >= K), weight (N, Kw>=K) -> (..., N).  Convenience over gemm()."""
     x, lda = _rows(x, "x")
     weight, ldw = _rows(weight, "weight")
@@ -613,7 +613,7 @@ def linear_rows(x, weight, bias=None, scale=None, shift=None, act=0, slope=0.0, 
     gemm(x, weight, out if want_out else None, M=M, N=N, K=K, lda=lda, ldw=ldw, ldc=ldc, bias=bias, rowbias=rowbias,
          rows_per_obj=rows_per_obj, res1=r1, ldr1=l1, res2=r2, ldr2=l2, scale=scale, shift=shift, act=act, slope=slope,
          colmax_keys=colmax_keys, k_alg=k_alg, w_split=w_split, a_scale=a_scale, c_scale=c_scale, flops_ref=flops_ref,
-         a_planes=a_planes, w_planes=w_planes, c_planes=c_planes, cp_col0=cp_col0)
+         a_planes=a_planes, w_planes=w_planes, c_planes=c_planes, cp_col0=cp_col0, pred=pred)
     return out
 
 
@@ -703,6 +703,64 @@ def dec_pack(w2, w3, w4, h1_permuted=False):
                                   _stream(w2)), "tgp_dec_pack")
     out.tgp_h1_permuted = bool(h1_permuted)
     return out
+
+
+def hs_chain_pack(w1, w2):
+    """W1 (N1, K1) of an HS layer's last GEMM and W2 (N2, N1) of the next layer's projection -> the fused pair's staging image
+    (tgp_hs_chain_pack); None for shapes the kernel does not serve"""
+    (N1, K1), (N2, k2) = w1.shape, w2.shape
+    nbytes = _lib.lib().tgp_hs_chain_pack_bytes(int(K1), int(N1), int(N2)) if k2 == N1 else -1
+    if nbytes < 0:
+        return None
+    w1, w2 = w1.contiguous(), w2.contiguous()
+    out = torch.empty(nbytes, device=w1.device, dtype=torch.uint8)
+    check(_lib.lib().tgp_hs_chain_pack(_p(w1), K1, K1, N1, _p(w2), N1, N2, _p(out), _stream(w1)), "tgp_hs_chain_pack")
+    out.tgp_shape = (int(K1), int(N1), int(N2))
+    return out
+
+
+def hs_chain(a_planes, units, c1, bias2, flag, rowbias=None, rows_per_obj=0, res1=None, res2=None, scale1=None, shift1=None, relu=True,
+             c1_planes=None, c1_col0=0, c2=None):
+    """c1 = act(bn(A W1^T + rowbias[object] + res1 + res2)), c2 = c1 W2^T + bias2 in ONE launch (tgp_hs_chain): an HS layer's last
+    GEMM and the next layer's projection.  a_planes: Planes of A (M rows); units: hs_chain_pack(W1, W2); c1 (M, N1) view (row stride
+    = its .stride(-2)), written; c1_planes: Planes that also receive c1 from K-column c1_col0; c2 (M, N2) (allocated when None); flag:
+    (1,) int32 zeroed by the caller, raised when the fp16 split's range is left -- the caller's two tile-kernel launches must follow,
+    predicated on it.  Returns c2."""
+    K1, N1, N2 = units.tgp_shape
+    M = a_planes.rows
+    c1r, ldc1 = _rows(c1, "c1")
+    if c2 is None:
+        c2 = torch.empty(M, N2, device=c1.device, dtype=torch.float32)
+    timed = GEMM_TIMER is not None
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(c1.device))
+    a = _lib.HsChainArgs()
+    a.a_planes, a.a_kt, a.a_amax = _p(a_planes.buf), a_planes.kt, _p(a_planes.amax)
+    a.M, a.K1, a.N1, a.N2 = M, K1, N1, N2
+    a.units = _p(units)
+    if rowbias is not None:
+        a.rowbias, a.ldrb, a.rows_per_obj = _p(rowbias), rowbias.stride(0), rows_per_obj
+    if res1 is not None:
+        res1, a.ldr1 = _rows(res1, "res1")
+        a.res1 = _p(res1)
+    if res2 is not None:
+        res2, a.ldr2 = _rows(res2, "res2")
+        a.res2 = _p(res2)
+    a.scale1, a.shift1, a.relu = _p(scale1), _p(shift1), int(bool(relu))
+    a.c1, a.ldc1 = _p(c1r), ldc1
+    if c1_planes is not None:
+        if c1_col0 % 16:
+            raise ValueError("hs_chain: c1_col0 must be a multiple of 16")
+        a.c1_planes, a.c1_kt, a.c1_kt0, a.c1_amax = _p(c1_planes.buf), c1_planes.kt, c1_col0 // 16, _p(c1_planes.amax)
+    a.bias2, a.c2, a.ldc2, a.flag = _p(bias2), _p(c2), c2.stride(-2), _p(flag)
+    check(_lib.lib().tgp_hs_chain(ctypes.byref(a), _stream(c1)), "tgp_hs_chain")
+    if timed:
+        e1.record(torch.cuda.current_stream(c1.device))
+        nb = 4.0 * (M * 16 * a_planes.kt + M * N1 * (2 + (res1 is not None) + (res2 is not None)) + M * N2 + N1 * K1 + N2 * N1)
+        fl = 2.0 * M * (N1 * K1 + N2 * N1)
+        GEMM_TIMER.append((e0, e1, fl, (M, N1 + N2, K1, 1), fl, nb, "fused"))
+    return c2
 
 
 def dec_l1(fine_planes, wa_planes, p1, idx1, p2, idx2, bias, scale, shift, rowbias, rows_per_obj, h1_planes, flag, k_alg=None):
