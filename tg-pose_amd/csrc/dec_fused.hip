@@ -328,6 +328,7 @@ struct DecL1Params {
     const float *rowbias; int ldrb, rows_per_obj;      // (may be NULL) per-object bias (B, 512)
     char *h1_pl; int h1_kt; uint32_t *h1_amax;          // out: the activation as planes in accumulator order, its magnitude words
     int *flag;
+    int knob;                              // (development build) timing-only variants: 1 = no stores, 2 = no gathers
     int M, tiles;
     int main_tiles;                        // tiles [0, main_tiles) are one workgroup each; the others one workgroup per 32-channel block
 };
@@ -401,13 +402,14 @@ __global__ __launch_bounds__(256, 1) void dec_l1_kernel(DecL1Params p)
     float amax = 0.f;
     auto gather1 = [&](DlG &d, const int cb, const int i) {              // i = 0 .. 11: one 16-byte load
         const int m = i & 3, which = i >> 2;
+        if (p.knob & 2) return;
         if (which == 0) d.g1[m] = *reinterpret_cast<const float4 *>(g1p + cb * 32 + 8 * m);
         else if (which == 1) d.g2[m] = *reinterpret_cast<const float4 *>(g2p + cb * 32 + 8 * m);
         else d.rb[m] = rbp ? *reinterpret_cast<const float4 *>(rbp + cb * 32 + 8 * m) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto store1 = [&](const uint32_t (&a)[16], const int cb, const int i) {   // i = 0 .. 3: (K-tile of the block, plane)
         const int s2 = i >> 1, plane = i & 1;
-        if (m0 >= p.M) return;
+        if (m0 >= p.M || (p.knob & 1)) return;
         *reinterpret_cast<uint4 *>(h1 + ((2 * cb + s2) * 2 + plane) * 1024) =
             make_uint4(a[plane * 8 + s2 * 4], a[plane * 8 + s2 * 4 + 1], a[plane * 8 + s2 * 4 + 2], a[plane * 8 + s2 * 4 + 3]);
     };
@@ -523,6 +525,11 @@ __global__ __launch_bounds__(256, 1) void dec_l1_kernel(DecL1Params p)
     }
 }
 
+#ifdef TGP_DEV
+static int tgp_dec_l1_knobs = 0;
+extern "C" int tgp_debug_set_dec_l1_knobs(int v) { tgp_dec_l1_knobs = v; return 0; }
+#endif
+
 extern "C" int tgp_dec_l1(const tgp_dec_l1_args *a, tgp_stream_t stream)
 {
     TGP_REQUIRE(a && a->fine_planes && a->wa_planes && a->p1 && a->p2 && a->idx1 && a->idx2 && a->bias && a->scale && a->shift &&
@@ -539,6 +546,10 @@ extern "C" int tgp_dec_l1(const tgp_dec_l1_args *a, tgp_stream_t stream)
     p.rowbias = a->rowbias, p.ldrb = a->ldrb, p.rows_per_obj = a->rows_per_obj > 0 ? a->rows_per_obj : a->M;
     p.h1_pl = reinterpret_cast<char *>(a->h1_planes), p.h1_kt = a->h1_kt, p.h1_amax = a->h1_amax;
     p.flag = a->flag, p.M = a->M, p.tiles = tgp_cdiv(a->M, 128);
+    p.knob = 0;
+#ifdef TGP_DEV
+    p.knob = tgp_dec_l1_knobs;
+#endif
     // a few tiles past a whole number of rounds (one workgroup per CU) go in single channel blocks
     static int cus = 0;
     if (!cus) {
