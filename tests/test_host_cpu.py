@@ -85,6 +85,17 @@ def test_fused_kernel_arg_structs_match_header_layout():
     H, C = _lib.HeadsFusedArgs, _lib.ConvMaxFusedArgs
     assert out == [ctypes.sizeof(H), H.idx2.offset, H.keys.offset, H.overflow.offset,
                    ctypes.sizeof(C), C.idx2.offset, C.slope.offset, C.overflow.offset]
+    # (ABI 7) the decoder's and the chained layer tails' structs: every field's offset
+    names = (("tgp_dec_fused_args", _lib.DecFusedArgs), ("tgp_dec_l1_args", _lib.DecL1Args), ("tgp_hs_chain_args", _lib.HsChainArgs))
+    fields = [(cn, f[0]) for cn, cls in names for f in cls._fields_]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "tgpose.h"\nint main(){' + "".join(
+        'printf("%%zu ", offsetof(%s, %s));' % cf for cf in fields) + "".join('printf("%%zu ", sizeof(%s));' % cn for cn, _ in names) + "return 0;}\n"
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        out = [int(x) for x in subprocess.check_output([os.path.join(d, "t")]).decode().split()]
+    want = [getattr(cls, f[0]).offset for _, cls in names for f in cls._fields_] + [ctypes.sizeof(cls) for _, cls in names]
+    assert out == want
 
 
 def test_state_dict_contract_matches_reference_checkpoint_names():
