@@ -3819,6 +3819,46 @@ def test_forward_with_chained_layer_tails_bit_identical(ops, B, N):
         assert torch.equal(got[0][k], got[1][k]), k
 
 
+def test_forward_with_chained_layer_tails_range_guard(ops):
+    """conv_0 scaled so that fm_0 leaves fp16's range: tgp_hs_chain raises its flag and the two tile-kernel launches, predicated on
+    it, rewrite fm_0 and conv_1's projection with their own per-tile guards -- the forward equals, bit for bit, the one with the
+    launches apart (every output finite)."""
+    from tgpose_amd import FLAGS, PoseNet9D, seeded_state_dict, engine
+    sd = seeded_state_dict(15)
+    w = sd["face_all.encoder.conv_0.conv2.weight"]                # as large as a weight may be without a pack-time rescale (2^15)
+    sd["face_all.encoder.conv_0.conv2.weight"] = w * (30000.0 / float(w.abs().max()))
+    net = PoseNet9D()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    FLAGS.train = 0
+    B, N = 8, 1028
+    pts, obj = synth_points(B, N, 43)
+    torch.manual_seed(8)
+    i1 = torch.randperm(N)[: N // 4]
+    smp = (i1, torch.randperm(N // 4)[: N // 16])
+    pk = net.packed(DEV)
+    assert pk.chains[0] is not None
+    got, flags = [], []
+    real = ops.hs_chain
+    old = engine.HS_CHAIN, engine.BRANCH_STREAMS
+    try:
+        ops.hs_chain = lambda *a, **k: (flags.append((a[1].tgp_shape, a[4])), real(*a, **k))[1]
+        for on in (True, False):
+            engine.HS_CHAIN, engine.BRANCH_STREAMS = on, False
+            probe = {}
+            with torch.no_grad():
+                out = engine.posenet_forward(pk, g(pts), g(obj), False, sample_idx=smp, probe=probe)
+            got.append({k: v.clone() for k, v in list(out.items()) + [(k, probe[k]) for k in ("recon", "h1", "h2")]})
+    finally:
+        ops.hs_chain = real
+        engine.HS_CHAIN, engine.BRANCH_STREAMS = old
+    raised = {shape: int(f.item()) for shape, f in flags}
+    assert raised[(132, 128, 1152)] == 1, raised
+    for k in got[0]:
+        assert torch.isfinite(got[0][k]).all(), k
+        assert torch.equal(got[0][k], got[1][k]), k
+
+
 @pytest.mark.parametrize("B,n,C,k,with_xyz", [(3, 1028, 128, 20, True), (2, 257, 256, 20, False), (4, 64, 512, 8, False), (2, 100, 128, 12, True)])
 def test_orl_rowbias_planes_equal_split_of_the_table(ops, B, n, C, k, with_xyz):
     """tgp_orl_rowbias_planes: the ORL pooling's LDS-staged table leaves as the fp16 planes of the layer's last GEMM operand (one
