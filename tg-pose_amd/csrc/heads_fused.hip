@@ -319,8 +319,11 @@ __global__ __launch_bounds__(256, 1) void heads_fused_kernel(HeadsParams p)
         }
     };
 
-    __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0): this wave's DMA has landed
-    __syncthreads();
+    // this wave's DMA pieces have landed when at most the 34 fragment loads issued after them (and what followed) are in flight: block 0's
+    // conv1 starts on the fragments that have arrived (the compiler's own waits cover each first use) instead of behind the last of them
+    if constexpr (PLANES) __builtin_amdgcn_s_waitcnt(0x0f70 | (34 & 15) | ((34 >> 4) << 14));
+    else __builtin_amdgcn_s_waitcnt(0x0f70);
+    __builtin_amdgcn_s_barrier();
     const unsigned long long t_pro = HP_T();
 
     // iteration 0: conv1 of block 0, gathers of block 0, the whole unit 0 (no conv2 to spread it through)
