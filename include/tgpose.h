@@ -730,6 +730,25 @@ int64_t tgp_hs_chain_pack_bytes(int K1, int N1, int N2);
 int tgp_hs_chain_pack(const float *w1, int ld1, int K1, int N1, const float *w2, int ld2, int N2, void *out, tgp_stream_t stream);
 int tgp_hs_chain(const tgp_hs_chain_args *args, tgp_stream_t stream);
 
+/* (ABI 7) C = A W^T (+ bias; NULL: none) for the projection shapes of the HS layers (gcn3d.py:170: K = 128 or 256, N % 128 == 0, e.g.
+ * N = 9 x width) and the coarse products of the factored wide layers (K = 512),
+ * csrc/hs_chain.hip hs_proj_kernel: the operand from its planes (a_planes / a_kt / a_amax as tgp_gemm_args.A_planes), a workgroup keeps
+ * its 128 rows' fragments for all columns and streams the weights (units = tgp_proj_pack(W (N, K))) once.  Same bits as tgp_gemm_f32 on
+ * the same planes, except in a 128-row tile that the fp16 range rule (a magnitude >= 65504 / NaN, or nothing >= 2^-4) sends to the exact
+ * path: computed here from a (M, K, row stride lda) and w (N, K, ldw) by fp32 fma chains in ascending k.  a / w may be NULL when a_amax is. */
+typedef struct tgp_proj_planes_args {
+    const void *a_planes; int a_kt; const uint32_t *a_amax;
+    const float *a; int lda;
+    int M; int K; int N;
+    const void *units;
+    const float *w; int ldw;
+    const float *bias;
+    float *c; int ldc;
+} tgp_proj_planes_args;
+int64_t tgp_proj_pack_bytes(int K, int N);
+int tgp_proj_pack(const float *w, int ld, int K, int N, void *out, tgp_stream_t stream);
+int tgp_proj_planes(const tgp_proj_planes_args *args, tgp_stream_t stream);
+
 /* (ABI 7) The decoder behind its first conv as ONE kernel (FaceRecon.py:105-117 Face_Dec in eval mode: conv 512 -> 512, 512 -> 256,
  * 256 -> 128, each + BatchNorm + ReLU, then conv 128 -> 3), csrc/dec_fused.hip: a wave owns 32 points for the whole chain, no activation
  * between the layers leaves its registers.

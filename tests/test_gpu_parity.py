@@ -3699,6 +3699,41 @@ def test_hs_chain_bit_identical_to_two_tile_launches(ops, B, n, K1, N1, N2, bn):
     assert int(flag.item()) == 1
 
 
+@pytest.mark.parametrize("M,K,N", [(32896, 128, 1152), (3084, 128, 1152), (8224, 128, 2304), (8224, 256, 2304), (2048, 256, 4608), (1000, 256, 2304),
+                                   (8224, 512, 4608), (2048, 512, 4608)])
+def test_proj_planes_bit_identical_to_tile_kernel(ops, M, K, N):
+    """tgp_proj_planes (the HS layers' projection GEMM with the operand's fragments resident for all output columns,
+    csrc/hs_chain.hip) against the tile kernel on the same planes: the same bits, for the four projection shapes of Face_Enc at
+    B = 32, partial tiles, an operand that is a column slice of a wider planes buffer; a tile wholly below 2^-4 and one beyond
+    fp16's range take the exact path (fp32 fma chains here, fp32 MFMA in the tile kernel): within 1e-5 of fp64 on both."""
+    gen = torch.Generator().manual_seed(M + K + N)
+    wide = g(torch.randn(M, 2 * K, generator=gen))
+    A = wide[:, :K]                                                 # row stride 2 K, planes with 2 K / 16 K-tiles
+    W, b = g(torch.randn(N, K, generator=gen) / K ** 0.5), (g(torch.randn(N, generator=gen)) if K < 512 else None)      # (the coarse products have no bias)
+    Ap = ops.planes_split(wide, K=2 * K)
+    ref = ops.linear_rows(A, W, bias=b, a_planes=Ap, w_planes=ops.planes_w(W), w_split=ops.split_w(W))
+    units = ops.proj_pack(W)
+    assert units is not None
+    out = torch.full((M, N + 8), 7.0, device=DEV)
+    ops.proj_planes(Ap, units, b, A, W, out=out[:, :N])
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, :N], ref) and bool((out[:, N:] == 7.0).all())
+    # the exact path: rows 0-127 tiny, rows 128-255 huge
+    wide2 = wide.clone()
+    wide2[:128] *= 1e-4
+    wide2[128:256] *= 1e6
+    A2 = wide2[:, :K]
+    Ap2 = ops.planes_split(wide2, K=2 * K)
+    got = ops.proj_planes(Ap2, units, b, A2, W)
+    ref2 = ops.linear_rows(A2, W, bias=b, a_planes=Ap2, w_planes=ops.planes_w(W), w_split=ops.split_w(W))
+    want = A2.double() @ W.double().t() + (b.double() if b is not None else 0.0)
+    for lo, hi in ((0, 128), (128, 256)):
+        sc = want[lo:hi].abs().max().item()
+        assert (got[lo:hi].double() - want[lo:hi]).abs().max().item() <= 1e-5 * sc
+        assert (ref2[lo:hi].double() - want[lo:hi]).abs().max().item() <= 1e-5 * sc
+    assert torch.equal(got[256:], ref2[256:])
+
+
 def test_gemm_pp_gathered_residuals_bit_identical(ops):
     """the factored layers' epilogue (gathered coarse products + per-object bias + max over points) on the pre-split kernel"""
     gen = torch.Generator().manual_seed(78)
@@ -3840,7 +3875,10 @@ def test_forward_with_chained_layer_tails_range_guard(ops):
     assert pk.chains[0] is not None
     got, flags = [], []
     real = ops.hs_chain
-    old = engine.HS_CHAIN, engine.BRANCH_STREAMS
+    # (the projections on the tile kernel in both runs: tgp_proj_planes computes a tile beyond fp16's range by fma chains, the tile kernel
+    # by fp32 MFMAs -- both exact-fp32 paths, not the same bits; test_proj_planes_bit_identical_to_tile_kernel bounds both against fp64)
+    old = engine.HS_CHAIN, engine.BRANCH_STREAMS, engine.PROJ_KERNEL
+    engine.PROJ_KERNEL = False
     try:
         ops.hs_chain = lambda *a, **k: (flags.append((a[1].tgp_shape, a[4])), real(*a, **k))[1]
         for on in (True, False):
@@ -3851,7 +3889,7 @@ def test_forward_with_chained_layer_tails_range_guard(ops):
             got.append({k: v.clone() for k, v in list(out.items()) + [(k, probe[k]) for k in ("recon", "h1", "h2")]})
     finally:
         ops.hs_chain = real
-        engine.HS_CHAIN, engine.BRANCH_STREAMS = old
+        engine.HS_CHAIN, engine.BRANCH_STREAMS, engine.PROJ_KERNEL = old
     raised = {shape: int(f.item()) for shape, f in flags}
     assert raised[(132, 128, 1152)] == 1, raised
     for k in got[0]:

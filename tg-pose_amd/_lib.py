@@ -117,6 +117,19 @@ class HsChainArgs(ctypes.Structure):
     ]
 
 
+class ProjPlanesArgs(ctypes.Structure):
+    """struct tgp_proj_planes_args (include/tgpose.h)"""
+    _fields_ = [
+        ("a_planes", c_vp), ("a_kt", c_int), ("a_amax", c_vp),
+        ("a", c_vp), ("lda", c_int),
+        ("M", c_int), ("K", c_int), ("N", c_int),
+        ("units", c_vp),
+        ("w", c_vp), ("ldw", c_int),
+        ("bias", c_vp),
+        ("c", c_vp), ("ldc", c_int),
+    ]
+
+
 class DecL1Args(ctypes.Structure):
     """struct tgp_dec_l1_args (include/tgpose.h)"""
     _fields_ = [
@@ -231,6 +244,9 @@ SIGNATURES = {
     "tgp_heads_w2_bytes": (c_i64, [c_int]),
     "tgp_dec_fused": (c_int, [ctypes.POINTER(DecFusedArgs), c_vp]),
     "tgp_hs_chain": (c_int, [ctypes.POINTER(HsChainArgs), c_vp]),
+    "tgp_proj_planes": (c_int, [ctypes.POINTER(ProjPlanesArgs), c_vp]),
+    "tgp_proj_pack_bytes": (c_i64, [c_int, c_int]),
+    "tgp_proj_pack": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "tgp_hs_chain_pack_bytes": (c_i64, [c_int, c_int, c_int]),
     "tgp_hs_chain_pack": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
     "tgp_dec_pack_bytes": (c_i64, []),

@@ -52,6 +52,8 @@ struct HcParams {
     int *flag;
     int M, main_tiles, tiles, nsplit;
     int knob;                                                    // (development build) timing-only variants: 1 = no stores of layer 2, 2 = no stores of layer 1, 4 = no layer-2 MFMAs
+    // hs_proj_kernel only: the fp32 operands of the exact path, the layer's true K, its groups of four output blocks
+    const float *a_f32; int lda; const float *w_f32; int ldw; int K2, ngt;
 };
 
 __device__ __forceinline__ float hc_mix_lo(uint32_t hpair, float v)     // v - (float)(low half of hpair), one rounding
@@ -66,6 +68,95 @@ __device__ __forceinline__ float hc_mix_hi(uint32_t hpair, float v)     // v - (
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hpair), "v"(v));
     return d;
 }
+
+// ---- the staging-unit body shared by the kernels of this file (expects: hc_smem, lane, dma(buf, j0), u_src)
+// One staging unit = up to 32 (K-step s, output block j) pairs, q = s * NB + j, three MFMAs each (smallest terms first, as in the
+// tile kernel: W lo x A hi, W hi x A lo, W hi x A hi); gap 1: the weight fragments of pair q + 2 (+ FILL_A), gap 2: a DMA piece of
+// the next unit (NDN of them; + FILL_B), gap 3: FILL_C.  BH / BL: the points' hi / lo fragments of K-step s.
+#define HC_BODY(BUF, NQ, ACC, NB, BH, BL, NDN, WAITCNT, FILL_A, FILL_B, FILL_C)                                                       \
+    {                                                                                                                        \
+        const char *wrow = hc_smem + (BUF) * HC_BUF + lane * 16;                                                             \
+        auto wfrag = [&](int q, int plane) { return *reinterpret_cast<const uint4 *>(wrow + (q * 2 + plane) * 1024); };      \
+        uint4 wh0 = wfrag(0, 0), wl0 = wfrag(0, 1), wh1 = wfrag((NQ) > 1 ? 1 : 0, 0), wl1 = wfrag((NQ) > 1 ? 1 : 0, 1);      \
+        HC_SB();                                                                                                             \
+        _Pragma("unroll") for (int q = 0; q < (NQ); ++q) {                                                                   \
+            const int s = q / (NB), j = q % (NB);                                                                            \
+            uint4 wh2 = wh1, wl2 = wl1;                                                                                      \
+            const hc16x8 bh = BH, bl = BL;                                                                                   \
+            ACC[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hc16x8, wl0), bh, ACC[j], 0, 0, 0);           \
+            HC_SB();                                                                                                         \
+            if (q + 2 < (NQ)) wh2 = wfrag(q + 2, 0), wl2 = wfrag(q + 2, 1);                                                  \
+            FILL_A;                                                                                                          \
+            HC_SB();                                                                                                         \
+            ACC[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hc16x8, wh0), bl, ACC[j], 0, 0, 0);           \
+            HC_SB();                                                                                                         \
+            if (q < (NDN)) dma((BUF) ^ 1, q);                                                                                \
+            FILL_B;                                                                                                          \
+            HC_SB();                                                                                                         \
+            ACC[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hc16x8, wh0), bh, ACC[j], 0, 0, 0);           \
+            HC_SB();                                                                                                         \
+            FILL_C;                                                                                                          \
+            HC_SB();                                                                                                         \
+            wh0 = wh1, wl0 = wl1, wh1 = wh2, wl1 = wl2;                                                                      \
+        }                                                                                                                    \
+        _Pragma("unroll") for (int q = (NQ); q < 16; ++q)       /* (a short unit has fewer gaps than the next unit has pieces) */ \
+            if (q < (NDN)) dma((BUF) ^ 1, q);                                                                                \
+        __builtin_amdgcn_s_waitcnt(WAITCNT);    /* this wave's share of the next unit has landed (what was issued after it may fly) */ \
+        __syncthreads();                        /* ... everybody's has, and this buffer's readers are done */                \
+    }
+
+#define HC_ZERO(ACC)                                                  \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                     \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) ACC[j][e] = 0.f;
+#define HC_GROUP(GI, ACC, PREV, GU0)                                                                                              \
+    {                                                                                                                        \
+        HC_ZERO(ACC)                                                                                                         \
+        const bool have_prev = (GI) > 0;                                                                                     \
+        _Pragma("unroll") for (int w = 0; w < U2; ++w) {                                                                     \
+            const int gu = (GU0) + (GI) * U2 + w;                          /* the unit's place in this workgroup's stream */    \
+            const int ndn = ((GI) + 1 < ng || w + 1 < U2) ? 16 : 0;                                                          \
+            u_src = u2_base + (int64_t)((GI) * U2 + w + 1) * HC_UNIT;                                                        \
+            /* the previous group's 16 stores go out in the unit's second half, behind its DMA pieces: the wait at the unit's end */  \
+            /* leaves exactly them in flight (vmcnt(16)) instead of draining the store path once per unit */                         \
+            if (have_prev && w == 0) {                                                                                       \
+                HC_BODY(gu & 1, 32, ACC, 4, __builtin_bit_cast(hc16x8, a2h[8 * w + s]), __builtin_bit_cast(hc16x8, a2l[8 * w + s]), \
+                        ndn, 0x4f70, if (q >= 16) store2(PREV, g0 + (GI) - 1, q - 16), , )                                   \
+            } else {                                                                                                         \
+                HC_BODY(gu & 1, 32, ACC, 4, __builtin_bit_cast(hc16x8, a2h[8 * w + s]), __builtin_bit_cast(hc16x8, a2l[8 * w + s]), \
+                        ndn, 0x0f70, , , )                                                                                   \
+            }                                                                                                                \
+        }                                                                                                                    \
+    }
+// layer 2 of a workgroup: groups g0 .. g0 + ng - 1 (expects a2h / a2l [K2T], U2, u2_base, g0, ng, rowc, live, h, p; the first unit staged
+// in buffer GU0_ & 1; BIASP_: the groups' bias in LDS)
+#define HC_LAYER2(GU0_, BIASP_) \
+    /* ================================================================= layer 2: per group of four output blocks U2 units of eight K-steps */ \
+    hc32x16 accA[4], accB[4]; \
+    float *c2p = p.c2 + (int64_t)rowc * p.ldc2 + 4 * h; \
+    /* a finished group leaves in the gaps of the next one: block jj, quad g of group `grp` from `acc`, + bias */ \
+    auto store2 = [&](const hc32x16 (&acc)[4], const int grp, const int idx) {      /* idx = 0 .. 15: (block, quad) */ \
+        const int jj = idx >> 2, g = idx & 3; \
+        const int c = 128 * grp + 32 * jj + 8 * g; \
+        const float4 b = *reinterpret_cast<const float4 *>((BIASP_) + (c - 128 * g0) + 4 * h); \
+        const float4 v = make_float4(acc[jj][4 * g] + b.x, acc[jj][4 * g + 1] + b.y, acc[jj][4 * g + 2] + b.z, acc[jj][4 * g + 3] + b.w); \
+        if (live && !(p.knob & 1)) *reinterpret_cast<float4 *>(c2p + c) = v; \
+    }; \
+    /* group gi of this workgroup into ACC, the previous group's stores (from PREV) in its first unit's gaps */ \
+    int gi = 0; \
+    if (p.knob & 4) return; \
+    _Pragma("unroll 1") \
+    for (; gi + 1 < ng; gi += 2) { \
+        HC_GROUP(gi, accA, accB, GU0_) \
+        HC_GROUP(gi + 1, accB, accA, GU0_) \
+    } \
+    if (gi < ng) {                                                /* an odd group count: the last one */ \
+        HC_GROUP(gi, accA, accB, GU0_) \
+    _Pragma("unroll") \
+        for (int i = 0; i < 16; ++i) store2(accA, g0 + gi, i); \
+    } else { \
+    _Pragma("unroll") \
+        for (int i = 0; i < 16; ++i) store2(accB, g0 + ng - 1, i); \
+    }
 
 // K1T: K-tiles of layer 1's operand; NB1 = N1 / 32; NG: groups of four output blocks of layer 2 (N2 = 128 NG); a main workgroup takes
 // NG / nsplit of them, the workgroups of the tiles past the last full round one each.
@@ -158,41 +249,6 @@ __global__ __launch_bounds__(256, 1) void hs_chain_kernel(HcParams p)
 
     __builtin_amdgcn_s_waitcnt(0x0f70);                           // vmcnt(0): this wave's DMA (and fragments) have landed
     __syncthreads();
-
-    // One staging unit = up to 32 (K-step s, output block j) pairs, q = s * NB + j, three MFMAs each (smallest terms first, as in the
-    // tile kernel: W lo x A hi, W hi x A lo, W hi x A hi); gap 1: the weight fragments of pair q + 2 (+ FILL_A), gap 2: a DMA piece of
-    // the next unit (NDN of them; + FILL_B), gap 3: FILL_C.  BH / BL: the points' hi / lo fragments of K-step s.
-#define HC_BODY(BUF, NQ, ACC, NB, BH, BL, NDN, WAITCNT, FILL_A, FILL_B, FILL_C)                                                       \
-    {                                                                                                                        \
-        const char *wrow = hc_smem + (BUF) * HC_BUF + lane * 16;                                                             \
-        auto wfrag = [&](int q, int plane) { return *reinterpret_cast<const uint4 *>(wrow + (q * 2 + plane) * 1024); };      \
-        uint4 wh0 = wfrag(0, 0), wl0 = wfrag(0, 1), wh1 = wfrag((NQ) > 1 ? 1 : 0, 0), wl1 = wfrag((NQ) > 1 ? 1 : 0, 1);      \
-        HC_SB();                                                                                                             \
-        _Pragma("unroll") for (int q = 0; q < (NQ); ++q) {                                                                   \
-            const int s = q / (NB), j = q % (NB);                                                                            \
-            uint4 wh2 = wh1, wl2 = wl1;                                                                                      \
-            const hc16x8 bh = BH, bl = BL;                                                                                   \
-            ACC[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hc16x8, wl0), bh, ACC[j], 0, 0, 0);           \
-            HC_SB();                                                                                                         \
-            if (q + 2 < (NQ)) wh2 = wfrag(q + 2, 0), wl2 = wfrag(q + 2, 1);                                                  \
-            FILL_A;                                                                                                          \
-            HC_SB();                                                                                                         \
-            ACC[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hc16x8, wh0), bl, ACC[j], 0, 0, 0);           \
-            HC_SB();                                                                                                         \
-            if (q < (NDN)) dma((BUF) ^ 1, q);                                                                                \
-            FILL_B;                                                                                                          \
-            HC_SB();                                                                                                         \
-            ACC[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hc16x8, wh0), bh, ACC[j], 0, 0, 0);           \
-            HC_SB();                                                                                                         \
-            FILL_C;                                                                                                          \
-            HC_SB();                                                                                                         \
-            wh0 = wh1, wl0 = wl1, wh1 = wh2, wl1 = wl2;                                                                      \
-        }                                                                                                                    \
-        _Pragma("unroll") for (int q = (NQ); q < 16; ++q)       /* (a short unit has fewer gaps than the next unit has pieces) */ \
-            if (q < (NDN)) dma((BUF) ^ 1, q);                                                                                \
-        __builtin_amdgcn_s_waitcnt(WAITCNT);    /* this wave's share of the next unit has landed (what was issued after it may fly) */ \
-        __syncthreads();                        /* ... everybody's has, and this buffer's readers are done */                \
-    }
 
     // ================================================================= layer 1: U1 units of SPU1 K-steps x NB1 output blocks (the last may be short)
     const char *u2_base = p.units + (int64_t)(U1M + g0 * U2) * HC_UNIT;         // this workgroup's first unit of layer 2
@@ -290,58 +346,87 @@ __global__ __launch_bounds__(256, 1) void hs_chain_kernel(HcParams p)
         }
     }
 
-    // ================================================================= layer 2: per group of four output blocks U2 units of eight K-steps
-    hc32x16 accA[4], accB[4];
-    float *c2p = p.c2 + (int64_t)rowc * p.ldc2 + 4 * h;
-    // a finished group leaves in the gaps of the next one: block jj, quad g of group `grp` from `acc`, + bias
-    auto store2 = [&](const hc32x16 (&acc)[4], const int grp, const int idx) {      // idx = 0 .. 15: (block, quad)
-        const int jj = idx >> 2, g = idx & 3;
-        const int c = 128 * grp + 32 * jj + 8 * g;
-        const float4 b = *reinterpret_cast<const float4 *>(s_vec + 2 * N1 + (c - 128 * g0) + 4 * h);
-        const float4 v = make_float4(acc[jj][4 * g] + b.x, acc[jj][4 * g + 1] + b.y, acc[jj][4 * g + 2] + b.z, acc[jj][4 * g + 3] + b.w);
-        if (live && !(p.knob & 1)) *reinterpret_cast<float4 *>(c2p + c) = v;
+    HC_LAYER2(U1, s_vec + 2 * N1)
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// A projection GEMM alone -- C = A W^T (+ bias) with K = 128, 256 or 512 and N a multiple of 128 (gcn3d.py:170 `feature_map @ weights +
+// bias` of conv_1 .. conv_4: N = 9 x the layer's width; the two coarse products of the factored wide layers, K = 512, N = 4608) -- as the layer-2 half of the kernel above: a wave keeps its 32 rows' operand
+// fragments (from the planes their producer wrote) for ALL output columns, the weights stream through LDS once per 128 rows instead of
+// once per 128 x 128 tile, and the result leaves at the rate the memory takes it (stores behind the DMA pieces, counted waits).  The
+// tile kernel on this shape is bound by staging both operands again for every column tile and by its store bursts (conv_1's projection:
+// 168 MB in 66 us).  Same products in the same order, same fp16 range rule per 128-row tile: the tile kernel's bits, except for a tile
+// the rule sends to the exact path, which is computed here by fp32 fma chains in ascending k (the tile kernel uses the fp32 MFMA).
+template <int K2T>
+__global__ __launch_bounds__(256, 1) void hs_proj_kernel(HcParams p)
+{
+    constexpr int U2 = K2T / 8;
+    extern __shared__ __attribute__((aligned(16))) char hc_smem[];            // 2 x HC_BUF, then the bias of this workgroup's groups
+    float *s_vec = reinterpret_cast<float *>(hc_smem + 2 * HC_BUF);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int tile, g0, ng;
+    {
+        const int gpw = p.ngt / p.nsplit, mainwg = p.main_tiles * p.nsplit;
+        if ((int)blockIdx.x < mainwg) tile = blockIdx.x / p.nsplit, g0 = (blockIdx.x % p.nsplit) * gpw, ng = gpw;
+        else tile = p.main_tiles + ((int)blockIdx.x - mainwg) / p.ngt, g0 = ((int)blockIdx.x - mainwg) % p.ngt, ng = 1;
+    }
+    const int m0 = tile * 128 + wave * 32;
+    const int nblk = (p.M + 31) >> 5;
+    const int rb = min(m0 >> 5, nblk - 1);
+    const int row = m0 + r;
+    const bool live = row < p.M;
+    const int rowc = min(row, p.M - 1);
+    (void)r;
+    // fp16 range rule of the tile kernel, per 128-row tile: a magnitude >= 65504 (or a NaN), or nothing at or above 2^-4 -> exact path
+    bool exact = false;
+    if (p.a_amax) {
+        uint32_t am = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int b = tile * 4 + i;
+            const uint32_t v = b < nblk ? p.a_amax[b] : 0u;
+            am = v > am ? v : am;
+        }
+        exact = am >= 0x477fe000u || (am != 0u && am < 0x3d800000u);
+    }
+    if (exact) {                                                  // (workgroup-uniform; nothing staged yet)
+        for (int n = 128 * g0 + lane; n < 128 * (g0 + ng); n += 64) {
+            const float *wr = p.w_f32 + (int64_t)n * p.ldw;
+            const float bn = p.bias2 ? p.bias2[n] : 0.f;
+            for (int rr = 0; rr < 32 && m0 + rr < p.M; ++rr) {
+                const float *ar = p.a_f32 + (int64_t)(m0 + rr) * p.lda;
+                float acc = 0.f;
+                for (int k = 0; k < p.K2; ++k) acc = fmaf(ar[k], wr[k], acc);
+                p.c2[(int64_t)(m0 + rr) * p.ldc2 + n] = acc + bn;
+            }
+        }
+        return;
+    }
+    const uint32_t voff0 = lane * 16 + wave * 1024;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)hc_smem) + wave * 1024;
+    const char *u2_base = p.units + (int64_t)g0 * U2 * HC_UNIT;
+    const char *u_src = u2_base;
+    auto dma = [&](const int buf, const int j0) {
+        const uint32_t lds = lds0 + buf * HC_BUF + j0 * 4096;
+        const uint32_t vo = voff0 + j0 * 4096;
+        asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(u_src), "{m0}"(lds) : "memory");
     };
-#define HC_ZERO(ACC)                                                  \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                     \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) ACC[j][e] = 0.f;
-    // group gi of this workgroup into ACC, the previous group's stores (from PREV) in its first unit's gaps
-#define HC_GROUP(GI, ACC, PREV)                                                                                              \
-    {                                                                                                                        \
-        HC_ZERO(ACC)                                                                                                         \
-        const bool have_prev = (GI) > 0;                                                                                     \
-        _Pragma("unroll") for (int w = 0; w < U2; ++w) {                                                                     \
-            const int gu = U1 + (GI) * U2 + w;                          /* the unit's place in this workgroup's stream */    \
-            const int ndn = ((GI) + 1 < ng || w + 1 < U2) ? 16 : 0;                                                          \
-            u_src = u2_base + (int64_t)((GI) * U2 + w + 1) * HC_UNIT;                                                        \
-            /* the previous group's 16 stores go out in the unit's second half, behind its DMA pieces: the wait at the unit's end */  \
-            /* leaves exactly them in flight (vmcnt(16)) instead of draining the store path once per unit */                         \
-            if (have_prev && w == 0) {                                                                                       \
-                HC_BODY(gu & 1, 32, ACC, 4, __builtin_bit_cast(hc16x8, a2h[8 * w + s]), __builtin_bit_cast(hc16x8, a2l[8 * w + s]), \
-                        ndn, 0x4f70, if (q >= 16) store2(PREV, g0 + (GI) - 1, q - 16), , )                                   \
-            } else {                                                                                                         \
-                HC_BODY(gu & 1, 32, ACC, 4, __builtin_bit_cast(hc16x8, a2h[8 * w + s]), __builtin_bit_cast(hc16x8, a2l[8 * w + s]), \
-                        ndn, 0x0f70, , , )                                                                                   \
-            }                                                                                                                \
-        }                                                                                                                    \
-    }
-    int gi = 0;
-    if (p.knob & 4) return;
-#pragma unroll 1
-    for (; gi + 1 < ng; gi += 2) {
-        HC_GROUP(gi, accA, accB)
-        HC_GROUP(gi + 1, accB, accA)
-    }
-    if (gi < ng) {                                                // an odd group count: the last one
-        HC_GROUP(gi, accA, accB)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) store2(accA, g0 + gi, i);
-    } else {
+    for (int j0 = 0; j0 < 16; ++j0) dma(0, j0);
+    for (int i = tid; i < 128 * ng; i += 256) s_vec[i] = p.bias2 ? p.bias2[128 * g0 + i] : 0.f;
+    uint4 a2h[K2T], a2l[K2T];
+    {
+        const char *src = p.a_pl + (int64_t)rb * p.a_kt * 2048 + lane * 16;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) store2(accB, g0 + ng - 1, i);
+        for (int s = 0; s < K2T; ++s) {
+            a2h[s] = *reinterpret_cast<const uint4 *>(src + s * 2048);
+            a2l[s] = *reinterpret_cast<const uint4 *>(src + s * 2048 + 1024);
+        }
     }
-#undef HC_GROUP
-#undef HC_ZERO
-#undef HC_BODY
+    __builtin_amdgcn_s_waitcnt(0x0f70);                           // vmcnt(0): this wave's DMA and fragments have landed
+    __syncthreads();
+    HC_LAYER2(0, s_vec)
 }
 
 // ---- weights -> staging units.  Layer 1: W1 (N1, K1) -> U1 units, pair q = s * NB1 + j of unit u = K-step u * (32 / NB1) + s, output
@@ -450,6 +535,67 @@ extern "C" int tgp_hs_chain(const tgp_hs_chain_args *a, tgp_stream_t stream)
     } else {
         if (const int e = tgp_lds_attr(attr_b, reinterpret_cast<const void *>(hs_chain_kernel<16, 8, 18>), lds)) return e;
         hipLaunchKernelGGL((hs_chain_kernel<16, 8, 18>), dim3(grid), dim3(256), lds, tgp_hs(stream), p);
+    }
+    return TGP_LAUNCH_RESULT();
+}
+
+extern "C" int64_t tgp_proj_pack_bytes(int K, int N)
+{
+    if (!((K == 128 || K == 256 || K == 512) && N > 0 && N % 128 == 0)) return -1;
+    return (int64_t)(N / 128) * (K / 128) * HC_UNIT;
+}
+
+extern "C" int tgp_proj_pack(const float *w, int ld, int K, int N, void *out, tgp_stream_t stream)
+{
+    TGP_REQUIRE(w && out && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && ld >= K && tgp_proj_pack_bytes(K, N) > 0);
+    const int units = (N / 128) * (K / 128);
+    hipLaunchKernelGGL(hs_chain_pack_kernel, dim3(units * 64), dim3(256), 0, tgp_hs(stream), w, ld, N, K, 4, K / 16, units, 1,
+                       reinterpret_cast<uint16_t *>(out));
+    return TGP_LAUNCH_RESULT();
+}
+
+extern "C" int tgp_proj_planes(const tgp_proj_planes_args *a, tgp_stream_t stream)
+{
+    TGP_REQUIRE(a && a->a_planes && a->units && a->c && a->M > 0 && tgp_proj_pack_bytes(a->K, a->N) > 0);
+    TGP_REQUIRE(a->a_kt >= a->K / 16 && (a->ldc & 3) == 0 && a->ldc >= a->N);
+    TGP_REQUIRE(!a->a_amax || (a->a && a->w && a->lda >= a->K && a->ldw >= a->K));      // the exact path reads the fp32 operands
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    TGP_REQUIRE(al16(a->a_planes) && al16(a->units) && al16(a->c) && al16(a->bias));
+    HcParams p = {};
+    p.a_pl = reinterpret_cast<const char *>(a->a_planes), p.a_kt = a->a_kt, p.a_amax = a->a_amax;
+    p.units = reinterpret_cast<const char *>(a->units);
+    p.bias2 = a->bias, p.c2 = a->c, p.ldc2 = a->ldc;
+    p.a_f32 = a->a, p.lda = a->lda, p.w_f32 = a->w, p.ldw = a->ldw, p.K2 = a->K, p.ngt = a->N / 128;
+    p.M = a->M, p.tiles = tgp_cdiv(a->M, 128);
+    p.knob = 0;
+#ifdef TGP_DEV
+    p.knob = tgp_hs_chain_knobs;
+#endif
+    // one workgroup per CU and round: a tile's groups are cut over as many workgroups as still fit one round of 256; with more than
+    // 256 tiles the few past the last full round go one group per workgroup
+    p.nsplit = 1;
+    if (p.tiles <= 256)
+        for (int d = 1; d <= p.ngt; ++d)
+            if (p.ngt % d == 0 && p.tiles * d <= 256) p.nsplit = d;
+    while (p.ngt / p.nsplit > 24) {                               // (a workgroup's bias slice lives in LDS behind the two buffers: <= 12 KB)
+        int d = p.nsplit + 1;
+        while (p.ngt % d) ++d;
+        p.nsplit = d;
+    }
+    const int round_tiles = 256 / p.nsplit, over = p.tiles % round_tiles;
+    p.main_tiles = (p.tiles > round_tiles && over > 0 && over <= 8) ? p.tiles - over : p.tiles;
+    const int grid = p.main_tiles * p.nsplit + (p.tiles - p.main_tiles) * p.ngt;
+    const int lds = 2 * HC_BUF + 128 * (p.ngt / p.nsplit) * 4;    // the bias of one workgroup's groups
+    static TgpLdsAttr attr8, attr16, attr32;
+    if (a->K == 512) {
+        if (const int e = tgp_lds_attr(attr32, reinterpret_cast<const void *>(hs_proj_kernel<32>), lds)) return e;
+        hipLaunchKernelGGL((hs_proj_kernel<32>), dim3(grid), dim3(256), lds, tgp_hs(stream), p);
+    } else if (a->K == 128) {
+        if (const int e = tgp_lds_attr(attr8, reinterpret_cast<const void *>(hs_proj_kernel<8>), lds)) return e;
+        hipLaunchKernelGGL((hs_proj_kernel<8>), dim3(grid), dim3(256), lds, tgp_hs(stream), p);
+    } else {
+        if (const int e = tgp_lds_attr(attr16, reinterpret_cast<const void *>(hs_proj_kernel<16>), lds)) return e;
+        hipLaunchKernelGGL((hs_proj_kernel<16>), dim3(grid), dim3(256), lds, tgp_hs(stream), p);
     }
     return TGP_LAUNCH_RESULT();
 }

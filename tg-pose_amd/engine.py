@@ -88,6 +88,8 @@ def pack_encoder(sd, e, device):
         c["wcat_s"] = ops.split_w(c["wcat"])
         if ops.planes_on():
             c["wcat_p"] = ops.planes_w(c["wcat"])
+            if c["wcat_p"].tgp_unscale is None:                 # (a weight inside fp16's range: no pack-time rescale)
+                c["wcat_u"] = ops.proj_pack(c["wcat"])
         c["bcat"] = torch.cat([sd[p + "bias"], torch.zeros(cout, device=device)]).contiguous()
         w2 = sd[p + "conv2.weight"][:, :, 0]
         c["w1"], c["w2"] = w2[:, :cout].contiguous(), w2[:, cout:].contiguous()
@@ -289,6 +291,8 @@ def pack_factored(wide, dec0):
     if ops.planes_on():
         for k in ("dec_a", "Wb", "Wc"):
             f[k + "_p"] = ops.planes_w(f[k])
+        for k in ("Wb", "Wc"):                                  # the coarse products on the projection kernel (ops.proj_planes)
+            f[k + "_u"] = ops.proj_pack(f[k]) if f[k + "_p"].tgp_unscale is None else None
     # the fused heads kernel (conv1 -> conv2 -> max in one launch) takes fp16 operands without a pack-time rescale
     f["w2p"] = f["Wa_hp"] = f["Wa_cp"] = None
     if (ops.GEMM_MODE == "split16" and getattr(f["Wa_s"], "tgp_unscale", None) is None
@@ -328,6 +332,7 @@ HEADS_TAIL = os.environ.get("TGP_HEADS_TAIL", "0") != "0"
 DEC_PLANES_ONLY = os.environ.get("TGP_DEC_PLANES_ONLY", "1") != "0"     # the decoder's inner activations as fp16 planes only
 DEC_L1 = os.environ.get("TGP_DEC_L1", "1") != "0"           # the decoder's first conv on the fused heads kernel's conv1 half (ops.dec_l1)
 DEC_FUSED = os.environ.get("TGP_DEC_FUSED", "1") != "0"     # ... and everything behind its first conv as one launch (csrc/dec_fused.hip)
+PROJ_KERNEL = os.environ.get("TGP_PROJ_KERNEL", "1") != "0"      # the HS layers' projection GEMMs on tgp_proj_planes (csrc/hs_chain.hip)
 # conv_0's / conv_2's last GEMM + the next layer's projection as one launch (csrc/hs_chain.hip, bit-identical results).  Built and measured
 # in round 5, OFF by default: alone the pairs take 71 / 70 us against 83-94 / 73-86 us as two launches, but the kernel holds its CUs
 # exclusively (one wave per SIMD, 150 KB of LDS) while it waits for its 186 MB of stores, and on the four-in-flight line the same-box A/B
@@ -486,7 +491,12 @@ def hs_layer(c, xyz, fmap, idx_rf, idx_orl, out, scale=None, shift=None, act=Non
     # (B,n,9C): centre|support|STE.  fmap_p: the input's fp16 planes, written by its producer -- the GEMM then runs on the
     # pre-split kernel (csrc/gemm_pp.hip), bit-identical results
     if proj9 is None:         # (else: computed with the previous layer's last GEMM, ops.hs_chain)
-        proj9 = ops.linear_rows(fmap, c["wcat"], bias=c["bcat"], w_split=c.get("wcat_s"), a_planes=fmap_p, w_planes=c.get("wcat_p"))
+        if (PROJ_KERNEL and fmap_p is not None and c.get("wcat_u") is not None and c["wcat_u"].tgp_shape[0] == fmap.shape[-1]
+                and ops._routes_to_big_tile(B * n, c["wcat"].shape[0], 1, True)):
+            # (round 5) the projection on its own kernel: the operand's fragments stay in registers for all 9 C columns (csrc/hs_chain.hip)
+            proj9 = ops.proj_planes(fmap_p, c["wcat_u"], c["bcat"], fmap, c["wcat"])
+        else:
+            proj9 = ops.linear_rows(fmap, c["wcat"], bias=c["bcat"], w_split=c.get("wcat_s"), a_planes=fmap_p, w_planes=c.get("wcat_p"))
     if join is not None:
         torch.cuda.current_stream(xyz.device).wait_event(join)
     g = ops.gconv_hs(xyz, idx_rf, proj9, c["sdn"], 7, C, dirs=dirs)
@@ -570,8 +580,7 @@ def encoder_forward(pk, points_c, obj_id, sample_idx, graphs, kmax=20, n_cls=6, 
         # on a side stream it runs beside conv_4, the two nearest-point searches, the row sort and the gather -- 160 us of small
         # launches that leave most CUs idle -- instead of in front of conv_5 on the critical path
         f = pk.fact
-        p1_fn = lambda: ops.linear_rows(fm23.reshape(-1, 512), f["Wb"], w_split=f["Wb_s"], flops_ref=0, a_planes=pl.get("fm23"),
-                                        w_planes=f.get("Wb_p"))
+        p1_fn = lambda: _coarse_product(fm23.reshape(-1, 512), f, "Wb", pl.get("fm23"))
         if not COARSE_SIDE:
             pass                                   # coarse_products computes it in line
         elif BRANCH_STREAMS:
@@ -756,12 +765,19 @@ def coarse_products(pk, inter, heads_only=False):
     P1 = inter.get("P1")
     pl = inter.get("planes") or {}
     if P1 is None:
-        P1 = ops.linear_rows(inter["fm23"].reshape(-1, 512), f["Wb"], w_split=f["Wb_s"], flops_ref=0, a_planes=pl.get("fm23"),
-                             w_planes=f.get("Wb_p"))
+        P1 = _coarse_product(inter["fm23"].reshape(-1, 512), f, "Wb", pl.get("fm23"))
     elif inter.get("P1_join") is not None:        # computed beside conv_4 (encoder_forward): join before the first consumer
         torch.cuda.current_stream(P1.device).wait_event(inter["P1_join"])
-    return P1, ops.linear_rows(inter["fm_4"].reshape(-1, 512), f["Wc"], w_split=f["Wc_s"], flops_ref=0, a_planes=pl.get("fm4"),
-                               w_planes=f.get("Wc_p"))
+    return P1, _coarse_product(inter["fm_4"].reshape(-1, 512), f, "Wc", pl.get("fm4"))
+
+
+def _coarse_product(x, f, key, x_planes):
+    """x (rows, 512) times the stacked coarse weight f[key]: on the projection kernel (round 5: the operand's fragments resident for
+    all 4608 columns) when the operand travels as planes and the launch would otherwise take the tile kernels -- whose bits it computes"""
+    W = f[key]
+    if PROJ_KERNEL and x_planes is not None and f.get(key + "_u") is not None and ops._routes_to_big_tile(x.shape[0], W.shape[0], 1, True):
+        return ops.proj_planes(x_planes, f[key + "_u"], None, x, W, flops_ref=0)
+    return ops.linear_rows(x, W, w_split=f[key + "_s"], flops_ref=0, a_planes=x_planes, w_planes=f.get(key + "_p"))
 
 
 def wide_gemm_factored(pk, fine, inter, P1, P2, N, arena=None, heads_only=False):

@@ -705,6 +705,47 @@ def dec_pack(w2, w3, w4, h1_permuted=False):
     return out
 
 
+def proj_pack(w):
+    """W (N, K) of a projection GEMM -> the staging image of tgp_proj_planes; None for shapes the kernel does not serve
+    (K = 128 / 256 / 512, N % 128 == 0)"""
+    N, K = w.shape
+    nbytes = _lib.lib().tgp_proj_pack_bytes(int(K), int(N))
+    if nbytes < 0:
+        return None
+    w = w.contiguous()
+    out = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+    check(_lib.lib().tgp_proj_pack(_p(w), K, K, N, _p(out), _stream(w)), "tgp_proj_pack")
+    out.tgp_shape = (int(K), int(N))
+    return out
+
+
+def proj_planes(a_planes, units, bias, x, weight, out=None, flops_ref=None):
+    """x W^T (+ bias) on the projection kernel (tgp_proj_planes): a_planes = the planes of x (its first K columns), units =
+    proj_pack(weight); x (..., K) fp32 rows and weight (N, K) are read only by tiles the fp16 range rule sends to the exact path."""
+    K, N = units.tgp_shape
+    x, lda = _rows(x, "x")
+    weight, ldw = _rows(weight, "weight")
+    M = a_planes.rows
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+    o, ldc = _rows(out, "out")
+    timed = GEMM_TIMER is not None
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(x.device))
+    a = _lib.ProjPlanesArgs()
+    a.a_planes, a.a_kt, a.a_amax = _p(a_planes.buf), a_planes.kt, _p(a_planes.amax)
+    a.a, a.lda, a.M, a.K, a.N = _p(x), lda, M, K, N
+    a.units, a.w, a.ldw, a.bias = _p(units), _p(weight), ldw, _p(bias)
+    a.c, a.ldc = _p(o), ldc
+    check(_lib.lib().tgp_proj_planes(ctypes.byref(a), _stream(x)), "tgp_proj_planes")
+    if timed:
+        e1.record(torch.cuda.current_stream(x.device))
+        fl = 2.0 * M * N * K
+        GEMM_TIMER.append((e0, e1, fl, (M, N, K, 1), fl if flops_ref is None else float(flops_ref), 4.0 * (M * K + N * K + M * N), "fused"))
+    return out
+
+
 def hs_chain_pack(w1, w2):
     """W1 (N1, K1) of an HS layer's last GEMM and W2 (N2, N1) of the next layer's projection -> the fused pair's staging image
     (tgp_hs_chain_pack); None for shapes the kernel does not serve"""
