@@ -36,6 +36,8 @@ typedef float hc32x16 __attribute__((ext_vector_type(16)));
 #define HC_UNIT (64 * 1024)                // one staging unit in memory: 32 (K-step, output block) pairs x 2 planes of 1 KB
 #define HC_BUF (72 * 1024)                 // an LDS buffer: room for 36 pairs (layer 1 of the 132 -> 128 shape is ONE unit of 9 K-steps x 4 blocks)
 #define HC_SB() __builtin_amdgcn_sched_barrier(0)
+#define HR_SLOT (32 * 1024)                // hs_proj_kernel: one slot of its ring of four half units
+__device__ __forceinline__ constexpr int hc_vmcnt(int n) { return 0x0f70 | (n & 15) | ((n >> 4) << 14); }
 
 struct HcParams {
     const char *a_pl; int a_kt; const uint32_t *a_amax;          // layer 1's operand (M rows) as blocked fp16 planes + its magnitude words
@@ -361,8 +363,8 @@ template <int K2T>
 __global__ __launch_bounds__(256, 1) void hs_proj_kernel(HcParams p)
 {
     constexpr int U2 = K2T / 8;
-    extern __shared__ __attribute__((aligned(16))) char hc_smem[];            // 2 x HC_BUF, then the bias of this workgroup's groups
-    float *s_vec = reinterpret_cast<float *>(hc_smem + 2 * HC_BUF);
+    extern __shared__ __attribute__((aligned(16))) char hc_smem[];            // 4 x HR_SLOT, then the bias of this workgroup's groups
+    float *s_vec = reinterpret_cast<float *>(hc_smem + 4 * HR_SLOT);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     int tile, g0, ng;
@@ -403,17 +405,28 @@ __global__ __launch_bounds__(256, 1) void hs_proj_kernel(HcParams p)
         }
         return;
     }
+    // ---- staging: the workgroup's weights are a stream of HALF units (32 KB = 16 (K-step, block) pairs = 48 MFMAs per wave) through a
+    // ring of four LDS slots: half unit k + 3 is requested while k is multiplied, so a piece has two half units (~3000 cycles) to
+    // arrive.  With two 64 KB buffers the next unit was requested one unit ahead and waited for at the end of the current one: on the
+    // K = 512 products that wait was a third of the kernel (138 us where the MFMAs are 81).
     const uint32_t voff0 = lane * 16 + wave * 1024;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)hc_smem) + wave * 1024;
     const char *u2_base = p.units + (int64_t)g0 * U2 * HC_UNIT;
     const char *u_src = u2_base;
-    auto dma = [&](const int buf, const int j0) {
-        const uint32_t lds = lds0 + buf * HC_BUF + j0 * 4096;
+    const int nhu = ng * U2 * 2;                                  // half units of this workgroup
+    auto dmah = [&](const int slot, const int j0) {               // piece j = 4 j0 + wave of the half unit at u_src
+        const uint32_t lds = lds0 + slot * HR_SLOT + j0 * 4096;
         const uint32_t vo = voff0 + j0 * 4096;
         asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(u_src), "{m0}"(lds) : "memory");
     };
 #pragma unroll
-    for (int j0 = 0; j0 < 16; ++j0) dma(0, j0);
+    for (int k = 0; k < 3; ++k) {
+        if (k < nhu) {
+            u_src = u2_base + (int64_t)k * HR_SLOT;
+#pragma unroll
+            for (int j0 = 0; j0 < 8; ++j0) dmah(k, j0);
+        }
+    }
     for (int i = tid; i < 128 * ng; i += 256) s_vec[i] = p.bias2 ? p.bias2[128 * g0 + i] : 0.f;
     uint4 a2h[K2T], a2l[K2T];
     {
@@ -424,9 +437,87 @@ __global__ __launch_bounds__(256, 1) void hs_proj_kernel(HcParams p)
             a2l[s] = *reinterpret_cast<const uint4 *>(src + s * 2048 + 1024);
         }
     }
-    __builtin_amdgcn_s_waitcnt(0x0f70);                           // vmcnt(0): this wave's DMA and fragments have landed
-    __syncthreads();
-    HC_LAYER2(0, s_vec)
+    __builtin_amdgcn_s_waitcnt(0x0070);                           // vmcnt(0) lgkmcnt(0): the first half units, the bias and the fragments are in
+    __builtin_amdgcn_s_barrier();
+
+    hc32x16 accA[4], accB[4];
+    float *c2p = p.c2 + (int64_t)rowc * p.ldc2 + 4 * h;
+    // a finished group leaves in the gaps of the next one: block jj, quad g of group `grp` from `acc`, + bias
+    auto store2 = [&](const hc32x16 (&acc)[4], const int grp, const int idx) {      // idx = 0 .. 15: (block, quad)
+        const int jj = idx >> 2, g = idx & 3;
+        const int c = 128 * grp + 32 * jj + 8 * g;
+        const float4 b = *reinterpret_cast<const float4 *>(s_vec + (c - 128 * g0) + 4 * h);
+        const float4 v = make_float4(acc[jj][4 * g] + b.x, acc[jj][4 * g + 1] + b.y, acc[jj][4 * g + 2] + b.z, acc[jj][4 * g + 3] + b.w);
+        if (live && !(p.knob & 1)) *reinterpret_cast<float4 *>(c2p + c) = v;
+    };
+    // half unit K_ (slot K_ & 3): pairs q = 0 .. 15 = K-steps S0_ .. S0_ + 3 x four output blocks into ACC; gap 1: the fragments of pair
+    // q + 2 and FILL_A, gap 2: a piece round of half unit K_ + 3.  The wait at its end leaves in flight what was requested after half
+    // unit K_ + 1: the rounds of K_ + 2 and K_ + 3 (8 each, where they exist) and this half unit's 16 stores (NST: it has them).
+#define HR_HALF(K_, ACC, S0_, NST, FILL_A)                                                                                   \
+    {                                                                                                                        \
+        const int k_ = (K_);                                                                                                 \
+        const char *wrow = hc_smem + (k_ & 3) * HR_SLOT + lane * 16;                                                         \
+        const bool stage = k_ + 3 < nhu;                                                                                     \
+        u_src = u2_base + (int64_t)(k_ + 3) * HR_SLOT;                                                                       \
+        auto wfrag = [&](int q, int plane) { return *reinterpret_cast<const uint4 *>(wrow + (q * 2 + plane) * 1024); };      \
+        uint4 wh0 = wfrag(0, 0), wl0 = wfrag(0, 1), wh1 = wfrag(1, 0), wl1 = wfrag(1, 1);                                    \
+        HC_SB();                                                                                                             \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                                     \
+            const int s = (S0_) + q / 4, j = q % 4;                                                                          \
+            uint4 wh2 = wh1, wl2 = wl1;                                                                                      \
+            const hc16x8 bh = __builtin_bit_cast(hc16x8, a2h[s]), bl = __builtin_bit_cast(hc16x8, a2l[s]);                   \
+            ACC[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hc16x8, wl0), bh, ACC[j], 0, 0, 0);           \
+            HC_SB();                                                                                                         \
+            if (q + 2 < 16) wh2 = wfrag(q + 2, 0), wl2 = wfrag(q + 2, 1);                                                    \
+            FILL_A;                                                                                                          \
+            HC_SB();                                                                                                         \
+            ACC[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hc16x8, wh0), bl, ACC[j], 0, 0, 0);           \
+            HC_SB();                                                                                                         \
+            if (q < 8 && stage) dmah((k_ + 3) & 3, q);                                                                       \
+            HC_SB();                                                                                                         \
+            ACC[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hc16x8, wh0), bh, ACC[j], 0, 0, 0);           \
+            HC_SB();                                                                                                         \
+            wh0 = wh1, wl0 = wl1, wh1 = wh2, wl1 = wl2;                                                                      \
+        }                                                                                                                    \
+        {                                                                                                                    \
+            const int nd = (k_ + 2 < nhu ? 1 : 0) + (stage ? 1 : 0);                                                         \
+            if (NST) {                                                                                                       \
+                if (nd == 2) __builtin_amdgcn_s_waitcnt(hc_vmcnt(32));                                                       \
+                else if (nd == 1) __builtin_amdgcn_s_waitcnt(hc_vmcnt(24));                                                  \
+                else __builtin_amdgcn_s_waitcnt(hc_vmcnt(16));                                                               \
+            } else {                                                                                                         \
+                if (nd == 2) __builtin_amdgcn_s_waitcnt(hc_vmcnt(16));                                                       \
+                else if (nd == 1) __builtin_amdgcn_s_waitcnt(hc_vmcnt(8));                                                   \
+                else __builtin_amdgcn_s_waitcnt(hc_vmcnt(0));                                                                \
+            }                                                                                                                \
+        }                                                                                                                    \
+        __builtin_amdgcn_s_barrier();       /* the next half unit is in for everybody, and this slot's readers are done */     \
+    }
+    // group GI of this workgroup into ACC; the previous group's 16 stores (from PREV) ride in its second half unit (NST: are there any)
+#define HR_GROUP(GI, ACC, PREV)                                                                                              \
+    {                                                                                                                        \
+        HC_ZERO(ACC)                                                                                                         \
+        const bool have_prev = (GI) > 0;                                                                                     \
+        _Pragma("unroll") for (int w = 0; w < U2; ++w) {                                                                     \
+            HR_HALF(((GI) * U2 + w) * 2, ACC, 8 * w, false, )                                                                \
+            HR_HALF(((GI) * U2 + w) * 2 + 1, ACC, 8 * w + 4, (w == 0 && have_prev), if (w == 0 && have_prev) store2(PREV, g0 + (GI) - 1, q)) \
+        }                                                                                                                    \
+    }
+    if (p.knob & 4) return;
+#pragma unroll 1
+    for (int gi = 0; gi < ng; gi += 2) {
+        HR_GROUP(gi, accA, accB)
+        if (gi + 1 < ng) HR_GROUP(gi + 1, accB, accA)
+    }
+    if (ng & 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) store2(accA, g0 + ng - 1, i);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) store2(accB, g0 + ng - 1, i);
+    }
+#undef HR_GROUP
+#undef HR_HALF
 }
 
 // ---- weights -> staging units.  Layer 1: W1 (N1, K1) -> U1 units, pair q = s * NB1 + j of unit u = K-step u * (32 / NB1) + s, output
@@ -585,7 +676,7 @@ extern "C" int tgp_proj_planes(const tgp_proj_planes_args *a, tgp_stream_t strea
     const int round_tiles = 256 / p.nsplit, over = p.tiles % round_tiles;
     p.main_tiles = (p.tiles > round_tiles && over > 0 && over <= 8) ? p.tiles - over : p.tiles;
     const int grid = p.main_tiles * p.nsplit + (p.tiles - p.main_tiles) * p.ngt;
-    const int lds = 2 * HC_BUF + 128 * (p.ngt / p.nsplit) * 4;    // the bias of one workgroup's groups
+    const int lds = 4 * HR_SLOT + 128 * (p.ngt / p.nsplit) * 4;   // the ring + the bias of one workgroup's groups
     static TgpLdsAttr attr8, attr16, attr32;
     if (a->K == 512) {
         if (const int e = tgp_lds_attr(attr32, reinterpret_cast<const void *>(hs_proj_kernel<32>), lds)) return e;
