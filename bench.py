@@ -201,6 +201,10 @@ ALGO_BYTES_B32 = {
     "dec_fused_kernel": 67.4e6 + 1.7e6 + 0.4e6 + 0.3e6,
     # fine + the decoder's 512 columns of the coarse products (8224 + 2048 rows) + weight planes + the activation out as fragments
     "dec_l1_kernel": 35.8e6 + 16.8e6 + 4.2e6 + 0.6e6 + 67.4e6,
+    # the projection kernel serves two launches per forward and instance (operand planes + weight + result, 4 B per element): their mean
+    "void hs_proj_kernel<8>": 0.5 * (169.0e6 + 81.1e6),                        # conv_1 (32896 x 1152 x 128), conv_2 (8224 x 2304 x 128)
+    "void hs_proj_kernel<16>": 0.5 * (86.6e6 + 45.1e6),                        # conv_3 (8224 x 2304 x 256), conv_4 (2048 x 4608 x 256)
+    "void hs_proj_kernel<32>": 0.5 * (177.9e6 + 51.4e6),                       # the coarse products (8224 / 2048 x 4608 x 512)
     "void gconv_kernel<128, false>": 4.83e6 * 32,       # conv_1's graph convolution, SURVEY 8d: 4.83 MB per object
     "void gconv_kernel<128, true>": 0.62e6 * 32,        # conv_0
     # conv_2 / conv_3 (n = 257, C = 256): centre + 7 support blocks of the projection (8224 x 2048 x 4 B), directions, lists, output
