@@ -120,7 +120,7 @@ __device__ __forceinline__ float hc_mix_hi(uint32_t hpair, float v)     // v - (
             u_src = u2_base + (int64_t)((GI) * U2 + w + 1) * HC_UNIT;                                                        \
             /* the previous group's 16 stores go out in the unit's second half, behind its DMA pieces: the wait at the unit's end */  \
             /* leaves exactly them in flight (vmcnt(16)) instead of draining the store path once per unit */                         \
-            if (have_prev && w == 0) {                                                                                       \
+            if (have_prev && w == 0 && m0 < p.M) {      /* (a wave past the last row issues no stores: it takes the plain wait) */ \
                 HC_BODY(gu & 1, 32, ACC, 4, __builtin_bit_cast(hc16x8, a2h[8 * w + s]), __builtin_bit_cast(hc16x8, a2l[8 * w + s]), \
                         ndn, 0x4f70, if (q >= 16) store2(PREV, g0 + (GI) - 1, q - 16), , )                                   \
             } else {                                                                                                         \
@@ -440,9 +440,15 @@ __global__ __launch_bounds__(256, 1) void hs_proj_kernel(HcParams p)
     __builtin_amdgcn_s_waitcnt(0x0070);                           // vmcnt(0) lgkmcnt(0): the first half units, the bias and the fragments are in
     __builtin_amdgcn_s_barrier();
 
+    // (a wave past the last row issues no stores: its waits count none, i.e. wait for more; a partly live wave issues all of them,
+    // masked)
+    const bool full = m0 < p.M;
     hc32x16 accA[4], accB[4];
     float *c2p = p.c2 + (int64_t)rowc * p.ldc2 + 4 * h;
-    // a finished group leaves in the gaps of the next one: block jj, quad g of group `grp` from `acc`, + bias
+    // a finished group leaves in the gaps of the next one: block jj, quad g of group `grp` from `acc`, + bias.  (Store shapes measured with
+    // the development build's knobs: this direct form touches 32 rows x 32 bytes per instruction; 16 rows x 64 bytes after one
+    // v_permlane16_swap per register pair was slower -- the swaps are vector instructions --, and the same bytes as 8 rows x 128 bytes
+    // through an LDS tile saturated the LDS, which the fragment reads already load to 60 %.)
     auto store2 = [&](const hc32x16 (&acc)[4], const int grp, const int idx) {      // idx = 0 .. 15: (block, quad)
         const int jj = idx >> 2, g = idx & 3;
         const int c = 128 * grp + 32 * jj + 8 * g;
@@ -481,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void hs_proj_kernel(HcParams p)
         }                                                                                                                    \
         {                                                                                                                    \
             const int nd = (k_ + 2 < nhu ? 1 : 0) + (stage ? 1 : 0);                                                         \
-            if (NST) {                                                                                                       \
+            if ((NST) && full) {                                                                                             \
                 if (nd == 2) __builtin_amdgcn_s_waitcnt(hc_vmcnt(32));                                                       \
                 else if (nd == 1) __builtin_amdgcn_s_waitcnt(hc_vmcnt(24));                                                  \
                 else __builtin_amdgcn_s_waitcnt(hc_vmcnt(16));                                                               \
