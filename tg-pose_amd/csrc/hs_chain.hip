@@ -27,6 +27,7 @@
 #include "tgp_common.h"
 #include "../../include/tgpose.h"
 #include <type_traits>
+#include <cstdlib>
 
 typedef _Float16 hc16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 hc16x4 __attribute__((ext_vector_type(4)));
@@ -369,9 +370,12 @@ __global__ __launch_bounds__(256, 1) void hs_proj_kernel(HcParams p)
     const int r = lane & 31, h = lane >> 5;
     int tile, g0, ng;
     {
-        const int gpw = p.ngt / p.nsplit, mainwg = p.main_tiles * p.nsplit;
-        if ((int)blockIdx.x < mainwg) tile = blockIdx.x / p.nsplit, g0 = (blockIdx.x % p.nsplit) * gpw, ng = gpw;
-        else tile = p.main_tiles + ((int)blockIdx.x - mainwg) / p.ngt, g0 = ((int)blockIdx.x - mainwg) % p.ngt, ng = 1;
+        // a main tile's groups go to nsplit workgroups in contiguous, nearly equal shares; the tiles behind them one group per workgroup
+        const int mainwg = p.main_tiles * p.nsplit;
+        if ((int)blockIdx.x < mainwg) {
+            const int sp = blockIdx.x % p.nsplit;
+            tile = blockIdx.x / p.nsplit, g0 = sp * p.ngt / p.nsplit, ng = (sp + 1) * p.ngt / p.nsplit - g0;
+        } else tile = p.main_tiles + ((int)blockIdx.x - mainwg) / p.ngt, g0 = ((int)blockIdx.x - mainwg) % p.ngt, ng = 1;
     }
     const int m0 = tile * 128 + wave * 32;
     const int nblk = (p.M + 31) >> 5;
@@ -668,21 +672,28 @@ extern "C" int tgp_proj_planes(const tgp_proj_planes_args *a, tgp_stream_t strea
 #ifdef TGP_DEV
     p.knob = tgp_hs_chain_knobs;
 #endif
-    // one workgroup per CU and round: a tile's groups are cut over as many workgroups as still fit one round of 256; with more than
-    // 256 tiles the few past the last full round go one group per workgroup
+    // one workgroup per CU and round.  A tile's groups are cut over as many workgroups as still fit one round of 256: in equal shares
+    // (a divisor of the group count) over all tiles -- or, for the K = 512 products with a partial last tile (8224 rows = 64 full tiles
+    // + 32 rows), over the FULL tiles in nearly equal shares (4 workgroups x 9 of the 36 groups = 256) with the partial tile's groups one
+    // per workgroup behind the round: 124-133 against 138-140 us on the level-1 coarse product, same box; the K <= 256 projections lose
+    // 1-3 us that way (their groups are short) and keep the first rule.  With more than 256 tiles the few past the last full round go
+    // one group per workgroup.
+    const int full_tiles = a->M / 128;
     p.nsplit = 1;
-    if (p.tiles <= 256)
-        for (int d = 1; d <= p.ngt; ++d)
-            if (p.ngt % d == 0 && p.tiles * d <= 256) p.nsplit = d;
-    while (p.ngt / p.nsplit > 24) {                               // (a workgroup's bias slice lives in LDS behind the two buffers: <= 12 KB)
-        int d = p.nsplit + 1;
-        while (p.ngt % d) ++d;
-        p.nsplit = d;
+    p.main_tiles = p.tiles;
+    if (a->K == 512 && full_tiles >= 1 && full_tiles < p.tiles && full_tiles <= 256) {
+        p.nsplit = 256 / full_tiles < p.ngt ? 256 / full_tiles : p.ngt;
+        p.main_tiles = full_tiles;
+    } else {
+        if (p.tiles <= 256)
+            for (int d = 1; d <= p.ngt; ++d)
+                if (p.ngt % d == 0 && p.tiles * d <= 256) p.nsplit = d;
+        const int rt = 256 / p.nsplit, ov = p.tiles % rt;
+        if (p.tiles > rt && ov > 0 && ov <= 8) p.main_tiles = p.tiles - ov;
     }
-    const int round_tiles = 256 / p.nsplit, over = p.tiles % round_tiles;
-    p.main_tiles = (p.tiles > round_tiles && over > 0 && over <= 8) ? p.tiles - over : p.tiles;
+    while ((p.ngt + p.nsplit - 1) / p.nsplit > 24) ++p.nsplit;      // (a workgroup's bias slice lives in LDS behind the ring: <= 12 KB)
     const int grid = p.main_tiles * p.nsplit + (p.tiles - p.main_tiles) * p.ngt;
-    const int lds = 4 * HR_SLOT + 128 * (p.ngt / p.nsplit) * 4;   // the ring + the bias of one workgroup's groups
+    const int lds = 4 * HR_SLOT + 128 * ((p.ngt + p.nsplit - 1) / p.nsplit) * 4;      // the ring + the bias of one workgroup's groups
     static TgpLdsAttr attr8, attr16, attr32;
     if (a->K == 512) {
         if (const int e = tgp_lds_attr(attr32, reinterpret_cast<const void *>(hs_proj_kernel<32>), lds)) return e;
