@@ -86,7 +86,8 @@ def test_fused_kernel_arg_structs_match_header_layout():
     assert out == [ctypes.sizeof(H), H.idx2.offset, H.keys.offset, H.overflow.offset,
                    ctypes.sizeof(C), C.idx2.offset, C.slope.offset, C.overflow.offset]
     # (ABI 7) the decoder's and the chained layer tails' structs: every field's offset
-    names = (("tgp_dec_fused_args", _lib.DecFusedArgs), ("tgp_dec_l1_args", _lib.DecL1Args), ("tgp_hs_chain_args", _lib.HsChainArgs))
+    names = (("tgp_dec_fused_args", _lib.DecFusedArgs), ("tgp_dec_l1_args", _lib.DecL1Args), ("tgp_hs_chain_args", _lib.HsChainArgs),
+             ("tgp_proj_planes_args", _lib.ProjPlanesArgs))
     fields = [(cn, f[0]) for cn, cls in names for f in cls._fields_]
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "tgpose.h"\nint main(){' + "".join(
         'printf("%%zu ", offsetof(%s, %s));' % cf for cf in fields) + "".join('printf("%%zu ", sizeof(%s));' % cn for cn, _ in names) + "return 0;}\n"
