@@ -423,15 +423,8 @@ __global__ __launch_bounds__(256, 1) void hs_proj_kernel(HcParams p)
         const uint32_t vo = voff0 + j0 * 4096;
         asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(u_src), "{m0}"(lds) : "memory");
     };
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        if (k < nhu) {
-            u_src = u2_base + (int64_t)k * HR_SLOT;
-#pragma unroll
-            for (int j0 = 0; j0 < 8; ++j0) dmah(k, j0);
-        }
-    }
-    for (int i = tid; i < 128 * ng; i += 256) s_vec[i] = p.bias2 ? p.bias2[128 * g0 + i] : 0.f;
+    // the wave's operand fragments and the bias first, then the first three half units: the matrix work starts when the fragments and
+    // half unit 0 are in (the rounds of half units 1 and 2 -- the 16 youngest requests -- still fly)
     uint4 a2h[K2T], a2l[K2T];
     {
         const char *src = p.a_pl + (int64_t)rb * p.a_kt * 2048 + lane * 16;
@@ -441,7 +434,18 @@ __global__ __launch_bounds__(256, 1) void hs_proj_kernel(HcParams p)
             a2l[s] = *reinterpret_cast<const uint4 *>(src + s * 2048 + 1024);
         }
     }
-    __builtin_amdgcn_s_waitcnt(0x0070);                           // vmcnt(0) lgkmcnt(0): the first half units, the bias and the fragments are in
+    for (int i = tid; i < 128 * ng; i += 256) s_vec[i] = p.bias2 ? p.bias2[128 * g0 + i] : 0.f;
+    HC_SB();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k < nhu) {
+            u_src = u2_base + (int64_t)k * HR_SLOT;
+#pragma unroll
+            for (int j0 = 0; j0 < 8; ++j0) dmah(k, j0);
+        }
+    }
+    if (nhu >= 3) __builtin_amdgcn_s_waitcnt(0x0070 | (16 & 15) | ((16 >> 4) << 14));      // vmcnt(16) lgkmcnt(0)
+    else __builtin_amdgcn_s_waitcnt(0x0070);                      // vmcnt(0) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
 
     // (a wave past the last row issues no stores: its waits count none, i.e. wait for more; a partly live wave issues all of them,
