@@ -698,15 +698,16 @@ extern "C" int tgp_proj_planes(const tgp_proj_planes_args *a, tgp_stream_t strea
     while ((p.ngt + p.nsplit - 1) / p.nsplit > 24) ++p.nsplit;      // (a workgroup's bias slice lives in LDS behind the ring: <= 12 KB)
     const int grid = p.main_tiles * p.nsplit + (p.tiles - p.main_tiles) * p.ngt;
     const int lds = 4 * HR_SLOT + 128 * ((p.ngt + p.nsplit - 1) / p.nsplit) * 4;      // the ring + the bias of one workgroup's groups
+    const int lds_max = 4 * HR_SLOT + 128 * 24 * 4;               // (the attribute is set once per device: the largest a launch can ask for)
     static TgpLdsAttr attr8, attr16, attr32;
     if (a->K == 512) {
-        if (const int e = tgp_lds_attr(attr32, reinterpret_cast<const void *>(hs_proj_kernel<32>), lds)) return e;
+        if (const int e = tgp_lds_attr(attr32, reinterpret_cast<const void *>(hs_proj_kernel<32>), lds_max)) return e;
         hipLaunchKernelGGL((hs_proj_kernel<32>), dim3(grid), dim3(256), lds, tgp_hs(stream), p);
     } else if (a->K == 128) {
-        if (const int e = tgp_lds_attr(attr8, reinterpret_cast<const void *>(hs_proj_kernel<8>), lds)) return e;
+        if (const int e = tgp_lds_attr(attr8, reinterpret_cast<const void *>(hs_proj_kernel<8>), lds_max)) return e;
         hipLaunchKernelGGL((hs_proj_kernel<8>), dim3(grid), dim3(256), lds, tgp_hs(stream), p);
     } else {
-        if (const int e = tgp_lds_attr(attr16, reinterpret_cast<const void *>(hs_proj_kernel<16>), lds)) return e;
+        if (const int e = tgp_lds_attr(attr16, reinterpret_cast<const void *>(hs_proj_kernel<16>), lds_max)) return e;
         hipLaunchKernelGGL((hs_proj_kernel<16>), dim3(grid), dim3(256), lds, tgp_hs(stream), p);
     }
     return TGP_LAUNCH_RESULT();
