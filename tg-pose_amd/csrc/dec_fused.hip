@@ -454,8 +454,10 @@ __global__ __launch_bounds__(256, 1) void dec_l1_kernel(DecL1Params p)
         }
     };
 
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    __syncthreads();
+    // the weights of block 0 and the vectors (LDS) are in when at most the 34 fragment loads issued after them (and what followed) fly:
+    // block 0's conv1 starts on the fragments that have arrived (heads_fused_kernel's prologue)
+    __builtin_amdgcn_s_waitcnt(0x0070 | (34 & 15) | ((34 >> 4) << 14));      // vmcnt(34) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
     // iteration cb (0 .. 17): conv1 of block cb (cb < 16) into acc[cb & 1]; in its gaps the weights of block cb + 1, the epilogue of
     // block cb - 1 (from acc[(cb - 1) & 1], g[(cb - 1) & 1] into a2[(cb - 1) & 1]), the gathers of block cb (into g[cb & 1]) and the
     // stores of block cb - 2 (from a2[cb & 1]).  MM / E1 / ST: which of the three this instance contains (compile-time).
