@@ -15,10 +15,11 @@ data-path collective (weak scaling); the only RCCL traffic is the barrier / max-
 around the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      the dominant kernel family (gemm_split_kernel / gemm_split512_kernel: the operand-split
-                GEMM on the fp16 matrix cores that holds the per-point MLPs, 95 % of the FLOPs), timed
-                with HIP events on the launch stream around every one of its launches: achieved =
-                algorithmic fp32 FLOPs / time.  Replayed graphs have no launch to bracket, so the
+  roofline      the dominant kernel class (the operand-split GEMMs on the fp16 matrix cores that hold the
+                per-point MLPs, 95 % of the FLOPs: hs_proj_kernel / gemm_pp_kernel and the fused heads /
+                conv_5 / decoder kernels), timed with HIP events on the launch stream around every one of
+                its launches: achieved = algorithmic fp32 FLOPs / time; `per_launch` prices each launch
+                at its own bound (MFMA or HBM).  Replayed graphs have no launch to bracket, so the
                 events go around serial eager launches of the same steps right after the timed region
                 (`roofline.measured` says which).
   cpu_baseline  the CPU oracle (the build's restatement of the reference's torch op sequence,
@@ -598,8 +599,9 @@ def main():
             peak_basis = ("algorithmic fp32 FLOPs; each fp32 product costs 6 bf16 MFMA terms (3-term operand split), so "
                           "the bound is the dense bf16 MFMA peak 2500 TFLOP/s / 6; for scale, the fp32 MFMA peak is 157.3")
         elif args.gemm == "split16":
-            kernel_name = ("gemm_pp_kernel<*> (both operands as fp16 planes) / gemm_split*_kernel<f16> (+ heads_fused_kernel / "
-                           "conv_max_fused_kernel: the same 3-term fp16 MFMA arithmetic)")
+            kernel_name = ("the fp16-split MFMA class of the forward: hs_proj_kernel<*> (projections, coarse products) / gemm_pp_kernel<*> "
+                           "(the layers' last GEMMs; both operands as fp16 planes) / heads_fused_kernel / conv_max_fused_kernel / "
+                           "dec_l1_kernel / dec_fused_kernel: the same 3-term fp16 MFMA arithmetic")
             peak = PEAK_BF16_MFMA_TFLOPS / 3.0
             peak_basis = ("algorithmic fp32 FLOPs; each fp32 product costs 3 fp16 MFMA terms (2-term operand split), so the "
                           "bound is the dense fp16 MFMA peak 2500 TFLOP/s / 3; for scale, the fp32 MFMA peak is 157.3")
